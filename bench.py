@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""bench.py -- training images/s of CRNN + 1-D CTC (BASELINE.json configs[1]) on N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = zero_grad + forward + CTC loss + backward (+ RCCL gradient all-reduce for N>1) + fused Adam on a
+device-resident synthetic batch of 256 crops of 32x128 per GPU (weak scaling: global batch = 256*N).
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline      -- the dominant MFMA kernel: algorithmic FLOPs of its launches / their HIP-event durations
+  cpu_baseline  -- the oracle (reference restatement, oracle/crnn.py) timed on this box's host cores (rank 0, N=1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def conv_flops(name, args, true_cin0=3):
+    """algorithmic FLOPs (2*MACs, un-padded channels) of one mr_conv2d_* call from its C-ABI arguments."""
+    if name == "mr_conv2d_fwd":
+        N, H, W, Cin, _ldx, Cout, _ldy, R, S = args[6:15]
+        Ho, Wo = args[21], args[22]
+    else:  # dgrad / wgrad share the tail layout
+        N, H, W, Cin, _ld1, Cout, _ld2, R, S = args[4:13]
+        Ho, Wo = args[19], args[20]
+    if Cin == 8 and Cout == 64:
+        Cin = true_cin0  # first layer: 3 input channels padded to one 16-byte vector
+    return 2.0 * N * Ho * Wo * Cout * R * S * Cin, N * Ho * Wo, Cout, Cin
+
+
+def kernel_label(lib, name, args, dtype_name):
+    if name == "mr_conv2d_fwd":
+        N, H, W, Cin, _ldx, Cout = args[6:12]
+        code = lib.mr_nt_tile_code(N * args[21] * args[22], Cout)
+        return "igemm_nt_kernel<%s,%d,%d,conv>" % (dtype_name, code // 1000, code % 1000)
+    if name == "mr_conv2d_dgrad":
+        N, H, W, Cin = args[4:8]
+        code = lib.mr_nt_tile_code(N * H * W, Cin)
+        return "igemm_nt_kernel<%s,%d,%d,conv>" % (dtype_name, code // 1000, code % 1000)
+    return "igemm_tn_kernel<%s,conv>" % dtype_name
+
+
+def cpu_baseline(batch_size, budget_s=20.0):
+    """Oracle CRNN train step (torch CPU kernels, fp32 weights, fp64 CTC -- what the reference executes) on the
+    host cores; bounded sample of the same workload."""
+    from oracle.crnn import CRNNOracle, synthetic_batch, train_step
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = CRNNOracle().train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    batch = synthetic_batch(batch_size, 32, 128, seed=0)
+    train_step(model, opt, batch)  # warm-up
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 5 and (steps < 2 or time.perf_counter() - t0 < budget_s):
+        train_step(model, opt, batch)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": batch_size * steps / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d CPU train steps of batch %d (32x128), torch %s, %d threads, %.1f s" %
+                      (steps, batch_size, torch.__version__, torch.get_num_threads(), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU (there is no CPU product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")
+    if args.gpus != world:
+        print("warning: --gpus %d but WORLD_SIZE %d (using WORLD_SIZE)" % (args.gpus, world), file=sys.stderr)
+
+    import megreader_amd as mr
+    from megreader_amd import _lib
+    from megreader_amd.backbones import crnn_backbone
+    from megreader_amd.decoders import CRNNDecoder
+    from megreader_amd.optim import FusedAdam
+    from oracle.crnn import synthetic_batch  # input generator only (BASELINE.md §3 value distributions)
+
+    lib = _lib.load()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    mr.set_compute_dtype(dtype)
+
+    class BasicModel(torch.nn.Module):  # reference structure/model.py:16-24
+        def __init__(self):
+            super().__init__()
+            self.backbone = crnn_backbone()
+            self.decoder = CRNNDecoder(in_channels=512, inner_channels=256)
+
+        def forward(self, data, *a, **k):
+            return self.decoder(self.backbone(data), *a, **k)
+
+    torch.manual_seed(0)
+    model = BasicModel().to(dev).train()
+    opt = FusedAdam(model.parameters(), lr=1e-3)  # experiments/recognition/crnn.yaml:82-89
+    opt.zero_grad()
+    net = model
+    if distributed:
+        from megreader_amd.apex.parallel import DistributedDataParallel
+        net = DistributedDataParallel(model)
+    batch = synthetic_batch(args.batch, 32, 128, seed=rank)
+    img = batch['image'].to(dev)
+    lab = batch['label'].to(dev)
+    ln = batch['length'].to(dev).long()
+
+    def step():
+        opt.zero_grad()
+        loss, _ = net(img, targets=lab, lengths=ln, train=True)
+        loss = loss.mean()
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = None
+    if not args.no_kernel_timer:
+        timer = _lib.KernelTimer(["mr_conv2d_fwd", "mr_conv2d_dgrad", "mr_conv2d_wgrad"])
+        _lib.TIMER = timer
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.TIMER = None
+    final_loss = float(last)
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        images = args.batch * world * args.steps
+        # ---- roofline of the dominant MFMA kernel from the live HIP-event records
+        roofline = None
+        kernels = {}
+        if timer is not None:
+            agg = {}
+            for name, cargs, t_ms in timer.results():
+                label = kernel_label(lib, name, cargs, args.dtype)
+                fl, _, _, _ = conv_flops(name, cargs)
+                a = agg.setdefault(label, [0.0, 0.0, 0])
+                a[0] += fl
+                a[1] += t_ms
+                a[2] += 1
+            for label, (fl, t_ms, n) in agg.items():
+                kernels[label] = {"launches_per_step": n / args.steps, "avg_us": 1e3 * t_ms / n,
+                                  "tflops": fl / (t_ms * 1e-3) / 1e12, "ms_per_step": t_ms / args.steps}
+            if agg:
+                dom = max(agg, key=lambda k: agg[k][1])
+                fl, t_ms, n = agg[dom]
+                ach = fl / (t_ms * 1e-3) / 1e12
+                peak = MFMA_PEAK_TFLOPS[args.dtype]
+                roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                            "avg_launch_us": round(1e3 * t_ms / n, 2), "launches": n,
+                            "flops_per_launch": fl / n}
+        out = {
+            "metric": "training images/sec, CRNN-CTC 32x128 crops, batch 256 per GPU",
+            "value": round(images / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "CRNN + 1D-CTC training step (BASELINE.json configs[1]): 32x128 crops, "
+                                   "T=33, C=38, Adam", "global_batch": args.batch * world,
+                       "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
+                       "train_flops_per_image": 3 * 1.80e9},
+            "final_loss": final_loss,
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        step_tflops = 3 * 1.80e9 * args.batch / (ms * 1e-3) / 1e12
+        out["step_tflops_per_gpu"] = round(step_tflops, 2)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.batch)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

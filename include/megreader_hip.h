@@ -1,0 +1,120 @@
+/* megreader_hip.h -- C ABI of libmegreader_hip.so (MI355X / gfx950 kernels for MegReader's training hot path).
+ *
+ * Every entry point takes raw device pointers, plain sizes and a hipStream_t; no torch types cross this
+ * boundary.  The library keeps no state and owns no memory: the caller allocates every output and scratch
+ * buffer.  All functions return 0 on success and a non-zero MR_ERR_* code otherwise; mr_last_error() returns
+ * a human-readable message for the calling thread.  Kernels are enqueued on `stream` and never synchronise.
+ *
+ * dtype codes: 0 = float32, 1 = bfloat16 (storage type of activations / operand images; accumulation is
+ * always float32, CTC recursions float64).
+ *
+ * Layout conventions: activations NHWC (channel contiguous), convolution weights KRSC, matrices row-major.
+ * "16-byte vector" = 4 float32 or 8 bfloat16; channel counts and leading dimensions of MFMA operands must
+ * be multiples of one vector.
+ *
+ * Each group cites the reference interface (file:line in Megvii-CSG/MegReader) it replaces.
+ */
+#ifndef MEGREADER_HIP_H
+#define MEGREADER_HIP_H
+
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MR_ABI_VERSION 1
+#define MR_DTYPE_F32 0
+#define MR_DTYPE_BF16 1
+
+const char* mr_last_error(void);
+int mr_abi_version(void);
+
+/* ---- GEMM family (replaces cuBLAS/cuDNN behind nn.Linear / nn.LSTM input projection:
+ *      decoders/crnn.py:13-24; decoders/attention_decoder.py:187-231) ------------------------------------- */
+/* C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]);  A,B,C of `dtype`, bias f32 (nullable), relu 0/1 */
+int mr_gemm_nt(int dtype, const void* A, long long lda, const void* B, int ldb, void* C, long long ldc,
+               const float* bias, int relu, int M, int N, int K, hipStream_t stream);
+/* tile (BM*1000+BN) the NT kernels pick for an M x N problem; host-only query used for profiling labels */
+int mr_nt_tile_code(int M, int N);
+/* C[NA,NB] (f32) += A[P,NA]^T * B[P,NB];  row_perm_h>0: gate-interleaved rows are written back in
+ * PyTorch gate-major order (see lstm section) */
+int mr_gemm_tn(int dtype, const void* A, long long lda, const void* B, long long ldb, float* C, int ldc, int P,
+               int NA, int NB, int row_perm_h, hipStream_t stream);
+
+/* ---- Convolution (replaces cuDNN conv fwd/dgrad/wgrad behind nn.Conv2d: backbones/crnn.py:44-55,
+ *      backbones/resnet.py:39-256, backbones/ppm.py:11-44, decoders/ctc_decoder2d.py:16-27) --------------- */
+int mr_conv2d_fwd(int dtype, const void* x, const void* w_krsc, const float* bias, void* y, int relu, int Nimg,
+                  int H, int W, int Cin, int ldx, int Cout, int ldy, int R, int S, int sh, int sw, int ph, int pw,
+                  int dh, int dw, int Ho, int Wo, hipStream_t stream);
+/* w_crsk = weights transposed to [Cin][R][S][Cout] (mr_prep_conv_weight) */
+int mr_conv2d_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, int Nimg, int H, int W, int Cin,
+                    int lddx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
+                    int Ho, int Wo, hipStream_t stream);
+/* dw_krsc (f32 [Cout][R][S][Cin]) is accumulated atomically: zero it first */
+int mr_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw_krsc, int Nimg, int H, int W, int Cin,
+                    int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
+                    int Ho, int Wo, hipStream_t stream);
+
+/* ---- layout / elementwise helpers ---------------------------------------------------------------------- */
+int mr_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int Cpad,
+                    hipStream_t stream);
+int mr_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int H, int W, int ld, hipStream_t stream);
+int mr_cast(int src_dtype, const void* src, int dst_dtype, void* dst, long long n, hipStream_t stream);
+int mr_relu_bwd(int dtype, const void* dy, const void* y, void* dx, long long n, hipStream_t stream);
+int mr_add(int dtype, const void* a, const void* b, void* out, long long n, int relu, hipStream_t stream);
+/* out[perm(c)] (f32) += sum_p x[p,c] */
+int mr_colsum(int dtype, const void* x, float* out, int P, int C, long long ld, int perm_h, hipStream_t stream);
+/* [A,B,C] -> [B,A,C] */
+int mr_permute_021(int dtype, const void* src, void* dst, int A, int B, int C, hipStream_t stream);
+/* fp32 master weights (logical [K][C][R][S], arbitrary strides) -> operand images of `dtype` */
+int mr_prep_conv_weight(int dtype, const float* src, long long sk, long long sc, long long sr, long long ss,
+                        void* dst_krsc, void* dst_crsk, int K, int C, int R, int S, int Cpad, hipStream_t stream);
+int mr_prep_matrix(int dtype, const float* src, void* dst_n, int ldn, void* dst_t, int ldt, int R, int C,
+                   int perm_h, hipStream_t stream);
+int mr_prep_bias(const float* a, const float* b, float* dst, int R, int perm_h, hipStream_t stream);
+
+/* ---- optimizers (replaces torch.optim.Adam / SGD at training/optimizer_scheduler.py:17-22) -------------- */
+/* hyper: device f32[8] = {lr, beta1 (SGD: momentum), beta2, eps, weight_decay, step, -, -}; step is
+ * incremented on device so the call is hipGraph-replay safe */
+int mr_adam_step(float* p, const float* g, float* m, float* v, long long n, float* hyper, hipStream_t stream);
+int mr_sgd_step(float* p, const float* g, float* buf, long long n, float* hyper, hipStream_t stream);
+
+/* ---- BatchNorm2d / MaxPool2d (backbones/crnn.py:17-31,49-52; backbones/resnet.py:26-30,199) ------------- */
+int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float* save_mean, float* save_rstd, double* sums, const void* residual,
+                    int relu, long long P, int C, float eps, float momentum, hipStream_t stream);
+int mr_bn_fwd_eval(int dtype, const void* x, void* y, const float* gamma, const float* beta,
+                   const float* running_mean, const float* running_var, float* tmp_mean, float* tmp_rstd,
+                   const void* residual, int relu, long long P, int C, float eps, hipStream_t stream);
+int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+              const float* save_rstd, double* sums, void* dx, void* dres, float* dgamma, float* dbeta, int relu,
+              long long P, int C, hipStream_t stream);
+int mr_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int kh,
+                   int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, hipStream_t stream);
+int mr_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C,
+                   int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, hipStream_t stream);
+
+/* ---- bidirectional LSTM recurrence (replaces cuDNN RNN behind nn.LSTM: decoders/crnn.py:13,21,91-93) ----- */
+int mr_lstm_fwd(int dtype, const void* xproj, const void* whh, void* out, float* cbuf, void* gates, int T, int N,
+                int H, hipStream_t stream);
+int mr_lstm_bwd(int dtype, const void* dout, const void* whhT, const float* cbuf, void* gates, float* dc, int T,
+                int N, int H, hipStream_t stream);
+
+/* ---- 1-D CTC fused with log-softmax (replaces log_softmax + nn.CTCLoss: decoders/crnn.py:48,96-98) ------- */
+int mr_ctc_fwd(int dtype, const void* logits, int ldl, const void* targets, int targets_i64,
+               const void* input_lengths, const void* target_lengths, int lengths_i64, int T, int N, int C, int S,
+               int blank, int zero_infinity, float* log_probs, double* alpha, double* nll, double* loss,
+               hipStream_t stream);
+int mr_ctc_bwd(int dtype, const float* log_probs, const double* alpha, const double* nll, const void* targets,
+               int targets_i64, const void* input_lengths, const void* target_lengths, int lengths_i64,
+               const double* grad_out, int T, int N, int C, int S, int blank, int zero_infinity, void* grad_logits,
+               int ldg, hipStream_t stream);
+
+/* eval head: softmax over classes of logits [T,N,C] -> f32 [N,C,1,T] (decoders/crnn.py:101-104) */
+int mr_softmax_nc1t(int dtype, const void* logits, int ldl, float* out, int T, int N, int C, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEGREADER_HIP_H */

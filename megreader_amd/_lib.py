@@ -1,0 +1,147 @@
+"""ctypes binding of libmegreader_hip.so (the C ABI declared in include/megreader_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (``make -C megreader_amd/csrc``).  There is no
+CPU fallback: if the shared object is missing or a kernel reports an error, the caller gets an exception.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmegreader_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "megreader_hip.h")
+
+MR_F32 = 0
+MR_BF16 = 1
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
+_CODES = {"p": _P, "i": _I, "l": _L, "f": _F, "s": _P}
+
+# name -> argument codes (p pointer, i int, l long long, f float, s hipStream_t)
+SIGNATURES = {
+    "mr_gemm_nt": "iplpiplpiiiis",
+    "mr_gemm_tn": "iplplpiiiiis",
+    "mr_conv2d_fwd": "ipppp" + "i" * 18 + "s",
+    "mr_conv2d_dgrad": "ippp" + "i" * 17 + "s",
+    "mr_conv2d_wgrad": "ippp" + "i" * 17 + "s",
+    "mr_nchw_to_nhwc": "ippiiiiis",
+    "mr_nhwc_to_nchw": "ippiiiiis",
+    "mr_cast": "ipipls",
+    "mr_relu_bwd": "ipppls".replace(" ", ""),
+    "mr_add": "ippplis",
+    "mr_colsum": "ippiilis",
+    "mr_permute_021": "ippiiis",
+    "mr_prep_conv_weight": "ipllllppiiiiis",
+    "mr_prep_matrix": "ippipiiiis",
+    "mr_prep_bias": "pppiis",
+    "mr_adam_step": "pppplps",
+    "mr_sgd_step": "ppplps",
+    "mr_bn_fwd_train": "ipppppppppp" + "iliffs",
+    "mr_bn_fwd_eval": "ippppppppp" + "ilifs",
+    "mr_bn_bwd": "ipppppppppp" + "pilis",
+    "mr_maxpool_fwd": "ippp" + "i" * 12 + "s",
+    "mr_maxpool_bwd": "ippp" + "i" * 12 + "s",
+    "mr_lstm_fwd": "ipppppiiis",
+    "mr_lstm_bwd": "ipppppiiis",
+    "mr_ctc_fwd": "ipipippiiiiiiipppps",
+    "mr_ctc_bwd": "ippppippipiiiiiipis",
+    "mr_softmax_nc1t": "ipipiiis",
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Names of all `int mr_*(...)` entry points declared in include/megreader_hip.h."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\bint\s+(mr_\w+)\s*\(", text)))
+
+
+def load():
+    """Load the shared library (once) and attach argument types.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libmegreader_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C megreader_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.mr_last_error.restype = ctypes.c_char_p
+    lib.mr_last_error.argtypes = []
+    lib.mr_abi_version.restype = ctypes.c_int
+    lib.mr_abi_version.argtypes = []
+    lib.mr_nt_tile_code.restype = ctypes.c_int
+    lib.mr_nt_tile_code.argtypes = [ctypes.c_int, ctypes.c_int]
+    for name, codes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [_CODES[c] for c in codes]
+    _lib = lib
+    return lib
+
+
+HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code")  # entry points that take no stream and launch nothing
+
+
+def dtype_code(dtype):
+    if dtype == torch.float32:
+        return MR_F32
+    if dtype == torch.bfloat16:
+        return MR_BF16
+    raise TypeError("megreader_amd kernels support float32 and bfloat16, got %s" % dtype)
+
+
+def vec_of(dtype):
+    return 4 if dtype == torch.float32 else 8
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class KernelTimer(object):
+    """Optional HIP-event bracketing of selected C-ABI calls on the stream they are launched on (bench.py uses it
+    to measure the dominant kernel's launch durations live inside the timed region)."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []  # (name, args, start_event, end_event)
+
+    def results(self):
+        """[(name, args, milliseconds)] -- call after torch.cuda.synchronize()."""
+        return [(n, a, s.elapsed_time(e)) for n, a, s, e in self.records]
+
+
+TIMER = None  # set to a KernelTimer to enable
+
+
+def call(name, *args):
+    """Invoke a C entry point on torch's current HIP stream; raise RuntimeError on a non-zero return code."""
+    lib = load()
+    timer = TIMER
+    if timer is not None and name in timer.names:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args, stream_ptr())
+        e1.record()
+        timer.records.append((name, args, e0, e1))
+    else:
+        rc = getattr(lib, name)(*args, stream_ptr())
+    if rc != 0:
+        raise RuntimeError("%s failed (code %d): %s" % (name, rc, lib.mr_last_error().decode()))
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NotImplementedError(
+                "megreader_amd ops run only on an AMD GPU (HIP); got a %s tensor. There is no CPU fallback." % t.device)

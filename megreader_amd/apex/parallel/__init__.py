@@ -1,0 +1,147 @@
+"""MI355X replacement for ``apex.parallel`` as used by the reference (structure/model.py:27-36,
+backbones/resnet.py:26-30): one process per GPU, gradients averaged with RCCL all-reduce over xGMI.
+
+Design (not a port of apex): parameters are grouped into buckets in reverse registration order (~ the order
+backward produces gradients).  A post-accumulate-grad hook marks a parameter ready; when a bucket is complete
+its gradients are all-reduced on a side HIP stream while backward keeps running on the main stream.  When the
+optimizer keeps gradients in one flat buffer (megreader_amd.optim), a bucket is a contiguous slice of it and is
+reduced in place with no flatten/unflatten copies; otherwise the bucket is packed into a staging buffer.  An
+end-of-backward callback launches incomplete buckets (parameters that received no gradient, e.g. the unused
+``cbr_deepsup`` / ``fc`` weights listed in SURVEY.md §8a), waits for the side stream and scales by 1/world.
+
+xGMI is a point-to-point mesh: large buckets (default 32 MiB) keep RCCL in its bandwidth regime and let it use all
+seven links; the whole CRNN gradient (33 MB) is a single bucket.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def _engine_callback(fn):
+    torch.autograd.Variable._execution_engine.queue_callback(fn)
+
+
+class DistributedDataParallel(nn.Module):
+    def __init__(self, module, message_size=8 * 1024 * 1024, delay_allreduce=False, gradient_average=True,
+                 process_group=None, **_ignored):
+        super().__init__()
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("torch.distributed must be initialised before DistributedDataParallel(...)")
+        self.module = module
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group)
+        self.gradient_average = gradient_average
+        self.delay_allreduce = delay_allreduce
+        self.bucket_elems = int(message_size)
+        self._params = [p for p in module.parameters() if p.requires_grad]
+        self._use_side_stream = len(self._params) > 0 and self._params[0].is_cuda
+        self._stream = torch.cuda.Stream() if self._use_side_stream else None
+        # rank 0's weights and buffers define the model (apex behaviour)
+        with torch.no_grad():
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, 0, group=process_group)
+        # buckets over reversed registration order
+        self._buckets, cur, cur_n = [], [], 0
+        for p in reversed(self._params):
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n >= self.bucket_elems:
+                self._buckets.append(cur)
+                cur, cur_n = [], 0
+        if cur:
+            self._buckets.append(cur)
+        self._bucket_of = {}
+        for bi, bucket in enumerate(self._buckets):
+            for p in bucket:
+                self._bucket_of[p] = bi
+        self._ready = [0] * len(self._buckets)
+        self._launched = [False] * len(self._buckets)
+        self._pending = []  # (bucket index, flat tensor, staged?, work handle)
+        self._callback_queued = False
+        for p in self._params:
+            p.register_post_accumulate_grad_hook(self._make_hook())
+
+    # ------------------------------------------------------------------ hooks
+    def _make_hook(self):
+        def hook(param):
+            if not self._callback_queued:
+                _engine_callback(self._finalize)
+                self._callback_queued = True
+            if self.delay_allreduce:
+                return
+            bi = self._bucket_of[param]
+            self._ready[bi] += 1
+            if self._ready[bi] == len(self._buckets[bi]) and not self._launched[bi]:
+                self._launch(bi)
+        return hook
+
+    def _flat_view(self, bucket):
+        """Contiguous in-place view over the bucket's gradients if they sit back to back in memory, else None."""
+        grads = [p.grad for p in bucket]
+        order = sorted(grads, key=lambda g: g.data_ptr())
+        base = order[0]
+        lo = base.data_ptr()
+        hi = max(g.data_ptr() + g.numel() * g.element_size() for g in order)
+        try:
+            storage_lo = base.untyped_storage().data_ptr()
+            if any(g.untyped_storage().data_ptr() != storage_lo for g in order):
+                return None
+        except Exception:
+            return None
+        span = (hi - lo) // base.element_size()
+        if span > 2 * sum(g.numel() for g in order):
+            return None  # too sparse: padding would dominate
+        # gaps are alignment padding inside the flat optimizer buffer (always zero) -- safe to reduce along
+        off = (lo - storage_lo) // base.element_size()
+        return torch.empty(0, dtype=base.dtype, device=base.device).set_(base.untyped_storage(), off, (span,), (1,))
+
+    def _launch(self, bi):
+        bucket = [p for p in self._buckets[bi] if p.grad is not None]
+        self._launched[bi] = True
+        if not bucket:
+            return
+        flat = self._flat_view(bucket)
+        staged = flat is None
+        if staged:
+            flat = torch.cat([p.grad.reshape(-1) for p in bucket])  # logical (row-major) element order
+        if self._use_side_stream:
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                flat.record_stream(self._stream)
+        else:
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((bucket, flat, staged, work))
+
+    def _finalize(self):
+        for bi in range(len(self._buckets)):
+            if not self._launched[bi]:
+                self._launch(bi)
+        scale = 1.0 / self.world_size if self.gradient_average else 1.0
+        for bucket, flat, staged, work in self._pending:
+            work.wait()  # RCCL: the current (main) stream waits for the collective; host does not block
+            self._finish_bucket(bucket, flat, staged, scale)
+        self._pending = []
+        self._ready = [0] * len(self._buckets)
+        self._launched = [False] * len(self._buckets)
+        self._callback_queued = False
+
+    @staticmethod
+    def _finish_bucket(bucket, flat, staged, scale):
+        if scale != 1.0:
+            flat.mul_(scale)
+        if staged:
+            off = 0
+            for p in bucket:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view(p.grad.shape))
+                off += n
+
+    def forward(self, *inputs, **kwargs):
+        return self.module(*inputs, **kwargs)
+
+
+class SyncBatchNorm(nn.SyncBatchNorm):
+    """Only reachable when the reference's config.sync_bn is switched on (backbones/resnet.py:26-30; default
+    False, config.py:14).  Falls back to torch's SyncBatchNorm over the same RCCL process group."""
+    pass

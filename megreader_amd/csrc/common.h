@@ -1,0 +1,96 @@
+// Shared device/host helpers for the gfx950 (MI355X / CDNA4) kernels.
+// Wave = 64 lanes everywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+namespace mr {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+enum { MR_F32 = 0, MR_BF16 = 1 };
+
+enum {
+  MR_OK = 0,
+  MR_ERR_ARG = 1,      // bad argument (shape / alignment / range)
+  MR_ERR_DTYPE = 2,    // unsupported dtype code
+  MR_ERR_LAUNCH = 3,   // hip launch error
+  MR_ERR_UNSUPPORTED = 4,
+};
+
+// last error message, returned by mr_last_error()
+void set_error(const char* fmt, ...);
+
+#define MR_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      mr::set_error(__VA_ARGS__);          \
+      return mr::MR_ERR_ARG;               \
+    }                                      \
+  } while (0)
+
+#define MR_CHECK_LAUNCH()                                              \
+  do {                                                                 \
+    hipError_t e__ = hipGetLastError();                                \
+    if (e__ != hipSuccess) {                                           \
+      mr::set_error("%s:%d hip launch failed: %s", __FILE__, __LINE__, \
+                    hipGetErrorString(e__));                           \
+      return mr::MR_ERR_LAUNCH;                                        \
+    }                                                                  \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }
+
+template <typename T> struct VecOf;             // 16-byte vector of T
+template <> struct VecOf<float> { static constexpr int N = 4; };
+template <> struct VecOf<bf16_t> { static constexpr int N = 8; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// store 4 consecutive values (address must be 4-element aligned)
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+  bf16x4 o;
+  o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+  *(bf16x4*)p = o;
+}
+__device__ __forceinline__ f32x4 load4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+  bf16x4 o = *(const bf16x4*)p;
+  f32x4 v;
+  v[0] = (float)o[0]; v[1] = (float)o[1]; v[2] = (float)o[2]; v[3] = (float)o[3];
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace mr

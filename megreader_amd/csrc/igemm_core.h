@@ -1,0 +1,444 @@
+// MFMA implicit-GEMM cores for gfx950.
+//
+//  igemm_nt_kernel : C[M,N]  = Agather[M,K] * B[N,K]^T   (conv fwd, conv dgrad, linear, LSTM x-proj / steps)
+//  igemm_tn_kernel : C[NA,NB] += sum_p A[p,NA] * Bgather[p,NB]   (conv wgrad, linear/LSTM weight grads)
+//
+// Layout contract: activations are NHWC (channel-contiguous), weights are [N][K] with K contiguous
+// (KRSC for convolutions).  One 16-byte vector (8 bf16 / 4 f32) is the unit of every global and LDS
+// access.  Workgroup = 256 threads = 4 waves (2x2), wave = 64 lanes.
+//
+// NT LDS image: [8 k-chunks][ROWS][16 B], slot(row, kc) = kc*ROWS + (row ^ kc).  The XOR keeps
+//   * ds_write_b128 conflict-free (an 8-lane group writes one row x 8 chunks -> 8 distinct 16-B bank groups)
+//   * ds_read_b128 conflict-free (each 16-lane service group of the MFMA fragment read touches
+//     16 rows that stay distinct mod 16).
+// The MFMA is issued with swapped operands (weights as the A operand) so each lane ends up with
+// 4 consecutive output channels of one pixel -> 8-byte (bf16) / 16-byte (f32) row-major stores.
+//
+// TN LDS image: [BP rows(p)][128 cols], 32-byte column pieces XOR-swizzled by a hash of the row so
+// that ds_read_b64_tr_b16 (the gfx950 LDS transpose read that turns "8 consecutive p at one column"
+// into an MFMA K-fragment) is conflict-free across a 32-lane half.
+#pragma once
+#include "common.h"
+
+namespace mr {
+
+struct ConvGeom {
+  int Hg, Wg, Cg, ldg;  // gathered tensor: spatial dims, channels per tap, pixel stride (elements)
+  int Hm, Wm;           // spatial dims of the row (M / P) index space
+  int R, S, sh, sw, ph, pw, dh, dw;
+  int mode;             // 1: forward gather   hi = hm*sh - ph + r*dh
+                        // 2: dgrad gather     hi = (hm + ph - r*dh) / sh   (must divide exactly)
+};
+
+__device__ __forceinline__ bool conv_src(const ConvGeom& g, int hm, int wm, int r, int s, int& hi, int& wi) {
+  if (g.mode == 1) {
+    hi = hm * g.sh - g.ph + r * g.dh;
+    wi = wm * g.sw - g.pw + s * g.dw;
+  } else {
+    int hn = hm + g.ph - r * g.dh;
+    int wn = wm + g.pw - s * g.dw;
+    if (hn < 0 || wn < 0) return false;
+    hi = hn / g.sh;
+    wi = wn / g.sw;
+    if (hi * g.sh != hn || wi * g.sw != wn) return false;
+  }
+  return (unsigned)hi < (unsigned)g.Hg && (unsigned)wi < (unsigned)g.Wg;
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  typedef bf16x8 Frag;
+  static __device__ __forceinline__ void run(f32x4& acc, const Frag& a, const Frag& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // exact-f32 MFMA (v_mfma_f32_16x16x4_f32).  A 16-byte fragment holds k = 4*(lane>>4)+j, j=0..3;
+  // A and B use the same k permutation so the sum is unchanged.
+  typedef f32x4 Frag;
+  static __device__ __forceinline__ void run(f32x4& acc, const Frag& a, const Frag& b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+  }
+};
+
+struct NtArgs {
+  const void* A;
+  const void* B;
+  int M, N, K;
+  long long lda;  // dense A row stride (elements); ignored in conv mode
+  int ldb;        // B row stride (elements)
+};
+
+__device__ __forceinline__ uint4 ldg16(const void* p) { return *(const uint4*)p; }
+
+// ---------------------------------------------------------------------------------------------
+// NT kernel.  AMODE 0: dense A[M,K] (row stride lda).  AMODE 1: A is an NHWC tensor gathered
+// im2col-style according to ConvGeom (K = R*S*Cg, k = (r*S+s)*Cg + c).
+// Epi: functor  void operator()(int m, int n, const f32x4& v)  -- v = C[m][n..n+3] in f32.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int AMODE, typename Epi>
+__device__ __forceinline__ void igemm_nt_body(const NtArgs& a, const ConvGeom& g, const Epi& epi) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int BK = 8 * VEC;
+  constexpr int AI = BM / 32, BI = BN / 32;
+  constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
+  typedef typename Mma<T>::Frag Frag;
+
+  __shared__ uint4 smem[8 * (BM + BN)];
+  uint4* sA = smem;
+  uint4* sB = smem + 8 * BM;
+
+  const int tid = threadIdx.x;
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kc = tid & 7, r0 = tid >> 3;
+
+  const T* __restrict__ A = (const T*)a.A;
+  const T* __restrict__ B = (const T*)a.B;
+
+  long long a_off[AI];
+  int a_h[AI], a_w[AI];
+  bool a_ok[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    a_ok[i] = m < a.M;
+    if (AMODE == 0) {
+      a_off[i] = (long long)m * a.lda;
+      a_h[i] = a_w[i] = 0;
+    } else {
+      const int wm = m % g.Wm;
+      const int t = m / g.Wm;
+      const int hm = t % g.Hm;
+      const int ni = t / g.Hm;
+      a_off[i] = (long long)ni * g.Hg * g.Wg * g.ldg;
+      a_h[i] = hm;
+      a_w[i] = wm;
+    }
+  }
+  long long b_off[BI];
+  bool b_ok[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int n = n0 + r0 + 32 * i;
+    b_ok[i] = n < a.N;
+    b_off[i] = (long long)n * a.ldb;
+  }
+
+  uint4 ra[AI], rb[BI];
+  auto load_tiles = [&](int k0) {
+    const int k = k0 + kc * VEC;
+    const bool kok = k < a.K;
+    int r = 0, s = 0, c = k;
+    if (AMODE == 1) {
+      const int tap = k / g.Cg;
+      c = k - tap * g.Cg;
+      r = tap / g.S;
+      s = tap - r * g.S;
+    }
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (a_ok[i] && kok) {
+        if (AMODE == 0) {
+          v = ldg16(A + a_off[i] + k);
+        } else {
+          int hi, wi;
+          if (conv_src(g, a_h[i], a_w[i], r, s, hi, wi))
+            v = ldg16(A + a_off[i] + ((long long)hi * g.Wg + wi) * g.ldg + c);
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (b_ok[i] && kok) v = ldg16(B + b_off[i] + k);
+      rb[i] = v;
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm_ = wave & 1, wn_ = wave >> 1;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_tiles(0);
+  for (int k0 = 0; k0 < a.K; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) sA[kc * BM + ((r0 + 32 * i) ^ kc)] = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) sB[kc * BN + ((r0 + 32 * i) ^ kc)] = rb[i];
+    __syncthreads();
+    if (k0 + BK < a.K) load_tiles(k0 + BK);  // global loads stay in flight under the MFMAs
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kcr = ks * 4 + lg;
+      Frag fa[TM], fb[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) fa[j] = *(const Frag*)&sA[kcr * BM + ((wm_ * WTM + j * 16 + l15) ^ kcr)];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fb[i] = *(const Frag*)&sB[kcr * BN + ((wn_ * WTN + i * 16 + l15) ^ kcr)];
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) Mma<T>::run(acc[i][j], fb[i], fa[j]);  // D[n][m]
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wm_ * WTM + j * 16 + l15;
+      const int n = n0 + wn_ * WTN + i * 16 + lg * 4;
+      epi(m, n, acc[i][j]);
+    }
+}
+
+template <typename T, int BM, int BN, int AMODE, typename Epi>
+__global__ __launch_bounds__(256) void igemm_nt_kernel(NtArgs a, ConvGeom g, Epi epi) {
+  igemm_nt_body<T, BM, BN, AMODE, Epi>(a, g, epi);
+}
+
+// Plain epilogue: C = act(acc + bias) stored as T, row-major with leading dim ldc.
+template <typename T> struct EpiStore {
+  T* C;
+  long long ldc;
+  const float* bias;  // [N] or null
+  int relu;
+  int M, N;
+  int vec_ok;  // ldc % 4 == 0 and C 16-byte aligned
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    if (m >= M || n >= N) return;
+    if (bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n + j < N) v[j] += bias[n + j];
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    T* p = C + (long long)m * ldc + n;
+    if (vec_ok && n + 3 < N) {
+      store4(p, v);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n + j < N) p[j] = from_f32<T>(v[j]);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// TN kernel: C[NA,NB] (f32, atomically accumulated) += sum_{p in split} A[p,NA] * Bg[p,NB]
+// BMODE 0: B dense [P, ldb].  BMODE 1: B = im2col(X) per ConvGeom (mode 1), NB = R*S*Cg.
+// Tile 128 x 128, 4 waves of 64 x 64.  grid = (tiles_a*tiles_b, 1, splits).
+// row_perm_h > 0: output row r is written to row  (r/ (4*h))*(4*h) + (r%4)*h + (r%(4*h))/4
+//   (gate-interleaved LSTM rows back to PyTorch's i,f,g,o-major order).
+// ---------------------------------------------------------------------------------------------
+struct TnArgs {
+  const void* A;
+  const void* B;
+  float* C;
+  int P, NA, NB;
+  long long lda, ldb;
+  int ldc;
+  int p_chunk;  // rows of P per split (multiple of the p-step)
+  int row_perm_h;
+};
+
+template <typename T> struct TnCfg;
+template <> struct TnCfg<bf16_t> {
+  static constexpr int BP = 32;
+  static constexpr int ROW_VECS = 16;   // 16-byte vectors per 128-col row
+  static constexpr int ROW_BYTES = 256;
+};
+template <> struct TnCfg<float> {
+  static constexpr int BP = 16;
+  static constexpr int ROW_VECS = 32;
+  static constexpr int ROW_BYTES = 576;  // 512 + 64 pad: consecutive rows shift by 16 banks
+};
+
+__device__ __forceinline__ int tn_hash(int p) { return (p & 3) | (((p >> 3) & 1) << 2); }
+
+template <typename T, int BMODE>
+__global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int BP = TnCfg<T>::BP;
+  constexpr int ROW_VECS = TnCfg<T>::ROW_VECS;
+  constexpr int ROW_BYTES = TnCfg<T>::ROW_BYTES;
+  constexpr int ROWS_PER_PASS = 256 / ROW_VECS;  // 16 (bf16) / 8 (f32)
+  constexpr int NI = BP / ROWS_PER_PASS;         // 2
+  constexpr bool IS_BF16 = (sizeof(T) == 2);
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BP * ROW_BYTES];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + BP * ROW_BYTES;
+
+  const int tid = threadIdx.x;
+  const int tiles_b = (a.NB + 127) / 128;
+  const int tile_b = blockIdx.x % tiles_b, tile_a = blockIdx.x / tiles_b;
+  const int na0 = tile_a * 128, nb0 = tile_b * 128;
+  const int p_begin = blockIdx.z * a.p_chunk;
+  const int p_end = min(a.P, p_begin + a.p_chunk);
+  if (p_begin >= p_end) return;
+
+  const T* __restrict__ A = (const T*)a.A;
+  const T* __restrict__ B = (const T*)a.B;
+
+  const int cc = tid % ROW_VECS;  // 16-byte column chunk
+  const int rr = tid / ROW_VECS;
+  const int ca = na0 + cc * VEC;  // A column of this thread's vector
+  const int cb = nb0 + cc * VEC;  // B column
+  const bool ca_ok = ca < a.NA, cb_ok = cb < a.NB;
+
+  int tr = 0, ts = 0, tc = cb;  // conv: tap (r,s) and channel of this thread's B column
+  if (BMODE == 1) {
+    const int tap = cb / g.Cg;
+    tc = cb - tap * g.Cg;
+    tr = tap / g.S;
+    ts = tap - tr * g.S;
+  }
+
+  // LDS byte offset of this thread's vector inside row p
+  auto lds_off = [&](int p) -> int {
+    if (IS_BF16) {
+      const int cp = cc >> 1;
+      return p * ROW_BYTES + ((cp ^ tn_hash(p)) << 5) + (cc & 1) * 16;
+    } else {
+      return p * ROW_BYTES + cc * 16;
+    }
+  };
+
+  uint4 ra[NI], rb[NI];
+  auto load_tiles = [&](int p0) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = p0 + rr + ROWS_PER_PASS * i;
+      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+      if (p < p_end) {
+        if (ca_ok) va = ldg16(A + (long long)p * a.lda + ca);
+        if (cb_ok) {
+          if (BMODE == 0) {
+            vb = ldg16(B + (long long)p * a.ldb + cb);
+          } else {
+            const int wm = p % g.Wm;
+            const int t = p / g.Wm;
+            const int hm = t % g.Hm;
+            const int ni = t / g.Hm;
+            int hi, wi;
+            if (conv_src(g, hm, wm, tr, ts, hi, wi))
+              vb = ldg16(B + ((long long)(ni * g.Hg + hi) * g.Wg + wi) * g.ldg + tc);
+          }
+        }
+      }
+      ra[i] = va;
+      rb[i] = vb;
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wa = wave & 1, wb = wave >> 1;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  f32x4 acc[4][4];  // [a tile][b tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_tiles(p_begin);
+  for (int p0 = p_begin; p0 < p_end; p0 += BP) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int pl = rr + ROWS_PER_PASS * i;
+      *(uint4*)(sA + lds_off(pl)) = ra[i];
+      *(uint4*)(sB + lds_off(pl)) = rb[i];
+    }
+    __syncthreads();
+    if (p0 + BP < p_end) load_tiles(p0 + BP);
+
+    if constexpr (IS_BF16) {
+      // K fragment (8 consecutive p at one column) via two ds_read_b64_tr_b16 per operand tile.
+      // Per 16-lane group: lane i supplies the address of row (i>>2), 8-byte piece (i&3) of a
+      // [4 rows][16 cols] block; the instruction hands lane i column i of that block.
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int cpa = (wa * 64 + t * 16) >> 4;
+        const int cpb = (wb * 64 + t * 16) >> 4;
+        s16x4 x[2], y[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int p = lg * 8 + hh * 4 + (l15 >> 2);
+          const int h = tn_hash(p);
+          const int oa = p * ROW_BYTES + ((cpa ^ h) << 5) + (l15 & 3) * 8;
+          const int ob = p * ROW_BYTES + ((cpb ^ h) << 5) + (l15 & 3) * 8;
+          x[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(sA + oa));
+          y[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(sB + ob));
+        }
+        union { s16x4 h[2]; bf16x8 v; } ua, ub;
+        ua.h[0] = x[0]; ua.h[1] = x[1];
+        ub.h[0] = y[0]; ub.h[1] = y[1];
+        fa[t] = ua.v;
+        fb[t] = ub.v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BP / 4; ++ks) {
+        const int p = ks * 4 + lg;
+        float fa[4], fb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          fa[t] = *(const float*)(sA + p * ROW_BYTES + (wa * 64 + t * 16 + l15) * 4);
+          fb[t] = *(const float*)(sB + p * ROW_BYTES + (wb * 64 + t * 16 + l15) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // D[i = a-row][j = b-col]: lane holds rows lg*4+reg, col l15.
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = nb0 + wb * 64 + j * 16 + l15;
+      if (col >= a.NB) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int row = na0 + wa * 64 + i * 16 + lg * 4 + q;
+        if (row >= a.NA) continue;
+        if (a.row_perm_h > 0) {
+          const int h4 = 4 * a.row_perm_h;
+          const int blk = row / h4, rin = row - blk * h4;
+          row = blk * h4 + (rin & 3) * a.row_perm_h + (rin >> 2);
+        }
+        atomicAdd(a.C + (long long)row * a.ldc + col, acc[i][j][q]);
+      }
+    }
+}
+
+}  // namespace mr

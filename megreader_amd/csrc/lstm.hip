@@ -1,0 +1,185 @@
+// Bidirectional single-layer LSTM (PyTorch / cuDNN semantics, gate order i,f,g,o) as MFMA GEMMs with the
+// gate non-linearities and cell update fused into the GEMM epilogue.  Replaces nn.LSTM(bidirectional=True)
+// at reference decoders/crnn.py:13,21 (cuDNN RNN in the reference).
+//
+// Internal layout ("gate-interleaved"): every 4H-wide gate axis is permuted so that column 4*j+q holds
+// gate q (i,f,g,o) of hidden unit j.  With the swapped-operand MFMA each lane then owns all four gates
+// of one (batch row, hidden unit) pair, so the recurrence epilogue needs no cross-lane traffic.
+//
+// Buffers (T = compute dtype, row-major):
+//   xproj  [Tn*N, 8H]   x_t W_ih^T + b_ih + b_hh for both directions (dir-major: [dir][4H]), gate-interleaved
+//   out    [Tn, N, 2H]  h_t ([:, :, 0:H] forward, [:, :, H:2H] reverse)
+//   cbuf   [Tn, N, 2H]  c_t (f32)
+//   gates  [Tn, N, 8H]  post-activation gates (fwd) ; reused in place for pre-activation gradients (bwd)
+//   whh    [2][4H, H]   recurrent weights, gate-interleaved rows     (step forward:  B operand)
+//   whhT   [2][H, 4H]   their transposes                             (step backward: B operand)
+#include "igemm_core.h"
+#include "../../include/megreader_hip.h"
+
+namespace mr {
+
+template <typename T> struct EpiLstmFwd {
+  const T* xproj;   // row t, dir offset applied: [N][8H] rows, + dir*4H
+  const float* c_prev;  // [N][2H] + dir*H, or null for the first step
+  float* c_out;     // [N][2H] + dir*H
+  T* h_out;         // [N][2H] + dir*H
+  T* gates_out;     // [N][8H] + dir*4H
+  int Nb, H;
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    if (m >= Nb || n >= 4 * H) return;
+    const int j = n >> 2;
+    const f32x4 x = load4(xproj + (long long)m * 8 * H + n);
+    const float ig = sigmoidf_(v[0] + x[0]);
+    const float fg = sigmoidf_(v[1] + x[1]);
+    const float gg = tanhf_(v[2] + x[2]);
+    const float og = sigmoidf_(v[3] + x[3]);
+    const float cp = c_prev ? c_prev[(long long)m * 2 * H + j] : 0.f;
+    const float c = fg * cp + ig * gg;
+    const float h = og * tanhf_(c);
+    c_out[(long long)m * 2 * H + j] = c;
+    h_out[(long long)m * 2 * H + j] = from_f32<T>(h);
+    f32x4 g4 = {ig, fg, gg, og};
+    store4(gates_out + (long long)m * 8 * H + n, g4);
+  }
+};
+
+template <typename T> struct EpiLstmBwd {
+  const T* dout;        // [N][2H] + dir*H   upstream gradient of h_t
+  const T* gates;       // [N][8H] + dir*4H  post-activation gates of step t (read)
+  T* dgates;            // [N][8H] + dir*4H  pre-activation gradients of step t (written; may alias gates)
+  const float* c_t;     // [N][2H] + dir*H
+  const float* c_prev;  // [N][2H] + dir*H or null (first forward step)
+  float* dc;            // [N][2H] + dir*H   carried cell gradient (read unless first bwd step, then written)
+  int first;            // first backward step: no carried dc
+  int Nb, H;
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    if (m >= Nb || n >= H) return;
+    const long long r2 = (long long)m * 2 * H, r8 = (long long)m * 8 * H;
+    const f32x4 up = load4(dout + r2 + n);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = n + jj;
+      const f32x4 g4 = load4(gates + r8 + 4 * j);
+      const float ig = g4[0], fg = g4[1], gg = g4[2], og = g4[3];
+      const float dh = v[jj] + up[jj];
+      const float tc = tanhf_(c_t[r2 + j]);
+      float dcv = dh * og * (1.f - tc * tc);
+      if (!first) dcv += dc[r2 + j];
+      const float cp = c_prev ? c_prev[r2 + j] : 0.f;
+      f32x4 d;
+      d[0] = dcv * gg * ig * (1.f - ig);
+      d[1] = dcv * cp * fg * (1.f - fg);
+      d[2] = dcv * ig * (1.f - gg * gg);
+      d[3] = dh * tc * og * (1.f - og);
+      dc[r2 + j] = dcv * fg;
+      store4(dgates + r8 + 4 * j, d);
+    }
+  }
+};
+
+template <typename T, typename Epi>
+__global__ __launch_bounds__(256) void lstm_step_kernel(NtArgs a0, NtArgs a1, Epi e0, Epi e1) {
+  ConvGeom g = {};
+  const NtArgs a = blockIdx.y == 0 ? a0 : a1;
+  const Epi e = blockIdx.y == 0 ? e0 : e1;
+  igemm_nt_body<T, 64, 64, 0, Epi>(a, g, e);
+}
+
+template <typename T>
+static int lstm_fwd_impl(const void* xproj_, const void* whh_, void* out_, float* cbuf, void* gates_, int Tn, int N,
+                         int H, hipStream_t stream) {
+  const T* xproj = (const T*)xproj_;
+  const T* whh = (const T*)whh_;
+  T* out = (T*)out_;
+  T* gates = (T*)gates_;
+  const long long s2 = (long long)N * 2 * H, s8 = (long long)N * 8 * H;
+  const int tiles = cdiv(N, 64) * cdiv(4 * H, 64);
+  for (int s = 0; s < Tn; ++s) {
+    NtArgs a[2];
+    EpiLstmFwd<T> e[2];
+    for (int d = 0; d < 2; ++d) {
+      const int t = d == 0 ? s : Tn - 1 - s;
+      const int tp = d == 0 ? t - 1 : t + 1;
+      a[d].A = s == 0 ? (const void*)out : (const void*)(out + tp * s2 + d * H);
+      a[d].B = whh + (long long)d * 4 * H * H;
+      a[d].M = N; a[d].N = 4 * H; a[d].K = s == 0 ? 0 : H; a[d].lda = 2 * H; a[d].ldb = H;
+      e[d].xproj = xproj + t * s8 + d * 4 * H;
+      e[d].c_prev = s == 0 ? nullptr : cbuf + tp * s2 + d * H;
+      e[d].c_out = cbuf + t * s2 + d * H;
+      e[d].h_out = out + t * s2 + d * H;
+      e[d].gates_out = gates + t * s8 + d * 4 * H;
+      e[d].Nb = N; e[d].H = H;
+    }
+    hipLaunchKernelGGL((lstm_step_kernel<T, EpiLstmFwd<T>>), dim3(tiles, 2), dim3(256), 0, stream, a[0], a[1], e[0],
+                       e[1]);
+  }
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+template <typename T>
+static int lstm_bwd_impl(const void* dout_, const void* whhT_, const float* cbuf, void* gates_, float* dc, int Tn,
+                         int N, int H, hipStream_t stream) {
+  const T* dout = (const T*)dout_;
+  const T* whhT = (const T*)whhT_;
+  T* gates = (T*)gates_;
+  const long long s2 = (long long)N * 2 * H, s8 = (long long)N * 8 * H;
+  const int tiles = cdiv(N, 64) * cdiv(H, 64);
+  for (int s = 0; s < Tn; ++s) {
+    NtArgs a[2];
+    EpiLstmBwd<T> e[2];
+    for (int d = 0; d < 2; ++d) {
+      // backward visits the steps in the reverse of the forward order of that direction
+      const int t = d == 0 ? Tn - 1 - s : s;
+      const int tn = d == 0 ? t + 1 : t - 1;  // step whose dgates feed the recurrent term
+      const int tp = d == 0 ? t - 1 : t + 1;  // previous step in forward order (c_{prev})
+      const bool has_prev = d == 0 ? t > 0 : t < Tn - 1;
+      a[d].A = s == 0 ? (const void*)gates : (const void*)(gates + tn * s8 + d * 4 * H);
+      a[d].B = whhT + (long long)d * 4 * H * H;
+      a[d].M = N; a[d].N = H; a[d].K = s == 0 ? 0 : 4 * H; a[d].lda = 8 * H; a[d].ldb = 4 * H;
+      e[d].dout = dout + t * s2 + d * H;
+      e[d].gates = gates + t * s8 + d * 4 * H;
+      e[d].dgates = gates + t * s8 + d * 4 * H;
+      e[d].c_t = cbuf + t * s2 + d * H;
+      e[d].c_prev = has_prev ? cbuf + tp * s2 + d * H : nullptr;
+      e[d].dc = dc + d * H;
+      e[d].first = s == 0;
+      e[d].Nb = N; e[d].H = H;
+    }
+    hipLaunchKernelGGL((lstm_step_kernel<T, EpiLstmBwd<T>>), dim3(tiles, 2), dim3(256), 0, stream, a[0], a[1], e[0],
+                       e[1]);
+  }
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+}  // namespace mr
+
+using namespace mr;
+
+extern "C" {
+
+// Recurrent part of the forward pass (input projection done by mr_gemm_nt beforehand).
+int mr_lstm_fwd(int dtype, const void* xproj, const void* whh, void* out, float* cbuf, void* gates, int T, int N,
+                int H, hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(T > 0 && N > 0 && H > 0 && H % vec == 0, "mr_lstm_fwd: bad shape T=%d N=%d H=%d", T, N, H);
+  if (dtype == MR_F32) return lstm_fwd_impl<float>(xproj, whh, out, cbuf, gates, T, N, H, stream);
+  if (dtype == MR_BF16) return lstm_fwd_impl<bf16_t>(xproj, whh, out, cbuf, gates, T, N, H, stream);
+  mr::set_error("mr_lstm_fwd: bad dtype %d", dtype);
+  return MR_ERR_DTYPE;
+}
+
+// Backward through time.  On return `gates` holds the pre-activation gradients (gate-interleaved) that feed
+// the weight / input gradient GEMMs.  dc: scratch f32 [N, 2H].
+int mr_lstm_bwd(int dtype, const void* dout, const void* whhT, const float* cbuf, void* gates, float* dc, int T,
+                int N, int H, hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(T > 0 && N > 0 && H > 0 && H % vec == 0 && H % 4 == 0, "mr_lstm_bwd: bad shape T=%d N=%d H=%d", T, N, H);
+  if (dtype == MR_F32) return lstm_bwd_impl<float>(dout, whhT, cbuf, gates, dc, T, N, H, stream);
+  if (dtype == MR_BF16) return lstm_bwd_impl<bf16_t>(dout, whhT, cbuf, gates, dc, T, N, H, stream);
+  mr::set_error("mr_lstm_bwd: bad dtype %d", dtype);
+  return MR_ERR_DTYPE;
+}
+
+}  // extern "C"

@@ -1,0 +1,374 @@
+// BatchNorm2d (training statistics) and MaxPool2d on NHWC tensors.  HBM-bound kernels.
+// Reference call sites: backbones/crnn.py:17-31,49-52 (MaxPool2d((2,2)), MaxPool2d((2,2),(2,1),(0,1)),
+// BatchNorm2d without activation), backbones/resnet.py:26-30 (BatchNorm2d), resnet.py:199 (MaxPool2d 3x3 s2 p1).
+#include "common.h"
+#include "../../include/megreader_hip.h"
+
+namespace mr {
+
+// ------------------------------------------------------------------ BN statistics
+// sums[0..C) += sum_p x[p,c]; sums[C..2C) += sum_p x[p,c]^2  (double atomics; f32 per-thread partials)
+// grid = (ceil(C/64), row_splits), block 256 (4 waves stride rows, lane = channel)
+template <typename T>
+__global__ void bn_stats_kernel(const T* __restrict__ x, double* __restrict__ sums, int P, int C, long long ld,
+                                int rows_per_block) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int p0 = blockIdx.y * rows_per_block;
+  const int p1 = min(P, p0 + rows_per_block);
+  float s = 0.f, q = 0.f;
+  if (c < C)
+    for (int p = p0 + wave; p < p1; p += 4) {
+      const float v = to_f32(x[(long long)p * ld + c]);
+      s += v;
+      q += v * v;
+    }
+  red[0][wave][lane] = s;
+  red[1][wave][lane] = q;
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    const double ds = (double)red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+    const double dq = (double)red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+    atomicAdd(sums + c, ds);
+    atomicAdd(sums + C + c, dq);
+  }
+}
+
+// mean / rstd from sums, running-stat update (PyTorch: running = (1-mom)*running + mom*stat, unbiased var)
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int P, int C, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ rstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = sums[c] / P;
+  double var = sums[C + c] / P - m * m;
+  if (var < 0) var = 0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unb = P > 1 ? var * ((double)P / (P - 1)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+// y = (x-mean)*rstd*gamma + beta (+residual) (relu)   ; vectorised, C % VEC == 0
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ mean,
+                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const T* __restrict__ residual, int relu,
+                                long long P, int C) {
+  constexpr int VEC = VecOf<T>::N;
+  const int cv = C / VEC;
+  const long long total = P * cv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cv) * VEC;
+    uint4 a = ((const uint4*)x)[i];
+    T* pa = (T*)&a;
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (residual) r = ((const uint4*)residual)[i];
+    const T* pr = (const T*)&r;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = c0 + j;
+      float v = (to_f32(pa[j]) - mean[c]) * rstd[c] * gamma[c] + beta[c];
+      if (residual) v += to_f32(pr[j]);
+      if (relu) v = fmaxf(v, 0.f);
+      pa[j] = from_f32<T>(v);
+    }
+    ((uint4*)y)[i] = a;
+  }
+}
+
+// backward reductions: sums[0..C) += sum dy' ; sums[C..2C) += sum dy' * xhat   (dy' = relu-masked dy)
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                     double* __restrict__ sums, int relu, int P, int C, int rows_per_block) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int p0 = blockIdx.y * rows_per_block;
+  const int p1 = min(P, p0 + rows_per_block);
+  float s = 0.f, q = 0.f;
+  if (c < C) {
+    const float mu = mean[c], rs = rstd[c];
+    for (int p = p0 + wave; p < p1; p += 4) {
+      const long long idx = (long long)p * C + c;
+      float g = to_f32(dy[idx]);
+      if (relu && !(to_f32(y[idx]) > 0.f)) g = 0.f;
+      s += g;
+      q += g * (to_f32(x[idx]) - mu) * rs;
+    }
+  }
+  red[0][wave][lane] = s;
+  red[1][wave][lane] = q;
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    const double ds = (double)red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+    const double dq = (double)red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+    atomicAdd(sums + c, ds);
+    atomicAdd(sums + C + c, dq);
+  }
+}
+
+// dx = gamma*rstd*(dy' - mean(dy') - xhat*mean(dy'*xhat)); also emits dgamma/dbeta (block 0) and the
+// relu-masked dy' as residual gradient when dres != null.
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const double* __restrict__ sums,
+                                    T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, int relu, long long P, int C) {
+  constexpr int VEC = VecOf<T>::N;
+  const int cv = C / VEC;
+  const long long total = P * cv;
+  const float invP = 1.f / (float)P;
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      dbeta[c] = (float)sums[c];
+      dgamma[c] = (float)sums[C + c];
+    }
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cv) * VEC;
+    uint4 g = ((const uint4*)dy)[i];
+    uint4 a = ((const uint4*)x)[i];
+    uint4 o = make_uint4(0, 0, 0, 0);
+    if (relu) o = ((const uint4*)y)[i];
+    T* pg = (T*)&g;
+    const T* pa = (const T*)&a;
+    const T* po = (const T*)&o;
+    uint4 out;
+    T* pout = (T*)&out;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = c0 + j;
+      float gv = to_f32(pg[j]);
+      if (relu && !(to_f32(po[j]) > 0.f)) gv = 0.f;
+      pg[j] = from_f32<T>(gv);
+      const float xh = (to_f32(pa[j]) - mean[c]) * rstd[c];
+      const float sb = (float)sums[c] * invP, sg = (float)sums[C + c] * invP;
+      pout[j] = from_f32<T>(gamma[c] * rstd[c] * (gv - sb - xh * sg));
+    }
+    ((uint4*)dx)[i] = out;
+    if (dres) ((uint4*)dres)[i] = g;
+  }
+}
+
+// eval-mode BN: y = (x - running_mean) / sqrt(running_var + eps) * gamma + beta
+__global__ void bn_eval_coeff_kernel(const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                     float* __restrict__ mean, float* __restrict__ rstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = rm[c];
+  rstd[c] = 1.f / sqrtf(rv[c] + eps);
+}
+
+// ------------------------------------------------------------------ MaxPool
+// one thread per (output pixel, 16-byte channel vector); idx = first max position (i*kw + j), PyTorch order
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ idx,
+                                   int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                                   int Ho, int Wo) {
+  constexpr int VEC = VecOf<T>::N;
+  const int cv = C / VEC;
+  const long long total = (long long)N * Ho * Wo * cv;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(t % cv);
+    long long q = t / cv;
+    const int wo = (int)(q % Wo);
+    q /= Wo;
+    const int ho = (int)(q % Ho);
+    const int n = (int)(q / Ho);
+    float best[VEC];
+    unsigned char bi[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    bool first = true;
+    for (int i = 0; i < kh; ++i) {
+      const int h = ho * sh - ph + i;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int jx = 0; jx < kw; ++jx) {
+        const int w = wo * sw - pw + jx;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const uint4 v = ((const uint4*)x)[(((long long)n * H + h) * W + w) * cv + c];
+        const T* pv = (const T*)&v;
+        const unsigned char code = (unsigned char)(i * kw + jx);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float f = to_f32(pv[j]);
+          if (first || f > best[j] || f != f) { best[j] = f; bi[j] = code; }
+        }
+        first = false;
+      }
+    }
+    uint4 o;
+    T* po = (T*)&o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) po[j] = from_f32<T>(best[j]);
+    ((uint4*)y)[t] = o;
+    unsigned char* pi = idx + t * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) pi[j] = bi[j];
+  }
+}
+
+// gather form (no atomics): each input pixel sums dy of the windows whose argmax points at it
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                   T* __restrict__ dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
+                                   int ph, int pw, int Ho, int Wo) {
+  constexpr int VEC = VecOf<T>::N;
+  const int cv = C / VEC;
+  const long long total = (long long)N * H * W * cv;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(t % cv);
+    long long q = t / cv;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H);
+    const int n = (int)(q / H);
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int i = 0; i < kh; ++i) {
+      const int hn = h + ph - i;
+      if (hn < 0) continue;
+      const int ho = hn / sh;
+      if (ho * sh != hn || ho >= Ho) continue;
+      for (int jx = 0; jx < kw; ++jx) {
+        const int wn = w + pw - jx;
+        if (wn < 0) continue;
+        const int wo = wn / sw;
+        if (wo * sw != wn || wo >= Wo) continue;
+        const long long o = (((long long)n * Ho + ho) * Wo + wo) * cv + c;
+        const uint4 g = ((const uint4*)dy)[o];
+        const T* pg = (const T*)&g;
+        const unsigned char* pi = idx + o * VEC;
+        const unsigned char code = (unsigned char)(i * kw + jx);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          if (pi[j] == code) acc[j] += to_f32(pg[j]);
+      }
+    }
+    uint4 out;
+    T* po = (T*)&out;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) po[j] = from_f32<T>(acc[j]);
+    ((uint4*)dx)[t] = out;
+  }
+}
+
+static inline int grid_for(long long n, int block, int max_blocks = 16384) {
+  long long b = (n + block - 1) / block;
+  if (b > max_blocks) b = max_blocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace mr
+
+using namespace mr;
+
+#define DISPATCH_T(dtype, ...)                                   \
+  if ((dtype) == MR_F32) { typedef float T; __VA_ARGS__; }       \
+  else if ((dtype) == MR_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+  else { mr::set_error("bad dtype %d", (dtype)); return MR_ERR_DTYPE; }
+
+static int split_rows(int P, int C, int& rpb) {
+  const int colg = cdiv(C, 64);
+  int splits = 2048 / colg;
+  if (splits < 1) splits = 1;
+  if (splits > cdiv(P, 32)) splits = cdiv(P, 32);
+  rpb = cdiv(P, splits);
+  return cdiv(P, rpb);
+}
+
+extern "C" {
+
+// Training-mode forward.  sums: scratch double[2*C] (zeroed here).  Saves mean/rstd (f32[C]) for backward.
+int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float* save_mean, float* save_rstd, double* sums, const void* residual,
+                    int relu, long long P, int C, float eps, float momentum, hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(C % vec == 0, "mr_bn_fwd_train: C (%d) must be a multiple of %d", C, vec);
+  MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_fwd_train: bad P");
+  hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream);
+  int rpb;
+  const int splits = split_rows((int)P, C, rpb);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(cdiv(C, 64), splits), dim3(256), 0, stream,
+                                       (const T*)x, sums, (int)P, C, (long long)C, rpb));
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const double*)sums, (int)P, C,
+                     eps, momentum, save_mean, save_rstd, running_mean, running_var);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(P * (C / vec), 256)), dim3(256), 0,
+                                       stream, (const T*)x, (T*)y, (const float*)save_mean, (const float*)save_rstd,
+                                       gamma, beta, (const T*)residual, relu, P, C));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_bn_fwd_eval(int dtype, const void* x, void* y, const float* gamma, const float* beta,
+                   const float* running_mean, const float* running_var, float* tmp_mean, float* tmp_rstd,
+                   const void* residual, int relu, long long P, int C, float eps, hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(C % vec == 0, "mr_bn_fwd_eval: C (%d) must be a multiple of %d", C, vec);
+  hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, running_mean, running_var, eps,
+                     tmp_mean, tmp_rstd, C);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(P * (C / vec), 256)), dim3(256), 0,
+                                       stream, (const T*)x, (T*)y, (const float*)tmp_mean, (const float*)tmp_rstd,
+                                       gamma, beta, (const T*)residual, relu, P, C));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+// Backward of training-mode BN (+ optional fused ReLU / residual).  y is only read when relu != 0.
+int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+              const float* save_rstd, double* sums, void* dx, void* dres, float* dgamma, float* dbeta, int relu,
+              long long P, int C, hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(C % vec == 0, "mr_bn_bwd: C (%d) must be a multiple of %d", C, vec);
+  MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_bwd: bad P");
+  hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream);
+  int rpb;
+  const int splits = split_rows((int)P, C, rpb);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(cdiv(C, 64), splits), dim3(256), 0, stream,
+                                       (const T*)dy, (const T*)x, (const T*)y, save_mean, save_rstd, sums, relu,
+                                       (int)P, C, rpb));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(P * (C / vec), 256)), dim3(256), 0,
+                                       stream, (const T*)dy, (const T*)x, (const T*)y, save_mean, save_rstd, gamma,
+                                       (const double*)sums, (T*)dx, (T*)dres, dgamma, dbeta, relu, P, C));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int kh,
+                   int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(C % vec == 0, "mr_maxpool_fwd: C (%d) must be a multiple of %d", C, vec);
+  MR_CHECK_ARG(kh * kw <= 255, "mr_maxpool_fwd: window too large");
+  MR_CHECK_ARG(Ho == (H + 2 * ph - kh) / sh + 1 && Wo == (W + 2 * pw - kw) / sw + 1,
+               "mr_maxpool_fwd: output size inconsistent");
+  const long long total = (long long)N * Ho * Wo * (C / vec);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
+                                       (const T*)x, (T*)y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, Ho, Wo));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C,
+                   int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(C % vec == 0, "mr_maxpool_bwd: C (%d) must be a multiple of %d", C, vec);
+  const long long total = (long long)N * H * W * (C / vec);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
+                                       (const T*)dy, idx, (T*)dx, N, H, W, C, kh, kw, sh, sw, ph, pw, Ho, Wo));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+}  // extern "C"

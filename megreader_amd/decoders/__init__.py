@@ -1,0 +1,2 @@
+"""Mirror of reference decoders/__init__.py:1-14 (the recognition heads on the hot path)."""
+from .crnn import CRNNDecoder  # noqa: F401

@@ -1,0 +1,475 @@
+"""torch.autograd Functions that route the training hot path through libmegreader_hip.so.
+
+Tensor convention between layers: *logical* NCHW shape with NHWC (channels_last) strides, stored in the
+compute dtype (bf16 by default, f32 in parity mode).  Weights stay fp32 ``nn.Parameter``s with the
+reference's names and shapes; every forward converts them to the operand images the kernels want
+(KRSC / transposed / gate-interleaved) with a small HIP kernel.
+
+There is no CPU path in this file: CPU tensors raise NotImplementedError (same as the reference's
+``ops/ctc_2d/ctc_loss_2d.py:12-13`` does for its CUDA-only op).
+"""
+import torch
+from torch.autograd import Function
+
+from .. import get_compute_dtype
+from .._lib import call, dtype_code, ptr, require_cuda, vec_of
+
+_ESIZE = {torch.float32: 4, torch.bfloat16: 2}
+
+
+def _ceil_to(x, m):
+    return (x + m - 1) // m * m
+
+
+def to_internal(x, dtype):
+    """logical [N,C,H,W] (any layout) -> NHWC-contiguous [N,H,W,Cp] tensor of `dtype` (view when possible)."""
+    N, C, H, W = x.shape
+    v = vec_of(dtype)
+    xp = x.permute(0, 2, 3, 1)
+    if x.dtype == dtype and xp.is_contiguous() and C % v == 0:
+        return xp
+    if xp.is_contiguous() and C % v == 0 and x.dtype in _ESIZE:
+        out = torch.empty(xp.shape, dtype=dtype, device=x.device)
+        call("mr_cast", dtype_code(x.dtype), ptr(xp), dtype_code(dtype), ptr(out), out.numel())
+        return out
+    xs = x.detach()
+    if xs.dtype != torch.float32:
+        xs = xs.float()
+    xs = xs.contiguous()
+    Cp = _ceil_to(C, v)
+    out = torch.empty((N, H, W, Cp), dtype=dtype, device=x.device)
+    call("mr_nchw_to_nhwc", dtype_code(dtype), ptr(xs), ptr(out), N, C, H, W, Cp)
+    return out
+
+
+def _grad_internal(g, dtype):
+    """incoming gradient (logical NCHW) -> NHWC contiguous tensor of the compute dtype."""
+    gp = g.permute(0, 2, 3, 1)
+    if g.dtype == dtype and gp.is_contiguous():
+        return gp
+    return to_internal(g, dtype)
+
+
+def _conv_out(size, k, s, p, d):
+    return (size + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+# --------------------------------------------------------------------------------------------------
+# Conv2d (+bias, +fused ReLU).  reference: nn.Conv2d at backbones/crnn.py:48, backbones/resnet.py:39-56
+# --------------------------------------------------------------------------------------------------
+class Conv2dFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation, relu):
+        require_cuda(x, weight, bias)
+        dtype = get_compute_dtype()
+        dt = dtype_code(dtype)
+        xi = to_internal(x, dtype)
+        N, H, W, Cp = xi.shape
+        K, C, R, S = weight.shape
+        if C > Cp or weight.dtype != torch.float32:
+            raise RuntimeError("conv weight %s does not match input channels %d" % (tuple(weight.shape), Cp))
+        sh, sw = stride
+        ph, pw = padding
+        dh, dw = dilation
+        Ho, Wo = _conv_out(H, R, sh, ph, dh), _conv_out(W, S, sw, pw, dw)
+        need_dx = ctx.needs_input_grad[0]
+        w_krsc = torch.empty((K, R, S, Cp), dtype=dtype, device=x.device)
+        w_crsk = torch.empty((C, R, S, K), dtype=dtype, device=x.device) if need_dx else None
+        if need_dx and Cp != C:
+            raise RuntimeError("input gradient requested for a channel-padded convolution input")
+        sk, sc, sr, ss = weight.stride()
+        call("mr_prep_conv_weight", dt, ptr(weight), sk, sc, sr, ss, ptr(w_krsc), ptr(w_crsk), K, C, R, S, Cp)
+        y = torch.empty((N, Ho, Wo, K), dtype=dtype, device=x.device)
+        call("mr_conv2d_fwd", dt, ptr(xi), ptr(w_krsc), ptr(bias), ptr(y), int(relu), N, H, W, Cp, Cp, K, K, R, S,
+             sh, sw, ph, pw, dh, dw, Ho, Wo)
+        ctx.save_for_backward(xi, w_crsk, y if relu else None)
+        ctx.geom = (N, H, W, Cp, C, K, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo)
+        ctx.relu = relu
+        ctx.has_bias = bias is not None
+        ctx.dtype = dtype
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xi, w_crsk, y = ctx.saved_tensors
+        N, H, W, Cp, C, K, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo = ctx.geom
+        dtype = ctx.dtype
+        dt = dtype_code(dtype)
+        g = _grad_internal(gy, dtype)
+        if ctx.relu:
+            gm = torch.empty_like(g)
+            call("mr_relu_bwd", dt, ptr(g), ptr(y), ptr(gm), g.numel())
+            g = gm
+        dx = dwt = db = None
+        if ctx.needs_input_grad[0]:
+            dxi = torch.empty((N, H, W, C), dtype=dtype, device=g.device)
+            call("mr_conv2d_dgrad", dt, ptr(g), ptr(w_crsk), ptr(dxi), N, H, W, C, C, K, K, R, S, sh, sw, ph, pw,
+                 dh, dw, Ho, Wo)
+            dx = dxi.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            gw = torch.zeros((K, R, S, Cp), dtype=torch.float32, device=g.device)
+            call("mr_conv2d_wgrad", dt, ptr(g), ptr(xi), ptr(gw), N, H, W, Cp, Cp, K, K, R, S, sh, sw, ph, pw, dh,
+                 dw, Ho, Wo)
+            if Cp != C:
+                gw = gw[..., :C]
+            dwt = gw.permute(0, 3, 1, 2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros((K,), dtype=torch.float32, device=g.device)
+            call("mr_colsum", dt, ptr(g), ptr(db), N * Ho * Wo, K, K, 0)
+        return dx, dwt, db, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), relu=False):
+    return Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation), bool(relu))
+
+
+# --------------------------------------------------------------------------------------------------
+# BatchNorm2d (batch statistics in training).  reference: nn.BatchNorm2d at backbones/crnn.py:50
+# --------------------------------------------------------------------------------------------------
+class BatchNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, residual):
+        require_cuda(x, gamma, beta)
+        dtype = get_compute_dtype()
+        dt = dtype_code(dtype)
+        xi = to_internal(x, dtype)
+        N, H, W, C = xi.shape
+        if C != gamma.numel():
+            raise RuntimeError("BatchNorm2d: channel mismatch (%d vs %d)" % (C, gamma.numel()))
+        P = N * H * W
+        ri = to_internal(residual, dtype) if residual is not None else None
+        y = torch.empty_like(xi)
+        mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+        if training:
+            sums = torch.empty((2 * C,), dtype=torch.float64, device=x.device)
+            call("mr_bn_fwd_train", dt, ptr(xi), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean),
+                 ptr(running_var), ptr(mean), ptr(rstd), ptr(sums), ptr(ri), int(relu), P, C, float(eps),
+                 float(momentum))
+        else:
+            call("mr_bn_fwd_eval", dt, ptr(xi), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                 ptr(mean), ptr(rstd), ptr(ri), int(relu), P, C, float(eps))
+        ctx.save_for_backward(xi, y if relu else None, gamma, mean, rstd)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        ctx.dtype = dtype
+        ctx.training_mode = training
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        if not ctx.training_mode:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not on the training hot path")
+        xi, y, gamma, mean, rstd = ctx.saved_tensors
+        dtype = ctx.dtype
+        dt = dtype_code(dtype)
+        g = _grad_internal(gy, dtype)
+        N, H, W, C = xi.shape
+        P = N * H * W
+        dx = torch.empty_like(xi)
+        dres = torch.empty_like(xi) if ctx.has_res else None
+        sums = torch.empty((2 * C,), dtype=torch.float64, device=g.device)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=g.device)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=g.device)
+        call("mr_bn_bwd", dt, ptr(g), ptr(xi), ptr(y), ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(dx),
+             ptr(dres), ptr(dgamma), ptr(dbeta), int(ctx.relu), P, C)
+        gres = dres.permute(0, 3, 1, 2) if ctx.has_res else None
+        return dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None, gres
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu=False, residual=None):
+    return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, bool(training), momentum, eps, bool(relu),
+                             residual)
+
+
+# --------------------------------------------------------------------------------------------------
+# MaxPool2d.  reference: nn.MaxPool2d at backbones/crnn.py:17-31
+# --------------------------------------------------------------------------------------------------
+class MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, kernel, stride, padding):
+        require_cuda(x)
+        dtype = get_compute_dtype()
+        dt = dtype_code(dtype)
+        xi = to_internal(x, dtype)
+        N, H, W, C = xi.shape
+        kh, kw = kernel
+        sh, sw = stride
+        ph, pw = padding
+        Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+        y = torch.empty((N, Ho, Wo, C), dtype=dtype, device=x.device)
+        idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+        call("mr_maxpool_fwd", dt, ptr(xi), ptr(y), ptr(idx), N, H, W, C, kh, kw, sh, sw, ph, pw, Ho, Wo)
+        ctx.save_for_backward(idx)
+        ctx.geom = (N, H, W, C, kh, kw, sh, sw, ph, pw, Ho, Wo)
+        ctx.dtype = dtype
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        N, H, W, C, kh, kw, sh, sw, ph, pw, Ho, Wo = ctx.geom
+        dtype = ctx.dtype
+        g = _grad_internal(gy, dtype)
+        dx = torch.empty((N, H, W, C), dtype=dtype, device=g.device)
+        call("mr_maxpool_bwd", dtype_code(dtype), ptr(g), ptr(idx), ptr(dx), N, H, W, C, kh, kw, sh, sw, ph, pw, Ho,
+             Wo)
+        return dx.permute(0, 3, 1, 2), None, None, None
+
+
+def max_pool2d(x, kernel, stride=None, padding=(0, 0)):
+    stride = kernel if stride is None else stride
+    return MaxPoolFn.apply(x, tuple(kernel), tuple(stride), tuple(padding))
+
+
+# --------------------------------------------------------------------------------------------------
+# [N,C,1,W] feature map -> [W,N,C] sequence (squeeze(2).permute(2,0,1) at reference decoders/crnn.py:88-89)
+# --------------------------------------------------------------------------------------------------
+class MapToSequenceFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        require_cuda(x)
+        dtype = get_compute_dtype()
+        xi = to_internal(x, dtype)  # [N,1,W,C]
+        N, H, W, C = xi.shape
+        if H != 1:
+            raise AssertionError("the height of conv must be 1")
+        out = torch.empty((W, N, C), dtype=dtype, device=x.device)
+        call("mr_permute_021", dtype_code(dtype), ptr(xi), ptr(out), N, W, C)
+        ctx.shape = (N, W, C)
+        ctx.dtype = dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, W, C = ctx.shape
+        dtype = ctx.dtype
+        if g.dtype != dtype or not g.is_contiguous():
+            g = g.to(dtype).contiguous()
+        dx = torch.empty((N, 1, W, C), dtype=dtype, device=g.device)
+        call("mr_permute_021", dtype_code(dtype), ptr(g), ptr(dx), W, N, C)
+        return dx.permute(0, 3, 1, 2)
+
+
+def map_to_sequence(x):
+    return MapToSequenceFn.apply(x)
+
+
+# --------------------------------------------------------------------------------------------------
+# Linear.  reference: nn.Linear at decoders/crnn.py:14,21 (BidirectionalLSTM.embedding)
+# Output columns are padded to a 16-byte multiple; the returned tensor is the [:, :N] view of that buffer.
+# --------------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        require_cuda(x, weight, bias)
+        dtype = get_compute_dtype()
+        dt = dtype_code(dtype)
+        v = vec_of(dtype)
+        lead = x.shape[:-1]
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        if x2.dtype != dtype or not x2.is_contiguous():
+            x2 = x2.to(dtype).contiguous()
+        M = x2.shape[0]
+        Nout = weight.shape[0]
+        Np = _ceil_to(Nout, v)
+        if K % v:
+            raise RuntimeError("Linear: in_features (%d) must be a multiple of %d" % (K, v))
+        w_n = torch.empty((Nout, K), dtype=dtype, device=x.device)
+        w_t = torch.zeros((K, Np), dtype=dtype, device=x.device) if Np != Nout else \
+            torch.empty((K, Np), dtype=dtype, device=x.device)
+        call("mr_prep_matrix", dt, ptr(weight), ptr(w_n), K, ptr(w_t), Np, Nout, K, 0)
+        y = torch.empty((M, Np), dtype=dtype, device=x.device)
+        if Np != Nout:
+            y[:, Nout:].zero_()
+        call("mr_gemm_nt", dt, ptr(x2), K, ptr(w_n), K, ptr(y), Np, ptr(bias), 0, M, Nout, K)
+        ctx.save_for_backward(x2, w_t)
+        ctx.dims = (M, K, Nout, Np)
+        ctx.lead = lead
+        ctx.has_bias = bias is not None
+        ctx.dtype = dtype
+        return y[:, :Nout].view(*lead, Nout) if Np == Nout else y.view(*lead, Np)[..., :Nout]
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w_t = ctx.saved_tensors
+        M, K, Nout, Np = ctx.dims
+        dtype = ctx.dtype
+        dt = dtype_code(dtype)
+        g2 = gy.reshape(-1, Nout) if gy.shape[-1] == Nout else gy
+        if Np != Nout:
+            gp = torch.zeros((M, Np), dtype=dtype, device=gy.device)
+            gp[:, :Nout] = g2
+        else:
+            gp = g2 if (g2.dtype == dtype and g2.is_contiguous()) else g2.to(dtype).contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx2 = torch.empty((M, K), dtype=dtype, device=gy.device)
+            call("mr_gemm_nt", dt, ptr(gp), Np, ptr(w_t), Np, ptr(dx2), K, 0, 0, M, K, Np)
+            dx = dx2.view(*ctx.lead, K)
+        if ctx.needs_input_grad[1]:
+            gw = torch.zeros((Np, K), dtype=torch.float32, device=gy.device)
+            call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, Np, K, 0)
+            dw = gw[:Nout]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.zeros((Np,), dtype=torch.float32, device=gy.device)
+            call("mr_colsum", dt, ptr(gp), ptr(gb), M, Np, Np, 0)
+            db = gb[:Nout]
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return LinearFn.apply(x, weight, bias)
+
+
+# --------------------------------------------------------------------------------------------------
+# Bidirectional LSTM.  reference: nn.LSTM(nIn, nHidden, bidirectional=True) at decoders/crnn.py:13
+# --------------------------------------------------------------------------------------------------
+class BiLSTMFn(Function):
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        require_cuda(x, w_ih)
+        dtype = get_compute_dtype()
+        dt = dtype_code(dtype)
+        v = vec_of(dtype)
+        es = _ESIZE[dtype]
+        if x.dtype != dtype or not x.is_contiguous():
+            x = x.to(dtype).contiguous()
+        T, N, I = x.shape
+        H = w_hh.shape[1]
+        if I % v or H % v:
+            raise RuntimeError("LSTM: input (%d) and hidden (%d) sizes must be multiples of %d" % (I, H, v))
+        dev = x.device
+        wcat = torch.empty((8 * H, I), dtype=dtype, device=dev)
+        wcat_t = torch.empty((I, 8 * H), dtype=dtype, device=dev)
+        whh = torch.empty((2, 4 * H, H), dtype=dtype, device=dev)
+        whh_t = torch.empty((2, H, 4 * H), dtype=dtype, device=dev)
+        bcat = torch.empty((8 * H,), dtype=torch.float32, device=dev)
+        for d, (wi, wh, bi, bh) in enumerate(((w_ih, w_hh, b_ih, b_hh), (w_ih_r, w_hh_r, b_ih_r, b_hh_r))):
+            call("mr_prep_matrix", dt, ptr(wi), ptr(wcat) + d * 4 * H * I * es, I, ptr(wcat_t) + d * 4 * H * es,
+                 8 * H, 4 * H, I, H)
+            call("mr_prep_matrix", dt, ptr(wh), ptr(whh) + d * 4 * H * H * es, H,
+                 ptr(whh_t) + d * 4 * H * H * es, 4 * H, 4 * H, H, H)
+            call("mr_prep_bias", ptr(bi), ptr(bh), ptr(bcat) + d * 4 * H * 4, 4 * H, H)
+        xproj = torch.empty((T * N, 8 * H), dtype=dtype, device=dev)
+        call("mr_gemm_nt", dt, ptr(x), I, ptr(wcat), I, ptr(xproj), 8 * H, ptr(bcat), 0, T * N, 8 * H, I)
+        out = torch.empty((T, N, 2 * H), dtype=dtype, device=dev)
+        cbuf = torch.empty((T, N, 2 * H), dtype=torch.float32, device=dev)
+        gates = torch.empty((T, N, 8 * H), dtype=dtype, device=dev)
+        call("mr_lstm_fwd", dt, ptr(xproj), ptr(whh), ptr(out), ptr(cbuf), ptr(gates), T, N, H)
+        ctx.save_for_backward(x, wcat_t, whh_t, out, cbuf, gates)
+        ctx.dims = (T, N, I, H)
+        ctx.dtype = dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, wcat_t, whh_t, out, cbuf, gates = ctx.saved_tensors
+        T, N, I, H = ctx.dims
+        dtype = ctx.dtype
+        dt = dtype_code(dtype)
+        es = _ESIZE[dtype]
+        dev = gout.device
+        if gout.dtype != dtype or not gout.is_contiguous():
+            gout = gout.to(dtype).contiguous()
+        dc = torch.empty((N, 2 * H), dtype=torch.float32, device=dev)
+        # NOTE: `gates` is rewritten in place with the pre-activation gradients (single backward pass only)
+        call("mr_lstm_bwd", dt, ptr(gout), ptr(whh_t), ptr(cbuf), ptr(gates), ptr(dc), T, N, H)
+        dgates = gates
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((T, N, I), dtype=dtype, device=dev)
+            call("mr_gemm_nt", dt, ptr(dgates), 8 * H, ptr(wcat_t), 8 * H, ptr(dx), I, 0, 0, T * N, I, 8 * H)
+        gw_ih = torch.zeros((2, 4 * H, I), dtype=torch.float32, device=dev)
+        call("mr_gemm_tn", dt, ptr(dgates), 8 * H, ptr(x), I, ptr(gw_ih), I, T * N, 8 * H, I, H)
+        gw_hh = torch.zeros((2, 4 * H, H), dtype=torch.float32, device=dev)
+        if T > 1:
+            P = (T - 1) * N
+            # forward direction: dgates[t] (t>=1) with h[t-1]
+            call("mr_gemm_tn", dt, ptr(dgates) + N * 8 * H * es, 8 * H, ptr(out), 2 * H, ptr(gw_hh), H, P, 4 * H,
+                 H, H)
+            # reverse direction: dgates[t] (t<=T-2) with h[t+1]
+            call("mr_gemm_tn", dt, ptr(dgates) + 4 * H * es, 8 * H, ptr(out) + (N * 2 * H + H) * es, 2 * H,
+                 ptr(gw_hh) + 4 * H * H * 4, H, P, 4 * H, H, H)
+        gb = torch.zeros((2, 4 * H), dtype=torch.float32, device=dev)
+        call("mr_colsum", dt, ptr(dgates), ptr(gb), T * N, 8 * H, 8 * H, H)
+        return (dx, gw_ih[0], gw_hh[0], gb[0], gb[0].clone(), gw_ih[1], gw_hh[1], gb[1], gb[1].clone())
+
+
+def bilstm(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+    return BiLSTMFn.apply(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
+
+
+# --------------------------------------------------------------------------------------------------
+# 1-D CTC loss fused with log-softmax.  reference: decoders/crnn.py:96-98
+#   pred = log_softmax(pred, dim=2).to(float64); loss = nn.CTCLoss(zero_infinity=True)(pred, targets, [T]*b, lengths)
+# Returns (loss f64 scalar, log_probs f32 [T,N,C]).
+# --------------------------------------------------------------------------------------------------
+class CTCLossFn(Function):
+    @staticmethod
+    def forward(ctx, logits, targets, input_lengths, target_lengths, blank, zero_infinity):
+        require_cuda(logits, targets, target_lengths)
+        T, N, C = logits.shape
+        dtype = logits.dtype
+        if dtype not in _ESIZE:
+            raise TypeError("ctc_loss: logits must be float32 or bfloat16")
+        if logits.stride(2) != 1 or logits.stride(1) * N != logits.stride(0):
+            logits = logits.contiguous()
+        ldl = logits.stride(1)
+        if targets.dim() != 2 or targets.shape[0] != N:
+            raise RuntimeError("ctc_loss: targets must be padded [N, S]")
+        S = targets.shape[1]
+        targets = targets.contiguous()
+        if targets.dtype not in (torch.int32, torch.int64):
+            targets = targets.long()
+        if input_lengths is None:
+            input_lengths = torch.full((N,), T, dtype=torch.int64, device=logits.device)
+        input_lengths = input_lengths.to(device=logits.device, dtype=torch.int64).contiguous()
+        target_lengths = target_lengths.to(device=logits.device, dtype=torch.int64).contiguous()
+        dev = logits.device
+        lp = torch.empty((T, N, C), dtype=torch.float32, device=dev)
+        alpha = torch.empty((N, T, 2 * S + 1), dtype=torch.float64, device=dev)
+        nll = torch.empty((N,), dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float64, device=dev)
+        t64 = int(targets.dtype == torch.int64)
+        call("mr_ctc_fwd", dtype_code(dtype), ptr(logits), ldl, ptr(targets), t64, ptr(input_lengths),
+             ptr(target_lengths), 1, T, N, C, S, int(blank), int(zero_infinity), ptr(lp), ptr(alpha), ptr(nll),
+             ptr(loss))
+        ctx.save_for_backward(lp, alpha, nll, targets, input_lengths, target_lengths)
+        ctx.dims = (T, N, C, S, int(blank), int(zero_infinity), t64)
+        ctx.dtype = dtype
+        ctx.mark_non_differentiable(lp)
+        return loss, lp
+
+    @staticmethod
+    def backward(ctx, gloss, _glp):
+        lp, alpha, nll, targets, input_lengths, target_lengths = ctx.saved_tensors
+        T, N, C, S, blank, zero_inf, t64 = ctx.dims
+        dtype = ctx.dtype
+        v = vec_of(dtype)
+        Cp = _ceil_to(C, v)
+        g = gloss.to(torch.float64).contiguous()
+        grad = torch.zeros((T, N, Cp), dtype=dtype, device=lp.device) if Cp != C else \
+            torch.empty((T, N, Cp), dtype=dtype, device=lp.device)
+        call("mr_ctc_bwd", dtype_code(dtype), ptr(lp), ptr(alpha), ptr(nll), ptr(targets), t64, ptr(input_lengths),
+             ptr(target_lengths), 1, ptr(g), T, N, C, S, blank, zero_inf, ptr(grad), Cp)
+        return grad[..., :C], None, None, None, None, None
+
+
+def ctc_loss_logits(logits, targets, input_lengths, target_lengths, blank=0, zero_infinity=True):
+    """mean-reduced CTC loss of log_softmax(logits) (fused); returns (loss, log_probs)."""
+    return CTCLossFn.apply(logits, targets, input_lengths, target_lengths, blank, zero_infinity)
+
+
+def softmax_eval_nc1t(logits):
+    """eval head of CRNNDecoder: logits [T,N,C] -> softmax over classes as f32 [N,C,1,T]
+    (reference decoders/crnn.py:101-104).  Inference only (no autograd)."""
+    require_cuda(logits)
+    T, N, C = logits.shape
+    lg = logits.detach()
+    if lg.stride(2) != 1 or lg.stride(1) * N != lg.stride(0):
+        lg = lg.contiguous()
+    out = torch.empty((N, C, 1, T), dtype=torch.float32, device=lg.device)
+    call("mr_softmax_nc1t", dtype_code(lg.dtype), ptr(lg), lg.stride(1), ptr(out), T, N, C)
+    return out

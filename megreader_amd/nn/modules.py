@@ -1,0 +1,98 @@
+"""nn.Module mirrors whose parameters keep the reference's names, shapes and default initialisation
+(they subclass the torch modules the reference instantiates) while `forward` runs the HIP kernels."""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import functional as F
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d drop-in (groups=1, zero padding) -- implicit-GEMM MFMA kernel, optional fused ReLU."""
+
+    def __init__(self, *args, fuse_relu=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.groups != 1 or self.padding_mode != "zeros" or isinstance(self.padding, str):
+            raise NotImplementedError("megreader_amd.nn.Conv2d supports groups=1 and explicit zero padding only")
+        self.fuse_relu = fuse_relu
+        # physical KRSC layout: the wgrad kernel's output is then adopted as .grad without a re-layout
+        self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def forward(self, x):
+        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.fuse_relu)
+
+
+class FusedReLU(nn.Module):
+    """Placeholder that keeps the reference's Sequential indices; the ReLU itself runs in the epilogue of
+    the preceding Conv2d / BatchNorm2d (constructed with fuse_relu=True)."""
+
+    def forward(self, x):
+        return x
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    def __init__(self, *args, fuse_relu=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        if not (self.affine and self.track_running_stats):
+            raise NotImplementedError("megreader_amd.nn.BatchNorm2d requires affine=True, track_running_stats=True")
+        self.fuse_relu = fuse_relu
+
+    def forward(self, x, residual=None):
+        momentum = 0.1 if self.momentum is None else self.momentum
+        if self.training:
+            self.num_batches_tracked.add_(1)
+        return F.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, momentum,
+                            self.eps, self.fuse_relu, residual)
+
+
+class MaxPool2d(nn.MaxPool2d):
+    def forward(self, x):
+        if self.ceil_mode or _pair(self.dilation) != (1, 1) or self.return_indices:
+            raise NotImplementedError("megreader_amd.nn.MaxPool2d: ceil_mode / dilation / return_indices unsupported")
+        stride = self.kernel_size if self.stride is None else self.stride
+        return F.max_pool2d(x, _pair(self.kernel_size), _pair(stride), _pair(self.padding))
+
+
+class Linear(nn.Linear):
+    def forward(self, x):
+        return F.linear(x, self.weight, self.bias)
+
+
+class LSTM(nn.Module):
+    """Single-layer bidirectional LSTM with nn.LSTM's parameter names (weight_ih_l0, ..., bias_hh_l0_reverse),
+    gate order (i, f, g, o) and default initialisation U(-1/sqrt(H), 1/sqrt(H))."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, bias=True, batch_first=False, dropout=0.0,
+                 bidirectional=False):
+        super().__init__()
+        if num_layers != 1 or not bias or batch_first or dropout or not bidirectional:
+            raise NotImplementedError("megreader_amd.nn.LSTM implements nn.LSTM(nIn, nHidden, bidirectional=True)")
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.num_layers, self.bidirectional = 1, True
+        for suffix in ("", "_reverse"):
+            self.register_parameter("weight_ih_l0" + suffix, nn.Parameter(torch.empty(4 * hidden_size, input_size)))
+            self.register_parameter("weight_hh_l0" + suffix, nn.Parameter(torch.empty(4 * hidden_size, hidden_size)))
+            self.register_parameter("bias_ih_l0" + suffix, nn.Parameter(torch.empty(4 * hidden_size)))
+            self.register_parameter("bias_hh_l0" + suffix, nn.Parameter(torch.empty(4 * hidden_size)))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.hidden_size) if self.hidden_size > 0 else 0
+        for w in self.parameters():
+            nn.init.uniform_(w, -stdv, stdv)
+
+    def flatten_parameters(self):  # API parity with nn.LSTM (reference decoders/crnn.py:91-92); nothing to do
+        pass
+
+    def forward(self, x, hx=None):
+        if hx is not None:
+            raise NotImplementedError("initial states are not used on the reference path")
+        out = F.bilstm(x, self.weight_ih_l0, self.weight_hh_l0, self.bias_ih_l0, self.bias_hh_l0,
+                       self.weight_ih_l0_reverse, self.weight_hh_l0_reverse, self.bias_ih_l0_reverse,
+                       self.bias_hh_l0_reverse)
+        return out, None

@@ -1,0 +1,116 @@
+"""Generate tests/golden/*.pt by executing the UNMODIFIED reference on CPU (this container only).
+
+    python oracle/gen_golden.py
+
+For every fixture the script also runs the oracle restatement on the same weights/inputs and refuses to write
+the file unless the two agree bit-for-bit (they execute the same torch CPU kernels) -- that is the pin of the
+oracle to the reference.  Weights are too large to commit (33 MB), so a fixture stores the RNG seed that
+reproduces them plus per-tensor checksums; inputs and outputs are stored in full.
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+
+from oracle import refimport  # noqa: E402
+from oracle.crnn import CRNNOracle, synthetic_batch  # noqa: E402
+from oracle.decode import greedy_decode  # noqa: E402
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+WEIGHT_SEED = 1234
+
+
+def checksums(state):
+    return {k: (float(v.double().sum()), float(v.double().abs().sum())) for k, v in state.items()}
+
+
+def crnn_fixture():
+    torch.set_num_threads(4)
+    sm = refimport.import_reference()
+    from concern.charsets import EnglishCharset
+    from structure.representers.ctc_representer import CTCRepresenter
+    charset = EnglishCharset()
+    args = {'backbone': 'crnn_backbone', 'decoder': 'CRNNDecoder',
+            'decoder_args': {'in_channels': 512, 'inner_channels': 256, 'need_reduce': False, 'charset': charset}}
+
+    torch.manual_seed(WEIGHT_SEED)
+    ref = sm.SequenceRecognitionModel(args, torch.device('cpu'))  # structure/model.py:160-181 (DataParallel on CPU)
+    torch.manual_seed(WEIGHT_SEED)
+    ora = CRNNOracle(num_classes=len(charset))
+    ref_state = {k.replace('model.module.', ''): v for k, v in ref.state_dict().items()}
+    assert list(ref_state.keys()) == list(ora.state_dict().keys()), "state_dict keys differ"
+    for k, v in ora.state_dict().items():
+        assert torch.equal(v, ref_state[k]), "seeded init differs at %s" % k
+
+    batch = synthetic_batch(3, height=32, width=64, seed=7)
+    out = {'weight_seed': WEIGHT_SEED, 'batch': batch, 'state_checksums': checksums(ref_state),
+           'state_keys': list(ref_state.keys()), 'state_shapes': {k: tuple(v.shape) for k, v in ref_state.items()}}
+
+    # ---- training forward / backward through the reference wrapper (batch dict in, (loss, pred) out)
+    ref.train()
+    ora.train()
+    loss_r, pred_r = ref.forward(dict(batch), training=True)
+    loss_r.mean().backward()
+    loss_o, pred_o = ora(batch['image'], targets=batch['label'], lengths=batch['length'].long(), train=True)
+    loss_o.mean().backward()
+    assert torch.equal(loss_r, loss_o) and torch.equal(pred_r, pred_o), "oracle forward != reference"
+    grads_r = {k.replace('model.module.', ''): p.grad for k, p in ref.named_parameters()}
+    for k, p in ora.named_parameters():
+        assert torch.equal(p.grad, grads_r[k]), "oracle grad != reference at %s" % k
+    out['train_loss'] = loss_r.detach().clone()
+    out['train_log_probs'] = pred_r.detach().clone()
+    out['grad_stats'] = {k: (float(g.double().norm()), g.flatten()[:8].clone()) for k, g in grads_r.items()}
+    # BN running stats after one training forward
+    out['bn_after'] = {k.replace('model.module.', ''): v.clone() for k, v in ref.state_dict().items()
+                       if 'running' in k}
+
+    # ---- three Adam steps (experiments/recognition/crnn.yaml:82-89: Adam, lr 1e-3) -- loss trajectory
+    opt_r = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    opt_o = torch.optim.Adam(ora.parameters(), lr=1e-3)
+    traj_r, traj_o = [], []
+    for _ in range(3):
+        opt_r.zero_grad()
+        l, _p = ref.forward(dict(batch), training=True)
+        l = l.mean()
+        l.backward()
+        opt_r.step()
+        traj_r.append(float(l))
+        opt_o.zero_grad()
+        l2, _p = ora(batch['image'], targets=batch['label'], lengths=batch['length'].long(), train=True)
+        l2 = l2.mean()
+        l2.backward()
+        opt_o.step()
+        traj_o.append(float(l2))
+    assert traj_r == traj_o, "oracle Adam trajectory != reference: %s vs %s" % (traj_r, traj_o)
+    out['adam_losses'] = traj_r
+
+    # ---- eval forward + greedy decode (structure/representers/ctc_representer.py:20-34)
+    ref.eval()
+    ora.eval()
+    with torch.no_grad():
+        ev_r = ref.forward(dict(batch), training=False)
+        ev_o = ora(batch['image'], train=False)
+    assert torch.equal(ev_r, ev_o), "oracle eval != reference"
+    rep = CTCRepresenter(charset=charset)
+    strings = rep.represent(batch, ev_r)
+    dec = greedy_decode(ev_r.numpy())
+    assert [charset.label_to_string(d) for d in dec] == [s['pred_string'] for s in strings], "decode differs"
+    out['eval_pred'] = ev_r.clone()
+    out['eval_decode'] = torch.from_numpy(dec)
+    out['eval_strings'] = [s['pred_string'] for s in strings]
+    out['label_strings'] = [s['label_string'] for s in strings]
+    os.makedirs(GOLDEN, exist_ok=True)
+    path = os.path.join(GOLDEN, "crnn_golden.pt")
+    torch.save(out, path)
+    print("wrote", path, os.path.getsize(path), "bytes; loss", float(loss_r), "adam", traj_r)
+
+
+if __name__ == "__main__":
+    if not refimport.available():
+        raise SystemExit("reference not available: golden vectors can only be regenerated in the build container")
+    os.chdir("/tmp")
+    crnn_fixture()

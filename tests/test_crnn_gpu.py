@@ -1,0 +1,179 @@
+"""End-to-end parity of the HIP CRNN training path against the oracle / the committed golden vectors.
+
+The golden file was produced by the UNMODIFIED reference (oracle/gen_golden.py); the oracle is bit-identical to
+it on CPU.  Bars (BASELINE.json north_star): loss and log-probabilities within 1e-4 in fp32, greedy decode
+bit-exact.  bf16 is the benchmark dtype: its drift is reported and bounded loosely.
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import megreader_amd as mr  # noqa: E402
+from megreader_amd.backbones import crnn_backbone  # noqa: E402
+from megreader_amd.decoders import CRNNDecoder  # noqa: E402
+from megreader_amd.optim import FusedAdam  # noqa: E402
+from oracle.crnn import CRNNOracle, synthetic_batch  # noqa: E402
+from oracle.decode import greedy_decode  # noqa: E402
+
+DEV = "cuda"
+
+
+class BasicModel(torch.nn.Module):
+    """reference structure/model.py:16-24: decoder(backbone(data), *args, **kwargs)."""
+
+    def __init__(self):
+        super().__init__()
+        self.backbone = crnn_backbone()
+        self.decoder = CRNNDecoder(in_channels=512, inner_channels=256, need_reduce=False)
+
+    def forward(self, data, *args, **kwargs):
+        return self.decoder(self.backbone(data), *args, **kwargs)
+
+
+@pytest.fixture(autouse=True)
+def _reset_dtype():
+    yield
+    mr.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return torch.load(os.path.join(golden_dir, "crnn_golden.pt"), weights_only=False)
+
+
+def _oracle(golden):
+    torch.manual_seed(golden['weight_seed'])
+    return CRNNOracle()
+
+
+def _to_dev(batch):
+    return batch['image'].to(DEV), batch['label'].to(DEV), batch['length'].to(DEV).long()
+
+
+def test_state_dict_interchange(golden):
+    model = BasicModel()
+    ora = _oracle(golden)
+    assert list(model.state_dict().keys()) == golden['state_keys']
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == golden['state_shapes'][k], k
+    model.load_state_dict(ora.state_dict(), strict=True)
+    model.to(DEV)
+    for k, v in model.state_dict().items():
+        s, a = golden['state_checksums'][k]
+        assert abs(float(v.double().sum()) - s) <= 1e-6 * max(1.0, a), k
+
+
+def test_fp32_training_parity_vs_reference_golden(golden):
+    mr.set_compute_dtype(torch.float32)
+    ora = _oracle(golden)
+    model = BasicModel()
+    model.load_state_dict(ora.state_dict())
+    model.to(DEV).train()
+    img, lab, ln = _to_dev(golden['batch'])
+    loss, pred = model(img, targets=lab, lengths=ln, train=True)
+    assert loss.dtype == torch.float64 and pred.dtype == torch.float64
+    assert abs(float(loss) - float(golden['train_loss'])) < 1e-4
+    assert float((pred.cpu() - golden['train_log_probs']).abs().max()) < 1e-4
+    loss.mean().backward()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        norm, head = golden['grad_stats'][k]
+        g = p.grad.float().cpu()
+        rel = abs(float(g.double().norm()) - norm) / max(norm, 1e-12)
+        worst = max(worst, rel)
+        assert rel < 2e-3, (k, rel)
+        assert float((g.flatten()[:8] - head).abs().max()) < 2e-3 * max(float(head.abs().max()), norm / g.numel() ** 0.5), k
+    print("worst relative grad-norm error (fp32):", worst)
+    for k, v in model.state_dict().items():
+        if 'running' in k:
+            assert float((v.cpu() - golden['bn_after'][k]).abs().max()) < 1e-4, k
+
+
+def test_fp32_adam_trajectory(golden):
+    mr.set_compute_dtype(torch.float32)
+    ora = _oracle(golden)
+    model = BasicModel()
+    model.load_state_dict(ora.state_dict())
+    model.to(DEV).train()
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    img, lab, ln = _to_dev(golden['batch'])
+    # the golden trajectory starts after one plain forward/backward that only moved BN running stats
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss, _ = model(img, targets=lab, lengths=ln, train=True)
+        loss.mean().backward()
+        opt.step()
+        losses.append(float(loss))
+    for a, b in zip(losses, golden['adam_losses']):
+        assert abs(a - b) < 2e-3 * max(1.0, abs(b)), (losses, golden['adam_losses'])
+
+
+def test_eval_and_greedy_decode_bit_exact(golden):
+    mr.set_compute_dtype(torch.float32)
+    ora = _oracle(golden)
+    # golden eval ran after BN stats moved by 4 training forwards and 3 Adam steps; redo them on the oracle (CPU)
+    batch = golden['batch']
+    ora.train()
+    l, _ = ora(batch['image'], targets=batch['label'], lengths=batch['length'].long(), train=True)
+    opt = torch.optim.Adam(ora.parameters(), lr=1e-3)
+    for _ in range(3):
+        opt.zero_grad()
+        l, _ = ora(batch['image'], targets=batch['label'], lengths=batch['length'].long(), train=True)
+        l.mean().backward()
+        opt.step()
+    ora.eval()
+    with torch.no_grad():
+        ev_o = ora(batch['image'], train=False)
+    assert float((ev_o - golden['eval_pred']).abs().max()) == 0.0  # oracle reproduces the reference exactly
+    model = BasicModel()
+    model.load_state_dict(ora.state_dict())
+    model.to(DEV).eval()
+    with torch.no_grad():
+        ev = model(batch['image'].to(DEV), train=False)
+    assert ev.shape == golden['eval_pred'].shape
+    assert float((ev.cpu() - golden['eval_pred']).abs().max()) < 1e-4
+    dec = greedy_decode(ev.cpu().numpy())
+    top2 = golden['eval_pred'].topk(2, dim=1).values
+    print("min top-1/top-2 margin:", float((top2[:, 0] - top2[:, 1]).min()))
+    assert (torch.from_numpy(dec) == golden['eval_decode']).all()
+
+
+def test_bf16_training_close_to_oracle(golden):
+    mr.set_compute_dtype(torch.bfloat16)
+    ora = _oracle(golden)
+    model = BasicModel()
+    model.load_state_dict(ora.state_dict())
+    model.to(DEV).train()
+    img, lab, ln = _to_dev(golden['batch'])
+    loss, pred = model(img, targets=lab, lengths=ln, train=True)
+    loss.mean().backward()
+    drift = abs(float(loss) - float(golden['train_loss']))
+    print("bf16 loss drift vs reference:", drift)
+    assert drift < 0.1
+    for k, p in model.named_parameters():
+        norm, _ = golden['grad_stats'][k]
+        rel = abs(float(p.grad.double().norm()) - norm) / max(norm, 1e-12)
+        assert rel < 0.25, (k, rel)
+
+
+def test_full_size_batch_runs_and_learns():
+    """BASELINE config 2 shape (N=256, 32x128, bf16): loss finite and decreasing over a few fused-Adam steps."""
+    mr.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(0)
+    model = BasicModel().to(DEV).train()
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    batch = synthetic_batch(256, 32, 128, seed=0)
+    img, lab, ln = _to_dev(batch)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss, _ = model(img, targets=lab, lengths=ln, train=True)
+        loss.mean().backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(l == l and abs(l) < 1e4 for l in losses), losses
+    assert losses[-1] < losses[0], losses

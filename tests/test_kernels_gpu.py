@@ -1,0 +1,274 @@
+"""Per-kernel parity of the HIP library (through the C ABI / autograd wrappers) against torch CPU references.
+
+fp32 mode uses the exact-f32 MFMA path: tolerances are f32 round-off class.  bf16 mode rounds operands to bf16,
+so the reference is computed on bf16-rounded inputs and compared with a bf16-output tolerance.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+import megreader_amd as mr  # noqa: E402
+from megreader_amd._lib import call, dtype_code, ptr  # noqa: E402
+from megreader_amd.nn import functional as F  # noqa: E402
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _tol(dtype, k=1):
+    return (2e-5 * math.sqrt(k) + 1e-6) if dtype == torch.float32 else (1.6e-2)
+
+
+def _rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.fixture(autouse=True)
+def _reset_dtype():
+    yield
+    mr.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (8448, 2048, 512), (200, 38, 512), (64, 1024, 256),
+                                   (1000, 136, 72), (33, 512, 2304)])
+def test_gemm_nt(dtype, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)  # asymmetric, M != N: catches transposed C writes
+    bias = torch.randn(N, generator=g)
+    Ad, Bd = A.to(DEV, dtype), B.to(DEV, dtype)
+    ldc = (N + 7) // 8 * 8
+    C = torch.full((M, ldc), 7.0, device=DEV, dtype=dtype)
+    call("mr_gemm_nt", dtype_code(dtype), ptr(Ad), K, ptr(Bd), K, ptr(C), ldc, ptr(bias.to(DEV)), 1, M, N, K)
+    ref = torch.relu(Ad.double().cpu() @ Bd.double().cpu().t() + bias.double())
+    assert _rel_err(C[:, :N], ref) < _tol(dtype, K)
+    if ldc != N:
+        assert float((C[:, N:].float() - 7.0).abs().max()) == 0.0  # pad columns untouched
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("P,NA,NB,perm", [(512, 128, 128, 0), (8448, 2048, 256, 256), (1000, 40, 512, 0),
+                                          (77, 256, 72, 0), (4096, 64, 576, 0)])
+def test_gemm_tn(dtype, P, NA, NB, perm):
+    g = torch.Generator().manual_seed(P + NA)
+    A = torch.randn(P, NA, generator=g)
+    B = torch.randn(P, NB, generator=g)
+    Ad, Bd = A.to(DEV, dtype), B.to(DEV, dtype)
+    C = torch.ones(NA, NB, device=DEV)  # accumulate semantics: starts at 1
+    call("mr_gemm_tn", dtype_code(dtype), ptr(Ad), NA, ptr(Bd), NB, ptr(C), NB, P, NA, NB, perm)
+    ref = Ad.double().cpu().t() @ Bd.double().cpu()
+    if perm:
+        blocks = ref.view(NA // (4 * perm), perm, 4, NB)          # row r = 4*j + q  ->  q*perm + j
+        ref = blocks.permute(0, 2, 1, 3).reshape(NA, NB)
+    ref = ref + 1.0
+    assert _rel_err(C, ref) < (_tol(dtype, P) if dtype == torch.float32 else 3e-3)
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 32, 64, 3, 64, 3, 1, 1, 1),       # CRNN conv0 (channel-padded input, no dgrad)
+    (2, 16, 32, 64, 128, 3, 1, 1, 1),     # CRNN conv1
+    (3, 2, 18, 512, 512, 2, 1, 0, 1),     # CRNN conv6 (2x2, pad 0)
+    (2, 9, 13, 32, 48, 3, 2, 1, 1),       # strided (ResNet)
+    (2, 12, 10, 16, 24, 3, 1, 2, 2),      # dilated (ResnetDilated)
+    (2, 8, 8, 64, 256, 1, 1, 0, 1),       # 1x1
+    (1, 15, 17, 24, 40, (2, 3), (2, 1), (0, 1), 1),  # attention encoder's (2,3) kernel, stride (2,1), pad (0,1)
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(dtype, case):
+    N, H, W, Cin, Cout, k, s, p, d = case
+    mr.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    conv = torch.nn.Conv2d(Cin, Cout, k, s, p, d)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.1)
+        conv.bias.copy_(torch.randn(Cout, generator=g))
+    need_dx = Cin % 8 == 0
+    # reference on (bf16-rounded) operands, f64 math
+    xr = x.to(dtype).double().requires_grad_(need_dx)
+    wr = conv.weight.detach().to(dtype).double().requires_grad_(True)
+    br = conv.bias.detach().double().requires_grad_(True)
+    yr = torch.relu(TF.conv2d(xr, wr, br, conv.stride, conv.padding, conv.dilation))
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.to(dtype).double())
+
+    xd = x.to(DEV)
+    if need_dx:
+        xd = xd.to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = conv.weight.detach().to(DEV).requires_grad_(True)
+    b = conv.bias.detach().to(DEV).requires_grad_(True)
+    y = F.conv2d(xd, w, b, conv.stride, conv.padding, conv.dilation, relu=True)
+    assert y.shape == yr.shape and y.dtype == dtype
+    tol = _tol(dtype, Cin * 9)
+    assert _rel_err(y, yr) < tol
+    y.backward(gy.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    assert _rel_err(w.grad, wr.grad) < (tol if dtype == torch.float32 else 2e-2)
+    assert _rel_err(b.grad, br.grad) < (tol if dtype == torch.float32 else 2e-2)
+    if need_dx:
+        assert _rel_err(xd.grad, xr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_batchnorm(dtype, relu):
+    mr.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W = 4, 64, 6, 9
+    x = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(dtype)
+    bn = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g))
+    xr = x.double().requires_grad_(True)
+    yr = bn(xr)
+    if relu:
+        yr = torch.relu(yr)
+    gy = torch.randn(yr.shape, generator=g).to(dtype)
+    yr.backward(gy.double())
+
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gamma = bn.weight.detach().float().to(DEV).requires_grad_(True)
+    beta = bn.bias.detach().float().to(DEV).requires_grad_(True)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    y = F.batch_norm(xd, gamma, beta, rm, rv, True, 0.1, 1e-5, relu=relu)
+    tol = 2e-5 if dtype == torch.float32 else 1.6e-2
+    assert _rel_err(y, yr) < tol
+    assert _rel_err(rm, bn.running_mean) < 1e-5 and _rel_err(rv, bn.running_var) < 1e-5
+    y.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
+    assert _rel_err(xd.grad, xr.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert _rel_err(gamma.grad, bn.weight.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+    assert _rel_err(beta.grad, bn.bias.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k,s,p", [((2, 2), (2, 2), (0, 0)), ((2, 2), (2, 1), (0, 1)), ((3, 3), (2, 2), (1, 1))])
+def test_maxpool(dtype, k, s, p):
+    mr.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 16, 10, 14, generator=g).to(dtype)
+    x = torch.relu(x)  # plenty of exact ties at 0: exercises the first-max rule
+    xr = x.double().requires_grad_(True)
+    yr = TF.max_pool2d(xr, k, s, p)
+    gy = torch.randn(yr.shape, generator=g).to(dtype)
+    yr.backward(gy.double())
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = F.max_pool2d(xd, k, s, p)
+    assert torch.equal(y.float().cpu(), yr.float())
+    y.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
+    assert _rel_err(xd.grad, xr.grad) < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear(dtype):
+    mr.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(3)
+    T, N, K, O = 5, 7, 64, 38
+    x = torch.randn(T, N, K, generator=g).to(dtype)
+    lin = torch.nn.Linear(K, O)
+    xr = x.double().requires_grad_(True)
+    wr = lin.weight.detach().to(dtype).double().requires_grad_(True)
+    br = lin.bias.detach().double().requires_grad_(True)
+    yr = TF.linear(xr, wr, br)
+    gy = torch.randn(yr.shape, generator=g).to(dtype)
+    yr.backward(gy.double())
+    xd = x.to(DEV).requires_grad_(True)
+    w = lin.weight.detach().to(DEV).requires_grad_(True)
+    b = lin.bias.detach().to(DEV).requires_grad_(True)
+    y = F.linear(xd, w, b)
+    assert y.shape == (T, N, O)
+    tol = _tol(dtype, K)
+    assert _rel_err(y, yr) < tol
+    y.backward(gy.to(DEV))
+    assert _rel_err(xd.grad, xr.grad) < tol
+    assert _rel_err(w.grad, wr.grad) < (tol if dtype == torch.float32 else 2e-2)
+    assert _rel_err(b.grad, br.grad) < (tol if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,N,I,H", [(5, 3, 64, 32), (9, 70, 32, 64)])
+def test_bilstm(dtype, T, N, I, H):
+    mr.set_compute_dtype(dtype)
+    torch.manual_seed(17)
+    ref = torch.nn.LSTM(I, H, bidirectional=True).double()
+    x = torch.randn(T, N, I).to(dtype)
+    if dtype == torch.bfloat16:  # reference sees the same bf16-rounded weights
+        with torch.no_grad():
+            for n_, p in ref.named_parameters():
+                if n_.startswith("weight"):
+                    p.copy_(p.float().to(dtype).double())
+    xr = x.double().requires_grad_(True)
+    yr, _ = ref(xr)
+    gy = torch.randn(yr.shape).to(dtype)
+    yr.backward(gy.double())
+    params = [getattr(ref, n_).detach().float().to(DEV).requires_grad_(True) for n_ in
+              ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse",
+               "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse")]
+    xd = x.to(DEV).requires_grad_(True)
+    y = F.bilstm(xd, *params)
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    assert _rel_err(y, yr) < tol
+    y.backward(gy.to(DEV))
+    assert _rel_err(xd.grad, xr.grad) < (2e-4 if dtype == torch.float32 else 4e-2)
+    names = ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse",
+             "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse")
+    for n_, p in zip(names, params):
+        assert _rel_err(p.grad, getattr(ref, n_).grad) < (2e-4 if dtype == torch.float32 else 4e-2), n_
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ctc_matches_torch_and_oracle(dtype):
+    from oracle.ctc import ctc_1d
+    g = torch.Generator().manual_seed(23)
+    T, N, C, S = 12, 6, 38, 32
+    logits = (torch.randn(T, N, C, generator=g) * 2).to(dtype)
+    lengths = torch.tensor([3, 1, 6, 0, 10, 5])
+    targets = torch.zeros(N, S, dtype=torch.int32)
+    for i, L in enumerate(lengths.tolist()):
+        targets[i, :L] = torch.randint(2, C, (L,), generator=g, dtype=torch.int32)
+    targets[2, 1] = targets[2, 0]            # repeated label
+    targets[4, :10] = 5                       # 10 repeats need T >= 19 > 12: infeasible -> zero_infinity path
+    xr = logits.float().requires_grad_(True)
+    lp = TF.log_softmax(xr, dim=2).double()
+    loss_r = TF.ctc_loss(lp, targets, torch.full((N,), T, dtype=torch.int32), lengths, zero_infinity=True)
+    loss_r.backward()
+    xd = logits.to(DEV).requires_grad_(True)
+    loss, logp = F.ctc_loss_logits(xd, targets.to(DEV), None, lengths.to(DEV))
+    assert loss.dtype == torch.float64
+    assert abs(float(loss) - float(loss_r)) < 1e-6 * max(1.0, abs(float(loss_r)))
+    assert float((logp.cpu() - lp.float()).abs().max()) < 2e-6
+    loss.backward()
+    gtol = 2e-6 if dtype == torch.float32 else 4e-3
+    assert float((xd.grad.float().cpu() - xr.grad).abs().max()) < gtol
+    o = ctc_1d(logits.float().numpy(), targets.numpy(), lengths.numpy())
+    assert abs(o['loss'] - float(loss)) < 1e-9 * max(1.0, abs(o['loss']))
+    assert float((torch.from_numpy(o['grad_logits']).float() - xd.grad.float().cpu()).abs().max()) < gtol
+
+
+def test_ctc_full_size_properties():
+    """BASELINE size (T=33, N=256, C=38): occupancy rows of the gradient sum to zero, loss finite and positive."""
+    g = torch.Generator().manual_seed(1)
+    T, N, C, S = 33, 256, 38, 32
+    logits = torch.randn(T, N, C, generator=g).to(DEV).requires_grad_(True)
+    lengths = torch.randint(3, 11, (N,), generator=g)
+    targets = torch.zeros(N, S, dtype=torch.int32)
+    for i, L in enumerate(lengths.tolist()):
+        targets[i, :L] = torch.randint(2, C, (L,), generator=g, dtype=torch.int32)
+    loss, _ = F.ctc_loss_logits(logits, targets.to(DEV), None, lengths.to(DEV))
+    loss.backward()
+    assert math.isfinite(float(loss)) and float(loss) > 0
+    assert float(logits.grad.sum(dim=2).abs().max()) < 1e-6   # sum_c (softmax - occupancy) = 0 for every (t, n)
+
+
+def test_cpu_tensor_fails_loudly():
+    with pytest.raises(NotImplementedError):
+        F.conv2d(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 3, 3))
