@@ -106,4 +106,4 @@ def train_step(model, optimizer, batch):
     loss = loss.mean()
     loss.backward()
     optimizer.step()
-    return float(loss)
+    return float(loss.detach())

@@ -82,10 +82,12 @@ def test_fp32_training_parity_vs_reference_golden(golden):
     for k, p in model.named_parameters():
         norm, head = golden['grad_stats'][k]
         g = p.grad.float().cpu()
-        rel = abs(float(g.double().norm()) - norm) / max(norm, 1e-12)
+        # conv biases in front of a BatchNorm have a mathematically zero gradient (round-off only): floor the scale
+        scale = max(norm, 1e-4)
+        rel = abs(float(g.double().norm()) - norm) / scale
         worst = max(worst, rel)
-        assert rel < 2e-3, (k, rel)
-        assert float((g.flatten()[:8] - head).abs().max()) < 2e-3 * max(float(head.abs().max()), norm / g.numel() ** 0.5), k
+        assert rel < 2e-3, (k, rel, norm)
+        assert float((g.flatten()[:8] - head).abs().max()) < 2e-3 * max(float(head.abs().max()), scale), k
     print("worst relative grad-norm error (fp32):", worst)
     for k, v in model.state_dict().items():
         if 'running' in k:
@@ -128,14 +130,16 @@ def test_eval_and_greedy_decode_bit_exact(golden):
     ora.eval()
     with torch.no_grad():
         ev_o = ora(batch['image'], train=False)
-    assert float((ev_o - golden['eval_pred']).abs().max()) == 0.0  # oracle reproduces the reference exactly
+    # same torch CPU kernels as the reference; bit-exact in the build container, round-off level on other hosts
+    assert float((ev_o - golden['eval_pred']).abs().max()) < 5e-5
     model = BasicModel()
     model.load_state_dict(ora.state_dict())
     model.to(DEV).eval()
     with torch.no_grad():
         ev = model(batch['image'].to(DEV), train=False)
     assert ev.shape == golden['eval_pred'].shape
-    assert float((ev.cpu() - golden['eval_pred']).abs().max()) < 1e-4
+    assert float((ev.cpu() - ev_o).abs().max()) < 1e-4
+    assert float((ev.cpu() - golden['eval_pred']).abs().max()) < 1.5e-4
     dec = greedy_decode(ev.cpu().numpy())
     top2 = golden['eval_pred'].topk(2, dim=1).values
     print("min top-1/top-2 margin:", float((top2[:, 0] - top2[:, 1]).min()))
@@ -156,8 +160,10 @@ def test_bf16_training_close_to_oracle(golden):
     assert drift < 0.1
     for k, p in model.named_parameters():
         norm, _ = golden['grad_stats'][k]
-        rel = abs(float(p.grad.double().norm()) - norm) / max(norm, 1e-12)
-        assert rel < 0.25, (k, rel)
+        if norm < 1e-5:
+            continue  # conv bias feeding a BatchNorm: mathematically zero gradient, only round-off
+        rel = abs(float(p.grad.double().norm()) - norm) / norm
+        assert rel < 0.25, (k, rel, norm)
 
 
 def test_full_size_batch_runs_and_learns():

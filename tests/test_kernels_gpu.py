@@ -237,7 +237,7 @@ def test_ctc_matches_torch_and_oracle(dtype):
         targets[i, :L] = torch.randint(2, C, (L,), generator=g, dtype=torch.int32)
     targets[2, 1] = targets[2, 0]            # repeated label
     targets[4, :10] = 5                       # 10 repeats need T >= 19 > 12: infeasible -> zero_infinity path
-    xr = logits.float().requires_grad_(True)
+    xr = logits.float().clone().requires_grad_(True)
     lp = TF.log_softmax(xr, dim=2).double()
     loss_r = TF.ctc_loss(lp, targets, torch.full((N,), T, dtype=torch.int32), lengths, zero_infinity=True)
     loss_r.backward()
@@ -250,7 +250,7 @@ def test_ctc_matches_torch_and_oracle(dtype):
     gtol = 2e-6 if dtype == torch.float32 else 4e-3
     assert float((xd.grad.float().cpu() - xr.grad).abs().max()) < gtol
     o = ctc_1d(logits.float().numpy(), targets.numpy(), lengths.numpy())
-    assert abs(o['loss'] - float(loss)) < 1e-9 * max(1.0, abs(o['loss']))
+    assert abs(o['loss'] - float(loss)) < 1e-6 * max(1.0, abs(o['loss']))  # f32 log-softmax round-off
     assert float((torch.from_numpy(o['grad_logits']).float() - xd.grad.float().cpu()).abs().max()) < gtol
 
 
