@@ -32,9 +32,12 @@ def conv_flops(name, args, true_cin0=3):
     if name == "mr_conv2d_fwd":
         N, H, W, Cin, _ldx, Cout, _ldy, R, S = args[6:15]
         Ho, Wo = args[21], args[22]
-    else:  # dgrad / wgrad share the tail layout
+    elif name == "mr_conv2d_dgrad":
         N, H, W, Cin, _ld1, Cout, _ld2, R, S = args[4:13]
         Ho, Wo = args[19], args[20]
+    else:  # wgrad: (dtype, dy, x, dw, dbias, N, H, W, Cin, ldx, Cout, lddy, R, S, ...6..., Ho, Wo)
+        N, H, W, Cin, _ld1, Cout, _ld2, R, S = args[5:14]
+        Ho, Wo = args[20], args[21]
     if Cin == 8 and Cout == 64:
         Cin = true_cin0  # first layer: 3 input channels padded to one 16-byte vector
     return 2.0 * N * Ho * Wo * Cout * R * S * Cin, N * Ho * Wo, Cout, Cin

@@ -38,9 +38,10 @@ int mr_gemm_nt(int dtype, const void* A, long long lda, const void* B, int ldb, 
 /* tile (BM*1000+BN) the NT kernels pick for an M x N problem; host-only query used for profiling labels */
 int mr_nt_tile_code(int M, int N);
 /* C[NA,NB] (f32) += A[P,NA]^T * B[P,NB];  row_perm_h>0: gate-interleaved rows are written back in
- * PyTorch gate-major order (see lstm section) */
+ * PyTorch gate-major order (see lstm section).  colsum (nullable, f32[NA]) += sum_p A[p,:] (bias gradient,
+ * fused into the same pass over A). */
 int mr_gemm_tn(int dtype, const void* A, long long lda, const void* B, long long ldb, float* C, int ldc, int P,
-               int NA, int NB, int row_perm_h, hipStream_t stream);
+               int NA, int NB, int row_perm_h, float* colsum, hipStream_t stream);
 
 /* ---- Convolution (replaces cuDNN conv fwd/dgrad/wgrad behind nn.Conv2d: backbones/crnn.py:44-55,
  *      backbones/resnet.py:39-256, backbones/ppm.py:11-44, decoders/ctc_decoder2d.py:16-27) --------------- */
@@ -51,10 +52,10 @@ int mr_conv2d_fwd(int dtype, const void* x, const void* w_krsc, const float* bia
 int mr_conv2d_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, int Nimg, int H, int W, int Cin,
                     int lddx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
                     int Ho, int Wo, hipStream_t stream);
-/* dw_krsc (f32 [Cout][R][S][Cin]) is accumulated atomically: zero it first */
-int mr_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw_krsc, int Nimg, int H, int W, int Cin,
-                    int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
-                    int Ho, int Wo, hipStream_t stream);
+/* dw_krsc (f32 [Cout][R][S][Cin]) and dbias (nullable, f32[Cout]) are accumulated atomically: zero them first */
+int mr_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw_krsc, float* dbias, int Nimg, int H, int W,
+                    int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh,
+                    int dw, int Ho, int Wo, hipStream_t stream);
 
 /* ---- layout / elementwise helpers ---------------------------------------------------------------------- */
 int mr_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int Cpad,
@@ -92,8 +93,10 @@ int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const flo
               long long P, int C, hipStream_t stream);
 int mr_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int kh,
                    int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, hipStream_t stream);
-int mr_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C,
-                   int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, hipStream_t stream);
+/* relu_y (nullable): the pool's input when it is the output of a ReLU -- fuses that ReLU's backward mask */
+int mr_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, const void* relu_y, void* dx, int N, int H,
+                   int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo,
+                   hipStream_t stream);
 
 /* ---- bidirectional LSTM recurrence (replaces cuDNN RNN behind nn.LSTM: decoders/crnn.py:13,21,91-93) ----- */
 int mr_lstm_fwd(int dtype, const void* xproj, const void* whh, void* out, float* cbuf, void* gates, int T, int N,

@@ -22,10 +22,10 @@ _CODES = {"p": _P, "i": _I, "l": _L, "f": _F, "s": _P}
 # name -> argument codes (p pointer, i int, l long long, f float, s hipStream_t)
 SIGNATURES = {
     "mr_gemm_nt": "iplpiplpiiiis",
-    "mr_gemm_tn": "iplplpiiiiis",
+    "mr_gemm_tn": "iplplpiiiiips",
     "mr_conv2d_fwd": "ipppp" + "i" * 18 + "s",
     "mr_conv2d_dgrad": "ippp" + "i" * 17 + "s",
-    "mr_conv2d_wgrad": "ippp" + "i" * 17 + "s",
+    "mr_conv2d_wgrad": "ipppp" + "i" * 17 + "s",
     "mr_nchw_to_nhwc": "ippiiiiis",
     "mr_nhwc_to_nchw": "ippiiiiis",
     "mr_cast": "ipipls",
@@ -42,7 +42,7 @@ SIGNATURES = {
     "mr_bn_fwd_eval": "ippppppppp" + "ilifs",
     "mr_bn_bwd": "ipppppppppp" + "pilis",
     "mr_maxpool_fwd": "ippp" + "i" * 12 + "s",
-    "mr_maxpool_bwd": "ippp" + "i" * 12 + "s",
+    "mr_maxpool_bwd": "ipppp" + "i" * 12 + "s",
     "mr_lstm_fwd": "ipppppiiis",
     "mr_lstm_bwd": "ipppppiiis",
     "mr_ctc_fwd": "ipipippiiiiiiipppps",

@@ -21,22 +21,24 @@ class CRNN(nn.Module):
         self.strides = [1, 1, 1, 1, 1, 1, 1]
         self.channels = [64, 128, 256, 256, 512, 512, 512, nc]
 
-        conv0 = nn.Sequential(self._make_layer(0), MaxPool2d((2, 2)))
-        conv1 = nn.Sequential(self._make_layer(1), MaxPool2d((2, 2)))
+        # conv+ReLU stages feed a max-pool: the pool's backward also applies the ReLU mask (one pass saved)
+        conv0 = nn.Sequential(self._make_layer(0, pooled=True), MaxPool2d((2, 2), relu_input=True))
+        conv1 = nn.Sequential(self._make_layer(1, pooled=True), MaxPool2d((2, 2), relu_input=True))
         conv2 = self._make_layer(2, True)
-        conv3 = nn.Sequential(self._make_layer(3), MaxPool2d((2, 2), (2, 1), (0, 1)))
+        conv3 = nn.Sequential(self._make_layer(3, pooled=True), MaxPool2d((2, 2), (2, 1), (0, 1), relu_input=True))
         conv4 = self._make_layer(4, True)
-        conv5 = nn.Sequential(self._make_layer(5), MaxPool2d((2, 2), (2, 1), (0, 1)))
+        conv5 = nn.Sequential(self._make_layer(5, pooled=True), MaxPool2d((2, 2), (2, 1), (0, 1), relu_input=True))
         conv6 = self._make_layer(6, True)
 
         self.cnn = nn.Sequential(conv0, conv1, conv2, conv3, conv4, conv5, conv6)
 
-    def _make_layer(self, i, batch_normalization=False):
+    def _make_layer(self, i, batch_normalization=False, pooled=False):
         in_channel = self.channels[i - 1]
         out_channel = self.channels[i]
         layer = list()
         layer.append(Conv2d(in_channel, out_channel, self.kernels[i], self.strides[i], self.paddings[i],
-                            fuse_relu=not batch_normalization))
+                            fuse_relu=not batch_normalization,
+                            relu_grad_downstream=pooled and not batch_normalization))
         if batch_normalization:
             layer.append(BatchNorm2d(out_channel))
         else:

@@ -93,7 +93,7 @@ int mr_gemm_nt(int dtype, const void* A, long long lda, const void* B, int ldb, 
 }
 
 int mr_gemm_tn(int dtype, const void* A, long long lda, const void* B, long long ldb, float* C, int ldc, int P,
-               int NA, int NB, int row_perm_h, hipStream_t stream) {
+               int NA, int NB, int row_perm_h, float* colsum, hipStream_t stream) {
   MR_CHECK_ARG(dtype == MR_F32 || dtype == MR_BF16, "mr_gemm_tn: bad dtype %d", dtype);
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(P > 0 && NA > 0 && NB > 0, "mr_gemm_tn: bad shape P=%d NA=%d NB=%d", P, NA, NB);
@@ -103,7 +103,7 @@ int mr_gemm_tn(int dtype, const void* A, long long lda, const void* B, long long
   MR_CHECK_ARG(row_perm_h == 0 || NA % (4 * row_perm_h) == 0, "mr_gemm_tn: NA must be a multiple of 4*row_perm_h");
   TnArgs a;
   a.A = A; a.B = B; a.C = C; a.P = P; a.NA = NA; a.NB = NB; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-  a.p_chunk = 0; a.row_perm_h = row_perm_h;
+  a.p_chunk = 0; a.row_perm_h = row_perm_h; a.colsum = colsum;
   ConvGeom g = {};
   if (dtype == MR_F32) return launch_tn<float, 0>(a, g, stream);
   return launch_tn<bf16_t, 0>(a, g, stream);
@@ -132,6 +132,10 @@ int mr_conv2d_fwd(int dtype, const void* x, const void* w_krsc, const float* bia
   a.A = x; a.B = w_krsc; a.M = Nimg * Ho * Wo; a.N = Cout; a.K = R * S * Cin; a.lda = 0; a.ldb = R * S * Cin;
   ConvGeom g;
   fill_geom(g, 1, H, W, Cin, ldx, Ho, Wo, R, S, sh, sw, ph, pw, dh, dw);
+  if (R * S <= 32) {
+    if (dtype == MR_F32) return dispatch_nt_store<float, 2>(a, g, y, ldy, bias, relu, stream);
+    return dispatch_nt_store<bf16_t, 2>(a, g, y, ldy, bias, relu, stream);
+  }
   if (dtype == MR_F32) return dispatch_nt_store<float, 1>(a, g, y, ldy, bias, relu, stream);
   return dispatch_nt_store<bf16_t, 1>(a, g, y, ldy, bias, relu, stream);
 }
@@ -148,14 +152,18 @@ int mr_conv2d_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, int
   a.A = dy; a.B = w_crsk; a.M = Nimg * H * W; a.N = Cin; a.K = R * S * Cout; a.lda = 0; a.ldb = R * S * Cout;
   ConvGeom g;
   fill_geom(g, 2, Ho, Wo, Cout, lddy, H, W, R, S, sh, sw, ph, pw, dh, dw);
+  if (R * S <= 32 && sh == 1 && sw == 1) {
+    if (dtype == MR_F32) return dispatch_nt_store<float, 2>(a, g, dx, lddx, nullptr, 0, stream);
+    return dispatch_nt_store<bf16_t, 2>(a, g, dx, lddx, nullptr, 0, stream);
+  }
   if (dtype == MR_F32) return dispatch_nt_store<float, 1>(a, g, dx, lddx, nullptr, 0, stream);
   return dispatch_nt_store<bf16_t, 1>(a, g, dx, lddx, nullptr, 0, stream);
 }
 
 // dw[k,r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*sh-ph+r*dh, wo*sw-pw+s*dw, c]   (f32, atomically accumulated)
-int mr_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw_krsc, int Nimg, int H, int W, int Cin,
-                    int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
-                    int Ho, int Wo, hipStream_t stream) {
+int mr_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw_krsc, float* dbias, int Nimg, int H, int W,
+                    int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh,
+                    int dw, int Ho, int Wo, hipStream_t stream) {
   MR_CHECK_ARG(dtype == MR_F32 || dtype == MR_BF16, "mr_conv2d_wgrad: bad dtype %d", dtype);
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(Cin % vec == 0 && ldx % vec == 0 && Cout % vec == 0 && lddy % vec == 0,
@@ -163,7 +171,7 @@ int mr_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw_krsc, in
   MR_CHECK_ARG(aligned16(dy) && aligned16(x), "mr_conv2d_wgrad: dy and x must be 16-byte aligned");
   TnArgs a;
   a.A = dy; a.B = x; a.C = dw_krsc; a.P = Nimg * Ho * Wo; a.NA = Cout; a.NB = R * S * Cin; a.lda = lddy;
-  a.ldb = 0; a.ldc = R * S * Cin; a.p_chunk = 0; a.row_perm_h = 0;
+  a.ldb = 0; a.ldc = R * S * Cin; a.p_chunk = 0; a.row_perm_h = 0; a.colsum = dbias;
   ConvGeom g;
   fill_geom(g, 1, H, W, Cin, ldx, Ho, Wo, R, S, sh, sw, ph, pw, dh, dw);
   if (dtype == MR_F32) return launch_tn<float, 1>(a, g, stream);

@@ -73,8 +73,11 @@ struct NtArgs {
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *(const uint4*)p; }
 
 // ---------------------------------------------------------------------------------------------
-// NT kernel.  AMODE 0: dense A[M,K] (row stride lda).  AMODE 1: A is an NHWC tensor gathered
-// im2col-style according to ConvGeom (K = R*S*Cg, k = (r*S+s)*Cg + c).
+// NT kernel.  AMODE 0: dense A[M,K] (row stride lda).  AMODE 1/2: A is an NHWC tensor gathered
+// im2col-style according to ConvGeom (K = R*S*Cg, k = (r*S+s)*Cg + c).  AMODE 2 is the fast path
+// (R*S <= 32 and, for dgrad, unit stride): every row precomputes one base offset and a tap-validity bit
+// mask, and the (tap, channel) position advances incrementally -- no division or bounds arithmetic in
+// the k-loop.  AMODE 1 is the fully general gather (strided dgrad).
 // Epi: functor  void operator()(int m, int n, const f32x4& v)  -- v = C[m][n..n+3] in f32.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int AMODE, typename Epi>
@@ -100,11 +103,13 @@ __device__ __forceinline__ void igemm_nt_body(const NtArgs& a, const ConvGeom& g
 
   long long a_off[AI];
   int a_h[AI], a_w[AI];
+  unsigned a_mask[AI];
   bool a_ok[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int m = m0 + r0 + 32 * i;
     a_ok[i] = m < a.M;
+    a_mask[i] = 0;
     if (AMODE == 0) {
       a_off[i] = (long long)m * a.lda;
       a_h[i] = a_w[i] = 0;
@@ -116,6 +121,21 @@ __device__ __forceinline__ void igemm_nt_body(const NtArgs& a, const ConvGeom& g
       a_off[i] = (long long)ni * g.Hg * g.Wg * g.ldg;
       a_h[i] = hm;
       a_w[i] = wm;
+      if (AMODE == 2) {
+        // base = source pixel of tap (0,0); tap (r,s) adds +-(r*dh*Wg + s*dw)*ldg
+        const int bh = g.mode == 1 ? hm * g.sh - g.ph : hm + g.ph;
+        const int bw = g.mode == 1 ? wm * g.sw - g.pw : wm + g.pw;
+        a_off[i] += ((long long)bh * g.Wg + bw) * g.ldg;
+        if (a_ok[i]) {
+          unsigned msk = 0;
+          for (int r = 0; r < g.R; ++r)
+            for (int s2 = 0; s2 < g.S; ++s2) {
+              int hi, wi;
+              if (conv_src(g, hm, wm, r, s2, hi, wi)) msk |= 1u << (r * g.S + s2);
+            }
+          a_mask[i] = msk;
+        }
+      }
     }
   }
   long long b_off[BI];
@@ -128,6 +148,16 @@ __device__ __forceinline__ void igemm_nt_body(const NtArgs& a, const ConvGeom& g
   }
 
   uint4 ra[AI], rb[BI];
+  // incremental (tap, channel) position of this thread's k-chunk (AMODE 2); calls come with k0 += BK
+  int f_tap = 0, f_r = 0, f_s = 0, f_c = kc * VEC;
+  if (AMODE == 2) {
+    while (f_c >= g.Cg) {
+      f_c -= g.Cg;
+      ++f_tap;
+      if (++f_s == g.S) { f_s = 0; ++f_r; }
+    }
+  }
+  const int taps = g.R * g.S;
   auto load_tiles = [&](int k0) {
     const int k = k0 + kc * VEC;
     const bool kok = k < a.K;
@@ -138,19 +168,37 @@ __device__ __forceinline__ void igemm_nt_body(const NtArgs& a, const ConvGeom& g
       r = tap / g.S;
       s = tap - r * g.S;
     }
+    if (AMODE == 2) {
+      const int toff = (f_r * g.dh * g.Wg + f_s * g.dw) * g.ldg;
+      const long long koff = (long long)(g.mode == 1 ? toff : -toff) + f_c;
+      const bool tok = f_tap < taps;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (a_ok[i] && kok) {
-        if (AMODE == 0) {
-          v = ldg16(A + a_off[i] + k);
-        } else {
-          int hi, wi;
-          if (conv_src(g, a_h[i], a_w[i], r, s, hi, wi))
-            v = ldg16(A + a_off[i] + ((long long)hi * g.Wg + wi) * g.ldg + c);
-        }
+      for (int i = 0; i < AI; ++i) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (tok && ((a_mask[i] >> f_tap) & 1u)) v = ldg16(A + a_off[i] + koff);
+        ra[i] = v;
       }
-      ra[i] = v;
+      f_c += BK;
+      while (f_c >= g.Cg) {
+        f_c -= g.Cg;
+        ++f_tap;
+        if (++f_s == g.S) { f_s = 0; ++f_r; }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (a_ok[i] && kok) {
+          if (AMODE == 0) {
+            v = ldg16(A + a_off[i] + k);
+          } else {
+            int hi, wi;
+            if (conv_src(g, a_h[i], a_w[i], r, s, hi, wi))
+              v = ldg16(A + a_off[i] + ((long long)hi * g.Wg + wi) * g.ldg + c);
+          }
+        }
+        ra[i] = v;
+      }
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
@@ -204,6 +252,104 @@ __device__ __forceinline__ void igemm_nt_body(const NtArgs& a, const ConvGeom& g
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Latency-optimised NT body for small, K-deep GEMMs on a dependency chain (LSTM steps):
+// one 64 x 64 output tile per workgroup, the 4 waves split K four ways (each k-iteration stages a
+// 64 x 4*BK panel of A and B with 8 coalesced 16-byte loads per thread and operand), partial tiles are
+// summed through LDS and the epilogue runs on the reduced f32 values.  4x fewer dependent
+// load->MFMA round trips than igemm_nt_body for the same K.
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename Epi>
+__device__ __forceinline__ void igemm_nt_ksplit_body(const NtArgs& a, const Epi& epi) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int BK = 8 * VEC;
+  typedef typename Mma<T>::Frag Frag;
+  __shared__ uint4 smem[2 * 4 * 8 * 64];  // A panels [4 waves][8 chunks][64 rows], then B: 64 KiB
+  uint4* sA = smem;
+  uint4* sB = smem + 4 * 8 * 64;
+
+  const int tid = threadIdx.x;
+  const int tiles_n = (a.N + 63) / 64;
+  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int m0 = tile_m * 64, n0 = tile_n * 64;
+  const int q = tid & 31;        // 16-byte chunk inside the 4*BK panel
+  const int ws = q >> 3, kc = q & 7;
+  const int r0 = tid >> 5;       // rows r0 + 8*i
+  const T* __restrict__ A = (const T*)a.A;
+  const T* __restrict__ B = (const T*)a.B;
+
+  uint4 ra[8], rb[8];
+  auto load_panels = [&](int k0) {
+    const int k = k0 + q * VEC;
+    const bool kok = k < a.K;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + r0 + 8 * i, n = n0 + r0 + 8 * i;
+      ra[i] = (kok && m < a.M) ? ldg16(A + (long long)m * a.lda + k) : make_uint4(0, 0, 0, 0);
+      rb[i] = (kok && n < a.N) ? ldg16(B + (long long)n * a.ldb + k) : make_uint4(0, 0, 0, 0);
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_panels(0);
+  for (int k0 = 0; k0 < a.K; k0 += 4 * BK) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = r0 + 8 * i;
+      sA[ws * 512 + kc * 64 + (row ^ kc)] = ra[i];
+      sB[ws * 512 + kc * 64 + (row ^ kc)] = rb[i];
+    }
+    __syncthreads();
+    if (k0 + 4 * BK < a.K) load_panels(k0 + 4 * BK);
+    if (k0 + wave * BK < a.K) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kcr = ks * 4 + lg;
+        Frag fa[4], fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fa[j] = *(const Frag*)&sA[wave * 512 + kcr * 64 + ((j * 16 + l15) ^ kcr)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fb[i] = *(const Frag*)&sB[wave * 512 + kcr * 64 + ((i * 16 + l15) ^ kcr)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Mma<T>::run(acc[i][j], fb[i], fa[j]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // cross-wave reduction through LDS: red[w][m][n] f32 (4 x 16 KiB)
+  float* red = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = j * 16 + l15, n = i * 16 + lg * 4;
+      *(f32x4*)&red[wave * 4096 + m * 64 + n] = acc[i][j];
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gidx = tid + 256 * i;
+    const int m = gidx >> 4, n = (gidx & 15) * 4;
+    f32x4 v = *(const f32x4*)&red[m * 64 + n];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const f32x4 u = *(const f32x4*)&red[w * 4096 + m * 64 + n];
+      v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+    }
+    epi(m0 + m, n0 + n, v);
+  }
+}
+
 template <typename T, int BM, int BN, int AMODE, typename Epi>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(NtArgs a, ConvGeom g, Epi epi) {
   igemm_nt_body<T, BM, BN, AMODE, Epi>(a, g, epi);
@@ -255,11 +401,12 @@ struct TnArgs {
   int ldc;
   int p_chunk;  // rows of P per split (multiple of the p-step)
   int row_perm_h;
+  float* colsum;  // optional [NA]: += sum_p A[p, na] (bias gradient), accumulated by the tile_b == 0 blocks
 };
 
 template <typename T> struct TnCfg;
 template <> struct TnCfg<bf16_t> {
-  static constexpr int BP = 32;
+  static constexpr int BP = 64;
   static constexpr int ROW_VECS = 16;   // 16-byte vectors per 128-col row
   static constexpr int ROW_BYTES = 256;
 };
@@ -278,7 +425,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
   constexpr int ROW_VECS = TnCfg<T>::ROW_VECS;
   constexpr int ROW_BYTES = TnCfg<T>::ROW_BYTES;
   constexpr int ROWS_PER_PASS = 256 / ROW_VECS;  // 16 (bf16) / 8 (f32)
-  constexpr int NI = BP / ROWS_PER_PASS;         // 2
+  constexpr int NI = BP / ROWS_PER_PASS;         // 4 (bf16) / 2 (f32)
   constexpr bool IS_BF16 = (sizeof(T) == 2);
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BP * ROW_BYTES];
@@ -321,6 +468,22 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
   };
 
   uint4 ra[NI], rb[NI];
+  const bool do_colsum = a.colsum != nullptr && tile_b == 0;
+  float csum[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) csum[j] = 0.f;
+  // pixel coordinates of this thread's rows, advanced incrementally by BP per step (no division in the loop)
+  int q_n[NI], q_h[NI], q_w[NI];
+  if (BMODE == 1) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = p_begin + rr + ROWS_PER_PASS * i;
+      q_w[i] = p % g.Wm;
+      const int t = p / g.Wm;
+      q_h[i] = t % g.Hm;
+      q_n[i] = t / g.Hm;
+    }
+  }
   auto load_tiles = [&](int p0) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -332,18 +495,21 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
           if (BMODE == 0) {
             vb = ldg16(B + (long long)p * a.ldb + cb);
           } else {
-            const int wm = p % g.Wm;
-            const int t = p / g.Wm;
-            const int hm = t % g.Hm;
-            const int ni = t / g.Hm;
             int hi, wi;
-            if (conv_src(g, hm, wm, tr, ts, hi, wi))
-              vb = ldg16(B + ((long long)(ni * g.Hg + hi) * g.Wg + wi) * g.ldg + tc);
+            if (conv_src(g, q_h[i], q_w[i], tr, ts, hi, wi))
+              vb = ldg16(B + ((long long)(q_n[i] * g.Hg + hi) * g.Wg + wi) * g.ldg + tc);
           }
         }
       }
       ra[i] = va;
       rb[i] = vb;
+      if (BMODE == 1) {
+        q_w[i] += BP;
+        while (q_w[i] >= g.Wm) {
+          q_w[i] -= g.Wm;
+          if (++q_h[i] == g.Hm) { q_h[i] = 0; ++q_n[i]; }
+        }
+      }
     }
   };
 
@@ -364,6 +530,11 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
       const int pl = rr + ROWS_PER_PASS * i;
       *(uint4*)(sA + lds_off(pl)) = ra[i];
       *(uint4*)(sB + lds_off(pl)) = rb[i];
+      if (do_colsum) {
+        const T* pv = (const T*)&ra[i];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) csum[j] += to_f32(pv[j]);
+      }
     }
     __syncthreads();
     if (p0 + BP < p_end) load_tiles(p0 + BP);
@@ -372,6 +543,8 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
       // K fragment (8 consecutive p at one column) via two ds_read_b64_tr_b16 per operand tile.
       // Per 16-lane group: lane i supplies the address of row (i>>2), 8-byte piece (i&3) of a
       // [4 rows][16 cols] block; the instruction hands lane i column i of that block.
+#pragma unroll
+      for (int kk = 0; kk < BP / 32; ++kk) {
       bf16x8 fa[4], fb[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -380,7 +553,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
         s16x4 x[2], y[2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          const int p = lg * 8 + hh * 4 + (l15 >> 2);
+          const int p = kk * 32 + lg * 8 + hh * 4 + (l15 >> 2);
           const int h = tn_hash(p);
           const int oa = p * ROW_BYTES + ((cpa ^ h) << 5) + (l15 & 3) * 8;
           const int ob = p * ROW_BYTES + ((cpb ^ h) << 5) + (l15 & 3) * 8;
@@ -400,6 +573,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int ks = 0; ks < BP / 4; ++ks) {
@@ -418,6 +592,24 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
       }
     }
     __syncthreads();
+  }
+
+  if (do_colsum) {  // reduce the per-thread column sums over the row groups through LDS
+    float* red = (float*)smem;  // [ROWS_PER_PASS][128]
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[rr * 128 + cc * VEC + j] = csum[j];
+    __syncthreads();
+    if (tid < 128 && na0 + tid < a.NA) {
+      float sum = 0.f;
+      for (int r = 0; r < ROWS_PER_PASS; ++r) sum += red[r * 128 + tid];
+      int row = na0 + tid;
+      if (a.row_perm_h > 0) {
+        const int h4 = 4 * a.row_perm_h;
+        const int blk = row / h4, rin = row - blk * h4;
+        row = blk * h4 + (rin & 3) * a.row_perm_h + (rin >> 2);
+      }
+      atomicAdd(a.colsum + row, sum);
+    }
   }
 
   // D[i = a-row][j = b-col]: lane holds rows lg*4+reg, col l15.

@@ -79,10 +79,9 @@ template <typename T> struct EpiLstmBwd {
 
 template <typename T, typename Epi>
 __global__ __launch_bounds__(256) void lstm_step_kernel(NtArgs a0, NtArgs a1, Epi e0, Epi e1) {
-  ConvGeom g = {};
   const NtArgs a = blockIdx.y == 0 ? a0 : a1;
   const Epi e = blockIdx.y == 0 ? e0 : e1;
-  igemm_nt_body<T, 64, 64, 0, Epi>(a, g, e);
+  igemm_nt_ksplit_body<T, Epi>(a, e);
 }
 
 template <typename T>

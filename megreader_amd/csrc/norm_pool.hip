@@ -220,8 +220,8 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
 // gather form (no atomics): each input pixel sums dy of the windows whose argmax points at it
 template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
-                                   T* __restrict__ dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
-                                   int ph, int pw, int Ho, int Wo) {
+                                   const T* __restrict__ relu_y, T* __restrict__ dx, int N, int H, int W, int C,
+                                   int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo) {
   constexpr int VEC = VecOf<T>::N;
   const int cv = C / VEC;
   const long long total = (long long)N * H * W * cv;
@@ -255,6 +255,13 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char
         for (int j = 0; j < VEC; ++j)
           if (pi[j] == code) acc[j] += to_f32(pg[j]);
       }
+    }
+    if (relu_y) {  // fused ReLU backward of the layer that produced the pool input
+      const uint4 yv = ((const uint4*)relu_y)[t];
+      const T* py = (const T*)&yv;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        if (!(to_f32(py[j]) > 0.f)) acc[j] = 0.f;
     }
     uint4 out;
     T* po = (T*)&out;
@@ -298,7 +305,7 @@ int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(C % vec == 0, "mr_bn_fwd_train: C (%d) must be a multiple of %d", C, vec);
   MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_fwd_train: bad P");
-  hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream);
+  (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream);
   int rpb;
   const int splits = split_rows((int)P, C, rpb);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(cdiv(C, 64), splits), dim3(256), 0, stream,
@@ -333,7 +340,7 @@ int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const flo
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(C % vec == 0, "mr_bn_bwd: C (%d) must be a multiple of %d", C, vec);
   MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_bwd: bad P");
-  hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream);
+  (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream);
   int rpb;
   const int splits = split_rows((int)P, C, rpb);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(cdiv(C, 64), splits), dim3(256), 0, stream,
@@ -360,13 +367,15 @@ int mr_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* idx, int N,
   return MR_OK;
 }
 
-int mr_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C,
-                   int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, hipStream_t stream) {
+int mr_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, const void* relu_y, void* dx, int N, int H,
+                   int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo,
+                   hipStream_t stream) {
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(C % vec == 0, "mr_maxpool_bwd: C (%d) must be a multiple of %d", C, vec);
   const long long total = (long long)N * H * W * (C / vec);
   DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
-                                       (const T*)dy, idx, (T*)dx, N, H, W, C, kh, kw, sh, sw, ph, pw, Ho, Wo));
+                                       (const T*)dy, idx, (const T*)relu_y, (T*)dx, N, H, W, C, kh, kw, sh, sw, ph,
+                                       pw, Ho, Wo));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

@@ -59,7 +59,7 @@ def _conv_out(size, k, s, p, d):
 # --------------------------------------------------------------------------------------------------
 class Conv2dFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation, relu):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, relu, relu_grad_downstream=False):
         require_cuda(x, weight, bias)
         dtype = get_compute_dtype()
         dt = dtype_code(dtype)
@@ -82,9 +82,9 @@ class Conv2dFn(Function):
         y = torch.empty((N, Ho, Wo, K), dtype=dtype, device=x.device)
         call("mr_conv2d_fwd", dt, ptr(xi), ptr(w_krsc), ptr(bias), ptr(y), int(relu), N, H, W, Cp, Cp, K, K, R, S,
              sh, sw, ph, pw, dh, dw, Ho, Wo)
-        ctx.save_for_backward(xi, w_crsk, y if relu else None)
+        ctx.save_for_backward(xi, w_crsk, y if (relu and not relu_grad_downstream) else None)
         ctx.geom = (N, H, W, Cp, C, K, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo)
-        ctx.relu = relu
+        ctx.relu = relu and not relu_grad_downstream  # else the consumer (max-pool) applies the ReLU mask
         ctx.has_bias = bias is not None
         ctx.dtype = dtype
         return y.permute(0, 3, 1, 2)
@@ -106,21 +106,28 @@ class Conv2dFn(Function):
             call("mr_conv2d_dgrad", dt, ptr(g), ptr(w_crsk), ptr(dxi), N, H, W, C, C, K, K, R, S, sh, sw, ph, pw,
                  dh, dw, Ho, Wo)
             dx = dxi.permute(0, 3, 1, 2)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if want_db:
+            db = torch.zeros((K,), dtype=torch.float32, device=g.device)
         if ctx.needs_input_grad[1]:
             gw = torch.zeros((K, R, S, Cp), dtype=torch.float32, device=g.device)
-            call("mr_conv2d_wgrad", dt, ptr(g), ptr(xi), ptr(gw), N, H, W, Cp, Cp, K, K, R, S, sh, sw, ph, pw, dh,
-                 dw, Ho, Wo)
+            # the bias gradient (column sums of dy) rides along the wgrad pass over dy
+            call("mr_conv2d_wgrad", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, K, K,
+                 R, S, sh, sw, ph, pw, dh, dw, Ho, Wo)
             if Cp != C:
                 gw = gw[..., :C]
             dwt = gw.permute(0, 3, 1, 2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.zeros((K,), dtype=torch.float32, device=g.device)
+        elif want_db:
             call("mr_colsum", dt, ptr(g), ptr(db), N * Ho * Wo, K, K, 0)
-        return dx, dwt, db, None, None, None, None
+        return dx, dwt, db, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), relu=False):
-    return Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation), bool(relu))
+def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), relu=False,
+           relu_grad_downstream=False):
+    """relu_grad_downstream=True: the only consumer is a max_pool2d(..., relu_input=True), whose backward applies
+    this layer's ReLU mask (saves one pass over the largest activation gradients)."""
+    return Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation), bool(relu),
+                          bool(relu_grad_downstream))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -187,7 +194,7 @@ def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, ep
 # --------------------------------------------------------------------------------------------------
 class MaxPoolFn(Function):
     @staticmethod
-    def forward(ctx, x, kernel, stride, padding):
+    def forward(ctx, x, kernel, stride, padding, relu_input=False):
         require_cuda(x)
         dtype = get_compute_dtype()
         dt = dtype_code(dtype)
@@ -200,26 +207,27 @@ class MaxPoolFn(Function):
         y = torch.empty((N, Ho, Wo, C), dtype=dtype, device=x.device)
         idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
         call("mr_maxpool_fwd", dt, ptr(xi), ptr(y), ptr(idx), N, H, W, C, kh, kw, sh, sw, ph, pw, Ho, Wo)
-        ctx.save_for_backward(idx)
+        ctx.save_for_backward(idx, xi if relu_input else None)
         ctx.geom = (N, H, W, C, kh, kw, sh, sw, ph, pw, Ho, Wo)
         ctx.dtype = dtype
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, gy):
-        (idx,) = ctx.saved_tensors
+        idx, relu_y = ctx.saved_tensors
         N, H, W, C, kh, kw, sh, sw, ph, pw, Ho, Wo = ctx.geom
         dtype = ctx.dtype
         g = _grad_internal(gy, dtype)
         dx = torch.empty((N, H, W, C), dtype=dtype, device=g.device)
-        call("mr_maxpool_bwd", dtype_code(dtype), ptr(g), ptr(idx), ptr(dx), N, H, W, C, kh, kw, sh, sw, ph, pw, Ho,
-             Wo)
-        return dx.permute(0, 3, 1, 2), None, None, None
+        call("mr_maxpool_bwd", dtype_code(dtype), ptr(g), ptr(idx), ptr(relu_y), ptr(dx), N, H, W, C, kh, kw, sh, sw,
+             ph, pw, Ho, Wo)
+        return dx.permute(0, 3, 1, 2), None, None, None, None
 
 
-def max_pool2d(x, kernel, stride=None, padding=(0, 0)):
+def max_pool2d(x, kernel, stride=None, padding=(0, 0), relu_input=False):
+    """relu_input=True: x is the output of a ReLU whose backward mask is fused into this op's backward."""
     stride = kernel if stride is None else stride
-    return MaxPoolFn.apply(x, tuple(kernel), tuple(stride), tuple(padding))
+    return MaxPoolFn.apply(x, tuple(kernel), tuple(stride), tuple(padding), bool(relu_input))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -308,13 +316,15 @@ class LinearFn(Function):
             dx2 = torch.empty((M, K), dtype=dtype, device=gy.device)
             call("mr_gemm_nt", dt, ptr(gp), Np, ptr(w_t), Np, ptr(dx2), K, 0, 0, M, K, Np)
             dx = dx2.view(*ctx.lead, K)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        gb = torch.zeros((Np,), dtype=torch.float32, device=gy.device) if want_db else None
         if ctx.needs_input_grad[1]:
             gw = torch.zeros((Np, K), dtype=torch.float32, device=gy.device)
-            call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, Np, K, 0)
+            call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, Np, K, 0, ptr(gb))
             dw = gw[:Nout]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = torch.zeros((Np,), dtype=torch.float32, device=gy.device)
+        elif want_db:
             call("mr_colsum", dt, ptr(gp), ptr(gb), M, Np, Np, 0)
+        if want_db:
             db = gb[:Nout]
         return dx, dw, db
 
@@ -382,18 +392,18 @@ class BiLSTMFn(Function):
             dx = torch.empty((T, N, I), dtype=dtype, device=dev)
             call("mr_gemm_nt", dt, ptr(dgates), 8 * H, ptr(wcat_t), 8 * H, ptr(dx), I, 0, 0, T * N, I, 8 * H)
         gw_ih = torch.zeros((2, 4 * H, I), dtype=torch.float32, device=dev)
-        call("mr_gemm_tn", dt, ptr(dgates), 8 * H, ptr(x), I, ptr(gw_ih), I, T * N, 8 * H, I, H)
+        gb = torch.zeros((2, 4 * H), dtype=torch.float32, device=dev)
+        # bias gradient = column sums of dgates, fused into the same pass
+        call("mr_gemm_tn", dt, ptr(dgates), 8 * H, ptr(x), I, ptr(gw_ih), I, T * N, 8 * H, I, H, ptr(gb))
         gw_hh = torch.zeros((2, 4 * H, H), dtype=torch.float32, device=dev)
         if T > 1:
             P = (T - 1) * N
             # forward direction: dgates[t] (t>=1) with h[t-1]
             call("mr_gemm_tn", dt, ptr(dgates) + N * 8 * H * es, 8 * H, ptr(out), 2 * H, ptr(gw_hh), H, P, 4 * H,
-                 H, H)
+                 H, H, 0)
             # reverse direction: dgates[t] (t<=T-2) with h[t+1]
             call("mr_gemm_tn", dt, ptr(dgates) + 4 * H * es, 8 * H, ptr(out) + (N * 2 * H + H) * es, 2 * H,
-                 ptr(gw_hh) + 4 * H * H * 4, H, P, 4 * H, H, H)
-        gb = torch.zeros((2, 4 * H), dtype=torch.float32, device=dev)
-        call("mr_colsum", dt, ptr(dgates), ptr(gb), T * N, 8 * H, 8 * H, H)
+                 ptr(gw_hh) + 4 * H * H * 4, H, P, 4 * H, H, H, 0)
         return (dx, gw_ih[0], gw_hh[0], gb[0], gb[0].clone(), gw_ih[1], gw_hh[1], gb[1], gb[1].clone())
 
 

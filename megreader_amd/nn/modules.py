@@ -15,16 +15,19 @@ def _pair(v):
 class Conv2d(nn.Conv2d):
     """nn.Conv2d drop-in (groups=1, zero padding) -- implicit-GEMM MFMA kernel, optional fused ReLU."""
 
-    def __init__(self, *args, fuse_relu=False, **kwargs):
+    def __init__(self, *args, fuse_relu=False, relu_grad_downstream=False, **kwargs):
         super().__init__(*args, **kwargs)
         if self.groups != 1 or self.padding_mode != "zeros" or isinstance(self.padding, str):
             raise NotImplementedError("megreader_amd.nn.Conv2d supports groups=1 and explicit zero padding only")
         self.fuse_relu = fuse_relu
+        # True only when the sole consumer is MaxPool2d(relu_input=True), which then applies the ReLU mask
+        self.relu_grad_downstream = relu_grad_downstream and fuse_relu
         # physical KRSC layout: the wgrad kernel's output is then adopted as .grad without a re-layout
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
     def forward(self, x):
-        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.fuse_relu)
+        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.fuse_relu,
+                        self.relu_grad_downstream)
 
 
 class FusedReLU(nn.Module):
@@ -51,11 +54,15 @@ class BatchNorm2d(nn.BatchNorm2d):
 
 
 class MaxPool2d(nn.MaxPool2d):
+    def __init__(self, *args, relu_input=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.relu_input = relu_input  # input is a ReLU output whose backward mask this op applies
+
     def forward(self, x):
         if self.ceil_mode or _pair(self.dilation) != (1, 1) or self.return_indices:
             raise NotImplementedError("megreader_amd.nn.MaxPool2d: ceil_mode / dilation / return_indices unsupported")
         stride = self.kernel_size if self.stride is None else self.stride
-        return F.max_pool2d(x, _pair(self.kernel_size), _pair(stride), _pair(self.padding))
+        return F.max_pool2d(x, _pair(self.kernel_size), _pair(stride), _pair(self.padding), self.relu_input)
 
 
 class Linear(nn.Linear):

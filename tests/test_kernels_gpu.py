@@ -61,13 +61,17 @@ def test_gemm_tn(dtype, P, NA, NB, perm):
     B = torch.randn(P, NB, generator=g)
     Ad, Bd = A.to(DEV, dtype), B.to(DEV, dtype)
     C = torch.ones(NA, NB, device=DEV)  # accumulate semantics: starts at 1
-    call("mr_gemm_tn", dtype_code(dtype), ptr(Ad), NA, ptr(Bd), NB, ptr(C), NB, P, NA, NB, perm)
+    cs = torch.full((NA,), 2.0, device=DEV)
+    call("mr_gemm_tn", dtype_code(dtype), ptr(Ad), NA, ptr(Bd), NB, ptr(C), NB, P, NA, NB, perm, ptr(cs))
     ref = Ad.double().cpu().t() @ Bd.double().cpu()
+    csr = Ad.double().cpu().sum(dim=0)
     if perm:
         blocks = ref.view(NA // (4 * perm), perm, 4, NB)          # row r = 4*j + q  ->  q*perm + j
         ref = blocks.permute(0, 2, 1, 3).reshape(NA, NB)
+        csr = csr.view(NA // (4 * perm), perm, 4).permute(0, 2, 1).reshape(NA)
     ref = ref + 1.0
     assert _rel_err(C, ref) < (_tol(dtype, P) if dtype == torch.float32 else 3e-3)
+    assert _rel_err(cs, csr + 2.0) < 1e-4
 
 
 CONV_CASES = [
@@ -272,3 +276,30 @@ def test_ctc_full_size_properties():
 def test_cpu_tensor_fails_loudly():
     with pytest.raises(NotImplementedError):
         F.conv2d(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 3, 3))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_relu_pool_fused_backward(dtype):
+    """conv(+ReLU, mask deferred) -> max-pool(relu_input): the pool's backward applies the ReLU mask."""
+    mr.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(2, 16, 8, 10, generator=g).to(dtype)
+    w = (torch.randn(24, 16, 3, 3, generator=g) * 0.2)
+    b = torch.randn(24, generator=g)
+    xr = x.double().requires_grad_(True)
+    wr = w.to(dtype).double().requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    yr = TF.max_pool2d(torch.relu(TF.conv2d(xr, wr, br, 1, 1)), (2, 2), (2, 1), (0, 1))
+    gy = torch.randn(yr.shape, generator=g).to(dtype)
+    yr.backward(gy.double())
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True)
+    y = F.max_pool2d(F.conv2d(xd, wd, bd, (1, 1), (1, 1), (1, 1), relu=True, relu_grad_downstream=True),
+                     (2, 2), (2, 1), (0, 1), relu_input=True)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert _rel_err(y, yr) < tol
+    y.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
+    assert _rel_err(xd.grad, xr.grad) < tol
+    assert _rel_err(wd.grad, wr.grad) < tol
+    assert _rel_err(bd.grad, br.grad) < tol
