@@ -1,8 +1,8 @@
 /* megreader_hip.h -- C ABI of libmegreader_hip.so (MI355X / gfx950 kernels for MegReader's training hot path).
  *
  * Every entry point takes raw device pointers, plain sizes and a hipStream_t; no torch types cross this
- * boundary.  The library keeps no state and owns no memory: the caller allocates every output and scratch
- * buffer.  All functions return 0 on success and a non-zero MR_ERR_* code otherwise; mr_last_error() returns
+ * boundary.  The library owns no tensors: the caller allocates every output and scratch buffer (its only state
+ * is one 4 KiB zero page per device, the source of padded vectors for direct-to-LDS loads).  All functions return 0 on success and a non-zero MR_ERR_* code otherwise; mr_last_error() returns
  * a human-readable message for the calling thread.  Kernels are enqueued on `stream` and never synchronise.
  *
  * dtype codes: 0 = float32, 1 = bfloat16 (storage type of activations / operand images; accumulation is
@@ -29,12 +29,18 @@ extern "C" {
 
 const char* mr_last_error(void);
 int mr_abi_version(void);
+/* creates the per-device zero page (the library's only state) eagerly; call before hipGraph capture */
+int mr_init(void);
+/* 2 = direct-to-LDS NT kernel (default), 1 = register-staged NT kernel (A/B comparison); returns the old value */
+int mr_set_nt_variant(int v);
 
 /* ---- GEMM family (replaces cuBLAS/cuDNN behind nn.Linear / nn.LSTM input projection:
  *      decoders/crnn.py:13-24; decoders/attention_decoder.py:187-231) ------------------------------------- */
 /* C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]);  A,B,C of `dtype`, bias f32 (nullable), relu 0/1 */
 int mr_gemm_nt(int dtype, const void* A, long long lda, const void* B, int ldb, void* C, long long ldc,
                const float* bias, int relu, int M, int N, int K, hipStream_t stream);
+/* tuning override: force one NT tile shape (bm 128|96|64, bn 128|64); bm = 0 restores the cost model */
+int mr_force_nt_tile(int bm, int bn);
 /* tile (BM*1000+BN) the NT kernels pick for an M x N problem; host-only query used for profiling labels */
 int mr_nt_tile_code(int M, int N);
 /* C[NA,NB] (f32) += A[P,NA]^T * B[P,NB];  row_perm_h>0: gate-interleaved rows are written back in

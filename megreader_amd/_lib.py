@@ -74,6 +74,12 @@ def load():
     lib.mr_last_error.argtypes = []
     lib.mr_abi_version.restype = ctypes.c_int
     lib.mr_abi_version.argtypes = []
+    lib.mr_init.restype = ctypes.c_int
+    lib.mr_init.argtypes = []
+    lib.mr_set_nt_variant.restype = ctypes.c_int
+    lib.mr_set_nt_variant.argtypes = [ctypes.c_int]
+    lib.mr_force_nt_tile.restype = ctypes.c_int
+    lib.mr_force_nt_tile.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mr_nt_tile_code.restype = ctypes.c_int
     lib.mr_nt_tile_code.argtypes = [ctypes.c_int, ctypes.c_int]
     for name, codes in SIGNATURES.items():
@@ -81,10 +87,13 @@ def load():
         fn.restype = ctypes.c_int
         fn.argtypes = [_CODES[c] for c in codes]
     _lib = lib
+    if torch.cuda.is_available():
+        if lib.mr_init() != 0:
+            raise RuntimeError("mr_init failed: %s" % lib.mr_last_error().decode())
     return lib
 
 
-HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code")  # entry points that take no stream and launch nothing
+HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_set_nt_variant", "mr_force_nt_tile")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

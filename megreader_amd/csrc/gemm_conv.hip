@@ -5,7 +5,28 @@
 #include "igemm_core.h"
 #include "../../include/megreader_hip.h"
 
+#include <mutex>
+
 namespace mr {
+
+// One 4 KiB page of zeros per device: the source of padded vectors for the direct-to-LDS loads (the only state
+// this library keeps).  Created on first use (mr_init() creates it eagerly, e.g. before hipGraph capture).
+static const void* zero_page() {
+  static std::mutex mu;
+  static void* pages[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!pages[dev]) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 4096) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 4096) != hipSuccess) return nullptr;
+    pages[dev] = p;
+  }
+  return pages[dev];
+}
+
+static int g_nt_variant = 2;  // 2 = direct-to-LDS kernel (default), 1 = register-staged kernel (A/B debugging)
 
 template <typename T, int BM, int BN, int AMODE>
 static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long long ldc, const float* bias,
@@ -19,38 +40,90 @@ static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long lon
   epi.N = a.N;
   epi.vec_ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
   const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+  if constexpr (AMODE != 1) {
+    if (g_nt_variant == 2) {
+      NtArgs a2 = a;
+      a2.zero = zero_page();
+      if (!a2.zero) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
+      hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, AMODE, EpiStore<T>>), dim3(tiles), dim3(256), 0, stream,
+                         a2, g, epi);
+      MR_CHECK_LAUNCH();
+      return MR_OK;
+    }
+  }
   hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, AMODE, EpiStore<T>>), dim3(tiles), dim3(256), 0, stream, a, g,
                      epi);
   MR_CHECK_LAUNCH();
   return MR_OK;
 }
 
-// tile selection shared by every NT launch: 64-wide N tile for N <= 64, and 64-row tiles when
-// 128-row tiles cannot fill the 256 CUs twice over
-static void nt_tile(int M, int N, bool& m64, bool& n64) {
-  n64 = N <= 64;
-  const int blocks128 = cdiv(M, 128) * cdiv(N, n64 ? 64 : 128);
-  m64 = blocks128 < 512;
+// Tile selection shared by every NT launch.  Candidates BM in {128, 96, 64} x BN in {128, 64}; pick the one with
+// the smallest modelled time = rounds(tiles / resident slots) * tile work / tile efficiency.  The model exists
+// for wave quantisation: e.g. M = 33792 (264 row tiles of 128) x N = 512 gives 1056 tiles on 512 slots = 3 rounds
+// with the last one 6 % full, while BM = 96 gives 1408 tiles = 2.75 rounds.
+struct TileChoice { int bm, bn; };
+static int num_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+      cus = p.multiProcessorCount;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+static TileChoice g_forced_tile = {0, 0};  // mr_force_nt_tile: tuning / A-B override
+static TileChoice nt_tile(int M, int N) {
+  if (g_forced_tile.bm) return g_forced_tile;
+  static const int bms[3] = {128, 96, 64};
+  static const int bns[2] = {128, 64};
+  // relative MFMA efficiency of a tile shape, calibrated on MI355X with tools/microbench_conv.py --tile
+  auto eff = [](int bm, int bn) {
+    if (bn == 128) return bm == 128 ? 1.0 : bm == 96 ? 0.90 : 0.85;
+    return bm == 128 ? 0.60 : bm == 96 ? 0.60 : 0.55;
+  };
+  const int cus = num_cus();
+  TileChoice best = {128, 128};
+  double best_t = 1e300;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 2; ++j) {
+      const int bm = bms[i], bn = bns[j];
+      if (bn == 128 && N <= 64) continue;
+      const long long tiles = (long long)cdiv(M, bm) * cdiv(N, bn);
+      const int lds = 2 * (bm + bn) * 128;                  // two k-step buffers
+      int per_cu = (160 * 1024) / lds;
+      if (per_cu > 3) per_cu = 3;                           // VGPR budget: 3 workgroups of 256 threads
+      // greedy makespan: c co-resident workgroups share a CU, each therefore runs c times slower
+      long long c = (tiles + cus - 1) / cus;
+      if (c > per_cu) c = per_cu;
+      const long long rounds = (tiles + cus * c - 1) / (cus * c);
+      const double t = (double)rounds * c * bm * bn / eff(bm, bn);
+      if (t < best_t) { best_t = t; best.bm = bm; best.bn = bn; }
+    }
+  return best;
 }
 
 template <typename T, int AMODE>
 static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long long ldc, const float* bias,
                              int relu, hipStream_t stream) {
-  bool m64, n64;
-  nt_tile(a.M, a.N, m64, n64);
-  if (m64) {
-    if (n64) return launch_nt_store<T, 64, 64, AMODE>(a, g, C, ldc, bias, relu, stream);
-    return launch_nt_store<T, 64, 128, AMODE>(a, g, C, ldc, bias, relu, stream);
-  }
-  if (n64) return launch_nt_store<T, 128, 64, AMODE>(a, g, C, ldc, bias, relu, stream);
-  return launch_nt_store<T, 128, 128, AMODE>(a, g, C, ldc, bias, relu, stream);
+  const TileChoice t = nt_tile(a.M, a.N);
+#define MR_NT_CASE(BM_, BN_) \
+  if (t.bm == BM_ && t.bn == BN_) return launch_nt_store<T, BM_, BN_, AMODE>(a, g, C, ldc, bias, relu, stream);
+  MR_NT_CASE(128, 128) MR_NT_CASE(128, 64) MR_NT_CASE(96, 128) MR_NT_CASE(96, 64) MR_NT_CASE(64, 128)
+  MR_NT_CASE(64, 64)
+#undef MR_NT_CASE
+  set_error("no NT tile for %dx%d", t.bm, t.bn);
+  return MR_ERR_ARG;
 }
 
 template <typename T, int BMODE>
 static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
   constexpr int BP = TnCfg<T>::BP;
   const int tiles = cdiv(a.NA, 128) * cdiv(a.NB, 128);
-  int splits = 2048 / tiles;
+  // ~2 workgroups per CU: every extra split costs a full 128x128 tile of f32 atomics in the epilogue
+  int splits = 512 / tiles;
   if (splits < 1) splits = 1;
   const int max_splits = cdiv(a.P, BP * 4);  // at least 4 p-steps per block
   if (splits > max_splits) splits = max_splits;
@@ -70,11 +143,31 @@ using namespace mr;
 
 extern "C" {
 
+// Eagerly create per-device state (the zero page).  Call once per device before capturing a hipGraph.
+int mr_init(void) {
+  if (!zero_page()) { set_error("mr_init: zero page allocation failed"); return MR_ERR_LAUNCH; }
+  return MR_OK;
+}
+
+// 2 = direct-to-LDS NT kernel (default), 1 = register-staged NT kernel.  Returns the previous setting.
+int mr_set_nt_variant(int v) {
+  const int old = g_nt_variant;
+  if (v == 1 || v == 2) g_nt_variant = v;
+  return old;
+}
+
+// Force every NT launch to one tile shape (bm in {128,96,64}, bn in {128,64}); bm = 0 restores the cost model.
+int mr_force_nt_tile(int bm, int bn) {
+  if (bm == 0) { g_forced_tile.bm = g_forced_tile.bn = 0; return MR_OK; }
+  MR_CHECK_ARG((bm == 128 || bm == 96 || bm == 64) && (bn == 128 || bn == 64), "mr_force_nt_tile: bad tile %dx%d", bm, bn);
+  g_forced_tile.bm = bm; g_forced_tile.bn = bn;
+  return MR_OK;
+}
+
 // Which NT tile (BM*1000 + BN) a problem of M rows x N columns is dispatched to (profiling / bench labels).
 int mr_nt_tile_code(int M, int N) {
-  bool m64, n64;
-  nt_tile(M, N, m64, n64);
-  return (m64 ? 64 : 128) * 1000 + (n64 ? 64 : 128);
+  const TileChoice t = nt_tile(M, N);
+  return t.bm * 1000 + t.bn;
 }
 
 int mr_gemm_nt(int dtype, const void* A, long long lda, const void* B, int ldb, void* C, long long ldc,
@@ -86,7 +179,7 @@ int mr_gemm_nt(int dtype, const void* A, long long lda, const void* B, int ldb, 
                "mr_gemm_nt: K/lda/ldb must be multiples of %d (K=%d lda=%lld ldb=%d)", vec, K, lda, ldb);
   MR_CHECK_ARG(aligned16(A) && aligned16(B), "mr_gemm_nt: A and B must be 16-byte aligned");
   NtArgs a;
-  a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
+  a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.zero = nullptr;
   ConvGeom g = {};
   if (dtype == MR_F32) return dispatch_nt_store<float, 0>(a, g, C, ldc, bias, relu, stream);
   return dispatch_nt_store<bf16_t, 0>(a, g, C, ldc, bias, relu, stream);
@@ -129,7 +222,7 @@ int mr_conv2d_fwd(int dtype, const void* x, const void* w_krsc, const float* bia
   MR_CHECK_ARG(Ho == (H + 2 * ph - dh * (R - 1) - 1) / sh + 1 && Wo == (W + 2 * pw - dw * (S - 1) - 1) / sw + 1,
                "mr_conv2d_fwd: output size %dx%d inconsistent with geometry", Ho, Wo);
   NtArgs a;
-  a.A = x; a.B = w_krsc; a.M = Nimg * Ho * Wo; a.N = Cout; a.K = R * S * Cin; a.lda = 0; a.ldb = R * S * Cin;
+  a.A = x; a.B = w_krsc; a.M = Nimg * Ho * Wo; a.N = Cout; a.K = R * S * Cin; a.lda = 0; a.ldb = R * S * Cin; a.zero = nullptr;
   ConvGeom g;
   fill_geom(g, 1, H, W, Cin, ldx, Ho, Wo, R, S, sh, sw, ph, pw, dh, dw);
   if (R * S <= 32) {
@@ -149,7 +242,7 @@ int mr_conv2d_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, int
   MR_CHECK_ARG(Cout % vec == 0 && lddy % vec == 0, "mr_conv2d_dgrad: Cout/lddy must be multiples of %d", vec);
   MR_CHECK_ARG(aligned16(dy) && aligned16(w_crsk), "mr_conv2d_dgrad: dy and w must be 16-byte aligned");
   NtArgs a;
-  a.A = dy; a.B = w_crsk; a.M = Nimg * H * W; a.N = Cin; a.K = R * S * Cout; a.lda = 0; a.ldb = R * S * Cout;
+  a.A = dy; a.B = w_crsk; a.M = Nimg * H * W; a.N = Cin; a.K = R * S * Cout; a.lda = 0; a.ldb = R * S * Cout; a.zero = nullptr;
   ConvGeom g;
   fill_geom(g, 2, Ho, Wo, Cout, lddy, H, W, R, S, sh, sw, ph, pw, dh, dw);
   if (R * S <= 32 && sh == 1 && sw == 1) {

@@ -68,6 +68,7 @@ struct NtArgs {
   int M, N, K;
   long long lda;  // dense A row stride (elements); ignored in conv mode
   int ldb;        // B row stride (elements)
+  const void* zero;  // >= 16 bytes of zeros in global memory (source of padded / out-of-range vectors)
 };
 
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *(const uint4*)p; }
@@ -254,96 +255,103 @@ __device__ __forceinline__ void igemm_nt_body(const NtArgs& a, const ConvGeom& g
 
 // ---------------------------------------------------------------------------------------------
 // Latency-optimised NT body for small, K-deep GEMMs on a dependency chain (LSTM steps):
-// one 64 x 64 output tile per workgroup, the 4 waves split K four ways (each k-iteration stages a
-// 64 x 4*BK panel of A and B with 8 coalesced 16-byte loads per thread and operand), partial tiles are
+// one BM x 64 output tile per workgroup (BM = 16 keeps >= 128 workgroups busy on the fused epilogue),
+// the 4 waves split K four ways (each k-iteration stages BM x 4*BK of A and 64 x 4*BK of B), partial tiles are
 // summed through LDS and the epilogue runs on the reduced f32 values.  4x fewer dependent
 // load->MFMA round trips than igemm_nt_body for the same K.
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename Epi>
+template <typename T, int BM, typename Epi>
 __device__ __forceinline__ void igemm_nt_ksplit_body(const NtArgs& a, const Epi& epi) {
   constexpr int VEC = VecOf<T>::N;
   constexpr int BK = 8 * VEC;
+  constexpr int TM = BM / 16;       // MFMA tiles along the (batch) row dimension per wave
+  constexpr int AI = BM / 8;        // A-panel vectors per thread per k-iteration
   typedef typename Mma<T>::Frag Frag;
-  __shared__ uint4 smem[2 * 4 * 8 * 64];  // A panels [4 waves][8 chunks][64 rows], then B: 64 KiB
+  // A panels [4 waves][8 chunks][BM rows], B panels [4][8][64]; reused as the f32 reduction buffer
+  constexpr int A_VECS = 4 * 8 * BM, B_VECS = 4 * 8 * 64;
+  constexpr int RED_VECS = 4 * BM * 64 / 4;
+  __shared__ uint4 smem[(A_VECS + B_VECS) > RED_VECS ? (A_VECS + B_VECS) : RED_VECS];
   uint4* sA = smem;
-  uint4* sB = smem + 4 * 8 * 64;
+  uint4* sB = smem + A_VECS;
 
   const int tid = threadIdx.x;
   const int tiles_n = (a.N + 63) / 64;
   const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
-  const int m0 = tile_m * 64, n0 = tile_n * 64;
+  const int m0 = tile_m * BM, n0 = tile_n * 64;
   const int q = tid & 31;        // 16-byte chunk inside the 4*BK panel
   const int ws = q >> 3, kc = q & 7;
   const int r0 = tid >> 5;       // rows r0 + 8*i
   const T* __restrict__ A = (const T*)a.A;
   const T* __restrict__ B = (const T*)a.B;
 
-  uint4 ra[8], rb[8];
+  uint4 ra[AI], rb[8];
   auto load_panels = [&](int k0) {
     const int k = k0 + q * VEC;
     const bool kok = k < a.K;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + r0 + 8 * i, n = n0 + r0 + 8 * i;
+    for (int i = 0; i < AI; ++i) {
+      const int m = m0 + r0 + 8 * i;
       ra[i] = (kok && m < a.M) ? ldg16(A + (long long)m * a.lda + k) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = n0 + r0 + 8 * i;
       rb[i] = (kok && n < a.N) ? ldg16(B + (long long)n * a.ldb + k) : make_uint4(0, 0, 0, 0);
     }
   };
 
   const int wave = tid >> 6, lane = tid & 63;
   const int l15 = lane & 15, lg = lane >> 4;
-  f32x4 acc[4][4];
+  f32x4 acc[4][TM];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   load_panels(0);
   for (int k0 = 0; k0 < a.K; k0 += 4 * BK) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = r0 + 8 * i;
-      sA[ws * 512 + kc * 64 + (row ^ kc)] = ra[i];
-      sB[ws * 512 + kc * 64 + (row ^ kc)] = rb[i];
-    }
+    for (int i = 0; i < AI; ++i) sA[ws * 8 * BM + kc * BM + ((r0 + 8 * i) ^ kc)] = ra[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sB[ws * 512 + kc * 64 + ((r0 + 8 * i) ^ kc)] = rb[i];
     __syncthreads();
     if (k0 + 4 * BK < a.K) load_panels(k0 + 4 * BK);
     if (k0 + wave * BK < a.K) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int kcr = ks * 4 + lg;
-        Frag fa[4], fb[4];
+        Frag fa[TM], fb[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fa[j] = *(const Frag*)&sA[wave * 512 + kcr * 64 + ((j * 16 + l15) ^ kcr)];
+        for (int j = 0; j < TM; ++j) fa[j] = *(const Frag*)&sA[wave * 8 * BM + kcr * BM + ((j * 16 + l15) ^ kcr)];
 #pragma unroll
         for (int i = 0; i < 4; ++i) fb[i] = *(const Frag*)&sB[wave * 512 + kcr * 64 + ((i * 16 + l15) ^ kcr)];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) Mma<T>::run(acc[i][j], fb[i], fa[j]);
+          for (int j = 0; j < TM; ++j) Mma<T>::run(acc[i][j], fb[i], fa[j]);
       }
     }
     __syncthreads();
   }
 
-  // cross-wave reduction through LDS: red[w][m][n] f32 (4 x 16 KiB)
+  // cross-wave reduction through LDS: red[w][m][n] f32
   float* red = (float*)smem;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < TM; ++j) {
       const int m = j * 16 + l15, n = i * 16 + lg * 4;
-      *(f32x4*)&red[wave * 4096 + m * 64 + n] = acc[i][j];
+      *(f32x4*)&red[wave * BM * 64 + m * 64 + n] = acc[i][j];
     }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < TM; ++i) {
     const int gidx = tid + 256 * i;
     const int m = gidx >> 4, n = (gidx & 15) * 4;
     f32x4 v = *(const f32x4*)&red[m * 64 + n];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-      const f32x4 u = *(const f32x4*)&red[w * 4096 + m * 64 + n];
+      const f32x4 u = *(const f32x4*)&red[w * BM * 64 + m * 64 + n];
       v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
     }
     epi(m0 + m, n0 + n, v);
@@ -353,6 +361,187 @@ __device__ __forceinline__ void igemm_nt_ksplit_body(const NtArgs& a, const Epi&
 template <typename T, int BM, int BN, int AMODE, typename Epi>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(NtArgs a, ConvGeom g, Epi epi) {
   igemm_nt_body<T, BM, BN, AMODE, Epi>(a, g, epi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT kernel v2: direct-to-LDS staging (global_load_lds, 16 B per lane), two LDS buffers, ONE barrier
+// per k-step.  The loads for k-step t+1 are issued before the MFMAs of k-step t and land while they run;
+// no staging VGPRs and no ds_write pass.
+//
+// LDS image per operand tile: [ROWS][8 chunks x 16 B] (128-byte rows); physical chunk = kc ^ ((row>>1)&7).
+// A wave's LDS-DMA instruction writes 64 consecutive 16-byte slots = 8 full rows, so the image is
+// lane-linear as the hardware requires and the swizzle lives in the per-lane SOURCE address: lane l of
+// row group j fetches row 8j + (l>>3), logical chunk (l&7) ^ ((row>>1)&7) -- each row is still fetched
+// as one full 128-byte line.  ds_read_b128 of an MFMA fragment (16 rows, one logical chunk) then hits
+// 16 distinct 16-byte bank slots.  Padded taps / rows beyond M / k beyond K read a global zero page.
+// AMODE 0: dense A.  AMODE 2: conv gather with per-row tap masks (R*S <= 32; dgrad: unit stride).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
+// branch-free select between a real source address and the zero page
+__device__ __forceinline__ const void* sel_ptr(bool ok, const void* p, const void* z) {
+  const unsigned long long m = 0ull - (unsigned long long)ok;
+  return (const void*)(((unsigned long long)p & m) | ((unsigned long long)z & ~m));
+}
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)gptr, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int BM, int BN, int AMODE, typename Epi>
+__global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g, Epi epi) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int BK = 8 * VEC;
+  constexpr int AI = BM / 32, BI = BN / 32;  // 8-row groups per wave
+  constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
+  constexpr int TILE_VECS = (BM + BN) * 8;
+  typedef typename Mma<T>::Frag Frag;
+
+  __shared__ uint4 smem[2 * TILE_VECS];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int lrow = lane >> 3, lpc = lane & 7;
+
+  const T* __restrict__ A = (const T*)a.A;
+  const T* __restrict__ B = (const T*)a.B;
+  const T* __restrict__ Z = (const T*)a.zero;
+
+  // ---- per-thread row descriptors
+  long long a_off[AI];
+  unsigned a_mask[AI];
+  int a_kc[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int row = (wave * AI + i) * 8 + lrow;
+    const int m = m0 + row;
+    a_kc[i] = (lpc ^ ((row >> 1) & 7)) * VEC;
+    a_mask[i] = 0;
+    a_off[i] = 0;
+    if (AMODE == 0) {
+      a_off[i] = (long long)m * a.lda;
+      a_mask[i] = m < a.M ? 1u : 0u;
+    } else if (m < a.M) {
+      const int wm = m % g.Wm;
+      const int t = m / g.Wm;
+      const int hm = t % g.Hm;
+      const int ni = t / g.Hm;
+      const int bh = g.mode == 1 ? hm * g.sh - g.ph : hm + g.ph;
+      const int bw = g.mode == 1 ? wm * g.sw - g.pw : wm + g.pw;
+      a_off[i] = (long long)ni * g.Hg * g.Wg * g.ldg + ((long long)bh * g.Wg + bw) * g.ldg;
+      unsigned msk = 0;
+      for (int r = 0; r < g.R; ++r)
+        for (int s2 = 0; s2 < g.S; ++s2) {
+          int hi, wi;
+          if (conv_src(g, hm, wm, r, s2, hi, wi)) msk |= 1u << (r * g.S + s2);
+        }
+      a_mask[i] = msk;
+    }
+  }
+  long long b_off[BI];
+  int b_kc[BI];
+  bool b_ok[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int row = (wave * BI + i) * 8 + lrow;
+    const int n = n0 + row;
+    b_kc[i] = (lpc ^ ((row >> 1) & 7)) * VEC;
+    b_ok[i] = n < a.N;
+    b_off[i] = (long long)n * a.ldb;
+  }
+
+  const bool cg_uniform = (AMODE == 2) && (g.Cg % BK == 0);  // whole k-step inside one tap
+  const int taps = g.R * g.S;
+  const int sgn = g.mode == 1 ? 1 : -1;
+
+  auto stage = [&](int buf, int k0) {
+    uint4* sA = smem + buf * TILE_VECS;
+    uint4* sB = sA + BM * 8;
+    if (AMODE == 0) {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int k = k0 + a_kc[i];
+        glds16(sel_ptr(a_mask[i] && k < a.K, A + a_off[i] + k, Z), sA + (wave * AI + i) * 64);
+      }
+    } else if (cg_uniform) {
+      const int tap = k0 / g.Cg;
+      const int c0 = k0 - tap * g.Cg;
+      const int r = tap / g.S, s2 = tap - r * g.S;
+      const long long koff = (long long)sgn * ((r * g.dh * g.Wg + s2 * g.dw) * g.ldg) + c0;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        glds16(sel_ptr((a_mask[i] >> tap) & 1u, A + a_off[i] + koff + a_kc[i], Z), sA + (wave * AI + i) * 64);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int k = k0 + a_kc[i];
+        const int tap = k / g.Cg;
+        const int c = k - tap * g.Cg;
+        const int r = tap / g.S, s2 = tap - r * g.S;
+        const T* src = Z;
+        if (tap < taps && ((a_mask[i] >> tap) & 1u))
+          src = A + a_off[i] + (long long)sgn * ((r * g.dh * g.Wg + s2 * g.dw) * g.ldg) + c;
+        glds16(src, sA + (wave * AI + i) * 64);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int k = k0 + b_kc[i];
+      glds16(sel_ptr(b_ok[i] && k < a.K, B + b_off[i] + k, Z), sB + (wave * BI + i) * 64);
+    }
+  };
+
+  const int wm_ = wave & 1, wn_ = wave >> 1;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (a.K + BK - 1) / BK;
+  if (nk > 0) stage(0, 0);
+  for (int t = 0; t < nk; ++t) {
+    __syncthreads();  // k-step t has landed (the compiler drains vmcnt before the barrier); buffer (t+1)&1 is free
+    if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
+    const uint4* sA = smem + (t & 1) * TILE_VECS;
+    const uint4* sB = sA + BM * 8;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kc = ks * 4 + lg;
+      Frag fa[TM], fb[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int r = wm_ * WTM + j * 16 + l15;
+        fa[j] = *(const Frag*)&sA[r * 8 + (kc ^ ((r >> 1) & 7))];
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int r = wn_ * WTN + i * 16 + l15;
+        fb[i] = *(const Frag*)&sB[r * 8 + (kc ^ ((r >> 1) & 7))];
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) Mma<T>::run(acc[i][j], fb[i], fa[j]);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wm_ * WTM + j * 16 + l15;
+      const int n = n0 + wn_ * WTN + i * 16 + lg * 4;
+      epi(m, n, acc[i][j]);
+    }
 }
 
 // Plain epilogue: C = act(acc + bias) stored as T, row-major with leading dim ldc.

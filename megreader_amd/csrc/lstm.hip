@@ -77,11 +77,13 @@ template <typename T> struct EpiLstmBwd {
   }
 };
 
+constexpr int LSTM_BM = 16;  // batch rows per workgroup: small tiles => many workgroups share the gate epilogue
+
 template <typename T, typename Epi>
 __global__ __launch_bounds__(256) void lstm_step_kernel(NtArgs a0, NtArgs a1, Epi e0, Epi e1) {
   const NtArgs a = blockIdx.y == 0 ? a0 : a1;
   const Epi e = blockIdx.y == 0 ? e0 : e1;
-  igemm_nt_ksplit_body<T, Epi>(a, e);
+  igemm_nt_ksplit_body<T, LSTM_BM, Epi>(a, e);
 }
 
 template <typename T>
@@ -92,7 +94,7 @@ static int lstm_fwd_impl(const void* xproj_, const void* whh_, void* out_, float
   T* out = (T*)out_;
   T* gates = (T*)gates_;
   const long long s2 = (long long)N * 2 * H, s8 = (long long)N * 8 * H;
-  const int tiles = cdiv(N, 64) * cdiv(4 * H, 64);
+  const int tiles = cdiv(N, LSTM_BM) * cdiv(4 * H, 64);
   for (int s = 0; s < Tn; ++s) {
     NtArgs a[2];
     EpiLstmFwd<T> e[2];
@@ -101,7 +103,7 @@ static int lstm_fwd_impl(const void* xproj_, const void* whh_, void* out_, float
       const int tp = d == 0 ? t - 1 : t + 1;
       a[d].A = s == 0 ? (const void*)out : (const void*)(out + tp * s2 + d * H);
       a[d].B = whh + (long long)d * 4 * H * H;
-      a[d].M = N; a[d].N = 4 * H; a[d].K = s == 0 ? 0 : H; a[d].lda = 2 * H; a[d].ldb = H;
+      a[d].M = N; a[d].N = 4 * H; a[d].K = s == 0 ? 0 : H; a[d].lda = 2 * H; a[d].ldb = H; a[d].zero = nullptr;
       e[d].xproj = xproj + t * s8 + d * 4 * H;
       e[d].c_prev = s == 0 ? nullptr : cbuf + tp * s2 + d * H;
       e[d].c_out = cbuf + t * s2 + d * H;
@@ -123,7 +125,7 @@ static int lstm_bwd_impl(const void* dout_, const void* whhT_, const float* cbuf
   const T* whhT = (const T*)whhT_;
   T* gates = (T*)gates_;
   const long long s2 = (long long)N * 2 * H, s8 = (long long)N * 8 * H;
-  const int tiles = cdiv(N, 64) * cdiv(H, 64);
+  const int tiles = cdiv(N, LSTM_BM) * cdiv(H, 64);
   for (int s = 0; s < Tn; ++s) {
     NtArgs a[2];
     EpiLstmBwd<T> e[2];
@@ -135,7 +137,7 @@ static int lstm_bwd_impl(const void* dout_, const void* whhT_, const float* cbuf
       const bool has_prev = d == 0 ? t > 0 : t < Tn - 1;
       a[d].A = s == 0 ? (const void*)gates : (const void*)(gates + tn * s8 + d * 4 * H);
       a[d].B = whhT + (long long)d * 4 * H * H;
-      a[d].M = N; a[d].N = H; a[d].K = s == 0 ? 0 : 4 * H; a[d].lda = 8 * H; a[d].ldb = 4 * H;
+      a[d].M = N; a[d].N = H; a[d].K = s == 0 ? 0 : 4 * H; a[d].lda = 8 * H; a[d].ldb = 4 * H; a[d].zero = nullptr;
       e[d].dout = dout + t * s2 + d * H;
       e[d].gates = gates + t * s8 + d * 4 * H;
       e[d].dgates = gates + t * s8 + d * 4 * H;

@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Timing of the BiLSTM layer kernels at CRNN shapes (T=33, N=256): recurrence fwd/bwd and the big GEMMs."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import megreader_amd as mr  # noqa: E402
+from megreader_amd.nn import functional as F  # noqa: E402
+
+
+def timeit(f, iters=10):
+    for _ in range(2):
+        f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / iters
+
+
+def main():
+    dtype = torch.bfloat16
+    mr.set_compute_dtype(dtype)
+    T, N, H = 33, 256, 256
+    for I in (512, 256):
+        torch.manual_seed(0)
+        ref = torch.nn.LSTM(I, H, bidirectional=True)
+        params = [p.detach().cuda().requires_grad_(True) for p in ref.parameters()]
+        x = torch.randn(T, N, I, device="cuda").to(dtype).requires_grad_(True)
+        g = torch.randn(T, N, 2 * H, device="cuda").to(dtype)
+
+        def fwd():
+            with torch.no_grad():
+                F.bilstm(x, *params)
+
+        def fwdbwd():
+            y = F.bilstm(x, *params)
+            y.backward(g)
+
+        tf = timeit(fwd)
+        tfb = timeit(fwdbwd)
+        print("BiLSTM I=%d: fwd %.1f us, fwd+bwd %.1f us (bwd ~%.1f us)" % (I, tf, tfb, tfb - tf))
+
+
+if __name__ == "__main__":
+    main()
