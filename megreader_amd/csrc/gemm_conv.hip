@@ -45,8 +45,13 @@ static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long lon
       NtArgs a2 = a;
       a2.zero = zero_page();
       if (!a2.zero) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
-      hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, AMODE, EpiStore<T>>), dim3(tiles), dim3(256), 0, stream,
-                         a2, g, epi);
+      constexpr int BK = 8 * VecOf<T>::N;
+      if (AMODE == 2 && (g.Cg % BK) != 0)
+        hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, (AMODE == 2 ? 3 : AMODE), EpiStore<T>>), dim3(tiles),
+                           dim3(256), 0, stream, a2, g, epi);
+      else
+        hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, AMODE, EpiStore<T>>), dim3(tiles), dim3(256), 0, stream,
+                           a2, g, epi);
       MR_CHECK_LAUNCH();
       return MR_OK;
     }
@@ -122,14 +127,29 @@ template <typename T, int BMODE>
 static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
   constexpr int BP = TnCfg<T>::BP;
   const int tiles = cdiv(a.NA, 128) * cdiv(a.NB, 128);
-  // ~2 workgroups per CU: every extra split costs a full 128x128 tile of f32 atomics in the epilogue
-  int splits = 512 / tiles;
-  if (splits < 1) splits = 1;
-  const int max_splits = cdiv(a.P, BP * 4);  // at least 4 p-steps per block
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
+  // split count: workgroups run 2 per CU and are latency-bound, so time ~ rounds(blocks / 2*CUs) * (p-steps per
+  // split + epilogue); the epilogue is a full 128x128 tile of f32 atomics (~8 p-steps of time)
+  const int cus = num_cus();
+  const int total_steps = cdiv(a.P, BP);
+  int splits = 1;
+  double best = 1e300;
+  for (int s = 1; s <= 1024 && 2 * s <= total_steps + 1; ++s) {
+    const long long blocks = (long long)tiles * s;
+    const long long rounds = (blocks + 2 * cus - 1) / (2 * cus);
+    const double cost = (double)rounds * (cdiv(total_steps, s) + 8.0);
+    if (cost < best) { best = cost; splits = s; }
+  }
   a.p_chunk = cdiv(cdiv(a.P, splits), BP) * BP;
   splits = cdiv(a.P, a.p_chunk);
+  if constexpr (sizeof(T) == 2) {
+    if (g_nt_variant == 2) {
+      const void* z = zero_page();
+      if (!z) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
+      hipLaunchKernelGGL((igemm_tn_glds_kernel<BMODE>), dim3(tiles, 1, splits), dim3(256), 0, stream, a, g, z);
+      MR_CHECK_LAUNCH();
+      return MR_OK;
+    }
+  }
   hipLaunchKernelGGL((igemm_tn_kernel<T, BMODE>), dim3(tiles, 1, splits), dim3(256), 0, stream, a, g);
   MR_CHECK_LAUNCH();
   return MR_OK;

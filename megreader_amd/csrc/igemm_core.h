@@ -389,6 +389,8 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)gptr, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 
+// AMODE 0: dense A.  AMODE 2: conv, Cg % BK == 0 (every k-step lies inside one tap: the tap state is scalar and
+// advances incrementally).  AMODE 3: conv with small / odd Cg (first layer): per-vector tap arithmetic.
 template <typename T, int BM, int BN, int AMODE, typename Epi>
 __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g, Epi epi) {
   constexpr int VEC = VecOf<T>::N;
@@ -410,10 +412,10 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
 
   const T* __restrict__ A = (const T*)a.A;
   const T* __restrict__ B = (const T*)a.B;
-  const T* __restrict__ Z = (const T*)a.zero;
+  const void* Z = a.zero;
 
-  // ---- per-thread row descriptors
-  long long a_off[AI];
+  // ---- per-thread row descriptors: source pointer of (row, logical chunk) at k = 0 / tap (0,0)
+  const T* a_ptr[AI];
   unsigned a_mask[AI];
   int a_kc[AI];
 #pragma unroll
@@ -422,9 +424,9 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
     const int m = m0 + row;
     a_kc[i] = (lpc ^ ((row >> 1) & 7)) * VEC;
     a_mask[i] = 0;
-    a_off[i] = 0;
+    a_ptr[i] = A;
     if (AMODE == 0) {
-      a_off[i] = (long long)m * a.lda;
+      a_ptr[i] = A + (long long)m * a.lda + a_kc[i];
       a_mask[i] = m < a.M ? 1u : 0u;
     } else if (m < a.M) {
       const int wm = m % g.Wm;
@@ -433,7 +435,8 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
       const int ni = t / g.Hm;
       const int bh = g.mode == 1 ? hm * g.sh - g.ph : hm + g.ph;
       const int bw = g.mode == 1 ? wm * g.sw - g.pw : wm + g.pw;
-      a_off[i] = (long long)ni * g.Hg * g.Wg * g.ldg + ((long long)bh * g.Wg + bw) * g.ldg;
+      a_ptr[i] = A + (long long)ni * g.Hg * g.Wg * g.ldg + ((long long)bh * g.Wg + bw) * g.ldg +
+                 (AMODE == 2 ? a_kc[i] : 0);
       unsigned msk = 0;
       for (int r = 0; r < g.R; ++r)
         for (int s2 = 0; s2 < g.S; ++s2) {
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
       a_mask[i] = msk;
     }
   }
-  long long b_off[BI];
+  const T* b_ptr[BI];
   int b_kc[BI];
   bool b_ok[BI];
 #pragma unroll
@@ -452,30 +455,33 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
     const int n = n0 + row;
     b_kc[i] = (lpc ^ ((row >> 1) & 7)) * VEC;
     b_ok[i] = n < a.N;
-    b_off[i] = (long long)n * a.ldb;
+    b_ptr[i] = B + (long long)n * a.ldb + b_kc[i];
   }
 
-  const bool cg_uniform = (AMODE == 2) && (g.Cg % BK == 0);  // whole k-step inside one tap
   const int taps = g.R * g.S;
   const int sgn = g.mode == 1 ? 1 : -1;
+  const bool k_exact = (a.K % BK) == 0;  // no partial last k-step: skip the k < K predicate
+  // scalar tap state of the NEXT k-step to stage (AMODE 2)
+  int s_tap = 0, s_r = 0, s_s = 0, s_c0 = 0;
 
-  auto stage = [&](int buf, int k0) {
-    uint4* sA = smem + buf * TILE_VECS;
+  auto stage = [&](uint4* sA, int k0) {
     uint4* sB = sA + BM * 8;
     if (AMODE == 0) {
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
-        const int k = k0 + a_kc[i];
-        glds16(sel_ptr(a_mask[i] && k < a.K, A + a_off[i] + k, Z), sA + (wave * AI + i) * 64);
+        const bool ok = a_mask[i] && (k_exact || k0 + a_kc[i] < a.K);
+        glds16(sel_ptr(ok, a_ptr[i] + k0, Z), sA + (wave * AI + i) * 64);
       }
-    } else if (cg_uniform) {
-      const int tap = k0 / g.Cg;
-      const int c0 = k0 - tap * g.Cg;
-      const int r = tap / g.S, s2 = tap - r * g.S;
-      const long long koff = (long long)sgn * ((r * g.dh * g.Wg + s2 * g.dw) * g.ldg) + c0;
+    } else if (AMODE == 2) {
+      const long long koff = (long long)(sgn * ((s_r * g.dh * g.Wg + s_s * g.dw) * g.ldg)) + s_c0;
+      const unsigned bit = 1u << s_tap;
 #pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        glds16(sel_ptr((a_mask[i] >> tap) & 1u, A + a_off[i] + koff + a_kc[i], Z), sA + (wave * AI + i) * 64);
+      for (int i = 0; i < AI; ++i) glds16(sel_ptr(a_mask[i] & bit, a_ptr[i] + koff, Z), sA + (wave * AI + i) * 64);
+      s_c0 += BK;
+      if (s_c0 >= g.Cg) {
+        s_c0 = 0;
+        ++s_tap;
+        if (++s_s == g.S) { s_s = 0; ++s_r; }
       }
     } else {
 #pragma unroll
@@ -484,21 +490,36 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
         const int tap = k / g.Cg;
         const int c = k - tap * g.Cg;
         const int r = tap / g.S, s2 = tap - r * g.S;
-        const T* src = Z;
-        if (tap < taps && ((a_mask[i] >> tap) & 1u))
-          src = A + a_off[i] + (long long)sgn * ((r * g.dh * g.Wg + s2 * g.dw) * g.ldg) + c;
-        glds16(src, sA + (wave * AI + i) * 64);
+        const bool ok = tap < taps && ((a_mask[i] >> tap) & 1u);
+        glds16(sel_ptr(ok, a_ptr[i] + (long long)(sgn * ((r * g.dh * g.Wg + s2 * g.dw) * g.ldg)) + c, Z),
+               sA + (wave * AI + i) * 64);
       }
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int k = k0 + b_kc[i];
-      glds16(sel_ptr(b_ok[i] && k < a.K, B + b_off[i] + k, Z), sB + (wave * BI + i) * 64);
+      const bool ok = b_ok[i] && (k_exact || k0 + b_kc[i] < a.K);
+      glds16(sel_ptr(ok, b_ptr[i] + k0, Z), sB + (wave * BI + i) * 64);
     }
   };
 
   const int wm_ = wave & 1, wn_ = wave >> 1;
   const int l15 = lane & 15, lg = lane >> 4;
+  // fragment read addresses (vector index inside one stage): row*8 + (kc ^ ((row>>1)&7)), kc = ks*4 + lg.
+  // (row>>1)&7 == l15>>1 for every tile row of this lane, so kc^x = (lg^x) ^ (ks*4): two bases per row.
+  const int xsw = (l15 >> 1) & 7;
+  int fa_off[TM][2], fb_off[TN][2];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int r = wm_ * WTM + j * 16 + l15;
+    fa_off[j][0] = r * 8 + (lg ^ xsw);
+    fa_off[j][1] = r * 8 + ((lg ^ xsw) ^ 4);
+  }
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int r = wn_ * WTN + i * 16 + l15;
+    fb_off[i][0] = BM * 8 + r * 8 + (lg ^ xsw);
+    fb_off[i][1] = BM * 8 + r * 8 + ((lg ^ xsw) ^ 4);
+  }
 
   f32x4 acc[TN][TM];
 #pragma unroll
@@ -506,32 +527,38 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (a.K + BK - 1) / BK;
-  if (nk > 0) stage(0, 0);
-  for (int t = 0; t < nk; ++t) {
-    __syncthreads();  // k-step t has landed (the compiler drains vmcnt before the barrier); buffer (t+1)&1 is free
-    if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
-    const uint4* sA = smem + (t & 1) * TILE_VECS;
-    const uint4* sB = sA + BM * 8;
+  auto compute = [&](const uint4* st) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int kc = ks * 4 + lg;
       Frag fa[TM], fb[TN];
 #pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int r = wm_ * WTM + j * 16 + l15;
-        fa[j] = *(const Frag*)&sA[r * 8 + (kc ^ ((r >> 1) & 7))];
-      }
+      for (int j = 0; j < TM; ++j) fa[j] = *(const Frag*)&st[fa_off[j][ks]];
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const int r = wn_ * WTN + i * 16 + l15;
-        fb[i] = *(const Frag*)&sB[r * 8 + (kc ^ ((r >> 1) & 7))];
-      }
+      for (int i = 0; i < TN; ++i) fb[i] = *(const Frag*)&st[fb_off[i][ks]];
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) Mma<T>::run(acc[i][j], fb[i], fa[j]);
     }
+  };
+
+  const int nk = (a.K + BK - 1) / BK;
+  uint4* st0 = smem;
+  uint4* st1 = smem + TILE_VECS;
+  if (nk > 0) stage(st0, 0);
+  // two k-steps per iteration so that the stage base is a compile-time constant in every LDS access
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    __syncthreads();  // k-step t landed (vmcnt drained before the barrier); stage 1 is free
+    stage(st1, (t + 1) * BK);
+    compute(st0);
+    __syncthreads();
+    if (t + 2 < nk) stage(st0, (t + 2) * BK);
+    compute(st1);
+  }
+  if (t < nk) {
+    __syncthreads();
+    compute(st0);
   }
 
 #pragma unroll
@@ -802,6 +829,217 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
   }
 
   // D[i = a-row][j = b-col]: lane holds rows lg*4+reg, col l15.
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = nb0 + wb * 64 + j * 16 + l15;
+      if (col >= a.NB) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int row = na0 + wa * 64 + i * 16 + lg * 4 + q;
+        if (row >= a.NA) continue;
+        if (a.row_perm_h > 0) {
+          const int h4 = 4 * a.row_perm_h;
+          const int blk = row / h4, rin = row - blk * h4;
+          row = blk * h4 + (rin & 3) * a.row_perm_h + (rin >> 2);
+        }
+        atomicAdd(a.C + (long long)row * a.ldc + col, acc[i][j][q]);
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN kernel v2 (bf16): direct-to-LDS staging of both operands, two LDS stages, one barrier per p-step.
+// Same LDS image as igemm_tn_kernel ([64 rows(p)][128 cols], 32-byte pieces XOR-swizzled by tn_hash(row)), so
+// the ds_read_b64_tr_b16 fragment reads are unchanged; because LDS-DMA writes lane-linearly (one wave
+// instruction = 4 full 256-byte rows), the swizzle is applied to the SOURCE column of each lane.
+// ---------------------------------------------------------------------------------------------
+template <int BMODE>
+__global__ __launch_bounds__(256) void igemm_tn_glds_kernel(TnArgs a, ConvGeom g, const void* zero) {
+  typedef bf16_t T;
+  constexpr int BP = 64, ROW_BYTES = 256, TILE_BYTES = BP * ROW_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // [stage][A|B]
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int tiles_b = (a.NB + 127) / 128;
+  const int tile_b = blockIdx.x % tiles_b, tile_a = blockIdx.x / tiles_b;
+  const int na0 = tile_a * 128, nb0 = tile_b * 128;
+  const int p_begin = blockIdx.z * a.p_chunk;
+  const int p_end = min(a.P, p_begin + a.p_chunk);
+  if (p_begin >= p_end) return;
+
+  const T* __restrict__ A = (const T*)a.A;
+  const T* __restrict__ B = (const T*)a.B;
+  const int lrow = lane >> 4, pc16 = lane & 15, pp = pc16 >> 1, half = pc16 & 1;
+
+  // This lane stages rows (wave*4+jj)*4 + lrow, jj = 0..3, physical 16-byte chunk pc16.  tn_hash(row) only
+  // depends on lrow and bit 1 of (wave*4+jj) = bit 1 of jj, so the lane has two logical columns (h2 = jj>>1).
+  int colA[2], colB[2], tr[2], ts[2], tc[2], dho[2], dwo[2];
+  bool okA[2], okB[2];
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int cp = pp ^ tn_hash((wave * 4 + 2 * h2) * 4 + lrow);
+    const int col = (cp * 2 + half) * 8;
+    colA[h2] = na0 + col;
+    colB[h2] = nb0 + col;
+    okA[h2] = colA[h2] < a.NA;
+    okB[h2] = colB[h2] < a.NB;
+    tr[h2] = ts[h2] = 0;
+    tc[h2] = colB[h2];
+    dho[h2] = dwo[h2] = 0;
+    if (BMODE == 1) {
+      const int tap = colB[h2] / g.Cg;
+      tc[h2] = colB[h2] - tap * g.Cg;
+      tr[h2] = tap / g.S;
+      ts[h2] = tap - tr[h2] * g.S;
+      dho[h2] = tr[h2] * g.dh - g.ph;  // forward gather (mode 1): hi = q_h*sh + dho, wi = q_w*sw + dwo
+      dwo[h2] = ts[h2] * g.dw - g.pw;
+    }
+  }
+  int q_n[4], q_h[4], q_w[4];
+  if (BMODE == 1) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int p = p_begin + (wave * 4 + jj) * 4 + lrow;
+      q_w[jj] = p % g.Wm;
+      const int t = p / g.Wm;
+      q_h[jj] = t % g.Hm;
+      q_n[jj] = t / g.Hm;
+    }
+  }
+
+  auto stage = [&](unsigned char* sA, int p0) {
+    unsigned char* sB = sA + TILE_BYTES;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int h2 = jj >> 1;
+      const int p = p0 + (wave * 4 + jj) * 4 + lrow;
+      const bool pv = p < p_end;
+      glds16(sel_ptr(pv && okA[h2], A + (long long)p * a.lda + colA[h2], zero), sA + (wave * 4 + jj) * 1024);
+      if (BMODE == 0) {
+        glds16(sel_ptr(pv && okB[h2], B + (long long)p * a.ldb + colB[h2], zero), sB + (wave * 4 + jj) * 1024);
+      } else {
+        const int hi = q_h[jj] * g.sh + dho[h2], wi = q_w[jj] * g.sw + dwo[h2];
+        const bool v = pv && okB[h2] && (unsigned)hi < (unsigned)g.Hg && (unsigned)wi < (unsigned)g.Wg;
+        const long long off = ((long long)(q_n[jj] * g.Hg + hi) * g.Wg + wi) * g.ldg + tc[h2];
+        glds16(sel_ptr(v, B + off, zero), sB + (wave * 4 + jj) * 1024);
+        q_w[jj] += BP;
+        while (q_w[jj] >= g.Wm) {
+          q_w[jj] -= g.Wm;
+          if (++q_h[jj] == g.Hm) { q_h[jj] = 0; ++q_n[jj]; }
+        }
+      }
+    }
+  };
+
+  const int wa = wave & 1, wb = wave >> 1;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const bool do_colsum = a.colsum != nullptr && tile_b == 0;
+  float csum[2][8];
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) csum[h2][j] = 0.f;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // transpose-read addresses: row p = kk*32 + lg*8 + hh*4 + (l15>>2); tn_hash(p) = (l15>>2) | ((lg&1)<<2) is a lane
+  // constant, so each operand tile t needs ONE base offset; kk / hh only add compile-time constants.
+  const int hsh = (l15 >> 2) | ((lg & 1) << 2);
+  const int rbase = (lg * 8 + (l15 >> 2)) * ROW_BYTES + (l15 & 3) * 8;
+  int offA[4], offB[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    offA[t] = rbase + (((wa * 4 + t) ^ hsh) << 5);
+    offB[t] = TILE_BYTES + rbase + (((wb * 4 + t) ^ hsh) << 5);
+  }
+
+  auto compute = [&](const unsigned char* st) {
+    if (do_colsum) {  // bias gradient: column sums of the A tile, re-read from LDS by the lane that staged it
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const uint4 v = *(const uint4*)(st + (wave * 4 + jj) * 1024 + lane * 16);
+        const T* pv = (const T*)&v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) csum[jj >> 1][j] += to_f32(pv[j]);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s16x4 x[2], y[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          x[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(st + offA[t] + kk * 32 * ROW_BYTES + hh * 4 * ROW_BYTES));
+          y[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(st + offB[t] + kk * 32 * ROW_BYTES + hh * 4 * ROW_BYTES));
+        }
+        union { s16x4 h[2]; bf16x8 v; } ua, ub;
+        ua.h[0] = x[0]; ua.h[1] = x[1];
+        ub.h[0] = y[0]; ub.h[1] = y[1];
+        fa[t] = ua.v;
+        fb[t] = ub.v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nsteps = (p_end - p_begin + BP - 1) / BP;
+  unsigned char* st0 = smem;
+  unsigned char* st1 = smem + 2 * TILE_BYTES;
+  stage(st0, p_begin);
+  int st = 0;
+  for (; st + 1 < nsteps; st += 2) {
+    __syncthreads();
+    stage(st1, p_begin + (st + 1) * BP);
+    compute(st0);
+    __syncthreads();
+    if (st + 2 < nsteps) stage(st0, p_begin + (st + 2) * BP);
+    compute(st1);
+  }
+  if (st < nsteps) {
+    __syncthreads();
+    compute(st0);
+  }
+
+  if (do_colsum) {  // block-level reduction of the per-lane partial column sums with LDS float atomics
+    __syncthreads();
+    float* red = (float*)smem;
+    if (tid < 128) red[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int col = colA[h2] - na0;  // logical column group staged for rows with (jj>>1) == h2
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&red[col + j], csum[h2][j]);
+    }
+    __syncthreads();
+    if (tid < 128 && na0 + tid < a.NA) {
+      int row = na0 + tid;
+      if (a.row_perm_h > 0) {
+        const int h4 = 4 * a.row_perm_h;
+        const int blk = row / h4, rin = row - blk * h4;
+        row = blk * h4 + (rin & 3) * a.row_perm_h + (rin >> 2);
+      }
+      atomicAdd(a.colsum + row, red[tid]);
+    }
+  }
+
+  // epilogue: atomic accumulation (see igemm_tn_kernel)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll

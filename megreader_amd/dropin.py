@@ -1,0 +1,54 @@
+"""Make the UNMODIFIED reference tree run on the MI355X kernels.
+
+    import megreader_amd.dropin as dropin
+    dropin.install("/path/to/MegReader")      # before `import structure.model` / `import trainer`
+
+or, with zero edits to the reference:   python -m megreader_amd.run train.py experiments/recognition/crnn.yaml ...
+
+What install() does:
+  * import shims for non-arithmetic third-party deps that may be missing (megreader_amd.compat);
+  * `apex`            -> megreader_amd.apex (RCCL DistributedDataParallel; structure/model.py:6,34, resnet.py:4);
+  * `ops`             -> megreader_amd.ops (ctc_loss_2d on HIP; decoders/ctc_decoder2d.py:12);
+  * the reference's own `backbones` / `decoders` packages are imported unchanged and the factories this package
+    implements are overridden in their namespaces (`backbones.crnn_backbone`, `decoders.CRNNDecoder`, ...), so
+    `getattr(backbones, args['backbone'])` (structure/model.py:20-21) resolves to the HIP modules while every
+    name that is not on the hot path (detection heads, losses) still comes from the reference.
+"""
+import importlib
+import os
+import sys
+
+OVERRIDES = {
+    "backbones": ("megreader_amd.backbones", ["crnn_backbone"]),
+    "decoders": ("megreader_amd.decoders", ["CRNNDecoder"]),
+}
+
+
+def install(reference_root=None):
+    from . import compat
+    compat.install()
+    from . import apex as _apex
+    sys.modules["apex"] = _apex
+    sys.modules["apex.parallel"] = _apex.parallel
+    from . import ops as _ops
+    sys.modules.setdefault("ops", _ops)
+    if reference_root is None:
+        reference_root = os.environ.get("MEGREADER_REFERENCE")
+    if reference_root:
+        reference_root = os.path.abspath(reference_root)
+        if reference_root not in sys.path:
+            sys.path.insert(0, reference_root)
+    installed = {}
+    for pkg, (ours, names) in OVERRIDES.items():
+        try:
+            ref_mod = importlib.import_module(pkg)
+        except ImportError:
+            # no reference tree on the path: expose our package under the reference's name
+            ref_mod = importlib.import_module(ours)
+            sys.modules[pkg] = ref_mod
+        our_mod = importlib.import_module(ours)
+        for name in names:
+            if hasattr(our_mod, name):
+                setattr(ref_mod, name, getattr(our_mod, name))
+                installed.setdefault(pkg, []).append(name)
+    return installed

@@ -1,0 +1,94 @@
+"""Data-parallel shim (megreader_amd.apex.parallel) on 2 ranks over gloo (CPU): parameter broadcast from rank 0,
+averaged gradients == mean of per-rank gradients == single-process gradient on the concatenated batch; unused
+parameters (grad None) are tolerated; delay_allreduce path agrees."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(8, 16)
+        self.conv = torch.nn.Conv2d(2, 3, 3)
+        self.conv.weight.data = self.conv.weight.data.contiguous(memory_format=torch.channels_last)
+        self.b = torch.nn.Linear(16, 4)
+        self.unused = torch.nn.Linear(4, 4)  # never receives a gradient (cf. PPMDeepsup.cbr_deepsup, ResNet.fc)
+
+    def forward(self, x, img):
+        return self.b(torch.relu(self.a(x))).sum(dim=1) + self.conv(img).mean(dim=(1, 2, 3))
+
+
+def _worker(rank, world, port, delay, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from megreader_amd.apex.parallel import DistributedDataParallel
+    torch.manual_seed(100 + rank)          # different init per rank: the shim must broadcast rank 0's weights
+    net = Net()
+    ddp = DistributedDataParallel(net, message_size=64, delay_allreduce=delay)  # tiny buckets -> several buckets
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(8, 8, generator=g)
+    IMG = torch.randn(8, 2, 5, 5, generator=g)
+    xs, ims = X[rank * 4:(rank + 1) * 4], IMG[rank * 4:(rank + 1) * 4]
+    for _ in range(2):                      # two iterations: bucket state must reset
+        net.zero_grad()
+        ddp(xs, ims).mean().backward()
+    # plain numpy payloads: no shared-memory tensor handles that die with the worker
+    grads = {k: p.grad.contiguous().numpy().copy() if p.grad is not None else None
+             for k, p in net.named_parameters()}
+    state = {k: v.contiguous().numpy().copy() for k, v in net.state_dict().items()}
+    q.put((rank, grads, state))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("delay", [False, True])
+def test_two_rank_gradient_average(delay):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, delay, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(2):
+        rank, grads, state = q.get(timeout=120)
+        results[rank] = ({k: None if v is None else torch.from_numpy(v) for k, v in grads.items()},
+                         {k: torch.from_numpy(v) for k, v in state.items()})
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # same weights on both ranks == rank 0's seed
+    torch.manual_seed(100)
+    ref = Net()
+    for k, v in ref.state_dict().items():
+        assert torch.equal(results[0][1][k], v) and torch.equal(results[1][1][k], v), k
+    # single-process gradient on the concatenated batch (mean loss, equal per-rank batch sizes)
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(8, 8, generator=g)
+    IMG = torch.randn(8, 2, 5, 5, generator=g)
+    ref(X, IMG).mean().backward()
+    for k, p in ref.named_parameters():
+        g0, g1 = results[0][0][k], results[1][0][k]
+        if p.grad is None:
+            assert g0 is None and g1 is None, k
+            continue
+        assert torch.allclose(g0, g1, atol=0, rtol=0), k           # identical on both ranks
+        assert torch.allclose(g0, p.grad, atol=1e-6, rtol=1e-5), k  # == full-batch gradient
