@@ -120,6 +120,19 @@ int mr_ctc_bwd(int dtype, const float* log_probs, const double* alpha, const dou
                const double* grad_out, int T, int N, int C, int S, int blank, int zero_infinity, void* grad_logits,
                int ldg, hipStream_t stream);
 
+/* ---- 2D-CTC (replaces the CUDA extension ops/ctc_2d: csrc/ctc2d.h:7-43, cuda/ctc2d_cuda_kernel.cu) -------------
+ * log_probs [T,H,N,C] contiguous (`dtype`), targets [N,S] i64, lengths [N] i64.  Reference pybind signatures:
+ *   ctc2d_forward(log_probs, targets, input_lengths, target_lengths, BLANK, TINY) -> (nll[N], log_alpha[N,T,H,2S+1])
+ *   ctc2d_backward(grad_out, log_probs, targets, input_lengths, target_lengths, nll, log_alpha, BLANK) -> grad
+ * Here the caller allocates nll / alpha (f32), the beta scratch (f32, same shape as alpha) and grad (`dtype`). */
+int mr_ctc2d_fwd(int dtype, const void* log_probs, const long long* targets, const long long* input_lengths,
+                 const long long* target_lengths, int T, int H, int N, int C, int S, int blank, float* nll,
+                 float* alpha, hipStream_t stream);
+int mr_ctc2d_bwd(int dtype, const float* grad_out, const void* log_probs, const long long* targets,
+                 const long long* input_lengths, const long long* target_lengths, const float* nll,
+                 const float* alpha, float* beta, void* grad, int T, int H, int N, int C, int S, int blank,
+                 hipStream_t stream);
+
 /* eval head: softmax over classes of logits [T,N,C] -> f32 [N,C,1,T] (decoders/crnn.py:101-104) */
 int mr_softmax_nc1t(int dtype, const void* logits, int ldl, float* out, int T, int N, int C, hipStream_t stream);
 

@@ -48,6 +48,8 @@ SIGNATURES = {
     "mr_ctc_fwd": "ipipippiiiiiiipppps",
     "mr_ctc_bwd": "ippppippipiiiiiipis",
     "mr_softmax_nc1t": "ipipiiis",
+    "mr_ctc2d_fwd": "ippppiiiiiipps",
+    "mr_ctc2d_bwd": "ippppppppp" + "iiiiiis",
 }
 
 _lib = None

@@ -109,8 +109,46 @@ def crnn_fixture():
     print("wrote", path, os.path.getsize(path), "bytes; loss", float(loss_r), "adam", traj_r)
 
 
+def ctc2d_fixture():
+    """Pin oracle/ctc2d.py to the reference's own pure-python 2D-CTC (decoders/ctc_loss2d.py:86-154), which takes
+    log-mask and log-classify separately and is valid while NLL <~ 80 (SURVEY.md §2b notes)."""
+    import warnings
+    import numpy as np
+    refimport.import_reference()
+    from decoders.ctc_loss2d import CTCLoss2D
+    from oracle.ctc2d import ctc2d, synthetic_lp
+    T, H, N, C, S = 14, 4, 5, 12, 8   # the python class indexes count_computable[t]: needs T <= 2S+1
+    rng = np.random.RandomState(11)
+    tl = rng.randint(1, 5, size=N).astype(np.int64)
+    tg = np.zeros((N, S), dtype=np.int64)
+    for i, L in enumerate(tl):
+        tg[i, :L] = rng.randint(1, C, size=L)
+    tg[1, 1] = tg[1, 0]
+    tl[1] = max(tl[1], 2)
+    il = np.full(N, T, dtype=np.int64)
+    lp, log_mask, log_cls = synthetic_lp(T, H, N, C, seed=4, peak=4.0, targets=tg, target_lengths=tl)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = CTCLoss2D(reduction='none')
+        nll_ref = ref(torch.from_numpy(log_mask), torch.from_numpy(log_cls), torch.from_numpy(tg),
+                      torch.from_numpy(il), torch.from_numpy(tl))
+    o = ctc2d(lp, tg, il, tl)
+    diff = float(np.abs(nll_ref.numpy() - o['nll']).max())
+    assert float(o['nll'].max()) < 60 and diff < 2e-5, (o['nll'], nll_ref, diff)
+    out = {'lp': torch.from_numpy(lp), 'targets': torch.from_numpy(tg), 'input_lengths': torch.from_numpy(il),
+           'target_lengths': torch.from_numpy(tl), 'nll_reference_python': nll_ref.float(),
+           'nll_oracle': torch.from_numpy(o['nll']), 'grad_oracle': torch.from_numpy(o['grad'])}
+    path = os.path.join(GOLDEN, "ctc2d_golden.pt")
+    torch.save(out, path)
+    print("wrote", path, os.path.getsize(path), "bytes; max |oracle - reference python| =", diff)
+
+
 if __name__ == "__main__":
     if not refimport.available():
         raise SystemExit("reference not available: golden vectors can only be regenerated in the build container")
     os.chdir("/tmp")
-    crnn_fixture()
+    which = sys.argv[1:] or ["crnn", "ctc2d"]
+    if "crnn" in which:
+        crnn_fixture()
+    if "ctc2d" in which:
+        ctc2d_fixture()
