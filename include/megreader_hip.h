@@ -74,9 +74,11 @@ int mr_add(int dtype, const void* a, const void* b, void* out, long long n, int 
 int mr_colsum(int dtype, const void* x, float* out, int P, int C, long long ld, int perm_h, hipStream_t stream);
 /* [A,B,C] -> [B,A,C] */
 int mr_permute_021(int dtype, const void* src, void* dst, int A, int B, int C, hipStream_t stream);
-/* fp32 master weights (logical [K][C][R][S], arbitrary strides) -> operand images of `dtype` */
+/* fp32 master weights (logical [K][C][R][S], arbitrary strides) -> operand images of `dtype`:
+ * dst_krsc [K][R][S][Cpad] (zero padded channels), dst_crsk [C][R][S][ldk] (transposed, for dgrad); either may be null */
 int mr_prep_conv_weight(int dtype, const float* src, long long sk, long long sc, long long sr, long long ss,
-                        void* dst_krsc, void* dst_crsk, int K, int C, int R, int S, int Cpad, hipStream_t stream);
+                        void* dst_krsc, void* dst_crsk, int K, int C, int R, int S, int Cpad, int ldk,
+                        hipStream_t stream);
 int mr_prep_matrix(int dtype, const float* src, void* dst_n, int ldn, void* dst_t, int ldt, int R, int C,
                    int perm_h, hipStream_t stream);
 int mr_prep_bias(const float* a, const float* b, float* dst, int R, int perm_h, hipStream_t stream);
@@ -132,6 +134,26 @@ int mr_ctc2d_bwd(int dtype, const float* grad_out, const void* log_probs, const 
                  const long long* input_lengths, const long long* target_lengths, const float* nll,
                  const float* alpha, float* beta, void* grad, int T, int H, int N, int C, int S, int blank,
                  hipStream_t stream);
+
+/* ---- ResNet50-dilated / PPM / 2D-CTC head helpers (backbones/ppm.py:11-44, decoders/ctc_decoder2d.py:16-45) ----- */
+int mr_adaptive_avgpool_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, int OH, int OW,
+                            hipStream_t stream);
+int mr_adaptive_avgpool_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int OH, int OW,
+                            hipStream_t stream);
+/* bilinear resize, align_corners=False; writes channels [coff, coff+C) of rows with stride ldy; accumulate=1 adds */
+int mr_bilinear_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, int OH, int OW, int ldy, int coff,
+                    int accumulate, hipStream_t stream);
+int mr_bilinear_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int OH, int OW, int lddy,
+                    int coff, hipStream_t stream);
+int mr_copy_channels(int dtype, const void* src, int lds, int soff, void* dst, int ldd, int doff, long long P, int C,
+                     hipStream_t stream);
+int mr_scale_channels(int dtype, const void* x, const float* scale, void* y, int N, long long HW, int C,
+                      hipStream_t stream);
+/* lp[w,h,n,c] = log(max(softmax_h(mask)[n,h,w] * softmax_c(cls)[n,h,w,c], tiny)); also returns both softmaxes (f32) */
+int mr_ctc2d_head_fwd(int dtype, const void* mask_logits, int lda, const void* cls_logits, int ldz, float* lp,
+                      float* mask_prob, float* cls_prob, int N, int H, int W, int C, float tiny, hipStream_t stream);
+int mr_ctc2d_head_bwd(int dtype, const float* grad_lp, const float* mask_prob, const float* cls_prob, void* dmask,
+                      int ldda, void* dcls, int lddz, int N, int H, int W, int C, float tiny, hipStream_t stream);
 
 /* eval head: softmax over classes of logits [T,N,C] -> f32 [N,C,1,T] (decoders/crnn.py:101-104) */
 int mr_softmax_nc1t(int dtype, const void* logits, int ldl, float* out, int T, int N, int C, hipStream_t stream);

@@ -33,7 +33,7 @@ SIGNATURES = {
     "mr_add": "ippplis",
     "mr_colsum": "ippiilis",
     "mr_permute_021": "ippiiis",
-    "mr_prep_conv_weight": "ipllllppiiiiis",
+    "mr_prep_conv_weight": "ipllllppiiiiiis",
     "mr_prep_matrix": "ippipiiiis",
     "mr_prep_bias": "pppiis",
     "mr_adam_step": "pppplps",
@@ -48,6 +48,14 @@ SIGNATURES = {
     "mr_ctc_fwd": "ipipippiiiiiiipppps",
     "mr_ctc_bwd": "ippppippipiiiiiipis",
     "mr_softmax_nc1t": "ipipiiis",
+    "mr_adaptive_avgpool_fwd": "ippiiiiiis",
+    "mr_adaptive_avgpool_bwd": "ippiiiiiis",
+    "mr_bilinear_fwd": "ipp" + "i" * 9 + "s",
+    "mr_bilinear_bwd": "ipp" + "i" * 8 + "s",
+    "mr_copy_channels": "ipiipiilis",
+    "mr_scale_channels": "ipppilis",
+    "mr_ctc2d_head_fwd": "ipipipppiiiifs",
+    "mr_ctc2d_head_bwd": "ippppipiiiiifs",
     "mr_ctc2d_fwd": "ippppiiiiiipps",
     "mr_ctc2d_bwd": "ippppppppp" + "iiiiiis",
 }

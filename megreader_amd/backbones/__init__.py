@@ -1,2 +1,4 @@
 """Mirror of reference backbones/__init__.py:1-4 (factories resolved by name from the YAML configs)."""
 from .crnn import crnn_backbone  # noqa: F401
+from .resnet import resnet18, resnet34, resnet50, resnet101, resnet152  # noqa: F401
+from .resnet_ppm import resnet50dilated_ppm  # noqa: F401

@@ -162,7 +162,7 @@ __global__ void permute_021_kernel(const T* __restrict__ src, T* __restrict__ ds
 template <typename T>
 __global__ void prep_conv_weight_kernel(const float* __restrict__ src, long long sk, long long sc, long long sr,
                                         long long ss, T* __restrict__ dst_krsc, T* __restrict__ dst_crsk, int K,
-                                        int C, int R, int S, int Cpad) {
+                                        int C, int R, int S, int Cpad, int ldk) {
   const long long total = (long long)K * R * S * Cpad;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -175,7 +175,7 @@ __global__ void prep_conv_weight_kernel(const float* __restrict__ src, long long
     float v = 0.f;
     if (c < C) v = src[k * sk + c * sc + r * sr + s * ss];
     if (dst_krsc) dst_krsc[i] = from_f32<T>(v);
-    if (dst_crsk && c < C) dst_crsk[(((long long)c * R + r) * S + s) * K + k] = from_f32<T>(v);
+    if (dst_crsk && c < C) dst_crsk[(((long long)c * R + r) * S + s) * ldk + k] = from_f32<T>(v);
   }
 }
 
@@ -360,12 +360,14 @@ int mr_permute_021(int dtype, const void* src, void* dst, int A, int B, int C, h
 }
 
 int mr_prep_conv_weight(int dtype, const float* src, long long sk, long long sc, long long sr, long long ss,
-                        void* dst_krsc, void* dst_crsk, int K, int C, int R, int S, int Cpad, hipStream_t stream) {
-  MR_CHECK_ARG(Cpad >= C, "mr_prep_conv_weight: Cpad < C");
+                        void* dst_krsc, void* dst_crsk, int K, int C, int R, int S, int Cpad, int ldk,
+                        hipStream_t stream) {
+  MR_CHECK_ARG(Cpad >= C && ldk >= K, "mr_prep_conv_weight: Cpad < C or ldk < K");
   MR_CHECK_ARG(dst_crsk == nullptr || Cpad == C, "mr_prep_conv_weight: crsk image requires Cpad == C");
   const long long total = (long long)K * R * S * Cpad;
   DISPATCH_T(dtype, hipLaunchKernelGGL((prep_conv_weight_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
-                                       stream, src, sk, sc, sr, ss, (T*)dst_krsc, (T*)dst_crsk, K, C, R, S, Cpad));
+                                       stream, src, sk, sc, sr, ss, (T*)dst_krsc, (T*)dst_crsk, K, C, R, S, Cpad,
+                                       ldk));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

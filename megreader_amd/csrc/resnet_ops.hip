@@ -1,0 +1,346 @@
+// HBM-bound helpers for the ResNet50-dilated / PPM backbone and the 2D-CTC head (NHWC tensors):
+//   adaptive average pooling  (backbones/ppm.py:13, nn.AdaptiveAvgPool2d(scale))
+//   bilinear resize, align_corners=False  (backbones/ppm.py:37-40, backbones/fpn_top_down.py:19)
+//   channel-slice copy (torch.cat / its backward, backbones/ppm.py:41)
+//   per-(sample, channel) scaling (nn.Dropout2d, backbones/ppm.py:27)
+//   2D-CTC head: log(max(softmax_H(mask) * softmax_C(classify), tiny)) -> [W,H,N,C]  (decoders/ctc_decoder2d.py:16-45)
+#include "common.h"
+#include "../../include/megreader_hip.h"
+
+namespace mr {
+
+static inline int grid_for(long long n, int block, int max_blocks = 16384) {
+  long long b = (n + block - 1) / block;
+  if (b > max_blocks) b = max_blocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__device__ __forceinline__ int bin_start(int i, int in, int out) { return (i * in) / out; }
+__device__ __forceinline__ int bin_end(int i, int in, int out) { return ((i + 1) * in + out - 1) / out; }
+
+// ---------------------------------------------------------------- adaptive average pool
+template <typename T>
+__global__ void adaptive_avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C,
+                                            int OH, int OW) {
+  const long long total = (long long)N * OH * OW * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long long q = i / C;
+    const int ow = (int)(q % OW);
+    q /= OW;
+    const int oh = (int)(q % OH);
+    const int n = (int)(q / OH);
+    const int h0 = bin_start(oh, H, OH), h1 = bin_end(oh, H, OH);
+    const int w0 = bin_start(ow, W, OW), w1 = bin_end(ow, W, OW);
+    float s = 0.f;
+    for (int h = h0; h < h1; ++h)
+      for (int w = w0; w < w1; ++w) s += to_f32(x[(((long long)n * H + h) * W + w) * C + c]);
+    y[i] = from_f32<T>(s / (float)((h1 - h0) * (w1 - w0)));
+  }
+}
+
+template <typename T>
+__global__ void adaptive_avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C,
+                                            int OH, int OW) {
+  const long long total = (long long)N * H * W * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long long q = i / C;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H);
+    const int n = (int)(q / H);
+    float s = 0.f;
+    for (int oh = 0; oh < OH; ++oh) {
+      const int h0 = bin_start(oh, H, OH), h1 = bin_end(oh, H, OH);
+      if (h < h0 || h >= h1) continue;
+      for (int ow = 0; ow < OW; ++ow) {
+        const int w0 = bin_start(ow, W, OW), w1 = bin_end(ow, W, OW);
+        if (w < w0 || w >= w1) continue;
+        s += to_f32(dy[(((long long)n * OH + oh) * OW + ow) * C + c]) / (float)((h1 - h0) * (w1 - w0));
+      }
+    }
+    dx[i] = from_f32<T>(s);
+  }
+}
+
+// ---------------------------------------------------------------- bilinear resize (align_corners = False)
+__device__ __forceinline__ void bilin_src(int o, int in, int out, int& i0, int& i1, float& l1) {
+  // PyTorch area_pixel_compute_source_index: src = (o + 0.5) * in/out - 0.5, clamped at 0
+  float src = ((float)o + 0.5f) * ((float)in / (float)out) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+// y[n, oh, ow, coff + c] (ld = ldy) (+)= bilinear(x)[...]; accumulate != 0 adds into y (FPN top-down add)
+template <typename T>
+__global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int OH,
+                                    int OW, int ldy, int coff, int accumulate) {
+  const long long total = (long long)N * OH * OW * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long long q = i / C;
+    const int ow = (int)(q % OW);
+    q /= OW;
+    const int oh = (int)(q % OH);
+    const int n = (int)(q / OH);
+    int h0, h1, w0, w1;
+    float lh, lw;
+    bilin_src(oh, H, OH, h0, h1, lh);
+    bilin_src(ow, W, OW, w0, w1, lw);
+    const T* xb = x + (long long)n * H * W * C + c;
+    const float v = (1.f - lh) * ((1.f - lw) * to_f32(xb[((long long)h0 * W + w0) * C]) +
+                                  lw * to_f32(xb[((long long)h0 * W + w1) * C])) +
+                    lh * ((1.f - lw) * to_f32(xb[((long long)h1 * W + w0) * C]) +
+                          lw * to_f32(xb[((long long)h1 * W + w1) * C]));
+    T* dst = y + (((long long)n * OH + oh) * OW + ow) * ldy + coff + c;
+    *dst = from_f32<T>(accumulate ? to_f32(*dst) + v : v);
+  }
+}
+
+// dx[n,h,w,c] = sum over output pixels of their interpolation weight on (h,w) times dy (gather form, no atomics)
+template <typename T>
+__global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C, int OH,
+                                    int OW, int lddy, int coff) {
+  const long long total = (long long)N * H * W * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long long q = i / C;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H);
+    const int n = (int)(q / H);
+    float s = 0.f;
+    for (int oh = 0; oh < OH; ++oh) {
+      int h0, h1;
+      float lh;
+      bilin_src(oh, H, OH, h0, h1, lh);
+      float wh = 0.f;
+      if (h0 == h) wh += 1.f - lh;
+      if (h1 == h) wh += lh;
+      if (wh == 0.f) continue;
+      for (int ow = 0; ow < OW; ++ow) {
+        int w0, w1;
+        float lw;
+        bilin_src(ow, W, OW, w0, w1, lw);
+        float ww = 0.f;
+        if (w0 == w) ww += 1.f - lw;
+        if (w1 == w) ww += lw;
+        if (ww == 0.f) continue;
+        s += wh * ww * to_f32(dy[(((long long)n * OH + oh) * OW + ow) * lddy + coff + c]);
+      }
+    }
+    dx[i] = from_f32<T>(s);
+  }
+}
+
+// ---------------------------------------------------------------- channel-slice copy: dst[p, doff + c] = src[p, soff + c]
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ src, int lds, int soff, T* __restrict__ dst, int ldd,
+                                     int doff, long long P, int C) {
+  constexpr int VEC = VecOf<T>::N;
+  const int cv = C / VEC;
+  const long long total = P * cv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    const long long p = i / cv;
+    *(uint4*)(dst + p * ldd + doff + c) = *(const uint4*)(src + p * lds + soff + c);
+  }
+}
+
+// ---------------------------------------------------------------- y[n,p,c] = x[n,p,c] * scale[n,c]  (Dropout2d)
+template <typename T>
+__global__ void scale_channels_kernel(const T* __restrict__ x, const float* __restrict__ scale, T* __restrict__ y,
+                                      int N, long long HW, int C) {
+  const long long total = (long long)N * HW * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int n = (int)(i / (HW * C));
+    y[i] = from_f32<T>(to_f32(x[i]) * scale[(long long)n * C + c]);
+  }
+}
+
+// ---------------------------------------------------------------- 2D-CTC head
+// mask logits a[n,h,w] (ld = lda, channel 0), class logits z[n,h,w,c] (ld = ldz).  One wave per (n, w) column:
+//   m[h] = softmax_h(a), p[h,c] = softmax_c(z[h]);  lp[w,h,n,c] = log(max(m[h]*p[h,c], tiny))   (f32 out)
+// also stores m [N,H,W] and p [N,H,W,C] (f32) for the backward / eval outputs.
+template <typename T>
+__global__ void ctc2d_head_fwd_kernel(const T* __restrict__ a, int lda, const T* __restrict__ z, int ldz,
+                                      float* __restrict__ lp, float* __restrict__ m_out, float* __restrict__ p_out,
+                                      int N, int H, int W, int C, float tiny) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // col = n*W + w
+  if (col >= N * W) return;
+  const int n = col / W, w = col - n * W;
+  // softmax over H of the mask logits (H is small: lanes stride over it)
+  float mx = -INFINITY;
+  for (int h = lane; h < H; h += 64) mx = fmaxf(mx, to_f32(a[(((long long)n * H + h) * W + w) * lda]));
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int h = lane; h < H; h += 64) se += expf(to_f32(a[(((long long)n * H + h) * W + w) * lda]) - mx);
+  se = wave_sum(se);
+  for (int h = 0; h < H; ++h) {
+    const long long pix = ((long long)n * H + h) * W + w;
+    const float mh = expf(to_f32(a[pix * lda]) - mx) / se;
+    if (lane == 0) m_out[pix] = mh;
+    const T* zr = z + pix * ldz;
+    float cm = -INFINITY;
+    for (int c = lane; c < C; c += 64) cm = fmaxf(cm, to_f32(zr[c]));
+    cm = wave_max(cm);
+    float cs = 0.f;
+    for (int c = lane; c < C; c += 64) cs += expf(to_f32(zr[c]) - cm);
+    cs = wave_sum(cs);
+    float* lrow = lp + (((long long)w * H + h) * N + n) * C;
+    for (int c = lane; c < C; c += 64) {
+      const float pc = expf(to_f32(zr[c]) - cm) / cs;
+      p_out[pix * C + c] = pc;
+      lrow[c] = logf(fmaxf(mh * pc, tiny));
+    }
+  }
+}
+
+// backward of the head: g = d loss / d lp [W,H,N,C].  With k = [m*p > tiny] (the clamp passes no gradient):
+//   da[h] = G_h - m[h] * sum_h' G_h',  G_h = sum_c g*k ;   dz[h,c] = g*k - p[h,c] * G_h
+template <typename T>
+__global__ void ctc2d_head_bwd_kernel(const float* __restrict__ g, const float* __restrict__ m,
+                                      const float* __restrict__ p, T* __restrict__ da, int ldda, T* __restrict__ dz,
+                                      int lddz, int N, int H, int W, int C, float tiny) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (col >= N * W) return;
+  const int n = col / W, w = col - n * W;
+  float Gtot = 0.f;
+  for (int h = 0; h < H; ++h) {
+    const long long pix = ((long long)n * H + h) * W + w;
+    const float mh = m[pix];
+    const float* grow = g + (((long long)w * H + h) * N + n) * C;
+    float Gh = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float pc = p[pix * C + c];
+      if (mh * pc > tiny) Gh += grow[c];
+    }
+    Gh = wave_sum(Gh);
+    Gtot += Gh;
+    T* dzr = dz + pix * lddz;
+    for (int c = lane; c < C; c += 64) {
+      const float pc = p[pix * C + c];
+      const float gk = (mh * pc > tiny) ? grow[c] : 0.f;
+      dzr[c] = from_f32<T>(gk - pc * Gh);
+    }
+  }
+  // second pass for da needs Gtot: recompute G_h (cheap)
+  for (int h = 0; h < H; ++h) {
+    const long long pix = ((long long)n * H + h) * W + w;
+    const float mh = m[pix];
+    const float* grow = g + (((long long)w * H + h) * N + n) * C;
+    float Gh = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float pc = p[pix * C + c];
+      if (mh * pc > tiny) Gh += grow[c];
+    }
+    Gh = wave_sum(Gh);
+    if (lane == 0) da[pix * ldda] = from_f32<T>(Gh - mh * Gtot);
+  }
+}
+
+}  // namespace mr
+
+using namespace mr;
+
+#define DISPATCH_T(dtype, ...)                                   \
+  if ((dtype) == MR_F32) { typedef float T; __VA_ARGS__; }       \
+  else if ((dtype) == MR_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+  else { mr::set_error("bad dtype %d", (dtype)); return MR_ERR_DTYPE; }
+
+extern "C" {
+
+int mr_adaptive_avgpool_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, int OH, int OW,
+                            hipStream_t stream) {
+  MR_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0, "mr_adaptive_avgpool_fwd: bad shape");
+  const long long total = (long long)N * OH * OW * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((adaptive_avgpool_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                       stream, (const T*)x, (T*)y, N, H, W, C, OH, OW));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_adaptive_avgpool_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int OH, int OW,
+                            hipStream_t stream) {
+  const long long total = (long long)N * H * W * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((adaptive_avgpool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                       stream, (const T*)dy, (T*)dx, N, H, W, C, OH, OW));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_bilinear_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, int OH, int OW, int ldy, int coff,
+                    int accumulate, hipStream_t stream) {
+  MR_CHECK_ARG(ldy >= coff + C, "mr_bilinear_fwd: channel slice out of range");
+  const long long total = (long long)N * OH * OW * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
+                                       (const T*)x, (T*)y, N, H, W, C, OH, OW, ldy, coff, accumulate));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_bilinear_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int OH, int OW, int lddy,
+                    int coff, hipStream_t stream) {
+  MR_CHECK_ARG(lddy >= coff + C, "mr_bilinear_bwd: channel slice out of range");
+  const long long total = (long long)N * H * W * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
+                                       (const T*)dy, (T*)dx, N, H, W, C, OH, OW, lddy, coff));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_copy_channels(int dtype, const void* src, int lds, int soff, void* dst, int ldd, int doff, long long P, int C,
+                     hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(C % vec == 0 && lds % vec == 0 && ldd % vec == 0 && soff % vec == 0 && doff % vec == 0,
+               "mr_copy_channels: sizes/offsets must be multiples of %d", vec);
+  MR_CHECK_ARG(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "mr_copy_channels: 16-byte alignment");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((copy_channels_kernel<T>), dim3(grid_for(P * (C / vec), 256)), dim3(256), 0,
+                                       stream, (const T*)src, lds, soff, (T*)dst, ldd, doff, P, C));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_scale_channels(int dtype, const void* x, const float* scale, void* y, int N, long long HW, int C,
+                      hipStream_t stream) {
+  const long long total = (long long)N * HW * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((scale_channels_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
+                                       (const T*)x, scale, (T*)y, N, HW, C));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_ctc2d_head_fwd(int dtype, const void* mask_logits, int lda, const void* cls_logits, int ldz, float* lp,
+                      float* mask_prob, float* cls_prob, int N, int H, int W, int C, float tiny, hipStream_t stream) {
+  MR_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0, "mr_ctc2d_head_fwd: bad shape");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((ctc2d_head_fwd_kernel<T>), dim3(cdiv(N * W, 4)), dim3(256), 0, stream,
+                                       (const T*)mask_logits, lda, (const T*)cls_logits, ldz, lp, mask_prob,
+                                       cls_prob, N, H, W, C, tiny));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_ctc2d_head_bwd(int dtype, const float* grad_lp, const float* mask_prob, const float* cls_prob, void* dmask,
+                      int ldda, void* dcls, int lddz, int N, int H, int W, int C, float tiny, hipStream_t stream) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((ctc2d_head_bwd_kernel<T>), dim3(cdiv(N * W, 4)), dim3(256), 0, stream,
+                                       grad_lp, mask_prob, cls_prob, (T*)dmask, ldda, (T*)dcls, lddz, N, H, W, C,
+                                       tiny));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+}  // extern "C"

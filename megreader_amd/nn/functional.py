@@ -63,39 +63,50 @@ class Conv2dFn(Function):
         require_cuda(x, weight, bias)
         dtype = get_compute_dtype()
         dt = dtype_code(dtype)
+        v = vec_of(dtype)
         xi = to_internal(x, dtype)
         N, H, W, Cp = xi.shape
         K, C, R, S = weight.shape
         if C > Cp or weight.dtype != torch.float32:
             raise RuntimeError("conv weight %s does not match input channels %d" % (tuple(weight.shape), Cp))
+        Kp = _ceil_to(K, v)  # output channels padded to one 16-byte vector (pad channels: zero weights, zero bias)
         sh, sw = stride
         ph, pw = padding
         dh, dw = dilation
         Ho, Wo = _conv_out(H, R, sh, ph, dh), _conv_out(W, S, sw, pw, dw)
         need_dx = ctx.needs_input_grad[0]
-        w_krsc = torch.empty((K, R, S, Cp), dtype=dtype, device=x.device)
-        w_crsk = torch.empty((C, R, S, K), dtype=dtype, device=x.device) if need_dx else None
+        alloc = torch.zeros if Kp != K else torch.empty
+        w_krsc = alloc((Kp, R, S, Cp), dtype=dtype, device=x.device)
+        w_crsk = alloc((C, R, S, Kp), dtype=dtype, device=x.device) if need_dx else None
         if need_dx and Cp != C:
             raise RuntimeError("input gradient requested for a channel-padded convolution input")
         sk, sc, sr, ss = weight.stride()
-        call("mr_prep_conv_weight", dt, ptr(weight), sk, sc, sr, ss, ptr(w_krsc), ptr(w_crsk), K, C, R, S, Cp)
-        y = torch.empty((N, Ho, Wo, K), dtype=dtype, device=x.device)
-        call("mr_conv2d_fwd", dt, ptr(xi), ptr(w_krsc), ptr(bias), ptr(y), int(relu), N, H, W, Cp, Cp, K, K, R, S,
+        call("mr_prep_conv_weight", dt, ptr(weight), sk, sc, sr, ss, ptr(w_krsc), ptr(w_crsk), K, C, R, S, Cp, Kp)
+        bias_k = bias
+        if bias is not None and Kp != K:
+            bias_k = torch.zeros((Kp,), dtype=torch.float32, device=x.device)
+            call("mr_prep_bias", ptr(bias), 0, ptr(bias_k), K, 0)
+        y = torch.empty((N, Ho, Wo, Kp), dtype=dtype, device=x.device)
+        call("mr_conv2d_fwd", dt, ptr(xi), ptr(w_krsc), ptr(bias_k), ptr(y), int(relu), N, H, W, Cp, Cp, Kp, Kp, R, S,
              sh, sw, ph, pw, dh, dw, Ho, Wo)
         ctx.save_for_backward(xi, w_crsk, y if (relu and not relu_grad_downstream) else None)
-        ctx.geom = (N, H, W, Cp, C, K, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo)
+        ctx.geom = (N, H, W, Cp, C, K, Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo)
         ctx.relu = relu and not relu_grad_downstream  # else the consumer (max-pool) applies the ReLU mask
         ctx.has_bias = bias is not None
         ctx.dtype = dtype
-        return y.permute(0, 3, 1, 2)
+        return (y if Kp == K else y[..., :K]).permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, gy):
         xi, w_crsk, y = ctx.saved_tensors
-        N, H, W, Cp, C, K, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo = ctx.geom
+        N, H, W, Cp, C, K, Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo = ctx.geom
         dtype = ctx.dtype
         dt = dtype_code(dtype)
-        g = _grad_internal(gy, dtype)
+        if Kp == K:
+            g = _grad_internal(gy, dtype)
+        else:  # re-pad the gradient to the padded channel count (small head convolutions only)
+            g = torch.zeros((N, Ho, Wo, Kp), dtype=dtype, device=gy.device)
+            g[..., :K] = gy.permute(0, 2, 3, 1)
         if ctx.relu:
             gm = torch.empty_like(g)
             call("mr_relu_bwd", dt, ptr(g), ptr(y), ptr(gm), g.numel())
@@ -103,22 +114,24 @@ class Conv2dFn(Function):
         dx = dwt = db = None
         if ctx.needs_input_grad[0]:
             dxi = torch.empty((N, H, W, C), dtype=dtype, device=g.device)
-            call("mr_conv2d_dgrad", dt, ptr(g), ptr(w_crsk), ptr(dxi), N, H, W, C, C, K, K, R, S, sh, sw, ph, pw,
+            call("mr_conv2d_dgrad", dt, ptr(g), ptr(w_crsk), ptr(dxi), N, H, W, C, C, Kp, Kp, R, S, sh, sw, ph, pw,
                  dh, dw, Ho, Wo)
             dx = dxi.permute(0, 3, 1, 2)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if want_db:
-            db = torch.zeros((K,), dtype=torch.float32, device=g.device)
+            db = torch.zeros((Kp,), dtype=torch.float32, device=g.device)
         if ctx.needs_input_grad[1]:
-            gw = torch.zeros((K, R, S, Cp), dtype=torch.float32, device=g.device)
+            gw = torch.zeros((Kp, R, S, Cp), dtype=torch.float32, device=g.device)
             # the bias gradient (column sums of dy) rides along the wgrad pass over dy
-            call("mr_conv2d_wgrad", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, K, K,
+            call("mr_conv2d_wgrad", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, Kp, Kp,
                  R, S, sh, sw, ph, pw, dh, dw, Ho, Wo)
-            if Cp != C:
-                gw = gw[..., :C]
+            if Cp != C or Kp != K:
+                gw = gw[:K, :, :, :C]
             dwt = gw.permute(0, 3, 1, 2)
         elif want_db:
-            call("mr_colsum", dt, ptr(g), ptr(db), N * Ho * Wo, K, K, 0)
+            call("mr_colsum", dt, ptr(g), ptr(db), N * Ho * Wo, Kp, Kp, 0)
+        if want_db and Kp != K:
+            db = db[:K]
         return dx, dwt, db, None, None, None, None, None
 
 
@@ -483,3 +496,185 @@ def softmax_eval_nc1t(logits):
     out = torch.empty((N, C, 1, T), dtype=torch.float32, device=lg.device)
     call("mr_softmax_nc1t", dtype_code(lg.dtype), ptr(lg), lg.stride(1), ptr(out), T, N, C)
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# PPM / FPN helpers.  reference: backbones/ppm.py:11-44, backbones/fpn_top_down.py:16-30
+# --------------------------------------------------------------------------------------------------
+class AdaptiveAvgPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, out_hw):
+        require_cuda(x)
+        dtype = get_compute_dtype()
+        xi = to_internal(x, dtype)
+        N, H, W, C = xi.shape
+        OH, OW = out_hw
+        y = torch.empty((N, OH, OW, C), dtype=dtype, device=x.device)
+        call("mr_adaptive_avgpool_fwd", dtype_code(dtype), ptr(xi), ptr(y), N, H, W, C, OH, OW)
+        ctx.geom = (N, H, W, C, OH, OW)
+        ctx.dtype = dtype
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, H, W, C, OH, OW = ctx.geom
+        g = _grad_internal(gy, ctx.dtype)
+        dx = torch.empty((N, H, W, C), dtype=ctx.dtype, device=g.device)
+        call("mr_adaptive_avgpool_bwd", dtype_code(ctx.dtype), ptr(g), ptr(dx), N, H, W, C, OH, OW)
+        return dx.permute(0, 3, 1, 2), None
+
+
+def adaptive_avg_pool2d(x, output_size):
+    if isinstance(output_size, int):
+        output_size = (output_size, output_size)
+    return AdaptiveAvgPoolFn.apply(x, tuple(output_size))
+
+
+class BilinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, out_hw):
+        require_cuda(x)
+        dtype = get_compute_dtype()
+        xi = to_internal(x, dtype)
+        N, H, W, C = xi.shape
+        OH, OW = out_hw
+        y = torch.empty((N, OH, OW, C), dtype=dtype, device=x.device)
+        call("mr_bilinear_fwd", dtype_code(dtype), ptr(xi), ptr(y), N, H, W, C, OH, OW, C, 0, 0)
+        ctx.geom = (N, H, W, C, OH, OW)
+        ctx.dtype = dtype
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, H, W, C, OH, OW = ctx.geom
+        g = _grad_internal(gy, ctx.dtype)
+        dx = torch.empty((N, H, W, C), dtype=ctx.dtype, device=g.device)
+        call("mr_bilinear_bwd", dtype_code(ctx.dtype), ptr(g), ptr(dx), N, H, W, C, OH, OW, C, 0)
+        return dx.permute(0, 3, 1, 2), None
+
+
+def interpolate_bilinear(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False)."""
+    return BilinearFn.apply(x, tuple(size))
+
+
+class CatChannelsFn(Function):
+    """torch.cat(tensors, 1) for NHWC-internal tensors whose channel counts are multiples of one vector."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        dtype = get_compute_dtype()
+        dt = dtype_code(dtype)
+        parts = [to_internal(x, dtype) for x in xs]
+        N, H, W, _ = parts[0].shape
+        chans = [p.shape[3] for p in parts]
+        Ct = sum(chans)
+        y = torch.empty((N, H, W, Ct), dtype=dtype, device=parts[0].device)
+        off = 0
+        for p, c in zip(parts, chans):
+            call("mr_copy_channels", dt, ptr(p), c, 0, ptr(y), Ct, off, N * H * W, c)
+            off += c
+        ctx.chans = chans
+        ctx.dtype = dtype
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        g = _grad_internal(gy, ctx.dtype)
+        N, H, W, Ct = g.shape
+        dt = dtype_code(ctx.dtype)
+        outs, off = [], 0
+        for c in ctx.chans:
+            d = torch.empty((N, H, W, c), dtype=ctx.dtype, device=g.device)
+            call("mr_copy_channels", dt, ptr(g), Ct, off, ptr(d), c, 0, N * H * W, c)
+            outs.append(d.permute(0, 3, 1, 2))
+            off += c
+        return tuple(outs)
+
+
+def cat_channels(tensors):
+    return CatChannelsFn.apply(*tensors)
+
+
+class ScaleChannelsFn(Function):
+    """y[n,c,h,w] = x[n,c,h,w] * scale[n,c]  (Dropout2d with a precomputed keep-mask / (1-p))."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        dtype = get_compute_dtype()
+        xi = to_internal(x, dtype)
+        N, H, W, C = xi.shape
+        y = torch.empty_like(xi)
+        call("mr_scale_channels", dtype_code(dtype), ptr(xi), ptr(scale), ptr(y), N, H * W, C)
+        ctx.save_for_backward(scale)
+        ctx.dtype = dtype
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (scale,) = ctx.saved_tensors
+        g = _grad_internal(gy, ctx.dtype)
+        N, H, W, C = g.shape
+        dx = torch.empty_like(g)
+        call("mr_scale_channels", dtype_code(ctx.dtype), ptr(g), ptr(scale), ptr(dx), N, H * W, C)
+        return dx.permute(0, 3, 1, 2), None
+
+
+def dropout2d(x, p, training):
+    """nn.Dropout2d: whole channels are zeroed per sample with probability p; kept channels scale by 1/(1-p).
+    The keep-mask comes from torch's generator (bernoulli on [N, C]); it cannot match the reference's RNG stream."""
+    if not training or p == 0.0:
+        return x
+    N, C = x.shape[0], x.shape[1]
+    keep = torch.empty((N, C), dtype=torch.float32, device=x.device).bernoulli_(1.0 - p)
+    return ScaleChannelsFn.apply(x, keep / (1.0 - p))
+
+
+# --------------------------------------------------------------------------------------------------
+# 2D-CTC head: pred = log(max(softmax_H(mask) * softmax_C(classify), tiny)).permute(3,2,0,1)
+# reference: decoders/ctc_decoder2d.py:16-45
+# --------------------------------------------------------------------------------------------------
+class CTC2DHeadFn(Function):
+    @staticmethod
+    def forward(ctx, mask_logits, cls_logits, tiny):
+        """mask_logits logical [N,1,H,W], cls_logits logical [N,C,H,W] (outputs of the HIP convs).
+        Returns (lp [W,H,N,C] f32, mask_prob [N,1,H,W] f32, cls_prob logical [N,C,H,W] f32)."""
+        require_cuda(mask_logits, cls_logits)
+        a = mask_logits.permute(0, 2, 3, 1)
+        z = cls_logits.permute(0, 2, 3, 1)
+        if a.stride(3) != 1 or z.stride(3) != 1 or a.dtype != z.dtype:
+            raise RuntimeError("ctc2d head expects channel-contiguous NHWC logits")
+        N, H, W, C = z.shape
+        lda, ldz = a.stride(2), z.stride(2)
+        for t, ld in ((a, lda), (z, ldz)):
+            if t.stride(1) != W * ld or t.stride(0) != H * W * ld:
+                raise RuntimeError("ctc2d head expects dense (row-padded) NHWC logits")
+        dev = z.device
+        lp = torch.empty((W, H, N, C), dtype=torch.float32, device=dev)
+        m = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+        p = torch.empty((N, H, W, C), dtype=torch.float32, device=dev)
+        call("mr_ctc2d_head_fwd", dtype_code(z.dtype), ptr(a), lda, ptr(z), ldz, ptr(lp), ptr(m), ptr(p), N, H, W, C,
+             float(tiny))
+        ctx.save_for_backward(m, p)
+        ctx.geom = (N, H, W, C, float(tiny))
+        ctx.dtype = z.dtype
+        ctx.mark_non_differentiable(m, p)
+        return lp, m.unsqueeze(1), p.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, glp, _gm, _gp):
+        m, p = ctx.saved_tensors
+        N, H, W, C, tiny = ctx.geom
+        dtype = ctx.dtype
+        v = vec_of(dtype)
+        Cp = _ceil_to(C, v)
+        g = glp.to(torch.float32).contiguous()
+        da = torch.zeros((N, H, W, v), dtype=dtype, device=g.device)
+        dz = torch.zeros((N, H, W, Cp), dtype=dtype, device=g.device) if Cp != C else \
+            torch.empty((N, H, W, Cp), dtype=dtype, device=g.device)
+        call("mr_ctc2d_head_bwd", dtype_code(dtype), ptr(g), ptr(m), ptr(p), ptr(da), v, ptr(dz), Cp, N, H, W, C, tiny)
+        return da[..., :1].permute(0, 3, 1, 2), dz[..., :C].permute(0, 3, 1, 2), None
+
+
+def ctc2d_head(mask_logits, cls_logits, tiny):
+    return CTC2DHeadFn.apply(mask_logits, cls_logits, tiny)

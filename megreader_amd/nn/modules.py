@@ -103,3 +103,14 @@ class LSTM(nn.Module):
                        self.weight_ih_l0_reverse, self.weight_hh_l0_reverse, self.bias_ih_l0_reverse,
                        self.bias_hh_l0_reverse)
         return out, None
+
+
+class AdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
+    def forward(self, x):
+        size = self.output_size if isinstance(self.output_size, (tuple, list)) else (self.output_size,) * 2
+        return F.adaptive_avg_pool2d(x, size)
+
+
+class Dropout2d(nn.Dropout2d):
+    def forward(self, x):
+        return F.dropout2d(x, self.p, self.training)

@@ -143,12 +143,74 @@ def ctc2d_fixture():
     print("wrote", path, os.path.getsize(path), "bytes; max |oracle - reference python| =", diff)
 
 
+def res50ppm_fixture():
+    """ResNet50-dilated + PPM + CTCDecoder2D (experiments/recognition/res50-ppm-2d-ctc.yaml) executed by the
+    UNMODIFIED reference modules on CPU; the only substitution is the CUDA-only `ops.ctc_loss_2d`, replaced by the
+    float64 oracle op (oracle/res50ppm.py:OracleCTC2D).  Dropout2d(0.1) is set to p = 0 on both sides (its RNG
+    stream cannot be reproduced by another implementation)."""
+    import types
+    from oracle.res50ppm import Res50PPM2DCTCOracle, synthetic_batch_2d, oracle_ctc_loss_2d
+    torch.set_num_threads(4)
+    ops = types.ModuleType("ops")
+    ops.ctc_loss_2d = oracle_ctc_loss_2d
+    sm = refimport.import_reference(ops_module=ops)
+    from concern.charsets import EnglishCharset
+    charset = EnglishCharset()
+    args = {'backbone': 'resnet50dilated_ppm', 'decoder': 'CTCDecoder2D',
+            'decoder_args': {'in_channels': 256, 'charset': charset}}
+    torch.manual_seed(WEIGHT_SEED)
+    ref = sm.SequenceRecognitionModel(args, torch.device('cpu'))
+    torch.manual_seed(WEIGHT_SEED)
+    ora = Res50PPM2DCTCOracle(num_classes=len(charset))
+    ref_state = {k.replace('model.module.', ''): v for k, v in ref.state_dict().items()}
+    assert list(ref_state.keys()) == list(ora.state_dict().keys()), "state_dict keys differ"
+    for k, v in ora.state_dict().items():
+        assert torch.equal(v, ref_state[k]), "seeded init differs at %s" % k
+    for m in list(ref.modules()) + list(ora.modules()):
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    batch = synthetic_batch_2d(2, 32, 64, seed=3)
+    out = {'weight_seed': WEIGHT_SEED, 'batch': batch, 'state_checksums': checksums(ref_state),
+           'state_keys': list(ref_state.keys()), 'state_shapes': {k: tuple(v.shape) for k, v in ref_state.items()}}
+    ref.train()
+    ora.train()
+    loss_r, pred_r = ref.forward(dict(batch), training=True)
+    loss_r.mean().backward()
+    loss_o, pred_o = ora(batch['image'], targets=batch['label'], lengths=batch['length'].long(), train=True)
+    loss_o.mean().backward()
+    assert torch.equal(loss_r, loss_o) and torch.equal(pred_r, pred_o), "oracle forward != reference"
+    grads_r = {k.replace('model.module.', ''): p.grad for k, p in ref.named_parameters()}
+    out['grad_stats'] = {}
+    for k, p in ora.named_parameters():
+        if p.grad is None:
+            assert grads_r[k] is None, k
+            out['grad_stats'][k] = None
+            continue
+        assert torch.equal(p.grad, grads_r[k]), "oracle grad != reference at %s" % k
+        out['grad_stats'][k] = (float(p.grad.double().norm()), p.grad.flatten()[:8].clone())
+    out['train_loss'] = loss_r.detach().clone()
+    out['train_pred'] = pred_r.detach().clone()
+    ref.eval()
+    ora.eval()
+    with torch.no_grad():
+        cls_r, mask_r = ref.forward(dict(batch), training=False)
+        cls_o, mask_o = ora(batch['image'], train=False)
+    assert torch.equal(cls_r, cls_o) and torch.equal(mask_r, mask_o), "oracle eval != reference"
+    out['eval_classify'] = cls_r.clone()
+    out['eval_mask'] = mask_r.clone()
+    path = os.path.join(GOLDEN, "res50ppm_golden.pt")
+    torch.save(out, path)
+    print("wrote", path, os.path.getsize(path), "bytes; loss", loss_r.tolist())
+
+
 if __name__ == "__main__":
     if not refimport.available():
         raise SystemExit("reference not available: golden vectors can only be regenerated in the build container")
     os.chdir("/tmp")
-    which = sys.argv[1:] or ["crnn", "ctc2d"]
+    which = sys.argv[1:] or ["crnn", "ctc2d", "res50ppm"]
     if "crnn" in which:
         crnn_fixture()
     if "ctc2d" in which:
         ctc2d_fixture()
+    if "res50ppm" in which:
+        res50ppm_fixture()

@@ -12,8 +12,11 @@ def available():
     return os.path.isdir(os.path.join(REF_ROOT, "backbones"))
 
 
-def import_reference():
-    """Put the reference on sys.path (after installing import shims for its non-arithmetic deps and an inert
+def import_reference(ops_module=None):
+    """ops_module: object to expose as the top-level `ops` package (the reference's own `ops` imports its CUDA-only
+    extension and cannot be imported on CPU; decoders/ctc_decoder2d.py:12 does `from ops import ctc_loss_2d`).
+
+    Put the reference on sys.path (after installing import shims for its non-arithmetic deps and an inert
     `apex` namespace -- the CPU path never touches apex: structure/model.py:27-36 only uses it under -d)."""
     if not available():
         raise RuntimeError("reference tree not found at %s" % REF_ROOT)
@@ -28,7 +31,9 @@ def import_reference():
         apex.parallel = types.ModuleType("apex.parallel")
         sys.modules["apex"] = apex
         sys.modules["apex.parallel"] = apex.parallel
-    for name in ("backbones", "decoders", "ops", "structure", "concern", "config"):
+    if ops_module is not None:
+        sys.modules["ops"] = ops_module
+    for name in ("backbones", "decoders", "structure", "concern", "config"):
         mod = sys.modules.get(name)
         if mod is not None and not getattr(mod, "__file__", "").startswith(REF_ROOT):
             raise RuntimeError("module %r is already imported from %s" % (name, getattr(mod, "__file__", "?")))

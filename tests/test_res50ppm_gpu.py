@@ -1,0 +1,169 @@
+"""ResNet50-dilated + PPM backbone and the 2D-CTC decoder on HIP vs golden vectors produced by the unmodified
+reference modules (oracle/gen_golden.py res50ppm; the CUDA-only ctc op substituted by the f64 oracle op)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+import megreader_amd as mr  # noqa: E402
+from megreader_amd.backbones import resnet50dilated_ppm  # noqa: E402
+from megreader_amd.decoders import CTCDecoder2D  # noqa: E402
+from megreader_amd.nn import functional as F  # noqa: E402
+from oracle.res50ppm import Res50PPM2DCTCOracle  # noqa: E402
+
+DEV = "cuda"
+
+
+class BasicModel(torch.nn.Module):  # reference structure/model.py:16-24
+    def __init__(self):
+        super().__init__()
+        self.backbone = resnet50dilated_ppm()
+        self.decoder = CTCDecoder2D(in_channels=256)
+
+    def forward(self, data, *args, **kwargs):
+        return self.decoder(self.backbone(data), *args, **kwargs)
+
+
+@pytest.fixture(autouse=True)
+def _reset_dtype():
+    yield
+    mr.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return torch.load(os.path.join(golden_dir, "res50ppm_golden.pt"), weights_only=False)
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def _models(golden, dtype):
+    mr.set_compute_dtype(dtype)
+    torch.manual_seed(golden['weight_seed'])
+    ora = Res50PPM2DCTCOracle(dropout=0.0)
+    model = BasicModel()
+    model.load_state_dict(ora.state_dict(), strict=True)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    return ora, model.to(DEV)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_small_ops_vs_torch(dtype):
+    mr.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 16, 5, 7, generator=g).to(dtype)
+    for out in (1, 2, 3, 6):
+        xr = x.double().requires_grad_(True)
+        yr = TF.adaptive_avg_pool2d(xr, out)
+        gy = torch.randn(yr.shape, generator=g).to(dtype)
+        yr.backward(gy.double())
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = F.adaptive_avg_pool2d(xd, out)
+        y.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
+        tol = 1e-5 if dtype == torch.float32 else 1.2e-2
+        assert _rel(y, yr) < tol and _rel(xd.grad, xr.grad) < tol
+    for (h, w), (oh, ow) in (((1, 1), (4, 8)), ((2, 2), (4, 8)), ((3, 3), (5, 7)), ((6, 6), (8, 32)), ((4, 8), (8, 16))):
+        x = torch.randn(2, 8, h, w, generator=g).to(dtype)
+        xr = x.double().requires_grad_(True)
+        yr = TF.interpolate(xr, (oh, ow), mode='bilinear', align_corners=False)
+        gy = torch.randn(yr.shape, generator=g).to(dtype)
+        yr.backward(gy.double())
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = F.interpolate_bilinear(xd, (oh, ow))
+        y.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
+        tol = 1e-5 if dtype == torch.float32 else 1.2e-2
+        assert _rel(y, yr) < tol and _rel(xd.grad, xr.grad) < tol
+    a = torch.randn(2, 8, 3, 4, generator=g).to(dtype)
+    b = torch.randn(2, 16, 3, 4, generator=g).to(dtype)
+    ad = a.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = b.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    c = F.cat_channels([ad, bd])
+    assert torch.equal(c.float().cpu(), torch.cat([a, b], 1).float())
+    c.backward(c.detach())
+    assert torch.equal(ad.grad.float().cpu(), a.float()) and torch.equal(bd.grad.float().cpu(), b.float())
+
+
+def test_ctc2d_head_vs_torch():
+    mr.set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(2)
+    N, C, H, W = 2, 38, 4, 6
+    a = torch.randn(N, 1, H, W, generator=g)
+    z = torch.randn(N, C, H, W, generator=g) * 3
+    tiny = torch.tensor(torch.finfo().tiny)
+    ar = a.double().requires_grad_(True)
+    zr = z.double().requires_grad_(True)
+    pr = torch.log(torch.max(torch.softmax(ar, 2) * torch.softmax(zr, 1), tiny.double())).permute(3, 2, 0, 1)
+    gp = torch.randn(pr.shape, generator=g).double()
+    pr.backward(gp)
+    # the HIP convs hand over row-padded NHWC logits; emulate with padded buffers
+    ab = torch.zeros(N, H, W, 4, device=DEV)
+    ab[..., :1] = a.permute(0, 2, 3, 1)
+    zb = torch.zeros(N, H, W, 40, device=DEV)
+    zb[..., :C] = z.permute(0, 2, 3, 1)
+    ad = ab[..., :1].permute(0, 3, 1, 2).requires_grad_(True)
+    zd = zb[..., :C].permute(0, 3, 1, 2).requires_grad_(True)
+    lp, m, p = F.ctc2d_head(ad, zd, float(tiny))
+    assert _rel(lp, pr) < 1e-5
+    assert _rel(m, torch.softmax(a.double(), 2)) < 1e-5 and _rel(p, torch.softmax(z.double(), 1)) < 1e-5
+    lp.backward(gp.float().to(DEV))
+    assert _rel(ad.grad, ar.grad) < 1e-4 and _rel(zd.grad, zr.grad) < 1e-4
+
+
+def test_state_dict_mirrors_reference(golden):
+    torch.manual_seed(golden['weight_seed'])
+    model = BasicModel()
+    assert list(model.state_dict().keys()) == golden['state_keys']
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == golden['state_shapes'][k], k
+        s, a = golden['state_checksums'][k]
+        assert abs(float(v.double().sum()) - s) <= 1e-6 * max(1.0, a), k   # same default init as the reference
+
+
+def test_fp32_parity_vs_reference_golden(golden):
+    ora, model = _models(golden, torch.float32)
+    b = golden['batch']
+    model.train()
+    loss, pred = model(b['image'].to(DEV), targets=b['label'].to(DEV), lengths=b['length'].to(DEV).long(), train=True)
+    assert loss.shape == golden['train_loss'].shape
+    assert float((loss.cpu() - golden['train_loss']).abs().max()) < 1e-4 * float(golden['train_loss'].abs().max())
+    finite = torch.isfinite(golden['train_pred']) & (golden['train_pred'] > -80)
+    assert float((pred.cpu() - golden['train_pred'])[finite].abs().max()) < 2e-3
+    loss.mean().backward()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        gs = golden['grad_stats'][k]
+        if gs is None:
+            assert p.grad is None, k      # unused parameters (cbr_deepsup) receive no gradient
+            continue
+        norm, _ = gs
+        if norm < 1e-6:
+            continue
+        rel = abs(float(p.grad.double().norm()) - norm) / norm
+        worst = max(worst, rel)
+        assert rel < 5e-3, (k, rel, norm)
+    print("worst relative grad-norm error:", worst)
+    model.eval()
+    with torch.no_grad():
+        cls, mask = model(b['image'].to(DEV), train=False)
+    # eval uses BN running stats, which moved by one training forward on both sides? the golden eval was taken
+    # after ONE training forward as well
+    assert _rel(cls, golden['eval_classify']) < 2e-3 and _rel(mask, golden['eval_mask']) < 2e-3
+
+
+def test_bf16_runs_close(golden):
+    ora, model = _models(golden, torch.bfloat16)
+    b = golden['batch']
+    model.train()
+    loss, _ = model(b['image'].to(DEV), targets=b['label'].to(DEV), lengths=b['length'].to(DEV).long(), train=True)
+    loss.mean().backward()
+    rel = float(((loss.cpu() - golden['train_loss']).abs() / golden['train_loss'].abs()).max())
+    print("bf16 relative loss drift:", rel)
+    assert rel < 0.05
