@@ -155,6 +155,22 @@ int mr_ctc2d_head_fwd(int dtype, const void* mask_logits, int lda, const void* c
 int mr_ctc2d_head_bwd(int dtype, const float* grad_lp, const float* mask_prob, const float* cls_prob, void* dmask,
                       int ldda, void* dcls, int lddz, int N, int H, int W, int C, float tiny, hipStream_t stream);
 
+/* ---- Modulated deformable conv v2 (replaces assets/ops/dcn: src/deform_conv_cuda.cpp:486-679 and
+ *      src/deform_conv_cuda_kernel.cu:569-766; python API functions/deform_conv.py:108-177) --------------------------
+ * forward  = mr_dcn2_im2col (whole batch) + mr_gemm_nt(col, w_krsc, bias)
+ * backward = mr_gemm_nt(dy, w^T) -> gcol; mr_dcn2_coord_grad; mr_dcn2_col2im; mr_dcn2_im2col + mr_gemm_tn (dW, dbias)
+ * offset / mask are f32 and indexed per sample as FLAT [2*kh*kw][Ho][Wo] / [kh*kw][Ho][Wo] arrays from the sample's
+ * base (per-sample strides off_bs / msk_bs), exactly like deform_conv_cuda_kernel.cu:599-612. */
+int mr_dcn2_im2col(int dtype, const void* x, const float* offset, long long off_bs, const float* mask,
+                   long long msk_bs, void* col, int N, int H, int W, int C, int kh, int kw, int stride, int pad,
+                   int dil, int Ho, int Wo, hipStream_t stream);
+int mr_dcn2_coord_grad(int dtype, const void* gcol, const void* x, const float* offset, long long off_bs,
+                       const float* mask, long long msk_bs, float* doffset, float* dmask, int N, int H, int W,
+                       int C, int kh, int kw, int stride, int pad, int dil, int Ho, int Wo, hipStream_t stream);
+int mr_dcn2_col2im(int dtype, const void* gcol, const float* offset, long long off_bs, const float* mask,
+                   long long msk_bs, float* dx, int N, int H, int W, int C, int kh, int kw, int stride, int pad,
+                   int dil, int Ho, int Wo, hipStream_t stream);
+
 /* eval head: softmax over classes of logits [T,N,C] -> f32 [N,C,1,T] (decoders/crnn.py:101-104) */
 int mr_softmax_nc1t(int dtype, const void* logits, int ldl, float* out, int T, int N, int C, hipStream_t stream);
 

@@ -56,6 +56,9 @@ SIGNATURES = {
     "mr_scale_channels": "ipppilis",
     "mr_ctc2d_head_fwd": "ipipipppiiiifs",
     "mr_ctc2d_head_bwd": "ippppipiiiiifs",
+    "mr_dcn2_im2col": "ipplplp" + "i" * 11 + "s",
+    "mr_dcn2_coord_grad": "ippplplpp" + "i" * 11 + "s",
+    "mr_dcn2_col2im": "ipplplp" + "i" * 11 + "s",
     "mr_ctc2d_fwd": "ippppiiiiiipps",
     "mr_ctc2d_bwd": "ippppppppp" + "iiiiiis",
 }

@@ -1,0 +1,183 @@
+"""Modulated deformable convolution (DCNv2) on HIP kernels.
+
+Mirror of reference assets/ops/dcn/functions/deform_conv.py:108-177 and modules/deform_conv.py:84-160: same
+constructor / call signatures, parameter names and initialisation, same errors (CPU tensors -> NotImplementedError,
+deform_conv.py:130-131), no shape check on offset / mask (the v2 host code has none, which is what makes the
+reference's stride-2 blocks work on a larger offset map -- SURVEY.md §3.3; this implementation indexes the maps the
+same flat way).  groups = deformable_groups = 1 only (all the reference's models).
+
+Forward: deformable im2col over the whole batch (one launch) + one MFMA GEMM against KRSC weights.
+Backward: gcol = dy * W (MFMA GEMM), offset/mask gradient kernel (wave reduction over channels), input gradient
+scatter (f32 atomics), and dW/dbias with the transpose-read wgrad GEMM on a recomputed column matrix.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.nn.modules.utils import _pair
+
+from .... import get_compute_dtype
+from ...._lib import call, dtype_code, ptr, vec_of
+from ....nn.functional import to_internal, _grad_internal
+
+
+class ModulatedDeformConvFunction(Function):
+
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
+                deformable_groups=1):
+        if not input.is_cuda:
+            raise NotImplementedError
+        if groups != 1 or deformable_groups != 1:
+            raise NotImplementedError("groups / deformable_groups > 1 are not used by any reference model")
+        dtype = get_compute_dtype()
+        dt = dtype_code(dtype)
+        v = vec_of(dtype)
+        xi = to_internal(input, dtype)
+        N, H, W, C = xi.shape
+        Co, Ci, kh, kw = weight.shape
+        if Ci != C or C % v or Co % v:
+            raise RuntimeError("modulated_deform_conv: channels (%d -> %d) must be multiples of %d" % (C, Co, v))
+        Ho = (H + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
+        Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+        # offsets / mask as contiguous f32 NCHW (they are small); flat per-sample indexing like the reference
+        off = offset.detach().to(torch.float32).contiguous()
+        msk = mask.detach().to(torch.float32).contiguous()
+        off_bs, msk_bs = off[0].numel(), msk[0].numel()
+        K = kh * kw * C
+        wk = weight.detach().permute(0, 2, 3, 1)
+        if not wk.is_contiguous():
+            wk = wk.contiguous()   # physical KRSC f32
+        w_n = torch.empty((Co, K), dtype=dtype, device=xi.device)
+        w_t = torch.empty((K, Co), dtype=dtype, device=xi.device)
+        call("mr_prep_matrix", dt, ptr(wk), ptr(w_n), K, ptr(w_t), Co, Co, K, 0)
+        col = torch.empty((N * Ho * Wo, K), dtype=dtype, device=xi.device)
+        call("mr_dcn2_im2col", dt, ptr(xi), ptr(off), off_bs, ptr(msk), msk_bs, ptr(col), N, H, W, C, kh, kw,
+             stride, padding, dilation, Ho, Wo)
+        y = torch.empty((N, Ho, Wo, Co), dtype=dtype, device=xi.device)
+        call("mr_gemm_nt", dt, ptr(col), K, ptr(w_n), K, ptr(y), Co, ptr(bias), 0, N * Ho * Wo, Co, K)
+        ctx.save_for_backward(xi, off, msk, w_t)
+        ctx.geom = (N, H, W, C, Co, kh, kw, stride, padding, dilation, Ho, Wo, off_bs, msk_bs)
+        ctx.with_bias = bias is not None
+        ctx.dtype = dtype
+        ctx.off_meta = (offset.shape, offset.dtype, mask.shape, mask.dtype)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        xi, off, msk, w_t = ctx.saved_tensors
+        N, H, W, C, Co, kh, kw, stride, padding, dilation, Ho, Wo, off_bs, msk_bs = ctx.geom
+        dtype = ctx.dtype
+        dt = dtype_code(dtype)
+        dev = xi.device
+        K = kh * kw * C
+        P = N * Ho * Wo
+        g = _grad_internal(grad_output, dtype)
+        gcol = torch.empty((P, K), dtype=dtype, device=dev)
+        call("mr_gemm_nt", dt, ptr(g), Co, ptr(w_t), Co, ptr(gcol), K, 0, 0, P, K, Co)
+        geo = (N, H, W, C, kh, kw, stride, padding, dilation, Ho, Wo)
+        grad_offset = torch.zeros_like(off)
+        grad_mask = torch.zeros_like(msk)
+        call("mr_dcn2_coord_grad", dt, ptr(gcol), ptr(xi), ptr(off), off_bs, ptr(msk), msk_bs, ptr(grad_offset),
+             ptr(grad_mask), *geo)
+        grad_input = None
+        if ctx.needs_input_grad[0]:
+            dx32 = torch.zeros((N, H, W, C), dtype=torch.float32, device=dev)
+            call("mr_dcn2_col2im", dt, ptr(gcol), ptr(off), off_bs, ptr(msk), msk_bs, ptr(dx32), *geo)
+            if dtype == torch.float32:
+                dxi = dx32
+            else:
+                dxi = torch.empty((N, H, W, C), dtype=dtype, device=dev)
+                call("mr_cast", 0, ptr(dx32), dt, ptr(dxi), dx32.numel())
+            grad_input = dxi.permute(0, 3, 1, 2)
+        grad_weight = grad_bias = None
+        if ctx.needs_input_grad[3] or (ctx.with_bias and ctx.needs_input_grad[4]):
+            col = gcol  # reuse the buffer: recompute the forward column matrix (the reference does the same)
+            call("mr_dcn2_im2col", dt, ptr(xi), ptr(off), off_bs, ptr(msk), msk_bs, ptr(col), *geo)
+            gw = torch.zeros((Co, kh, kw, C), dtype=torch.float32, device=dev)
+            gb = torch.zeros((Co,), dtype=torch.float32, device=dev) if ctx.with_bias else None
+            call("mr_gemm_tn", dt, ptr(g), Co, ptr(col), K, ptr(gw), K, P, Co, K, 0, ptr(gb))
+            grad_weight = gw.permute(0, 3, 1, 2)
+            grad_bias = gb
+        oshape, odtype, mshape, mdtype = ctx.off_meta
+        return (grad_input, grad_offset.to(odtype), grad_mask.to(mdtype), grad_weight, grad_bias, None, None, None,
+                None, None)
+
+
+modulated_deform_conv = ModulatedDeformConvFunction.apply
+
+
+class ModulatedDeformConv(nn.Module):
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=True):
+        super(ModulatedDeformConv, self).__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = stride
+        self.padding = padding
+        self.dilation = dilation
+        self.groups = groups
+        self.deformable_groups = deformable_groups
+        self.with_bias = bias
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+        self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)  # physical KRSC
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def forward(self, x, offset, mask):
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                     self.dilation, self.groups, self.deformable_groups)
+
+
+class ModulatedDeformConvPack(ModulatedDeformConv):
+
+    def __init__(self, *args, **kwargs):
+        super(ModulatedDeformConvPack, self).__init__(*args, **kwargs)
+        from ....nn import Conv2d
+        self.conv_offset_mask = Conv2d(self.in_channels,
+                                       self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1],
+                                       kernel_size=self.kernel_size, stride=_pair(self.stride),
+                                       padding=_pair(self.padding), bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset_mask.weight.data.zero_()
+        self.conv_offset_mask.bias.data.zero_()
+
+    def forward(self, x):
+        out = self.conv_offset_mask(x)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        mask = torch.sigmoid(mask)
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                     self.dilation, self.groups, self.deformable_groups)
+
+
+def deform_conv(*a, **k):
+    raise NotImplementedError("DeformConv v1 is exported by the reference but used by no model (SURVEY.md §2b)")
+
+
+class DeformConv(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError("DeformConv v1 is exported by the reference but used by no model (SURVEY.md §2b)")
+
+
+DeformConvPack = DeformConv

@@ -9,6 +9,7 @@ BatchNorm kernel.  Pretrained-weight download (resnet.py:271-309) needs a networ
 """
 import math
 
+import torch
 import torch.nn as nn
 
 from ..nn import Conv2d, BatchNorm2d, MaxPool2d, FusedReLU, Linear
@@ -155,7 +156,9 @@ class ResNet(nn.Module):
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
-                m.weight.data.normal_(0, math.sqrt(2. / n))
+                # draw in logical (OIHW) order like the reference's contiguous weights, then store into the
+                # physically-KRSC parameter: identical values for identical seeds
+                m.weight.data.copy_(torch.empty(m.weight.shape).normal_(0, math.sqrt(2. / n)))
             elif isinstance(m, nn.BatchNorm2d):
                 m.weight.data.fill_(1)
                 m.bias.data.zero_()

@@ -1,0 +1,239 @@
+// Modulated deformable convolution v2 (DCNv2) sampling kernels for gfx950, NHWC activations.
+// Replaces assets/ops/dcn/src/deform_conv_cuda_kernel.cu:569-766 (modulated im2col / col2im / col2im_coord) and,
+// together with the MFMA GEMMs (mr_gemm_nt / mr_gemm_tn), the host functions deform_conv_cuda.cpp:486-679.
+//
+// Differences from the reference by design: the whole batch is processed in one launch and one GEMM (the reference
+// loops over images, one im2col + one cuBLAS GEMM each); activations are channel-contiguous, so every bilinear
+// corner is one 16-byte vector load shared by 8 channels; the column matrix is [pixels][tap*C + c] = the A operand
+// of the NT GEMM against KRSC weights, in the compute dtype.  Offsets / masks are read exactly like the reference
+// does: per sample, as FLAT [2*9][Ho][Wo] / [9][Ho][Wo] f32 arrays from the base of that sample's (possibly
+// larger) NCHW buffer (reference quirk Q10) -- their gradients are written back the same way.
+// All three kernels are HBM / L2-bound gather-scatter work; groups = deformable_groups = 1.
+#include "common.h"
+#include "../../include/megreader_hip.h"
+
+namespace mr {
+
+struct DcnGeom {
+  int N, H, W, C, Ho, Wo, kh, kw, stride, pad, dil;
+  long long off_bs, msk_bs;  // per-sample strides (elements) of the offset / mask buffers
+};
+
+__device__ __forceinline__ bool dcn_point(const DcnGeom& g, const float* off_b, int tap, int ho, int wo, float& ph,
+                                          float& pw) {
+  const int i = tap / g.kw, j = tap - i * g.kw;
+  const long long o = ((long long)(2 * tap) * g.Ho + ho) * g.Wo + wo;
+  ph = (float)(ho * g.stride - g.pad + i * g.dil) + off_b[o];
+  pw = (float)(wo * g.stride - g.pad + j * g.dil) + off_b[o + (long long)g.Ho * g.Wo];
+  return ph > -1.f && pw > -1.f && ph < (float)g.H && pw < (float)g.W;
+}
+
+// col[p, tap*C + c] = valid ? mask * bilinear(x[n,:,:,c], p_tap) : 0     thread = (p, tap, 16-byte channel vector)
+template <typename T>
+__global__ void dcn2_im2col_kernel(const T* __restrict__ x, const float* __restrict__ offset,
+                                   const float* __restrict__ mask, T* __restrict__ col, DcnGeom g) {
+  constexpr int VEC = VecOf<T>::N;
+  const int cv = g.C / VEC;
+  const int taps = g.kh * g.kw;
+  const long long total = (long long)g.N * g.Ho * g.Wo * taps * cv;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(t % cv) * VEC;
+    long long q = t / cv;
+    const int tap = (int)(q % taps);
+    const long long p = q / taps;
+    const int wo = (int)(p % g.Wo);
+    const long long r = p / g.Wo;
+    const int ho = (int)(r % g.Ho);
+    const int n = (int)(r / g.Ho);
+    float ph, pw;
+    const bool valid = dcn_point(g, offset + n * g.off_bs, tap, ho, wo, ph, pw);
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    if (valid) {
+      const float m = mask[n * g.msk_bs + ((long long)tap * g.Ho + ho) * g.Wo + wo];
+      const int hl = (int)floorf(ph), wl = (int)floorf(pw);
+      const float lh = ph - (float)hl, lw = pw - (float)wl;
+      const int hh = hl + 1, wh = wl + 1;
+      const T* xb = x + (long long)n * g.H * g.W * g.C + c0;
+      const float wgt[4] = {(1.f - lh) * (1.f - lw) * m, (1.f - lh) * lw * m, lh * (1.f - lw) * m, lh * lw * m};
+      const int hs[4] = {hl, hl, hh, hh}, ws[4] = {wl, wh, wl, wh};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (hs[k] < 0 || hs[k] > g.H - 1 || ws[k] < 0 || ws[k] > g.W - 1) continue;
+        const uint4 v = *(const uint4*)(xb + ((long long)hs[k] * g.W + ws[k]) * g.C);
+        const T* pv = (const T*)&v;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += wgt[k] * to_f32(pv[j]);
+      }
+    }
+    uint4 out;
+    T* po = (T*)&out;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) po[j] = from_f32<T>(acc[j]);
+    *(uint4*)(col + p * ((long long)taps * g.C) + (long long)tap * g.C + c0) = out;
+  }
+}
+
+// gradient w.r.t. offsets and mask: one wave per (p, tap), lanes stride the channels, wave reduction.
+//   dmask[tap]      = sum_c gcol * (valid ? bilinear : 0)
+//   doff[2tap+dir]  = sum_c gcol * mask * d bilinear / d p_dir   (0 when invalid)
+template <typename T>
+__global__ void dcn2_coord_kernel(const T* __restrict__ gcol, const T* __restrict__ x,
+                                  const float* __restrict__ offset, const float* __restrict__ mask,
+                                  float* __restrict__ doffset, float* __restrict__ dmask, DcnGeom g) {
+  const int taps = g.kh * g.kw;
+  const int lane = threadIdx.x & 63;
+  const long long item = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long items = (long long)g.N * g.Ho * g.Wo * taps;
+  if (item >= items) return;
+  const int tap = (int)(item % taps);
+  const long long p = item / taps;
+  const int wo = (int)(p % g.Wo);
+  const long long r = p / g.Wo;
+  const int ho = (int)(r % g.Ho);
+  const int n = (int)(r / g.Ho);
+  float ph, pw;
+  const bool valid = dcn_point(g, offset + n * g.off_bs, tap, ho, wo, ph, pw);
+  float dm = 0.f, dh = 0.f, dw = 0.f;
+  if (valid) {
+    const float m = mask[n * g.msk_bs + ((long long)tap * g.Ho + ho) * g.Wo + wo];
+    const int hl = (int)floorf(ph), wl = (int)floorf(pw);
+    const float lh = ph - (float)hl, lw = pw - (float)wl;
+    const int hh = hl + 1, wh = wl + 1;
+    const bool o1 = hl >= 0 && wl >= 0, o2 = hl >= 0 && wh <= g.W - 1, o3 = hh <= g.H - 1 && wl >= 0,
+               o4 = hh <= g.H - 1 && wh <= g.W - 1;
+    const T* xb = x + (long long)n * g.H * g.W * g.C;
+    const T* gp = gcol + p * ((long long)taps * g.C) + (long long)tap * g.C;
+    for (int c = lane; c < g.C; c += 64) {
+      const float gv = to_f32(gp[c]);
+      const float v1 = o1 ? to_f32(xb[((long long)hl * g.W + wl) * g.C + c]) : 0.f;
+      const float v2 = o2 ? to_f32(xb[((long long)hl * g.W + wh) * g.C + c]) : 0.f;
+      const float v3 = o3 ? to_f32(xb[((long long)hh * g.W + wl) * g.C + c]) : 0.f;
+      const float v4 = o4 ? to_f32(xb[((long long)hh * g.W + wh) * g.C + c]) : 0.f;
+      dm += gv * ((1.f - lh) * (1.f - lw) * v1 + (1.f - lh) * lw * v2 + lh * (1.f - lw) * v3 + lh * lw * v4);
+      dh += gv * m * (-(1.f - lw) * v1 - lw * v2 + (1.f - lw) * v3 + lw * v4);
+      dw += gv * m * (-(1.f - lh) * v1 + (1.f - lh) * v2 - lh * v3 + lh * v4);
+    }
+  }
+  dm = wave_sum(dm);
+  dh = wave_sum(dh);
+  dw = wave_sum(dw);
+  if (lane == 0) {
+    const long long hw = (long long)g.Ho * g.Wo, o = (long long)ho * g.Wo + wo;
+    doffset[n * g.off_bs + (2 * tap) * hw + o] = dh;
+    doffset[n * g.off_bs + (2 * tap + 1) * hw + o] = dw;
+    dmask[n * g.msk_bs + tap * hw + o] = dm;
+  }
+}
+
+// gradient w.r.t. the input: dx[n, corner, c] += gcol * mask * bilinear weight   (f32 atomics; 4 corners)
+template <typename T>
+__global__ void dcn2_col2im_kernel(const T* __restrict__ gcol, const float* __restrict__ offset,
+                                   const float* __restrict__ mask, float* __restrict__ dx, DcnGeom g) {
+  const int taps = g.kh * g.kw;
+  const long long total = (long long)g.N * g.Ho * g.Wo * taps * g.C;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(t % g.C);
+    long long q = t / g.C;
+    const int tap = (int)(q % taps);
+    const long long p = q / taps;
+    const int wo = (int)(p % g.Wo);
+    const long long r = p / g.Wo;
+    const int ho = (int)(r % g.Ho);
+    const int n = (int)(r / g.Ho);
+    float ph, pw;
+    if (!dcn_point(g, offset + n * g.off_bs, tap, ho, wo, ph, pw)) continue;
+    const float m = mask[n * g.msk_bs + ((long long)tap * g.Ho + ho) * g.Wo + wo];
+    const float gv = to_f32(gcol[p * ((long long)taps * g.C) + (long long)tap * g.C + c]) * m;
+    if (gv == 0.f) continue;
+    const int hl = (int)floorf(ph), wl = (int)floorf(pw);
+    const float lh = ph - (float)hl, lw = pw - (float)wl;
+    const int hh = hl + 1, wh = wl + 1;
+    float* db = dx + (long long)n * g.H * g.W * g.C + c;
+    if (hl >= 0 && wl >= 0) atomicAdd(db + ((long long)hl * g.W + wl) * g.C, gv * (1.f - lh) * (1.f - lw));
+    if (hl >= 0 && wh <= g.W - 1) atomicAdd(db + ((long long)hl * g.W + wh) * g.C, gv * (1.f - lh) * lw);
+    if (hh <= g.H - 1 && wl >= 0) atomicAdd(db + ((long long)hh * g.W + wl) * g.C, gv * lh * (1.f - lw));
+    if (hh <= g.H - 1 && wh <= g.W - 1) atomicAdd(db + ((long long)hh * g.W + wh) * g.C, gv * lh * lw);
+  }
+}
+
+static inline int grid_for(long long n, int block, int max_blocks = 32768) {
+  long long b = (n + block - 1) / block;
+  if (b > max_blocks) b = max_blocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+static int make_geom(DcnGeom& g, int N, int H, int W, int C, int kh, int kw, int stride, int pad, int dil, int Ho,
+                     int Wo, long long off_bs, long long msk_bs) {
+  g.N = N; g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.kh = kh; g.kw = kw; g.stride = stride; g.pad = pad;
+  g.dil = dil; g.off_bs = off_bs; g.msk_bs = msk_bs;
+  MR_CHECK_ARG(Ho == (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1 &&
+                   Wo == (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1,
+               "dcn: output size %dx%d inconsistent with geometry", Ho, Wo);
+  MR_CHECK_ARG(off_bs >= (long long)2 * kh * kw * Ho * Wo && msk_bs >= (long long)kh * kw * Ho * Wo,
+               "dcn: offset / mask buffers are smaller than the output grid needs");
+  return MR_OK;
+}
+
+}  // namespace mr
+
+using namespace mr;
+
+#define DISPATCH_T(dtype, ...)                                   \
+  if ((dtype) == MR_F32) { typedef float T; __VA_ARGS__; }       \
+  else if ((dtype) == MR_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+  else { mr::set_error("bad dtype %d", (dtype)); return MR_ERR_DTYPE; }
+
+extern "C" {
+
+// x NHWC [N,H,W,C] (`dtype`); offset f32 [N][>= 2*kh*kw*Ho*Wo] / mask f32 [N][>= kh*kw*Ho*Wo] with per-sample
+// strides off_bs / msk_bs; col [N*Ho*Wo, kh*kw*C] (`dtype`)
+int mr_dcn2_im2col(int dtype, const void* x, const float* offset, long long off_bs, const float* mask,
+                   long long msk_bs, void* col, int N, int H, int W, int C, int kh, int kw, int stride, int pad,
+                   int dil, int Ho, int Wo, hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(C % vec == 0, "mr_dcn2_im2col: C (%d) must be a multiple of %d", C, vec);
+  DcnGeom g;
+  int rc = make_geom(g, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo, off_bs, msk_bs);
+  if (rc) return rc;
+  const long long total = (long long)N * Ho * Wo * kh * kw * (C / vec);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_im2col_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
+                                       (const T*)x, offset, mask, (T*)col, g));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+// doffset / dmask: f32 buffers shaped like offset / mask (the entries addressed by the flat [.,Ho,Wo] view are
+// written, the rest must be pre-zeroed by the caller like the reference's torch.zeros_like)
+int mr_dcn2_coord_grad(int dtype, const void* gcol, const void* x, const float* offset, long long off_bs,
+                       const float* mask, long long msk_bs, float* doffset, float* dmask, int N, int H, int W,
+                       int C, int kh, int kw, int stride, int pad, int dil, int Ho, int Wo, hipStream_t stream) {
+  DcnGeom g;
+  int rc = make_geom(g, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo, off_bs, msk_bs);
+  if (rc) return rc;
+  const long long items = (long long)N * Ho * Wo * kh * kw;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_coord_kernel<T>), dim3((unsigned)cdivll(items, 4)), dim3(256), 0, stream,
+                                       (const T*)gcol, (const T*)x, offset, mask, doffset, dmask, g));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+// dx: f32 NHWC [N,H,W,C], pre-zeroed, accumulated with atomics
+int mr_dcn2_col2im(int dtype, const void* gcol, const float* offset, long long off_bs, const float* mask,
+                   long long msk_bs, float* dx, int N, int H, int W, int C, int kh, int kw, int stride, int pad,
+                   int dil, int Ho, int Wo, hipStream_t stream) {
+  DcnGeom g;
+  int rc = make_geom(g, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo, off_bs, msk_bs);
+  if (rc) return rc;
+  const long long total = (long long)N * Ho * Wo * kh * kw * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_col2im_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
+                                       (const T*)gcol, offset, mask, dx, g));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+"""Oracle restatement (torch float64, differentiable) of the reference's CUDA-only modulated deformable conv v2.
+
+Follows assets/ops/dcn/src/deform_conv_cuda_kernel.cu:
+    :466-496  dmcn_im2col_bilinear (corners outside the image contribute 0)
+    :569-632  modulated_deformable_im2col_gpu_kernel: sample at (h_in + i*dil + dh, w_in + j*dil + dw), valid iff
+              h > -1 and w > -1 and h < H and w < W; offsets / mask are read as FLAT [.., Ho, Wo] arrays from the base
+              pointer of offset[b] / mask[b] (:599-612) -- matters when the offset map is larger than the output
+              grid (reference quirk Q10: stride-2 DCN conv with a stride-1 offset conv, backbones/resnet.py:136-142)
+and the host GEMM of assets/ops/dcn/src/deform_conv_cuda.cpp:534-563.  The backward of the op is autograd through
+this forward: SURVEY.md Appendix A.4 verified that the reference's explicit backward kernels (:634-766) equal it.
+
+PARITY STATUS: the reference has no CPU implementation / tests of this op ("parity unpinned" by the reference);
+anchors (tests/test_oracle_dcn.py): zero offsets and unit mask == F.conv2d; integer offsets == shifted conv taps;
+gradcheck of the restatement.
+"""
+import torch
+
+
+def _flat_view(t, rows, Ho, Wo):
+    """t [N, ch, Ho', Wo'] -> flat-reinterpreted [N, rows, Ho, Wo] exactly as the kernel indexes it."""
+    N = t.shape[0]
+    flat = t.reshape(N, -1)
+    need = rows * Ho * Wo
+    if flat.shape[1] < need:
+        raise ValueError("offset/mask buffer smaller than the output grid needs")
+    return flat[:, :need].reshape(N, rows, Ho, Wo)
+
+
+def modulated_deform_conv2d(x, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1):
+    """x [N,C,H,W]; offset [N,2*kh*kw,Ho',Wo'] as (dh, dw) pairs per tap; mask [N,kh*kw,Ho',Wo']; weight [Co,C,kh,kw].
+    groups = deformable_groups = 1 (the only configuration the reference models use)."""
+    N, C, H, W = x.shape
+    Co, _, kh, kw = weight.shape
+    Ho = (H + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
+    Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+    off = _flat_view(offset, 2 * kh * kw, Ho, Wo)
+    msk = _flat_view(mask, kh * kw, Ho, Wo)
+    ho = torch.arange(Ho, dtype=x.dtype).view(1, Ho, 1)
+    wo = torch.arange(Wo, dtype=x.dtype).view(1, 1, Wo)
+    xf = x.reshape(N, C, H * W)
+    cols = []
+    for i in range(kh):
+        for j in range(kw):
+            k = i * kw + j
+            ph = ho * stride - padding + i * dilation + off[:, 2 * k]
+            pw = wo * stride - padding + j * dilation + off[:, 2 * k + 1]
+            valid = (ph > -1) & (pw > -1) & (ph < H) & (pw < W)
+            hl = torch.floor(ph)
+            wl = torch.floor(pw)
+            lh, lw = ph - hl, pw - wl
+            hl, wl = hl.long(), wl.long()
+            hh, wh = hl + 1, wl + 1
+
+            def corner(hc, wc, ok):
+                idx = (hc.clamp(0, H - 1) * W + wc.clamp(0, W - 1)).view(N, 1, Ho * Wo).expand(N, C, Ho * Wo)
+                v = torch.gather(xf, 2, idx).view(N, C, Ho, Wo)
+                return v * ok.view(N, 1, Ho, Wo).to(x.dtype)
+
+            v1 = corner(hl, wl, (hl >= 0) & (wl >= 0))
+            v2 = corner(hl, wh, (hl >= 0) & (wh <= W - 1))
+            v3 = corner(hh, wl, (hh <= H - 1) & (wl >= 0))
+            v4 = corner(hh, wh, (hh <= H - 1) & (wh <= W - 1))
+            w1 = ((1 - lh) * (1 - lw)).unsqueeze(1)
+            w2 = ((1 - lh) * lw).unsqueeze(1)
+            w3 = (lh * (1 - lw)).unsqueeze(1)
+            w4 = (lh * lw).unsqueeze(1)
+            bil = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4
+            cols.append(bil * (valid.to(x.dtype) * msk[:, k]).unsqueeze(1))
+    col = torch.stack(cols, dim=2)  # [N, C, kh*kw, Ho, Wo]
+    y = torch.einsum('nckhw,ock->nohw', col, weight.reshape(Co, C, kh * kw))
+    if bias is not None:
+        y = y + bias.view(1, Co, 1, 1)
+    return y
