@@ -79,7 +79,9 @@ int mr_permute_021(int dtype, const void* src, void* dst, int A, int B, int C, h
 int mr_prep_conv_weight(int dtype, const float* src, long long sk, long long sc, long long sr, long long ss,
                         void* dst_krsc, void* dst_crsk, int K, int C, int R, int S, int Cpad, int ldk,
                         hipStream_t stream);
-int mr_prep_matrix(int dtype, const float* src, void* dst_n, int ldn, void* dst_t, int ldt, int R, int C,
+/* src f32 [R][C] with row stride lds (elements) -> dst_n [R][ldn] and/or dst_t [C][ldt] of `dtype` (rows permuted to
+ * the gate-interleaved order when perm_h > 0) */
+int mr_prep_matrix(int dtype, const float* src, int lds, void* dst_n, int ldn, void* dst_t, int ldt, int R, int C,
                    int perm_h, hipStream_t stream);
 int mr_prep_bias(const float* a, const float* b, float* dst, int R, int perm_h, hipStream_t stream);
 
@@ -170,6 +172,27 @@ int mr_dcn2_coord_grad(int dtype, const void* gcol, const void* x, const float* 
 int mr_dcn2_col2im(int dtype, const void* gcol, const float* offset, long long off_bs, const float* mask,
                    long long msk_bs, float* dx, int N, int H, int W, int C, int kh, int kw, int stride, int pad,
                    int dil, int Ho, int Wo, hipStream_t stream);
+
+/* ---- Attention-GRU decoder step kernels (decoders/attention_decoder.py:146-231; the GEMMs use mr_gemm_nt/tn) ----- */
+int mr_attn_step_fwd(int dtype, const void* hproj, const void* eproj, const float* v, const void* enc, float* weights,
+                     void* context, int N, int T, int Hd, int Ep, hipStream_t stream);
+/* deproj / denc (f32, shared by all steps of a sequence) are accumulated (+=); dv (f32) is accumulated atomically */
+int mr_attn_step_bwd(int dtype, const void* dcontext, const float* dweights, const void* hproj, const void* eproj,
+                     const float* v, const void* enc, const float* weights, void* dhproj, float* deproj, float* dv,
+                     float* denc, int N, int T, int Hd, int Ep, hipStream_t stream);
+int mr_gru_gates_fwd(int dtype, const void* gi_a, const void* gi_b, const void* gh, const void* h, void* hnew,
+                     float* save, int N, int H, hipStream_t stream);
+int mr_gru_gates_bwd(int dtype, const void* dhnew, const float* save, const void* gh, const void* h, void* dgi,
+                     void* dgh, void* dh, int N, int H, hipStream_t stream);
+int mr_nll_step_fwd(int dtype, const void* logits, int ldl, const long long* target, long long tstride,
+                    const float* mask, float* lp, float* loss, long long* argmax, int N, int C, int accumulate,
+                    int softmax_out, hipStream_t stream);
+int mr_nll_step_bwd(int dtype, const float* gloss, const float* lp, const long long* target, long long tstride,
+                    const float* mask, void* dlogits, int ldd, int N, int C, hipStream_t stream);
+int mr_embed_rows_fwd(int dtype, const float* W, const float* b, const long long* idx, long long istride, void* out,
+                      int N, int Hd, int V, hipStream_t stream);
+int mr_embed_rows_bwd(int dtype, const void* g, const long long* idx, long long istride, float* dW, float* db, int N,
+                      int Hd, int V, hipStream_t stream);
 
 /* eval head: softmax over classes of logits [T,N,C] -> f32 [N,C,1,T] (decoders/crnn.py:101-104) */
 int mr_softmax_nc1t(int dtype, const void* logits, int ldl, float* out, int T, int N, int C, hipStream_t stream);

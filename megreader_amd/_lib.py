@@ -34,7 +34,7 @@ SIGNATURES = {
     "mr_colsum": "ippiilis",
     "mr_permute_021": "ippiiis",
     "mr_prep_conv_weight": "ipllllppiiiiiis",
-    "mr_prep_matrix": "ippipiiiis",
+    "mr_prep_matrix": "ipipipiiiis",
     "mr_prep_bias": "pppiis",
     "mr_adam_step": "pppplps",
     "mr_sgd_step": "ppplps",
@@ -59,6 +59,14 @@ SIGNATURES = {
     "mr_dcn2_im2col": "ipplplp" + "i" * 11 + "s",
     "mr_dcn2_coord_grad": "ippplplpp" + "i" * 11 + "s",
     "mr_dcn2_col2im": "ipplplp" + "i" * 11 + "s",
+    "mr_attn_step_fwd": "ipppppp" + "iiii" + "s",
+    "mr_attn_step_bwd": "ippppppppppp" + "iiii" + "s",
+    "mr_gru_gates_fwd": "ippppppiis",
+    "mr_gru_gates_bwd": "ipppppppiis",
+    "mr_nll_step_fwd": "ipiplppppiiiis",
+    "mr_nll_step_bwd": "ippplppiiis",
+    "mr_embed_rows_fwd": "ippplpiiis",
+    "mr_embed_rows_bwd": "ipplppiiis",
     "mr_ctc2d_fwd": "ippppiiiiiipps",
     "mr_ctc2d_bwd": "ippppppppp" + "iiiiiis",
 }

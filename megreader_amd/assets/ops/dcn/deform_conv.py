@@ -51,7 +51,7 @@ class ModulatedDeformConvFunction(Function):
             wk = wk.contiguous()   # physical KRSC f32
         w_n = torch.empty((Co, K), dtype=dtype, device=xi.device)
         w_t = torch.empty((K, Co), dtype=dtype, device=xi.device)
-        call("mr_prep_matrix", dt, ptr(wk), ptr(w_n), K, ptr(w_t), Co, Co, K, 0)
+        call("mr_prep_matrix", dt, ptr(wk), K, ptr(w_n), K, ptr(w_t), Co, Co, K, 0)
         col = torch.empty((N * Ho * Wo, K), dtype=dtype, device=xi.device)
         call("mr_dcn2_im2col", dt, ptr(xi), ptr(off), off_bs, ptr(msk), msk_bs, ptr(col), N, H, W, C, kh, kw,
              stride, padding, dilation, Ho, Wo)

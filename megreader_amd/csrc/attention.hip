@@ -1,0 +1,342 @@
+// Per-step kernels of the Bahdanau-attention GRU decoder (reference decoders/attention_decoder.py:146-231).
+// The GEMMs of a step (hidden/context/word projections, GRU gates, output layer) run on the MFMA NT kernel; these
+// kernels fuse everything between them:
+//   attn_step : energy[n,t] = v . tanh(hproj[n] + eproj[n,t]);  w = softmax_t(energy);  context[n] = sum_t w[n,t] enc[n,t]
+//               (the reference materialises cat([hidden x T, enc]) [N,T,1057] and runs Linear(1057->512) on it every
+//                step; splitting the Linear into its hidden and encoder halves makes eproj a once-per-sequence GEMM)
+//   gru_gates : r,z,n gate algebra of nn.GRUCell (gate order r,z,n) and h' = (1-z) n + z h
+//   nll_step  : log_softmax + NLLLoss(reduction='none') * mask + argmax  (attention_decoder.py:95-106)
+//   embed_rows: word_linear(one_hot(idx)) = W^T[idx] + b
+// One workgroup per batch row; T (<= 64 positions) and the channel counts are tiny: latency-bound step kernels.
+#include "common.h"
+#include "../../include/megreader_hip.h"
+
+namespace mr {
+
+// ---------------------------------------------------------------- attention step
+template <typename T>
+__global__ __launch_bounds__(256) void attn_step_fwd_kernel(const T* __restrict__ hproj, const T* __restrict__ eproj,
+                                                            const float* __restrict__ v, const T* __restrict__ enc,
+                                                            float* __restrict__ weights, T* __restrict__ context,
+                                                            int Tn, int Hd, int Ep) {
+  __shared__ float en[64];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T* hp = hproj + (long long)n * Hd;
+  for (int t = wave; t < Tn; t += 4) {
+    const T* ep = eproj + ((long long)n * Tn + t) * Hd;
+    float s = 0.f;
+    for (int j = lane; j < Hd; j += 64) s += v[j] * tanhf(to_f32(hp[j]) + to_f32(ep[j]));
+    s = wave_sum(s);
+    if (lane == 0) en[t] = s;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float e = lane < Tn ? en[lane] : -INFINITY;
+    const float mx = wave_max(e);
+    float ex = lane < Tn ? expf(e - mx) : 0.f;
+    const float sm = wave_sum(ex);
+    if (lane < Tn) {
+      en[lane] = ex / sm;
+      weights[(long long)n * Tn + lane] = ex / sm;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < Ep; c += 256) {
+    float s = 0.f;
+    for (int t = 0; t < Tn; ++t) s += en[t] * to_f32(enc[((long long)n * Tn + t) * Ep + c]);
+    context[(long long)n * Ep + c] = from_f32<T>(s);
+  }
+}
+
+// backward of one attention step.  deproj / denc are ACCUMULATED (+=) into f32 buffers shared by all steps; dv is
+// accumulated with atomics; dhproj is written.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_step_bwd_kernel(const T* __restrict__ dcontext,
+                                                            const float* __restrict__ dweights,
+                                                            const T* __restrict__ hproj, const T* __restrict__ eproj,
+                                                            const float* __restrict__ v, const T* __restrict__ enc,
+                                                            const float* __restrict__ weights, T* __restrict__ dhproj,
+                                                            float* __restrict__ deproj, float* __restrict__ dv,
+                                                            float* __restrict__ denc, int Tn, int Hd, int Ep) {
+  __shared__ float dw[64], de[64], wsh[64];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int t = tid; t < Tn; t += 256) wsh[t] = weights[(long long)n * Tn + t];
+  // dw[t] = dcontext . enc[n,t]  (+ upstream gradient of the returned attention map)
+  for (int t = wave; t < Tn; t += 4) {
+    float s = 0.f;
+    for (int c = lane; c < Ep; c += 64)
+      s += to_f32(dcontext[(long long)n * Ep + c]) * to_f32(enc[((long long)n * Tn + t) * Ep + c]);
+    s = wave_sum(s);
+    if (lane == 0) dw[t] = s + (dweights ? dweights[(long long)n * Tn + t] : 0.f);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float w = lane < Tn ? wsh[lane] : 0.f;
+    const float d = lane < Tn ? dw[lane] : 0.f;
+    const float dot = wave_sum(w * d);
+    if (lane < Tn) de[lane] = w * (d - dot);
+  }
+  __syncthreads();
+  // denc[n,t,c] += w[t] * dcontext[c]
+  for (int i = tid; i < Tn * Ep; i += 256) {
+    const int t = i / Ep, c = i - t * Ep;
+    denc[((long long)n * Tn + t) * Ep + c] += wsh[t] * to_f32(dcontext[(long long)n * Ep + c]);
+  }
+  // through tanh: g[t,j] = de[t] * v[j] * (1 - th^2);  dhproj[j] = sum_t g; deproj[t,j] += g; dv[j] += de[t]*th
+  for (int j = tid; j < Hd; j += 256) {
+    const float hj = to_f32(hproj[(long long)n * Hd + j]);
+    const float vj = v[j];
+    float dh = 0.f, dvj = 0.f;
+    for (int t = 0; t < Tn; ++t) {
+      const long long o = ((long long)n * Tn + t) * Hd + j;
+      const float th = tanhf(hj + to_f32(eproj[o]));
+      const float g = de[t] * vj * (1.f - th * th);
+      dh += g;
+      deproj[o] += g;
+      dvj += de[t] * th;
+    }
+    dhproj[(long long)n * Hd + j] = from_f32<T>(dh);
+    atomicAdd(dv + j, dvj);
+  }
+}
+
+// ---------------------------------------------------------------- GRU gates (nn.GRUCell, gate order r, z, n)
+// gi = gi_a (+ gi_b) : input projections incl. b_ih;  gh : hidden projection incl. b_hh;  all [N, 3H]
+template <typename T>
+__global__ void gru_gates_fwd_kernel(const T* __restrict__ gi_a, const T* __restrict__ gi_b,
+                                     const T* __restrict__ gh, const T* __restrict__ h, T* __restrict__ hnew,
+                                     float* __restrict__ save, int N, int H) {
+  const long long total = (long long)N * H;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % H);
+    const long long n = i / H;
+    const long long b3 = n * 3 * H;
+    float ir = to_f32(gi_a[b3 + j]), iz = to_f32(gi_a[b3 + H + j]), in_ = to_f32(gi_a[b3 + 2 * H + j]);
+    if (gi_b) {
+      ir += to_f32(gi_b[b3 + j]);
+      iz += to_f32(gi_b[b3 + H + j]);
+      in_ += to_f32(gi_b[b3 + 2 * H + j]);
+    }
+    const float hr = to_f32(gh[b3 + j]), hz = to_f32(gh[b3 + H + j]), hn = to_f32(gh[b3 + 2 * H + j]);
+    const float r = sigmoidf_(ir + hr), z = sigmoidf_(iz + hz);
+    const float nn_ = tanhf_(in_ + r * hn);
+    const float hp = to_f32(h[i]);
+    hnew[i] = from_f32<T>((1.f - z) * nn_ + z * hp);
+    save[b3 + j] = r;
+    save[b3 + H + j] = z;
+    save[b3 + 2 * H + j] = nn_;
+  }
+}
+
+// given dh' : dgi [N,3H] (same for gi_a and gi_b), dgh [N,3H], dh_prev [N,H]
+template <typename T>
+__global__ void gru_gates_bwd_kernel(const T* __restrict__ dhnew, const float* __restrict__ save,
+                                     const T* __restrict__ gh, const T* __restrict__ h, T* __restrict__ dgi,
+                                     T* __restrict__ dgh, T* __restrict__ dh, int N, int H) {
+  const long long total = (long long)N * H;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % H);
+    const long long n = i / H;
+    const long long b3 = n * 3 * H;
+    const float r = save[b3 + j], z = save[b3 + H + j], nn_ = save[b3 + 2 * H + j];
+    const float hn = to_f32(gh[b3 + 2 * H + j]);
+    const float hp = to_f32(h[i]);
+    const float g = to_f32(dhnew[i]);
+    const float dn = g * (1.f - z);
+    const float dz = g * (hp - nn_);
+    const float dpre_n = dn * (1.f - nn_ * nn_);
+    const float dr = dpre_n * hn;
+    const float dpre_r = dr * r * (1.f - r);
+    const float dpre_z = dz * z * (1.f - z);
+    dgi[b3 + j] = from_f32<T>(dpre_r);
+    dgi[b3 + H + j] = from_f32<T>(dpre_z);
+    dgi[b3 + 2 * H + j] = from_f32<T>(dpre_n);
+    dgh[b3 + j] = from_f32<T>(dpre_r);
+    dgh[b3 + H + j] = from_f32<T>(dpre_z);
+    dgh[b3 + 2 * H + j] = from_f32<T>(dpre_n * r);
+    dh[i] = from_f32<T>(g * z);
+  }
+}
+
+// ---------------------------------------------------------------- log-softmax + masked NLL + argmax (one wave per row)
+template <typename T>
+__global__ void nll_step_fwd_kernel(const T* __restrict__ logits, int ldl, const long long* __restrict__ target,
+                                    long long tstride, const float* __restrict__ mask, float* __restrict__ lp,
+                                    float* __restrict__ loss, long long* __restrict__ argmax, int N, int C,
+                                    int accumulate, int softmax_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const T* row = logits + (long long)n * ldl;
+  float mx = -INFINITY;
+  int am = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) {
+    const float x = to_f32(row[c]);
+    if (x > mx) { mx = x; am = c; }
+  }
+  // wave arg-max with first-index tie break
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float omx = __shfl_xor(mx, o, 64);
+    const int oam = __shfl_xor(am, o, 64);
+    if (omx > mx || (omx == mx && oam < am)) { mx = omx; am = oam; }
+  }
+  float se = 0.f;
+  for (int c = lane; c < C; c += 64) se += expf(to_f32(row[c]) - mx);
+  se = wave_sum(se);
+  const float lz = mx + logf(se);
+  for (int c = lane; c < C; c += 64) {
+    const float l = to_f32(row[c]) - lz;
+    lp[(long long)n * C + c] = softmax_out ? expf(l) : l;
+  }
+  if (lane == 0) {
+    if (argmax) argmax[n] = am;
+    if (loss) {
+      const long long tg = target[(long long)n * tstride];
+      const float l = -(to_f32(row[tg]) - lz) * (mask ? mask[n] : 1.f);
+      loss[n] = accumulate ? loss[n] + l : l;
+    }
+  }
+}
+
+// dlogits[n,c] = gloss[n] * mask[n] * (exp(lp[n,c]) - [c == target])
+template <typename T>
+__global__ void nll_step_bwd_kernel(const float* __restrict__ gloss, const float* __restrict__ lp,
+                                    const long long* __restrict__ target, long long tstride,
+                                    const float* __restrict__ mask, T* __restrict__ dlogits, int ldd, int N, int C) {
+  const long long total = (long long)N * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long n = i / C;
+    const float g = gloss[n] * (mask ? mask[n] : 1.f);
+    const float d = expf(lp[i]) - (c == (int)target[n * tstride] ? 1.f : 0.f);
+    dlogits[n * ldd + c] = from_f32<T>(g * d);
+  }
+}
+
+// ---------------------------------------------------------------- embedding rows: out[n,:] = Wt[idx[n],:] + b
+// W is the Linear weight [Hd, V] (row-major, f32): Wt[idx] is column idx of W.
+template <typename T>
+__global__ void embed_rows_fwd_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                      const long long* __restrict__ idx, long long istride, T* __restrict__ out,
+                                      int N, int Hd, int V) {
+  const long long total = (long long)N * Hd;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % Hd);
+    const long long n = i / Hd;
+    const long long k = idx[n * istride];
+    out[i] = from_f32<T>(W[(long long)j * V + k] + (b ? b[j] : 0.f));
+  }
+}
+
+template <typename T>
+__global__ void embed_rows_bwd_kernel(const T* __restrict__ g, const long long* __restrict__ idx, long long istride,
+                                      float* __restrict__ dW, float* __restrict__ db, int N, int Hd, int V) {
+  const long long total = (long long)N * Hd;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % Hd);
+    const long long n = i / Hd;
+    const float gv = to_f32(g[i]);
+    atomicAdd(dW + (long long)j * V + idx[n * istride], gv);
+    if (db) atomicAdd(db + j, gv);
+  }
+}
+
+static inline int grid_for(long long n, int block, int max_blocks = 8192) {
+  long long b = (n + block - 1) / block;
+  if (b > max_blocks) b = max_blocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace mr
+
+using namespace mr;
+
+#define DISPATCH_T(dtype, ...)                                   \
+  if ((dtype) == MR_F32) { typedef float T; __VA_ARGS__; }       \
+  else if ((dtype) == MR_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+  else { mr::set_error("bad dtype %d", (dtype)); return MR_ERR_DTYPE; }
+
+extern "C" {
+
+int mr_attn_step_fwd(int dtype, const void* hproj, const void* eproj, const float* v, const void* enc, float* weights,
+                     void* context, int N, int Tn, int Hd, int Ep, hipStream_t stream) {
+  MR_CHECK_ARG(N > 0 && Tn > 0 && Tn <= 64 && Hd > 0 && Ep > 0, "mr_attn_step_fwd: bad shape (T must be <= 64)");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((attn_step_fwd_kernel<T>), dim3(N), dim3(256), 0, stream, (const T*)hproj,
+                                       (const T*)eproj, v, (const T*)enc, weights, (T*)context, Tn, Hd, Ep));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_attn_step_bwd(int dtype, const void* dcontext, const float* dweights, const void* hproj, const void* eproj,
+                     const float* v, const void* enc, const float* weights, void* dhproj, float* deproj, float* dv,
+                     float* denc, int N, int Tn, int Hd, int Ep, hipStream_t stream) {
+  MR_CHECK_ARG(N > 0 && Tn > 0 && Tn <= 64, "mr_attn_step_bwd: bad shape");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((attn_step_bwd_kernel<T>), dim3(N), dim3(256), 0, stream, (const T*)dcontext,
+                                       dweights, (const T*)hproj, (const T*)eproj, v, (const T*)enc, weights,
+                                       (T*)dhproj, deproj, dv, denc, Tn, Hd, Ep));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_gru_gates_fwd(int dtype, const void* gi_a, const void* gi_b, const void* gh, const void* h, void* hnew,
+                     float* save, int N, int H, hipStream_t stream) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((gru_gates_fwd_kernel<T>), dim3(grid_for((long long)N * H, 256)), dim3(256), 0,
+                                       stream, (const T*)gi_a, (const T*)gi_b, (const T*)gh, (const T*)h, (T*)hnew,
+                                       save, N, H));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_gru_gates_bwd(int dtype, const void* dhnew, const float* save, const void* gh, const void* h, void* dgi,
+                     void* dgh, void* dh, int N, int H, hipStream_t stream) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((gru_gates_bwd_kernel<T>), dim3(grid_for((long long)N * H, 256)), dim3(256), 0,
+                                       stream, (const T*)dhnew, save, (const T*)gh, (const T*)h, (T*)dgi, (T*)dgh,
+                                       (T*)dh, N, H));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+// lp: f32 [N,C] log-probabilities (or probabilities when softmax_out); loss (nullable) f32 [N], accumulate adds to it;
+// target / argmax are i64 (target read with element stride tstride)
+int mr_nll_step_fwd(int dtype, const void* logits, int ldl, const long long* target, long long tstride,
+                    const float* mask, float* lp, float* loss, long long* argmax, int N, int C, int accumulate,
+                    int softmax_out, hipStream_t stream) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((nll_step_fwd_kernel<T>), dim3(cdiv(N, 4)), dim3(256), 0, stream,
+                                       (const T*)logits, ldl, target, tstride, mask, lp, loss, argmax, N, C,
+                                       accumulate, softmax_out));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_nll_step_bwd(int dtype, const float* gloss, const float* lp, const long long* target, long long tstride,
+                    const float* mask, void* dlogits, int ldd, int N, int C, hipStream_t stream) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((nll_step_bwd_kernel<T>), dim3(grid_for((long long)N * C, 256)), dim3(256), 0,
+                                       stream, gloss, lp, target, tstride, mask, (T*)dlogits, ldd, N, C));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_embed_rows_fwd(int dtype, const float* W, const float* b, const long long* idx, long long istride, void* out,
+                      int N, int Hd, int V, hipStream_t stream) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((embed_rows_fwd_kernel<T>), dim3(grid_for((long long)N * Hd, 256)), dim3(256),
+                                       0, stream, W, b, idx, istride, (T*)out, N, Hd, V));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_embed_rows_bwd(int dtype, const void* g, const long long* idx, long long istride, float* dW, float* db, int N,
+                      int Hd, int V, hipStream_t stream) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((embed_rows_bwd_kernel<T>), dim3(grid_for((long long)N * Hd, 256)), dim3(256),
+                                       0, stream, (const T*)g, idx, istride, dW, db, N, Hd, V));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+}  // extern "C"

@@ -183,7 +183,7 @@ __global__ void prep_conv_weight_kernel(const float* __restrict__ src, long long
 // src f32 [R][C] row-major.  dst (T) row r' = perm(r) where, if perm_h > 0, r = q*perm_h + j -> r' = 4*j + q
 // (PyTorch gate-major i,f,g,o rows -> gate-interleaved rows).  dst_n: [R][ldn] normal, dst_t: [C][ldt] transposed.
 template <typename T>
-__global__ void prep_matrix_kernel(const float* __restrict__ src, T* __restrict__ dst_n, int ldn,
+__global__ void prep_matrix_kernel(const float* __restrict__ src, int lds, T* __restrict__ dst_n, int ldn,
                                    T* __restrict__ dst_t, int ldt, int R, int C, int perm_h) {
   const long long total = (long long)R * C;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -196,7 +196,7 @@ __global__ void prep_matrix_kernel(const float* __restrict__ src, T* __restrict_
       const int blk = r / h4, rin = r - blk * h4;
       rp = blk * h4 + 4 * (rin % perm_h) + rin / perm_h;
     }
-    const T v = from_f32<T>(src[i]);
+    const T v = from_f32<T>(src[(long long)r * lds + c]);
     if (dst_n) dst_n[(long long)rp * ldn + c] = v;
     if (dst_t) dst_t[(long long)c * ldt + rp] = v;
   }
@@ -372,12 +372,12 @@ int mr_prep_conv_weight(int dtype, const float* src, long long sk, long long sc,
   return MR_OK;
 }
 
-int mr_prep_matrix(int dtype, const float* src, void* dst_n, int ldn, void* dst_t, int ldt, int R, int C,
+int mr_prep_matrix(int dtype, const float* src, int lds, void* dst_n, int ldn, void* dst_t, int ldt, int R, int C,
                    int perm_h, hipStream_t stream) {
   MR_CHECK_ARG(perm_h == 0 || R % (4 * perm_h) == 0, "mr_prep_matrix: R must be a multiple of 4*perm_h");
   const long long total = (long long)R * C;
   DISPATCH_T(dtype, hipLaunchKernelGGL((prep_matrix_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
-                                       src, (T*)dst_n, ldn, (T*)dst_t, ldt, R, C, perm_h));
+                                       src, lds, (T*)dst_n, ldn, (T*)dst_t, ldt, R, C, perm_h));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

@@ -1,3 +1,4 @@
 """Mirror of reference decoders/__init__.py:1-14 (the recognition heads on the hot path)."""
 from .crnn import CRNNDecoder  # noqa: F401
 from .ctc_decoder2d import CTCDecoder2D  # noqa: F401
+from .attention_decoder import AttentionDecoder  # noqa: F401

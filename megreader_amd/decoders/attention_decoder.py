@@ -1,0 +1,366 @@
+"""Attention (Bahdanau) GRU recognition head on HIP kernels.
+
+Mirror of reference decoders/attention_decoder.py:10-231: same constructor, same module / parameter names
+(`encode.*`, `decoder.{embedding,word_linear,attn.attn,attn.v,rnn,out}`, `onehot_embedding_{x,y}`), same default
+initialisation order, same forward contract (training: `(loss[N], attention[N, max_size, height, max_size])`,
+eval: `pred[N, max_size] int32`), same teacher-forcing coin (`np.random.rand() < 0.5` unless `gt_as_output` is set,
+quirk Q16) and the same loss mask `timestep <= lengths`.
+
+What runs where: the 7-conv encoder uses the HIP conv/BN/pool layers; each decode step is
+  embed_rows -> [GEMM hproj] -> attn_step -> [GEMMs gi_w, gi_c, gh] -> gru_gates -> [GEMM out] -> nll_step
+with the GEMMs on the MFMA NT/TN kernels.  The reference's per-step Linear(1057 -> 512) over cat([hidden x T, enc])
+is split algebraically into hidden and encoder halves, so the encoder half (eproj) is one GEMM per sequence.
+Weights shared by the 32 steps are converted once per forward; their gradients (and those of eproj / enc / v)
+accumulate in f32 buffers across the steps and are handed to autograd by the step that runs backward last (step 0).
+Glue that is pure data movement on tiny tensors (one-hot position embeddings, cat/pad of the encoder sequence) uses
+torch ops.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from .. import get_compute_dtype
+from .._lib import call, dtype_code, ptr, vec_of
+from ..charsets import DefaultCharset
+from ..nn import Conv2d, BatchNorm2d, MaxPool2d, FusedReLU
+
+
+def _ceil_to(x, m):
+    return (x + m - 1) // m * m
+
+
+class _SeqLinear(object):
+    """y = x W^T + b for a weight shared by all steps of one forward pass.  `weight` may be a column slice of a
+    parameter; K is zero-padded to `kp` (x must already be kp wide)."""
+
+    def __init__(self, weight, bias, kp, dtype):
+        self.weight, self.bias = weight, bias
+        self.dtype = dtype
+        v = vec_of(dtype)
+        self.nout, self.k = weight.shape
+        self.kp = kp
+        self.np_ = _ceil_to(self.nout, v)
+        dev = weight.device
+        wd = weight.detach()
+        assert wd.stride(1) == 1 and kp % v == 0 and kp >= self.k
+        self.w_n = torch.zeros((self.nout, kp), dtype=dtype, device=dev)
+        self.w_t = torch.zeros((kp, self.np_), dtype=dtype, device=dev)
+        call("mr_prep_matrix", dtype_code(dtype), ptr(wd), wd.stride(0), ptr(self.w_n), kp, ptr(self.w_t), self.np_,
+             self.nout, self.k, 0)
+        self.bias_d = bias.detach() if bias is not None else None
+        self.gw = None
+        self.gb = None
+        self.calls = 0
+
+    def __call__(self, x):
+        first = self.calls == 0
+        self.calls += 1
+        return _SeqLinearFn.apply(x, self.weight, self.bias, self, first)
+
+
+class _SeqLinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, seq, first):
+        dt = dtype_code(seq.dtype)
+        M = x.shape[0]
+        assert x.dim() == 2 and x.shape[1] == seq.kp and x.is_contiguous() and x.dtype == seq.dtype
+        y = torch.empty((M, seq.np_), dtype=seq.dtype, device=x.device)
+        if seq.np_ != seq.nout:
+            y[:, seq.nout:].zero_()
+        call("mr_gemm_nt", dt, ptr(x), seq.kp, ptr(seq.w_n), seq.kp, ptr(y), seq.np_, ptr(seq.bias_d), 0, M, seq.nout,
+             seq.kp)
+        ctx.save_for_backward(x)
+        ctx.seq, ctx.first = seq, first
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        seq = ctx.seq
+        dt = dtype_code(seq.dtype)
+        M = x.shape[0]
+        g = gy if (gy.is_contiguous() and gy.dtype == seq.dtype) else gy.to(seq.dtype).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, seq.kp), dtype=seq.dtype, device=x.device)
+            call("mr_gemm_nt", dt, ptr(g), seq.np_, ptr(seq.w_t), seq.np_, ptr(dx), seq.kp, 0, 0, M, seq.kp, seq.np_)
+        if seq.gw is None:
+            seq.gw = torch.zeros((seq.np_, seq.kp), dtype=torch.float32, device=x.device)
+            seq.gb = torch.zeros((seq.np_,), dtype=torch.float32, device=x.device)
+        call("mr_gemm_tn", dt, ptr(g), seq.np_, ptr(x), seq.kp, ptr(seq.gw), seq.kp, M, seq.np_, seq.kp, 0,
+             ptr(seq.gb) if seq.bias is not None else 0)
+        gw = gb = None
+        if ctx.first:  # the first forward call runs its backward last: every step has accumulated by now
+            gw = seq.gw[:seq.nout, :seq.k]
+            gb = seq.gb[:seq.nout] if seq.bias is not None else None
+        return dx, gw, gb, None, None
+
+
+class _EmbedRowsFn(Function):
+    """word_linear(one_hot(idx)) = W^T[idx] + b   (attention_decoder.py:212-215)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, idx, state, first):
+        dtype = state['dtype']
+        N, Hd, V = idx.shape[0], weight.shape[0], weight.shape[1]
+        out = torch.empty((N, Hd), dtype=dtype, device=weight.device)
+        call("mr_embed_rows_fwd", dtype_code(dtype), ptr(weight), ptr(bias), ptr(idx), idx.stride(0), ptr(out), N,
+             Hd, V)
+        ctx.save_for_backward(idx)
+        ctx.meta = (state, first, N, Hd, V, dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        state, first, N, Hd, V, dtype = ctx.meta
+        if 'gW' not in state:
+            state['gW'] = torch.zeros((Hd, V), dtype=torch.float32, device=g.device)
+            state['gb'] = torch.zeros((Hd,), dtype=torch.float32, device=g.device)
+        g = g if g.is_contiguous() else g.contiguous()
+        call("mr_embed_rows_bwd", dtype_code(dtype), ptr(g), ptr(idx), idx.stride(0), ptr(state['gW']),
+             ptr(state['gb']), N, Hd, V)
+        if first:
+            return state['gW'], state['gb'], None, None, None
+        return None, None, None, None, None
+
+
+class _AttnStepFn(Function):
+    @staticmethod
+    def forward(ctx, hproj, eproj, enc, v, state, first):
+        dtype = state['dtype']
+        N, Tn, Hd = eproj.shape
+        Ep = enc.shape[2]
+        w = torch.empty((N, Tn), dtype=torch.float32, device=hproj.device)
+        context = torch.empty((N, Ep), dtype=dtype, device=hproj.device)
+        call("mr_attn_step_fwd", dtype_code(dtype), ptr(hproj), ptr(eproj), ptr(v), ptr(enc), ptr(w), ptr(context), N,
+             Tn, Hd, Ep)
+        ctx.save_for_backward(hproj, eproj, enc, v, w)
+        ctx.meta = (state, first, N, Tn, Hd, Ep, dtype)
+        return w, context
+
+    @staticmethod
+    def backward(ctx, gw, gcontext):
+        hproj, eproj, enc, v, w = ctx.saved_tensors
+        state, first, N, Tn, Hd, Ep, dtype = ctx.meta
+        dev = hproj.device
+        if 'deproj' not in state:
+            state['deproj'] = torch.zeros((N, Tn, Hd), dtype=torch.float32, device=dev)
+            state['denc'] = torch.zeros((N, Tn, Ep), dtype=torch.float32, device=dev)
+            state['dv'] = torch.zeros((Hd,), dtype=torch.float32, device=dev)
+        gcontext = gcontext.to(dtype).contiguous()
+        gwp = gw.to(torch.float32).contiguous() if gw is not None else None
+        dh = torch.empty((N, Hd), dtype=dtype, device=dev)
+        call("mr_attn_step_bwd", dtype_code(dtype), ptr(gcontext), ptr(gwp), ptr(hproj), ptr(eproj), ptr(v), ptr(enc),
+             ptr(w), ptr(dh), ptr(state['deproj']), ptr(state['dv']), ptr(state['denc']), N, Tn, Hd, Ep)
+        if first:
+            return dh, state['deproj'].to(dtype), state['denc'].to(dtype), state['dv'], None, None
+        return dh, None, None, None, None, None
+
+
+class _GruGatesFn(Function):
+    @staticmethod
+    def forward(ctx, gi_a, gi_b, gh, h, dtype):
+        N, H = h.shape
+        hnew = torch.empty_like(h)
+        save = torch.empty((N, 3 * H), dtype=torch.float32, device=h.device)
+        call("mr_gru_gates_fwd", dtype_code(dtype), ptr(gi_a), ptr(gi_b), ptr(gh), ptr(h), ptr(hnew), ptr(save), N, H)
+        ctx.save_for_backward(save, gh, h)
+        ctx.dtype = dtype
+        return hnew
+
+    @staticmethod
+    def backward(ctx, g):
+        save, gh, h = ctx.saved_tensors
+        N, H = h.shape
+        dtype = ctx.dtype
+        g = g.to(dtype).contiguous()
+        dgi = torch.empty((N, 3 * H), dtype=dtype, device=h.device)
+        dgh = torch.empty((N, 3 * H), dtype=dtype, device=h.device)
+        dh = torch.empty_like(h)
+        call("mr_gru_gates_bwd", dtype_code(dtype), ptr(g), ptr(save), ptr(gh), ptr(h), ptr(dgi), ptr(dgh), ptr(dh), N,
+             H)
+        return dgi, dgi, dgh, dh, None
+
+
+class _NllStepFn(Function):
+    """loss[n] = NLLLoss(log_softmax(logits), target)[n] * mask[n]; also returns argmax (attention_decoder.py:95-106)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, mask, C):
+        N = logits.shape[0]
+        dev = logits.device
+        lp = torch.empty((N, C), dtype=torch.float32, device=dev)
+        loss = torch.empty((N,), dtype=torch.float32, device=dev)
+        am = torch.empty((N,), dtype=torch.int64, device=dev)
+        call("mr_nll_step_fwd", dtype_code(logits.dtype), ptr(logits), logits.stride(0), ptr(target), target.stride(0),
+             ptr(mask), ptr(lp), ptr(loss), ptr(am), N, C, 0, 0)
+        ctx.save_for_backward(lp, target, mask)
+        ctx.meta = (N, C, logits.shape[1], logits.dtype)
+        ctx.mark_non_differentiable(am)
+        return loss, am
+
+    @staticmethod
+    def backward(ctx, gloss, _gam):
+        lp, target, mask = ctx.saved_tensors
+        N, C, ld, dtype = ctx.meta
+        gl = gloss.to(torch.float32).contiguous()
+        d = torch.zeros((N, ld), dtype=dtype, device=lp.device)
+        call("mr_nll_step_bwd", dtype_code(dtype), ptr(gl), ptr(lp), ptr(target), target.stride(0), ptr(mask), ptr(d),
+             ld, N, C)
+        return d, None, None, None
+
+
+class Attn(nn.Module):
+    """parameter holder with the reference's names / init (attention_decoder.py:134-144)."""
+
+    def __init__(self, method, hidden_dims, embed_size):
+        super(Attn, self).__init__()
+        self.method = method
+        self.hidden_dims = hidden_dims
+        self.embed_size = embed_size
+        self.attn = nn.Linear(2 * self.hidden_dims + embed_size, hidden_dims)
+        self.v = nn.Parameter(torch.rand(hidden_dims))
+        stdv = 1. / np.sqrt(self.v.size(0))
+        self.v.data.normal_(mean=0, std=stdv)
+
+
+class AttentionRNNCell(nn.Module):
+    """parameter holder (attention_decoder.py:180-198); the step itself is driven by AttentionDecoder."""
+
+    def __init__(self, hidden_dims, embedded_dims, nr_classes, n_layers=1, dropout_p=0, bidirectional=False):
+        super(AttentionRNNCell, self).__init__()
+        self.hidden_dims = hidden_dims
+        self.embedded_dims = embedded_dims
+        self.nr_classes = nr_classes
+        self.n_layers = n_layers
+        self.dropout_p = dropout_p
+        self.embedding = nn.Embedding(nr_classes, nr_classes)
+        self.embedding.weight.data = torch.eye(nr_classes)
+        self.dropout = nn.Dropout(dropout_p)
+        self.word_linear = nn.Linear(nr_classes, hidden_dims)
+        self.attn = Attn('concat', hidden_dims, embedded_dims)
+        self.rnn = nn.GRUCell(2 * hidden_dims + embedded_dims, hidden_dims)
+        self.out = nn.Linear(hidden_dims, nr_classes)
+
+
+class AttentionDecoder(nn.Module):
+    def __init__(self, in_channels, charset=DefaultCharset(), inner_channels=512, max_size=32, height=1,
+                 gt_as_output=None, step_dropout=0, **kwargs):
+        super(AttentionDecoder, self).__init__()
+        if step_dropout:
+            raise NotImplementedError("step_dropout > 0 is not used by any reference experiment")
+        self.inner_channels = inner_channels
+        self.encode = self._init_encoder(in_channels)
+        self.max_size = max_size
+        self.charset = charset
+        self.height = height
+        self.decoder = AttentionRNNCell(inner_channels, max_size + height, len(charset))
+        self.step_dropout = step_dropout
+        self.onehot_embedding_x = nn.Embedding(max_size, max_size)
+        self.onehot_embedding_x.weight.data = torch.eye(max_size)
+        self.onehot_embedding_y = nn.Embedding(height, height)
+        self.onehot_embedding_y.weight.data = torch.eye(height)
+        self.gt_as_output = gt_as_output
+        self.loss_function = nn.NLLLoss(reduction='none')
+
+    def _init_encoder(self, in_channels, stride=(2, 1), padding=(0, 1)):
+        c = self.inner_channels
+        return nn.Sequential(
+            self.conv_bn_relu(in_channels, c), self.conv_bn_relu(c, c), MaxPool2d((2, 2), (2, 2), (0, 0)),
+            self.conv_bn_relu(c, c), self.conv_bn_relu(c, c), MaxPool2d(stride, stride, (0, 0)),
+            self.conv_bn_relu(c, c), self.conv_bn_relu(c, c), MaxPool2d(stride, stride, (0, 0)),
+            self.conv_bn_relu(c, c, kernel_size=(2, 3), stride=stride, padding=padding))
+
+    def _get_gt_as_output(self):
+        if self.gt_as_output is not None:
+            return self.gt_as_output
+        return np.random.rand() < 0.5
+
+    def conv_bn_relu(self, input_channels, output_channels, kernel_size=3, stride=1, padding=1):
+        return nn.Sequential(Conv2d(input_channels, output_channels, kernel_size=kernel_size, stride=stride,
+                                    padding=padding),
+                             BatchNorm2d(output_channels, fuse_relu=True), FusedReLU())
+
+    def _sequence(self, feature):
+        """encoder features + one-hot position embeddings as [N, T, Ep] (Ep = 545 padded to one vector)."""
+        dtype = get_compute_dtype()
+        seq = self.encode(feature)                       # logical [N, C, height, max_size]
+        N, C, Hh, Ww = seq.shape
+        if Hh != self.height or Ww != self.max_size:
+            raise RuntimeError("attention encoder output %dx%d does not match height=%d, max_size=%d"
+                               % (Hh, Ww, self.height, self.max_size))
+        dev = seq.device
+        iy, ix = torch.meshgrid(torch.arange(self.height, device=dev), torch.arange(self.max_size, device=dev),
+                                indexing='ij')
+        emb_x = self.onehot_embedding_x(ix).to(dtype)     # [h, w, max_size]
+        emb_y = self.onehot_embedding_y(iy).to(dtype)     # [h, w, height]
+        T = self.height * self.max_size
+        feat = seq.permute(0, 2, 3, 1).reshape(N, T, C)   # NHWC view -> [N, T, C]
+        parts = [feat.to(dtype), emb_y.reshape(1, T, -1).expand(N, -1, -1), emb_x.reshape(1, T, -1).expand(N, -1, -1)]
+        E = C + self.height + self.max_size
+        Ep = _ceil_to(E, vec_of(dtype))
+        if Ep != E:
+            parts.append(torch.zeros((N, T, Ep - E), dtype=dtype, device=dev))
+        return torch.cat(parts, dim=2).contiguous(), E, dtype
+
+    def forward(self, feature, targets=None, lengths=None, train=False):
+        if not feature.is_cuda:
+            raise NotImplementedError("megreader_amd decoders run on the GPU only")
+        enc, E, dtype = self._sequence(feature)
+        N, T, Ep = enc.shape
+        Hd = self.inner_channels
+        cell = self.decoder
+        C = len(self.charset)
+        dev = enc.device
+        Wa = cell.attn.attn.weight
+        lin_e = _SeqLinear(Wa[:, Hd:Hd + E], cell.attn.attn.bias, Ep, dtype)
+        lin_h = _SeqLinear(Wa[:, :Hd], None, Hd, dtype)
+        lin_iw = _SeqLinear(cell.rnn.weight_ih[:, :Hd], cell.rnn.bias_ih, Hd, dtype)
+        lin_ic = _SeqLinear(cell.rnn.weight_ih[:, Hd:Hd + E], None, Ep, dtype)
+        lin_hh = _SeqLinear(cell.rnn.weight_hh, cell.rnn.bias_hh, Hd, dtype)
+        lin_out = _SeqLinear(cell.out.weight, cell.out.bias, Hd, dtype)
+        eproj = lin_e(enc.view(N * T, Ep))[:, :Hd].reshape(N, T, Hd)
+        if not eproj.is_contiguous():
+            eproj = eproj.contiguous()
+        emb_state = {'dtype': dtype}
+        att_state = {'dtype': dtype}
+        hidden = torch.zeros((N, Hd), dtype=dtype, device=dev)
+        timestep_input = torch.full((N,), int(self.charset.blank), dtype=torch.int64, device=dev)
+
+        def step(t, word_idx, hidden):
+            first = t == 0
+            word = _EmbedRowsFn.apply(cell.word_linear.weight, cell.word_linear.bias, word_idx, emb_state, first)
+            w, context = _AttnStepFn.apply(lin_h(hidden), eproj, enc, cell.attn.v, att_state, first)
+            hnew = _GruGatesFn.apply(lin_iw(word), lin_ic(context), lin_hh(hidden), hidden, dtype)
+            return lin_out(hnew), hnew, w
+
+        if self.training:
+            targets = targets.to(device=dev, dtype=torch.long)
+            lengths_d = lengths.to(dev)
+            loss = None
+            atts = []
+            for timestep in range(self.max_size):
+                logits, hidden, w = step(timestep, timestep_input, hidden)
+                mask = (timestep <= lengths_d).type(torch.float)
+                l, am = _NllStepFn.apply(logits, targets[:, timestep], mask, C)
+                loss = l if loss is None else loss + l
+                atts.append(w.unsqueeze(1))
+                timestep_input = targets[:, timestep] if self._get_gt_as_output() else am
+            attention_pred = torch.cat(atts, dim=1)
+            return loss, attention_pred.view(N, -1, self.height, self.max_size)
+        else:
+            pred = torch.full((N, self.max_size), int(self.charset.blank), dtype=torch.int32, device=dev)
+            probs = torch.empty((N, C), dtype=torch.float32, device=dev)
+            am = torch.empty((N,), dtype=torch.int64, device=dev)
+            with torch.no_grad():
+                for timestep in range(self.max_size):
+                    logits, hidden, w = step(timestep, timestep_input, hidden)
+                    call("mr_nll_step_fwd", dtype_code(dtype), ptr(logits), logits.stride(0), 0, 0, 0, ptr(probs), 0,
+                         ptr(am), N, C, 0, 1)
+                    timestep_input = am.clone()
+                    pred[:, timestep] = am
+                    if bool((am == self.charset.blank).all()):
+                        break
+            return pred

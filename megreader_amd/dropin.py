@@ -19,8 +19,11 @@ import os
 import sys
 
 OVERRIDES = {
-    "backbones": ("megreader_amd.backbones", ["crnn_backbone"]),
-    "decoders": ("megreader_amd.decoders", ["CRNNDecoder"]),
+    "backbones": ("megreader_amd.backbones", ["crnn_backbone", "resnet18", "resnet34", "resnet50", "resnet101",
+                                              "resnet152", "deformable_resnet50", "resnet50dilated_ppm",
+                                              "Resnet18FPN", "Resnet34FPN", "Resnet50FPN", "Resnet101FPN",
+                                              "Resnet152FPN"]),
+    "decoders": ("megreader_amd.decoders", ["CRNNDecoder", "CTCDecoder2D", "AttentionDecoder"]),
 }
 
 
@@ -32,6 +35,21 @@ def install(reference_root=None):
     sys.modules["apex.parallel"] = _apex.parallel
     from . import ops as _ops
     sys.modules.setdefault("ops", _ops)
+    # `from assets.ops.dcn import ModulatedDeformConv` (backbones/resnet.py:59-64,129-134): the reference's package
+    # imports its CUDA extension at import time, so the HIP mirror is registered under the same dotted name
+    from .assets.ops import dcn as _dcn
+    import types
+    if "assets" not in sys.modules:
+        pkg = types.ModuleType("assets")
+        pkg.__path__ = []
+        sys.modules["assets"] = pkg
+    if "assets.ops" not in sys.modules:
+        sub = types.ModuleType("assets.ops")
+        sub.__path__ = []
+        sys.modules["assets.ops"] = sub
+        sys.modules["assets"].ops = sub
+    sys.modules["assets.ops.dcn"] = _dcn
+    sys.modules["assets.ops"].dcn = _dcn
     if reference_root is None:
         reference_root = os.environ.get("MEGREADER_REFERENCE")
     if reference_root:

@@ -300,7 +300,7 @@ class LinearFn(Function):
         w_n = torch.empty((Nout, K), dtype=dtype, device=x.device)
         w_t = torch.zeros((K, Np), dtype=dtype, device=x.device) if Np != Nout else \
             torch.empty((K, Np), dtype=dtype, device=x.device)
-        call("mr_prep_matrix", dt, ptr(weight), ptr(w_n), K, ptr(w_t), Np, Nout, K, 0)
+        call("mr_prep_matrix", dt, ptr(weight), K, ptr(w_n), K, ptr(w_t), Np, Nout, K, 0)
         y = torch.empty((M, Np), dtype=dtype, device=x.device)
         if Np != Nout:
             y[:, Nout:].zero_()
@@ -370,9 +370,9 @@ class BiLSTMFn(Function):
         whh_t = torch.empty((2, H, 4 * H), dtype=dtype, device=dev)
         bcat = torch.empty((8 * H,), dtype=torch.float32, device=dev)
         for d, (wi, wh, bi, bh) in enumerate(((w_ih, w_hh, b_ih, b_hh), (w_ih_r, w_hh_r, b_ih_r, b_hh_r))):
-            call("mr_prep_matrix", dt, ptr(wi), ptr(wcat) + d * 4 * H * I * es, I, ptr(wcat_t) + d * 4 * H * es,
+            call("mr_prep_matrix", dt, ptr(wi), I, ptr(wcat) + d * 4 * H * I * es, I, ptr(wcat_t) + d * 4 * H * es,
                  8 * H, 4 * H, I, H)
-            call("mr_prep_matrix", dt, ptr(wh), ptr(whh) + d * 4 * H * H * es, H,
+            call("mr_prep_matrix", dt, ptr(wh), H, ptr(whh) + d * 4 * H * H * es, H,
                  ptr(whh_t) + d * 4 * H * H * es, 4 * H, 4 * H, H, H)
             call("mr_prep_bias", ptr(bi), ptr(bh), ptr(bcat) + d * 4 * H * 4, 4 * H, H)
         xproj = torch.empty((T * N, 8 * H), dtype=dtype, device=dev)
@@ -556,6 +556,39 @@ class BilinearFn(Function):
 def interpolate_bilinear(x, size):
     """F.interpolate(x, size, mode='bilinear', align_corners=False)."""
     return BilinearFn.apply(x, tuple(size))
+
+
+class UpsampleAddFn(Function):
+    """F.interpolate(x, size=y.shape[2:], mode='bilinear') + y  (FPN top-down, backbones/fpn_top_down.py:16-19)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        require_cuda(x, y)
+        dtype = get_compute_dtype()
+        dt = dtype_code(dtype)
+        xi, yi = to_internal(x, dtype), to_internal(y, dtype)
+        N, H, W, C = xi.shape
+        _, OH, OW, C2 = yi.shape
+        if C != C2:
+            raise RuntimeError("upsample_add: channel mismatch")
+        out = torch.empty_like(yi)
+        call("mr_copy_channels", dt, ptr(yi), C, 0, ptr(out), C, 0, N * OH * OW, C)
+        call("mr_bilinear_fwd", dt, ptr(xi), ptr(out), N, H, W, C, OH, OW, C, 0, 1)
+        ctx.geom = (N, H, W, C, OH, OW)
+        ctx.dtype = dtype
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        N, H, W, C, OH, OW = ctx.geom
+        g = _grad_internal(g_out, ctx.dtype)
+        dx = torch.empty((N, H, W, C), dtype=ctx.dtype, device=g.device)
+        call("mr_bilinear_bwd", dtype_code(ctx.dtype), ptr(g), ptr(dx), N, H, W, C, OH, OW, C, 0)
+        return dx.permute(0, 3, 1, 2), g_out
+
+
+def upsample_add(x, y):
+    return UpsampleAddFn.apply(x, y)
 
 
 class CatChannelsFn(Function):

@@ -203,14 +203,72 @@ def res50ppm_fixture():
     print("wrote", path, os.path.getsize(path), "bytes; loss", loss_r.tolist())
 
 
+def fpn_attention_fixture():
+    """ResNet50-FPN + AttentionDecoder (experiments/recognition/fpn50-attention-decoder.yaml with
+    backbone_args resnet_pretrained=False -- no network -- and gt_as_output=True for determinism), all of it the
+    unmodified reference on CPU.  Input 64x256 (the decoder's conv encoder requires it)."""
+    from oracle.fpn_attention import FPNAttentionOracle
+    from oracle.crnn import synthetic_batch
+    torch.set_num_threads(8)
+    sm = refimport.import_reference()
+    from concern.charsets import EnglishCharset
+    charset = EnglishCharset()
+    args = {'backbone': 'Resnet50FPN', 'backbone_args': {'resnet_pretrained': False}, 'decoder': 'AttentionDecoder',
+            'decoder_args': {'in_channels': 256, 'charset': charset, 'gt_as_output': True}}
+    torch.manual_seed(WEIGHT_SEED)
+    ref = sm.SequenceRecognitionModel(args, torch.device('cpu'))
+    torch.manual_seed(WEIGHT_SEED)
+    ora = FPNAttentionOracle(len(charset))
+    ref_state = {k.replace('model.module.', ''): v for k, v in ref.state_dict().items()}
+    assert list(ref_state.keys()) == list(ora.state_dict().keys()), \
+        [(a, b) for a, b in zip(ref_state.keys(), ora.state_dict().keys()) if a != b][:5]
+    for k, v in ora.state_dict().items():
+        assert torch.equal(v, ref_state[k]), "seeded init differs at %s" % k
+    batch = synthetic_batch(2, 64, 256, seed=5)
+    out = {'weight_seed': WEIGHT_SEED, 'batch': batch, 'state_checksums': checksums(ref_state),
+           'state_keys': list(ref_state.keys()), 'state_shapes': {k: tuple(v.shape) for k, v in ref_state.items()}}
+    ref.train()
+    ora.train()
+    loss_r, att_r = ref.forward(dict(batch), training=True)
+    loss_r.mean().backward()
+    loss_o, att_o = ora(batch['image'], targets=batch['label'], lengths=batch['length'].long(), train=True)
+    loss_o.mean().backward()
+    assert torch.allclose(loss_r, loss_o, rtol=1e-6, atol=1e-6) and torch.allclose(att_r, att_o, atol=1e-6), \
+        (loss_r, loss_o)
+    grads_r = {k.replace('model.module.', ''): p.grad for k, p in ref.named_parameters()}
+    out['grad_stats'] = {}
+    for k, p in ora.named_parameters():
+        if p.grad is None:
+            assert grads_r[k] is None, k
+            out['grad_stats'][k] = None
+            continue
+        gr = grads_r[k]
+        assert float((p.grad - gr).abs().max()) <= 1e-5 * max(1e-6, float(gr.abs().max())) + 1e-8, k
+        out['grad_stats'][k] = (float(gr.double().norm()), gr.flatten()[:8].clone())
+    out['train_loss'] = loss_r.detach().clone()
+    out['train_attention'] = att_r.detach().clone()
+    ref.eval()
+    ora.eval()
+    with torch.no_grad():
+        pred_r = ref.forward(dict(batch), training=False)
+        pred_o = ora(batch['image'], train=False)
+    assert torch.equal(pred_r, pred_o)
+    out['eval_pred'] = pred_r.clone()
+    path = os.path.join(GOLDEN, "fpn_attention_golden.pt")
+    torch.save(out, path)
+    print("wrote", path, os.path.getsize(path), "bytes; loss", loss_r.tolist())
+
+
 if __name__ == "__main__":
     if not refimport.available():
         raise SystemExit("reference not available: golden vectors can only be regenerated in the build container")
     os.chdir("/tmp")
-    which = sys.argv[1:] or ["crnn", "ctc2d", "res50ppm"]
+    which = sys.argv[1:] or ["crnn", "ctc2d", "res50ppm", "fpn_attention"]
     if "crnn" in which:
         crnn_fixture()
     if "ctc2d" in which:
         ctc2d_fixture()
     if "res50ppm" in which:
         res50ppm_fixture()
+    if "fpn_attention" in which:
+        fpn_attention_fixture()

@@ -60,9 +60,10 @@ class _Bottleneck(nn.Module):
 
 
 class _Res50Dilated(nn.Module):
-    """resnet50 (deep stem) with the ResnetDilated(dilate_scale=8) rewrite already applied."""
+    """resnet50 (deep stem); dilate=True applies the ResnetDilated(dilate_scale=8) rewrite, dilate=False keeps the
+    plain stride-32 network together with its unused `fc` / `smooth` parameters (backbones/resnet.py:210-213)."""
 
-    def __init__(self):
+    def __init__(self, dilate=True):
         super().__init__()
         self.conv1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
@@ -75,18 +76,23 @@ class _Res50Dilated(nn.Module):
         self.layer2 = self._layer(128, 4, 2)
         self.layer3 = self._layer(256, 6, 2)
         self.layer4 = self._layer(512, 3, 2)
-        # parameters the reference creates (and initialises, consuming RNG) but never uses or keeps in ResnetDilated
+        # parameters the reference creates (and initialises, consuming RNG) but never uses; ResnetDilated drops them
         fc = nn.Linear(2048, 1000)
         smooth = nn.Conv2d(2048, 256, 1, 1, 1)
-        for m in list(self.modules()) + [smooth]:
+        if not dilate:
+            self.avgpool = nn.AvgPool2d(7, stride=1)
+            self.fc = fc
+            self.smooth = smooth
+        for m in list(self.modules()) + ([smooth] if dilate else []):
             if isinstance(m, nn.Conv2d):
                 m.weight.data.normal_(0, math.sqrt(2. / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
             elif isinstance(m, nn.BatchNorm2d):
                 m.weight.data.fill_(1)
                 m.bias.data.zero_()
         del fc
-        self._dilate(self.layer3, 2)
-        self._dilate(self.layer4, 4)
+        if dilate:
+            self._dilate(self.layer3, 2)
+            self._dilate(self.layer4, 4)
 
     def _layer(self, planes, blocks, stride):
         down = None
@@ -116,7 +122,11 @@ class _Res50Dilated(nn.Module):
         x = F.relu(self.bn2(self.conv2(x)))
         x = F.relu(self.bn3(self.conv3(x)))
         x = F.max_pool2d(x, 3, 2, 1)
-        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x2 = self.layer1(x)
+        x3 = self.layer2(x2)
+        x4 = self.layer3(x3)
+        x5 = self.layer4(x4)
+        return x2, x3, x4, x5
 
 
 class _PPM(nn.Module):
@@ -130,7 +140,8 @@ class _PPM(nn.Module):
                                        nn.BatchNorm2d(512), nn.ReLU(), nn.Dropout2d(dropout),
                                        nn.Conv2d(512, inner_channels, 1))
 
-    def forward(self, c5):
+    def forward(self, conv_out):
+        c5 = conv_out[-1]
         size = c5.shape[2:]
         outs = [c5] + [F.interpolate(b(c5), size, mode='bilinear', align_corners=False) for b in self.ppm]
         return self.conv_last(torch.cat(outs, 1))
