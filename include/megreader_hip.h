@@ -189,11 +189,6 @@ int mr_nll_step_fwd(int dtype, const void* logits, int ldl, const long long* tar
                     int softmax_out, hipStream_t stream);
 int mr_nll_step_bwd(int dtype, const float* gloss, const float* lp, const long long* target, long long tstride,
                     const float* mask, void* dlogits, int ldd, int N, int C, hipStream_t stream);
-int mr_embed_rows_fwd(int dtype, const float* W, const float* b, const long long* idx, long long istride, void* out,
-                      int N, int Hd, int V, hipStream_t stream);
-int mr_embed_rows_bwd(int dtype, const void* g, const long long* idx, long long istride, float* dW, float* db, int N,
-                      int Hd, int V, hipStream_t stream);
-
 /* eval head: softmax over classes of logits [T,N,C] -> f32 [N,C,1,T] (decoders/crnn.py:101-104) */
 int mr_softmax_nc1t(int dtype, const void* logits, int ldl, float* out, int T, int N, int C, hipStream_t stream);
 

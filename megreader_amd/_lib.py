@@ -65,8 +65,6 @@ SIGNATURES = {
     "mr_gru_gates_bwd": "ipppppppiis",
     "mr_nll_step_fwd": "ipiplppppiiiis",
     "mr_nll_step_bwd": "ippplppiiis",
-    "mr_embed_rows_fwd": "ippplpiiis",
-    "mr_embed_rows_bwd": "ipplppiiis",
     "mr_ctc2d_fwd": "ippppiiiiiipps",
     "mr_ctc2d_bwd": "ippppppppp" + "iiiiiis",
 }

@@ -6,7 +6,6 @@
 //                step; splitting the Linear into its hidden and encoder halves makes eproj a once-per-sequence GEMM)
 //   gru_gates : r,z,n gate algebra of nn.GRUCell (gate order r,z,n) and h' = (1-z) n + z h
 //   nll_step  : log_softmax + NLLLoss(reduction='none') * mask + argmax  (attention_decoder.py:95-106)
-//   embed_rows: word_linear(one_hot(idx)) = W^T[idx] + b
 // One workgroup per batch row; T (<= 64 positions) and the channel counts are tiny: latency-bound step kernels.
 #include "common.h"
 #include "../../include/megreader_hip.h"
@@ -217,36 +216,6 @@ __global__ void nll_step_bwd_kernel(const float* __restrict__ gloss, const float
   }
 }
 
-// ---------------------------------------------------------------- embedding rows: out[n,:] = Wt[idx[n],:] + b
-// W is the Linear weight [Hd, V] (row-major, f32): Wt[idx] is column idx of W.
-template <typename T>
-__global__ void embed_rows_fwd_kernel(const float* __restrict__ W, const float* __restrict__ b,
-                                      const long long* __restrict__ idx, long long istride, T* __restrict__ out,
-                                      int N, int Hd, int V) {
-  const long long total = (long long)N * Hd;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int j = (int)(i % Hd);
-    const long long n = i / Hd;
-    const long long k = idx[n * istride];
-    out[i] = from_f32<T>(W[(long long)j * V + k] + (b ? b[j] : 0.f));
-  }
-}
-
-template <typename T>
-__global__ void embed_rows_bwd_kernel(const T* __restrict__ g, const long long* __restrict__ idx, long long istride,
-                                      float* __restrict__ dW, float* __restrict__ db, int N, int Hd, int V) {
-  const long long total = (long long)N * Hd;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int j = (int)(i % Hd);
-    const long long n = i / Hd;
-    const float gv = to_f32(g[i]);
-    atomicAdd(dW + (long long)j * V + idx[n * istride], gv);
-    if (db) atomicAdd(db + j, gv);
-  }
-}
-
 static inline int grid_for(long long n, int block, int max_blocks = 8192) {
   long long b = (n + block - 1) / block;
   if (b > max_blocks) b = max_blocks;
@@ -319,22 +288,6 @@ int mr_nll_step_bwd(int dtype, const float* gloss, const float* lp, const long l
                     const float* mask, void* dlogits, int ldd, int N, int C, hipStream_t stream) {
   DISPATCH_T(dtype, hipLaunchKernelGGL((nll_step_bwd_kernel<T>), dim3(grid_for((long long)N * C, 256)), dim3(256), 0,
                                        stream, gloss, lp, target, tstride, mask, (T*)dlogits, ldd, N, C));
-  MR_CHECK_LAUNCH();
-  return MR_OK;
-}
-
-int mr_embed_rows_fwd(int dtype, const float* W, const float* b, const long long* idx, long long istride, void* out,
-                      int N, int Hd, int V, hipStream_t stream) {
-  DISPATCH_T(dtype, hipLaunchKernelGGL((embed_rows_fwd_kernel<T>), dim3(grid_for((long long)N * Hd, 256)), dim3(256),
-                                       0, stream, W, b, idx, istride, (T*)out, N, Hd, V));
-  MR_CHECK_LAUNCH();
-  return MR_OK;
-}
-
-int mr_embed_rows_bwd(int dtype, const void* g, const long long* idx, long long istride, float* dW, float* db, int N,
-                      int Hd, int V, hipStream_t stream) {
-  DISPATCH_T(dtype, hipLaunchKernelGGL((embed_rows_bwd_kernel<T>), dim3(grid_for((long long)N * Hd, 256)), dim3(256),
-                                       0, stream, (const T*)g, idx, istride, dW, db, N, Hd, V));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

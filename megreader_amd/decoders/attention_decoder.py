@@ -7,7 +7,7 @@ eval: `pred[N, max_size] int32`), same teacher-forcing coin (`np.random.rand() <
 quirk Q16) and the same loss mask `timestep <= lengths`.
 
 What runs where: the 7-conv encoder uses the HIP conv/BN/pool layers; each decode step is
-  embed_rows -> [GEMM hproj] -> attn_step -> [GEMMs gi_w, gi_c, gh] -> gru_gates -> [GEMM out] -> nll_step
+  [GEMM word] -> [GEMM hproj] -> attn_step -> [GEMMs gi_w, gi_c, gh] -> gru_gates -> [GEMM out] -> nll_step
 with the GEMMs on the MFMA NT/TN kernels.  The reference's per-step Linear(1057 -> 512) over cat([hidden x T, enc])
 is split algebraically into hidden and encoder halves, so the encoder half (eproj) is one GEMM per sequence.
 Weights shared by the 32 steps are converted once per forward; their gradients (and those of eproj / enc / v)
@@ -95,35 +95,6 @@ class _SeqLinearFn(Function):
             gw = seq.gw[:seq.nout, :seq.k]
             gb = seq.gb[:seq.nout] if seq.bias is not None else None
         return dx, gw, gb, None, None
-
-
-class _EmbedRowsFn(Function):
-    """word_linear(one_hot(idx)) = W^T[idx] + b   (attention_decoder.py:212-215)."""
-
-    @staticmethod
-    def forward(ctx, weight, bias, idx, state, first):
-        dtype = state['dtype']
-        N, Hd, V = idx.shape[0], weight.shape[0], weight.shape[1]
-        out = torch.empty((N, Hd), dtype=dtype, device=weight.device)
-        call("mr_embed_rows_fwd", dtype_code(dtype), ptr(weight), ptr(bias), ptr(idx), idx.stride(0), ptr(out), N,
-             Hd, V)
-        ctx.save_for_backward(idx)
-        ctx.meta = (state, first, N, Hd, V, dtype)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        (idx,) = ctx.saved_tensors
-        state, first, N, Hd, V, dtype = ctx.meta
-        if 'gW' not in state:
-            state['gW'] = torch.zeros((Hd, V), dtype=torch.float32, device=g.device)
-            state['gb'] = torch.zeros((Hd,), dtype=torch.float32, device=g.device)
-        g = g if g.is_contiguous() else g.contiguous()
-        call("mr_embed_rows_bwd", dtype_code(dtype), ptr(g), ptr(idx), idx.stride(0), ptr(state['gW']),
-             ptr(state['gb']), N, Hd, V)
-        if first:
-            return state['gW'], state['gb'], None, None, None
-        return None, None, None, None, None
 
 
 class _AttnStepFn(Function):
@@ -321,17 +292,21 @@ class AttentionDecoder(nn.Module):
         lin_ic = _SeqLinear(cell.rnn.weight_ih[:, Hd:Hd + E], None, Ep, dtype)
         lin_hh = _SeqLinear(cell.rnn.weight_hh, cell.rnn.bias_hh, Hd, dtype)
         lin_out = _SeqLinear(cell.out.weight, cell.out.bias, Hd, dtype)
+        Cp = _ceil_to(C, vec_of(dtype))
+        lin_word = _SeqLinear(cell.word_linear.weight, cell.word_linear.bias, Cp, dtype)
         eproj = lin_e(enc.view(N * T, Ep))[:, :Hd].reshape(N, T, Hd)
         if not eproj.is_contiguous():
             eproj = eproj.contiguous()
-        emb_state = {'dtype': dtype}
         att_state = {'dtype': dtype}
         hidden = torch.zeros((N, Hd), dtype=dtype, device=dev)
         timestep_input = torch.full((N,), int(self.charset.blank), dtype=torch.int64, device=dev)
 
         def step(t, word_idx, hidden):
             first = t == 0
-            word = _EmbedRowsFn.apply(cell.word_linear.weight, cell.word_linear.bias, word_idx, emb_state, first)
+            # embedding is a trainable [V, V] table initialised to the identity (attention_decoder.py:190-191): look
+            # the row up (tiny gather, torch) and run word_linear on it
+            emb = torch.nn.functional.embedding(word_idx, cell.embedding.weight)
+            word = lin_word(torch.nn.functional.pad(emb, (0, Cp - C)).to(dtype))
             w, context = _AttnStepFn.apply(lin_h(hidden), eproj, enc, cell.attn.v, att_state, first)
             hnew = _GruGatesFn.apply(lin_iw(word), lin_ic(context), lin_hh(hidden), hidden, dtype)
             return lin_out(hnew), hnew, w
