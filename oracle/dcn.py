@@ -71,3 +71,45 @@ def modulated_deform_conv2d(x, offset, mask, weight, bias=None, stride=1, paddin
     if bias is not None:
         y = y + bias.view(1, Co, 1, 1)
     return y
+
+
+class OracleModulatedDeformConv(torch.nn.Module):
+    """CPU stand-in with the constructor / parameters / init of assets/ops/dcn/modules/deform_conv.py:84-128, used
+    (a) as the `assets.ops.dcn.ModulatedDeformConv` shim when the unmodified reference ResNet is executed on CPU for
+    golden vectors and (b) inside the oracle's own deformable ResNet."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=True):
+        super().__init__()
+        import math
+        assert groups == 1 and deformable_groups == 1
+        ks = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, ks
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.weight = torch.nn.Parameter(torch.Tensor(out_channels, in_channels, *ks))
+        if bias:
+            self.bias = torch.nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        n = in_channels * ks[0] * ks[1]
+        self.weight.data.uniform_(-1. / math.sqrt(n), 1. / math.sqrt(n))
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def forward(self, x, offset, mask):
+        return modulated_deform_conv2d(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                       self.dilation)
+
+
+def perturb_offset_convs(model, seed=99):
+    """The reference zero-initialises every conv2_offset (backbones/resnet.py:222-226), which would leave the
+    deformable sampling trivial (offsets 0, mask 0.5).  Tests give them small seeded random values instead --
+    applied identically to the reference model, the oracle and the HIP model (parameter order = named_parameters)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if 'conv2_offset' in name:
+                if name.endswith('weight'):
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.5)

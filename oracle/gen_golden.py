@@ -259,11 +259,57 @@ def fpn_attention_fixture():
     print("wrote", path, os.path.getsize(path), "bytes; loss", loss_r.tolist())
 
 
+def deformable_resnet_fixture():
+    """deformable_resnet50 (backbones/resnet.py:295-309, the DB detector's backbone) executed by the unmodified
+    reference graph code on CPU, with `assets.ops.dcn.ModulatedDeformConv` (CUDA-only) substituted by the float64-
+    capable oracle module (oracle/dcn.py).  Exercises the stride-2 / stride-1-offset-map quirk (Q10) end to end."""
+    import types
+    from oracle.dcn import OracleModulatedDeformConv, perturb_offset_convs
+    from oracle.res50ppm import _Res50Dilated
+    torch.set_num_threads(8)
+    dcn = types.ModuleType("assets.ops.dcn")
+    dcn.ModulatedDeformConv = OracleModulatedDeformConv
+    refimport.import_reference(dcn_module=dcn)
+    import backbones
+    torch.manual_seed(WEIGHT_SEED)
+    ref = backbones.deformable_resnet50(pretrained=False)
+    torch.manual_seed(WEIGHT_SEED)
+    ora = _Res50Dilated(dilate=False, dcn=True)
+    assert list(ref.state_dict().keys()) == list(ora.state_dict().keys())
+    for k, v in ora.state_dict().items():
+        assert torch.equal(v, ref.state_dict()[k]), "seeded init differs at %s" % k
+    perturb_offset_convs(ref)
+    perturb_offset_convs(ora)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(1, 3, 64, 64, generator=g)
+    ref.train()
+    ora.train()
+    fr, fo = ref(x), ora(x)
+    for a, b in zip(fr, fo):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
+    loss_r = sum(f.square().mean() for f in fr)
+    loss_r.backward()
+    sum(f.square().mean() for f in fo).backward()
+    out = {'weight_seed': WEIGHT_SEED, 'x': x, 'state_checksums': checksums(ref.state_dict()),
+           'state_keys': list(ref.state_dict().keys()), 'features': [f.detach().clone() for f in fr],
+           'loss': float(loss_r), 'grad_stats': {}}
+    go = dict(ora.named_parameters())
+    for k, p in ref.named_parameters():
+        if p.grad is None:
+            out['grad_stats'][k] = None
+            continue
+        assert float((p.grad - go[k].grad).abs().max()) <= 1e-5 * max(1e-6, float(p.grad.abs().max())) + 1e-9, k
+        out['grad_stats'][k] = (float(p.grad.double().norm()), p.grad.flatten()[:8].clone())
+    path = os.path.join(GOLDEN, "deformable_resnet50_golden.pt")
+    torch.save(out, path)
+    print("wrote", path, os.path.getsize(path), "bytes; loss", float(loss_r))
+
+
 if __name__ == "__main__":
     if not refimport.available():
         raise SystemExit("reference not available: golden vectors can only be regenerated in the build container")
     os.chdir("/tmp")
-    which = sys.argv[1:] or ["crnn", "ctc2d", "res50ppm", "fpn_attention"]
+    which = sys.argv[1:] or ["crnn", "ctc2d", "res50ppm", "fpn_attention", "deformable_resnet"]
     if "crnn" in which:
         crnn_fixture()
     if "ctc2d" in which:
@@ -272,3 +318,5 @@ if __name__ == "__main__":
         res50ppm_fixture()
     if "fpn_attention" in which:
         fpn_attention_fixture()
+    if "deformable_resnet" in which:
+        deformable_resnet_fixture()

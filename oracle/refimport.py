@@ -12,7 +12,7 @@ def available():
     return os.path.isdir(os.path.join(REF_ROOT, "backbones"))
 
 
-def import_reference(ops_module=None):
+def import_reference(ops_module=None, dcn_module=None):
     """ops_module: object to expose as the top-level `ops` package (the reference's own `ops` imports its CUDA-only
     extension and cannot be imported on CPU; decoders/ctc_decoder2d.py:12 does `from ops import ctc_loss_2d`).
 
@@ -33,6 +33,13 @@ def import_reference(ops_module=None):
         sys.modules["apex.parallel"] = apex.parallel
     if ops_module is not None:
         sys.modules["ops"] = ops_module
+    if dcn_module is not None:  # `from assets.ops.dcn import ModulatedDeformConv` (backbones/resnet.py:129-134)
+        for name in ("assets", "assets.ops"):
+            if name not in sys.modules:
+                pkg = types.ModuleType(name)
+                pkg.__path__ = []
+                sys.modules[name] = pkg
+        sys.modules["assets.ops.dcn"] = dcn_module
     for name in ("backbones", "decoders", "structure", "concern", "config"):
         mod = sys.modules.get(name)
         if mod is not None and not getattr(mod, "__file__", "").startswith(REF_ROOT):

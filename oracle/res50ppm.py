@@ -41,11 +41,17 @@ oracle_ctc_loss_2d = OracleCTC2D.apply
 
 
 class _Bottleneck(nn.Module):
-    def __init__(self, inplanes, planes, stride=1, downsample=None):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dcn=False):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.with_dcn = dcn
+        if dcn:  # backbones/resnet.py:125-142: 27-channel offset conv (stride 1 ALWAYS) + modulated deformable conv
+            from .dcn import OracleModulatedDeformConv
+            self.conv2_offset = nn.Conv2d(planes, 27, 3, padding=1)
+            self.conv2 = OracleModulatedDeformConv(planes, planes, 3, padding=1, stride=stride, bias=False)
+        else:
+            self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
         self.bn2 = nn.BatchNorm2d(planes)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
         self.bn3 = nn.BatchNorm2d(planes * 4)
@@ -53,7 +59,12 @@ class _Bottleneck(nn.Module):
 
     def forward(self, x):
         y = F.relu(self.bn1(self.conv1(x)))
-        y = F.relu(self.bn2(self.conv2(y)))
+        if self.with_dcn:
+            om = self.conv2_offset(y)
+            y = self.conv2(y, om[:, :18], om[:, -9:].sigmoid())   # resnet.py:162-164
+        else:
+            y = self.conv2(y)
+        y = F.relu(self.bn2(y))
         y = self.bn3(self.conv3(y))
         r = x if self.downsample is None else self.downsample(x)
         return F.relu(y + r)
@@ -63,8 +74,9 @@ class _Res50Dilated(nn.Module):
     """resnet50 (deep stem); dilate=True applies the ResnetDilated(dilate_scale=8) rewrite, dilate=False keeps the
     plain stride-32 network together with its unused `fc` / `smooth` parameters (backbones/resnet.py:210-213)."""
 
-    def __init__(self, dilate=True):
+    def __init__(self, dilate=True, dcn=False):
         super().__init__()
+        self._dcn = dcn
         self.conv1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.conv2 = nn.Conv2d(64, 64, 3, 1, 1, bias=False)
@@ -73,9 +85,9 @@ class _Res50Dilated(nn.Module):
         self.bn3 = nn.BatchNorm2d(128)
         self.inplanes = 128
         self.layer1 = self._layer(64, 3, 1)
-        self.layer2 = self._layer(128, 4, 2)
-        self.layer3 = self._layer(256, 6, 2)
-        self.layer4 = self._layer(512, 3, 2)
+        self.layer2 = self._layer(128, 4, 2, dcn)
+        self.layer3 = self._layer(256, 6, 2, dcn)
+        self.layer4 = self._layer(512, 3, 2, dcn)
         # parameters the reference creates (and initialises, consuming RNG) but never uses; ResnetDilated drops them
         fc = nn.Linear(2048, 1000)
         smooth = nn.Conv2d(2048, 256, 1, 1, 1)
@@ -90,18 +102,22 @@ class _Res50Dilated(nn.Module):
                 m.weight.data.fill_(1)
                 m.bias.data.zero_()
         del fc
+        for m in self.modules():   # resnet.py:222-226: offset convs start at zero
+            if isinstance(m, _Bottleneck) and m.with_dcn:
+                nn.init.constant_(m.conv2_offset.weight, 0)
+                nn.init.constant_(m.conv2_offset.bias, 0)
         if dilate:
             self._dilate(self.layer3, 2)
             self._dilate(self.layer4, 4)
 
-    def _layer(self, planes, blocks, stride):
+    def _layer(self, planes, blocks, stride, dcn=False):
         down = None
         if stride != 1 or self.inplanes != planes * 4:
             down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
                                  nn.BatchNorm2d(planes * 4))
-        layers = [_Bottleneck(self.inplanes, planes, stride, down)]
+        layers = [_Bottleneck(self.inplanes, planes, stride, down, dcn)]
         self.inplanes = planes * 4
-        layers += [_Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        layers += [_Bottleneck(self.inplanes, planes, dcn=dcn) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
     @staticmethod

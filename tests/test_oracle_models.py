@@ -1,0 +1,70 @@
+"""CPU pins of the larger oracle models against the golden vectors produced by the unmodified reference
+(oracle/gen_golden.py): ResNet50-dilated+PPM+2D-CTC and ResNet50-FPN+attention decoder."""
+import os
+
+import pytest
+import torch
+
+from oracle.fpn_attention import FPNAttentionOracle
+from oracle.res50ppm import Res50PPM2DCTCOracle
+
+
+def _check_state(model, golden):
+    state = model.state_dict()
+    assert list(state.keys()) == golden['state_keys']
+    for k, v in state.items():
+        s, a = golden['state_checksums'][k]
+        assert abs(float(v.double().sum()) - s) <= 1e-9 * max(1.0, a), k
+
+
+def test_res50ppm_oracle_matches_reference_golden(golden_dir):
+    torch.set_num_threads(4)
+    g = torch.load(os.path.join(golden_dir, "res50ppm_golden.pt"), weights_only=False)
+    torch.manual_seed(g['weight_seed'])
+    m = Res50PPM2DCTCOracle(dropout=0.0).train()
+    _check_state(m, g)
+    assert len(m.state_dict()) == 377 and sum(p.numel() for p in m.parameters()) == 52746727
+    b = g['batch']
+    loss, pred = m(b['image'], targets=b['label'], lengths=b['length'].long(), train=True)
+    assert float((loss - g['train_loss']).abs().max()) < 1e-4 * float(g['train_loss'].abs().max())
+    loss.mean().backward()
+    for k, p in m.named_parameters():
+        gs = g['grad_stats'][k]
+        if gs is None:
+            assert p.grad is None, k
+        elif gs[0] > 1e-6:
+            assert abs(float(p.grad.double().norm()) - gs[0]) <= 1e-3 * gs[0], k
+
+
+def test_fpn_attention_oracle_matches_reference_golden(golden_dir):
+    torch.set_num_threads(4)
+    g = torch.load(os.path.join(golden_dir, "fpn_attention_golden.pt"), weights_only=False)
+    torch.manual_seed(g['weight_seed'])
+    m = FPNAttentionOracle().train()
+    _check_state(m, g)
+    assert len(m.state_dict()) == 339 + 63
+    b = g['batch']
+    loss, att = m(b['image'], targets=b['label'], lengths=b['length'].long(), train=True)
+    assert float((loss - g['train_loss']).abs().max()) < 1e-4 * float(g['train_loss'].abs().max())
+    assert float((att - g['train_attention']).abs().max()) < 1e-5
+
+
+def test_product_mirrors_share_the_reference_state_dicts(golden_dir):
+    """The HIP mirrors (constructed on CPU, no forward) have the reference's keys, shapes and seeded default init."""
+    from megreader_amd.backbones import resnet50dilated_ppm, Resnet50FPN
+    from megreader_amd.decoders import CTCDecoder2D, AttentionDecoder
+
+    class M(torch.nn.Module):
+        def __init__(self, b, d):
+            super().__init__()
+            self.backbone, self.decoder = b, d
+
+    for name, make in (("res50ppm_golden.pt", lambda: M(resnet50dilated_ppm(), CTCDecoder2D(in_channels=256))),
+                       ("fpn_attention_golden.pt",
+                        lambda: M(Resnet50FPN(resnet_pretrained=False), AttentionDecoder(in_channels=256)))):
+        g = torch.load(os.path.join(golden_dir, name), weights_only=False)
+        torch.manual_seed(g['weight_seed'])
+        m = make()
+        _check_state(m, g)
+        for k, v in m.state_dict().items():
+            assert tuple(v.shape) == g['state_shapes'][k], k
