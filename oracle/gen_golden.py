@@ -278,6 +278,7 @@ def deformable_resnet_fixture():
     assert list(ref.state_dict().keys()) == list(ora.state_dict().keys())
     for k, v in ora.state_dict().items():
         assert torch.equal(v, ref.state_dict()[k]), "seeded init differs at %s" % k
+    init_checksums = checksums(ref.state_dict())
     perturb_offset_convs(ref)
     perturb_offset_convs(ora)
     g = torch.Generator().manual_seed(17)
@@ -290,7 +291,7 @@ def deformable_resnet_fixture():
     loss_r = sum(f.square().mean() for f in fr)
     loss_r.backward()
     sum(f.square().mean() for f in fo).backward()
-    out = {'weight_seed': WEIGHT_SEED, 'x': x, 'state_checksums': checksums(ref.state_dict()),
+    out = {'weight_seed': WEIGHT_SEED, 'x': x, 'state_checksums': init_checksums,
            'state_keys': list(ref.state_dict().keys()), 'features': [f.detach().clone() for f in fr],
            'loss': float(loss_r), 'grad_stats': {}}
     go = dict(ora.named_parameters())
