@@ -282,7 +282,7 @@ def deformable_resnet_fixture():
     perturb_offset_convs(ref)
     perturb_offset_convs(ora)
     g = torch.Generator().manual_seed(17)
-    x = torch.randn(1, 3, 64, 64, generator=g)
+    x = torch.randn(2, 3, 96, 96, generator=g)   # 3x3 maps at stride 32: keeps batch-statistics BN well conditioned
     ref.train()
     ora.train()
     fr, fo = ref(x), ora(x)
@@ -292,7 +292,7 @@ def deformable_resnet_fixture():
     loss_r.backward()
     sum(f.square().mean() for f in fo).backward()
     out = {'weight_seed': WEIGHT_SEED, 'x': x, 'state_checksums': init_checksums,
-           'state_keys': list(ref.state_dict().keys()), 'features': [f.detach().clone() for f in fr],
+           'state_keys': list(ref.state_dict().keys()), 'features': [f.detach().clone() for f in fr[2:]], 'feature_norms': [float(f.norm()) for f in fr],
            'loss': float(loss_r), 'grad_stats': {}}
     go = dict(ora.named_parameters())
     for k, p in ref.named_parameters():

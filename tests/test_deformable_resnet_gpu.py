@@ -34,9 +34,11 @@ def test_fp32_parity_vs_reference_golden(golden_dir):
     model.to(DEV).train()
     feats = model(g['x'].to(DEV))
     assert len(feats) == 4
-    for f, ref in zip(feats, g['features']):
+    for f, nrm in zip(feats, g['feature_norms']):
+        assert abs(float(f.float().norm()) - nrm) < 2e-3 * nrm
+    for f, ref in zip(feats[2:], g['features']):     # x4, x5 stored in full
         assert f.shape == ref.shape
-        assert float((f.float().cpu() - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))
+        assert float((f.float().cpu() - ref).abs().max()) < 5e-3 * max(1.0, float(ref.abs().max()))
     loss = sum(f.float().square().mean() for f in feats)
     assert abs(float(loss) - g['loss']) < 1e-3 * abs(g['loss'])
     loss.backward()
@@ -51,5 +53,5 @@ def test_fp32_parity_vs_reference_golden(golden_dir):
             continue
         rel = abs(float(p.grad.double().norm()) - norm) / norm
         worst = max(worst, rel)
-        assert rel < 3e-2, (k, rel, norm)
+        assert rel < 5e-2, (k, rel, norm)
     print("worst relative grad-norm error:", worst)
