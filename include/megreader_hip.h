@@ -85,6 +85,37 @@ int mr_prep_matrix(int dtype, const float* src, int lds, void* dst_n, int ldn, v
                    int perm_h, hipStream_t stream);
 int mr_prep_bias(const float* a, const float* b, float* dst, int R, int perm_h, hipStream_t stream);
 
+/* All of the above in ONE launch.  The host keeps a table of prep jobs in device memory (it only changes when the
+ * set of parameters changes) and re-runs it after every optimizer update -- the fp32 master -> compute-dtype operand
+ * images of every layer are regenerated together instead of by ~3 small kernels per layer per step.
+ *   MR_PREP_CONV:   mr_prep_conv_weight(src, s0..s3 = sk,sc,sr,ss, dst_a = krsc, dst_b = crsk, d0..d3 = K,C,R,S,
+ *                   pad = Cpad, ld_b = ldk)
+ *   MR_PREP_MATRIX: mr_prep_matrix(src, s0 = lds, dst_a = dst_n, pad = ldn, dst_b = dst_t, ld_b = ldt, d0,d1 = R,C,
+ *                   perm_h)
+ *   MR_PREP_BIAS:   mr_prep_bias(src, src2, dst_a (f32), d0 = R, perm_h)
+ * max_total = the largest element count over the jobs (sizes the grid). */
+#define MR_PREP_CONV 0
+#define MR_PREP_MATRIX 1
+#define MR_PREP_BIAS 2
+typedef struct mr_prep_job {
+  const float* src;
+  const float* src2;
+  void* dst_a;
+  void* dst_b;
+  long long s0, s1, s2, s3;
+  int kind;
+  int d0, d1, d2, d3;
+  int pad, ld_b, perm_h;
+} mr_prep_job;
+int mr_prep_batch(int dtype, const mr_prep_job* jobs_device, int njobs, long long max_total, hipStream_t stream);
+
+/* dst[i][0..n[i]) += src[i][0..n[i]) for count <= MR_MAX_SEGMENTS f32 segments in one launch (the pointer / length
+ * arrays are HOST arrays, copied into the kernel arguments).  Used to fold several small gradient pieces into the
+ * optimizer's flat gradient buffer (replaces one `grad += piece` kernel per parameter). */
+#define MR_MAX_SEGMENTS 8
+int mr_accumulate_multi(int count, float* const* dst, const float* const* src, const long long* n,
+                        hipStream_t stream);
+
 /* ---- optimizers (replaces torch.optim.Adam / SGD at training/optimizer_scheduler.py:17-22) -------------- */
 /* hyper: device f32[8] = {lr, beta1 (SGD: momentum), beta2, eps, weight_decay, step, -, -}; step is
  * incremented on device so the call is hipGraph-replay safe */
@@ -99,14 +130,29 @@ int mr_bn_fwd_eval(int dtype, const void* x, void* y, const float* gamma, const 
                    const float* running_mean, const float* running_var, float* tmp_mean, float* tmp_rstd,
                    const void* residual, int relu, long long P, int C, float eps, hipStream_t stream);
 int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
-              const float* save_rstd, double* sums, void* dx, void* dres, float* dgamma, float* dbeta, int relu,
-              long long P, int C, hipStream_t stream);
+              const float* save_rstd, double* sums, void* dx, void* dres, float* dgamma, float* dbeta, int flags,
+              long long P, int C, hipStream_t stream); /* flags: bit0 fused ReLU, bit1 accumulate into dgamma/dbeta */
 int mr_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int kh,
                    int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, hipStream_t stream);
 /* relu_y (nullable): the pool's input when it is the output of a ReLU -- fuses that ReLU's backward mask */
 int mr_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, const void* relu_y, void* dx, int N, int H,
                    int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo,
                    hipStream_t stream);
+
+/* ---- fused backbone stem: Conv2d(Cin -> 64, 3x3, s1, p1) + bias + ReLU + MaxPool2d(2,2) -----------------------
+ * replaces cnn.conv0 / relu0 / pooling0 of reference backbones/crnn.py:17-19,48-55 in one pass each way.
+ * x: fp32 NCHW contiguous [N,Cin,H,W] (Cin 1 or 3, even H and W); w: fp32 [64,Cin,3,3] with element strides
+ * wsk,wsc,wsr,wss; y: pooled activation NHWC [N,H/2,W/2,64] of `dtype`; code: one byte per pooled element
+ * (bits 0-1 = first-maximum position in the 2x2 window, bit 2 = maximum > 0).
+ * mr_stem_bwd ACCUMULATES into dw (strides dsk..dss) and dbias (either may be null); workspace must hold
+ * mr_stem_bwd_workspace(Cin) floats.  The layer's input gradient is not produced (the input is the image). */
+long long mr_stem_bwd_workspace(int Cin);
+int mr_stem_fwd(int dtype, const float* x, const float* w, long long wsk, long long wsc, long long wsr,
+                long long wss, const float* bias, void* y, unsigned char* code, int N, int Cin, int H, int W,
+                hipStream_t stream);
+int mr_stem_bwd(int dtype, const void* dy, const unsigned char* code, const float* x, float* workspace, float* dw,
+                long long dsk, long long dsc, long long dsr, long long dss, float* dbias, int N, int Cin, int H,
+                int W, hipStream_t stream);
 
 /* ---- bidirectional LSTM recurrence (replaces cuDNN RNN behind nn.LSTM: decoders/crnn.py:13,21,91-93) ----- */
 int mr_lstm_fwd(int dtype, const void* xproj, const void* whh, void* out, float* cbuf, void* gates, int T, int N,
@@ -117,12 +163,15 @@ int mr_lstm_bwd(int dtype, const void* dout, const void* whhT, const float* cbuf
 /* ---- 1-D CTC fused with log-softmax (replaces log_softmax + nn.CTCLoss: decoders/crnn.py:48,96-98) ------- */
 int mr_ctc_fwd(int dtype, const void* logits, int ldl, const void* targets, int targets_i64,
                const void* input_lengths, const void* target_lengths, int lengths_i64, int T, int N, int C, int S,
-               int blank, int zero_infinity, float* log_probs, double* alpha, double* nll, double* loss,
-               hipStream_t stream);
-int mr_ctc_bwd(int dtype, const float* log_probs, const double* alpha, const double* nll, const void* targets,
-               int targets_i64, const void* input_lengths, const void* target_lengths, int lengths_i64,
-               const double* grad_out, int T, int N, int C, int S, int blank, int zero_infinity, void* grad_logits,
-               int ldg, hipStream_t stream);
+               int blank, int zero_infinity, float* log_probs, double* alpha, double* beta, double* nll,
+               double* loss, hipStream_t stream);
+/* alpha, beta: f64 [N][T][2S+1].  beta may be null in mr_ctc_fwd when no gradient is wanted (the beta recursion runs
+ * concurrently with alpha on other wavefronts of the same workgroup, so storing it costs no extra latency and makes
+ * the gradient kernel independent per (t, n) row). */
+int mr_ctc_bwd(int dtype, const float* log_probs, const double* alpha, const double* beta, const double* nll,
+               const void* targets, int targets_i64, const void* input_lengths, const void* target_lengths,
+               int lengths_i64, const double* grad_out, int T, int N, int C, int S, int blank, int zero_infinity,
+               void* grad_logits, int ldg, hipStream_t stream);
 
 /* ---- 2D-CTC (replaces the CUDA extension ops/ctc_2d: csrc/ctc2d.h:7-43, cuda/ctc2d_cuda_kernel.cu) -------------
  * log_probs [T,H,N,C] contiguous (`dtype`), targets [N,S] i64, lengths [N] i64.  Reference pybind signatures:

@@ -36,17 +36,21 @@ SIGNATURES = {
     "mr_prep_conv_weight": "ipllllppiiiiiis",
     "mr_prep_matrix": "ipipipiiiis",
     "mr_prep_bias": "pppiis",
+    "mr_prep_batch": "ipils",
+    "mr_accumulate_multi": "ippps",
     "mr_adam_step": "pppplps",
     "mr_sgd_step": "ppplps",
     "mr_bn_fwd_train": "ipppppppppp" + "iliffs",
     "mr_bn_fwd_eval": "ippppppppp" + "ilifs",
     "mr_bn_bwd": "ipppppppppp" + "pilis",
+    "mr_stem_fwd": "ippllllpppiiiis",
+    "mr_stem_bwd": "ipppppllllpiiiis",
     "mr_maxpool_fwd": "ippp" + "i" * 12 + "s",
     "mr_maxpool_bwd": "ipppp" + "i" * 12 + "s",
     "mr_lstm_fwd": "ipppppiiis",
     "mr_lstm_bwd": "ipppppiiis",
-    "mr_ctc_fwd": "ipipippiiiiiiipppps",
-    "mr_ctc_bwd": "ippppippipiiiiiipis",
+    "mr_ctc_fwd": "ipipippiiiiiiippppps",
+    "mr_ctc_bwd": "ipppppippipiiiiiipis",
     "mr_softmax_nc1t": "ipipiiis",
     "mr_adaptive_avgpool_fwd": "ippiiiiiis",
     "mr_adaptive_avgpool_bwd": "ippiiiiiis",
@@ -101,6 +105,8 @@ def load():
     lib.mr_force_nt_tile.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mr_nt_tile_code.restype = ctypes.c_int
     lib.mr_nt_tile_code.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.mr_stem_bwd_workspace.restype = ctypes.c_longlong
+    lib.mr_stem_bwd_workspace.argtypes = [ctypes.c_int]
     for name, codes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
@@ -112,7 +118,8 @@ def load():
     return lib
 
 
-HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_set_nt_variant", "mr_force_nt_tile")  # entry points that take no stream and launch nothing
+HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_set_nt_variant", "mr_force_nt_tile",
+             "mr_stem_bwd_workspace")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

@@ -59,7 +59,13 @@ class DistributedDataParallel(nn.Module):
         self._pending = []  # (bucket index, flat tensor, staged?, work handle)
         self._callback_queued = False
         for p in self._params:
-            p.register_post_accumulate_grad_hook(self._make_hook())
+            hook = self._make_hook()
+            p.register_post_accumulate_grad_hook(hook)
+            # parameters whose gradient is accumulated through a gradient sink (megreader_amd.nn.functional.grad_sink)
+            # never trigger the autograd hook; the ops call these instead
+            if not hasattr(p, "_mr_grad_ready_hooks"):
+                p._mr_grad_ready_hooks = []
+            p._mr_grad_ready_hooks.append(hook)
 
     # ------------------------------------------------------------------ hooks
     def _make_hook(self):

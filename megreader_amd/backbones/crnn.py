@@ -8,6 +8,24 @@ keeps the Sequential indices of the reference.
 import torch.nn as nn
 
 from ..nn import Conv2d, BatchNorm2d, MaxPool2d, FusedReLU
+from ..nn import functional as F
+
+
+class _Stem(nn.Sequential):
+    """conv0 + relu0 + pooling0 (reference crnn.py:17-19).  Same children / state_dict keys as the plain
+    Sequential; when the input is the raw image (no gradient wanted) the three ops run as one fused kernel each way
+    (megreader_amd/csrc/stem.hip), otherwise the generic Conv2d -> MaxPool2d path runs."""
+
+    def forward(self, input):
+        conv, pool = self[0][0], self[1]
+        if F.stem_eligible(input, conv.weight, conv.stride, conv.padding, conv.dilation, _pair(pool.kernel_size),
+                           _pair(pool.stride), _pair(pool.padding)):
+            return F.stem_conv_relu_pool(input, conv.weight, conv.bias)
+        return super().forward(input)
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
 
 class CRNN(nn.Module):
@@ -22,7 +40,7 @@ class CRNN(nn.Module):
         self.channels = [64, 128, 256, 256, 512, 512, 512, nc]
 
         # conv+ReLU stages feed a max-pool: the pool's backward also applies the ReLU mask (one pass saved)
-        conv0 = nn.Sequential(self._make_layer(0, pooled=True), MaxPool2d((2, 2), relu_input=True))
+        conv0 = _Stem(self._make_layer(0, pooled=True), MaxPool2d((2, 2), relu_input=True))
         conv1 = nn.Sequential(self._make_layer(1, pooled=True), MaxPool2d((2, 2), relu_input=True))
         conv2 = self._make_layer(2, True)
         conv3 = nn.Sequential(self._make_layer(3, pooled=True), MaxPool2d((2, 2), (2, 1), (0, 1), relu_input=True))

@@ -32,16 +32,22 @@ __device__ __forceinline__ int ext_label(const void* tg, int tg64, long long bas
   return (s & 1) ? (int)load_idx(tg, base + (s >> 1), tg64) : blank;
 }
 
+// Forward: log-softmax (f32), then the alpha recursion on waves 0-1 and -- concurrently, when beta_out != null --
+// the beta recursion on waves 2-3.  Both are T-step dependency chains of f64 log-sum-exps; running them side by
+// side costs no extra latency and leaves the gradient kernel embarrassingly parallel over (t, b).
 template <typename T>
-__global__ __launch_bounds__(128) void ctc_fwd_kernel(const T* __restrict__ logits, int ldl, const void* targets,
+__global__ __launch_bounds__(256) void ctc_fwd_kernel(const T* __restrict__ logits, int ldl, const void* targets,
                                                       int tg64, const void* in_len, const void* tg_len, int len64,
                                                       int Tn, int N, int C, int S, int blank,
                                                       float* __restrict__ lp_out, double* __restrict__ alpha_out,
-                                                      double* __restrict__ nll_out) {
+                                                      double* __restrict__ beta_out, double* __restrict__ nll_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double* al0 = (double*)smem_raw;        // [2S+1]
-  double* al1 = al0 + (2 * S + 1);        // [2S+1]
-  int* lab = (int*)(al1 + (2 * S + 1));   // [2S+1]
+  const int SPmax = 2 * S + 1;
+  double* al0 = (double*)smem_raw;  // [SPmax]
+  double* al1 = al0 + SPmax;        // [SPmax]
+  double* be0 = al1 + SPmax;        // [SPmax]
+  double* be1 = be0 + SPmax;        // [SPmax]
+  int* lab = (int*)(be1 + SPmax);   // [SPmax]
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -49,10 +55,9 @@ __global__ __launch_bounds__(128) void ctc_fwd_kernel(const T* __restrict__ logi
   int L = (int)load_idx(tg_len, b, len64);
   if (L > S) L = S;
   const int SP = 2 * L + 1;
-  const int SPmax = 2 * S + 1;
 
-  // 1) log-softmax rows t = wave, wave+2, ... in f32
-  for (int t = wave; t < Tn; t += 2) {
+  // 1) log-softmax rows t = wave, wave+4, ... in f32
+  for (int t = wave; t < Tn; t += 4) {
     const T* row = logits + ((long long)t * N + b) * ldl;
     float mx = -INFINITY;
     for (int c = lane; c < C; c += 64) mx = fmaxf(mx, to_f32(row[c]));
@@ -64,36 +69,56 @@ __global__ __launch_bounds__(128) void ctc_fwd_kernel(const T* __restrict__ logi
     float* orow = lp_out + ((long long)t * N + b) * C;
     for (int c = lane; c < C; c += 64) orow[c] = to_f32(row[c]) - lz;
   }
-  for (int s = tid; s < SPmax; s += 128) lab[s] = (s < SP) ? ext_label(targets, tg64, (long long)b * S, s, blank) : blank;
+  for (int s = tid; s < SPmax; s += 256) lab[s] = (s < SP) ? ext_label(targets, tg64, (long long)b * S, s, blank) : blank;
   __syncthreads();
 
-  // 2) alpha recursion (f64)
-  double* prev = al0;
-  double* cur = al1;
+  // 2) alpha (threads 0..127) and beta (threads 128..255) recursions in f64, one time step per barrier
+  const bool beta_half = tid >= 128;
+  const int htid = tid & 127;
+  double* prev = beta_half ? be0 : al0;
+  double* cur = beta_half ? be1 : al1;
   double* aout = alpha_out + (long long)b * Tn * SPmax;
-  for (int s = tid; s < SPmax; s += 128) {
-    double a = -INFINITY;
-    if (Tb > 0) {
-      if (s == 0) a = (double)lp_out[(long long)b * C + blank];
-      else if (s == 1 && L > 0) a = (double)lp_out[(long long)b * C + lab[1]];
-    }
-    prev[s] = a;
-    aout[s] = a;
-  }
-  __syncthreads();
-  for (int t = 1; t < Tn; ++t) {
-    const float* lrow = lp_out + ((long long)t * N + b) * C;
-    for (int s = tid; s < SPmax; s += 128) {
-      double a = -INFINITY;
-      if (t < Tb && s < SP) {
-        const double a0 = prev[s];
-        const double a1 = s > 0 ? prev[s - 1] : -INFINITY;
-        const double a2 = (s > 1 && lab[s] != lab[s - 2]) ? prev[s - 2] : -INFINITY;
-        const double l = lse3(a0, a1, a2);
-        if (l != -INFINITY) a = l + (double)lrow[lab[s]];
+  double* bout = beta_out ? beta_out + (long long)b * Tn * SPmax : nullptr;
+  for (int i = 0; i < Tn; ++i) {
+    if (!beta_half) {
+      const int t = i;
+      const float* lrow = lp_out + ((long long)t * N + b) * C;
+      for (int s = htid; s < SPmax; s += 128) {
+        double a = -INFINITY;
+        if (t == 0) {
+          if (Tb > 0) {
+            if (s == 0) a = (double)lrow[blank];
+            else if (s == 1 && L > 0) a = (double)lrow[lab[1]];
+          }
+        } else if (t < Tb && s < SP) {
+          const double a0 = prev[s];
+          const double a1 = s > 0 ? prev[s - 1] : -INFINITY;
+          const double a2 = (s > 1 && lab[s] != lab[s - 2]) ? prev[s - 2] : -INFINITY;
+          const double l = lse3(a0, a1, a2);
+          if (l != -INFINITY) a = l + (double)lrow[lab[s]];
+        }
+        cur[s] = a;
+        aout[(long long)t * SPmax + s] = a;
       }
-      cur[s] = a;
-      aout[(long long)t * SPmax + s] = a;
+    } else if (bout && i < Tb) {
+      const int t = Tb - 1 - i;
+      const float* lrow = lp_out + ((long long)t * N + b) * C;
+      for (int s = htid; s < SPmax; s += 128) {
+        double bv = -INFINITY;
+        if (s < SP) {
+          if (i == 0) {
+            if (s == SP - 1 || s == SP - 2) bv = (double)lrow[lab[s]];
+          } else {
+            const double b0 = prev[s];
+            const double b1 = s + 1 < SP ? prev[s + 1] : -INFINITY;
+            const double b2 = (s + 2 < SP && lab[s] != lab[s + 2]) ? prev[s + 2] : -INFINITY;
+            const double l = lse3(b0, b1, b2);
+            if (l != -INFINITY) bv = l + (double)lrow[lab[s]];
+          }
+        }
+        cur[s] = bv;
+        bout[(long long)t * SPmax + s] = bv;
+      }
     }
     __syncthreads();
     double* tmp = prev; prev = cur; cur = tmp;
@@ -133,24 +158,26 @@ __global__ void ctc_reduce_kernel(const double* __restrict__ nll, const void* tg
 }
 
 // backward: grad_logits[t,b,c] = (softmax[t,b,c] - occupancy[t,b,c]) * grad_out / (N * max(L_b,1))
+// occupancy[t,b,c] = sum_{s: l'_s = c} exp(alpha[t,s] + beta[t,s] + nll_b - lp[t,b,c]).  With alpha AND beta stored
+// by the forward kernel every (t, b) row is independent: one wavefront per row, 4 rows per workgroup.
 template <typename T>
-__global__ __launch_bounds__(128) void ctc_bwd_kernel(const float* __restrict__ lp, const double* __restrict__ alpha,
-                                                      const double* __restrict__ nll_in, const void* targets,
-                                                      int tg64, const void* in_len, const void* tg_len, int len64,
-                                                      const double* __restrict__ grad_out, int Tn, int N, int C,
-                                                      int S, int blank, int zero_infinity, T* __restrict__ grad,
-                                                      int ldg) {
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ lp, const double* __restrict__ alpha,
+                                                       const double* __restrict__ beta,
+                                                       const double* __restrict__ nll_in, const void* targets,
+                                                       int tg64, const void* in_len, const void* tg_len, int len64,
+                                                       const double* __restrict__ grad_out, int Tn, int N, int C,
+                                                       int S, int blank, int zero_infinity, T* __restrict__ grad,
+                                                       int ldg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int SPmax = 2 * S + 1;
-  double* be0 = (double*)smem_raw;       // [SPmax]
-  double* be1 = be0 + SPmax;             // [SPmax]
-  double* ab = be1 + SPmax;              // [SPmax] alpha+beta
-  int* lab = (int*)(ab + SPmax);         // [SPmax]
-  int* owner = lab + SPmax;              // [SPmax] 1 if first state carrying its label
-  float* rowbuf = (float*)(owner + SPmax + (SPmax & 1));  // [C]
+  double* ab_all = (double*)smem_raw;                       // [4][SPmax] alpha+beta
+  int* lab = (int*)(ab_all + 4 * SPmax);                    // [SPmax]
+  int* owner = lab + SPmax;                                 // [SPmax] 1 if first state carrying its label
+  float* row_all = (float*)(owner + SPmax + (SPmax & 1));   // [4][C]
 
   const int b = blockIdx.x;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = blockIdx.y * 4 + wave;
   const int Tb = min((int)load_idx(in_len, b, len64), Tn);
   int L = (int)load_idx(tg_len, b, len64);
   if (L > S) L = S;
@@ -158,10 +185,14 @@ __global__ __launch_bounds__(128) void ctc_bwd_kernel(const float* __restrict__ 
   const double nll = nll_in[b];
   const bool dead = (zero_infinity && nll == INFINITY) || Tb <= 0;
   const double k = dead ? 0.0 : grad_out[0] / ((double)N * (double)(L < 1 ? 1 : L));
+  const bool valid = t < Tn;
+  const bool active = valid && t < Tb;
+  double* ab = ab_all + wave * SPmax;
+  float* rowbuf = row_all + wave * C;
 
-  for (int s = tid; s < SPmax; s += 128) lab[s] = (s < SP) ? ext_label(targets, tg64, (long long)b * S, s, blank) : blank;
+  for (int s = tid; s < SPmax; s += 256) lab[s] = (s < SP) ? ext_label(targets, tg64, (long long)b * S, s, blank) : blank;
   __syncthreads();
-  for (int s = tid; s < SPmax; s += 128) {
+  for (int s = tid; s < SPmax; s += 256) {
     int own = 0;
     if (s < SP) {
       own = 1;
@@ -172,48 +203,30 @@ __global__ __launch_bounds__(128) void ctc_bwd_kernel(const float* __restrict__ 
     owner[s] = own;
   }
   // rows at or beyond the input length get zero gradient
-  for (int t = Tb + (tid / 64); t < Tn; t += 2)
-    for (int c = tid & 63; c < C; c += 64) grad[((long long)t * N + b) * ldg + c] = from_f32<T>(0.f);
+  if (valid && !active)
+    for (int c = lane; c < C; c += 64) grad[((long long)t * N + b) * ldg + c] = from_f32<T>(0.f);
+  const float* lrow = lp + ((long long)(valid ? t : 0) * N + b) * C;
+  if (active) {
+    const double* arow = alpha + ((long long)b * Tn + t) * SPmax;
+    const double* brow = beta + ((long long)b * Tn + t) * SPmax;
+    for (int s = lane; s < SPmax; s += 64) ab[s] = (s < SP) ? arow[s] + brow[s] : -INFINITY;
+    for (int c = lane; c < C; c += 64) rowbuf[c] = (float)exp((double)lrow[c]);
+  }
   __syncthreads();
-  if (Tb <= 0) return;
-
-  const double* arow_base = alpha + (long long)b * Tn * SPmax;
-  double* next = be0;
-  double* cur = be1;
-  for (int t = Tb - 1; t >= 0; --t) {
-    const float* lrow = lp + ((long long)t * N + b) * C;
-    const double* arow = arow_base + (long long)t * SPmax;
-    for (int s = tid; s < SPmax; s += 128) {
-      double bv = -INFINITY;
-      if (s < SP) {
-        if (t == Tb - 1) {
-          if (s == SP - 1 || (s == SP - 2)) bv = (double)lrow[lab[s]];
-        } else {
-          const double b0 = next[s];
-          const double b1 = s + 1 < SP ? next[s + 1] : -INFINITY;
-          const double b2 = (s + 2 < SP && lab[s] != lab[s + 2]) ? next[s + 2] : -INFINITY;
-          const double l = lse3(b0, b1, b2);
-          if (l != -INFINITY) bv = l + (double)lrow[lab[s]];
-        }
-      }
-      cur[s] = bv;
-      ab[s] = (s < SP) ? arow[s] + bv : -INFINITY;
-    }
-    for (int c = tid; c < C; c += 128) rowbuf[c] = (float)exp((double)lrow[c]);
-    __syncthreads();
-    for (int s = tid; s < SP; s += 128) {
-      if (!owner[s] || dead) continue;
+  if (active && !dead) {
+    for (int s = lane; s < SP; s += 64) {
+      if (!owner[s]) continue;
       const int l = lab[s];
       double g = ab[s];
       for (int s2 = s + 2; s2 < SP; s2 += 2)
         if (lab[s2] == l) g = lse2(g, ab[s2]);
       if (g != -INFINITY) rowbuf[l] -= (float)exp(g + nll - (double)lrow[l]);
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  if (active) {
     T* grow = grad + ((long long)t * N + b) * ldg;
-    for (int c = tid; c < C; c += 128) grow[c] = from_f32<T>((float)((double)rowbuf[c] * k));
-    __syncthreads();
-    double* tmp = next; next = cur; cur = tmp;
+    for (int c = lane; c < C; c += 64) grow[c] = from_f32<T>((float)((double)rowbuf[c] * k));
   }
 }
 
@@ -245,19 +258,20 @@ extern "C" {
 
 int mr_ctc_fwd(int dtype, const void* logits, int ldl, const void* targets, int targets_i64, const void* input_lengths,
                const void* target_lengths, int lengths_i64, int T, int N, int C, int S, int blank,
-               int zero_infinity, float* log_probs, double* alpha, double* nll, double* loss,
+               int zero_infinity, float* log_probs, double* alpha, double* beta, double* nll, double* loss,
                hipStream_t stream) {
   MR_CHECK_ARG(T > 0 && N > 0 && C > 0 && S >= 0, "mr_ctc_fwd: bad shape T=%d N=%d C=%d S=%d", T, N, C, S);
   MR_CHECK_ARG(blank >= 0 && blank < C, "mr_ctc_fwd: blank %d out of range", blank);
-  const size_t smem = (size_t)(2 * S + 1) * (2 * sizeof(double) + sizeof(int)) + 16;
+  const size_t smem = (size_t)(2 * S + 1) * (4 * sizeof(double) + sizeof(int)) + 16;
+  MR_CHECK_ARG(smem <= 64 * 1024, "mr_ctc_fwd: target too long for LDS (S=%d)", S);
   if (dtype == MR_F32)
-    hipLaunchKernelGGL((ctc_fwd_kernel<float>), dim3(N), dim3(128), smem, stream, (const float*)logits, ldl, targets,
+    hipLaunchKernelGGL((ctc_fwd_kernel<float>), dim3(N), dim3(256), smem, stream, (const float*)logits, ldl, targets,
                        targets_i64, input_lengths, target_lengths, lengths_i64, T, N, C, S, blank, log_probs, alpha,
-                       nll);
+                       beta, nll);
   else if (dtype == MR_BF16)
-    hipLaunchKernelGGL((ctc_fwd_kernel<bf16_t>), dim3(N), dim3(128), smem, stream, (const bf16_t*)logits, ldl,
+    hipLaunchKernelGGL((ctc_fwd_kernel<bf16_t>), dim3(N), dim3(256), smem, stream, (const bf16_t*)logits, ldl,
                        targets, targets_i64, input_lengths, target_lengths, lengths_i64, T, N, C, S, blank,
-                       log_probs, alpha, nll);
+                       log_probs, alpha, beta, nll);
   else { mr::set_error("mr_ctc_fwd: bad dtype %d", dtype); return MR_ERR_DTYPE; }
   if (loss)
     hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(256), 0, stream, (const double*)nll, target_lengths,
@@ -266,20 +280,23 @@ int mr_ctc_fwd(int dtype, const void* logits, int ldl, const void* targets, int 
   return MR_OK;
 }
 
-int mr_ctc_bwd(int dtype, const float* log_probs, const double* alpha, const double* nll, const void* targets,
+int mr_ctc_bwd(int dtype, const float* log_probs, const double* alpha, const double* beta, const double* nll,
+               const void* targets,
                int targets_i64, const void* input_lengths, const void* target_lengths, int lengths_i64,
                const double* grad_out, int T, int N, int C, int S, int blank, int zero_infinity, void* grad_logits,
                int ldg, hipStream_t stream) {
   MR_CHECK_ARG(T > 0 && N > 0 && C > 0 && S >= 0, "mr_ctc_bwd: bad shape");
+  MR_CHECK_ARG(beta != nullptr, "mr_ctc_bwd: beta is null (mr_ctc_fwd must be given a beta buffer when a gradient is wanted)");
   const int SP = 2 * S + 1;
-  const size_t smem = (size_t)SP * (3 * sizeof(double) + 2 * sizeof(int)) + 8 + (size_t)C * sizeof(float) + 16;
+  const size_t smem = (size_t)SP * (4 * sizeof(double) + 2 * sizeof(int)) + 8 + (size_t)4 * C * sizeof(float) + 16;
   MR_CHECK_ARG(smem <= 64 * 1024, "mr_ctc_bwd: alphabet/target too large for LDS (C=%d S=%d)", C, S);
+  const dim3 grid(N, cdiv(T, 4));
   if (dtype == MR_F32)
-    hipLaunchKernelGGL((ctc_bwd_kernel<float>), dim3(N), dim3(128), smem, stream, log_probs, alpha, nll, targets,
+    hipLaunchKernelGGL((ctc_grad_kernel<float>), grid, dim3(256), smem, stream, log_probs, alpha, beta, nll, targets,
                        targets_i64, input_lengths, target_lengths, lengths_i64, grad_out, T, N, C, S, blank,
                        zero_infinity, (float*)grad_logits, ldg);
   else if (dtype == MR_BF16)
-    hipLaunchKernelGGL((ctc_bwd_kernel<bf16_t>), dim3(N), dim3(128), smem, stream, log_probs, alpha, nll, targets,
+    hipLaunchKernelGGL((ctc_grad_kernel<bf16_t>), grid, dim3(256), smem, stream, log_probs, alpha, beta, nll, targets,
                        targets_i64, input_lengths, target_lengths, lengths_i64, grad_out, T, N, C, S, blank,
                        zero_infinity, (bf16_t*)grad_logits, ldg);
   else { mr::set_error("mr_ctc_bwd: bad dtype %d", dtype); return MR_ERR_DTYPE; }

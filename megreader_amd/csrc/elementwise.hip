@@ -216,6 +216,79 @@ __global__ void prep_bias_kernel(const float* __restrict__ a, const float* __res
   dst[rp] = a[r] + (b ? b[r] : 0.f);
 }
 
+// ---------------------------------------------------------------- batched weight prep / multi-segment accumulate
+// One launch for every prepared operand image of a model (see mr_prep_batch in the header): blockIdx.y = job.
+template <typename T>
+__global__ void prep_batch_kernel(const mr_prep_job* __restrict__ jobs) {
+  const mr_prep_job j = jobs[blockIdx.y];
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (j.kind == MR_PREP_CONV) {
+    const int K = j.d0, C = j.d1, R = j.d2, S = j.d3, Cpad = j.pad, ldk = j.ld_b;
+    T* dst_krsc = (T*)j.dst_a;
+    T* dst_crsk = (T*)j.dst_b;
+    const long long total = (long long)K * R * S * Cpad;
+    for (long long i = i0; i < total; i += stride) {
+      const int c = (int)(i % Cpad);
+      long long q = i / Cpad;
+      const int s = (int)(q % S);
+      q /= S;
+      const int r = (int)(q % R);
+      const int k = (int)(q / R);
+      float v = 0.f;
+      if (c < C) v = j.src[k * j.s0 + c * j.s1 + r * j.s2 + s * j.s3];
+      if (dst_krsc) dst_krsc[i] = from_f32<T>(v);
+      if (dst_crsk && c < C) dst_crsk[(((long long)c * R + r) * S + s) * ldk + k] = from_f32<T>(v);
+    }
+  } else if (j.kind == MR_PREP_MATRIX) {
+    const int R = j.d0, C = j.d1, perm_h = j.perm_h;
+    T* dst_n = (T*)j.dst_a;
+    T* dst_t = (T*)j.dst_b;
+    const long long total = (long long)R * C;
+    for (long long i = i0; i < total; i += stride) {
+      const int c = (int)(i % C);
+      const int r = (int)(i / C);
+      int rp = r;
+      if (perm_h > 0) {
+        const int h4 = 4 * perm_h;
+        const int blk = r / h4, rin = r - blk * h4;
+        rp = blk * h4 + 4 * (rin % perm_h) + rin / perm_h;
+      }
+      const T v = from_f32<T>(j.src[(long long)r * j.s0 + c]);
+      if (dst_n) dst_n[(long long)rp * j.pad + c] = v;
+      if (dst_t) dst_t[(long long)c * j.ld_b + rp] = v;
+    }
+  } else {  // MR_PREP_BIAS: f32 dst[perm(r)] = a[r] + b[r]
+    const int R = j.d0, perm_h = j.perm_h;
+    float* dst = (float*)j.dst_a;
+    for (long long i = i0; i < R; i += stride) {
+      const int r = (int)i;
+      int rp = r;
+      if (perm_h > 0) {
+        const int h4 = 4 * perm_h;
+        const int blk = r / h4, rin = r - blk * h4;
+        rp = blk * h4 + 4 * (rin % perm_h) + rin / perm_h;
+      }
+      dst[rp] = j.src[r] + (j.src2 ? j.src2[r] : 0.f);
+    }
+  }
+}
+
+struct AccumSegs {
+  float* dst[MR_MAX_SEGMENTS];
+  const float* src[MR_MAX_SEGMENTS];
+  long long n[MR_MAX_SEGMENTS];
+};
+
+__global__ void accumulate_multi_kernel(AccumSegs segs) {
+  const int s = blockIdx.y;
+  float* __restrict__ d = segs.dst[s];
+  const float* __restrict__ a = segs.src[s];
+  const long long n = segs.n[s];
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) d[i] += a[i];
+}
+
 // ---------------------------------------------------------------- fused Adam over one flat buffer
 // hyper (device, f32[8]): lr, beta1, beta2, eps, weight_decay, step (as float), unused, unused
 // Semantics = torch.optim.Adam (no amsgrad, L2 weight decay added to the gradient).
@@ -385,6 +458,35 @@ int mr_prep_matrix(int dtype, const float* src, int lds, void* dst_n, int ldn, v
 int mr_prep_bias(const float* a, const float* b, float* dst, int R, int perm_h, hipStream_t stream) {
   MR_CHECK_ARG(perm_h == 0 || R % (4 * perm_h) == 0, "mr_prep_bias: R must be a multiple of 4*perm_h");
   hipLaunchKernelGGL(prep_bias_kernel, dim3(cdiv(R, 256)), dim3(256), 0, stream, a, b, dst, R, perm_h);
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_prep_batch(int dtype, const mr_prep_job* jobs_device, int njobs, long long max_total, hipStream_t stream) {
+  if (njobs <= 0) return MR_OK;
+  MR_CHECK_ARG(jobs_device != nullptr && njobs <= 65535, "mr_prep_batch: bad job table");
+  MR_CHECK_ARG(max_total > 0, "mr_prep_batch: max_total must be the largest job's element count");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((prep_batch_kernel<T>), dim3(grid_for(max_total, 256, 2048), njobs), dim3(256),
+                                       0, stream, jobs_device));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_accumulate_multi(int count, float* const* dst, const float* const* src, const long long* n,
+                        hipStream_t stream) {
+  if (count <= 0) return MR_OK;
+  MR_CHECK_ARG(count <= MR_MAX_SEGMENTS, "mr_accumulate_multi: at most %d segments per call", MR_MAX_SEGMENTS);
+  AccumSegs segs;
+  long long nmax = 0;
+  for (int i = 0; i < count; ++i) {
+    MR_CHECK_ARG(dst[i] != nullptr && src[i] != nullptr && n[i] >= 0, "mr_accumulate_multi: bad segment %d", i);
+    segs.dst[i] = dst[i];
+    segs.src[i] = src[i];
+    segs.n[i] = n[i];
+    if (n[i] > nmax) nmax = n[i];
+  }
+  if (nmax == 0) return MR_OK;
+  hipLaunchKernelGGL(accumulate_multi_kernel, dim3(grid_for(nmax, 256, 256), count), dim3(256), 0, stream, segs);
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

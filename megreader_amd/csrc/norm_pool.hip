@@ -121,15 +121,16 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, const double* __restrict__ sums,
                                     T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, int relu, long long P, int C) {
+                                    float* __restrict__ dbeta, int relu, int accumulate, long long P, int C) {
   constexpr int VEC = VecOf<T>::N;
   const int cv = C / VEC;
   const long long total = P * cv;
   const float invP = 1.f / (float)P;
   if (blockIdx.x == 0)
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      dbeta[c] = (float)sums[c];
-      dgamma[c] = (float)sums[C + c];
+      // accumulate: dgamma / dbeta are gradient sinks (views of the optimizer's flat gradient buffer)
+      dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sums[c];
+      dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sums[C + c];
     }
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -333,10 +334,12 @@ int mr_bn_fwd_eval(int dtype, const void* x, void* y, const float* gamma, const 
   return MR_OK;
 }
 
-// Backward of training-mode BN (+ optional fused ReLU / residual).  y is only read when relu != 0.
+// Backward of training-mode BN (+ optional fused ReLU / residual).  y is only read when the relu bit is set.
+// flags: bit 0 = fused ReLU, bit 1 = accumulate (+=) into dgamma / dbeta instead of overwriting them.
 int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
-              const float* save_rstd, double* sums, void* dx, void* dres, float* dgamma, float* dbeta, int relu,
+              const float* save_rstd, double* sums, void* dx, void* dres, float* dgamma, float* dbeta, int flags,
               long long P, int C, hipStream_t stream) {
+  const int relu = flags & 1, accumulate = (flags >> 1) & 1;
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(C % vec == 0, "mr_bn_bwd: C (%d) must be a multiple of %d", C, vec);
   MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_bwd: bad P");
@@ -348,7 +351,7 @@ int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const flo
                                        (int)P, C, rpb));
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(P * (C / vec), 256)), dim3(256), 0,
                                        stream, (const T*)dy, (const T*)x, (const T*)y, save_mean, save_rstd, gamma,
-                                       (const double*)sums, (T*)dx, (T*)dres, dgamma, dbeta, relu, P, C));
+                                       (const double*)sums, (T*)dx, (T*)dres, dgamma, dbeta, relu, accumulate, P, C));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

@@ -8,17 +8,66 @@ reference's names and shapes; every forward converts them to the operand images 
 There is no CPU path in this file: CPU tensors raise NotImplementedError (same as the reference's
 ``ops/ctc_2d/ctc_loss_2d.py:12-13`` does for its CUDA-only op).
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 
 from .. import get_compute_dtype
-from .._lib import call, dtype_code, ptr, require_cuda, vec_of
+from . import prep
+from .._lib import call, dtype_code, load, ptr, require_cuda, vec_of
 
 _ESIZE = {torch.float32: 4, torch.bfloat16: 2}
 
 
 def _ceil_to(x, m):
     return (x + m - 1) // m * m
+
+
+def grad_sink(param, physical_shape=None):
+    """Gradient sink protocol.  megreader_amd.optim attaches to every parameter it owns a persistent f32 view of its
+    flat gradient buffer (`param._mr_grad_sink`, also installed as `param.grad`).  Backward kernels that accumulate
+    (`+=`) anyway -- the split-P wgrad GEMMs and column sums -- write straight into that view and the autograd
+    Function returns None for the parameter: no temporary gradient, no zero-fill, no `grad += tmp` kernel.
+    Returns the sink tensor if it exists and its memory is dense in the layout the kernel writes
+    (`physical_shape`: e.g. KRSC for a channels_last OIHW conv weight), else None (normal autograd path)."""
+    sink = getattr(param, "_mr_grad_sink", None)
+    if sink is None or sink.dtype != torch.float32 or not sink.is_cuda:
+        return None
+    # only while the sink IS param.grad: after `model.zero_grad()` (grad=None) or a user-assigned .grad the normal
+    # autograd accumulation path must run, otherwise stale sums would survive in the flat buffer
+    if param.grad is None or param.grad.data_ptr() != sink.data_ptr():
+        return None
+    if physical_shape == "strided":   # the kernel takes explicit strides
+        return sink
+    if physical_shape is not None:
+        if len(physical_shape) == 4:
+            phys = sink.permute(0, 2, 3, 1)
+            if tuple(phys.shape) != tuple(physical_shape) or not phys.is_contiguous():
+                return None
+        elif tuple(sink.shape) != tuple(physical_shape) or not sink.is_contiguous():
+            return None
+    elif not sink.is_contiguous():
+        return None
+    return sink
+
+
+def notify_grad_ready(param):
+    """Tell data-parallel wrappers that `param`'s gradient was accumulated through its sink (the autograd
+    post-accumulate hook does not fire when a Function returns None)."""
+    for hook in getattr(param, "_mr_grad_ready_hooks", ()):
+        hook(param)
+
+
+def accumulate_multi(pairs):
+    """dst += src for a list of (dst, src) dense f32 tensor pairs, 8 pairs per launch (mr_accumulate_multi)."""
+    for i in range(0, len(pairs), 8):
+        chunk = pairs[i:i + 8]
+        n = len(chunk)
+        dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in chunk])
+        src = (ctypes.c_void_p * n)(*[s.data_ptr() for _, s in chunk])
+        cnt = (ctypes.c_longlong * n)(*[s.numel() for _, s in chunk])
+        call("mr_accumulate_multi", n, dst, src, cnt)
 
 
 def to_internal(x, dtype):
@@ -54,6 +103,29 @@ def _conv_out(size, k, s, p, d):
     return (size + 2 * p - d * (k - 1) - 1) // s + 1
 
 
+def _conv_operands(weight, bias, dtype, Cp, Kp, need_dx):
+    """Compute-dtype images of a conv weight: KRSC (forward / wgrad layout), CRSK (dgrad) and the padded bias.
+    Persistent buffers, regenerated only when the parameter changes (megreader_amd.nn.prep)."""
+    K, C, R, S = weight.shape
+    dev = weight.device
+
+    def build(old):
+        if old is None:
+            alloc = torch.zeros if Kp != K else torch.empty
+            w_krsc = alloc((Kp, R, S, Cp), dtype=dtype, device=dev)
+            w_crsk = alloc((C, R, S, Kp), dtype=dtype, device=dev) if need_dx else None
+            bias_p = torch.zeros((Kp,), dtype=torch.float32, device=dev) if (bias is not None and Kp != K) else None
+        else:
+            w_krsc, w_crsk, bias_p = old
+        jobs = [prep.conv_job(ptr(weight), weight.stride(), ptr(w_krsc), ptr(w_crsk), K, C, R, S, Cp, Kp)]
+        if bias_p is not None:
+            jobs.append(prep.bias_job(ptr(bias), 0, ptr(bias_p), K, 0))
+        return (w_krsc, w_crsk, bias_p), jobs
+
+    w_krsc, w_crsk, bias_p = prep.prepared((weight, bias), ("conv", Cp, Kp, bool(need_dx)), build, dtype)
+    return w_krsc, w_crsk, (bias_p if bias_p is not None else bias)
+
+
 # --------------------------------------------------------------------------------------------------
 # Conv2d (+bias, +fused ReLU).  reference: nn.Conv2d at backbones/crnn.py:48, backbones/resnet.py:39-56
 # --------------------------------------------------------------------------------------------------
@@ -75,21 +147,14 @@ class Conv2dFn(Function):
         dh, dw = dilation
         Ho, Wo = _conv_out(H, R, sh, ph, dh), _conv_out(W, S, sw, pw, dw)
         need_dx = ctx.needs_input_grad[0]
-        alloc = torch.zeros if Kp != K else torch.empty
-        w_krsc = alloc((Kp, R, S, Cp), dtype=dtype, device=x.device)
-        w_crsk = alloc((C, R, S, Kp), dtype=dtype, device=x.device) if need_dx else None
         if need_dx and Cp != C:
             raise RuntimeError("input gradient requested for a channel-padded convolution input")
-        sk, sc, sr, ss = weight.stride()
-        call("mr_prep_conv_weight", dt, ptr(weight), sk, sc, sr, ss, ptr(w_krsc), ptr(w_crsk), K, C, R, S, Cp, Kp)
-        bias_k = bias
-        if bias is not None and Kp != K:
-            bias_k = torch.zeros((Kp,), dtype=torch.float32, device=x.device)
-            call("mr_prep_bias", ptr(bias), 0, ptr(bias_k), K, 0)
+        w_krsc, w_crsk, bias_k = _conv_operands(weight, bias, dtype, Cp, Kp, need_dx)
         y = torch.empty((N, Ho, Wo, Kp), dtype=dtype, device=x.device)
         call("mr_conv2d_fwd", dt, ptr(xi), ptr(w_krsc), ptr(bias_k), ptr(y), int(relu), N, H, W, Cp, Cp, Kp, Kp, R, S,
              sh, sw, ph, pw, dh, dw, Ho, Wo)
         ctx.save_for_backward(xi, w_crsk, y if (relu and not relu_grad_downstream) else None)
+        ctx.params = (weight, bias)
         ctx.geom = (N, H, W, Cp, C, K, Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo)
         ctx.relu = relu and not relu_grad_downstream  # else the consumer (max-pool) applies the ReLU mask
         ctx.has_bias = bias is not None
@@ -117,21 +182,33 @@ class Conv2dFn(Function):
             call("mr_conv2d_dgrad", dt, ptr(g), ptr(w_crsk), ptr(dxi), N, H, W, C, C, Kp, Kp, R, S, sh, sw, ph, pw,
                  dh, dw, Ho, Wo)
             dx = dxi.permute(0, 3, 1, 2)
+        weight_p, bias_p = ctx.params
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        # gradient sinks (see grad_sink): the wgrad / bias kernels accumulate directly into the flat gradient buffer
+        w_sink = grad_sink(weight_p, (K, R, S, C)) if (ctx.needs_input_grad[1] and Cp == C and Kp == K) else None
+        b_sink = grad_sink(bias_p, (K,)) if (want_db and Kp == K) else None
         if want_db:
-            db = torch.zeros((Kp,), dtype=torch.float32, device=g.device)
+            db = b_sink if b_sink is not None else torch.zeros((Kp,), dtype=torch.float32, device=g.device)
         if ctx.needs_input_grad[1]:
-            gw = torch.zeros((Kp, R, S, Cp), dtype=torch.float32, device=g.device)
+            gw = w_sink if w_sink is not None else torch.zeros((Kp, R, S, Cp), dtype=torch.float32, device=g.device)
             # the bias gradient (column sums of dy) rides along the wgrad pass over dy
             call("mr_conv2d_wgrad", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, Kp, Kp,
                  R, S, sh, sw, ph, pw, dh, dw, Ho, Wo)
-            if Cp != C or Kp != K:
-                gw = gw[:K, :, :, :C]
-            dwt = gw.permute(0, 3, 1, 2)
+            if w_sink is not None:
+                dwt = None
+                notify_grad_ready(weight_p)
+            else:
+                if Cp != C or Kp != K:
+                    gw = gw[:K, :, :, :C]
+                dwt = gw.permute(0, 3, 1, 2)
         elif want_db:
             call("mr_colsum", dt, ptr(g), ptr(db), N * Ho * Wo, Kp, Kp, 0)
-        if want_db and Kp != K:
-            db = db[:K]
+        if want_db:
+            if b_sink is not None:
+                db = None
+                notify_grad_ready(bias_p)
+            elif Kp != K:
+                db = db[:K]
         return dx, dwt, db, None, None, None, None, None
 
 
@@ -170,6 +247,7 @@ class BatchNormFn(Function):
             call("mr_bn_fwd_eval", dt, ptr(xi), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                  ptr(mean), ptr(rstd), ptr(ri), int(relu), P, C, float(eps))
         ctx.save_for_backward(xi, y if relu else None, gamma, mean, rstd)
+        ctx.params = (gamma, beta)
         ctx.relu = relu
         ctx.has_res = residual is not None
         ctx.dtype = dtype
@@ -189,17 +267,91 @@ class BatchNormFn(Function):
         dx = torch.empty_like(xi)
         dres = torch.empty_like(xi) if ctx.has_res else None
         sums = torch.empty((2 * C,), dtype=torch.float64, device=g.device)
-        dgamma = torch.empty((C,), dtype=torch.float32, device=g.device)
-        dbeta = torch.empty((C,), dtype=torch.float32, device=g.device)
+        gamma_p, beta_p = ctx.params
+        g_sink, b_sink = grad_sink(gamma_p, (C,)), grad_sink(beta_p, (C,))
+        sunk = g_sink is not None and b_sink is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+        if sunk:
+            dgamma, dbeta = g_sink, b_sink
+        else:
+            dgamma = torch.empty((C,), dtype=torch.float32, device=g.device)
+            dbeta = torch.empty((C,), dtype=torch.float32, device=g.device)
         call("mr_bn_bwd", dt, ptr(g), ptr(xi), ptr(y), ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(dx),
-             ptr(dres), ptr(dgamma), ptr(dbeta), int(ctx.relu), P, C)
+             ptr(dres), ptr(dgamma), ptr(dbeta), int(ctx.relu) | (2 if sunk else 0), P, C)
         gres = dres.permute(0, 3, 1, 2) if ctx.has_res else None
+        if sunk:
+            notify_grad_ready(gamma_p)
+            notify_grad_ready(beta_p)
+            dgamma = dbeta = None
         return dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None, gres
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu=False, residual=None):
     return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, bool(training), momentum, eps, bool(relu),
                              residual)
+
+
+# --------------------------------------------------------------------------------------------------
+# Backbone stem: Conv2d(Cin->64, 3x3, s1, p1) + ReLU + MaxPool2d(2,2) in one kernel each way.
+# reference: cnn.conv0 / relu0 / pooling0 at backbones/crnn.py:17-19,48-55
+# --------------------------------------------------------------------------------------------------
+def stem_eligible(x, weight, stride, padding, dilation, pool_kernel, pool_stride, pool_padding):
+    return (x.is_cuda and x.dim() == 4 and not x.requires_grad and x.shape[1] in (1, 3) and
+            tuple(weight.shape) == (64, x.shape[1], 3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and
+            tuple(dilation) == (1, 1) and tuple(pool_kernel) == (2, 2) and tuple(pool_stride) == (2, 2) and
+            tuple(pool_padding) == (0, 0) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and
+            16 * (x.shape[3] + 2) * x.shape[1] <= 48 * 1024)
+
+
+class StemConvReluPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        require_cuda(x, weight, bias)
+        dtype = get_compute_dtype()
+        dt = dtype_code(dtype)
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        N, C, H, W = x.shape
+        y = torch.empty((N, H // 2, W // 2, 64), dtype=dtype, device=x.device)
+        code = torch.empty((N, H // 2, W // 2, 64), dtype=torch.uint8, device=x.device)
+        sk, sc, sr, ss = weight.stride()
+        call("mr_stem_fwd", dt, ptr(x), ptr(weight), sk, sc, sr, ss, ptr(bias), ptr(y), ptr(code), N, C, H, W)
+        ctx.save_for_backward(x, code)
+        ctx.params = (weight, bias)
+        ctx.dtype = dtype
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, code = ctx.saved_tensors
+        weight_p, bias_p = ctx.params
+        dtype = ctx.dtype
+        N, C, H, W = x.shape
+        g = _grad_internal(gy, dtype)
+        want_dw = ctx.needs_input_grad[1]
+        want_db = bias_p is not None and ctx.needs_input_grad[2]
+        w_sink = grad_sink(weight_p, "strided") if want_dw else None
+        b_sink = grad_sink(bias_p, (64,)) if want_db else None
+        dw = db = None
+        if want_dw:
+            dw = w_sink if w_sink is not None else torch.zeros_like(weight_p)
+        if want_db:
+            db = b_sink if b_sink is not None else torch.zeros((64,), dtype=torch.float32, device=g.device)
+        if dw is not None or db is not None:
+            ws = torch.empty((load().mr_stem_bwd_workspace(C),), dtype=torch.float32, device=g.device)
+            sk, sc, sr, ss = dw.stride() if dw is not None else (0, 0, 0, 0)
+            call("mr_stem_bwd", dtype_code(dtype), ptr(g), ptr(code), ptr(x), ptr(ws), ptr(dw), sk, sc, sr, ss, ptr(db),
+                 N, C, H, W)
+        if w_sink is not None:
+            notify_grad_ready(weight_p)
+            dw = None
+        if b_sink is not None:
+            notify_grad_ready(bias_p)
+            db = None
+        return None, dw, db
+
+
+def stem_conv_relu_pool(x, weight, bias):
+    return StemConvReluPoolFn.apply(x, weight, bias)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -297,15 +449,21 @@ class LinearFn(Function):
         Np = _ceil_to(Nout, v)
         if K % v:
             raise RuntimeError("Linear: in_features (%d) must be a multiple of %d" % (K, v))
-        w_n = torch.empty((Nout, K), dtype=dtype, device=x.device)
-        w_t = torch.zeros((K, Np), dtype=dtype, device=x.device) if Np != Nout else \
-            torch.empty((K, Np), dtype=dtype, device=x.device)
-        call("mr_prep_matrix", dt, ptr(weight), K, ptr(w_n), K, ptr(w_t), Np, Nout, K, 0)
+        def build(old):
+            if old is None:
+                w_n_ = torch.empty((Nout, K), dtype=dtype, device=x.device)
+                w_t_ = (torch.zeros if Np != Nout else torch.empty)((K, Np), dtype=dtype, device=x.device)
+            else:
+                w_n_, w_t_ = old
+            return (w_n_, w_t_), [prep.matrix_job(ptr(weight), K, ptr(w_n_), K, ptr(w_t_), Np, Nout, K, 0)]
+
+        w_n, w_t = prep.prepared((weight,), ("linear", Np), build, dtype)
         y = torch.empty((M, Np), dtype=dtype, device=x.device)
         if Np != Nout:
             y[:, Nout:].zero_()
         call("mr_gemm_nt", dt, ptr(x2), K, ptr(w_n), K, ptr(y), Np, ptr(bias), 0, M, Nout, K)
         ctx.save_for_backward(x2, w_t)
+        ctx.params = (weight, bias)
         ctx.dims = (M, K, Nout, Np)
         ctx.lead = lead
         ctx.has_bias = bias is not None
@@ -329,16 +487,27 @@ class LinearFn(Function):
             dx2 = torch.empty((M, K), dtype=dtype, device=gy.device)
             call("mr_gemm_nt", dt, ptr(gp), Np, ptr(w_t), Np, ptr(dx2), K, 0, 0, M, K, Np)
             dx = dx2.view(*ctx.lead, K)
+        weight_p, bias_p = ctx.params
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        gb = torch.zeros((Np,), dtype=torch.float32, device=gy.device) if want_db else None
+        w_sink = grad_sink(weight_p, (Nout, K)) if (ctx.needs_input_grad[1] and Np == Nout) else None
+        b_sink = grad_sink(bias_p, (Nout,)) if (want_db and Np == Nout) else None
+        gb = None
+        if want_db:
+            gb = b_sink if b_sink is not None else torch.zeros((Np,), dtype=torch.float32, device=gy.device)
         if ctx.needs_input_grad[1]:
-            gw = torch.zeros((Np, K), dtype=torch.float32, device=gy.device)
+            gw = w_sink if w_sink is not None else torch.zeros((Np, K), dtype=torch.float32, device=gy.device)
             call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, Np, K, 0, ptr(gb))
-            dw = gw[:Nout]
+            if w_sink is not None:
+                notify_grad_ready(weight_p)
+            else:
+                dw = gw[:Nout]
         elif want_db:
             call("mr_colsum", dt, ptr(gp), ptr(gb), M, Np, Np, 0)
         if want_db:
-            db = gb[:Nout]
+            if b_sink is not None:
+                notify_grad_ready(bias_p)
+            else:
+                db = gb[:Nout]
         return dx, dw, db
 
 
@@ -364,17 +533,28 @@ class BiLSTMFn(Function):
         if I % v or H % v:
             raise RuntimeError("LSTM: input (%d) and hidden (%d) sizes must be multiples of %d" % (I, H, v))
         dev = x.device
-        wcat = torch.empty((8 * H, I), dtype=dtype, device=dev)
-        wcat_t = torch.empty((I, 8 * H), dtype=dtype, device=dev)
-        whh = torch.empty((2, 4 * H, H), dtype=dtype, device=dev)
-        whh_t = torch.empty((2, H, 4 * H), dtype=dtype, device=dev)
-        bcat = torch.empty((8 * H,), dtype=torch.float32, device=dev)
-        for d, (wi, wh, bi, bh) in enumerate(((w_ih, w_hh, b_ih, b_hh), (w_ih_r, w_hh_r, b_ih_r, b_hh_r))):
-            call("mr_prep_matrix", dt, ptr(wi), I, ptr(wcat) + d * 4 * H * I * es, I, ptr(wcat_t) + d * 4 * H * es,
-                 8 * H, 4 * H, I, H)
-            call("mr_prep_matrix", dt, ptr(wh), H, ptr(whh) + d * 4 * H * H * es, H,
-                 ptr(whh_t) + d * 4 * H * H * es, 4 * H, 4 * H, H, H)
-            call("mr_prep_bias", ptr(bi), ptr(bh), ptr(bcat) + d * 4 * H * 4, 4 * H, H)
+        sources = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
+
+        def build(old):
+            if old is None:
+                wcat_ = torch.empty((8 * H, I), dtype=dtype, device=dev)
+                wcat_t_ = torch.empty((I, 8 * H), dtype=dtype, device=dev)
+                whh_ = torch.empty((2, 4 * H, H), dtype=dtype, device=dev)
+                whh_t_ = torch.empty((2, H, 4 * H), dtype=dtype, device=dev)
+                bcat_ = torch.empty((8 * H,), dtype=torch.float32, device=dev)
+            else:
+                wcat_, wcat_t_, whh_, whh_t_, bcat_ = old
+            jobs = []
+            for d, (wi, wh, bi, bh) in enumerate(((w_ih, w_hh, b_ih, b_hh), (w_ih_r, w_hh_r, b_ih_r, b_hh_r))):
+                # gate-major (i,f,g,o) rows -> gate-interleaved rows; both directions side by side
+                jobs.append(prep.matrix_job(ptr(wi), I, ptr(wcat_) + d * 4 * H * I * es, I,
+                                            ptr(wcat_t_) + d * 4 * H * es, 8 * H, 4 * H, I, H))
+                jobs.append(prep.matrix_job(ptr(wh), H, ptr(whh_) + d * 4 * H * H * es, H,
+                                            ptr(whh_t_) + d * 4 * H * H * es, 4 * H, 4 * H, H, H))
+                jobs.append(prep.bias_job(ptr(bi), ptr(bh), ptr(bcat_) + d * 4 * H * 4, 4 * H, H))
+            return (wcat_, wcat_t_, whh_, whh_t_, bcat_), jobs
+
+        wcat, wcat_t, whh, whh_t, bcat = prep.prepared(sources, ("bilstm",), build, dtype)
         xproj = torch.empty((T * N, 8 * H), dtype=dtype, device=dev)
         call("mr_gemm_nt", dt, ptr(x), I, ptr(wcat), I, ptr(xproj), 8 * H, ptr(bcat), 0, T * N, 8 * H, I)
         out = torch.empty((T, N, 2 * H), dtype=dtype, device=dev)
@@ -382,6 +562,7 @@ class BiLSTMFn(Function):
         gates = torch.empty((T, N, 8 * H), dtype=dtype, device=dev)
         call("mr_lstm_fwd", dt, ptr(xproj), ptr(whh), ptr(out), ptr(cbuf), ptr(gates), T, N, H)
         ctx.save_for_backward(x, wcat_t, whh_t, out, cbuf, gates)
+        ctx.params = sources
         ctx.dims = (T, N, I, H)
         ctx.dtype = dtype
         return out
@@ -404,20 +585,35 @@ class BiLSTMFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((T, N, I), dtype=dtype, device=dev)
             call("mr_gemm_nt", dt, ptr(dgates), 8 * H, ptr(wcat_t), 8 * H, ptr(dx), I, 0, 0, T * N, I, 8 * H)
-        gw_ih = torch.zeros((2, 4 * H, I), dtype=torch.float32, device=dev)
-        gb = torch.zeros((2, 4 * H), dtype=torch.float32, device=dev)
+        sinks = [grad_sink(p, tuple(p.shape)) for p in ctx.params]
+        use_sinks = all(s is not None for s in sinks)
+        # one zeroed scratch: [2,4H,I] input-weight gradients (both directions from ONE GEMM) + [2,4H] bias sums
+        scratch = torch.zeros((2 * 4 * H * (I + 1),), dtype=torch.float32, device=dev)
+        gw_ih = scratch[:2 * 4 * H * I].view(2, 4 * H, I)
+        gb = scratch[2 * 4 * H * I:].view(2, 4 * H)
         # bias gradient = column sums of dgates, fused into the same pass
         call("mr_gemm_tn", dt, ptr(dgates), 8 * H, ptr(x), I, ptr(gw_ih), I, T * N, 8 * H, I, H, ptr(gb))
-        gw_hh = torch.zeros((2, 4 * H, H), dtype=torch.float32, device=dev)
+        if use_sinks:   # recurrent-weight gradients accumulate straight into the flat gradient buffer
+            g_hh = (sinks[1], sinks[5])
+        else:
+            gw_hh = torch.zeros((2, 4 * H, H), dtype=torch.float32, device=dev)
+            g_hh = (gw_hh[0], gw_hh[1])
         if T > 1:
             P = (T - 1) * N
             # forward direction: dgates[t] (t>=1) with h[t-1]
-            call("mr_gemm_tn", dt, ptr(dgates) + N * 8 * H * es, 8 * H, ptr(out), 2 * H, ptr(gw_hh), H, P, 4 * H,
+            call("mr_gemm_tn", dt, ptr(dgates) + N * 8 * H * es, 8 * H, ptr(out), 2 * H, ptr(g_hh[0]), H, P, 4 * H,
                  H, H, 0)
             # reverse direction: dgates[t] (t<=T-2) with h[t+1]
             call("mr_gemm_tn", dt, ptr(dgates) + 4 * H * es, 8 * H, ptr(out) + (N * 2 * H + H) * es, 2 * H,
-                 ptr(gw_hh) + 4 * H * H * 4, H, P, 4 * H, H, H, 0)
-        return (dx, gw_ih[0], gw_hh[0], gb[0], gb[0].clone(), gw_ih[1], gw_hh[1], gb[1], gb[1].clone())
+                 ptr(g_hh[1]), H, P, 4 * H, H, H, 0)
+        if use_sinks:
+            # w_ih, b_ih, b_hh of both directions: one launch folds the scratch into the six sinks
+            accumulate_multi([(sinks[0], gw_ih[0]), (sinks[4], gw_ih[1]), (sinks[2], gb[0]), (sinks[3], gb[0]),
+                              (sinks[6], gb[1]), (sinks[7], gb[1])])
+            for p in ctx.params:
+                notify_grad_ready(p)
+            return (dx,) + (None,) * 8
+        return (dx, gw_ih[0], g_hh[0], gb[0], gb[0].clone(), gw_ih[1], g_hh[1], gb[1], gb[1].clone())
 
 
 def bilstm(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
@@ -453,13 +649,15 @@ class CTCLossFn(Function):
         dev = logits.device
         lp = torch.empty((T, N, C), dtype=torch.float32, device=dev)
         alpha = torch.empty((N, T, 2 * S + 1), dtype=torch.float64, device=dev)
+        # beta is produced by the same kernel (concurrently with alpha) when a gradient may be asked for
+        beta = torch.empty((N, T, 2 * S + 1), dtype=torch.float64, device=dev) if ctx.needs_input_grad[0] else None
         nll = torch.empty((N,), dtype=torch.float64, device=dev)
         loss = torch.empty((), dtype=torch.float64, device=dev)
         t64 = int(targets.dtype == torch.int64)
         call("mr_ctc_fwd", dtype_code(dtype), ptr(logits), ldl, ptr(targets), t64, ptr(input_lengths),
-             ptr(target_lengths), 1, T, N, C, S, int(blank), int(zero_infinity), ptr(lp), ptr(alpha), ptr(nll),
-             ptr(loss))
-        ctx.save_for_backward(lp, alpha, nll, targets, input_lengths, target_lengths)
+             ptr(target_lengths), 1, T, N, C, S, int(blank), int(zero_infinity), ptr(lp), ptr(alpha), ptr(beta),
+             ptr(nll), ptr(loss))
+        ctx.save_for_backward(lp, alpha, beta, nll, targets, input_lengths, target_lengths)
         ctx.dims = (T, N, C, S, int(blank), int(zero_infinity), t64)
         ctx.dtype = dtype
         ctx.mark_non_differentiable(lp)
@@ -467,7 +665,7 @@ class CTCLossFn(Function):
 
     @staticmethod
     def backward(ctx, gloss, _glp):
-        lp, alpha, nll, targets, input_lengths, target_lengths = ctx.saved_tensors
+        lp, alpha, beta, nll, targets, input_lengths, target_lengths = ctx.saved_tensors
         T, N, C, S, blank, zero_inf, t64 = ctx.dims
         dtype = ctx.dtype
         v = vec_of(dtype)
@@ -475,7 +673,8 @@ class CTCLossFn(Function):
         g = gloss.to(torch.float64).contiguous()
         grad = torch.zeros((T, N, Cp), dtype=dtype, device=lp.device) if Cp != C else \
             torch.empty((T, N, Cp), dtype=dtype, device=lp.device)
-        call("mr_ctc_bwd", dtype_code(dtype), ptr(lp), ptr(alpha), ptr(nll), ptr(targets), t64, ptr(input_lengths),
+        call("mr_ctc_bwd", dtype_code(dtype), ptr(lp), ptr(alpha), ptr(beta), ptr(nll), ptr(targets), t64,
+             ptr(input_lengths),
              ptr(target_lengths), 1, ptr(g), T, N, C, S, blank, zero_inf, ptr(grad), Cp)
         return grad[..., :C], None, None, None, None, None
 

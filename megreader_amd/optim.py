@@ -12,6 +12,7 @@ training step advances bias correction correctly.
 import torch
 
 from ._lib import call, ptr
+from .nn import prep
 
 _ALIGN = 64  # elements; keeps every parameter slice 256-byte aligned
 
@@ -51,6 +52,8 @@ class _FlatOptimizer(torch.optim.Optimizer):
                 if p.grad is not None:
                     gview.copy_(p.grad)
                 p.grad = gview
+                # gradient sink (megreader_amd.nn.functional.grad_sink): accumulating backward kernels write here
+                p._mr_grad_sink = gview
             self._flat.append({'p': flat_p, 'g': flat_g, 'params': params, 'offs': offs, 'n': total,
                                's1': torch.zeros(total, dtype=torch.float32, device=dev),
                                's2': torch.zeros(total, dtype=torch.float32, device=dev),
@@ -65,6 +68,12 @@ class _FlatOptimizer(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         """One memset per group.  Gradients stay attached (views of the flat buffer) unless set_to_none=True."""
         if set_to_none:
+            if self._flat is not None:
+                for f in self._flat:
+                    if f is not None:
+                        for p in f['params']:
+                            if hasattr(p, "_mr_grad_sink"):
+                                del p._mr_grad_sink
             self._flat = None
             return super().zero_grad(set_to_none=True)
         if self._flat is None:
@@ -78,12 +87,15 @@ class _FlatOptimizer(torch.optim.Optimizer):
             n = p.numel()
             lo = f['g'].data_ptr() + off * 4
             if p.grad is None:
+                # grad_sink() is inactive while .grad is None, so nothing was accumulated for this parameter
                 f['g'][off:off + n].zero_()
                 p.grad = f['g'][off:off + n].as_strided(p.shape, p.stride())
+                p._mr_grad_sink = p.grad
             elif p.grad.data_ptr() != lo:
                 view = f['g'][off:off + n].as_strided(p.shape, p.stride())
                 view.copy_(p.grad)
                 p.grad = view
+                p._mr_grad_sink = view
 
     def _hyper_values(self, group):
         raise NotImplementedError
@@ -108,6 +120,9 @@ class _FlatOptimizer(torch.optim.Optimizer):
                 f['hyper'][:5].copy_(torch.tensor(vals, dtype=torch.float32), non_blocking=False)
                 f['hyper_host'] = vals
             self._launch(f)
+            # the update went through raw pointers (no autograd version bump): regenerate the compute-dtype
+            # operand images of these parameters in one launch
+            prep.refresh(f['params'], f)
         return loss
 
 

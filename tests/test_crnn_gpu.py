@@ -114,6 +114,44 @@ def test_fp32_adam_trajectory(golden):
         assert abs(a - b) < 2e-3 * max(1.0, abs(b)), (losses, golden['adam_losses'])
 
 
+def test_gradient_sinks_match_autograd_accumulation(golden):
+    """Weight gradients accumulated straight into the flat optimizer buffer (megreader_amd.nn.functional.grad_sink)
+    equal the ones autograd accumulates, including over two backward passes, and revert to the autograd path after
+    `model.zero_grad()` (grad = None)."""
+    mr.set_compute_dtype(torch.float32)
+    ora = _oracle(golden)
+    img, lab, ln = _to_dev(golden['batch'])
+
+    def grads(use_sink, passes):
+        torch.manual_seed(0)
+        model = BasicModel()
+        model.load_state_dict(ora.state_dict())
+        model.to(DEV).train()
+        if use_sink:
+            opt = FusedAdam(model.parameters(), lr=1e-3)
+            opt.zero_grad()
+            assert any(getattr(p, "_mr_grad_sink", None) is not None for p in model.parameters())
+        for _ in range(passes):
+            loss, _ = model(img, targets=lab, lengths=ln, train=True)
+            loss.mean().backward()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters()}, model
+
+    for passes in (1, 2):
+        ref, _ = grads(False, passes)
+        got, model = grads(True, passes)
+        for k in ref:
+            scale = float(ref[k].abs().max()) + 1e-6
+            assert float((ref[k] - got[k]).abs().max()) <= 2e-5 * scale + 1e-7, (passes, k)
+    # after model.zero_grad() the sinks are inactive: plain autograd grads, flat buffer untouched
+    model.zero_grad(set_to_none=True)
+    loss, _ = model(img, targets=lab, lengths=ln, train=True)
+    loss.mean().backward()
+    ref1, _ = grads(False, 1)
+    for k, p in model.named_parameters():
+        scale = float(ref1[k].abs().max()) + 1e-6
+        assert float((ref1[k] - p.grad).abs().max()) <= 5e-4 * scale + 1e-7, k
+
+
 def test_eval_and_greedy_decode_bit_exact(golden):
     mr.set_compute_dtype(torch.float32)
     ora = _oracle(golden)
