@@ -93,7 +93,11 @@ int mr_prep_bias(const float* a, const float* b, float* dst, int R, int perm_h, 
  *   MR_PREP_MATRIX: mr_prep_matrix(src, s0 = lds, dst_a = dst_n, pad = ldn, dst_b = dst_t, ld_b = ldt, d0,d1 = R,C,
  *                   perm_h)
  *   MR_PREP_BIAS:   mr_prep_bias(src, src2, dst_a (f32), d0 = R, perm_h)
- * max_total = the largest element count over the jobs (sizes the grid). */
+ * Work unit = one 64x64 tile of the job's logical matrix (conv: K rows x R*S*Cpad columns; matrix: R x C; bias:
+ * 4096 elements).  The jobs are laid end to end on the grid: job.block_start = index of its first tile (jobs
+ * sorted by block_start, job 0 starts at 0); total_blocks = sum over jobs of
+ *   conv: ceil(K/64)*ceil(R*S*Cpad/64), matrix: ceil(R/64)*ceil(C/64), bias: ceil(R/4096).
+ * Transposed images need dst_b 16-byte aligned and ld_b a multiple of one 16-byte vector for the fast path. */
 #define MR_PREP_CONV 0
 #define MR_PREP_MATRIX 1
 #define MR_PREP_BIAS 2
@@ -106,8 +110,9 @@ typedef struct mr_prep_job {
   int kind;
   int d0, d1, d2, d3;
   int pad, ld_b, perm_h;
+  int block_start, reserved;
 } mr_prep_job;
-int mr_prep_batch(int dtype, const mr_prep_job* jobs_device, int njobs, long long max_total, hipStream_t stream);
+int mr_prep_batch(int dtype, const mr_prep_job* jobs_device, int njobs, long long total_blocks, hipStream_t stream);
 
 /* dst[i][0..n[i]) += src[i][0..n[i]) for count <= MR_MAX_SEGMENTS f32 segments in one launch (the pointer / length
  * arrays are HOST arrays, copied into the kernel arguments).  Used to fold several small gradient pieces into the
@@ -159,6 +164,9 @@ int mr_lstm_fwd(int dtype, const void* xproj, const void* whh, void* out, float*
                 int H, hipStream_t stream);
 int mr_lstm_bwd(int dtype, const void* dout, const void* whhT, const float* cbuf, void* gates, float* dc, int T,
                 int N, int H, hipStream_t stream);
+/* tuning knob (host only): column-tile width of the step kernels; 0 = LDS-staged split-K body, else the
+ * direct-fragment body.  fwd_bn in {0,32,64}, bwd_bn in {0,16,32,64}; negative leaves the setting unchanged. */
+int mr_set_lstm_variant(int fwd_bn, int bwd_bn);
 
 /* ---- 1-D CTC fused with log-softmax (replaces log_softmax + nn.CTCLoss: decoders/crnn.py:48,96-98) ------- */
 int mr_ctc_fwd(int dtype, const void* logits, int ldl, const void* targets, int targets_i64,

@@ -105,6 +105,8 @@ def load():
     lib.mr_force_nt_tile.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mr_nt_tile_code.restype = ctypes.c_int
     lib.mr_nt_tile_code.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.mr_set_lstm_variant.restype = ctypes.c_int
+    lib.mr_set_lstm_variant.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mr_stem_bwd_workspace.restype = ctypes.c_longlong
     lib.mr_stem_bwd_workspace.argtypes = [ctypes.c_int]
     for name, codes in SIGNATURES.items():
@@ -119,7 +121,7 @@ def load():
 
 
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_set_nt_variant", "mr_force_nt_tile",
-             "mr_stem_bwd_workspace")  # entry points that take no stream and launch nothing
+             "mr_stem_bwd_workspace", "mr_set_lstm_variant")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

@@ -217,52 +217,29 @@ __global__ void prep_bias_kernel(const float* __restrict__ a, const float* __res
 }
 
 // ---------------------------------------------------------------- batched weight prep / multi-segment accumulate
-// One launch for every prepared operand image of a model (see mr_prep_batch in the header): blockIdx.y = job.
+// One launch for every prepared operand image of a model (see mr_prep_batch in the header).  Work unit = one 64x64
+// tile of a job's logical matrix (conv: rows k, columns (r,s,c) with c padded to Cpad; matrix: rows in DESTINATION
+// (gate-interleaved) order, columns c): the tile is loaded once (all 16 loads of a thread in flight together), cast,
+// written row-wise to the normal image and -- through LDS -- column-wise to the transposed image, so that both
+// images are written in full 128-byte runs (the transposed one used to be 2-byte scatter writes).
 template <typename T>
-__global__ void prep_batch_kernel(const mr_prep_job* __restrict__ jobs) {
-  const mr_prep_job j = jobs[blockIdx.y];
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (j.kind == MR_PREP_CONV) {
-    const int K = j.d0, C = j.d1, R = j.d2, S = j.d3, Cpad = j.pad, ldk = j.ld_b;
-    T* dst_krsc = (T*)j.dst_a;
-    T* dst_crsk = (T*)j.dst_b;
-    const long long total = (long long)K * R * S * Cpad;
-    for (long long i = i0; i < total; i += stride) {
-      const int c = (int)(i % Cpad);
-      long long q = i / Cpad;
-      const int s = (int)(q % S);
-      q /= S;
-      const int r = (int)(q % R);
-      const int k = (int)(q / R);
-      float v = 0.f;
-      if (c < C) v = j.src[k * j.s0 + c * j.s1 + r * j.s2 + s * j.s3];
-      if (dst_krsc) dst_krsc[i] = from_f32<T>(v);
-      if (dst_crsk && c < C) dst_crsk[(((long long)c * R + r) * S + s) * ldk + k] = from_f32<T>(v);
-    }
-  } else if (j.kind == MR_PREP_MATRIX) {
-    const int R = j.d0, C = j.d1, perm_h = j.perm_h;
-    T* dst_n = (T*)j.dst_a;
-    T* dst_t = (T*)j.dst_b;
-    const long long total = (long long)R * C;
-    for (long long i = i0; i < total; i += stride) {
-      const int c = (int)(i % C);
-      const int r = (int)(i / C);
-      int rp = r;
-      if (perm_h > 0) {
-        const int h4 = 4 * perm_h;
-        const int blk = r / h4, rin = r - blk * h4;
-        rp = blk * h4 + 4 * (rin % perm_h) + rin / perm_h;
-      }
-      const T v = from_f32<T>(j.src[(long long)r * j.s0 + c]);
-      if (dst_n) dst_n[(long long)rp * j.pad + c] = v;
-      if (dst_t) dst_t[(long long)c * j.ld_b + rp] = v;
-    }
-  } else {  // MR_PREP_BIAS: f32 dst[perm(r)] = a[r] + b[r]
+__global__ __launch_bounds__(256) void prep_batch_kernel(const mr_prep_job* __restrict__ jobs, int njobs) {
+  __shared__ int starts[1024];
+  __shared__ T tile[64][66];
+  for (int t = threadIdx.x; t < njobs; t += blockDim.x) starts[t] = jobs[t].block_start;
+  __syncthreads();
+  int lo = 0, hi = njobs - 1;  // last job whose block_start <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (starts[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const mr_prep_job j = jobs[lo];
+  const int lb = (int)blockIdx.x - j.block_start;
+  const int tid = threadIdx.x;
+  if (j.kind == MR_PREP_BIAS) {  // f32 dst[perm(r)] = a[r] + b[r]
     const int R = j.d0, perm_h = j.perm_h;
     float* dst = (float*)j.dst_a;
-    for (long long i = i0; i < R; i += stride) {
-      const int r = (int)i;
+    for (int r = lb * 4096 + tid; r < R && r < (lb + 1) * 4096; r += 256) {
       int rp = r;
       if (perm_h > 0) {
         const int h4 = 4 * perm_h;
@@ -271,6 +248,80 @@ __global__ void prep_batch_kernel(const mr_prep_job* __restrict__ jobs) {
       }
       dst[rp] = j.src[r] + (j.src2 ? j.src2[r] : 0.f);
     }
+    return;
+  }
+  const bool conv = j.kind == MR_PREP_CONV;
+  const int rows = j.d0;
+  const int cols = conv ? j.d2 * j.d3 * j.pad : j.d1;
+  const int tiles_c = (cols + 63) / 64;
+  const int r0 = (lb / tiles_c) * 64, c0 = (lb % tiles_c) * 64;
+
+  // ---- phase 1: load + cast; row-wise image
+  const int col = tid & 63, rq = tid >> 6;
+  const int colg = c0 + col;
+  long long src_col = 0;   // source offset contributed by the column
+  bool col_ok = colg < cols;
+  if (conv) {
+    const int c = colg % j.pad, rs = colg / j.pad;
+    const int r = rs / j.d3, s = rs - r * j.d3;
+    src_col = c * j.s1 + r * j.s2 + s * j.s3;
+    col_ok = col_ok && c < j.d1;  // padded channels are zeros
+  } else {
+    src_col = colg;
+  }
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int rg = r0 + rq + 4 * i;  // destination row
+    long long src_row;
+    if (conv) {
+      src_row = (long long)rg * j.s0;
+    } else {
+      int r = rg;
+      if (j.perm_h > 0) {  // inverse of r = q*H + jj -> rp = 4*jj + q
+        const int h4 = 4 * j.perm_h;
+        const int blk = rg / h4, rin = rg - blk * h4;
+        r = blk * h4 + (rin & 3) * j.perm_h + (rin >> 2);
+      }
+      src_row = (long long)r * j.s0;
+    }
+    v[i] = (col_ok && rg < rows) ? j.src[src_row + src_col] : 0.f;
+  }
+  T* dst_a = (T*)j.dst_a;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int rl = rq + 4 * i, rg = r0 + rl;
+    const T t = from_f32<T>(v[i]);
+    tile[rl][col] = t;
+    if (dst_a && rg < rows && colg < cols) dst_a[(long long)rg * (conv ? cols : j.pad) + colg] = t;
+  }
+  T* dst_b = (T*)j.dst_b;
+  if (!dst_b) return;
+  __syncthreads();
+  // ---- phase 2: column-wise (transposed) image: thread = (tile column, 16-row segment)
+  const int tc = tid >> 2, seg = tid & 3;
+  const int cg = c0 + tc;
+  if (cg >= cols) return;
+  long long trow;
+  if (conv) {
+    const int c = cg % j.pad, rs = cg / j.pad;
+    if (c >= j.d1) return;
+    trow = (long long)c * j.d2 * j.d3 + rs;  // (c*R + r)*S + s
+  } else {
+    trow = cg;
+  }
+  T* out = dst_b + trow * j.ld_b + r0 + seg * 16;
+  if (r0 + 64 <= rows && (j.ld_b % (16 / (int)sizeof(T))) == 0) {
+    T buf[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) buf[e] = tile[seg * 16 + e][tc];
+    uint4* o4 = (uint4*)out;
+    const uint4* b4 = (const uint4*)buf;
+#pragma unroll
+    for (int q = 0; q < (int)(16 * sizeof(T) / 16); ++q) o4[q] = b4[q];
+  } else {
+    for (int e = 0; e < 16; ++e)
+      if (r0 + seg * 16 + e < rows) out[e] = tile[seg * 16 + e][tc];
   }
 }
 
@@ -462,12 +513,12 @@ int mr_prep_bias(const float* a, const float* b, float* dst, int R, int perm_h, 
   return MR_OK;
 }
 
-int mr_prep_batch(int dtype, const mr_prep_job* jobs_device, int njobs, long long max_total, hipStream_t stream) {
+int mr_prep_batch(int dtype, const mr_prep_job* jobs_device, int njobs, long long total_blocks, hipStream_t stream) {
   if (njobs <= 0) return MR_OK;
-  MR_CHECK_ARG(jobs_device != nullptr && njobs <= 65535, "mr_prep_batch: bad job table");
-  MR_CHECK_ARG(max_total > 0, "mr_prep_batch: max_total must be the largest job's element count");
-  DISPATCH_T(dtype, hipLaunchKernelGGL((prep_batch_kernel<T>), dim3(grid_for(max_total, 256, 2048), njobs), dim3(256),
-                                       0, stream, jobs_device));
+  MR_CHECK_ARG(jobs_device != nullptr && njobs <= 1024, "mr_prep_batch: bad job table (at most 1024 jobs)");
+  MR_CHECK_ARG(total_blocks > 0 && total_blocks < (1ll << 31), "mr_prep_batch: bad total_blocks");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((prep_batch_kernel<T>), dim3((unsigned)total_blocks), dim3(256), 0, stream,
+                                       jobs_device, njobs));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

@@ -358,6 +358,88 @@ __device__ __forceinline__ void igemm_nt_ksplit_body(const NtArgs& a, const Epi&
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Latency-optimised NT body for the LSTM recurrence (one BM x BN output tile per workgroup, K split over the
+// 4 waves).  Every wave fetches its whole K slice as MFMA fragments straight from global memory (L2-resident
+// operands: h_{t-1} / dgates and the recurrent weights) with all loads in flight at once -- no LDS staging, no
+// barrier in the k-loop -- so a step costs ONE memory round trip + the MFMAs + the cross-wave reduction, instead
+// of K/(4*BK) staged load->LDS->MFMA rounds.  The 16-byte vector a lane loads for (row l15, chunk lg) is exactly
+// its fragment of one Mma<T>::run; A and B use the same k order so any K (multiple of the vector width) works.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, typename Epi>
+__device__ __forceinline__ void igemm_nt_kdirect_body(const NtArgs& a, const Epi& epi) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int KR = 4 * VEC;  // k extent of one Mma<T>::run
+  constexpr int TM = BM / 16, TN = BN / 16, KC = 8;
+  typedef typename Mma<T>::Frag Frag;
+  __shared__ float red[4 * BM * BN];
+
+  const int tid = threadIdx.x;
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const T* __restrict__ A = (const T*)a.A;
+  const T* __restrict__ B = (const T*)a.B;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int kw = ((a.K + 4 * KR - 1) / (4 * KR)) * KR;  // per-wave K slice
+  const int k_lo = wave * kw;
+  const int k_hi = (k_lo + kw < a.K) ? k_lo + kw : a.K;
+  for (int kp = k_lo; kp < k_hi; kp += KC * KR) {
+    uint4 fa[TM][KC], fb[TN][KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const int k = kp + c * KR + lg * VEC;
+      const bool ok = k < k_hi;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int m = m0 + 16 * j + l15;
+        fa[j][c] = (ok && m < a.M) ? ldg16(A + (long long)m * a.lda + k) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int n = n0 + 16 * i + l15;
+        fb[i][c] = (ok && n < a.N) ? ldg16(B + (long long)n * a.ldb + k) : make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          Mma<T>::run(acc[i][j], *(const Frag*)&fb[i][c], *(const Frag*)&fa[j][c]);
+  }
+
+  // cross-wave reduction through LDS: red[w][m][n] f32
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = j * 16 + l15, n = i * 16 + lg * 4;
+      *(f32x4*)&red[wave * BM * BN + m * BN + n] = acc[i][j];
+    }
+  __syncthreads();
+  constexpr int NV = BM * BN / 4;  // f32x4 vectors of the tile
+  for (int gidx = tid; gidx < NV; gidx += 256) {
+    const int m = gidx / (BN / 4), n = (gidx % (BN / 4)) * 4;
+    f32x4 v = *(const f32x4*)&red[m * BN + n];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const f32x4 u = *(const f32x4*)&red[w * BM * BN + m * BN + n];
+      v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+    }
+    epi(m0 + m, n0 + n, v);
+  }
+}
+
 template <typename T, int BM, int BN, int AMODE, typename Epi>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(NtArgs a, ConvGeom g, Epi epi) {
   igemm_nt_body<T, BM, BN, AMODE, Epi>(a, g, epi);

@@ -77,14 +77,25 @@ template <typename T> struct EpiLstmBwd {
   }
 };
 
-constexpr int LSTM_BM = 16;  // batch rows per workgroup: small tiles => many workgroups share the gate epilogue
+constexpr int LSTM_BM = 16;      // batch rows per workgroup: small tiles => many workgroups share the gate epilogue
+constexpr int LSTM_BN_FWD = 64;  // gate columns per workgroup (forward: 4H columns, K = H)
+constexpr int LSTM_BN_BWD = 32;  // hidden columns per workgroup (backward: H columns, K = 4H -- the deeper reduction
+                                 // gets narrower tiles so that all CUs share the longer fragment fetch)
 
-template <typename T, typename Epi>
+// BN > 0: direct-fragment body with BN-column tiles; BN == 0: LDS-staged split-K body (64-column tiles)
+template <typename T, int BN, typename Epi>
 __global__ __launch_bounds__(256) void lstm_step_kernel(NtArgs a0, NtArgs a1, Epi e0, Epi e1) {
   const NtArgs a = blockIdx.y == 0 ? a0 : a1;
   const Epi e = blockIdx.y == 0 ? e0 : e1;
-  igemm_nt_ksplit_body<T, LSTM_BM, Epi>(a, e);
+  if constexpr (BN == 0)
+    igemm_nt_ksplit_body<T, LSTM_BM, Epi>(a, e);
+  else
+    igemm_nt_kdirect_body<T, LSTM_BM, BN, Epi>(a, e);
 }
+
+// tuning knobs (mr_set_lstm_variant): column-tile width of the step kernels, 0 = LDS-staged split-K body
+static int g_lstm_fwd_bn = 0;
+static int g_lstm_bwd_bn = LSTM_BN_BWD;
 
 template <typename T>
 static int lstm_fwd_impl(const void* xproj_, const void* whh_, void* out_, float* cbuf, void* gates_, int Tn, int N,
@@ -94,7 +105,8 @@ static int lstm_fwd_impl(const void* xproj_, const void* whh_, void* out_, float
   T* out = (T*)out_;
   T* gates = (T*)gates_;
   const long long s2 = (long long)N * 2 * H, s8 = (long long)N * 8 * H;
-  const int tiles = cdiv(N, LSTM_BM) * cdiv(4 * H, 64);
+  const int bn = g_lstm_fwd_bn;
+  const int tiles = cdiv(N, LSTM_BM) * cdiv(4 * H, bn ? bn : 64);
   for (int s = 0; s < Tn; ++s) {
     NtArgs a[2];
     EpiLstmFwd<T> e[2];
@@ -111,8 +123,15 @@ static int lstm_fwd_impl(const void* xproj_, const void* whh_, void* out_, float
       e[d].gates_out = gates + t * s8 + d * 4 * H;
       e[d].Nb = N; e[d].H = H;
     }
-    hipLaunchKernelGGL((lstm_step_kernel<T, EpiLstmFwd<T>>), dim3(tiles, 2), dim3(256), 0, stream, a[0], a[1], e[0],
-                       e[1]);
+    if (bn == 0)
+      hipLaunchKernelGGL((lstm_step_kernel<T, 0, EpiLstmFwd<T>>), dim3(tiles, 2), dim3(256), 0, stream, a[0], a[1],
+                         e[0], e[1]);
+    else if (bn == 32)
+      hipLaunchKernelGGL((lstm_step_kernel<T, 32, EpiLstmFwd<T>>), dim3(tiles, 2), dim3(256), 0, stream, a[0], a[1],
+                         e[0], e[1]);
+    else
+      hipLaunchKernelGGL((lstm_step_kernel<T, 64, EpiLstmFwd<T>>), dim3(tiles, 2), dim3(256), 0, stream, a[0], a[1],
+                         e[0], e[1]);
   }
   MR_CHECK_LAUNCH();
   return MR_OK;
@@ -125,7 +144,8 @@ static int lstm_bwd_impl(const void* dout_, const void* whhT_, const float* cbuf
   const T* whhT = (const T*)whhT_;
   T* gates = (T*)gates_;
   const long long s2 = (long long)N * 2 * H, s8 = (long long)N * 8 * H;
-  const int tiles = cdiv(N, LSTM_BM) * cdiv(H, 64);
+  const int bn = g_lstm_bwd_bn;
+  const int tiles = cdiv(N, LSTM_BM) * cdiv(H, bn ? bn : 64);
   for (int s = 0; s < Tn; ++s) {
     NtArgs a[2];
     EpiLstmBwd<T> e[2];
@@ -147,8 +167,18 @@ static int lstm_bwd_impl(const void* dout_, const void* whhT_, const float* cbuf
       e[d].first = s == 0;
       e[d].Nb = N; e[d].H = H;
     }
-    hipLaunchKernelGGL((lstm_step_kernel<T, EpiLstmBwd<T>>), dim3(tiles, 2), dim3(256), 0, stream, a[0], a[1], e[0],
-                       e[1]);
+    if (bn == 0)
+      hipLaunchKernelGGL((lstm_step_kernel<T, 0, EpiLstmBwd<T>>), dim3(tiles, 2), dim3(256), 0, stream, a[0], a[1],
+                         e[0], e[1]);
+    else if (bn == 16)
+      hipLaunchKernelGGL((lstm_step_kernel<T, 16, EpiLstmBwd<T>>), dim3(tiles, 2), dim3(256), 0, stream, a[0], a[1],
+                         e[0], e[1]);
+    else if (bn == 32)
+      hipLaunchKernelGGL((lstm_step_kernel<T, 32, EpiLstmBwd<T>>), dim3(tiles, 2), dim3(256), 0, stream, a[0], a[1],
+                         e[0], e[1]);
+    else
+      hipLaunchKernelGGL((lstm_step_kernel<T, 64, EpiLstmBwd<T>>), dim3(tiles, 2), dim3(256), 0, stream, a[0], a[1],
+                         e[0], e[1]);
   }
   MR_CHECK_LAUNCH();
   return MR_OK;
@@ -159,6 +189,17 @@ static int lstm_bwd_impl(const void* dout_, const void* whhT_, const float* cbuf
 using namespace mr;
 
 extern "C" {
+
+// Tuning knob: column-tile width of the recurrence step kernels.  fwd_bn in {0, 32, 64}, bwd_bn in {0, 16, 32, 64};
+// 0 selects the LDS-staged split-K body, other values the direct-fragment body.  Negative = leave unchanged.
+int mr_set_lstm_variant(int fwd_bn, int bwd_bn) {
+  MR_CHECK_ARG(fwd_bn < 0 || fwd_bn == 0 || fwd_bn == 32 || fwd_bn == 64, "mr_set_lstm_variant: bad fwd_bn %d", fwd_bn);
+  MR_CHECK_ARG(bwd_bn < 0 || bwd_bn == 0 || bwd_bn == 16 || bwd_bn == 32 || bwd_bn == 64,
+               "mr_set_lstm_variant: bad bwd_bn %d", bwd_bn);
+  if (fwd_bn >= 0) g_lstm_fwd_bn = fwd_bn;
+  if (bwd_bn >= 0) g_lstm_bwd_bn = bwd_bn;
+  return MR_OK;
+}
 
 // Recurrent part of the forward pass (input projection done by mr_gemm_nt beforehand).
 int mr_lstm_fwd(int dtype, const void* xproj, const void* whh, void* out, float* cbuf, void* gates, int T, int N,

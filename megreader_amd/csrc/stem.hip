@@ -22,7 +22,7 @@
 namespace mr {
 
 constexpr int STEM_COUT = 64;
-constexpr int STEM_BWD_GROUPS = 512;  // workgroups (= partial sums) of the backward main kernel
+constexpr int STEM_BWD_GROUPS = 1024;  // workgroups (= partial sums) of the backward main kernel
 
 template <typename T> __device__ __forceinline__ float round_as(float v) { return to_f32(from_f32<T>(v)); }
 
@@ -158,7 +158,237 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ dy,
   }
 }
 
-// dw[o][c][dr][ds] (strided) += sum_g partial[g][k][o];  dbias[o] += sum_g partial[g][9*CIN][o].  One block per k.
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 MFMA variants (Wo % 16 == 0).  The 3x3xCin filter is a K = 9*Cin <= 27 (padded to 32) reduction: exactly one
+// v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 channels.  Operand fragments are gathered from the bf16 LDS patch:
+// k = (dr*3 + ds)*Cin + c lives at patch offset dr*ROW + (ds*Cin + c) from the pixel's top-left element.
+// ------------------------------------------------------------------------------------------------------------------
+// All global loads of a thread are issued before the first LDS store (a plain load->store loop with a run-time trip
+// count serialises one memory round trip per iteration).
+template <int CIN>
+__device__ __forceinline__ void stem_stage_patch_bf16(bf16_t* patch, const float* __restrict__ x, int n, int ph,
+                                                      int H, int W) {
+  const int PW = W + 2;
+  const int per_row = CIN * W, total = 4 * per_row;
+  constexpr int U = 8;
+  for (int base = 0; base < total; base += U * 256) {
+    float v[U];
+    int dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * 256 + threadIdx.x;
+      const int r = idx / per_row, rem = idx - r * per_row;
+      const int c = rem / W, col = rem - c * W;
+      const int row = 2 * ph - 1 + r;
+      const bool ok = idx < total && row >= 0 && row < H;
+      v[u] = ok ? x[((long long)(n * CIN + c) * H + row) * W + col] : 0.f;
+      dst[u] = idx < total ? (r * PW + col + 1) * CIN + c : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (dst[u] >= 0) patch[dst[u]] = (bf16_t)v[u];
+  }
+  if (threadIdx.x < 4 * 2 * CIN) {
+    const int r = threadIdx.x / (2 * CIN), rem = threadIdx.x - r * 2 * CIN;
+    const int side = rem / CIN, c = rem - side * CIN;
+    patch[(r * PW + (side ? W + 1 : 0)) * CIN + c] = (bf16_t)0.f;
+  }
+}
+
+// Forward.  One workgroup per pooled output row (strip); wave = 16 pooled pixels: 4 window positions x 4 channel
+// tiles = 16 MFMAs.  MFMA row r of channel tile ct is channel (r>>2)*16 + ct*4 + (r&3), so that a lane (pixel l15,
+// row group lg) ends up with the 16 CONSECUTIVE channels lg*16 .. lg*16+15 of its pixel for all four window
+// positions: max / arg-max / ReLU happen in registers and the lane writes 32 contiguous bytes of y and 16 of codes.
+// The filter bank is packed to bf16 [64][32] in LDS by the whole workgroup (loads issued together with the patch
+// rows: one memory round trip per workgroup), then read back as MFMA fragments.
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            long long wsk, long long wsc, long long wsr,
+                                                            long long wss, const float* __restrict__ bias,
+                                                            bf16_t* __restrict__ y, unsigned char* __restrict__ code,
+                                                            int N, int H, int W) {
+  extern __shared__ float patch_raw[];
+  bf16_t* patch = (bf16_t*)patch_raw;
+  __shared__ __attribute__((aligned(16))) bf16_t wpack[STEM_COUT * 32];
+  __shared__ float bsh[STEM_COUT];
+  constexpr int KT = 9 * CIN;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int Ho = H / 2, Wo = W / 2, PW = W + 2, ROW = PW * CIN;
+  {
+    float wv8[8];  // all 8 loads in flight before the first LDS store
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = u * 256 + threadIdx.x;
+      const int ch = i >> 5, k = i & 31;
+      const int dr = k / (3 * CIN), rem = k - dr * 3 * CIN, ds = rem / CIN, c = rem - ds * CIN;
+      wv8[u] = k < KT ? w[ch * wsk + c * wsc + dr * wsr + ds * wss] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wpack[u * 256 + threadIdx.x] = (bf16_t)wv8[u];
+  }
+  if (threadIdx.x < STEM_COUT) bsh[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  int koff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = 8 * lg + i;
+    const int dr = k / (3 * CIN), rem = k - dr * 3 * CIN;
+    koff[i] = k < KT ? dr * ROW + rem : 0;
+  }
+
+  for (int strip = blockIdx.x; strip < N * Ho; strip += gridDim.x) {
+    const int n = strip / Ho, ph = strip - n * Ho;
+    __syncthreads();
+    stem_stage_patch_bf16<CIN>(patch, x, n, ph, H, W);
+    __syncthreads();
+    for (int pw0 = wv * 16; pw0 < Wo; pw0 += 64) {
+      const int pw = pw0 + l15;
+      bf16x8 xf[4];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int base = ((qq >> 1) * PW + 2 * pw + (qq & 1)) * CIN;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xf[qq][i] = patch[base + koff[i]];
+      }
+      bf16_t yo[16];
+      unsigned char co[16];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int ch = (l15 >> 2) * 16 + ct * 4 + (l15 & 3);
+        const bf16x8 wf = *(const bf16x8*)&wpack[ch * 32 + 8 * lg];
+        f32x4 acc[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          acc[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[qq], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const f32x4 bv = *(const f32x4*)&bsh[lg * 16 + ct * 4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float best = acc[0][r];
+          int q = 0;
+#pragma unroll
+          for (int qq = 1; qq < 4; ++qq)
+            if (acc[qq][r] > best) {  // strict > keeps the first maximum
+              best = acc[qq][r];
+              q = qq;
+            }
+          best += bv[r];
+          const bool pos = best > 0.f;
+          yo[ct * 4 + r] = (bf16_t)(pos ? best : 0.f);
+          co[ct * 4 + r] = (unsigned char)(q | (pos ? 4 : 0));
+        }
+      }
+      const long long o = ((long long)strip * Wo + pw) * STEM_COUT + lg * 16;
+      *(uint4*)(y + o) = *(const uint4*)&yo[0];
+      *(uint4*)(y + o + 8) = *(const uint4*)&yo[8];
+      *(uint4*)(code + o) = *(const uint4*)&co[0];
+    }
+  }
+}
+
+// Backward.  dW[ch][k] = sum over (pooled pixel, window position) of G[ch] * X[k]: per 8 pooled pixels one
+// 32-deep reduction step (8 pixels x 4 positions).  Lane group lg owns pixels 2*lg, 2*lg+1 and all 4 positions, so
+// the G fragment of a lane (channel l15 of tile mt) needs just 2 gradient values + 2 codes.  An extra im2col column
+// k = 9*Cin of ones yields the bias gradient in the same MFMAs.  The gradient / code loads of a chunk are issued
+// one chunk ahead (the first one before the patch barrier) so they overlap the staging and the MFMAs.
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const bf16_t* __restrict__ dy,
+                                                            const unsigned char* __restrict__ code,
+                                                            const float* __restrict__ x, float* __restrict__ partial,
+                                                            int N, int H, int W) {
+  extern __shared__ float patch_raw[];
+  bf16_t* patch = (bf16_t*)patch_raw;
+  constexpr int KT = 9 * CIN;
+  __shared__ float red[4][KT + 1][STEM_COUT];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int Ho = H / 2, Wo = W / 2, PW = W + 2, ROW = PW * CIN;
+  // X-fragment gather offsets of this lane: k = l15 + 16*nt, reduction slot i -> pixel 2*lg + (i>>2), position i&3
+  int xoff[2][8];
+  int xkind[2];  // 0 gather, 1 ones (bias column), 2 zeros
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int k = l15 + 16 * nt;
+    const int dr = k / (3 * CIN), rem = k - dr * 3 * CIN;
+    xkind[nt] = k < KT ? 0 : (k == KT ? 1 : 2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int px = 2 * lg + (i >> 2), qq = i & 3;
+      xoff[nt][i] = k < KT ? ((qq >> 1) * PW + 2 * px + (qq & 1)) * CIN + dr * ROW + rem : 0;
+    }
+  }
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16_t one = (bf16_t)1.f, zero = (bf16_t)0.f;
+
+  bf16_t gd[4][2];
+  unsigned char gc[4][2];
+  auto load_chunk = [&](int strip, int pw0) {
+    const long long o = ((long long)strip * Wo + pw0 + 2 * lg) * STEM_COUT + l15;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const long long oo = o + (long long)h * STEM_COUT + mt * 16;
+        gd[mt][h] = dy[oo];
+        gc[mt][h] = code[oo];
+      }
+  };
+
+  for (int strip = blockIdx.x; strip < N * Ho; strip += gridDim.x) {
+    const int n = strip / Ho, ph = strip - n * Ho;
+    const bool has_chunk = wv * 8 < Wo;
+    if (has_chunk) load_chunk(strip, wv * 8);
+    __syncthreads();
+    stem_stage_patch_bf16<CIN>(patch, x, n, ph, H, W);
+    __syncthreads();
+    for (int pw0 = wv * 8; pw0 < Wo; pw0 += 32) {
+      bf16x8 gf[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int cd = gc[mt][h];
+          const bf16_t g = (cd & 4) ? gd[mt][h] : zero;
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) gf[mt][h * 4 + qq] = ((cd & 3) == qq) ? g : zero;
+        }
+      if (pw0 + 32 < Wo) load_chunk(strip, pw0 + 32);  // next chunk's loads fly during this chunk's MFMAs
+      bf16x8 xf[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bf16_t v = patch[2 * pw0 * CIN + xoff[nt][i]];
+          xf[nt][i] = xkind[nt] == 0 ? v : (xkind[nt] == 1 ? one : zero);
+        }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[mt], xf[nt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  // D rows = channels mt*16 + lg*4 + r, columns = k = l15 + 16*nt
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int k = l15 + 16 * nt;
+      if (k <= KT)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv][k][mt * 16 + lg * 4 + r] = acc[mt][nt][r];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (KT + 1) * STEM_COUT; i += blockDim.x) {
+    const int k = i / STEM_COUT, oc = i - k * STEM_COUT;
+    partial[(long long)blockIdx.x * (KT + 1) * STEM_COUT + i] = red[0][k][oc] + red[1][k][oc] + red[2][k][oc] + red[3][k][oc];
+  }
+}
+
+// dw[o][c][dr][ds] (strided) += sum_g partial[g][k][o];  dbias[o] += sum_g partial[g][9*CIN][o].
+// grid (9*CIN + 1, 8): block (k, z) sums the partials g = z, z+8, ... with 8 thread groups, then one atomic per (k, o).
 template <int CIN>
 __global__ __launch_bounds__(512) void stem_bwd_reduce_kernel(const float* __restrict__ partial, int G,
                                                               float* __restrict__ dw, long long dsk, long long dsc,
@@ -168,7 +398,7 @@ __global__ __launch_bounds__(512) void stem_bwd_reduce_kernel(const float* __res
   __shared__ float red[8][STEM_COUT];
   const int k = blockIdx.x, o = threadIdx.x & 63, part = threadIdx.x >> 6;  // 8 parts
   float s = 0.f;
-  for (int g = part; g < G; g += 8) s += partial[((long long)g * (KT + 1) + k) * STEM_COUT + o];
+  for (int g = blockIdx.y + 8 * part; g < G; g += 64) s += partial[((long long)g * (KT + 1) + k) * STEM_COUT + o];
   red[part][o] = s;
   __syncthreads();
   if (part == 0) {
@@ -176,9 +406,9 @@ __global__ __launch_bounds__(512) void stem_bwd_reduce_kernel(const float* __res
     for (int p = 1; p < 8; ++p) s += red[p][o];
     if (k < KT) {
       const int c = k % CIN, t = k / CIN, ds = t % 3, dr = t / 3;
-      if (dw) dw[o * dsk + c * dsc + dr * dsr + ds * dss] += s;
+      if (dw) atomicAdd(&dw[o * dsk + c * dsc + dr * dsr + ds * dss], s);
     } else if (dbias) {
-      dbias[o] += s;
+      atomicAdd(&dbias[o], s);
     }
   }
 }
@@ -213,6 +443,16 @@ int mr_stem_fwd(int dtype, const float* x, const float* w, long long wsk, long l
   const size_t lds = sizeof(float) * 4 * (W + 2) * Cin;
   const int strips = N * (H / 2);
   const int grid = strips < 8192 ? strips : 8192;
+  if (dtype == MR_BF16 && (W / 2) % 16 == 0) {  // MFMA path
+    if (Cin == 3)
+      hipLaunchKernelGGL((stem_fwd_mfma_kernel<3>), dim3(grid), dim3(256), lds, stream, x, w, wsk, wsc, wsr, wss,
+                         bias, (bf16_t*)y, code, N, H, W);
+    else
+      hipLaunchKernelGGL((stem_fwd_mfma_kernel<1>), dim3(grid), dim3(256), lds, stream, x, w, wsk, wsc, wsr, wss,
+                         bias, (bf16_t*)y, code, N, H, W);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+  }
   if (Cin == 3) {
     DISPATCH_T(dtype, hipLaunchKernelGGL((stem_fwd_kernel<T, 3>), dim3(grid), dim3(256), lds, stream, x, w, wsk, wsc,
                                          wsr, wss, bias, (T*)y, code, N, H, W));
@@ -233,15 +473,30 @@ int mr_stem_bwd(int dtype, const void* dy, const unsigned char* code, const floa
   const size_t lds = sizeof(float) * 4 * (W + 2) * Cin;
   const int strips = N * (H / 2);
   const int G = strips < STEM_BWD_GROUPS ? strips : STEM_BWD_GROUPS;
+  if (dtype == MR_BF16 && (W / 2) % 16 == 0) {  // MFMA path
+    if (Cin == 3) {
+      hipLaunchKernelGGL((stem_bwd_mfma_kernel<3>), dim3(G), dim3(256), lds, stream, (const bf16_t*)dy, code, x,
+                         workspace, N, H, W);
+      hipLaunchKernelGGL((stem_bwd_reduce_kernel<3>), dim3(9 * 3 + 1, 8), dim3(512), 0, stream, workspace, G, dw, dsk,
+                         dsc, dsr, dss, dbias);
+    } else {
+      hipLaunchKernelGGL((stem_bwd_mfma_kernel<1>), dim3(G), dim3(256), lds, stream, (const bf16_t*)dy, code, x,
+                         workspace, N, H, W);
+      hipLaunchKernelGGL((stem_bwd_reduce_kernel<1>), dim3(9 * 1 + 1, 8), dim3(512), 0, stream, workspace, G, dw, dsk,
+                         dsc, dsr, dss, dbias);
+    }
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+  }
   if (Cin == 3) {
     DISPATCH_T(dtype, hipLaunchKernelGGL((stem_bwd_kernel<T, 3>), dim3(G), dim3(256), lds, stream, (const T*)dy, code,
                                          x, workspace, N, H, W));
-    hipLaunchKernelGGL((stem_bwd_reduce_kernel<3>), dim3(9 * 3 + 1), dim3(512), 0, stream, workspace, G, dw, dsk, dsc,
+    hipLaunchKernelGGL((stem_bwd_reduce_kernel<3>), dim3(9 * 3 + 1, 8), dim3(512), 0, stream, workspace, G, dw, dsk, dsc,
                        dsr, dss, dbias);
   } else {
     DISPATCH_T(dtype, hipLaunchKernelGGL((stem_bwd_kernel<T, 1>), dim3(G), dim3(256), lds, stream, (const T*)dy, code,
                                          x, workspace, N, H, W));
-    hipLaunchKernelGGL((stem_bwd_reduce_kernel<1>), dim3(9 * 1 + 1), dim3(512), 0, stream, workspace, G, dw, dsk, dsc,
+    hipLaunchKernelGGL((stem_bwd_reduce_kernel<1>), dim3(9 * 1 + 1, 8), dim3(512), 0, stream, workspace, G, dw, dsk, dsc,
                        dsr, dss, dbias);
   }
   MR_CHECK_LAUNCH();

@@ -31,7 +31,20 @@ class PrepJob(ctypes.Structure):
                 ("dst_b", ctypes.c_void_p), ("s0", ctypes.c_longlong), ("s1", ctypes.c_longlong),
                 ("s2", ctypes.c_longlong), ("s3", ctypes.c_longlong), ("kind", ctypes.c_int), ("d0", ctypes.c_int),
                 ("d1", ctypes.c_int), ("d2", ctypes.c_int), ("d3", ctypes.c_int), ("pad", ctypes.c_int),
-                ("ld_b", ctypes.c_int), ("perm_h", ctypes.c_int)]
+                ("ld_b", ctypes.c_int), ("perm_h", ctypes.c_int), ("block_start", ctypes.c_int),
+                ("reserved", ctypes.c_int)]
+
+
+
+def job_blocks(j):
+    """Grid blocks (64x64 tiles) of one job -- must match prep_batch_kernel (csrc/elementwise.hip)."""
+    if j['kind'] == KIND_CONV:
+        return ((j['d0'] + 63) // 64) * ((j['d2'] * j['d3'] * j['pad'] + 63) // 64)
+    if j['kind'] == KIND_MATRIX:
+        return ((j['d0'] + 63) // 64) * ((j['d1'] + 63) // 64)
+    return (j['d0'] + 4095) // 4096
+
+MAX_JOBS = 1024     # per mr_prep_batch launch
 
 
 def conv_job(src, strides, dst_krsc, dst_crsk, K, C, R, S, Cpad, ldk):
@@ -107,17 +120,23 @@ class _Plan(object):
         by_dtype = {}
         for e in entries:
             by_dtype.setdefault(e.dtype, []).extend(e.jobs)
-        for dtype, jobs in by_dtype.items():
+        chunks = [(dtype, jobs[i:i + MAX_JOBS]) for dtype, jobs in by_dtype.items()
+                  for i in range(0, len(jobs), MAX_JOBS)]
+        for dtype, jobs in chunks:
             arr = (PrepJob * len(jobs))()
+            nblocks = 0
             for slot, j in zip(arr, jobs):
                 for name, _ in PrepJob._fields_:
-                    setattr(slot, name, j[name])
+                    if name in j:
+                        setattr(slot, name, j[name])
+                slot.block_start = nblocks
+                nblocks += job_blocks(j)
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            self.tables.append((dtype_code(dtype), host.to(device), len(jobs), max(j['total'] for j in jobs)))
+            self.tables.append((dtype_code(dtype), host.to(device), len(jobs), nblocks))
 
     def launch(self):
-        for dt, table, njobs, max_total in self.tables:
-            call("mr_prep_batch", dt, ptr(table), njobs, max_total)
+        for dt, table, njobs, nblocks in self.tables:
+            call("mr_prep_batch", dt, ptr(table), njobs, nblocks)
 
 
 def refresh(params, holder):

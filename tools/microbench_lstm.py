@@ -23,10 +23,15 @@ def timeit(f, iters=10):
 
 
 def main():
+    from megreader_amd._lib import load
     dtype = torch.bfloat16
     mr.set_compute_dtype(dtype)
     T, N, H = 33, 256, 256
-    for I in (512, 256):
+    variants = [(0, 0), (0, 16), (0, 32), (0, 64), (32, 32), (64, 32)] if "--sweep" in sys.argv else [(-1, -1)]
+    for fv, bv in variants:
+      load().mr_set_lstm_variant(fv, bv)
+      print("variant fwd_bn=%d bwd_bn=%d" % (fv, bv))
+      for I in (512,):
         torch.manual_seed(0)
         ref = torch.nn.LSTM(I, H, bidirectional=True)
         params = [p.detach().cuda().requires_grad_(True) for p in ref.parameters()]
@@ -41,9 +46,21 @@ def main():
             y = F.bilstm(x, *params)
             y.backward(g)
 
-        tf = timeit(fwd)
-        tfb = timeit(fwdbwd)
-        print("BiLSTM I=%d: fwd %.1f us, fwd+bwd %.1f us (bwd ~%.1f us)" % (I, tf, tfb, tfb - tf))
+        # graph replay removes the host launch cost (the training step runs the same way)
+        def graphed(fn):
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                fn()
+            torch.cuda.current_stream().wait_stream(s)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                fn()
+            return gr.replay
+
+        tf = timeit(graphed(fwd))
+        tfb = timeit(graphed(fwdbwd))
+        print("  BiLSTM I=%d: fwd %.1f us, fwd+bwd %.1f us (bwd ~%.1f us)" % (I, tf, tfb, tfb - tf))
 
 
 if __name__ == "__main__":
