@@ -93,14 +93,16 @@ int mr_prep_bias(const float* a, const float* b, float* dst, int R, int perm_h, 
  *   MR_PREP_MATRIX: mr_prep_matrix(src, s0 = lds, dst_a = dst_n, pad = ldn, dst_b = dst_t, ld_b = ldt, d0,d1 = R,C,
  *                   perm_h)
  *   MR_PREP_BIAS:   mr_prep_bias(src, src2, dst_a (f32), d0 = R, perm_h)
+ *   MR_PREP_STEM:   mr_stem_pack(src, s0..s3 = sk,sc,sr,ss, dst_a = wpack, d1 = Cin)   (one block)
  * Work unit = one 64x64 tile of the job's logical matrix (conv: K rows x R*S*Cpad columns; matrix: R x C; bias:
  * 4096 elements).  The jobs are laid end to end on the grid: job.block_start = index of its first tile (jobs
  * sorted by block_start, job 0 starts at 0); total_blocks = sum over jobs of
- *   conv: ceil(K/64)*ceil(R*S*Cpad/64), matrix: ceil(R/64)*ceil(C/64), bias: ceil(R/4096).
+ *   conv: ceil(K/64)*ceil(R*S*Cpad/64), matrix: ceil(R/64)*ceil(C/64), bias: ceil(R/4096), stem: 1.
  * Transposed images need dst_b 16-byte aligned and ld_b a multiple of one 16-byte vector for the fast path. */
 #define MR_PREP_CONV 0
 #define MR_PREP_MATRIX 1
 #define MR_PREP_BIAS 2
+#define MR_PREP_STEM 3
 typedef struct mr_prep_job {
   const float* src;
   const float* src2;
@@ -152,9 +154,14 @@ int mr_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, const vo
  * mr_stem_bwd ACCUMULATES into dw (strides dsk..dss) and dbias (either may be null); workspace must hold
  * mr_stem_bwd_workspace(Cin) floats.  The layer's input gradient is not produced (the input is the image). */
 long long mr_stem_bwd_workspace(int Cin);
+/* wpack (bf16 [64][32], k = (dr*3+ds)*Cin + c, zero padded): the filter bank pre-packed for the bf16 MFMA kernel by
+ * mr_stem_pack / an MR_PREP_STEM job.  When it is null (or dtype is f32, or W/2 is not a multiple of 16) mr_stem_fwd
+ * runs the generic FMA kernel straight from w. */
+int mr_stem_pack(const float* w, long long wsk, long long wsc, long long wsr, long long wss, void* wpack, int Cin,
+                 hipStream_t stream);
 int mr_stem_fwd(int dtype, const float* x, const float* w, long long wsk, long long wsc, long long wsr,
-                long long wss, const float* bias, void* y, unsigned char* code, int N, int Cin, int H, int W,
-                hipStream_t stream);
+                long long wss, const void* wpack, const float* bias, void* y, unsigned char* code, int N, int Cin,
+                int H, int W, hipStream_t stream);
 int mr_stem_bwd(int dtype, const void* dy, const unsigned char* code, const float* x, float* workspace, float* dw,
                 long long dsk, long long dsc, long long dsr, long long dss, float* dbias, int N, int Cin, int H,
                 int W, hipStream_t stream);

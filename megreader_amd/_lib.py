@@ -43,7 +43,8 @@ SIGNATURES = {
     "mr_bn_fwd_train": "ipppppppppp" + "iliffs",
     "mr_bn_fwd_eval": "ippppppppp" + "ilifs",
     "mr_bn_bwd": "ipppppppppp" + "pilis",
-    "mr_stem_fwd": "ippllllpppiiiis",
+    "mr_stem_pack": "pllllpis",
+    "mr_stem_fwd": "ippllllppppiiiis",
     "mr_stem_bwd": "ipppppllllpiiiis",
     "mr_maxpool_fwd": "ippp" + "i" * 12 + "s",
     "mr_maxpool_bwd": "ipppp" + "i" * 12 + "s",

@@ -250,6 +250,16 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(const mr_prep_job* __re
     }
     return;
   }
+  if (j.kind == MR_PREP_STEM) {  // bf16-style packed stem filter bank [64][32] (see csrc/stem.hip)
+    const int CIN = j.d1, KT = 9 * CIN;
+    T* dst = (T*)j.dst_a;
+    for (int i = tid; i < 64 * 32; i += 256) {
+      const int ch = i >> 5, k = i & 31;
+      const int dr = k / (3 * CIN), rem = k - dr * 3 * CIN, ds = rem / CIN, c = rem - ds * CIN;
+      dst[i] = from_f32<T>(k < KT ? j.src[ch * j.s0 + c * j.s1 + dr * j.s2 + ds * j.s3] : 0.f);
+    }
+    return;
+  }
   const bool conv = j.kind == MR_PREP_CONV;
   const int rows = j.d0;
   const int cols = conv ? j.d2 * j.d3 * j.pad : j.d1;

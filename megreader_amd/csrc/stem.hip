@@ -163,30 +163,27 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ dy,
 // v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 channels.  Operand fragments are gathered from the bf16 LDS patch:
 // k = (dr*3 + ds)*Cin + c lives at patch offset dr*ROW + (ds*Cin + c) from the pixel's top-left element.
 // ------------------------------------------------------------------------------------------------------------------
-// All global loads of a thread are issued before the first LDS store (a plain load->store loop with a run-time trip
-// count serialises one memory round trip per iteration).
+// Division-free staging: waves 0,2 fetch patch rows 0,1 and waves 1,3 rows 2,3; a wave pair covers 128 columns per
+// pass.  All global loads of a thread are issued before its first LDS store.
 template <int CIN>
 __device__ __forceinline__ void stem_stage_patch_bf16(bf16_t* patch, const float* __restrict__ x, int n, int ph,
                                                       int H, int W) {
   const int PW = W + 2;
-  const int per_row = CIN * W, total = 4 * per_row;
-  constexpr int U = 8;
-  for (int base = 0; base < total; base += U * 256) {
-    float v[U];
-    int dst[U];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rbase = (wv & 1) * 2;
+  for (int col = lane + 64 * (wv >> 1); col < W; col += 128) {
+    float v[2][CIN];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = base + u * 256 + threadIdx.x;
-      const int r = idx / per_row, rem = idx - r * per_row;
-      const int c = rem / W, col = rem - c * W;
-      const int row = 2 * ph - 1 + r;
-      const bool ok = idx < total && row >= 0 && row < H;
-      v[u] = ok ? x[((long long)(n * CIN + c) * H + row) * W + col] : 0.f;
-      dst[u] = idx < total ? (r * PW + col + 1) * CIN + c : -1;
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 2 * ph - 1 + rbase + rr;
+      const bool rv = row >= 0 && row < H;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) v[rr][c] = rv ? x[((long long)(n * CIN + c) * H + row) * W + col] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (dst[u] >= 0) patch[dst[u]] = (bf16_t)v[u];
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) patch[((rbase + rr) * PW + col + 1) * CIN + c] = (bf16_t)v[rr][c];
   }
   if (threadIdx.x < 4 * 2 * CIN) {
     const int r = threadIdx.x / (2 * CIN), rem = threadIdx.x - r * 2 * CIN;
@@ -195,38 +192,45 @@ __device__ __forceinline__ void stem_stage_patch_bf16(bf16_t* patch, const float
   }
 }
 
+// Filter bank packed for the MFMA forward: bf16 [64 channels][32 k], k = (dr*3 + ds)*Cin + c, zero for k >= 9*Cin.
+// Produced once per optimizer step (MR_PREP_STEM job of mr_prep_batch, or mr_stem_pack).
+template <int CIN>
+__global__ void stem_pack_kernel(const float* __restrict__ w, long long wsk, long long wsc, long long wsr,
+                                 long long wss, bf16_t* __restrict__ wpack) {
+  constexpr int KT = 9 * CIN;
+  for (int i = threadIdx.x; i < STEM_COUT * 32; i += blockDim.x) {
+    const int ch = i >> 5, k = i & 31;
+    const int dr = k / (3 * CIN), rem = k - dr * 3 * CIN, ds = rem / CIN, c = rem - ds * CIN;
+    wpack[i] = (bf16_t)(k < KT ? w[ch * wsk + c * wsc + dr * wsr + ds * wss] : 0.f);
+  }
+}
+
 // Forward.  One workgroup per pooled output row (strip); wave = 16 pooled pixels: 4 window positions x 4 channel
 // tiles = 16 MFMAs.  MFMA row r of channel tile ct is channel (r>>2)*16 + ct*4 + (r&3), so that a lane (pixel l15,
 // row group lg) ends up with the 16 CONSECUTIVE channels lg*16 .. lg*16+15 of its pixel for all four window
 // positions: max / arg-max / ReLU happen in registers and the lane writes 32 contiguous bytes of y and 16 of codes.
-// The filter bank is packed to bf16 [64][32] in LDS by the whole workgroup (loads issued together with the patch
-// rows: one memory round trip per workgroup), then read back as MFMA fragments.
+// The kernel is VALU-bound (arg-max bookkeeping), so everything else is kept off the vector ALU: the filter bank
+// arrives pre-packed (4 fragment loads per lane), staging is division-free.
 template <int CIN>
-__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            long long wsk, long long wsc, long long wsr,
-                                                            long long wss, const float* __restrict__ bias,
-                                                            bf16_t* __restrict__ y, unsigned char* __restrict__ code,
-                                                            int N, int H, int W) {
+__global__ __launch_bounds__(256, 3) void stem_fwd_mfma_kernel(const float* __restrict__ x,
+                                                            const bf16_t* __restrict__ wpack,
+                                                            const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                            unsigned char* __restrict__ code, int N, int H, int W) {
   extern __shared__ float patch_raw[];
   bf16_t* patch = (bf16_t*)patch_raw;
-  __shared__ __attribute__((aligned(16))) bf16_t wpack[STEM_COUT * 32];
-  __shared__ float bsh[STEM_COUT];
   constexpr int KT = 9 * CIN;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
   const int Ho = H / 2, Wo = W / 2, PW = W + 2, ROW = PW * CIN;
-  {
-    float wv8[8];  // all 8 loads in flight before the first LDS store
+  bf16x8 wf[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = u * 256 + threadIdx.x;
-      const int ch = i >> 5, k = i & 31;
-      const int dr = k / (3 * CIN), rem = k - dr * 3 * CIN, ds = rem / CIN, c = rem - ds * CIN;
-      wv8[u] = k < KT ? w[ch * wsk + c * wsc + dr * wsr + ds * wss] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) wpack[u * 256 + threadIdx.x] = (bf16_t)wv8[u];
+  for (int ct = 0; ct < 4; ++ct) {
+    const int ch = (l15 >> 2) * 16 + ct * 4 + (l15 & 3);
+    wf[ct] = *(const bf16x8*)(wpack + ch * 32 + 8 * lg);
   }
-  if (threadIdx.x < STEM_COUT) bsh[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  f32x4 bv[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+    bv[ct] = bias ? *(const f32x4*)(bias + lg * 16 + ct * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   int koff[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -253,27 +257,23 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
       unsigned char co[16];
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        const int ch = (l15 >> 2) * 16 + ct * 4 + (l15 & 3);
-        const bf16x8 wf = *(const bf16x8*)&wpack[ch * 32 + 8 * lg];
         f32x4 acc[4];
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
-          acc[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[qq], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        const f32x4 bv = *(const f32x4*)&bsh[lg * 16 + ct * 4];
+          acc[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct], xf[qq], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float best = acc[0][r];
-          int q = 0;
-#pragma unroll
-          for (int qq = 1; qq < 4; ++qq)
-            if (acc[qq][r] > best) {  // strict > keeps the first maximum
-              best = acc[qq][r];
-              q = qq;
-            }
-          best += bv[r];
+          // first maximum of the window, in scan order
+          // (compare + select instead of fmaxf: no NaN canonicalisation, and the compares are needed anyway)
+          const float a0 = acc[0][r], a1 = acc[1][r], a2 = acc[2][r], a3 = acc[3][r];
+          const bool c1 = a1 > a0, c2 = a3 > a2;
+          const float m01 = c1 ? a1 : a0, m23 = c2 ? a3 : a2;
+          const bool c3 = m23 > m01;
+          const int q = c3 ? (c2 ? 3 : 2) : (c1 ? 1 : 0);
+          const float best = (c3 ? m23 : m01) + bv[ct][r];
           const bool pos = best > 0.f;
           yo[ct * 4 + r] = (bf16_t)(pos ? best : 0.f);
-          co[ct * 4 + r] = (unsigned char)(q | (pos ? 4 : 0));
+          co[ct * 4 + r] = (unsigned char)(pos ? (q | 4) : q);
         }
       }
       const long long o = ((long long)strip * Wo + pw) * STEM_COUT + lg * 16;
@@ -288,26 +288,31 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
 // 32-deep reduction step (8 pixels x 4 positions).  Lane group lg owns pixels 2*lg, 2*lg+1 and all 4 positions, so
 // the G fragment of a lane (channel l15 of tile mt) needs just 2 gradient values + 2 codes.  An extra im2col column
 // k = 9*Cin of ones yields the bias gradient in the same MFMAs.  The gradient / code loads of a chunk are issued
-// one chunk ahead (the first one before the patch barrier) so they overlap the staging and the MFMAs.
+// one chunk ahead (the first one before the patch barrier) so they overlap the staging and the MFMAs.  Fragments
+// are assembled with 32-bit integer ops on the raw bf16 bits (the kernel is VALU-bound).
 template <int CIN>
-__global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(256, 4) void stem_bwd_mfma_kernel(const bf16_t* __restrict__ dy,
                                                             const unsigned char* __restrict__ code,
                                                             const float* __restrict__ x, float* __restrict__ partial,
                                                             int N, int H, int W) {
   extern __shared__ float patch_raw[];
   bf16_t* patch = (bf16_t*)patch_raw;
+  const unsigned short* patch16 = (const unsigned short*)patch_raw;
+  const unsigned short* dy16 = (const unsigned short*)dy;
   constexpr int KT = 9 * CIN;
   __shared__ float red[4][KT + 1][STEM_COUT];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
   const int Ho = H / 2, Wo = W / 2, PW = W + 2, ROW = PW * CIN;
-  // X-fragment gather offsets of this lane: k = l15 + 16*nt, reduction slot i -> pixel 2*lg + (i>>2), position i&3
+  // X-fragment gather offsets of this lane: k = l15 + 16*nt, reduction slot i -> pixel 2*lg + (i>>2), position i&3.
+  // Lanes of the bias column (k == 9*Cin) use all-ones, lanes beyond it zeros: value = (raw & xand) | xor_.
   int xoff[2][8];
-  int xkind[2];  // 0 gather, 1 ones (bias column), 2 zeros
+  unsigned xand[2], xor_[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int k = l15 + 16 * nt;
     const int dr = k / (3 * CIN), rem = k - dr * 3 * CIN;
-    xkind[nt] = k < KT ? 0 : (k == KT ? 1 : 2);
+    xand[nt] = k < KT ? 0xFFFFFFFFu : 0u;
+    xor_[nt] = k == KT ? 0x3F803F80u : 0u;  // bf16 1.0 in both halves
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int px = 2 * lg + (i >> 2), qq = i & 3;
@@ -319,10 +324,8 @@ __global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const bf16_t* __rest
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bf16_t one = (bf16_t)1.f, zero = (bf16_t)0.f;
 
-  bf16_t gd[4][2];
-  unsigned char gc[4][2];
+  unsigned gd[4][2], gc[4][2];
   auto load_chunk = [&](int strip, int pw0) {
     const long long o = ((long long)strip * Wo + pw0 + 2 * lg) * STEM_COUT + l15;
 #pragma unroll
@@ -330,43 +333,46 @@ __global__ __launch_bounds__(256) void stem_bwd_mfma_kernel(const bf16_t* __rest
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const long long oo = o + (long long)h * STEM_COUT + mt * 16;
-        gd[mt][h] = dy[oo];
+        gd[mt][h] = dy16[oo];
         gc[mt][h] = code[oo];
       }
   };
 
   for (int strip = blockIdx.x; strip < N * Ho; strip += gridDim.x) {
     const int n = strip / Ho, ph = strip - n * Ho;
-    const bool has_chunk = wv * 8 < Wo;
-    if (has_chunk) load_chunk(strip, wv * 8);
+    if (wv * 8 < Wo) load_chunk(strip, wv * 8);
     __syncthreads();
     stem_stage_patch_bf16<CIN>(patch, x, n, ph, H, W);
     __syncthreads();
     for (int pw0 = wv * 8; pw0 < Wo; pw0 += 32) {
-      bf16x8 gf[4];
+      // G fragment: dword d of (mt) holds reduction slots 2d, 2d+1 = pixel h = d>>1, positions 2(d&1), 2(d&1)+1
+      u32x4 gf[4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int cd = gc[mt][h];
-          const bf16_t g = (cd & 4) ? gd[mt][h] : zero;
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) gf[mt][h * 4 + qq] = ((cd & 3) == qq) ? g : zero;
+          const unsigned cd = gc[mt][h];
+          const unsigned g = (cd & 4u) ? gd[mt][h] : 0u;
+          const unsigned sh = g << ((cd & 1u) * 16u);   // low half for even positions, high half for odd
+          gf[mt][h * 2 + 0] = (cd & 2u) ? 0u : sh;     // positions 0,1
+          gf[mt][h * 2 + 1] = (cd & 2u) ? sh : 0u;     // positions 2,3
         }
       if (pw0 + 32 < Wo) load_chunk(strip, pw0 + 32);  // next chunk's loads fly during this chunk's MFMAs
-      bf16x8 xf[2];
+      u32x4 xf[2];
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const bf16_t v = patch[2 * pw0 * CIN + xoff[nt][i]];
-          xf[nt][i] = xkind[nt] == 0 ? v : (xkind[nt] == 1 ? one : zero);
+        for (int d = 0; d < 4; ++d) {
+          const unsigned lo = patch16[2 * pw0 * CIN + xoff[nt][2 * d]];
+          const unsigned hi = patch16[2 * pw0 * CIN + xoff[nt][2 * d + 1]];
+          xf[nt][d] = ((lo | (hi << 16)) & xand[nt]) | xor_[nt];
         }
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[mt], xf[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&gf[mt], *(const bf16x8*)&xf[nt],
+                                                                acc[mt][nt], 0, 0, 0);
     }
   }
   __syncthreads();
@@ -436,20 +442,32 @@ extern "C" {
 
 long long mr_stem_bwd_workspace(int Cin) { return (long long)STEM_BWD_GROUPS * (9 * Cin + 1) * STEM_COUT; }
 
+// bf16 filter bank for the MFMA forward path ([64][32], see stem_pack_kernel)
+int mr_stem_pack(const float* w, long long wsk, long long wsc, long long wsr, long long wss, void* wpack, int Cin,
+                 hipStream_t stream) {
+  MR_CHECK_ARG(Cin == 1 || Cin == 3, "mr_stem_pack: Cin must be 1 or 3");
+  if (Cin == 3)
+    hipLaunchKernelGGL((stem_pack_kernel<3>), dim3(1), dim3(256), 0, stream, w, wsk, wsc, wsr, wss, (bf16_t*)wpack);
+  else
+    hipLaunchKernelGGL((stem_pack_kernel<1>), dim3(1), dim3(256), 0, stream, w, wsk, wsc, wsr, wss, (bf16_t*)wpack);
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
 int mr_stem_fwd(int dtype, const float* x, const float* w, long long wsk, long long wsc, long long wsr,
-                long long wss, const float* bias, void* y, unsigned char* code, int N, int Cin, int H, int W,
-                hipStream_t stream) {
+                long long wss, const void* wpack, const float* bias, void* y, unsigned char* code, int N, int Cin,
+                int H, int W, hipStream_t stream) {
   if (int rc = stem_check("mr_stem_fwd", N, Cin, H, W)) return rc;
   const size_t lds = sizeof(float) * 4 * (W + 2) * Cin;
   const int strips = N * (H / 2);
   const int grid = strips < 8192 ? strips : 8192;
-  if (dtype == MR_BF16 && (W / 2) % 16 == 0) {  // MFMA path
+  if (dtype == MR_BF16 && (W / 2) % 16 == 0 && wpack != nullptr) {  // MFMA path
     if (Cin == 3)
-      hipLaunchKernelGGL((stem_fwd_mfma_kernel<3>), dim3(grid), dim3(256), lds, stream, x, w, wsk, wsc, wsr, wss,
-                         bias, (bf16_t*)y, code, N, H, W);
+      hipLaunchKernelGGL((stem_fwd_mfma_kernel<3>), dim3(grid), dim3(256), lds, stream, x, (const bf16_t*)wpack, bias,
+                         (bf16_t*)y, code, N, H, W);
     else
-      hipLaunchKernelGGL((stem_fwd_mfma_kernel<1>), dim3(grid), dim3(256), lds, stream, x, w, wsk, wsc, wsr, wss,
-                         bias, (bf16_t*)y, code, N, H, W);
+      hipLaunchKernelGGL((stem_fwd_mfma_kernel<1>), dim3(grid), dim3(256), lds, stream, x, (const bf16_t*)wpack, bias,
+                         (bf16_t*)y, code, N, H, W);
     MR_CHECK_LAUNCH();
     return MR_OK;
   }

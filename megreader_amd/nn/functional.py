@@ -314,7 +314,15 @@ class StemConvReluPoolFn(Function):
         y = torch.empty((N, H // 2, W // 2, 64), dtype=dtype, device=x.device)
         code = torch.empty((N, H // 2, W // 2, 64), dtype=torch.uint8, device=x.device)
         sk, sc, sr, ss = weight.stride()
-        call("mr_stem_fwd", dt, ptr(x), ptr(weight), sk, sc, sr, ss, ptr(bias), ptr(y), ptr(code), N, C, H, W)
+        wpack = None
+        if dtype == torch.bfloat16:  # filter bank pre-packed for the MFMA kernel (regenerated with the other images)
+            def build(old):
+                buf = old[0] if old is not None else torch.empty((64, 32), dtype=dtype, device=x.device)
+                return (buf,), [prep.stem_job(ptr(weight), (sk, sc, sr, ss), ptr(buf), C)]
+
+            wpack = prep.prepared((weight,), ("stem", C), build, dtype)[0]
+        call("mr_stem_fwd", dt, ptr(x), ptr(weight), sk, sc, sr, ss, ptr(wpack), ptr(bias), ptr(y), ptr(code), N, C,
+             H, W)
         ctx.save_for_backward(x, code)
         ctx.params = (weight, bias)
         ctx.dtype = dtype

@@ -22,7 +22,7 @@ import torch
 
 from .._lib import call, dtype_code, ptr
 
-KIND_CONV, KIND_MATRIX, KIND_BIAS = 0, 1, 2
+KIND_CONV, KIND_MATRIX, KIND_BIAS, KIND_STEM = 0, 1, 2, 3
 
 
 class PrepJob(ctypes.Structure):
@@ -42,6 +42,8 @@ def job_blocks(j):
         return ((j['d0'] + 63) // 64) * ((j['d2'] * j['d3'] * j['pad'] + 63) // 64)
     if j['kind'] == KIND_MATRIX:
         return ((j['d0'] + 63) // 64) * ((j['d1'] + 63) // 64)
+    if j['kind'] == KIND_STEM:
+        return 1
     return (j['d0'] + 4095) // 4096
 
 MAX_JOBS = 1024     # per mr_prep_batch launch
@@ -63,11 +65,19 @@ def bias_job(a, b, dst, R, perm_h):
                 ld_b=0, perm_h=perm_h, total=R)
 
 
+def stem_job(src, strides, dst, cin):
+    sk, sc, sr, ss = strides
+    return dict(kind=KIND_STEM, src=src, src2=0, dst_a=dst, dst_b=0, s0=sk, s1=sc, s2=sr, s3=ss, d0=64, d1=cin, d2=3,
+                d3=3, pad=0, ld_b=0, perm_h=0, total=64 * 32)
+
+
 def run_job(dt, j):
     """One job through the individual C entry points (the miss path)."""
     if j['kind'] == KIND_CONV:
         call("mr_prep_conv_weight", dt, j['src'], j['s0'], j['s1'], j['s2'], j['s3'], j['dst_a'], j['dst_b'], j['d0'],
              j['d1'], j['d2'], j['d3'], j['pad'], j['ld_b'])
+    elif j['kind'] == KIND_STEM:
+        call("mr_stem_pack", j['src'], j['s0'], j['s1'], j['s2'], j['s3'], j['dst_a'], j['d1'])
     elif j['kind'] == KIND_MATRIX:
         call("mr_prep_matrix", dt, j['src'], j['s0'], j['dst_a'], j['pad'], j['dst_b'], j['ld_b'], j['d0'], j['d1'],
              j['perm_h'])
