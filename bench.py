@@ -44,13 +44,14 @@ def conv_flops(name, args, true_cin0=3):
 
 
 def kernel_label(lib, name, args, dtype_name):
+    dt = 1 if dtype_name == "bf16" else 0
     if name == "mr_conv2d_fwd":
-        N, H, W, Cin, _ldx, Cout = args[6:12]
-        code = lib.mr_nt_tile_code(N * args[21] * args[22], Cout)
+        N, H, W, Cin, _ldx, Cout, _ldy, R, S = args[6:15]
+        code = lib.mr_nt_kernel_code(dt, N * args[21] * args[22], Cout, R * S * Cin, Cin)
         return "igemm_nt_kernel<%s,%d,%d,conv>" % (dtype_name, code // 1000, code % 1000)
     if name == "mr_conv2d_dgrad":
-        N, H, W, Cin = args[4:8]
-        code = lib.mr_nt_tile_code(N * H * W, Cin)
+        N, H, W, Cin, _ld1, Cout, _ld2, R, S = args[4:13]
+        code = lib.mr_nt_kernel_code(dt, N * H * W, Cin, R * S * Cout, Cout)
         return "igemm_nt_kernel<%s,%d,%d,conv>" % (dtype_name, code // 1000, code % 1000)
     return "igemm_tn_kernel<%s,conv>" % dtype_name
 

@@ -41,8 +41,14 @@ int mr_gemm_nt(int dtype, const void* A, long long lda, const void* B, int ldb, 
                const float* bias, int relu, int M, int N, int K, hipStream_t stream);
 /* tuning override: force one NT tile shape (bm 128|96|64, bn 128|64); bm = 0 restores the cost model */
 int mr_force_nt_tile(int bm, int bn);
+/* big-tile (8-wave, 256x256 / 288x256) NT kernel policy: 0 automatic, -1 never, 1 / 2 force (tuning override);
+ * returns the previous setting */
+int mr_set_nt_big(int mode);
 /* tile (BM*1000+BN) the NT kernels pick for an M x N problem; host-only query used for profiling labels */
 int mr_nt_tile_code(int M, int N);
+/* same, including the big-tile policy (returns 256256 for the 8-wave 256x256 kernel); cg = channels of the gathered
+ * conv operand, 0 for a dense GEMM */
+int mr_nt_kernel_code(int dtype, int M, int N, int K, int cg);
 /* C[NA,NB] (f32) += A[P,NA]^T * B[P,NB];  row_perm_h>0: gate-interleaved rows are written back in
  * PyTorch gate-major order (see lstm section).  colsum (nullable, f32[NA]) += sum_p A[p,:] (bias gradient,
  * fused into the same pass over A). */

@@ -26,6 +26,8 @@ static const void* zero_page() {
   return pages[dev];
 }
 
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
 static int g_nt_variant = 2;  // 2 = direct-to-LDS kernel (default), 1 = register-staged kernel (A/B debugging)
 
 template <typename T, int BM, int BN, int AMODE>
@@ -62,11 +64,6 @@ static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long lon
   return MR_OK;
 }
 
-// Tile selection shared by every NT launch.  Candidates BM in {128, 96, 64} x BN in {128, 64}; pick the one with
-// the smallest modelled time = rounds(tiles / resident slots) * tile work / tile efficiency.  The model exists
-// for wave quantisation: e.g. M = 33792 (264 row tiles of 128) x N = 512 gives 1056 tiles on 512 slots = 3 rounds
-// with the last one 6 % full, while BM = 96 gives 1408 tiles = 2.75 rounds.
-struct TileChoice { int bm, bn; };
 static int num_cus() {
   static int cus = 0;
   if (!cus) {
@@ -79,6 +76,65 @@ static int num_cus() {
   }
   return cus;
 }
+
+// ---- big-tile (8-wave) NT kernel: bf16, dense or fast-gather conv operands ---------------------------------------
+// g_big_mode: 0 = automatic (nt_big_choice), -1 = never, 1 = always 256x256, 2 = always 288x256 (tuning override)
+static int g_big_mode = 0;
+
+// 0 = use the 4-wave kernels, 1 = 256x256 (8 waves), 2 = 288x256 (12 waves; tuning only).  The big tiles run one
+// workgroup per CU, so they only pay when the tile count fills whole rounds of the CUs.  Measured on MI355X (bf16,
+// tools/microbench_conv.py --big): 65536x256 (256 tiles, one exact round) K=2304: 653 -> 804 TF/s forward,
+// 724 -> 888 TF/s dgrad; 33792x512 is 264 tiles of 256x256 (two rounds, the second 3 % full): 742 -> 604 TF/s, and
+// the 288x256 variant that would fit it in one round (236 tiles) spills registers at 12 waves: 742 -> 628 TF/s.
+// So: automatic = 256x256 only, and only at >= 85 % CU utilisation.
+static int nt_big_choice(int M, int N, int K) {
+  if (g_big_mode < 0) return 0;
+  if (g_big_mode > 0) return g_big_mode;
+  if (N % 256 != 0 || K < 512) return 0;
+  const int cus = num_cus();
+  const long long tiles = (long long)cdiv(M, 256) * (N / 256);
+  const long long rounds = (tiles + cus - 1) / cus;
+  const double util = (double)M * N / ((double)rounds * cus * 256 * 256);
+  return util >= 0.85 ? 1 : 0;
+}
+
+template <typename T, int WM, int WN, int TM, int TN, int AMODE>
+static int launch_nt_big(const NtArgs& a, const ConvGeom& g, void* C, long long ldc, const float* bias, int relu,
+                         hipStream_t stream) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  EpiStore<T> epi;
+  epi.C = (T*)C;
+  epi.ldc = ldc;
+  epi.bias = bias;
+  epi.relu = relu;
+  epi.M = a.M;
+  epi.N = a.N;
+  epi.vec_ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
+  NtArgs a2 = a;
+  a2.zero = zero_page();
+  if (!a2.zero) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
+  auto kern = igemm_nt_big_kernel<T, WM, WN, TM, TN, AMODE, EpiStore<T>>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
+      return MR_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
+  const int grid = cdiv(tiles_m, 8) * 8 * tiles_n;  // XCD-aware map: see the kernel
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, stream, a2, g, epi);
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+// Tile selection shared by every NT launch.  Candidates BM in {128, 96, 64} x BN in {128, 64}; pick the one with
+// the smallest modelled time = rounds(tiles / resident slots) * tile work / tile efficiency.  The model exists
+// for wave quantisation: e.g. M = 33792 (264 row tiles of 128) x N = 512 gives 1056 tiles on 512 slots = 3 rounds
+// with the last one 6 % full, while BM = 96 gives 1408 tiles = 2.75 rounds.
+struct TileChoice { int bm, bn; };
 static TileChoice g_forced_tile = {0, 0};  // mr_force_nt_tile: tuning / A-B override
 static TileChoice nt_tile(int M, int N) {
   if (g_forced_tile.bm) return g_forced_tile;
@@ -113,6 +169,14 @@ static TileChoice nt_tile(int M, int N) {
 template <typename T, int AMODE>
 static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long long ldc, const float* bias,
                              int relu, hipStream_t stream) {
+  if constexpr (sizeof(T) == 2 && (AMODE == 0 || AMODE == 2)) {
+    constexpr int BK = 8 * VecOf<T>::N;
+    if (g_nt_variant == 2 && !g_forced_tile.bm && (AMODE == 0 || (g.Cg % BK) == 0) && aligned16(C)) {
+      const int big = nt_big_choice(a.M, a.N, a.K);
+      if (big == 1) return launch_nt_big<T, 2, 4, 8, 4, AMODE>(a, g, C, ldc, bias, relu, stream);
+      if (big == 2) return launch_nt_big<T, 3, 4, 6, 4, AMODE>(a, g, C, ldc, bias, relu, stream);  // 288x256, 12 waves
+    }
+  }
   const TileChoice t = nt_tile(a.M, a.N);
 #define MR_NT_CASE(BM_, BN_) \
   if (t.bm == BM_ && t.bn == BN_) return launch_nt_store<T, BM_, BN_, AMODE>(a, g, C, ldc, bias, relu, stream);
@@ -155,8 +219,6 @@ static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
   return MR_OK;
 }
 
-static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
-
 }  // namespace mr
 
 using namespace mr;
@@ -176,6 +238,14 @@ int mr_set_nt_variant(int v) {
   return old;
 }
 
+// Big-tile (8-wave) NT kernel policy: 0 automatic, -1 never, 1 always 256x256, 2 always 288x256 (needs N % 256 == 0
+// callers; a tuning / A-B override).  Returns the previous setting.
+int mr_set_nt_big(int mode) {
+  const int old = g_big_mode;
+  if (mode >= -1 && mode <= 2) g_big_mode = mode;
+  return old;
+}
+
 // Force every NT launch to one tile shape (bm in {128,96,64}, bn in {128,64}); bm = 0 restores the cost model.
 int mr_force_nt_tile(int bm, int bn) {
   if (bm == 0) { g_forced_tile.bm = g_forced_tile.bn = 0; return MR_OK; }
@@ -188,6 +258,17 @@ int mr_force_nt_tile(int bm, int bn) {
 int mr_nt_tile_code(int M, int N) {
   const TileChoice t = nt_tile(M, N);
   return t.bm * 1000 + t.bn;
+}
+
+// Same query including the big-tile policy: cg = channel count of the gathered conv operand (0 for a dense GEMM).
+// Returns 256256 when the 8-wave 256x256 kernel would run for a bf16 problem of this shape.
+int mr_nt_kernel_code(int dtype, int M, int N, int K, int cg) {
+  if (dtype == MR_BF16 && g_nt_variant == 2 && !g_forced_tile.bm && (cg == 0 || cg % 64 == 0)) {
+    const int big = nt_big_choice(M, N, K);
+    if (big == 1) return 256256;
+    if (big == 2) return 288256;
+  }
+  return mr_nt_tile_code(M, N);
 }
 
 int mr_gemm_nt(int dtype, const void* A, long long lda, const void* B, int ldb, void* C, long long ldc,

@@ -653,6 +653,194 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// NT kernel v3 ("big tile"): the same direct-to-LDS / XOR-swizzled scheme as igemm_nt_glds_kernel with
+// WM x WN waves (8 waves = 512 threads) and a (WM*TM*16) x (WN*TN*16) tile, e.g. 256x256 or 288x256.
+// Why: with a 64x64 wave tile the v2 kernel moves one LDS byte per 32 flops and its prefetch distance (one k-step =
+// 32 MFMAs per wave = ~210 ns) is shorter than the L2/HBM latency, so it plateaus at ~1/3 of the MFMA peak.  A
+// 128x64 (or 144x64) wave tile needs 0.75x the ds_read bytes and half the LDS-DMA bytes per flop, and one k-step
+// of MFMAs (64-72 per wave, two waves per SIMD) covers a full memory round trip.
+// LDS: 2 stages x (BM + BN) x 128 B (128-139 KB, dynamic) -> one workgroup per CU; the host picks this kernel
+// only when the tile count fills the 256 CUs in whole rounds (see nt_big_choice in gemm_conv.hip).
+// Tile -> workgroup map is XCD-aware: the column tiles of one row tile (which re-read the same activation rows)
+// get consecutive slots of the SAME XCD (hardware workgroup id % 8 = XCD), so the re-read hits that XCD's L2.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int WM, int WN, int TM, int TN, int AMODE, typename Epi>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_nt_big_kernel(NtArgs a, ConvGeom g, Epi epi) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int BK = 8 * VEC;
+  constexpr int NW = WM * WN;
+  constexpr int WTM = TM * 16, WTN = TN * 16, BM = WM * WTM, BN = WN * WTN;
+  constexpr int AG = BM / 8, BG = BN / 8;                      // 8-row staging groups
+  constexpr int AI = (AG + NW - 1) / NW, BI = (BG + NW - 1) / NW;
+  constexpr int TILE_VECS = (BM + BN) * 8;
+  typedef typename Mma<T>::Frag Frag;
+  static_assert(AMODE == 0 || AMODE == 2, "big-tile kernel: dense or fast conv gather only");
+
+  extern __shared__ uint4 smem_big[];
+  uint4* smem = smem_big;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+  // XCD-aware map: hardware block b -> xcd = b & 7, slot = b >> 3
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile_m = (slot / tiles_n) * 8 + xcd, tile_n = slot % tiles_n;
+  if (tile_m >= tiles_m) return;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int lrow = lane >> 3, lpc = lane & 7;
+
+  const T* __restrict__ A = (const T*)a.A;
+  const T* __restrict__ B = (const T*)a.B;
+  const void* Z = a.zero;
+
+  // per-thread row descriptors: 32-bit element offset of (row, logical chunk) at k = 0 / tap (0,0) + tap mask.
+  // (operands are < 2^31 elements; offsets instead of pointers halve the descriptor registers)
+  auto kc_of = [&](int gi) { return (lpc ^ (((gi * 8 + lrow) >> 1) & 7)) * VEC; };
+  int a_off[AI];
+  unsigned a_mask[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int gi = wave + i * NW;
+    const int m = m0 + gi * 8 + lrow;
+    a_mask[i] = 0;
+    a_off[i] = 0;
+    if (gi < AG) {
+      if (AMODE == 0) {
+        a_off[i] = (int)((long long)m * a.lda + kc_of(gi));
+        a_mask[i] = m < a.M ? 1u : 0u;
+      } else if (m < a.M) {
+        const int wm = m % g.Wm;
+        const int t = m / g.Wm;
+        const int hm = t % g.Hm;
+        const int ni = t / g.Hm;
+        const int bh = g.mode == 1 ? hm * g.sh - g.ph : hm + g.ph;
+        const int bw = g.mode == 1 ? wm * g.sw - g.pw : wm + g.pw;
+        a_off[i] = (int)((long long)ni * g.Hg * g.Wg * g.ldg + ((long long)bh * g.Wg + bw) * g.ldg + kc_of(gi));
+        unsigned msk = 0;
+        for (int r = 0; r < g.R; ++r)
+          for (int s2 = 0; s2 < g.S; ++s2) {
+            int hi, wi;
+            if (conv_src(g, hm, wm, r, s2, hi, wi)) msk |= 1u << (r * g.S + s2);
+          }
+        a_mask[i] = msk;
+      }
+    }
+  }
+  int b_off[BI];
+  unsigned b_okmask = 0;
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int gi = wave + i * NW;
+    const int n = n0 + gi * 8 + lrow;
+    if (gi < BG && n < a.N) b_okmask |= 1u << i;
+    b_off[i] = (int)((long long)n * a.ldb + kc_of(gi));
+  }
+
+  const int sgn = g.mode == 1 ? 1 : -1;
+  const bool k_exact = (a.K % BK) == 0;
+  int s_tap = 0, s_r = 0, s_s = 0, s_c0 = 0;  // scalar tap state of the NEXT k-step to stage (AMODE 2)
+
+  auto stage = [&](uint4* sA, int k0) {
+    uint4* sB = sA + BM * 8;
+    if (AMODE == 0) {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int gi = wave + i * NW;
+        if (AG % NW == 0 || gi < AG) {
+          const bool ok = a_mask[i] && (k_exact || k0 + kc_of(gi) < a.K);
+          glds16(sel_ptr(ok, A + a_off[i] + k0, Z), sA + gi * 64);
+        }
+      }
+    } else {
+      const int koff = sgn * ((s_r * g.dh * g.Wg + s_s * g.dw) * g.ldg) + s_c0;
+      const unsigned bit = 1u << s_tap;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int gi = wave + i * NW;
+        if (AG % NW == 0 || gi < AG) glds16(sel_ptr(a_mask[i] & bit, A + (a_off[i] + koff), Z), sA + gi * 64);
+      }
+      s_c0 += BK;
+      if (s_c0 >= g.Cg) {
+        s_c0 = 0;
+        ++s_tap;
+        if (++s_s == g.S) { s_s = 0; ++s_r; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int gi = wave + i * NW;
+      if (BG % NW == 0 || gi < BG) {
+        const bool ok = ((b_okmask >> i) & 1u) && (k_exact || k0 + kc_of(gi) < a.K);
+        glds16(sel_ptr(ok, B + b_off[i] + k0, Z), sB + gi * 64);
+      }
+    }
+  };
+
+  const int wm_ = wave % WM, wn_ = wave / WM;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int xsw = (l15 >> 1) & 7;
+  // fragment base offsets (vector index inside a stage) of this lane: row*8 + (kc ^ xsw), kc = ks*4 + lg
+  const int fa_base = (wm_ * WTM + l15) * 8 + (lg ^ xsw);
+  const int fb_base = BM * 8 + (wn_ * WTN + l15) * 8 + (lg ^ xsw);
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](const uint4* st) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4* sa = st + (ks ? (fa_base ^ 4) : fa_base);
+      const uint4* sb = st + (ks ? (fb_base ^ 4) : fb_base);
+      Frag fb[TN];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fb[i] = *(const Frag*)&sb[i * 128];
+      // A fragments are streamed (two in flight) rather than all TM held at once: keeps the 288-row variant inside
+      // the 256-register budget of two waves per SIMD
+      Frag fa = *(const Frag*)&sa[0];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        Frag nxt = fa;
+        if (j + 1 < TM) nxt = *(const Frag*)&sa[(j + 1) * 128];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) Mma<T>::run(acc[i][j], fb[i], fa);
+        fa = nxt;
+      }
+    }
+  };
+
+  const int nk = (a.K + BK - 1) / BK;
+  uint4* st0 = smem;
+  uint4* st1 = smem + TILE_VECS;
+  if (nk > 0) stage(st0, 0);
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    __syncthreads();  // k-step t landed (vmcnt drained before the barrier); stage 1 is free
+    stage(st1, (t + 1) * BK);
+    compute(st0);
+    __syncthreads();
+    if (t + 2 < nk) stage(st0, (t + 2) * BK);
+    compute(st1);
+  }
+  if (t < nk) {
+    __syncthreads();
+    compute(st0);
+  }
+
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wm_ * WTM + j * 16 + l15;
+      const int n = n0 + wn_ * WTN + i * 16 + lg * 4;
+      epi(m, n, acc[i][j]);
+    }
+}
+
 // Plain epilogue: C = act(acc + bias) stored as T, row-major with leading dim ldc.
 template <typename T> struct EpiStore {
   T* C;

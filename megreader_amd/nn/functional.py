@@ -8,7 +8,9 @@ reference's names and shapes; every forward converts them to the operand images 
 There is no CPU path in this file: CPU tensors raise NotImplementedError (same as the reference's
 ``ops/ctc_2d/ctc_loss_2d.py:12-13`` does for its CUDA-only op).
 """
+import contextlib
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -57,6 +59,37 @@ def notify_grad_ready(param):
     post-accumulate hook does not fire when a Function returns None)."""
     for hook in getattr(param, "_mr_grad_ready_hooks", ()):
         hook(param)
+
+
+class _Side(object):
+    """Side HIP stream for weight-gradient GEMMs that nothing later in the backward pass depends on.  The LSTM
+    recurrences are launch-latency-bound chains that leave most CUs idle; the weight-gradient GEMMs of one layer run
+    beside the recurrence chain of the next.  Fork = the side stream waits for the producing stream; join = an
+    autograd-engine callback at the end of the backward pass makes the backward stream wait for the side stream, so
+    everything after `backward()` (optimizer, gradient clipping, the next zero_grad) is ordered as usual.  Inside a
+    hipGraph capture this records a fork/join in the graph."""
+    stream = None
+    pending = []    # tensors the side stream still reads / writes: kept alive until the join
+    queued = False
+    enabled = os.environ.get("MEGREADER_OVERLAP", "0") == "1"  # measured slower on the CRNN step (see DESIGN.md): off
+
+    @staticmethod
+    def fork():
+        main = torch.cuda.current_stream()
+        if _Side.stream is None or _Side.stream.device != main.device:
+            _Side.stream = torch.cuda.Stream(device=main.device)
+        _Side.stream.wait_stream(main)
+        if not _Side.queued:
+            torch.autograd.Variable._execution_engine.queue_callback(_Side.join)
+            _Side.queued = True
+        return _Side.stream
+
+    @staticmethod
+    def join():
+        if _Side.stream is not None:
+            torch.cuda.current_stream().wait_stream(_Side.stream)
+        del _Side.pending[:]
+        _Side.queued = False
 
 
 def accumulate_multi(pairs):
@@ -504,7 +537,15 @@ class LinearFn(Function):
             gb = b_sink if b_sink is not None else torch.zeros((Np,), dtype=torch.float32, device=gy.device)
         if ctx.needs_input_grad[1]:
             gw = w_sink if w_sink is not None else torch.zeros((Np, K), dtype=torch.float32, device=gy.device)
-            call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, Np, K, 0, ptr(gb))
+            # sunk gradients have no consumer inside the backward pass: side stream (see _Side)
+            overlap = (w_sink is not None and (gb is None or b_sink is not None) and _Side.enabled and
+                       not getattr(weight_p, "_mr_grad_ready_hooks", None))
+            if overlap:
+                with torch.cuda.stream(_Side.fork()):
+                    call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, Np, K, 0, ptr(gb))
+                _Side.pending.extend((gp, x2))
+            else:
+                call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, Np, K, 0, ptr(gb))
             if w_sink is not None:
                 notify_grad_ready(weight_p)
             else:
@@ -589,35 +630,44 @@ class BiLSTMFn(Function):
         # NOTE: `gates` is rewritten in place with the pre-activation gradients (single backward pass only)
         call("mr_lstm_bwd", dt, ptr(gout), ptr(whh_t), ptr(cbuf), ptr(gates), ptr(dc), T, N, H)
         dgates = gates
+        sinks = [grad_sink(p, tuple(p.shape)) for p in ctx.params]
+        use_sinks = all(s is not None for s in sinks)
+        # with sinks nothing downstream consumes the weight gradients: run their GEMMs on the side stream, beside the
+        # next layer's recurrence chain (not under data-parallel hooks, which want the gradients as they complete)
+        overlap = (use_sinks and _Side.enabled and
+                   not any(getattr(p, "_mr_grad_ready_hooks", None) for p in ctx.params))
+        side = _Side.fork() if overlap else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((T, N, I), dtype=dtype, device=dev)
             call("mr_gemm_nt", dt, ptr(dgates), 8 * H, ptr(wcat_t), 8 * H, ptr(dx), I, 0, 0, T * N, I, 8 * H)
-        sinks = [grad_sink(p, tuple(p.shape)) for p in ctx.params]
-        use_sinks = all(s is not None for s in sinks)
-        # one zeroed scratch: [2,4H,I] input-weight gradients (both directions from ONE GEMM) + [2,4H] bias sums
-        scratch = torch.zeros((2 * 4 * H * (I + 1),), dtype=torch.float32, device=dev)
-        gw_ih = scratch[:2 * 4 * H * I].view(2, 4 * H, I)
-        gb = scratch[2 * 4 * H * I:].view(2, 4 * H)
-        # bias gradient = column sums of dgates, fused into the same pass
-        call("mr_gemm_tn", dt, ptr(dgates), 8 * H, ptr(x), I, ptr(gw_ih), I, T * N, 8 * H, I, H, ptr(gb))
-        if use_sinks:   # recurrent-weight gradients accumulate straight into the flat gradient buffer
-            g_hh = (sinks[1], sinks[5])
-        else:
-            gw_hh = torch.zeros((2, 4 * H, H), dtype=torch.float32, device=dev)
-            g_hh = (gw_hh[0], gw_hh[1])
-        if T > 1:
-            P = (T - 1) * N
-            # forward direction: dgates[t] (t>=1) with h[t-1]
-            call("mr_gemm_tn", dt, ptr(dgates) + N * 8 * H * es, 8 * H, ptr(out), 2 * H, ptr(g_hh[0]), H, P, 4 * H,
-                 H, H, 0)
-            # reverse direction: dgates[t] (t<=T-2) with h[t+1]
-            call("mr_gemm_tn", dt, ptr(dgates) + 4 * H * es, 8 * H, ptr(out) + (N * 2 * H + H) * es, 2 * H,
-                 ptr(g_hh[1]), H, P, 4 * H, H, H, 0)
+        with torch.cuda.stream(side) if overlap else contextlib.nullcontext():
+            # one zeroed scratch: [2,4H,I] input-weight gradients (both directions from ONE GEMM) + [2,4H] bias sums
+            scratch = torch.zeros((2 * 4 * H * (I + 1),), dtype=torch.float32, device=dev)
+            gw_ih = scratch[:2 * 4 * H * I].view(2, 4 * H, I)
+            gb = scratch[2 * 4 * H * I:].view(2, 4 * H)
+            # bias gradient = column sums of dgates, fused into the same pass
+            call("mr_gemm_tn", dt, ptr(dgates), 8 * H, ptr(x), I, ptr(gw_ih), I, T * N, 8 * H, I, H, ptr(gb))
+            if use_sinks:   # recurrent-weight gradients accumulate straight into the flat gradient buffer
+                g_hh = (sinks[1], sinks[5])
+            else:
+                gw_hh = torch.zeros((2, 4 * H, H), dtype=torch.float32, device=dev)
+                g_hh = (gw_hh[0], gw_hh[1])
+            if T > 1:
+                P = (T - 1) * N
+                # forward direction: dgates[t] (t>=1) with h[t-1]
+                call("mr_gemm_tn", dt, ptr(dgates) + N * 8 * H * es, 8 * H, ptr(out), 2 * H, ptr(g_hh[0]), H, P,
+                     4 * H, H, H, 0)
+                # reverse direction: dgates[t] (t<=T-2) with h[t+1]
+                call("mr_gemm_tn", dt, ptr(dgates) + 4 * H * es, 8 * H, ptr(out) + (N * 2 * H + H) * es, 2 * H,
+                     ptr(g_hh[1]), H, P, 4 * H, H, H, 0)
+            if use_sinks:
+                # w_ih, b_ih, b_hh of both directions: one launch folds the scratch into the six sinks
+                accumulate_multi([(sinks[0], gw_ih[0]), (sinks[4], gw_ih[1]), (sinks[2], gb[0]), (sinks[3], gb[0]),
+                                  (sinks[6], gb[1]), (sinks[7], gb[1])])
+        if overlap:
+            _Side.pending.extend((dgates, x, out, scratch))
         if use_sinks:
-            # w_ih, b_ih, b_hh of both directions: one launch folds the scratch into the six sinks
-            accumulate_multi([(sinks[0], gw_ih[0]), (sinks[4], gw_ih[1]), (sinks[2], gb[0]), (sinks[3], gb[0]),
-                              (sinks[6], gb[1]), (sinks[7], gb[1])])
             for p in ctx.params:
                 notify_grad_ready(p)
             return (dx,) + (None,) * 8

@@ -303,3 +303,69 @@ def test_conv_relu_pool_fused_backward(dtype):
     assert _rel_err(xd.grad, xr.grad) < tol
     assert _rel_err(wd.grad, wr.grad) < tol
     assert _rel_err(bd.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_big_tile_nt_kernel_bit_identical_to_4wave_kernel(mode):
+    """The 8/12-wave 256x256 / 288x256 NT kernel (picked automatically for CU-filling shapes) against the 4-wave
+    kernel on the same operands: same MFMA instruction, same k order per output element -> bit-identical results.
+    Covers dense GEMM, conv forward and conv dgrad operands, ragged last row tiles and two column tiles."""
+    from megreader_amd._lib import load
+    lib = load()
+    dtype = torch.bfloat16
+    dt = dtype_code(dtype)
+    g = torch.Generator().manual_seed(5 + mode)
+
+    def both(fn):
+        old = lib.mr_set_nt_big(-1)
+        try:
+            ref = fn()
+            lib.mr_set_nt_big(mode)
+            out = fn()
+        finally:
+            lib.mr_set_nt_big(old)
+        return ref, out
+
+    # dense: M ragged against 256 and 288, N = 512 (two column tiles), K not a multiple of 64
+    M, N, K = 1000, 512, 1096
+    A = torch.randn(M, K, generator=g).to(DEV, dtype)
+    B = torch.randn(N, K, generator=g).to(DEV, dtype)
+    bias = torch.randn(N, generator=g).to(DEV)
+
+    def dense():
+        C = torch.zeros(M, N, device=DEV, dtype=dtype)
+        call("mr_gemm_nt", dt, ptr(A), K, ptr(B), K, ptr(C), N, ptr(bias), 1, M, N, K)
+        return C
+
+    ref, out = both(dense)
+    assert torch.equal(ref, out)
+    want = torch.relu(A.double().cpu() @ B.double().cpu().t() + bias.double().cpu())
+    assert _rel_err(out, want) < _tol(dtype, K)
+
+    # conv forward / dgrad (3x3, pad 1 and the 2x2 pad 0 head), C = K = 256
+    for (Nb, H, W, C, Kc, k, p) in [(5, 8, 32, 256, 256, 3, 1), (9, 2, 34, 256, 512, 2, 0)]:
+        Ho, Wo = H + 2 * p - k + 1, W + 2 * p - k + 1
+        x = torch.randn(Nb, H, W, C, generator=g).to(DEV, dtype)
+        w = (torch.randn(Kc, k, k, C, generator=g) * 0.05).to(DEV, dtype)
+        wt = (torch.randn(C, k, k, Kc, generator=g) * 0.05).to(DEV, dtype)
+        dy = torch.randn(Nb, Ho, Wo, Kc, generator=g).to(DEV, dtype)
+        cb = torch.randn(Kc, generator=g).to(DEV)
+
+        def fwd():
+            y = torch.zeros(Nb, Ho, Wo, Kc, device=DEV, dtype=dtype)
+            call("mr_conv2d_fwd", dt, ptr(x), ptr(w), ptr(cb), ptr(y), 1, Nb, H, W, C, C, Kc, Kc, k, k, 1, 1, p, p, 1, 1,
+                 Ho, Wo)
+            return y
+
+        def dgrad():
+            dx = torch.zeros(Nb, H, W, C, device=DEV, dtype=dtype)
+            call("mr_conv2d_dgrad", dt, ptr(dy), ptr(wt), ptr(dx), Nb, H, W, C, C, Kc, Kc, k, k, 1, 1, p, p, 1, 1, Ho,
+                 Wo)
+            return dx
+
+        for fn in (fwd, dgrad):
+            ref, out = both(fn)
+            assert torch.equal(ref, out), (fn.__name__, Nb, H, W, C, Kc, k)
+        want = torch.relu(TF.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu().permute(0, 3, 1, 2),
+                                    cb.double().cpu(), 1, p)).permute(0, 2, 3, 1)
+        assert _rel_err(fwd(), want) < _tol(dtype, C * k * k)
