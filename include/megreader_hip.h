@@ -44,6 +44,9 @@ int mr_force_nt_tile(int bm, int bn);
 /* big-tile (8-wave, 256x256 / 288x256) NT kernel policy: 0 automatic, -1 never, 1 / 2 force (tuning override);
  * returns the previous setting */
 int mr_set_nt_big(int mode);
+/* experimental 256x256 TN (weight-gradient) kernel: 1 = use it, 0 / -1 = never (default; it is currently slower,
+ * see gemm_conv.hip:launch_tn); returns the previous setting */
+int mr_set_tn_big(int mode);
 /* tile (BM*1000+BN) the NT kernels pick for an M x N problem; host-only query used for profiling labels */
 int mr_nt_tile_code(int M, int N);
 /* same, including the big-tile policy (returns 256256 for the 8-wave 256x256 kernel); cg = channels of the gathered
@@ -147,7 +150,8 @@ int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const flo
               long long P, int C, hipStream_t stream); /* flags: bit0 fused ReLU, bit1 accumulate into dgamma/dbeta */
 int mr_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int kh,
                    int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, hipStream_t stream);
-/* relu_y (nullable): the pool's input when it is the output of a ReLU -- fuses that ReLU's backward mask */
+/* relu_y (nullable): the pool's OUTPUT [N,Ho,Wo,C] when its input is the output of a ReLU -- fuses that ReLU's backward
+ * mask (value at the arg-max position == pooled output, so the mask is read at pooled resolution) */
 int mr_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, const void* relu_y, void* dx, int N, int H,
                    int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo,
                    hipStream_t stream);

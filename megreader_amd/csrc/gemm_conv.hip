@@ -44,15 +44,16 @@ static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long lon
   const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
   if constexpr (AMODE != 1) {
     if (g_nt_variant == 2) {
+      const int grid = cdiv(cdiv(a.M, BM), 8) * 8 * cdiv(a.N, BN);  // XCD-aware tile map, see the kernel
       NtArgs a2 = a;
       a2.zero = zero_page();
       if (!a2.zero) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
       constexpr int BK = 8 * VecOf<T>::N;
       if (AMODE == 2 && (g.Cg % BK) != 0)
-        hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, (AMODE == 2 ? 3 : AMODE), EpiStore<T>>), dim3(tiles),
+        hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, (AMODE == 2 ? 3 : AMODE), EpiStore<T>>), dim3(grid),
                            dim3(256), 0, stream, a2, g, epi);
       else
-        hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, AMODE, EpiStore<T>>), dim3(tiles), dim3(256), 0, stream,
+        hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, AMODE, EpiStore<T>>), dim3(grid), dim3(256), 0, stream,
                            a2, g, epi);
       MR_CHECK_LAUNCH();
       return MR_OK;
@@ -80,6 +81,7 @@ static int num_cus() {
 // ---- big-tile (8-wave) NT kernel: bf16, dense or fast-gather conv operands ---------------------------------------
 // g_big_mode: 0 = automatic (nt_big_choice), -1 = never, 1 = always 256x256, 2 = always 288x256 (tuning override)
 static int g_big_mode = 0;
+static int g_tn_big = 0;  // TN big-tile kernel: 1 = use it (experimental, see launch_tn), otherwise never
 
 // 0 = use the 4-wave kernels, 1 = 256x256 (8 waves), 2 = 288x256 (12 waves; tuning only).  The big tiles run one
 // workgroup per CU, so they only pay when the tile count fills whole rounds of the CUs.  Measured on MI355X (bf16,
@@ -203,13 +205,49 @@ static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
     const double cost = (double)rounds * (cdiv(total_steps, s) + 8.0);
     if (cost < best) { best = cost; splits = s; }
   }
+  if constexpr (sizeof(T) == 2) {
+    // big-tile variant (256x256, one workgroup per CU): halves the L2 -> LDS operand traffic that bounds the
+    // 128x128 kernel.  EXPERIMENTAL, opt-in only (mr_set_tn_big(1)): correct (tests/test_kernels_gpu.py) but 3.5x
+    // SLOWER on MI355X as compiled today -- at 256 registers per wave hipcc spills ~20 VGPRs inside the k-loop, and
+    // every scratch reload carries an s_waitcnt vmcnt(0) that also drains the in-flight LDS-DMA prefetch, which
+    // serialises the pipeline (conv5 wgrad: 630 -> 161 TFLOP/s).  Needs a hand-allocated register budget.
+    if (g_nt_variant == 2 && g_tn_big > 0) {
+      const void* z = zero_page();
+      if (!z) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
+      const int btiles = cdiv(a.NA, 256) * cdiv(a.NB, 256);
+      int bsplits = 1;
+      double bbest = 1e300;
+      // one workgroup per CU; the epilogue is a 256x256 tile of f32 atomics (~16 p-steps of time)
+      for (int s = 1; s <= 1024 && 2 * s <= total_steps + 1; ++s) {
+        const long long blocks = (long long)btiles * s;
+        const long long rounds = (blocks + cus - 1) / cus;
+        const double cost = (double)rounds * (cdiv(total_steps, s) + 16.0);
+        if (cost < bbest) { bbest = cost; bsplits = s; }
+      }
+      a.p_chunk = cdiv(cdiv(a.P, bsplits), BP) * BP;
+      bsplits = cdiv(a.P, a.p_chunk);
+      constexpr int lds = 2 * 4 * 64 * 256 + 1024;  // 2 stages x [A0|A1|B0|B1] x 16 KB + the column-sum accumulator
+      auto kern = igemm_tn_big_kernel<BMODE>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+          set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", lds);
+          return MR_ERR_LAUNCH;
+        }
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(btiles * bsplits), dim3(512), lds, stream, a, g, z);
+      MR_CHECK_LAUNCH();
+      return MR_OK;
+    }
+  }
   a.p_chunk = cdiv(cdiv(a.P, splits), BP) * BP;
   splits = cdiv(a.P, a.p_chunk);
   if constexpr (sizeof(T) == 2) {
     if (g_nt_variant == 2) {
       const void* z = zero_page();
       if (!z) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
-      hipLaunchKernelGGL((igemm_tn_glds_kernel<BMODE>), dim3(tiles, 1, splits), dim3(256), 0, stream, a, g, z);
+      hipLaunchKernelGGL((igemm_tn_glds_kernel<BMODE>), dim3(tiles * splits), dim3(256), 0, stream, a, g, z);
       MR_CHECK_LAUNCH();
       return MR_OK;
     }
@@ -243,6 +281,14 @@ int mr_set_nt_variant(int v) {
 int mr_set_nt_big(int mode) {
   const int old = g_big_mode;
   if (mode >= -1 && mode <= 2) g_big_mode = mode;
+  return old;
+}
+
+// Big-tile (256x256) TN kernel: 1 = use it (experimental, currently slower -- see launch_tn), 0 / -1 = never.
+// Returns the previous setting.
+int mr_set_tn_big(int mode) {
+  const int old = g_tn_big;
+  if (mode >= -1 && mode <= 1) g_tn_big = mode;
   return old;
 }
 

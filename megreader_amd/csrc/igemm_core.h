@@ -487,8 +487,14 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int tiles_n = (a.N + BN - 1) / BN;
-  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+  // XCD-aware tile map (grid = ceil(tiles_m/8)*8*tiles_n): hardware workgroup id b runs on XCD b % 8; the column
+  // tiles of one row tile -- which gather the same activation rows -- take consecutive slots of the SAME XCD, so
+  // the rows are fetched into one L2 instead of tiles_n of them (measured on the N = 512 layers: FETCH_SIZE per
+  // launch was ~5x the algorithmic bytes with the plain b -> (b / tiles_n, b % tiles_n) map).
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile_m = (slot / tiles_n) * 8 + xcd, tile_n = slot % tiles_n;
+  if (tile_m >= tiles_m) return;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int lrow = lane >> 3, lpc = lane & 7;
 
@@ -1134,10 +1140,20 @@ __global__ __launch_bounds__(256) void igemm_tn_glds_kernel(TnArgs a, ConvGeom g
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int tiles_b = (a.NB + 127) / 128;
-  const int tile_b = blockIdx.x % tiles_b, tile_a = blockIdx.x / tiles_b;
+  const int tiles_b = (a.NB + 127) / 128, tiles_a = (a.NA + 127) / 128;
+  // XCD-aware work map (1-D grid of tiles * splits workgroups).  Hardware workgroup b runs on XCD b % 8.  Virtual
+  // order vb = split-major (all tiles of P-chunk 0, then chunk 1, ...); every XCD takes one CONTIGUOUS eighth of
+  // it, i.e. whole P-chunks: the workgroups that share an L2 stream through the same rows of dy / x, which are
+  // then fetched from HBM about once instead of once per XCD (FETCH_SIZE per launch was ~5x the algorithmic bytes
+  // with tiles dealt round-robin over the XCDs).
+  const int total = gridDim.x;
+  const int xq = total >> 3, xr = total & 7, xcd = blockIdx.x & 7;
+  const int vb = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
+  const int ntiles = tiles_a * tiles_b;
+  const int split = vb / ntiles, tile = vb - split * ntiles;
+  const int tile_b = tile % tiles_b, tile_a = tile / tiles_b;
   const int na0 = tile_a * 128, nb0 = tile_b * 128;
-  const int p_begin = blockIdx.z * a.p_chunk;
+  const int p_begin = split * a.p_chunk;
   const int p_end = min(a.P, p_begin + a.p_chunk);
   if (p_begin >= p_end) return;
 
@@ -1319,6 +1335,224 @@ __global__ __launch_bounds__(256) void igemm_tn_glds_kernel(TnArgs a, ConvGeom g
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         int row = na0 + wa * 64 + i * 16 + lg * 4 + q;
+        if (row >= a.NA) continue;
+        if (a.row_perm_h > 0) {
+          const int h4 = 4 * a.row_perm_h;
+          const int blk = row / h4, rin = row - blk * h4;
+          row = blk * h4 + (rin & 3) * a.row_perm_h + (rin >> 2);
+        }
+        atomicAdd(a.C + (long long)row * a.ldc + col, acc[i][j][q]);
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN kernel, big tile: 256 (NA) x 256 (NB) output tile, 8 waves, 64-row p-steps, 128 KB of dynamic LDS (one
+// workgroup per CU).  Why: the 128x128 kernel re-reads every operand element from L2 once per tile of the OTHER
+// operand -- for the CRNN wgrads that is 2.4 GB of L2->LDS traffic per launch at ~9.5 TB/s, i.e. the kernel is
+// bound by L2 bandwidth, not by the MFMA pipe (25 % busy).  A 256x256 tile halves that traffic and gives each
+// wave a 128x64 sub-tile (32 MFMAs per 12 transposed fragment reads instead of 16 per 8).
+// LDS image: each operand tile is stored as TWO independent 128-column sub-tiles in exactly the layout of
+// igemm_tn_glds_kernel ([64 rows][256 B], 32-byte pieces XOR-swizzled by tn_hash(row)); waves 0-3 stage sub-tile 0
+// of A and B, waves 4-7 sub-tile 1, with that kernel's lane mapping.  Compute wave (wa, wb): A sub-tile wa (all
+// 8 column blocks), B sub-tile wb>>1, column blocks (wb&1)*4 .. +3.
+// ---------------------------------------------------------------------------------------------
+template <int BMODE>
+__global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g, const void* zero) {
+  typedef bf16_t T;
+  constexpr int BP = 64, ROW_BYTES = 256, SUB_BYTES = BP * ROW_BYTES;  // one 128-column sub-tile = 16 KB
+  constexpr int STAGE_BYTES = 4 * SUB_BYTES;                           // [A0 | A1 | B0 | B1]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_tn_big[];
+  unsigned char* smem = smem_tn_big;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int sub = wave >> 2, w4 = wave & 3;  // staging role: sub-tile and wave index inside it
+  const int tiles_b = (a.NB + 255) / 256, tiles_a = (a.NA + 255) / 256;
+  // XCD-aware work map, see igemm_tn_glds_kernel
+  const int total = gridDim.x;
+  const int xq = total >> 3, xr = total & 7, xcd = blockIdx.x & 7;
+  const int vb = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
+  const int ntiles = tiles_a * tiles_b;
+  const int split = vb / ntiles, tile = vb - split * ntiles;
+  const int tile_b = tile % tiles_b, tile_a = tile / tiles_b;
+  const int na0 = tile_a * 256, nb0 = tile_b * 256;
+  const int p_begin = split * a.p_chunk;
+  const int p_end = min(a.P, p_begin + a.p_chunk);
+  if (p_begin >= p_end) return;
+
+  const T* __restrict__ A = (const T*)a.A;
+  const T* __restrict__ B = (const T*)a.B;
+  const int lrow = lane >> 4, pc16 = lane & 15, pp = pc16 >> 1, half = pc16 & 1;
+
+  int colA[2], colB[2], tr[2], ts[2], tc[2], dho[2], dwo[2];
+  bool okA[2], okB[2];
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int cp = pp ^ tn_hash((w4 * 4 + 2 * h2) * 4 + lrow);
+    const int col = sub * 128 + (cp * 2 + half) * 8;
+    colA[h2] = na0 + col;
+    colB[h2] = nb0 + col;
+    okA[h2] = colA[h2] < a.NA;
+    okB[h2] = colB[h2] < a.NB;
+    tr[h2] = ts[h2] = 0;
+    tc[h2] = colB[h2];
+    dho[h2] = dwo[h2] = 0;
+    if (BMODE == 1) {
+      const int tap = colB[h2] / g.Cg;
+      tc[h2] = colB[h2] - tap * g.Cg;
+      tr[h2] = tap / g.S;
+      ts[h2] = tap - tr[h2] * g.S;
+      dho[h2] = tr[h2] * g.dh - g.ph;
+      dwo[h2] = ts[h2] * g.dw - g.pw;
+    }
+  }
+  // pixel coordinates of this lane's FIRST staged row (jj = 0) of the next p-step; rows jj = 1..3 are 4, 8, 12
+  // pixels further and are derived on the fly (keeps 9 registers out of the 256-register budget)
+  int q_n = 0, q_h = 0, q_w = 0;
+  if (BMODE == 1) {
+    const int p = p_begin + (w4 * 4) * 4 + lrow;
+    q_w = p % g.Wm;
+    const int t = p / g.Wm;
+    q_h = t % g.Hm;
+    q_n = t / g.Hm;
+  }
+
+  auto stage = [&](unsigned char* st, int p0) {
+    unsigned char* sA = st + sub * SUB_BYTES;
+    unsigned char* sB = st + (2 + sub) * SUB_BYTES;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int h2 = jj >> 1;
+      const int p = p0 + (w4 * 4 + jj) * 4 + lrow;
+      const bool pv = p < p_end;
+      glds16(sel_ptr(pv && okA[h2], A + (long long)p * a.lda + colA[h2], zero), sA + (w4 * 4 + jj) * 1024);
+      if (BMODE == 0) {
+        glds16(sel_ptr(pv && okB[h2], B + (long long)p * a.ldb + colB[h2], zero), sB + (w4 * 4 + jj) * 1024);
+      } else {
+        int jn = q_n, jh = q_h, jw = q_w + 4 * jj;
+        while (jw >= g.Wm) {
+          jw -= g.Wm;
+          if (++jh == g.Hm) { jh = 0; ++jn; }
+        }
+        const int hi = jh * g.sh + dho[h2], wi = jw * g.sw + dwo[h2];
+        const bool v = pv && okB[h2] && (unsigned)hi < (unsigned)g.Hg && (unsigned)wi < (unsigned)g.Wg;
+        const long long off = ((long long)(jn * g.Hg + hi) * g.Wg + wi) * g.ldg + tc[h2];
+        glds16(sel_ptr(v, B + off, zero), sB + (w4 * 4 + jj) * 1024);
+      }
+    }
+    if (BMODE == 1) {
+      q_w += BP;
+      while (q_w >= g.Wm) {
+        q_w -= g.Wm;
+        if (++q_h == g.Hm) { q_h = 0; ++q_n; }
+      }
+    }
+  };
+
+  const int wa = wave & 1, wb = wave >> 1;  // compute role: 2 x 4 waves, wave tile 128 (NA) x 64 (NB)
+  const int l15 = lane & 15, lg = lane >> 4;
+  const bool do_colsum = a.colsum != nullptr && tile_b == 0;
+  float* cs_red = (float*)(smem + 2 * STAGE_BYTES);  // [256] column sums of the A tile (bias gradient)
+  if (do_colsum && tid < 256) cs_red[tid] = 0.f;       // ordered before its first use by the k-loop's barriers
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int hsh = (l15 >> 2) | ((lg & 1) << 2);
+  const int rbase = (lg * 8 + (l15 >> 2)) * ROW_BYTES + (l15 & 3) * 8;
+  const int baseA = wa * SUB_BYTES + rbase;
+  const int baseB = (2 + (wb >> 1)) * SUB_BYTES + rbase;
+  const int cb0 = (wb & 1) * 4;
+
+  auto compute = [&](const unsigned char* st) {
+    if (do_colsum) {
+      // bias gradient: column sums of the A tile.  Each lane re-reads the 4 chunks it staged, adds the two rows
+      // that share a column group, and pushes 16 values per step into the LDS accumulator with float atomics
+      // (no live registers across the MFMA section; only the tile_b == 0 workgroups pay for it)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const uint4 v0 = *(const uint4*)(st + sub * SUB_BYTES + (w4 * 4 + 2 * h2) * 1024 + lane * 16);
+        const uint4 v1 = *(const uint4*)(st + sub * SUB_BYTES + (w4 * 4 + 2 * h2 + 1) * 1024 + lane * 16);
+        const T* p0 = (const T*)&v0;
+        const T* p1 = (const T*)&v1;
+        const int col = colA[h2] - na0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&cs_red[col + j], to_f32(p0[j]) + to_f32(p1[j]));
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        union { s16x4 h[2]; bf16x8 v; } ub;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+          ub.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(
+              st + baseB + (((cb0 + t) ^ hsh) << 5) + kk * 32 * ROW_BYTES + hh * 4 * ROW_BYTES));
+        fb[t] = ub.v;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        union { s16x4 h[2]; bf16x8 v; } ua;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+          ua.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(
+              st + baseA + ((i ^ hsh) << 5) + kk * 32 * ROW_BYTES + hh * 4 * ROW_BYTES));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  const int nsteps = (p_end - p_begin + BP - 1) / BP;
+  unsigned char* st0 = smem;
+  unsigned char* st1 = smem + STAGE_BYTES;
+  stage(st0, p_begin);
+  int st = 0;
+  for (; st + 1 < nsteps; st += 2) {
+    __syncthreads();
+    stage(st1, p_begin + (st + 1) * BP);
+    compute(st0);
+    __syncthreads();
+    if (st + 2 < nsteps) stage(st0, p_begin + (st + 2) * BP);
+    compute(st1);
+  }
+  if (st < nsteps) {
+    __syncthreads();
+    compute(st0);
+  }
+
+  if (do_colsum) {
+    __syncthreads();
+    float* red = cs_red;
+    if (tid < 256 && na0 + tid < a.NA) {
+      int row = na0 + tid;
+      if (a.row_perm_h > 0) {
+        const int h4 = 4 * a.row_perm_h;
+        const int blk = row / h4, rin = row - blk * h4;
+        row = blk * h4 + (rin & 3) * a.row_perm_h + (rin >> 2);
+      }
+      atomicAdd(a.colsum + row, red[tid]);
+    }
+  }
+
+  // epilogue: atomic accumulation (see igemm_tn_kernel)
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = nb0 + wb * 64 + j * 16 + l15;
+      if (col >= a.NB) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int row = na0 + wa * 128 + i * 16 + lg * 4 + q;
         if (row >= a.NA) continue;
         if (a.row_perm_h > 0) {
           const int h4 = 4 * a.row_perm_h;

@@ -252,17 +252,21 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char
         const T* pg = (const T*)&g;
         const unsigned char* pi = idx + o * VEC;
         const unsigned char code = (unsigned char)(i * kw + jx);
+        if (relu_y) {
+          // fused ReLU backward of the layer that produced the pool input: the value at the arg-max position IS the
+          // pooled output, so the mask is read at pooled resolution (a quarter of the bytes of the full-resolution
+          // ReLU output)
+          const uint4 yv = ((const uint4*)relu_y)[o];
+          const T* py = (const T*)&yv;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j)
-          if (pi[j] == code) acc[j] += to_f32(pg[j]);
+          for (int j = 0; j < VEC; ++j)
+            if (pi[j] == code && to_f32(py[j]) > 0.f) acc[j] += to_f32(pg[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j)
+            if (pi[j] == code) acc[j] += to_f32(pg[j]);
+        }
       }
-    }
-    if (relu_y) {  // fused ReLU backward of the layer that produced the pool input
-      const uint4 yv = ((const uint4*)relu_y)[t];
-      const T* py = (const T*)&yv;
-#pragma unroll
-      for (int j = 0; j < VEC; ++j)
-        if (!(to_f32(py[j]) > 0.f)) acc[j] = 0.f;
     }
     uint4 out;
     T* po = (T*)&out;

@@ -413,7 +413,7 @@ class MaxPoolFn(Function):
         y = torch.empty((N, Ho, Wo, C), dtype=dtype, device=x.device)
         idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
         call("mr_maxpool_fwd", dt, ptr(xi), ptr(y), ptr(idx), N, H, W, C, kh, kw, sh, sw, ph, pw, Ho, Wo)
-        ctx.save_for_backward(idx, xi if relu_input else None)
+        ctx.save_for_backward(idx, y if relu_input else None)  # the ReLU mask is read at pooled resolution
         ctx.geom = (N, H, W, C, kh, kw, sh, sw, ph, pw, Ho, Wo)
         ctx.dtype = dtype
         return y.permute(0, 3, 1, 2)

@@ -369,3 +369,63 @@ def test_big_tile_nt_kernel_bit_identical_to_4wave_kernel(mode):
         want = torch.relu(TF.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu().permute(0, 3, 1, 2),
                                     cb.double().cpu(), 1, p)).permute(0, 2, 3, 1)
         assert _rel_err(fwd(), want) < _tol(dtype, C * k * k)
+
+
+def test_big_tile_tn_kernel_matches_128_tile_kernel():
+    """The 256x256 TN (weight-gradient) kernel against the 128x128 kernel and an f64 reference: dense with
+    gate-interleaved row permutation + fused column sums, conv wgrad (3x3 pad 1; 2x2 pad 0) with the fused bias
+    gradient, ragged NB (not a multiple of 256) and P not a multiple of the 64-row step."""
+    from megreader_amd._lib import load
+    lib = load()
+    dtype = torch.bfloat16
+    dt = dtype_code(dtype)
+    g = torch.Generator().manual_seed(11)
+
+    def both(fn):
+        old = lib.mr_set_tn_big(-1)
+        try:
+            ref = fn()
+            lib.mr_set_tn_big(1)
+            out = fn()
+        finally:
+            lib.mr_set_tn_big(old)
+        return ref, out
+
+    # dense: NA = 512 with the LSTM row permutation (perm = 64), NB = 320 (ragged), P = 1000
+    P, NA, NB, perm = 1000, 512, 320, 64
+    A = torch.randn(P, NA, generator=g).to(DEV, dtype)
+    B = torch.randn(P, NB, generator=g).to(DEV, dtype)
+
+    def dense():
+        C = torch.ones(NA, NB, device=DEV)
+        cs = torch.full((NA,), 2.0, device=DEV)
+        call("mr_gemm_tn", dt, ptr(A), NA, ptr(B), NB, ptr(C), NB, P, NA, NB, perm, ptr(cs))
+        return C, cs
+
+    (c0, s0), (c1, s1) = both(dense)
+    ref = A.double().cpu().t() @ B.double().cpu()
+    ref = ref.view(NA // (4 * perm), perm, 4, NB).permute(0, 2, 1, 3).reshape(NA, NB) + 1.0
+    csr = A.double().cpu().sum(dim=0).view(NA // (4 * perm), perm, 4).permute(0, 2, 1).reshape(NA) + 2.0
+    assert _rel_err(c1, ref) < 2e-5 and _rel_err(c0, ref) < 2e-5
+    assert _rel_err(s1, csr) < 2e-5 and _rel_err(s0, csr) < 2e-5
+
+    for (Nb, H, W, C, Kc, k, p) in [(3, 8, 32, 256, 256, 3, 1), (7, 2, 34, 256, 512, 2, 0)]:
+        Ho, Wo = H + 2 * p - k + 1, W + 2 * p - k + 1
+        x = torch.randn(Nb, H, W, C, generator=g).to(DEV, dtype)
+        dy = torch.randn(Nb, Ho, Wo, Kc, generator=g).to(DEV, dtype)
+
+        def wgrad():
+            gw = torch.zeros(Kc, k, k, C, device=DEV)
+            gb = torch.zeros(Kc, device=DEV)
+            call("mr_conv2d_wgrad", dt, ptr(dy), ptr(x), ptr(gw), ptr(gb), Nb, H, W, C, C, Kc, Kc, k, k, 1, 1, p, p, 1, 1,
+                 Ho, Wo)
+            return gw, gb
+
+        (w0, b0), (w1, b1) = both(wgrad)
+        xr = x.double().cpu().permute(0, 3, 1, 2)
+        wr = torch.zeros(Kc, C, k, k, dtype=torch.float64, requires_grad=True)
+        TF.conv2d(xr, wr, None, 1, p).backward(dy.double().cpu().permute(0, 3, 1, 2))
+        want = wr.grad.permute(0, 2, 3, 1)
+        assert _rel_err(w1, want) < 2e-5 and _rel_err(w0, want) < 2e-5, (Nb, H, W)
+        bsum = dy.double().cpu().sum(dim=(0, 1, 2))
+        assert _rel_err(b1, bsum) < 2e-5 and _rel_err(b0, bsum) < 2e-5
