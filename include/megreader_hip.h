@@ -44,8 +44,8 @@ int mr_force_nt_tile(int bm, int bn);
 /* big-tile (8-wave, 256x256 / 288x256) NT kernel policy: 0 automatic, -1 never, 1 / 2 force (tuning override);
  * returns the previous setting */
 int mr_set_nt_big(int mode);
-/* experimental 256x256 TN (weight-gradient) kernel: 1 = use it, 0 / -1 = never (default; it is currently slower,
- * see gemm_conv.hip:launch_tn); returns the previous setting */
+/* experimental wide-tile TN (weight-gradient) kernels: 1 = 256x256, 2 = 128x256, 0 / -1 = never (default; they are
+ * currently slower, see gemm_conv.hip:launch_tn); returns the previous setting */
 int mr_set_tn_big(int mode);
 /* tile (BM*1000+BN) the NT kernels pick for an M x N problem; host-only query used for profiling labels */
 int mr_nt_tile_code(int M, int N);

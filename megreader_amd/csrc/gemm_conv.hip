@@ -81,7 +81,7 @@ static int num_cus() {
 // ---- big-tile (8-wave) NT kernel: bf16, dense or fast-gather conv operands ---------------------------------------
 // g_big_mode: 0 = automatic (nt_big_choice), -1 = never, 1 = always 256x256, 2 = always 288x256 (tuning override)
 static int g_big_mode = 0;
-static int g_tn_big = 0;  // TN big-tile kernel: 1 = use it (experimental, see launch_tn), otherwise never
+static int g_tn_big = 0;  // wide-tile TN kernels: 1 = 256x256, 2 = 128x256 (experimental, see launch_tn), else never
 
 // 0 = use the 4-wave kernels, 1 = 256x256 (8 waves), 2 = 288x256 (12 waves; tuning only).  The big tiles run one
 // workgroup per CU, so they only pay when the tile count fills whole rounds of the CUs.  Measured on MI355X (bf16,
@@ -189,6 +189,39 @@ static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long l
   return MR_ERR_ARG;
 }
 
+// Wide-tile TN kernel launch: SA = 2 -> 256x256 tile, SA = 1 -> 128 (NA) x 256 (NB) tile; one workgroup per CU.
+template <int BMODE, int SA>
+static int launch_tn_big(TnArgs a, const ConvGeom& g, int total_steps, hipStream_t stream) {
+  const void* z = zero_page();
+  if (!z) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
+  const int cus = num_cus();
+  const int btiles = cdiv(a.NA, 128 * SA) * cdiv(a.NB, 256);
+  int bsplits = 1;
+  double bbest = 1e300;
+  // one workgroup per CU; the epilogue is a full tile of f32 atomics (~8 p-steps of time per 128x128 of it)
+  for (int s = 1; s <= 1024 && 2 * s <= total_steps + 1; ++s) {
+    const long long blocks = (long long)btiles * s;
+    const long long rounds = (blocks + cus - 1) / cus;
+    const double cost = (double)rounds * (cdiv(total_steps, s) + 8.0 * SA);
+    if (cost < bbest) { bbest = cost; bsplits = s; }
+  }
+  a.p_chunk = cdiv(cdiv(a.P, bsplits), 64) * 64;
+  bsplits = cdiv(a.P, a.p_chunk);
+  constexpr int lds = 2 * (SA + 2) * 64 * 256 + 1024;  // 2 stages x [A.. | B0 | B1] x 16 KB + column-sum accumulator
+  auto kern = igemm_tn_big_kernel<BMODE, SA>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", lds);
+      return MR_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(btiles * bsplits), dim3(512), lds, stream, a, g, z);
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
 template <typename T, int BMODE>
 static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
   constexpr int BP = TnCfg<T>::BP;
@@ -206,39 +239,17 @@ static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
     if (cost < best) { best = cost; splits = s; }
   }
   if constexpr (sizeof(T) == 2) {
-    // big-tile variant (256x256, one workgroup per CU): halves the L2 -> LDS operand traffic that bounds the
-    // 128x128 kernel.  EXPERIMENTAL, opt-in only (mr_set_tn_big(1)): correct (tests/test_kernels_gpu.py) but 3.5x
-    // SLOWER on MI355X as compiled today -- at 256 registers per wave hipcc spills ~20 VGPRs inside the k-loop, and
-    // every scratch reload carries an s_waitcnt vmcnt(0) that also drains the in-flight LDS-DMA prefetch, which
-    // serialises the pipeline (conv5 wgrad: 630 -> 161 TFLOP/s).  Needs a hand-allocated register budget.
+    // wide-tile variants (mode 1: 256x256, mode 2: 128x256; one 8-wave workgroup per CU): they cut the L2 -> LDS
+    // operand traffic of the 128x128 kernel to 0.5x / 0.75x.  EXPERIMENTAL, opt-in only (mr_set_tn_big): both are
+    // bit-for-bit sane (tests/test_kernels_gpu.py) but measured 3-4x SLOWER on MI355X (conv5 wgrad 630 -> 161 /
+    // 252 TFLOP/s).  Mode 1 spills ~20 VGPRs inside the k-loop and every scratch reload carries an
+    // s_waitcnt vmcnt(0) that also drains the in-flight LDS-DMA prefetch; mode 2 has no spills, so the common
+    // cause is elsewhere (one barrier-coupled workgroup per CU with only 32 MFMAs per wave between barriers cannot
+    // hide the load latency that two independent 4-wave workgroups hide) -- left for a counter-based look.
     if (g_nt_variant == 2 && g_tn_big > 0) {
-      const void* z = zero_page();
-      if (!z) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
-      const int btiles = cdiv(a.NA, 256) * cdiv(a.NB, 256);
-      int bsplits = 1;
-      double bbest = 1e300;
-      // one workgroup per CU; the epilogue is a 256x256 tile of f32 atomics (~16 p-steps of time)
-      for (int s = 1; s <= 1024 && 2 * s <= total_steps + 1; ++s) {
-        const long long blocks = (long long)btiles * s;
-        const long long rounds = (blocks + cus - 1) / cus;
-        const double cost = (double)rounds * (cdiv(total_steps, s) + 16.0);
-        if (cost < bbest) { bbest = cost; bsplits = s; }
-      }
-      a.p_chunk = cdiv(cdiv(a.P, bsplits), BP) * BP;
-      bsplits = cdiv(a.P, a.p_chunk);
-      constexpr int lds = 2 * 4 * 64 * 256 + 1024;  // 2 stages x [A0|A1|B0|B1] x 16 KB + the column-sum accumulator
-      auto kern = igemm_tn_big_kernel<BMODE>;
-      static bool attr_set = false;
-      if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-          set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", lds);
-          return MR_ERR_LAUNCH;
-        }
-        attr_set = true;
-      }
-      hipLaunchKernelGGL(kern, dim3(btiles * bsplits), dim3(512), lds, stream, a, g, z);
-      MR_CHECK_LAUNCH();
-      return MR_OK;
+      const int rc = g_tn_big == 2 ? launch_tn_big<BMODE, 1>(a, g, total_steps, stream)
+                                   : launch_tn_big<BMODE, 2>(a, g, total_steps, stream);
+      return rc;
     }
   }
   a.p_chunk = cdiv(cdiv(a.P, splits), BP) * BP;
@@ -284,11 +295,11 @@ int mr_set_nt_big(int mode) {
   return old;
 }
 
-// Big-tile (256x256) TN kernel: 1 = use it (experimental, currently slower -- see launch_tn), 0 / -1 = never.
+// Wide-tile TN kernels: 1 = 256x256, 2 = 128x256 (experimental, currently slower -- see launch_tn), 0 / -1 = never.
 // Returns the previous setting.
 int mr_set_tn_big(int mode) {
   const int old = g_tn_big;
-  if (mode >= -1 && mode <= 1) g_tn_big = mode;
+  if (mode >= -1 && mode <= 2) g_tn_big = mode;
   return old;
 }
 

@@ -1357,11 +1357,14 @@ __global__ __launch_bounds__(256) void igemm_tn_glds_kernel(TnArgs a, ConvGeom g
 // of A and B, waves 4-7 sub-tile 1, with that kernel's lane mapping.  Compute wave (wa, wb): A sub-tile wa (all
 // 8 column blocks), B sub-tile wb>>1, column blocks (wb&1)*4 .. +3.
 // ---------------------------------------------------------------------------------------------
-template <int BMODE>
+// SA = number of 128-column A sub-tiles: 2 -> 256x256 tile (wave tile 128x64), 1 -> 128 (NA) x 256 (NB) tile (wave
+// tile 64x64, 64 accumulator registers: no spills; L2 operand traffic 0.75x of the 128x128 kernel).
+template <int BMODE, int SA>
 __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g, const void* zero) {
   typedef bf16_t T;
   constexpr int BP = 64, ROW_BYTES = 256, SUB_BYTES = BP * ROW_BYTES;  // one 128-column sub-tile = 16 KB
-  constexpr int STAGE_BYTES = 4 * SUB_BYTES;                           // [A0 | A1 | B0 | B1]
+  constexpr int STAGE_BYTES = (SA + 2) * SUB_BYTES;                    // [A0 | (A1) | B0 | B1]
+  constexpr int TA = 128 * SA, TI = 4 * SA;                            // tile rows (NA), A column blocks per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_tn_big[];
   unsigned char* smem = smem_tn_big;
 
@@ -1369,7 +1372,7 @@ __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int sub = wave >> 2, w4 = wave & 3;  // staging role: sub-tile and wave index inside it
-  const int tiles_b = (a.NB + 255) / 256, tiles_a = (a.NA + 255) / 256;
+  const int tiles_b = (a.NB + 255) / 256, tiles_a = (a.NA + TA - 1) / TA;
   // XCD-aware work map, see igemm_tn_glds_kernel
   const int total = gridDim.x;
   const int xq = total >> 3, xr = total & 7, xcd = blockIdx.x & 7;
@@ -1377,7 +1380,7 @@ __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g,
   const int ntiles = tiles_a * tiles_b;
   const int split = vb / ntiles, tile = vb - split * ntiles;
   const int tile_b = tile % tiles_b, tile_a = tile / tiles_b;
-  const int na0 = tile_a * 256, nb0 = tile_b * 256;
+  const int na0 = tile_a * TA, nb0 = tile_b * 256;
   const int p_begin = split * a.p_chunk;
   const int p_end = min(a.P, p_begin + a.p_chunk);
   if (p_begin >= p_end) return;
@@ -1394,7 +1397,7 @@ __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g,
     const int col = sub * 128 + (cp * 2 + half) * 8;
     colA[h2] = na0 + col;
     colB[h2] = nb0 + col;
-    okA[h2] = colA[h2] < a.NA;
+    okA[h2] = colA[h2] < a.NA && sub < SA;
     okB[h2] = colB[h2] < a.NB;
     tr[h2] = ts[h2] = 0;
     tc[h2] = colB[h2];
@@ -1421,13 +1424,14 @@ __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g,
 
   auto stage = [&](unsigned char* st, int p0) {
     unsigned char* sA = st + sub * SUB_BYTES;
-    unsigned char* sB = st + (2 + sub) * SUB_BYTES;
+    unsigned char* sB = st + (SA + sub) * SUB_BYTES;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int h2 = jj >> 1;
       const int p = p0 + (w4 * 4 + jj) * 4 + lrow;
       const bool pv = p < p_end;
-      glds16(sel_ptr(pv && okA[h2], A + (long long)p * a.lda + colA[h2], zero), sA + (w4 * 4 + jj) * 1024);
+      if (SA == 2 || sub == 0)
+        glds16(sel_ptr(pv && okA[h2], A + (long long)p * a.lda + colA[h2], zero), sA + (w4 * 4 + jj) * 1024);
       if (BMODE == 0) {
         glds16(sel_ptr(pv && okB[h2], B + (long long)p * a.ldb + colB[h2], zero), sB + (w4 * 4 + jj) * 1024);
       } else {
@@ -1451,26 +1455,28 @@ __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g,
     }
   };
 
-  const int wa = wave & 1, wb = wave >> 1;  // compute role: 2 x 4 waves, wave tile 128 (NA) x 64 (NB)
+  const int wa = wave & 1, wb = wave >> 1;  // compute role: 2 x 4 waves, wave tile (64*SA) (NA) x 64 (NB)
   const int l15 = lane & 15, lg = lane >> 4;
   const bool do_colsum = a.colsum != nullptr && tile_b == 0;
+  const bool cs_lane = do_colsum && sub < SA;  // lanes that staged a piece of the A tile
   float* cs_red = (float*)(smem + 2 * STAGE_BYTES);  // [256] column sums of the A tile (bias gradient)
-  if (do_colsum && tid < 256) cs_red[tid] = 0.f;       // ordered before its first use by the k-loop's barriers
+  if (do_colsum && tid < TA) cs_red[tid] = 0.f;       // ordered before its first use by the k-loop's barriers
 
-  f32x4 acc[8][4];
+  f32x4 acc[TI][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int hsh = (l15 >> 2) | ((lg & 1) << 2);
   const int rbase = (lg * 8 + (l15 >> 2)) * ROW_BYTES + (l15 & 3) * 8;
-  const int baseA = wa * SUB_BYTES + rbase;
-  const int baseB = (2 + (wb >> 1)) * SUB_BYTES + rbase;
+  const int baseA = (SA == 2 ? wa : 0) * SUB_BYTES + rbase;
+  const int baseB = (SA + (wb >> 1)) * SUB_BYTES + rbase;
   const int cb0 = (wb & 1) * 4;
+  const int ca0 = SA == 2 ? 0 : wa * 4;  // first A column block of this wave
 
   auto compute = [&](const unsigned char* st) {
-    if (do_colsum) {
+    if (cs_lane) {
       // bias gradient: column sums of the A tile.  Each lane re-reads the 4 chunks it staged, adds the two rows
       // that share a column group, and pushes 16 values per step into the LDS accumulator with float atomics
       // (no live registers across the MFMA section; only the tile_b == 0 workgroups pay for it)
@@ -1498,12 +1504,12 @@ __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g,
         fb[t] = ub.v;
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < TI; ++i) {
         union { s16x4 h[2]; bf16x8 v; } ua;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
           ua.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(
-              st + baseA + ((i ^ hsh) << 5) + kk * 32 * ROW_BYTES + hh * 4 * ROW_BYTES));
+              st + baseA + (((ca0 + i) ^ hsh) << 5) + kk * 32 * ROW_BYTES + hh * 4 * ROW_BYTES));
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, fb[j], acc[i][j], 0, 0, 0);
@@ -1532,7 +1538,7 @@ __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g,
   if (do_colsum) {
     __syncthreads();
     float* red = cs_red;
-    if (tid < 256 && na0 + tid < a.NA) {
+    if (tid < TA && na0 + tid < a.NA) {
       int row = na0 + tid;
       if (a.row_perm_h > 0) {
         const int h4 = 4 * a.row_perm_h;
@@ -1545,14 +1551,14 @@ __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g,
 
   // epilogue: atomic accumulation (see igemm_tn_kernel)
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = nb0 + wb * 64 + j * 16 + l15;
       if (col >= a.NB) continue;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        int row = na0 + wa * 128 + i * 16 + lg * 4 + q;
+        int row = na0 + wa * (64 * SA) + i * 16 + lg * 4 + q;
         if (row >= a.NA) continue;
         if (a.row_perm_h > 0) {
           const int h4 = 4 * a.row_perm_h;

@@ -371,8 +371,10 @@ def test_big_tile_nt_kernel_bit_identical_to_4wave_kernel(mode):
         assert _rel_err(fwd(), want) < _tol(dtype, C * k * k)
 
 
-def test_big_tile_tn_kernel_matches_128_tile_kernel():
-    """The 256x256 TN (weight-gradient) kernel against the 128x128 kernel and an f64 reference: dense with
+@pytest.mark.parametrize("mode", [1, 2])
+def test_big_tile_tn_kernel_matches_128_tile_kernel(mode):
+    """The wide-tile TN (weight-gradient) kernels (mode 1: 256x256, mode 2: 128x256) against the 128x128 kernel and
+    an f64 reference: dense with
     gate-interleaved row permutation + fused column sums, conv wgrad (3x3 pad 1; 2x2 pad 0) with the fused bias
     gradient, ragged NB (not a multiple of 256) and P not a multiple of the 64-row step."""
     from megreader_amd._lib import load
@@ -385,7 +387,7 @@ def test_big_tile_tn_kernel_matches_128_tile_kernel():
         old = lib.mr_set_tn_big(-1)
         try:
             ref = fn()
-            lib.mr_set_tn_big(1)
+            lib.mr_set_tn_big(mode)
             out = fn()
         finally:
             lib.mr_set_tn_big(old)
