@@ -56,6 +56,21 @@ def kernel_label(lib, name, args, dtype_name):
     return "igemm_tn_kernel<%s,conv>" % dtype_name
 
 
+def pmc_traffic(label):
+    """HBM-side bytes per launch of `label` from the committed PMC passes (profiles/r01_pmc_traffic.json, produced
+    by tools/final_profile.sh + tools/pmc_to_json.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    same command, FETCH_SIZE doubled for gfx950).  PMC counters cannot be read inside this process."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        data = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    if label not in data:
+        return None, None
+    return data[label]["bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, %d launches)" % \
+        data[label]["launches"]
+
+
 def cpu_baseline(batch_size=64, budget_s=20.0):
     """Oracle CRNN train step (torch CPU kernels, fp32 weights, fp64 CTC -- what the reference executes) on the
     host cores; a bounded sample (smaller batch, a few steps) of the same workload."""
@@ -215,9 +230,13 @@ def main():
         kernels = {}
         if timer is not None:
             agg = {}
+            algo_bytes = {}
             for name, cargs, t_ms in timer.results():
                 label = kernel_label(lib, name, cargs, args.dtype)
-                fl, _, _, _ = conv_flops(name, cargs)
+                fl, pix, cout, cin = conv_flops(name, cargs)
+                # algorithmic bytes of the launch: both activation tensors once + the weights once (2-byte elements)
+                es = 2 if args.dtype == "bf16" else 4
+                algo_bytes[label] = algo_bytes.get(label, 0.0) + es * (pix * cout + pix * cin) + es * fl / (2.0 * pix)
                 a = agg.setdefault(label, [0.0, 0.0, 0])
                 a[0] += fl
                 a[1] += t_ms
@@ -231,8 +250,11 @@ def main():
                 fl, t_ms, n = agg[dom]
                 ach = fl / (t_ms * 1e-3) / 1e12
                 peak = MFMA_PEAK_TFLOPS[args.dtype]
+                traffic, traffic_src = pmc_traffic(dom)
                 roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                            "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
+                            "algorithmic_bytes_per_launch": round(algo_bytes[dom] / n) if dom in algo_bytes else None,
                             "avg_launch_us": round(1e3 * t_ms / n, 2), "launches": n,
                             "flops_per_launch": fl / n,
                             "measured": "HIP events around every launch, %s" %

@@ -243,10 +243,13 @@ __device__ __forceinline__ void igemm_nt_body(const NtArgs& a, const ConvGeom& g
     __syncthreads();
   }
 
+  // row block outer, column block inner: the TN stores of one output row land back to back, so its 128-byte line is
+  // completed in L2 before it can be evicted half-written (the 256x256 kernel wrote 2.5x its output bytes to HBM
+  // with the loops the other way round)
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
+  for (int j = 0; j < TM; ++j)
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
+    for (int i = 0; i < TN; ++i) {
       const int m = m0 + wm_ * WTM + j * 16 + l15;
       const int n = n0 + wn_ * WTN + i * 16 + lg * 4;
       epi(m, n, acc[i][j]);
@@ -540,7 +543,11 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
     const int row = (wave * BI + i) * 8 + lrow;
-    const int n = n0 + row;
+    // LDS row -> output channel: inside each wave tile (WTN columns) LDS row i16*16 + lg*4 + r holds channel
+    // lg*(4*TN) + i16*4 + r, so that the 4 channels a lane gets from each of its TN column blocks are consecutive
+    // (TN*4-channel runs per lane -> 16-byte stores in the epilogue)
+    const int rb = row % WTN;
+    const int n = n0 + (row - rb) + ((rb >> 2) & 3) * (4 * TN) + (rb >> 4) * 4 + (rb & 3);
     b_kc[i] = (lpc ^ ((row >> 1) & 7)) * VEC;
     b_ok[i] = n < a.N;
     b_ptr[i] = B + (long long)n * a.ldb + b_kc[i];
@@ -649,14 +656,16 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
     compute(st0);
   }
 
+  // row block outer, column block inner: the TN stores of one output row land back to back, so its 128-byte line is
+  // completed in L2 before it can be evicted half-written (the 256x256 kernel wrote 2.5x its output bytes to HBM
+  // with the loops the other way round)
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
+  for (int j = 0; j < TM; ++j) {
+    f32x4 run[TN];
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int m = m0 + wm_ * WTM + j * 16 + l15;
-      const int n = n0 + wn_ * WTN + i * 16 + lg * 4;
-      epi(m, n, acc[i][j]);
-    }
+    for (int i = 0; i < TN; ++i) run[i] = acc[i][j];
+    epi.template store_run<TN>(m0 + wm_ * WTM + j * 16 + l15, n0 + wn_ * WTN + lg * (4 * TN), run);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -739,7 +748,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_nt_big_kernel(NtArgs a, Co
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
     const int gi = wave + i * NW;
-    const int n = n0 + gi * 8 + lrow;
+    const int row = gi * 8 + lrow;
+    const int rb = row % WTN;  // LDS row -> channel permutation inside a wave tile, see igemm_nt_glds_kernel
+    const int n = n0 + (row - rb) + ((rb >> 2) & 3) * (4 * TN) + (rb >> 4) * 4 + (rb & 3);
     if (gi < BG && n < a.N) b_okmask |= 1u << i;
     b_off[i] = (int)((long long)n * a.ldb + kc_of(gi));
   }
@@ -837,14 +848,16 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_nt_big_kernel(NtArgs a, Co
     compute(st0);
   }
 
+  // row block outer, column block inner: the TN stores of one output row land back to back, so its 128-byte line is
+  // completed in L2 before it can be evicted half-written (the 256x256 kernel wrote 2.5x its output bytes to HBM
+  // with the loops the other way round)
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
+  for (int j = 0; j < TM; ++j) {
+    f32x4 run[TN];
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int m = m0 + wm_ * WTM + j * 16 + l15;
-      const int n = n0 + wn_ * WTN + i * 16 + lg * 4;
-      epi(m, n, acc[i][j]);
-    }
+    for (int i = 0; i < TN; ++i) run[i] = acc[i][j];
+    epi.template store_run<TN>(m0 + wm_ * WTM + j * 16 + l15, n0 + wn_ * WTN + lg * (4 * TN), run);
+  }
 }
 
 // Plain epilogue: C = act(acc + bias) stored as T, row-major with leading dim ldc.
@@ -873,6 +886,35 @@ template <typename T> struct EpiStore {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (n + j < N) p[j] = from_f32<T>(v[j]);
+    }
+  }
+  // CNT*4 consecutive channels n .. n+4*CNT-1 of row m (the direct-to-LDS kernels permute the B rows inside each
+  // wave tile so that a lane owns consecutive channels across its column blocks): 16-byte stores
+  template <int CNT>
+  __device__ __forceinline__ void store_run(int m, int n, const f32x4* v) const {
+    constexpr int E16 = 16 / (int)sizeof(T);  // elements per 16-byte store
+    if (m >= M) return;
+    if (vec_ok && (ldc % E16) == 0 && (n % E16) == 0 && n + 4 * CNT <= N && (4 * CNT) % E16 == 0) {
+      float x[4 * CNT];
+#pragma unroll
+      for (int i = 0; i < CNT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = v[i][j];
+          if (bias) t += bias[n + 4 * i + j];
+          if (relu) t = fmaxf(t, 0.f);
+          x[4 * i + j] = t;
+        }
+      T out[4 * CNT];
+#pragma unroll
+      for (int e = 0; e < 4 * CNT; ++e) out[e] = from_f32<T>(x[e]);
+      uint4* dst = (uint4*)(C + (long long)m * ldc + n);
+      const uint4* src = (const uint4*)out;
+#pragma unroll
+      for (int q = 0; q < 4 * CNT / E16; ++q) dst[q] = src[q];
+    } else {
+#pragma unroll
+      for (int i = 0; i < CNT; ++i) (*this)(m, n + 4 * i, v[i]);
     }
   }
 };

@@ -15,4 +15,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   if [ -n "$f" ]; then python tools/pmc_summary.py "$f" > $out/pmc_$c.txt 2>&1; grep -A2 "igemm\|lstm_step" $out/pmc_$c.txt | head -40; fi
   rm -rf $out/pmc_$c
 done
+python tools/pmc_to_json.py $out/pmc_FETCH_SIZE.txt $out/pmc_WRITE_SIZE.txt $out/pmc_traffic.json > /dev/null 2>&1
 rm -rf $out/trace

@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Turn the two PMC summaries (tools/pmc_summary.py output of separate FETCH_SIZE / WRITE_SIZE passes) into
+profiles/r01_pmc_traffic.json: HBM-side bytes per launch of the conv igemm kernels, keyed by bench.py's kernel labels.
+FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled (gfx950 counts 128-byte requests as 64 B, see
+/opt/skills/guides/MI355X_MICROARCH.md "HBM").  Usage: pmc_to_json.py FETCH.txt WRITE.txt OUT.json"""
+import json
+import re
+import sys
+
+
+def parse(path):
+    out, name = {}, None
+    for line in open(path):
+        if not line.startswith(" "):
+            name = line.strip()
+        else:
+            m = re.search(r"(\w+)\s+n=\s*(\d+)\s+mean=([0-9.e+]+)", line)
+            if m and name:
+                out[name] = (float(m.group(3)), int(m.group(2)))
+    return out
+
+
+def label(name):
+    m = re.search(r"igemm_nt_glds_kernelIDF16bLi(\d+)ELi(\d+)ELi[23]E", name)
+    if m:
+        return "igemm_nt_kernel<bf16,%s,%s,conv>" % (m.group(1), m.group(2))
+    if "igemm_nt_big_kernelIDF16bLi2ELi4ELi8ELi4ELi2E" in name:
+        return "igemm_nt_kernel<bf16,256,256,conv>"
+    if "igemm_tn_glds_kernel<1>" in name or "igemm_tn_glds_kernelILi1E" in name:
+        return "igemm_tn_kernel<bf16,conv>"
+    return None
+
+
+def main():
+    fetch, write = parse(sys.argv[1]), parse(sys.argv[2])
+    out = {}
+    for name, (fkb, n) in fetch.items():
+        lab = label(name)
+        if lab is None or name not in write:
+            continue
+        wkb = write[name][0]
+        out[lab] = {"fetch_size_kb_mean": fkb, "write_size_kb_mean": wkb, "launches": n,
+                    "bytes_per_launch": 2.0 * fkb * 1024 + wkb * 1024,
+                    "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes, mean per launch"}
+    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
