@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
+    ap.add_argument("--workload", default="crnn", choices=["crnn", "res50ppm"],
+                    help="crnn = BASELINE.json configs[1] (the metric's workload, default); res50ppm = configs[2]: "
+                         "ResNet50-dilated-PPM + 2D-CTC on 32x128 crops (secondary line, same JSON shape)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,15 +151,32 @@ def main():
         def forward(self, data, *a, **k):
             return self.decoder(self.backbone(data), *a, **k)
 
+    if args.workload == "res50ppm":
+        from megreader_amd.backbones import resnet50dilated_ppm
+        from megreader_amd.decoders import CTCDecoder2D
+        from oracle.res50ppm import synthetic_batch_2d
+
+        class BasicModel(torch.nn.Module):  # noqa: F811  res50-ppm-2d-ctc.yaml: resnet50dilated_ppm + CTCDecoder2D
+            def __init__(self):
+                super().__init__()
+                self.backbone = resnet50dilated_ppm()
+                self.decoder = CTCDecoder2D(in_channels=256)
+
+            def forward(self, data, *a, **k):
+                return self.decoder(self.backbone(data), *a, **k)
+
     torch.manual_seed(0)
     model = BasicModel().to(dev).train()
-    opt = FusedAdam(model.parameters(), lr=1e-3)  # experiments/recognition/crnn.yaml:82-89
+    opt = FusedAdam(model.parameters(), lr=1e-3)  # experiments/recognition/crnn.yaml:82-89 (both YAMLs use Adam)
     opt.zero_grad()
     net = model
     if distributed:
         from megreader_amd.apex.parallel import DistributedDataParallel
         net = DistributedDataParallel(model)
-    batch = synthetic_batch(args.batch, 32, 128, seed=rank)
+    if args.workload == "res50ppm":
+        batch = synthetic_batch_2d(args.batch, 32, 128, seed=rank, max_len=3)
+    else:
+        batch = synthetic_batch(args.batch, 32, 128, seed=rank)
     img = batch['image'].to(dev)
     lab = batch['label'].to(dev)
     ln = batch['length'].to(dev).long()
@@ -250,7 +270,8 @@ def main():
                 fl, t_ms, n = agg[dom]
                 ach = fl / (t_ms * 1e-3) / 1e12
                 peak = MFMA_PEAK_TFLOPS[args.dtype]
-                traffic, traffic_src = pmc_traffic(dom)
+                # the committed PMC passes are of the CRNN workload
+                traffic, traffic_src = pmc_traffic(dom) if args.workload == "crnn" else (None, None)
                 roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                             "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                             "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
@@ -260,24 +281,32 @@ def main():
                             "measured": "HIP events around every launch, %s" %
                                         ("eager pass after the graph-replayed timed region" if use_graph
                                          else "inside the timed region")}
+        if args.workload == "res50ppm":
+            metric_name = "training images/sec, ResNet50-PPM-2D-CTC 32x128 crops, batch %d per GPU" % args.batch
+            workload_name = ("ResNet50-dilated-PPM + 2D-CTC training step (BASELINE.json configs[2]): 32x128 crops, "
+                             "T=16 H=4 C=38, Adam")
+            fwd_flops = 6.02e9  # forward FLOPs per 32x128 image
+        else:
+            metric_name = "training images/sec, CRNN-CTC 32x128 crops, batch 256 per GPU"
+            workload_name = "CRNN + 1D-CTC training step (BASELINE.json configs[1]): 32x128 crops, T=33, C=38, Adam"
+            fwd_flops = 1.80e9
         out = {
-            "metric": "training images/sec, CRNN-CTC 32x128 crops, batch 256 per GPU",
+            "metric": metric_name,
             "value": round(images / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "CRNN + 1D-CTC training step (BASELINE.json configs[1]): 32x128 crops, "
-                                   "T=33, C=38, Adam", "global_batch": args.batch * world,
+            "config": {"workload": workload_name, "global_batch": args.batch * world,
                        "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
                        "launch": "hipGraph replay" if use_graph else "eager",
-                       "train_flops_per_image": 3 * 1.80e9},
+                       "train_flops_per_image": 3 * fwd_flops},
             "final_loss": final_loss,
             "roofline": roofline,
             "kernels": kernels,
         }
-        step_tflops = 3 * 1.80e9 * args.batch / (ms * 1e-3) / 1e12
+        step_tflops = 3 * fwd_flops * args.batch / (ms * 1e-3) / 1e12
         out["step_tflops_per_gpu"] = round(step_tflops, 2)
         out["host_enqueue_ms_per_step"] = round(1e3 * host_enqueue / args.steps, 3)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "crnn":
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None

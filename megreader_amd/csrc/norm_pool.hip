@@ -35,6 +35,83 @@ __global__ void bn_stats_kernel(const T* __restrict__ x, double* __restrict__ su
   }
 }
 
+// Vectorised per-channel reductions (used when C/VEC <= 256): a thread owns one 16-byte channel vector and every
+// (256 / (C/VEC))-th row of the block's row range, so every load is 16 B per lane and a wave reads whole 128-byte
+// lines (the lane-per-channel kernels above move 2 bytes per lane per load and top out near 2 TB/s).
+// MODE 0: s = sum x, q = sum x^2.   MODE 1: s = sum dy', q = sum dy' * xhat   (dy' = relu-masked dy)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_vec_kernel(const T* __restrict__ a, const T* __restrict__ xin,
+                                                            const T* __restrict__ yin,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            double* __restrict__ sums, int relu, int P, int C,
+                                                            int rows_per_block) {
+  constexpr int VEC = VecOf<T>::N;
+  __shared__ float red[2][256 * VEC];  // [s|q][group][C] with groups * C == 256 * VEC
+  const int cv = C / VEC;
+  const int groups = 256 / cv;  // >= 1
+  const int g = threadIdx.x / cv, v = threadIdx.x - g * cv;
+  const int p0 = blockIdx.x * rows_per_block;
+  const int p1 = min(P, p0 + rows_per_block);
+  float s[VEC], q[VEC], mu[VEC], rs[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    s[j] = q[j] = 0.f;
+    mu[j] = 0.f;
+    rs[j] = 1.f;
+  }
+  if (g < groups) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        mu[j] = mean[v * VEC + j];
+        rs[j] = rstd[v * VEC + j];
+      }
+    }
+    for (int p = p0 + g; p < p1; p += groups) {
+      const long long i = (long long)p * cv + v;
+      const uint4 av = ((const uint4*)a)[i];
+      const T* pa = (const T*)&av;
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float x = to_f32(pa[j]);
+          s[j] += x;
+          q[j] += x * x;
+        }
+      } else {
+        const uint4 xv = ((const uint4*)xin)[i];
+        const T* px = (const T*)&xv;
+        uint4 yv = make_uint4(0, 0, 0, 0);
+        if (relu) yv = ((const uint4*)yin)[i];
+        const T* py = (const T*)&yv;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float gd = to_f32(pa[j]);
+          if (relu && !(to_f32(py[j]) > 0.f)) gd = 0.f;
+          s[j] += gd;
+          q[j] += gd * (to_f32(px[j]) - mu[j]) * rs[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      red[0][g * C + v * VEC + j] = s[j];
+      red[1][g * C + v * VEC + j] = q[j];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double ds = 0, dq = 0;
+    for (int gg = 0; gg < groups; ++gg) {
+      ds += (double)red[0][gg * C + c];
+      dq += (double)red[1][gg * C + c];
+    }
+    atomicAdd(sums + c, ds);
+    atomicAdd(sums + C + c, dq);
+  }
+}
+
 // mean / rstd from sums, running-stat update (PyTorch: running = (1-mom)*running + mom*stat, unbiased var)
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, int P, int C, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ rstd,
@@ -301,6 +378,16 @@ static int split_rows(int P, int C, int& rpb) {
   return cdiv(P, rpb);
 }
 
+// row split for bn_reduce_vec_kernel: ~2048 blocks, each at least 4 rows per thread group
+static int split_rows_vec(int P, int cv, int& rpb) {
+  const int groups = 256 / cv;
+  int splits = 2048;
+  if (splits > cdiv(P, 4 * groups)) splits = cdiv(P, 4 * groups);
+  if (splits < 1) splits = 1;
+  rpb = cdiv(P, splits);
+  return cdiv(P, rpb);
+}
+
 extern "C" {
 
 // Training-mode forward.  sums: scratch double[2*C] (zeroed here).  Saves mean/rstd (f32[C]) for backward.
@@ -312,9 +399,16 @@ int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const
   MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_fwd_train: bad P");
   (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream);
   int rpb;
-  const int splits = split_rows((int)P, C, rpb);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(cdiv(C, 64), splits), dim3(256), 0, stream,
-                                       (const T*)x, sums, (int)P, C, (long long)C, rpb));
+  if (C / vec <= 256 && 256 % (C / vec) == 0) {
+    const int splits = split_rows_vec((int)P, C / vec, rpb);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_vec_kernel<T, 0>), dim3(splits), dim3(256), 0, stream,
+                                         (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
+                                         (const float*)nullptr, sums, 0, (int)P, C, rpb));
+  } else {
+    const int splits = split_rows((int)P, C, rpb);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(cdiv(C, 64), splits), dim3(256), 0, stream,
+                                         (const T*)x, sums, (int)P, C, (long long)C, rpb));
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const double*)sums, (int)P, C,
                      eps, momentum, save_mean, save_rstd, running_mean, running_var);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(P * (C / vec), 256)), dim3(256), 0,
@@ -349,10 +443,17 @@ int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const flo
   MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_bwd: bad P");
   (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream);
   int rpb;
-  const int splits = split_rows((int)P, C, rpb);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(cdiv(C, 64), splits), dim3(256), 0, stream,
-                                       (const T*)dy, (const T*)x, (const T*)y, save_mean, save_rstd, sums, relu,
-                                       (int)P, C, rpb));
+  if (C / vec <= 256 && 256 % (C / vec) == 0) {
+    const int splits = split_rows_vec((int)P, C / vec, rpb);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_vec_kernel<T, 1>), dim3(splits), dim3(256), 0, stream,
+                                         (const T*)dy, (const T*)x, (const T*)y, save_mean, save_rstd, sums, relu,
+                                         (int)P, C, rpb));
+  } else {
+    const int splits = split_rows((int)P, C, rpb);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(cdiv(C, 64), splits), dim3(256), 0, stream,
+                                         (const T*)dy, (const T*)x, (const T*)y, save_mean, save_rstd, sums, relu,
+                                         (int)P, C, rpb));
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(P * (C / vec), 256)), dim3(256), 0,
                                        stream, (const T*)dy, (const T*)x, (const T*)y, save_mean, save_rstd, gamma,
                                        (const double*)sums, (T*)dx, (T*)dres, dgamma, dbeta, relu, accumulate, P, C));
