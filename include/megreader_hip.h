@@ -141,13 +141,15 @@ int mr_sgd_step(float* p, const float* g, float* buf, long long n, float* hyper,
 /* ---- BatchNorm2d / MaxPool2d (backbones/crnn.py:17-31,49-52; backbones/resnet.py:26-30,199) ------------- */
 int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* save_mean, float* save_rstd, double* sums, const void* residual,
-                    int relu, long long P, int C, float eps, float momentum, hipStream_t stream);
+                    int relu, long long P, int C, float eps, float momentum, long long* num_batches_tracked,
+                    hipStream_t stream); /* num_batches_tracked (nullable): int64 step counter, incremented by one;
+                                          relu: bit0 fused ReLU, bit2 `sums` is already zero (skip the memset) */
 int mr_bn_fwd_eval(int dtype, const void* x, void* y, const float* gamma, const float* beta,
                    const float* running_mean, const float* running_var, float* tmp_mean, float* tmp_rstd,
                    const void* residual, int relu, long long P, int C, float eps, hipStream_t stream);
 int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
               const float* save_rstd, double* sums, void* dx, void* dres, float* dgamma, float* dbeta, int flags,
-              long long P, int C, hipStream_t stream); /* flags: bit0 fused ReLU, bit1 accumulate into dgamma/dbeta */
+              long long P, int C, hipStream_t stream); /* flags: bit0 fused ReLU, bit1 accumulate into dgamma/dbeta, bit2 `sums` is already zero */
 int mr_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int kh,
                    int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, hipStream_t stream);
 /* relu_y (nullable): the pool's OUTPUT [N,Ho,Wo,C] when its input is the output of a ReLU -- fuses that ReLU's backward

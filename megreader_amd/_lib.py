@@ -40,7 +40,7 @@ SIGNATURES = {
     "mr_accumulate_multi": "ippps",
     "mr_adam_step": "pppplps",
     "mr_sgd_step": "ppplps",
-    "mr_bn_fwd_train": "ipppppppppp" + "iliffs",
+    "mr_bn_fwd_train": "ipppppppppp" + "iliffps",
     "mr_bn_fwd_eval": "ippppppppp" + "ilifs",
     "mr_bn_bwd": "ipppppppppp" + "pilis",
     "mr_stem_pack": "pllllpis",

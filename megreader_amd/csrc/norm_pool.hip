@@ -115,8 +115,10 @@ __global__ __launch_bounds__(256) void bn_reduce_vec_kernel(const T* __restrict_
 // mean / rstd from sums, running-stat update (PyTorch: running = (1-mom)*running + mom*stat, unbiased var)
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, int P, int C, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ rstd,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ num_batches_tracked) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;  // nn.BatchNorm2d's step counter (one launch saved)
   if (c >= C) return;
   const double m = sums[c] / P;
   double var = sums[C + c] / P - m * m;
@@ -393,11 +395,14 @@ extern "C" {
 // Training-mode forward.  sums: scratch double[2*C] (zeroed here).  Saves mean/rstd (f32[C]) for backward.
 int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* save_mean, float* save_rstd, double* sums, const void* residual,
-                    int relu, long long P, int C, float eps, float momentum, hipStream_t stream) {
+                    int relu, long long P, int C, float eps, float momentum, long long* num_batches_tracked,
+                    hipStream_t stream) {
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(C % vec == 0, "mr_bn_fwd_train: C (%d) must be a multiple of %d", C, vec);
   MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_fwd_train: bad P");
-  (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream);
+  const int presum_zero = (relu >> 2) & 1;  // flags bit 2: the caller hands over an already zeroed `sums`
+  relu &= 1;
+  if (!presum_zero) (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream);
   int rpb;
   if (C / vec <= 256 && 256 % (C / vec) == 0) {
     const int splits = split_rows_vec((int)P, C / vec, rpb);
@@ -410,7 +415,7 @@ int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const
                                          (const T*)x, sums, (int)P, C, (long long)C, rpb));
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const double*)sums, (int)P, C,
-                     eps, momentum, save_mean, save_rstd, running_mean, running_var);
+                     eps, momentum, save_mean, save_rstd, running_mean, running_var, num_batches_tracked);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(P * (C / vec), 256)), dim3(256), 0,
                                        stream, (const T*)x, (T*)y, (const float*)save_mean, (const float*)save_rstd,
                                        gamma, beta, (const T*)residual, relu, P, C));
@@ -437,11 +442,11 @@ int mr_bn_fwd_eval(int dtype, const void* x, void* y, const float* gamma, const 
 int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
               const float* save_rstd, double* sums, void* dx, void* dres, float* dgamma, float* dbeta, int flags,
               long long P, int C, hipStream_t stream) {
-  const int relu = flags & 1, accumulate = (flags >> 1) & 1;
+  const int relu = flags & 1, accumulate = (flags >> 1) & 1, presum_zero = (flags >> 2) & 1;
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(C % vec == 0, "mr_bn_bwd: C (%d) must be a multiple of %d", C, vec);
   MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_bwd: bad P");
-  (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream);
+  if (!presum_zero) (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream);
   int rpb;
   if (C / vec <= 256 && 256 % (C / vec) == 0) {
     const int splits = split_rows_vec((int)P, C / vec, rpb);

@@ -61,6 +61,39 @@ def notify_grad_ready(param):
         hook(param)
 
 
+class ZeroArena(object):
+    """Pre-zeroed f64 scratch for the per-channel reduction buffers of BatchNorm (2C doubles per call, forward and
+    backward).  Each call used to zero its own buffer with a memset (120 tiny launches per ResNet-50 step).  Slices
+    are handed out once per zeroing by a bump pointer; `reset()` -- called by the fused optimizers' `zero_grad()` --
+    re-zeroes the used prefix with ONE fill and rewinds.  When the arena is exhausted (nobody calls reset: eval
+    loops, foreign optimizers) `take` returns None and the caller falls back to its own memset."""
+    SIZE = 1 << 20  # doubles (8 MB)
+    arenas = {}
+
+    def __init__(self, device):
+        self.buf = torch.zeros((ZeroArena.SIZE,), dtype=torch.float64, device=device)
+        self.offset = 0
+
+    @staticmethod
+    def take(device, n):
+        a = ZeroArena.arenas.get(device)
+        if a is None:
+            a = ZeroArena.arenas[device] = ZeroArena(device)
+        n = (n + 31) // 32 * 32
+        if a.offset + n > ZeroArena.SIZE:
+            return None
+        out = a.buf[a.offset:a.offset + n]
+        a.offset += n
+        return out
+
+    @staticmethod
+    def reset(device):
+        a = ZeroArena.arenas.get(device)
+        if a is not None and a.offset:
+            a.buf[:a.offset].zero_()
+            a.offset = 0
+
+
 class _Side(object):
     """Side HIP stream for weight-gradient GEMMs that nothing later in the backward pass depends on.  The LSTM
     recurrences are launch-latency-bound chains that leave most CUs idle; the weight-gradient GEMMs of one layer run
@@ -258,7 +291,8 @@ def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
 # --------------------------------------------------------------------------------------------------
 class BatchNormFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, residual):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, residual,
+                num_batches_tracked=None):
         require_cuda(x, gamma, beta)
         dtype = get_compute_dtype()
         dt = dtype_code(dtype)
@@ -272,10 +306,13 @@ class BatchNormFn(Function):
         mean = torch.empty((C,), dtype=torch.float32, device=x.device)
         rstd = torch.empty((C,), dtype=torch.float32, device=x.device)
         if training:
-            sums = torch.empty((2 * C,), dtype=torch.float64, device=x.device)
+            sums = ZeroArena.take(x.device, 2 * C)
+            prezeroed = sums is not None
+            if not prezeroed:
+                sums = torch.empty((2 * C,), dtype=torch.float64, device=x.device)
             call("mr_bn_fwd_train", dt, ptr(xi), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean),
-                 ptr(running_var), ptr(mean), ptr(rstd), ptr(sums), ptr(ri), int(relu), P, C, float(eps),
-                 float(momentum))
+                 ptr(running_var), ptr(mean), ptr(rstd), ptr(sums), ptr(ri), int(relu) | (4 if prezeroed else 0), P, C,
+                 float(eps), float(momentum), ptr(num_batches_tracked))
         else:
             call("mr_bn_fwd_eval", dt, ptr(xi), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                  ptr(mean), ptr(rstd), ptr(ri), int(relu), P, C, float(eps))
@@ -299,7 +336,10 @@ class BatchNormFn(Function):
         P = N * H * W
         dx = torch.empty_like(xi)
         dres = torch.empty_like(xi) if ctx.has_res else None
-        sums = torch.empty((2 * C,), dtype=torch.float64, device=g.device)
+        sums = ZeroArena.take(g.device, 2 * C)
+        prezeroed = sums is not None
+        if not prezeroed:
+            sums = torch.empty((2 * C,), dtype=torch.float64, device=g.device)
         gamma_p, beta_p = ctx.params
         g_sink, b_sink = grad_sink(gamma_p, (C,)), grad_sink(beta_p, (C,))
         sunk = g_sink is not None and b_sink is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
@@ -309,18 +349,22 @@ class BatchNormFn(Function):
             dgamma = torch.empty((C,), dtype=torch.float32, device=g.device)
             dbeta = torch.empty((C,), dtype=torch.float32, device=g.device)
         call("mr_bn_bwd", dt, ptr(g), ptr(xi), ptr(y), ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(dx),
-             ptr(dres), ptr(dgamma), ptr(dbeta), int(ctx.relu) | (2 if sunk else 0), P, C)
+             ptr(dres), ptr(dgamma), ptr(dbeta), int(ctx.relu) | (2 if sunk else 0) | (4 if prezeroed else 0), P, C)
         gres = dres.permute(0, 3, 1, 2) if ctx.has_res else None
         if sunk:
             notify_grad_ready(gamma_p)
             notify_grad_ready(beta_p)
             dgamma = dbeta = None
-        return dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None, gres
+        return dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None, gres, None
 
 
-def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu=False, residual=None):
+def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu=False, residual=None,
+               num_batches_tracked=None):
+    """num_batches_tracked (int64 scalar tensor, optional): incremented on the device by the statistics kernel."""
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not training):
+        num_batches_tracked = None
     return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, bool(training), momentum, eps, bool(relu),
-                             residual)
+                             residual, num_batches_tracked)
 
 
 # --------------------------------------------------------------------------------------------------

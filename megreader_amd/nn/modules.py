@@ -47,10 +47,10 @@ class BatchNorm2d(nn.BatchNorm2d):
 
     def forward(self, x, residual=None):
         momentum = 0.1 if self.momentum is None else self.momentum
-        if self.training:
-            self.num_batches_tracked.add_(1)
+        # num_batches_tracked is advanced by the statistics kernel itself (no separate tiny launch per BN layer)
         return F.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, momentum,
-                            self.eps, self.fuse_relu, residual)
+                            self.eps, self.fuse_relu, residual,
+                            self.num_batches_tracked if self.training else None)
 
 
 class MaxPool2d(nn.MaxPool2d):

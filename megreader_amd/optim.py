@@ -13,6 +13,7 @@ import torch
 
 from ._lib import call, ptr
 from .nn import prep
+from .nn.functional import ZeroArena
 
 _ALIGN = 64  # elements; keeps every parameter slice 256-byte aligned
 
@@ -81,6 +82,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         for f in self._flat:
             if f is not None:
                 f['g'].zero_()
+                ZeroArena.reset(f['g'].device)  # pre-zeroed reduction scratch of the BatchNorm layers
 
     def _sync_views(self, f):
         for p, off in zip(f['params'], f['offs']):

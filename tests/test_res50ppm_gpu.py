@@ -59,8 +59,9 @@ def _models(golden, dtype):
 def test_small_ops_vs_torch(dtype):
     mr.set_compute_dtype(dtype)
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(2, 16, 5, 7, generator=g).to(dtype)
-    for out in (1, 2, 3, 6):
+    # (2,3) -> 6: output larger than the input by more than 2x (several bins per input row); (4,16): the PPM's map
+    for (hh, ww), out in [((5, 7), o) for o in (1, 2, 3, 6)] + [((2, 3), 6), ((4, 16), 6), ((4, 16), 3), ((1, 1), 2)]:
+        x = torch.randn(2, 16, hh, ww, generator=g).to(dtype)
         xr = x.double().requires_grad_(True)
         yr = TF.adaptive_avg_pool2d(xr, out)
         gy = torch.randn(yr.shape, generator=g).to(dtype)
