@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void bn_reduce_vec_kernel(const T* __restrict_
         rs[j] = rstd[v * VEC + j];
       }
     }
+#pragma unroll 4
     for (int p = p0 + g; p < p1; p += groups) {
       const long long i = (long long)p * cv + v;
       const uint4 av = ((const uint4*)a)[i];
@@ -380,10 +381,11 @@ static int split_rows(int P, int C, int& rpb) {
   return cdiv(P, rpb);
 }
 
-// row split for bn_reduce_vec_kernel: ~2048 blocks, each at least 4 rows per thread group
+// row split for bn_reduce_vec_kernel: <= 512 blocks (every block ends with 2C f64 atomics: 2048 blocks made the
+// atomics, not the reads, the bottleneck), each at least 4 rows per thread group
 static int split_rows_vec(int P, int cv, int& rpb) {
   const int groups = 256 / cv;
-  int splits = 2048;
+  int splits = 512;
   if (splits > cdiv(P, 4 * groups)) splits = cdiv(P, 4 * groups);
   if (splits < 1) splits = 1;
   rpb = cdiv(P, splits);
