@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="take the multi-GPU code path even with WORLD_SIZE=1 (single-GPU test of that path)")
     ap.add_argument("--workload", default="crnn", choices=["crnn", "res50ppm"],
                     help="crnn = BASELINE.json configs[1] (the metric's workload, default); res50ppm = configs[2]: "
                          "ResNet50-dilated-PPM + 2D-CTC on 32x128 crops (secondary line, same JSON shape)")
@@ -123,7 +125,7 @@ def main():
         raise SystemExit("bench.py needs an AMD GPU (there is no CPU product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    distributed = world > 1 or args.force_ddp
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -170,9 +172,16 @@ def main():
     opt = FusedAdam(model.parameters(), lr=1e-3)  # experiments/recognition/crnn.yaml:82-89 (both YAMLs use Adam)
     opt.zero_grad()
     net = model
-    if distributed:
+    use_graph = not args.no_graph
+    if distributed and not use_graph:
+        # eager data parallel: the apex-style shim (bucketed all-reduce overlapped with backward)
         from megreader_amd.apex.parallel import DistributedDataParallel
         net = DistributedDataParallel(model)
+    elif distributed:
+        # graphed data parallel: two hipGraphs per step with one in-place all-reduce of the flat gradient buffer
+        # between them (megreader_amd.runtime); rank 0's weights define the model
+        from megreader_amd.runtime import broadcast_parameters
+        broadcast_parameters(model)
     if args.workload == "res50ppm":
         batch = synthetic_batch_2d(args.batch, 32, 128, seed=rank, max_len=3)
     else:
@@ -194,20 +203,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = (not args.no_graph) and not distributed
-    for _ in range(args.warmup):
+    for _ in range(args.warmup if not (distributed and use_graph) else 0):
         step()
     graphed = None
     if use_graph:
         # the whole step (zero_grad, forward, CTC, backward, fused Adam) as ONE captured hipGraph; the timed region
         # replays it.  Same kernels, same work -- only the ~150 host-side launches per step are gone.
-        from megreader_amd.runtime import GraphedTrainStep
+        from megreader_amd.runtime import GraphedTrainStep, data_parallel_grad_sync
 
         def loss_fn(i, l, n):
             loss, _ = net(i, targets=l, lengths=n, train=True)
             return loss.mean()
 
-        graphed = GraphedTrainStep(loss_fn, opt, [img, lab, ln], warmup=2)
+        sync = data_parallel_grad_sync(opt) if distributed else None
+        graphed = GraphedTrainStep(loss_fn, opt, [img, lab, ln], warmup=max(2, args.warmup if distributed else 2),
+                                   grad_sync=sync)
         run = graphed
     else:
         run = step
@@ -297,7 +307,9 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload_name, "global_batch": args.batch * world,
                        "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
-                       "launch": "hipGraph replay" if use_graph else "eager",
+                       "launch": ("hipGraph replay" if not distributed else
+                                  "2 hipGraphs + eager in-place RCCL all-reduce of the flat gradients") if use_graph
+                       else ("eager" if not distributed else "eager, apex-style DDP shim (bucketed, overlapped)"),
                        "train_flops_per_image": 3 * fwd_flops},
             "final_loss": final_loss,
             "roofline": roofline,
