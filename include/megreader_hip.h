@@ -71,6 +71,13 @@ int mr_conv2d_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, int
 int mr_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw_krsc, float* dbias, int Nimg, int H, int W,
                     int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh,
                     int dw, int Ho, int Wo, hipStream_t stream);
+/* mr_conv2d_wgrad with a caller-owned row table of the im2col gather: rowtab = N*Ho*Wo entries of 8 bytes
+ * ({element offset of the pixel's window in x, validity bit per tap}); build != 0 fills it first, build == 0 trusts
+ * it (a layer's geometry is constant: build once, reuse every step).  bf16 and R*S <= 32; otherwise, or with
+ * rowtab == NULL, identical to mr_conv2d_wgrad. */
+int mr_conv2d_wgrad_tab(int dtype, const void* dy, const void* x, float* dw_krsc, float* dbias, int N, int H, int W,
+                        int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh,
+                        int dw, int Ho, int Wo, void* rowtab, int build, hipStream_t stream);
 
 /* ---- layout / elementwise helpers ---------------------------------------------------------------------- */
 int mr_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int Cpad,

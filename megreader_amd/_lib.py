@@ -26,6 +26,7 @@ SIGNATURES = {
     "mr_conv2d_fwd": "ipppp" + "i" * 18 + "s",
     "mr_conv2d_dgrad": "ippp" + "i" * 17 + "s",
     "mr_conv2d_wgrad": "ipppp" + "i" * 17 + "s",
+    "mr_conv2d_wgrad_tab": "ipppp" + "i" * 17 + "pis",
     "mr_nchw_to_nhwc": "ippiiiiis",
     "mr_nhwc_to_nchw": "ippiiiiis",
     "mr_cast": "ipipls",

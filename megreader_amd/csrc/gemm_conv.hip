@@ -354,7 +354,7 @@ int mr_gemm_tn(int dtype, const void* A, long long lda, const void* B, long long
   MR_CHECK_ARG(row_perm_h == 0 || NA % (4 * row_perm_h) == 0, "mr_gemm_tn: NA must be a multiple of 4*row_perm_h");
   TnArgs a;
   a.A = A; a.B = B; a.C = C; a.P = P; a.NA = NA; a.NB = NB; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-  a.p_chunk = 0; a.row_perm_h = row_perm_h; a.colsum = colsum;
+  a.p_chunk = 0; a.row_perm_h = row_perm_h; a.colsum = colsum; a.rowtab = nullptr;
   ConvGeom g = {};
   if (dtype == MR_F32) return launch_tn<float, 0>(a, g, stream);
   return launch_tn<bf16_t, 0>(a, g, stream);
@@ -422,11 +422,36 @@ int mr_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw_krsc, fl
   MR_CHECK_ARG(aligned16(dy) && aligned16(x), "mr_conv2d_wgrad: dy and x must be 16-byte aligned");
   TnArgs a;
   a.A = dy; a.B = x; a.C = dw_krsc; a.P = Nimg * Ho * Wo; a.NA = Cout; a.NB = R * S * Cin; a.lda = lddy;
-  a.ldb = 0; a.ldc = R * S * Cin; a.p_chunk = 0; a.row_perm_h = 0; a.colsum = dbias;
+  a.ldb = 0; a.ldc = R * S * Cin; a.p_chunk = 0; a.row_perm_h = 0; a.colsum = dbias; a.rowtab = nullptr;
   ConvGeom g;
   fill_geom(g, 1, H, W, Cin, ldx, Ho, Wo, R, S, sh, sw, ph, pw, dh, dw);
   if (dtype == MR_F32) return launch_tn<float, 1>(a, g, stream);
   return launch_tn<bf16_t, 1>(a, g, stream);
+}
+
+// Same as mr_conv2d_wgrad with a caller-owned ROW TABLE of the gather (8 bytes per output pixel, see
+// tn_rowtab_kernel): build != 0 fills it first (one small kernel), build == 0 trusts its contents -- the geometry of
+// a layer never changes, so callers build it once and pass it to every later step.  bf16, R*S <= 32 only
+// (otherwise, or with rowtab == null, this is mr_conv2d_wgrad).
+int mr_conv2d_wgrad_tab(int dtype, const void* dy, const void* x, float* dw_krsc, float* dbias, int Nimg, int H,
+                        int W, int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw,
+                        int dh, int dw, int Ho, int Wo, void* rowtab, int build, hipStream_t stream) {
+  if (rowtab == nullptr || dtype != MR_BF16 || R * S > 32 || g_nt_variant != 2 || g_tn_big > 0)
+    return mr_conv2d_wgrad(dtype, dy, x, dw_krsc, dbias, Nimg, H, W, Cin, ldx, Cout, lddy, R, S, sh, sw, ph, pw, dh,
+                           dw, Ho, Wo, stream);
+  MR_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && Cout % 8 == 0 && lddy % 8 == 0,
+               "mr_conv2d_wgrad_tab: Cin/ldx/Cout/lddy must be multiples of 8");
+  MR_CHECK_ARG(aligned16(dy) && aligned16(x) && ((uintptr_t)rowtab & 7) == 0, "mr_conv2d_wgrad_tab: alignment");
+  TnArgs a;
+  a.A = dy; a.B = x; a.C = dw_krsc; a.P = Nimg * Ho * Wo; a.NA = Cout; a.NB = R * S * Cin; a.lda = lddy;
+  a.ldb = 0; a.ldc = R * S * Cin; a.p_chunk = 0; a.row_perm_h = 0; a.colsum = dbias; a.rowtab = (const int2*)rowtab;
+  ConvGeom g;
+  fill_geom(g, 1, H, W, Cin, ldx, Ho, Wo, R, S, sh, sw, ph, pw, dh, dw);
+  if (build) {
+    hipLaunchKernelGGL(tn_rowtab_kernel, dim3(cdiv(a.P, 256)), dim3(256), 0, stream, g, a.P, (int2*)rowtab);
+    MR_CHECK_LAUNCH();
+  }
+  return launch_tn<bf16_t, 2>(a, g, stream);
 }
 
 }  // extern "C"

@@ -936,7 +936,30 @@ struct TnArgs {
   int p_chunk;  // rows of P per split (multiple of the p-step)
   int row_perm_h;
   float* colsum;  // optional [NA]: += sum_p A[p, na] (bias gradient), accumulated by the tile_b == 0 blocks
+  const int2* rowtab;  // BMODE 2: per output pixel {element offset of its window's top-left input pixel, tap mask}
 };
+
+// Row table of the conv-wgrad gather (one entry per output pixel p = (n, ho, wo)):
+//   .x = ((n*Hg + ho*sh)*Wg + wo*sw) * ldg      (element offset BEFORE the (-ph, -pw) / tap shift, which is a
+//                                                 per-column constant in the GEMM kernel)
+//   .y = bit (r*S + s) set  <=>  tap (r, s) of this pixel reads inside the image
+// The geometry is fixed per layer, so the table is built once and re-used by every training step; it turns the
+// per-step, per-row index arithmetic of the streaming (pixel) dimension into one 8-byte load.
+static __global__ void tn_rowtab_kernel(ConvGeom g, int P, int2* __restrict__ tab) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int qw = p % g.Wm;
+  const int t = p / g.Wm;
+  const int qh = t % g.Hm;
+  const int qn = t / g.Hm;
+  unsigned mask = 0;
+  for (int r = 0; r < g.R; ++r)
+    for (int s = 0; s < g.S; ++s) {
+      const int hi = qh * g.sh + r * g.dh - g.ph, wi = qw * g.sw + s * g.dw - g.pw;
+      if ((unsigned)hi < (unsigned)g.Hg && (unsigned)wi < (unsigned)g.Wg) mask |= 1u << (r * g.S + s);
+    }
+  tab[p] = make_int2((int)((((long long)qn * g.Hg + qh * g.sh) * g.Wg + qw * g.sw) * g.ldg), (int)mask);
+}
 
 template <typename T> struct TnCfg;
 template <> struct TnCfg<bf16_t> {
@@ -1174,7 +1197,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
 // instruction = 4 full 256-byte rows), the swizzle is applied to the SOURCE column of each lane.
 // ---------------------------------------------------------------------------------------------
 template <int BMODE>
-__global__ __launch_bounds__(256) void igemm_tn_glds_kernel(TnArgs a, ConvGeom g, const void* zero) {
+__global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeom g, const void* zero) {
   typedef bf16_t T;
   constexpr int BP = 64, ROW_BYTES = 256, TILE_BYTES = BP * ROW_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // [stage][A|B]
@@ -1205,7 +1228,17 @@ __global__ __launch_bounds__(256) void igemm_tn_glds_kernel(TnArgs a, ConvGeom g
 
   // This lane stages rows (wave*4+jj)*4 + lrow, jj = 0..3, physical 16-byte chunk pc16.  tn_hash(row) only
   // depends on lrow and bit 1 of (wave*4+jj) = bit 1 of jj, so the lane has two logical columns (h2 = jj>>1).
-  int colA[2], colB[2], tr[2], ts[2], tc[2], dho[2], dwo[2];
+  //
+  // Address generation is the hot part of this kernel (it was VALU-bound: ~400 vector ALU instructions, 70 of them
+  // quarter-rate 64-bit multiplies, per 32 MFMAs), so every staged row keeps 32-bit ELEMENT OFFSETS that advance by
+  // additions only (operands are < 2^31 elements):
+  //   A / dense B: off = p*ld + col                                -> += BP*ld per p-step
+  //   conv B:      pix = ((n*Hg + qh*sh)*Wg + qw*sw)*ldg (the window's top-left input pixel, before the tap shift)
+  //                -> += BP*sw*ldg per p-step, += wrap_w when the row index wraps, += wrap_h when the image wraps;
+  //                the tap (r,s) and channel of this lane's column add a per-column constant tapoff[h2].
+  //   conv B with a row table (BMODE 2): pix and the tap-validity mask of every row come from a[].rowtab (one
+  //                8-byte load per row, issued one p-step ahead); nothing is computed per step.
+  int colA[2], colB[2], tapoff[2], dho[2], dwo[2], tapbit[2];
   bool okA[2], okB[2];
 #pragma unroll
   for (int h2 = 0; h2 < 2; ++h2) {
@@ -1215,52 +1248,85 @@ __global__ __launch_bounds__(256) void igemm_tn_glds_kernel(TnArgs a, ConvGeom g
     colB[h2] = nb0 + col;
     okA[h2] = colA[h2] < a.NA;
     okB[h2] = colB[h2] < a.NB;
-    tr[h2] = ts[h2] = 0;
-    tc[h2] = colB[h2];
+    tapoff[h2] = colB[h2];
     dho[h2] = dwo[h2] = 0;
-    if (BMODE == 1) {
+    tapbit[h2] = 0;
+    if (BMODE != 0) {
       const int tap = colB[h2] / g.Cg;
-      tc[h2] = colB[h2] - tap * g.Cg;
-      tr[h2] = tap / g.S;
-      ts[h2] = tap - tr[h2] * g.S;
-      dho[h2] = tr[h2] * g.dh - g.ph;  // forward gather (mode 1): hi = q_h*sh + dho, wi = q_w*sw + dwo
-      dwo[h2] = ts[h2] * g.dw - g.pw;
+      const int tc = colB[h2] - tap * g.Cg;
+      const int tr = tap / g.S, ts = tap - tr * g.S;
+      dho[h2] = tr * g.dh - g.ph;  // forward gather (mode 1): hi = q_h*sh + dho, wi = q_w*sw + dwo
+      dwo[h2] = ts * g.dw - g.pw;
+      tapoff[h2] = (dho[h2] * g.Wg + dwo[h2]) * g.ldg + tc;
+      tapbit[h2] = tap;
     }
   }
-  int q_n[4], q_h[4], q_w[4];
-  if (BMODE == 1) {
+  int rowoff[4], soffA[4], soffB[4], q_h[4], q_w[4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int p = p_begin + (wave * 4 + jj) * 4 + lrow;
+  for (int jj = 0; jj < 4; ++jj) {
+    rowoff[jj] = (wave * 4 + jj) * 4 + lrow;
+    const int p = p_begin + rowoff[jj];
+    soffA[jj] = (int)((long long)p * a.lda) + colA[jj >> 1];
+    q_h[jj] = q_w[jj] = 0;
+    if (BMODE == 0) {
+      soffB[jj] = (int)((long long)p * a.ldb) + colB[jj >> 1];
+    } else if (BMODE == 2) {
+      soffB[jj] = 0;
+    } else {
       q_w[jj] = p % g.Wm;
       const int t = p / g.Wm;
       q_h[jj] = t % g.Hm;
-      q_n[jj] = t / g.Hm;
+      const int qn = t / g.Hm;
+      soffB[jj] = (int)((((long long)qn * g.Hg + q_h[jj] * g.sh) * g.Wg + q_w[jj] * g.sw) * g.ldg);
     }
   }
+  const int stepA = BP * (int)a.lda;
+  const int stepB = BMODE == 0 ? BP * (int)a.ldb : BP * g.sw * g.ldg;
+  // BMODE 2: row-table entries of the rows this lane stages next (prefetched one p-step ahead)
+  int2 ent[4];
+  auto fetch_entries = [&](int p0) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int p = p0 + rowoff[jj];
+      ent[jj] = p < p_end ? a.rowtab[p] : make_int2(0, 0);
+    }
+  };
+  if (BMODE == 2) fetch_entries(p_begin);
+  const int wrap_w = BMODE == 1 ? (g.sh * g.Wg - g.Wm * g.sw) * g.ldg : 0;
+  const int wrap_h = BMODE == 1 ? (g.Hg - g.Hm * g.sh) * g.Wg * g.ldg : 0;
 
   auto stage = [&](unsigned char* sA, int p0) {
     unsigned char* sB = sA + TILE_BYTES;
+    const int rows_left = p_end - p0;  // uniform
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int h2 = jj >> 1;
-      const int p = p0 + (wave * 4 + jj) * 4 + lrow;
-      const bool pv = p < p_end;
-      glds16(sel_ptr(pv && okA[h2], A + (long long)p * a.lda + colA[h2], zero), sA + (wave * 4 + jj) * 1024);
+      const bool pv = rowoff[jj] < rows_left;
+      glds16(sel_ptr(pv && okA[h2], A + soffA[jj], zero), sA + (wave * 4 + jj) * 1024);
+      soffA[jj] += stepA;
       if (BMODE == 0) {
-        glds16(sel_ptr(pv && okB[h2], B + (long long)p * a.ldb + colB[h2], zero), sB + (wave * 4 + jj) * 1024);
+        glds16(sel_ptr(pv && okB[h2], B + soffB[jj], zero), sB + (wave * 4 + jj) * 1024);
+        soffB[jj] += stepB;
+      } else if (BMODE == 2) {
+        const bool v = okB[h2] && ((ent[jj].y >> tapbit[h2]) & 1);  // rows beyond p_end carry an empty mask
+        glds16(sel_ptr(v, B + (ent[jj].x + tapoff[h2]), zero), sB + (wave * 4 + jj) * 1024);
       } else {
         const int hi = q_h[jj] * g.sh + dho[h2], wi = q_w[jj] * g.sw + dwo[h2];
         const bool v = pv && okB[h2] && (unsigned)hi < (unsigned)g.Hg && (unsigned)wi < (unsigned)g.Wg;
-        const long long off = ((long long)(q_n[jj] * g.Hg + hi) * g.Wg + wi) * g.ldg + tc[h2];
-        glds16(sel_ptr(v, B + off, zero), sB + (wave * 4 + jj) * 1024);
+        glds16(sel_ptr(v, B + (soffB[jj] + tapoff[h2]), zero), sB + (wave * 4 + jj) * 1024);
         q_w[jj] += BP;
+        soffB[jj] += stepB;
         while (q_w[jj] >= g.Wm) {
           q_w[jj] -= g.Wm;
-          if (++q_h[jj] == g.Hm) { q_h[jj] = 0; ++q_n[jj]; }
+          soffB[jj] += wrap_w;
+          if (++q_h[jj] == g.Hm) {
+            q_h[jj] = 0;
+            soffB[jj] += wrap_h;
+          }
         }
       }
     }
+    if (BMODE == 2) fetch_entries(p0 + BP);
   };
 
   const int wa = wave & 1, wb = wave >> 1;

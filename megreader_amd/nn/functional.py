@@ -169,6 +169,23 @@ def _conv_out(size, k, s, p, d):
     return (size + 2 * p - d * (k - 1) - 1) // s + 1
 
 
+_ROWTABS = {}
+
+
+def _wgrad_rowtab(device, geom):
+    """Cached row table of the wgrad gather for one conv geometry (see mr_conv2d_wgrad_tab).  Returns
+    (tensor, build_flag): build_flag is 1 only for the call that has to fill it."""
+    key = (device, geom)
+    tab = _ROWTABS.get(key)
+    if tab is not None:
+        return tab, 0
+    n, ho, wo = geom[0], geom[-2], geom[-1]
+    if len(_ROWTABS) > 256:
+        _ROWTABS.clear()
+    tab = _ROWTABS[key] = torch.empty((n * ho * wo, 2), dtype=torch.int32, device=device)
+    return tab, 1
+
+
 def _conv_operands(weight, bias, dtype, Cp, Kp, need_dx):
     """Compute-dtype images of a conv weight: KRSC (forward / wgrad layout), CRSK (dgrad) and the padded bias.
     Persistent buffers, regenerated only when the parameter changes (megreader_amd.nn.prep)."""
@@ -258,8 +275,13 @@ class Conv2dFn(Function):
         if ctx.needs_input_grad[1]:
             gw = w_sink if w_sink is not None else torch.zeros((Kp, R, S, Cp), dtype=torch.float32, device=g.device)
             # the bias gradient (column sums of dy) rides along the wgrad pass over dy
-            call("mr_conv2d_wgrad", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, Kp, Kp,
-                 R, S, sh, sw, ph, pw, dh, dw, Ho, Wo)
+            # the gather's row table (8 bytes per output pixel) depends only on the layer geometry: built on first
+            # use, then passed to every later step (bf16, R*S <= 32; otherwise the call is plain mr_conv2d_wgrad)
+            tab, build = (None, 0)
+            if dtype == torch.bfloat16 and R * S <= 32:
+                tab, build = _wgrad_rowtab(g.device, (N, H, W, Cp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo))
+            call("mr_conv2d_wgrad_tab", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, Kp,
+                 Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo, ptr(tab), build)
             if w_sink is not None:
                 dwt = None
                 notify_grad_ready(weight_p)

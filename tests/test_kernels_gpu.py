@@ -431,3 +431,38 @@ def test_big_tile_tn_kernel_matches_128_tile_kernel(mode):
         assert _rel_err(w1, want) < 2e-5 and _rel_err(w0, want) < 2e-5, (Nb, H, W)
         bsum = dy.double().cpu().sum(dim=(0, 1, 2))
         assert _rel_err(b1, bsum) < 2e-5 and _rel_err(b0, bsum) < 2e-5
+
+
+def test_conv_wgrad_row_table_matches_plain_wgrad():
+    """mr_conv2d_wgrad_tab (per-pixel row table of the gather, built once) against mr_conv2d_wgrad: strided, dilated,
+    asymmetric padding, 2x2 without padding, P not a multiple of the 64-row step; second call re-uses the table."""
+    dtype = torch.bfloat16
+    dt = dtype_code(dtype)
+    g = torch.Generator().manual_seed(23)
+    cases = [(3, 8, 32, 64, 72, 3, 3, 1, 1, 1, 1, 1, 1), (2, 9, 11, 16, 40, 3, 3, 2, 2, 1, 1, 1, 1),
+             (5, 2, 34, 128, 128, 2, 2, 1, 1, 0, 0, 1, 1), (2, 12, 10, 32, 24, 3, 3, 1, 1, 2, 2, 2, 2),
+             (2, 7, 9, 8, 16, 3, 1, 1, 2, 1, 0, 1, 1)]
+    for (Nb, H, W, C, Kc, R, S, sh, sw, ph, pw, dh, dw) in cases:
+        Ho = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1
+        Wo = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
+        x = torch.randn(Nb, H, W, C, generator=g).to(DEV, dtype)
+        dy = torch.randn(Nb, Ho, Wo, Kc, generator=g).to(DEV, dtype)
+        tab = torch.empty(Nb * Ho * Wo, 2, dtype=torch.int32, device=DEV)
+
+        def run(name, *extra):
+            gw = torch.zeros(Kc, R, S, C, device=DEV)
+            gb = torch.zeros(Kc, device=DEV)
+            call(name, dt, ptr(dy), ptr(x), ptr(gw), ptr(gb), Nb, H, W, C, C, Kc, Kc, R, S, sh, sw, ph, pw, dh, dw, Ho,
+                 Wo, *extra)
+            return gw, gb
+
+        w0, b0 = run("mr_conv2d_wgrad")
+        w1, b1 = run("mr_conv2d_wgrad_tab", ptr(tab), 1)
+        w2, b2 = run("mr_conv2d_wgrad_tab", ptr(tab), 0)
+        case = (Nb, H, W, C, Kc, R, S, sh, sw, ph, pw, dh, dw)
+        assert _rel_err(w1, w0) < 2e-5 and _rel_err(w2, w0) < 2e-5, case
+        assert _rel_err(b1, b0) < 2e-5 and _rel_err(b2, b0) < 2e-5, case
+        xr = x.double().cpu().permute(0, 3, 1, 2)
+        wr = torch.zeros(Kc, C, R, S, dtype=torch.float64, requires_grad=True)
+        TF.conv2d(xr, wr, None, (sh, sw), (ph, pw), (dh, dw)).backward(dy.double().cpu().permute(0, 3, 1, 2))
+        assert _rel_err(w1, wr.grad.permute(0, 2, 3, 1)) < 2e-5, case

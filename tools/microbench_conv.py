@@ -54,6 +54,10 @@ def main():
         gw = torch.zeros(K, k, k, C, device=dev)
         gb = torch.zeros(K, device=dev)
         bias = torch.zeros(K, device=dev)
+        tab = torch.empty(N * Ho * Wo, 2, dtype=torch.int32, device=dev)
+        call("mr_conv2d_wgrad_tab", dt, ptr(dy), ptr(x), ptr(gw), ptr(gb), N, H, W, C, C, K, K, k, k, 1, 1, p, p, 1, 1,
+             Ho, Wo, ptr(tab), 1)   # builds the row table (and runs once)
+        gw.zero_(); gb.zero_()
         flops = 2.0 * N * Ho * Wo * K * k * k * C
         ops = {
             "fwd": lambda: call("mr_conv2d_fwd", dt, ptr(x), ptr(w), ptr(bias), ptr(y), 1, N, H, W, C, C, K, K, k, k,
@@ -62,6 +66,8 @@ def main():
                                   p, p, 1, 1, Ho, Wo),
             "wgrad": lambda: call("mr_conv2d_wgrad", dt, ptr(dy), ptr(x), ptr(gw), ptr(gb), N, H, W, C, C, K, K, k,
                                   k, 1, 1, p, p, 1, 1, Ho, Wo),
+            "wgradtab": lambda: call("mr_conv2d_wgrad_tab", dt, ptr(dy), ptr(x), ptr(gw), ptr(gb), N, H, W, C, C, K, K,
+                                     k, k, 1, 1, p, p, 1, 1, Ho, Wo, ptr(tab), 0),
         }
         line = "L%d M=%7d N=%3d K=%4d " % (li, N * Ho * Wo, K, k * k * C)
         for name in which:
