@@ -47,6 +47,9 @@ int mr_set_nt_big(int mode);
 /* experimental wide-tile TN (weight-gradient) kernels: 1 = 256x256, 2 = 128x256, 0 / -1 = never (default; they are
  * currently slower, see gemm_conv.hip:launch_tn); returns the previous setting */
 int mr_set_tn_big(int mode);
+/* TN kernel operand staging: 1 = raw buffer resources (out-of-range -> zeros), 0 = flat pointers + zero page;
+ * returns the previous setting */
+int mr_set_tn_buf(int mode);
 /* tile (BM*1000+BN) the NT kernels pick for an M x N problem; host-only query used for profiling labels */
 int mr_nt_tile_code(int M, int N);
 /* same, including the big-tile policy (returns 256256 for the 8-wave 256x256 kernel); cg = channels of the gathered

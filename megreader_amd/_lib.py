@@ -109,6 +109,8 @@ def load():
     lib.mr_nt_tile_code.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mr_nt_kernel_code.restype = ctypes.c_int
     lib.mr_nt_kernel_code.argtypes = [ctypes.c_int] * 5
+    lib.mr_set_tn_buf.restype = ctypes.c_int
+    lib.mr_set_tn_buf.argtypes = [ctypes.c_int]
     lib.mr_set_tn_big.restype = ctypes.c_int
     lib.mr_set_tn_big.argtypes = [ctypes.c_int]
     lib.mr_set_nt_big.restype = ctypes.c_int
@@ -130,7 +132,7 @@ def load():
 
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_set_nt_variant", "mr_force_nt_tile",
              "mr_stem_bwd_workspace", "mr_set_lstm_variant", "mr_set_nt_big",
-             "mr_nt_kernel_code", "mr_set_tn_big")  # entry points that take no stream and launch nothing
+             "mr_nt_kernel_code", "mr_set_tn_big", "mr_set_tn_buf")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

@@ -474,6 +474,19 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)gptr, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 
+// Same LDS-DMA through a raw buffer resource (buffer_load_dwordx4 ... offen lds): the address is a scalar
+// descriptor + a 32-bit per-lane BYTE offset, and an offset beyond num_records returns zeros -- so a padded /
+// out-of-range vector costs one v_cndmask (offset := 0xFFFFFFFF) instead of a 64-bit pointer add plus a 64-bit select
+// against the zero page.  num_records = 2 GiB: operands must be smaller than that (the host checks).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, (int)0x80000000u, 0x00020000);
+}
+__device__ __forceinline__ void glds16_buf(rsrc_t r, bool ok, int elem_off, int esize_shift, void* lds_wave_base) {
+  const unsigned voff = ok ? ((unsigned)elem_off << esize_shift) : 0xFFFFFFFFu;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)lds_wave_base, 16, (int)voff, 0, 0, 0);
+}
+
 // AMODE 0: dense A.  AMODE 2: conv, Cg % BK == 0 (every k-step lies inside one tap: the tap state is scalar and
 // advances incrementally).  AMODE 3: conv with small / odd Cg (first layer): per-vector tap arithmetic.
 template <typename T, int BM, int BN, int AMODE, typename Epi>
@@ -1196,7 +1209,8 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
 // the ds_read_b64_tr_b16 fragment reads are unchanged; because LDS-DMA writes lane-linearly (one wave
 // instruction = 4 full 256-byte rows), the swizzle is applied to the SOURCE column of each lane.
 // ---------------------------------------------------------------------------------------------
-template <int BMODE>
+// BUF: stage through raw buffer resources (glds16_buf) instead of flat pointers + zero page
+template <int BMODE, bool BUF = false>
 __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeom g, const void* zero) {
   typedef bf16_t T;
   constexpr int BP = 64, ROW_BYTES = 256, TILE_BYTES = BP * ROW_BYTES;
@@ -1295,6 +1309,13 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
   const int wrap_w = BMODE == 1 ? (g.sh * g.Wg - g.Wm * g.sw) * g.ldg : 0;
   const int wrap_h = BMODE == 1 ? (g.Hg - g.Hm * g.sh) * g.Wg * g.ldg : 0;
 
+  const rsrc_t rsA = make_rsrc(A), rsB = make_rsrc(B);
+  auto gload = [&](bool isB, bool ok, int off, void* lds) {
+    if (BUF)
+      glds16_buf(isB ? rsB : rsA, ok, off, 1, lds);
+    else
+      glds16(sel_ptr(ok, (isB ? B : A) + off, zero), lds);
+  };
   auto stage = [&](unsigned char* sA, int p0) {
     unsigned char* sB = sA + TILE_BYTES;
     const int rows_left = p_end - p0;  // uniform
@@ -1302,18 +1323,18 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
     for (int jj = 0; jj < 4; ++jj) {
       const int h2 = jj >> 1;
       const bool pv = rowoff[jj] < rows_left;
-      glds16(sel_ptr(pv && okA[h2], A + soffA[jj], zero), sA + (wave * 4 + jj) * 1024);
+      gload(false, pv && okA[h2], soffA[jj], sA + (wave * 4 + jj) * 1024);
       soffA[jj] += stepA;
       if (BMODE == 0) {
-        glds16(sel_ptr(pv && okB[h2], B + soffB[jj], zero), sB + (wave * 4 + jj) * 1024);
+        gload(true, pv && okB[h2], soffB[jj], sB + (wave * 4 + jj) * 1024);
         soffB[jj] += stepB;
       } else if (BMODE == 2) {
         const bool v = okB[h2] && ((ent[jj].y >> tapbit[h2]) & 1);  // rows beyond p_end carry an empty mask
-        glds16(sel_ptr(v, B + (ent[jj].x + tapoff[h2]), zero), sB + (wave * 4 + jj) * 1024);
+        gload(true, v, ent[jj].x + tapoff[h2], sB + (wave * 4 + jj) * 1024);
       } else {
         const int hi = q_h[jj] * g.sh + dho[h2], wi = q_w[jj] * g.sw + dwo[h2];
         const bool v = pv && okB[h2] && (unsigned)hi < (unsigned)g.Hg && (unsigned)wi < (unsigned)g.Wg;
-        glds16(sel_ptr(v, B + (soffB[jj] + tapoff[h2]), zero), sB + (wave * 4 + jj) * 1024);
+        gload(true, v, soffB[jj] + tapoff[h2], sB + (wave * 4 + jj) * 1024);
         q_w[jj] += BP;
         soffB[jj] += stepB;
         while (q_w[jj] >= g.Wm) {
@@ -1378,11 +1399,11 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
           y[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (s16x4 __attribute__((address_space(3)))*)(st + offB[t] + kk * 32 * ROW_BYTES + hh * 4 * ROW_BYTES));
         }
-        union { s16x4 h[2]; bf16x8 v; } ua, ub;
-        ua.h[0] = x[0]; ua.h[1] = x[1];
-        ub.h[0] = y[0]; ub.h[1] = y[1];
-        fa[t] = ua.v;
-        fb[t] = ub.v;
+        // concatenate the two 64-bit halves as a vector shuffle (a union round trip made hipcc assemble every
+        // fragment with v_mov_b64 pairs: 42 extra VALU per p-step)
+        typedef short s16x8_t __attribute__((ext_vector_type(8)));
+        fa[t] = __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(x[0], x[1], 0, 1, 2, 3, 4, 5, 6, 7));
+        fb[t] = __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(y[0], y[1], 0, 1, 2, 3, 4, 5, 6, 7));
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--layers", default="")
     ap.add_argument("--tile", default="", help="force NT tile, e.g. 96x128")
     ap.add_argument("--variant", type=int, default=2, help="NT kernel: 2 direct-to-LDS, 1 register staged")
+    ap.add_argument("--tnbuf", type=int, default=0, help="TN kernel staging through buffer resources (0/1)")
     ap.add_argument("--tnbig", type=int, default=0, help="big-tile TN kernel: 0 auto, -1 never, 1 always")
     ap.add_argument("--big", type=int, default=0, help="big-tile NT kernel: 0 auto, -1 never, 1 256x256, 2 288x256")
     a = ap.parse_args()
@@ -32,6 +33,7 @@ def main():
     _lib.load().mr_set_nt_variant(a.variant)
     _lib.load().mr_set_nt_big(a.big)
     _lib.load().mr_set_tn_big(a.tnbig)
+    _lib.load().mr_set_tn_buf(a.tnbuf)
     if a.tile:
         bm, bn = [int(v) for v in a.tile.split("x")]
         assert _lib.load().mr_force_nt_tile(bm, bn) == 0
