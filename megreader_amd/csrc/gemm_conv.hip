@@ -30,6 +30,16 @@ static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 static int g_nt_variant = 2;  // 2 = direct-to-LDS kernel (default), 1 = register-staged kernel (A/B debugging)
 
+// The direct-to-LDS NT kernels address their operands through buffer resources with 2 GiB of records.
+template <typename T>
+static bool nt_fits_buffer(const NtArgs& a, const ConvGeom& g, int amode) {
+  const long long es = sizeof(T);
+  const long long bytesA = amode == 0 ? (long long)a.M * a.lda * es
+                                      : ((long long)a.M / ((long long)g.Hm * g.Wm) + 1) * g.Hg * g.Wg * g.ldg * es;
+  const long long bytesB = (long long)a.N * a.ldb * es;
+  return bytesA < (1ll << 31) && bytesB < (1ll << 31);
+}
+
 template <typename T, int BM, int BN, int AMODE>
 static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long long ldc, const float* bias,
                            int relu, hipStream_t stream) {
@@ -43,7 +53,7 @@ static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long lon
   epi.vec_ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
   const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
   if constexpr (AMODE != 1) {
-    if (g_nt_variant == 2) {
+    if (g_nt_variant == 2 && nt_fits_buffer<T>(a, g, AMODE)) {
       const int grid = cdiv(cdiv(a.M, BM), 8) * 8 * cdiv(a.N, BN);  // XCD-aware tile map, see the kernel
       NtArgs a2 = a;
       a2.zero = zero_page();
@@ -174,7 +184,8 @@ static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long l
                              int relu, hipStream_t stream) {
   if constexpr (sizeof(T) == 2 && (AMODE == 0 || AMODE == 2)) {
     constexpr int BK = 8 * VecOf<T>::N;
-    if (g_nt_variant == 2 && !g_forced_tile.bm && (AMODE == 0 || (g.Cg % BK) == 0) && aligned16(C)) {
+    if (g_nt_variant == 2 && !g_forced_tile.bm && (AMODE == 0 || (g.Cg % BK) == 0) && aligned16(C) &&
+        nt_fits_buffer<T>(a, g, AMODE)) {
       const int big = nt_big_choice(a.M, a.N, a.K);
       if (big == 1) return launch_nt_big<T, 2, 4, 8, 4, AMODE>(a, g, C, ldc, bias, relu, stream);
       if (big == 2) return launch_nt_big<T, 3, 4, 6, 4, AMODE>(a, g, C, ldc, bias, relu, stream);  // 288x256, 12 waves

@@ -516,10 +516,13 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
 
   const T* __restrict__ A = (const T*)a.A;
   const T* __restrict__ B = (const T*)a.B;
-  const void* Z = a.zero;
+  (void)a.zero;
 
   // ---- per-thread row descriptors: source pointer of (row, logical chunk) at k = 0 / tap (0,0)
-  const T* a_ptr[AI];
+  // operands are staged through raw buffer resources: 32-bit element offsets, out-of-range -> zeros (glds16_buf)
+  constexpr int ESH = sizeof(T) == 2 ? 1 : 2;
+  const rsrc_t rsA = make_rsrc(A), rsB = make_rsrc(B);
+  int a_ptr[AI];
   unsigned a_mask[AI];
   int a_kc[AI];
 #pragma unroll
@@ -528,9 +531,9 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
     const int m = m0 + row;
     a_kc[i] = (lpc ^ ((row >> 1) & 7)) * VEC;
     a_mask[i] = 0;
-    a_ptr[i] = A;
+    a_ptr[i] = 0;
     if (AMODE == 0) {
-      a_ptr[i] = A + (long long)m * a.lda + a_kc[i];
+      a_ptr[i] = (int)((long long)m * a.lda + a_kc[i]);
       a_mask[i] = m < a.M ? 1u : 0u;
     } else if (m < a.M) {
       const int wm = m % g.Wm;
@@ -539,8 +542,8 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
       const int ni = t / g.Hm;
       const int bh = g.mode == 1 ? hm * g.sh - g.ph : hm + g.ph;
       const int bw = g.mode == 1 ? wm * g.sw - g.pw : wm + g.pw;
-      a_ptr[i] = A + (long long)ni * g.Hg * g.Wg * g.ldg + ((long long)bh * g.Wg + bw) * g.ldg +
-                 (AMODE == 2 ? a_kc[i] : 0);
+      a_ptr[i] = (int)((long long)ni * g.Hg * g.Wg * g.ldg + ((long long)bh * g.Wg + bw) * g.ldg +
+                       (AMODE == 2 ? a_kc[i] : 0));
       unsigned msk = 0;
       for (int r = 0; r < g.R; ++r)
         for (int s2 = 0; s2 < g.S; ++s2) {
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
       a_mask[i] = msk;
     }
   }
-  const T* b_ptr[BI];
+  int b_ptr[BI];
   int b_kc[BI];
   bool b_ok[BI];
 #pragma unroll
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
     const int n = n0 + (row - rb) + ((rb >> 2) & 3) * (4 * TN) + (rb >> 4) * 4 + (rb & 3);
     b_kc[i] = (lpc ^ ((row >> 1) & 7)) * VEC;
     b_ok[i] = n < a.N;
-    b_ptr[i] = B + (long long)n * a.ldb + b_kc[i];
+    b_ptr[i] = (int)((long long)n * a.ldb + b_kc[i]);
   }
 
   const int taps = g.R * g.S;
@@ -578,13 +581,13 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
         const bool ok = a_mask[i] && (k_exact || k0 + a_kc[i] < a.K);
-        glds16(sel_ptr(ok, a_ptr[i] + k0, Z), sA + (wave * AI + i) * 64);
+        glds16_buf(rsA, ok, a_ptr[i] + k0, ESH, sA + (wave * AI + i) * 64);
       }
     } else if (AMODE == 2) {
-      const long long koff = (long long)(sgn * ((s_r * g.dh * g.Wg + s_s * g.dw) * g.ldg)) + s_c0;
+      const int koff = sgn * ((s_r * g.dh * g.Wg + s_s * g.dw) * g.ldg) + s_c0;
       const unsigned bit = 1u << s_tap;
 #pragma unroll
-      for (int i = 0; i < AI; ++i) glds16(sel_ptr(a_mask[i] & bit, a_ptr[i] + koff, Z), sA + (wave * AI + i) * 64);
+      for (int i = 0; i < AI; ++i) glds16_buf(rsA, a_mask[i] & bit, a_ptr[i] + koff, ESH, sA + (wave * AI + i) * 64);
       s_c0 += BK;
       if (s_c0 >= g.Cg) {
         s_c0 = 0;
@@ -599,14 +602,14 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
         const int c = k - tap * g.Cg;
         const int r = tap / g.S, s2 = tap - r * g.S;
         const bool ok = tap < taps && ((a_mask[i] >> tap) & 1u);
-        glds16(sel_ptr(ok, a_ptr[i] + (long long)(sgn * ((r * g.dh * g.Wg + s2 * g.dw) * g.ldg)) + c, Z),
-               sA + (wave * AI + i) * 64);
+        glds16_buf(rsA, ok, a_ptr[i] + sgn * ((r * g.dh * g.Wg + s2 * g.dw) * g.ldg) + c, ESH,
+                   sA + (wave * AI + i) * 64);
       }
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const bool ok = b_ok[i] && (k_exact || k0 + b_kc[i] < a.K);
-      glds16(sel_ptr(ok, b_ptr[i] + k0, Z), sB + (wave * BI + i) * 64);
+      glds16_buf(rsB, ok, b_ptr[i] + k0, ESH, sB + (wave * BI + i) * 64);
     }
   };
 
@@ -721,7 +724,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_nt_big_kernel(NtArgs a, Co
 
   const T* __restrict__ A = (const T*)a.A;
   const T* __restrict__ B = (const T*)a.B;
-  const void* Z = a.zero;
+  (void)a.zero;
+  constexpr int ESH = sizeof(T) == 2 ? 1 : 2;
+  const rsrc_t rsA = make_rsrc(A), rsB = make_rsrc(B);
 
   // per-thread row descriptors: 32-bit element offset of (row, logical chunk) at k = 0 / tap (0,0) + tap mask.
   // (operands are < 2^31 elements; offsets instead of pointers halve the descriptor registers)
@@ -780,7 +785,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_nt_big_kernel(NtArgs a, Co
         const int gi = wave + i * NW;
         if (AG % NW == 0 || gi < AG) {
           const bool ok = a_mask[i] && (k_exact || k0 + kc_of(gi) < a.K);
-          glds16(sel_ptr(ok, A + a_off[i] + k0, Z), sA + gi * 64);
+          glds16_buf(rsA, ok, a_off[i] + k0, ESH, sA + gi * 64);
         }
       }
     } else {
@@ -789,7 +794,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_nt_big_kernel(NtArgs a, Co
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
         const int gi = wave + i * NW;
-        if (AG % NW == 0 || gi < AG) glds16(sel_ptr(a_mask[i] & bit, A + (a_off[i] + koff), Z), sA + gi * 64);
+        if (AG % NW == 0 || gi < AG) glds16_buf(rsA, a_mask[i] & bit, a_off[i] + koff, ESH, sA + gi * 64);
       }
       s_c0 += BK;
       if (s_c0 >= g.Cg) {
@@ -803,7 +808,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_nt_big_kernel(NtArgs a, Co
       const int gi = wave + i * NW;
       if (BG % NW == 0 || gi < BG) {
         const bool ok = ((b_okmask >> i) & 1u) && (k_exact || k0 + kc_of(gi) < a.K);
-        glds16(sel_ptr(ok, B + b_off[i] + k0, Z), sB + gi * 64);
+        glds16_buf(rsB, ok, b_off[i] + k0, ESH, sB + gi * 64);
       }
     }
   };
