@@ -223,7 +223,7 @@ def main():
         run = step
     timer = None
     if not args.no_kernel_timer and not use_graph:
-        timer = _lib.KernelTimer(["mr_conv2d_fwd", "mr_conv2d_dgrad", "mr_conv2d_wgrad"])
+        timer = _lib.KernelTimer(["mr_conv2d_fwd", "mr_conv2d_dgrad", "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab"])
         _lib.TIMER = timer
     barrier()
     t0 = time.perf_counter()
@@ -238,7 +238,7 @@ def main():
     if use_graph and not args.no_kernel_timer:
         # HIP events cannot bracket kernels inside a graph replay: measure the dominant kernel's launch durations
         # on the same stream with the same tensors in an eager pass right after the timed region
-        timer = _lib.KernelTimer(["mr_conv2d_fwd", "mr_conv2d_dgrad", "mr_conv2d_wgrad"])
+        timer = _lib.KernelTimer(["mr_conv2d_fwd", "mr_conv2d_dgrad", "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab"])
         _lib.TIMER = timer
         timer_steps = min(args.steps, 10)
         for _ in range(timer_steps):

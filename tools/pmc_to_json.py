@@ -26,7 +26,7 @@ def label(name):
         return "igemm_nt_kernel<bf16,%s,%s,conv>" % (m.group(1), m.group(2))
     if "igemm_nt_big_kernelIDF16bLi2ELi4ELi8ELi4ELi2E" in name:
         return "igemm_nt_kernel<bf16,256,256,conv>"
-    if "igemm_tn_glds_kernel<1>" in name or "igemm_tn_glds_kernelILi1E" in name:
+    if re.search(r"igemm_tn_glds_kernel<[12]", name) or re.search(r"igemm_tn_glds_kernelILi[12]E", name):
         return "igemm_tn_kernel<bf16,conv>"
     return None
 
