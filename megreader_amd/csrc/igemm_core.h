@@ -311,6 +311,15 @@ __device__ __forceinline__ void igemm_nt_ksplit_body(const NtArgs& a, const Epi&
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // epilogue operands of this thread's output vectors (epilogue element gidx = tid + 256*i -> (m, n)): in flight
+  // during the whole k-loop
+  typename Epi::Pre pre[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int gidx = tid + 256 * i;
+    pre[i] = epi.prefetch(m0 + (gidx >> 4), n0 + (gidx & 15) * 4);
+  }
+
   load_panels(0);
   for (int k0 = 0; k0 < a.K; k0 += 4 * BK) {
 #pragma unroll
@@ -357,7 +366,7 @@ __device__ __forceinline__ void igemm_nt_ksplit_body(const NtArgs& a, const Epi&
       const f32x4 u = *(const f32x4*)&red[w * BM * 64 + m * 64 + n];
       v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
     }
-    epi(m0 + m, n0 + n, v);
+    epi.apply(m0 + m, n0 + n, v, pre[i]);
   }
 }
 
@@ -391,6 +400,11 @@ __device__ __forceinline__ void igemm_nt_kdirect_body(const NtArgs& a, const Epi
   for (int i = 0; i < TN; ++i)
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int NV = BM * BN / 4;  // f32x4 vectors of the tile; thread tid owns vector tid (NV <= 256)
+  static_assert(NV <= 256, "one epilogue vector per thread");
+  const int em = tid / (BN / 4), en = (tid % (BN / 4)) * 4;
+  typename Epi::Pre pre = epi.prefetch(tid < NV ? m0 + em : a.M, n0 + en);  // in flight during the k-loop
 
   const int kw = ((a.K + 4 * KR - 1) / (4 * KR)) * KR;  // per-wave K slice
   const int k_lo = wave * kw;
@@ -430,16 +444,14 @@ __device__ __forceinline__ void igemm_nt_kdirect_body(const NtArgs& a, const Epi
       *(f32x4*)&red[wave * BM * BN + m * BN + n] = acc[i][j];
     }
   __syncthreads();
-  constexpr int NV = BM * BN / 4;  // f32x4 vectors of the tile
-  for (int gidx = tid; gidx < NV; gidx += 256) {
-    const int m = gidx / (BN / 4), n = (gidx % (BN / 4)) * 4;
-    f32x4 v = *(const f32x4*)&red[m * BN + n];
+  if (tid < NV) {
+    f32x4 v = *(const f32x4*)&red[em * BN + en];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-      const f32x4 u = *(const f32x4*)&red[w * BM * BN + m * BN + n];
+      const f32x4 u = *(const f32x4*)&red[w * BM * BN + em * BN + en];
       v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
     }
-    epi(m0 + m, n0 + n, v);
+    epi.apply(m0 + em, n0 + en, v, pre);
   }
 }
 

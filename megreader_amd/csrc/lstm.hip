@@ -25,16 +25,27 @@ template <typename T> struct EpiLstmFwd {
   T* h_out;         // [N][2H] + dir*H
   T* gates_out;     // [N][8H] + dir*4H
   int Nb, H;
-  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+  // Operands of the gate math that do not depend on the recurrent GEMM: fetched BEFORE the k-loop so that their
+  // memory round trip overlaps the GEMM instead of following it (the step kernels are pure latency chains).
+  struct Pre { f32x4 x; float cp; };
+  __device__ __forceinline__ Pre prefetch(int m, int n) const {
+    Pre p;
+    p.x = f32x4{0.f, 0.f, 0.f, 0.f};
+    p.cp = 0.f;
+    if (m < Nb && n < 4 * H) {
+      p.x = load4(xproj + (long long)m * 8 * H + n);
+      if (c_prev) p.cp = c_prev[(long long)m * 2 * H + (n >> 2)];
+    }
+    return p;
+  }
+  __device__ __forceinline__ void apply(int m, int n, f32x4 v, const Pre& p) const {
     if (m >= Nb || n >= 4 * H) return;
     const int j = n >> 2;
-    const f32x4 x = load4(xproj + (long long)m * 8 * H + n);
-    const float ig = sigmoidf_(v[0] + x[0]);
-    const float fg = sigmoidf_(v[1] + x[1]);
-    const float gg = tanhf_(v[2] + x[2]);
-    const float og = sigmoidf_(v[3] + x[3]);
-    const float cp = c_prev ? c_prev[(long long)m * 2 * H + j] : 0.f;
-    const float c = fg * cp + ig * gg;
+    const float ig = sigmoidf_(v[0] + p.x[0]);
+    const float fg = sigmoidf_(v[1] + p.x[1]);
+    const float gg = tanhf_(v[2] + p.x[2]);
+    const float og = sigmoidf_(v[3] + p.x[3]);
+    const float c = fg * p.cp + ig * gg;
     const float h = og * tanhf_(c);
     c_out[(long long)m * 2 * H + j] = c;
     h_out[(long long)m * 2 * H + j] = from_f32<T>(h);
@@ -52,28 +63,44 @@ template <typename T> struct EpiLstmBwd {
   float* dc;            // [N][2H] + dir*H   carried cell gradient (read unless first bwd step, then written)
   int first;            // first backward step: no carried dc
   int Nb, H;
-  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+  // everything the gate algebra reads besides the recurrent GEMM result (see EpiLstmFwd::Pre)
+  struct Pre { f32x4 up, g[4], ct, dcv, cp; };
+  __device__ __forceinline__ Pre prefetch(int m, int n) const {
+    Pre p;
+    p.up = p.ct = p.dcv = p.cp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) p.g[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (m < Nb && n < H) {
+      const long long r2 = (long long)m * 2 * H, r8 = (long long)m * 8 * H;
+      p.up = load4(dout + r2 + n);
+      p.ct = *(const f32x4*)(c_t + r2 + n);
+      if (!first) p.dcv = *(const f32x4*)(dc + r2 + n);
+      if (c_prev) p.cp = *(const f32x4*)(c_prev + r2 + n);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) p.g[jj] = load4(gates + r8 + 4 * (n + jj));
+    }
+    return p;
+  }
+  __device__ __forceinline__ void apply(int m, int n, f32x4 v, const Pre& p) const {
     if (m >= Nb || n >= H) return;
     const long long r2 = (long long)m * 2 * H, r8 = (long long)m * 8 * H;
-    const f32x4 up = load4(dout + r2 + n);
+    f32x4 dc_out;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = n + jj;
-      const f32x4 g4 = load4(gates + r8 + 4 * j);
-      const float ig = g4[0], fg = g4[1], gg = g4[2], og = g4[3];
-      const float dh = v[jj] + up[jj];
-      const float tc = tanhf_(c_t[r2 + j]);
-      float dcv = dh * og * (1.f - tc * tc);
-      if (!first) dcv += dc[r2 + j];
-      const float cp = c_prev ? c_prev[r2 + j] : 0.f;
+      const float ig = p.g[jj][0], fg = p.g[jj][1], gg = p.g[jj][2], og = p.g[jj][3];
+      const float dh = v[jj] + p.up[jj];
+      const float tc = tanhf_(p.ct[jj]);
+      const float dcv = dh * og * (1.f - tc * tc) + p.dcv[jj];
       f32x4 d;
       d[0] = dcv * gg * ig * (1.f - ig);
-      d[1] = dcv * cp * fg * (1.f - fg);
+      d[1] = dcv * p.cp[jj] * fg * (1.f - fg);
       d[2] = dcv * ig * (1.f - gg * gg);
       d[3] = dh * tc * og * (1.f - og);
-      dc[r2 + j] = dcv * fg;
+      dc_out[jj] = dcv * fg;
       store4(dgates + r8 + 4 * j, d);
     }
+    *(f32x4*)(dc + r2 + n) = dc_out;
   }
 };
 
