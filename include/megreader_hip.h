@@ -134,6 +134,8 @@ typedef struct mr_prep_job {
   int block_start, reserved;
 } mr_prep_job;
 int mr_prep_batch(int dtype, const mr_prep_job* jobs_device, int njobs, long long total_blocks, hipStream_t stream);
+/* sizeof(mr_prep_job) as compiled into the library (host only): bindings verify their struct mirror against it */
+int mr_sizeof_prep_job(void);
 
 /* dst[i][0..n[i]) += src[i][0..n[i]) for count <= MR_MAX_SEGMENTS f32 segments in one launch (the pointer / length
  * arrays are HOST arrays, copied into the kernel arguments).  Used to fold several small gradient pieces into the

@@ -107,6 +107,8 @@ def load():
     lib.mr_force_nt_tile.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mr_nt_tile_code.restype = ctypes.c_int
     lib.mr_nt_tile_code.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.mr_sizeof_prep_job.restype = ctypes.c_int
+    lib.mr_sizeof_prep_job.argtypes = []
     lib.mr_nt_kernel_code.restype = ctypes.c_int
     lib.mr_nt_kernel_code.argtypes = [ctypes.c_int] * 5
     lib.mr_set_tn_buf.restype = ctypes.c_int
@@ -132,7 +134,7 @@ def load():
 
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_set_nt_variant", "mr_force_nt_tile",
              "mr_stem_bwd_workspace", "mr_set_lstm_variant", "mr_set_nt_big",
-             "mr_nt_kernel_code", "mr_set_tn_big", "mr_set_tn_buf")  # entry points that take no stream and launch nothing
+             "mr_nt_kernel_code", "mr_set_tn_big", "mr_set_tn_buf", "mr_sizeof_prep_job")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

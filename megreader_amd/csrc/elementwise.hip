@@ -523,6 +523,9 @@ int mr_prep_bias(const float* a, const float* b, float* dst, int R, int perm_h, 
   return MR_OK;
 }
 
+// sizeof(mr_prep_job) as compiled into the library (host-side bindings check their struct mirror against it)
+int mr_sizeof_prep_job(void) { return (int)sizeof(mr_prep_job); }
+
 int mr_prep_batch(int dtype, const mr_prep_job* jobs_device, int njobs, long long total_blocks, hipStream_t stream) {
   if (njobs <= 0) return MR_OK;
   MR_CHECK_ARG(jobs_device != nullptr && njobs <= 1024, "mr_prep_batch: bad job table (at most 1024 jobs)");

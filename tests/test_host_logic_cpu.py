@@ -1,0 +1,98 @@
+"""Host-side logic of the training path that needs no GPU: the struct mirror of the batched-prep job table, the grid
+arithmetic shared between prep.py and the kernel, the pre-zeroed BatchNorm scratch arena, gradient-sink activation
+rules, the wgrad row-table cache and the PMC post-processing used for bench.py's roofline.traffic."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_prep_job_struct_mirror_matches_the_library():
+    from megreader_amd import _lib
+    from megreader_amd.nn import prep
+    lib = _lib.load()
+    assert ctypes.sizeof(prep.PrepJob) == lib.mr_sizeof_prep_job()
+    # every key a job description carries is a struct field (or the host-only element count)
+    for job in (prep.conv_job(1, (27, 1, 9, 3), 2, 3, 64, 3, 3, 3, 8, 64),
+                prep.matrix_job(1, 512, 2, 512, 3, 1024, 1024, 512, 256),
+                prep.bias_job(1, 2, 3, 1024, 256), prep.stem_job(1, (27, 1, 9, 3), 2, 3)):
+        fields = {n for n, _ in prep.PrepJob._fields_}
+        assert set(job) - fields == {"total"}
+
+
+def test_prep_job_block_counts():
+    from megreader_amd.nn import prep
+    # conv: ceil(K/64) * ceil(R*S*Cpad/64); matrix: ceil(R/64)*ceil(C/64); bias: ceil(R/4096); stem: 1
+    assert prep.job_blocks(prep.conv_job(0, (1, 1, 1, 1), 0, 0, 512, 512, 3, 3, 512, 512)) == 8 * 72
+    assert prep.job_blocks(prep.conv_job(0, (1, 1, 1, 1), 0, 0, 20, 16, 3, 2, 16, 24)) == 1 * 2
+    assert prep.job_blocks(prep.matrix_job(0, 512, 0, 512, 0, 2048, 1024, 512, 256)) == 16 * 8
+    assert prep.job_blocks(prep.matrix_job(0, 512, 0, 512, 0, 40, 38, 512, 0)) == 1 * 8
+    assert prep.job_blocks(prep.bias_job(0, 0, 0, 1024, 256)) == 1
+    assert prep.job_blocks(prep.bias_job(0, 0, 0, 5000, 0)) == 2
+    assert prep.job_blocks(prep.stem_job(0, (1, 1, 1, 1), 0, 3)) == 1
+
+
+def test_zero_arena_hands_out_each_slice_once_per_reset():
+    from megreader_amd.nn.functional import ZeroArena
+    dev = torch.device("cpu")
+    ZeroArena.arenas.pop(dev, None)
+    a = ZeroArena.take(dev, 100)
+    b = ZeroArena.take(dev, 7)
+    assert a.numel() == 128 and b.numel() == 32 and a.data_ptr() != b.data_ptr()   # 32-double granularity
+    assert float(a.abs().sum()) == 0.0 and float(b.abs().sum()) == 0.0
+    a.fill_(3.0)
+    b.fill_(5.0)
+    ZeroArena.reset(dev)
+    a2 = ZeroArena.take(dev, 100)
+    assert a2.data_ptr() == a.data_ptr() and float(a2.abs().sum()) == 0.0           # rewound and re-zeroed
+    # exhaustion -> None (callers fall back to their own memset), never a dirty slice
+    assert ZeroArena.take(dev, ZeroArena.SIZE) is None
+    ZeroArena.arenas.pop(dev, None)
+
+
+def test_grad_sink_is_only_active_while_it_is_the_param_grad():
+    from megreader_amd.nn.functional import grad_sink
+    p = torch.nn.Parameter(torch.zeros(4, 3))
+    assert grad_sink(p, (4, 3)) is None                       # no sink attached
+    sink = torch.zeros(4, 3)
+    p._mr_grad_sink = sink
+    assert grad_sink(p, (4, 3)) is None                       # CPU tensors never qualify (and .grad is None)
+    p.grad = torch.zeros(4, 3)
+    assert grad_sink(p, (4, 3)) is None                       # .grad is a different tensor -> autograd path
+
+
+def test_wgrad_rowtab_cache_builds_once_per_geometry():
+    from megreader_amd.nn import functional as F
+    F._ROWTABS.clear()
+    dev = torch.device("cpu")
+    g1 = (4, 8, 32, 256, 3, 3, 1, 1, 1, 1, 1, 1, 8, 32)
+    t1, build1 = F._wgrad_rowtab(dev, g1)
+    t2, build2 = F._wgrad_rowtab(dev, g1)
+    t3, build3 = F._wgrad_rowtab(dev, (2,) + g1[1:])
+    assert build1 == 1 and build2 == 0 and build3 == 1
+    assert t1 is t2 and t1.shape == (4 * 8 * 32, 2) and t1.dtype == torch.int32 and t3.shape[0] == 2 * 8 * 32
+    F._ROWTABS.clear()
+
+
+def test_pmc_post_processing(tmp_path):
+    fetch = tmp_path / "f.txt"
+    write = tmp_path / "w.txt"
+    fetch.write_text("_ZN2mr20igemm_nt_glds_kernelIDF16bLi96ELi128ELi2ENS_8EpiStoreIDF16bEEE\n"
+                     "   FETCH_SIZE                   n= 30 mean=4.8e+04\n"
+                     "void mr::igemm_tn_glds_kernel<2, true>\n   FETCH_SIZE                   n= 30 mean=4.2e+04\n"
+                     "_ZN2mr18maxpool_fwd_kernelIDF16bEEvPKT_\n   FETCH_SIZE                   n=  3 mean=1e+04\n")
+    write.write_text("_ZN2mr20igemm_nt_glds_kernelIDF16bLi96ELi128ELi2ENS_8EpiStoreIDF16bEEE\n"
+                     "   WRITE_SIZE                   n= 30 mean=2.4e+04\n"
+                     "void mr::igemm_tn_glds_kernel<2, true>\n   WRITE_SIZE                   n= 30 mean=3.8e+04\n")
+    out = tmp_path / "t.json"
+    subprocess.check_call([sys.executable, os.path.join(REPO, "tools", "pmc_to_json.py"), str(fetch), str(write),
+                           str(out)], stdout=subprocess.DEVNULL)
+    d = json.load(open(out))
+    assert set(d) == {"igemm_nt_kernel<bf16,96,128,conv>", "igemm_tn_kernel<bf16,conv>"}
+    nt = d["igemm_nt_kernel<bf16,96,128,conv>"]
+    assert nt["bytes_per_launch"] == 2 * 4.8e4 * 1024 + 2.4e4 * 1024 and nt["launches"] == 30   # FETCH_SIZE doubled
