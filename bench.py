@@ -138,7 +138,7 @@ def main():
     from megreader_amd.backbones import crnn_backbone
     from megreader_amd.decoders import CRNNDecoder
     from megreader_amd.optim import FusedAdam
-    from oracle.crnn import synthetic_batch  # input generator only (BASELINE.md §3 value distributions)
+    from megreader_amd.synthetic import recognition_batch as synthetic_batch  # BASELINE.md §3 value distributions
 
     lib = _lib.load()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -156,7 +156,7 @@ def main():
     if args.workload == "res50ppm":
         from megreader_amd.backbones import resnet50dilated_ppm
         from megreader_amd.decoders import CTCDecoder2D
-        from oracle.res50ppm import synthetic_batch_2d
+        from megreader_amd.synthetic import recognition_batch_2d as synthetic_batch_2d
 
         class BasicModel(torch.nn.Module):  # noqa: F811  res50-ppm-2d-ctc.yaml: resnet50dilated_ppm + CTCDecoder2D
             def __init__(self):

@@ -191,10 +191,18 @@ int mr_stem_bwd(int dtype, const void* dy, const unsigned char* code, const floa
                 int W, hipStream_t stream);
 
 /* ---- bidirectional LSTM recurrence (replaces cuDNN RNN behind nn.LSTM: decoders/crnn.py:13,21,91-93) ----- */
+/* ws / ws_bytes: exchange workspace of the persistent one-launch recurrence (size from mr_lstm_ws_bytes; zeroed by
+ * the call with a memset on `stream`; its last 256 bytes hold a status word: 0 = ok, 1 / 2 = a bounded spin of the
+ * forward / backward kernel timed out).  Null / 0 selects one launch per time step.  dc is only used by the
+ * per-step path (f32 [N, 2H] scratch). */
 int mr_lstm_fwd(int dtype, const void* xproj, const void* whh, void* out, float* cbuf, void* gates, int T, int N,
-                int H, hipStream_t stream);
+                int H, void* ws, long long ws_bytes, hipStream_t stream);
 int mr_lstm_bwd(int dtype, const void* dout, const void* whhT, const float* cbuf, void* gates, float* dc, int T,
-                int N, int H, hipStream_t stream);
+                int N, int H, void* ws, long long ws_bytes, hipStream_t stream);
+/* host only: workspace bytes the persistent recurrence wants (0 = not applicable: f32, H != 256, ...), and its
+ * on/off switch (default on) */
+long long mr_lstm_ws_bytes(int dtype, int T, int N, int H);
+int mr_set_lstm_persist(int on);
 /* tuning knob (host only): column-tile width of the step kernels; 0 = LDS-staged split-K body, else the
  * direct-fragment body.  fwd_bn in {0,32,64}, bwd_bn in {0,16,32,64}; negative leaves the setting unchanged. */
 int mr_set_lstm_variant(int fwd_bn, int bwd_bn);

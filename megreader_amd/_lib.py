@@ -49,8 +49,8 @@ SIGNATURES = {
     "mr_stem_bwd": "ipppppllllpiiiis",
     "mr_maxpool_fwd": "ippp" + "i" * 12 + "s",
     "mr_maxpool_bwd": "ipppp" + "i" * 12 + "s",
-    "mr_lstm_fwd": "ipppppiiis",
-    "mr_lstm_bwd": "ipppppiiis",
+    "mr_lstm_fwd": "ipppppiiipls",
+    "mr_lstm_bwd": "ipppppiiipls",
     "mr_ctc_fwd": "ipipippiiiiiiippppps",
     "mr_ctc_bwd": "ipppppippipiiiiiipis",
     "mr_softmax_nc1t": "ipipiiis",
@@ -119,6 +119,10 @@ def load():
     lib.mr_set_nt_big.argtypes = [ctypes.c_int]
     lib.mr_set_lstm_variant.restype = ctypes.c_int
     lib.mr_set_lstm_variant.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.mr_set_lstm_persist.restype = ctypes.c_int
+    lib.mr_set_lstm_persist.argtypes = [ctypes.c_int]
+    lib.mr_lstm_ws_bytes.restype = ctypes.c_longlong
+    lib.mr_lstm_ws_bytes.argtypes = [ctypes.c_int] * 4
     lib.mr_stem_bwd_workspace.restype = ctypes.c_longlong
     lib.mr_stem_bwd_workspace.argtypes = [ctypes.c_int]
     for name, codes in SIGNATURES.items():
@@ -133,7 +137,7 @@ def load():
 
 
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_set_nt_variant", "mr_force_nt_tile",
-             "mr_stem_bwd_workspace", "mr_set_lstm_variant", "mr_set_nt_big",
+             "mr_stem_bwd_workspace", "mr_set_lstm_variant", "mr_set_nt_big", "mr_set_lstm_persist", "mr_lstm_ws_bytes",
              "mr_nt_kernel_code", "mr_set_tn_big", "mr_set_tn_buf", "mr_sizeof_prep_job")  # entry points that take no stream and launch nothing
 
 

@@ -17,6 +17,9 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+_PAD = 64  # megreader_amd.optim._ALIGN: parameter slices of the flat buffers start on 64-element boundaries
+
+
 def _engine_callback(fn):
     torch.autograd.Variable._execution_engine.queue_callback(fn)
 
@@ -54,8 +57,11 @@ class DistributedDataParallel(nn.Module):
         for bi, bucket in enumerate(self._buckets):
             for p in bucket:
                 self._bucket_of[p] = bi
-        self._ready = [0] * len(self._buckets)
+        self._ready = [set() for _ in self._buckets]
         self._launched = [False] * len(self._buckets)
+        # parameters known to receive more than one gradient contribution per backward (weight sharing): their bucket
+        # is only launched from the end-of-backward callback.  Filled by `mark_shared(param)`.
+        self._uses = {}
         self._pending = []  # (bucket index, flat tensor, staged?, work handle)
         self._callback_queued = False
         for p in self._params:
@@ -67,6 +73,11 @@ class DistributedDataParallel(nn.Module):
                 p._mr_grad_ready_hooks = []
             p._mr_grad_ready_hooks.append(hook)
 
+    def mark_shared(self, param, uses=2):
+        """Declare that `param` is used `uses` times per forward (its gradient is complete only after that many
+        accumulations): its bucket is then reduced from the end-of-backward callback instead of the first hook."""
+        self._uses[id(param)] = uses
+
     # ------------------------------------------------------------------ hooks
     def _make_hook(self):
         def hook(param):
@@ -76,8 +87,10 @@ class DistributedDataParallel(nn.Module):
             if self.delay_allreduce:
                 return
             bi = self._bucket_of[param]
-            self._ready[bi] += 1
-            if self._ready[bi] == len(self._buckets[bi]) and not self._launched[bi]:
+            # readiness is tracked per parameter: a module used twice in one forward fires its sink hook twice
+            self._ready[bi].add(id(param))
+            if len(self._ready[bi]) == len(self._buckets[bi]) and not self._launched[bi] and \
+                    self._uses.get(id(param), 1) <= 1:
                 self._launch(bi)
         return hook
 
@@ -95,9 +108,17 @@ class DistributedDataParallel(nn.Module):
         except Exception:
             return None
         span = (hi - lo) // base.element_size()
-        if span > 2 * sum(g.numel() for g in order):
-            return None  # too sparse: padding would dominate
-        # gaps are alignment padding inside the flat optimizer buffer (always zero) -- safe to reduce along
+        # the bucket's gradients must TILE the span: consecutive slices separated only by the flat optimizer buffer's
+        # alignment padding (< _PAD elements, always zero).  A larger gap means somebody else's gradient lives inside
+        # the span (reordered param groups, a frozen parameter, another bucket): reducing the span in place would
+        # all-reduce and scale that gradient twice -> staged path instead.
+        es = base.element_size()
+        end = lo
+        for g in order:
+            gap = (g.data_ptr() - end) // es
+            if gap < 0 or gap >= _PAD:
+                return None
+            end = g.data_ptr() + g.numel() * es
         off = (lo - storage_lo) // base.element_size()
         return torch.empty(0, dtype=base.dtype, device=base.device).set_(base.untyped_storage(), off, (span,), (1,))
 
@@ -128,7 +149,7 @@ class DistributedDataParallel(nn.Module):
             work.wait()  # RCCL: the current (main) stream waits for the collective; host does not block
             self._finish_bucket(bucket, flat, staged, scale)
         self._pending = []
-        self._ready = [0] * len(self._buckets)
+        self._ready = [set() for _ in self._buckets]
         self._launched = [False] * len(self._buckets)
         self._callback_queued = False
 

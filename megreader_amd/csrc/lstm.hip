@@ -211,6 +211,15 @@ static int lstm_bwd_impl(const void* dout_, const void* whhT_, const float* cbuf
   return MR_OK;
 }
 
+// lstm_persist.hip
+bool lstm_persist_ok(int dtype, int T, int N, int H);
+long long lstm_persist_ws(int dtype, int T, int N, int H);
+int lstm_fwd_persist(const void* xproj, const void* whh, void* out, float* cbuf, void* gates, int T, int N, void* ws,
+                     long long ws_bytes, hipStream_t stream);
+int lstm_bwd_persist(const void* dout, const void* whhT, const float* cbuf, void* gates, int T, int N, void* ws,
+                     long long ws_bytes, hipStream_t stream);
+static int g_lstm_persist = 1;
+
 }  // namespace mr
 
 using namespace mr;
@@ -228,11 +237,27 @@ int mr_set_lstm_variant(int fwd_bn, int bwd_bn) {
   return MR_OK;
 }
 
+// Host-only switch: 1 (default) = persistent one-launch recurrence where applicable, 0 = per-step launches.
+int mr_set_lstm_persist(int on) {
+  g_lstm_persist = on != 0;
+  return MR_OK;
+}
+
+// Bytes of exchange workspace the persistent recurrence wants for this problem; 0 = it does not apply (f32 parity
+// mode, H != 256, batch too large for co-residency) and mr_lstm_fwd/bwd run one launch per step.
+long long mr_lstm_ws_bytes(int dtype, int T, int N, int H) {
+  return g_lstm_persist ? lstm_persist_ws(dtype, T, N, H) : 0;
+}
+
 // Recurrent part of the forward pass (input projection done by mr_gemm_nt beforehand).
+// ws / ws_bytes: exchange workspace of the persistent kernel (mr_lstm_ws_bytes; zeroed by the call itself) or
+// null / 0 for the per-step launches.
 int mr_lstm_fwd(int dtype, const void* xproj, const void* whh, void* out, float* cbuf, void* gates, int T, int N,
-                int H, hipStream_t stream) {
+                int H, void* ws, long long ws_bytes, hipStream_t stream) {
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(T > 0 && N > 0 && H > 0 && H % vec == 0, "mr_lstm_fwd: bad shape T=%d N=%d H=%d", T, N, H);
+  if (ws && ws_bytes > 0 && g_lstm_persist && lstm_persist_ok(dtype, T, N, H))
+    return lstm_fwd_persist(xproj, whh, out, cbuf, gates, T, N, ws, ws_bytes, stream);
   if (dtype == MR_F32) return lstm_fwd_impl<float>(xproj, whh, out, cbuf, gates, T, N, H, stream);
   if (dtype == MR_BF16) return lstm_fwd_impl<bf16_t>(xproj, whh, out, cbuf, gates, T, N, H, stream);
   mr::set_error("mr_lstm_fwd: bad dtype %d", dtype);
@@ -242,9 +267,11 @@ int mr_lstm_fwd(int dtype, const void* xproj, const void* whh, void* out, float*
 // Backward through time.  On return `gates` holds the pre-activation gradients (gate-interleaved) that feed
 // the weight / input gradient GEMMs.  dc: scratch f32 [N, 2H].
 int mr_lstm_bwd(int dtype, const void* dout, const void* whhT, const float* cbuf, void* gates, float* dc, int T,
-                int N, int H, hipStream_t stream) {
+                int N, int H, void* ws, long long ws_bytes, hipStream_t stream) {
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(T > 0 && N > 0 && H > 0 && H % vec == 0 && H % 4 == 0, "mr_lstm_bwd: bad shape T=%d N=%d H=%d", T, N, H);
+  if (ws && ws_bytes > 0 && g_lstm_persist && lstm_persist_ok(dtype, T, N, H))
+    return lstm_bwd_persist(dout, whhT, cbuf, gates, T, N, ws, ws_bytes, stream);
   if (dtype == MR_F32) return lstm_bwd_impl<float>(dout, whhT, cbuf, gates, dc, T, N, H, stream);
   if (dtype == MR_BF16) return lstm_bwd_impl<bf16_t>(dout, whhT, cbuf, gates, dc, T, N, H, stream);
   mr::set_error("mr_lstm_bwd: bad dtype %d", dtype);

@@ -633,6 +633,22 @@ def linear(x, weight, bias=None):
 # --------------------------------------------------------------------------------------------------
 # Bidirectional LSTM.  reference: nn.LSTM(nIn, nHidden, bidirectional=True) at decoders/crnn.py:13
 # --------------------------------------------------------------------------------------------------
+LSTM_STATUS = None   # tests set this to a list: status words of the persistent-recurrence workspaces handed out
+
+
+def _lstm_workspace(dt, T, N, H, dev):
+    """Exchange buffer of the persistent (one launch per layer and pass) recurrence, or None when the library runs one
+    launch per step for this problem (mr_lstm_ws_bytes == 0).  Allocated per call from torch's caching allocator --
+    inside a hipGraph capture it belongs to the graph's pool; the C call zeroes it (memset node) before the kernel."""
+    nbytes = load().mr_lstm_ws_bytes(dt, T, N, H)
+    if nbytes <= 0:
+        return None
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    if LSTM_STATUS is not None:
+        LSTM_STATUS.append(ws[nbytes - 256:nbytes - 252])
+    return ws
+
+
 class BiLSTMFn(Function):
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
@@ -675,7 +691,9 @@ class BiLSTMFn(Function):
         out = torch.empty((T, N, 2 * H), dtype=dtype, device=dev)
         cbuf = torch.empty((T, N, 2 * H), dtype=torch.float32, device=dev)
         gates = torch.empty((T, N, 8 * H), dtype=dtype, device=dev)
-        call("mr_lstm_fwd", dt, ptr(xproj), ptr(whh), ptr(out), ptr(cbuf), ptr(gates), T, N, H)
+        ws = _lstm_workspace(dt, T, N, H, dev)
+        call("mr_lstm_fwd", dt, ptr(xproj), ptr(whh), ptr(out), ptr(cbuf), ptr(gates), T, N, H, ptr(ws),
+             0 if ws is None else ws.numel())
         ctx.save_for_backward(x, wcat_t, whh_t, out, cbuf, gates)
         ctx.params = sources
         ctx.dims = (T, N, I, H)
@@ -692,9 +710,11 @@ class BiLSTMFn(Function):
         dev = gout.device
         if gout.dtype != dtype or not gout.is_contiguous():
             gout = gout.to(dtype).contiguous()
-        dc = torch.empty((N, 2 * H), dtype=torch.float32, device=dev)
+        ws = _lstm_workspace(dt, T, N, H, dev)
+        dc = torch.empty((N, 2 * H), dtype=torch.float32, device=dev) if ws is None else None
         # NOTE: `gates` is rewritten in place with the pre-activation gradients (single backward pass only)
-        call("mr_lstm_bwd", dt, ptr(gout), ptr(whh_t), ptr(cbuf), ptr(gates), ptr(dc), T, N, H)
+        call("mr_lstm_bwd", dt, ptr(gout), ptr(whh_t), ptr(cbuf), ptr(gates), ptr(dc), T, N, H, ptr(ws),
+             0 if ws is None else ws.numel())
         dgates = gates
         sinks = [grad_sink(p, tuple(p.shape)) for p in ctx.params]
         use_sinks = all(s is not None for s in sinks)

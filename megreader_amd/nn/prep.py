@@ -86,7 +86,7 @@ def run_job(dt, j):
 
 
 class _Entry(object):
-    __slots__ = ("params", "stamp", "buffers", "jobs", "dtype")
+    __slots__ = ("params", "stamp", "buffers", "jobs", "dtype", "home")
 
     def __init__(self, params, buffers, jobs, dtype):
         self.params = params
@@ -94,6 +94,11 @@ class _Entry(object):
         self.jobs = jobs
         self.dtype = dtype
         self.stamp = _stamp(params)
+        # the jobs hold RAW source pointers: the entry can only be refreshed while the parameters still live there
+        self.home = tuple(p.data_ptr() for p in params if p is not None)
+
+    def at_home(self):
+        return self.home == tuple(p.data_ptr() for p in self.params if p is not None)
 
 
 def _stamp(params):
@@ -156,6 +161,8 @@ def refresh(params, holder):
     for p in params:
         cache = p.__dict__.get("_mr_prep")
         if cache:
+            for k in [k for k, e in cache.items() if not e.at_home()]:
+                del cache[k]    # a source parameter was re-pointed (p.data = ...): rebuilt by the next forward
             entries.extend(cache.values())
     if not entries:
         holder.pop('prep_plan', None)

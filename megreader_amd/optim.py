@@ -59,6 +59,9 @@ class _FlatOptimizer(torch.optim.Optimizer):
                                's1': torch.zeros(total, dtype=torch.float32, device=dev),
                                's2': torch.zeros(total, dtype=torch.float32, device=dev),
                                'hyper': torch.zeros(8, dtype=torch.float32, device=dev), 'hyper_host': None})
+            # operand images prepared by an earlier forward (before the parameters moved into the flat buffer) hold
+            # jobs that read the OLD storage: drop them, the next forward rebuilds them from the new home
+            prep.invalidate(params)
 
     def flat_grads(self):
         """List of flat gradient buffers (one per param group); used by the DDP shim for zero-copy buckets."""
@@ -67,22 +70,19 @@ class _FlatOptimizer(torch.optim.Optimizer):
         return [f['g'] for f in self._flat if f is not None]
 
     def zero_grad(self, set_to_none=False):
-        """One memset per group.  Gradients stay attached (views of the flat buffer) unless set_to_none=True."""
-        if set_to_none:
-            if self._flat is not None:
-                for f in self._flat:
-                    if f is not None:
-                        for p in f['params']:
-                            if hasattr(p, "_mr_grad_sink"):
-                                del p._mr_grad_sink
-            self._flat = None
-            return super().zero_grad(set_to_none=True)
+        """One memset per group.  Gradients stay attached (views of the flat buffer) unless set_to_none=True, which
+        detaches `.grad` (torch semantics: the next backward goes through autograd's accumulation, and `step()`
+        folds the result back into the flat buffer).  The flat buffers, the optimizer state (moments, momentum, the
+        device step counter) and the parameters' home are NEVER dropped once created."""
         if self._flat is None:
             self._materialize()
         for f in self._flat:
             if f is not None:
                 f['g'].zero_()
                 ZeroArena.reset(f['g'].device)  # pre-zeroed reduction scratch of the BatchNorm layers
+                if set_to_none:
+                    for p in f['params']:
+                        p.grad = None     # grad_sink() is inactive while .grad is None; _sync_views re-attaches
 
     def _sync_views(self, f):
         for p, off in zip(f['params'], f['offs']):
@@ -105,6 +105,22 @@ class _FlatOptimizer(torch.optim.Optimizer):
     def _launch(self, f):
         raise NotImplementedError
 
+    def _push_hyper(self, group, f):
+        vals = self._hyper_values(group)
+        if vals != f['hyper_host']:
+            f['hyper'][:5].copy_(torch.tensor(vals, dtype=torch.float32), non_blocking=False)
+            f['hyper_host'] = vals
+
+    def push_hyper(self):
+        """Copy changed hyper-parameters (lr schedule: trainer.py:43-47,81 `update_learning_rate`) to their device
+        slots.  `step()` does this itself; a captured hipGraph replay (megreader_amd.runtime.GraphedTrainStep) never
+        re-runs the Python `step()`, so it calls this before every replay."""
+        if self._flat is None:
+            return
+        for group, f in zip(self.param_groups, self._flat):
+            if f is not None:
+                self._push_hyper(group, f)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -117,10 +133,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
             if f is None:
                 continue
             self._sync_views(f)
-            vals = self._hyper_values(group)
-            if vals != f['hyper_host']:
-                f['hyper'][:5].copy_(torch.tensor(vals, dtype=torch.float32), non_blocking=False)
-                f['hyper_host'] = vals
+            self._push_hyper(group, f)
             self._launch(f)
             # the update went through raw pointers (no autograd version bump): regenerate the compute-dtype
             # operand images of these parameters in one launch

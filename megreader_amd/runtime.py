@@ -96,6 +96,9 @@ class GraphedTrainStep(object):
             dst.copy_(src, non_blocking=True)
 
     def __call__(self):
+        # the captured update kernel reads lr / betas / weight decay from device slots: push schedule changes made
+        # on the host since the last step (the Python optimizer.step() that normally does it is not re-run)
+        self.optimizer.push_hyper()
         self.graph.replay()
         if self.graph_update is not None:
             self.grad_sync()

@@ -96,3 +96,15 @@ def test_pmc_post_processing(tmp_path):
     assert set(d) == {"igemm_nt_kernel<bf16,96,128,conv>", "igemm_tn_kernel<bf16,conv>"}
     nt = d["igemm_nt_kernel<bf16,96,128,conv>"]
     assert nt["bytes_per_launch"] == 2 * 4.8e4 * 1024 + 2.4e4 * 1024 and nt["launches"] == 30   # FETCH_SIZE doubled
+
+
+def test_synthetic_batches_match_the_oracle_generators():
+    """bench.py's product leg imports nothing from oracle/: its generator must equal the oracle's (the one the
+    golden fixtures were made with)."""
+    from megreader_amd.synthetic import recognition_batch, recognition_batch_2d
+    from oracle.crnn import synthetic_batch
+    from oracle.res50ppm import synthetic_batch_2d
+    a, b = recognition_batch(5, 32, 128, seed=3), synthetic_batch(5, 32, 128, seed=3)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    a, b = recognition_batch_2d(5, 32, 128, seed=4, max_len=3), synthetic_batch_2d(5, 32, 128, seed=4, max_len=3)
+    assert all(torch.equal(a[k], b[k]) for k in a)

@@ -229,6 +229,66 @@ def test_bilstm(dtype, T, N, I, H):
         assert _rel_err(p.grad, getattr(ref, n_).grad) < (2e-4 if dtype == torch.float32 else 4e-2), n_
 
 
+@pytest.mark.parametrize("T,N,I", [(33, 256, 512), (33, 256, 256), (7, 40, 64), (2, 16, 64), (1, 5, 64)])
+def test_bilstm_persistent_recurrence(T, N, I):
+    """The one-launch persistent recurrence (csrc/lstm_persist.hip: W_hh slices in registers, h all-gathered /
+    dh reduce-scattered between workgroups through tagged granules) against (a) the per-step launches it replaces,
+    same bf16 operands and f32 accumulation, every output and every gradient element-wise, and (b) a float64 torch
+    LSTM.  Shapes: the CRNN layers at the benchmarked batch (both input widths), a ragged batch (40 = 2.5 groups of
+    16 rows), and the T=2 / T=1 edge cases (one / no exchange)."""
+    from megreader_amd._lib import load
+    from megreader_amd.nn import functional as Fn
+    H = 256
+    dtype = torch.bfloat16
+    mr.set_compute_dtype(dtype)
+    lib = load()
+    assert lib.mr_lstm_ws_bytes(1, T, N, H) > 0, "persistent path must apply at H=256 in bf16"
+    assert lib.mr_lstm_ws_bytes(0, T, N, H) == 0, "f32 parity mode runs the per-step kernels"
+    torch.manual_seed(3)
+    ref = torch.nn.LSTM(I, H, bidirectional=True).double()
+    with torch.no_grad():
+        for n_, p in ref.named_parameters():
+            if n_.startswith("weight"):
+                p.copy_(p.float().to(dtype).double())
+    names = ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse",
+             "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse")
+    x = torch.randn(T, N, I).to(dtype)
+    gy = torch.randn(T, N, 2 * H).to(dtype)
+
+    def run(persist):
+        lib.mr_set_lstm_persist(persist)
+        params = [getattr(ref, n_).detach().float().to(DEV).requires_grad_(True) for n_ in names]
+        xd = x.to(DEV).requires_grad_(True)
+        y = F.bilstm(xd, *params)
+        y.backward(gy.to(DEV))
+        torch.cuda.synchronize()
+        return [y.detach().float().cpu(), xd.grad.float().cpu()] + [p.grad.float().cpu() for p in params]
+
+    Fn.LSTM_STATUS = []
+    try:
+        got = run(1)
+        assert len(Fn.LSTM_STATUS) == 2, "forward and backward must both have taken the persistent path"
+        assert all(int(s_.view(torch.int32).item()) == 0 for s_ in Fn.LSTM_STATUS), "a bounded spin timed out"
+    finally:
+        Fn.LSTM_STATUS = None
+    try:
+        want = run(0)
+    finally:
+        lib.mr_set_lstm_persist(1)
+    labels = ["y", "dx"] + list(names)
+    for lab, a, b in zip(labels, got, want):
+        # same operands, same accumulation precision; the v_exp/v_rcp gate functions and the summation order of the
+        # recurrent GEMM differ in the last f32 bits, which bf16 rounding of h occasionally turns into one bf16 ulp
+        assert _rel_err(a, b) < 6e-3, (lab, _rel_err(a, b))
+    xr = x.double().requires_grad_(True)
+    yr, _ = ref(xr)
+    yr.backward(gy.double())
+    assert _rel_err(got[0], yr) < 2e-2
+    assert _rel_err(got[1], xr.grad) < 4e-2
+    for n_, a in zip(names, got[2:]):
+        assert _rel_err(a, getattr(ref, n_).grad) < 4e-2, n_
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_ctc_matches_torch_and_oracle(dtype):
     from oracle.ctc import ctc_1d

@@ -28,10 +28,12 @@ def main():
     mr.set_compute_dtype(dtype)
     T, N, H = 33, 256, 256
     variants = [(0, 0), (0, 16), (0, 32), (0, 64), (32, 32), (64, 32)] if "--sweep" in sys.argv else [(-1, -1)]
+    persist = 0 if "--no-persist" in sys.argv else 1
+    load().mr_set_lstm_persist(persist)
     for fv, bv in variants:
       load().mr_set_lstm_variant(fv, bv)
-      print("variant fwd_bn=%d bwd_bn=%d" % (fv, bv))
-      for I in (512,):
+      print("variant fwd_bn=%d bwd_bn=%d persistent=%d" % (fv, bv, persist))
+      for I in (512, 256):
         torch.manual_seed(0)
         ref = torch.nn.LSTM(I, H, bidirectional=True)
         params = [p.detach().cuda().requires_grad_(True) for p in ref.parameters()]
