@@ -288,6 +288,40 @@ int mr_nll_step_bwd(int dtype, const float* gloss, const float* lp, const long l
 /* eval head: softmax over classes of logits [T,N,C] -> f32 [N,C,1,T] (decoders/crnn.py:101-104) */
 int mr_softmax_nc1t(int dtype, const void* logits, int ldl, float* out, int T, int N, int C, hipStream_t stream);
 
+/* ---- evaluation decode + metrics on the GPU ------------------------------------------------
+ * mr_ctc_greedy_decode: structure/representers/ctc_representer.py:20-34.  pred[n,c,t] at pred + n*sn + c*sc + t*st
+ *   (element strides; dtype 0 = f32, 1 = bf16, 2 = f64).  argmax over c (first index on ties); a symbol is skipped if
+ *   it equals `previous` or is `unknown` (an unknown does not update `previous`); emitted if != blank.
+ *   out: i32 [N, T] blank padded; out_len (nullable): i32 [N] number of emitted symbols.
+ * mr_ctc2d_greedy_decode: structure/representers/ctc_representer2d.py:27-51.  classify[n,c,h,w], mask[n,0,h,w] f32
+ *   with element strides; per column h* = argmax_h max_c(classify*mask), c* = argmax_c at h*; same collapse.
+ * mr_seq_measure: structure/measurers/sequence_recognition_measurer.py:66-72,101-112 on id sequences (blank / unknown
+ *   dropped as concern/charsets.py:60-62 does; fold: nullable id -> canonical id table for `.upper()`):
+ *   acc[n] = sequences equal; ed[n] = Levenshtein distance (-1 if a sequence exceeds 63 symbols);
+ *   score[n] (f64) = 0 if len(label) == 0 else 1 - min(len, ed) / len. */
+int mr_ctc_greedy_decode(int dtype, const void* pred, long long sn, long long sc, long long st, int N, int C, int T,
+                         int blank, int unknown, int* out, int* out_len, hipStream_t stream);
+int mr_ctc2d_greedy_decode(const float* classify, long long cn, long long cc, long long ch, long long cw,
+                           const float* mask, long long mn, long long mh, long long mw, int N, int C, int H, int W,
+                           int blank, int unknown, int* out, int* out_len, hipStream_t stream);
+int mr_seq_measure(const int* labels, int S, const int* preds, int S2, int N, int blank, int unknown, const int* fold,
+                   int* acc, int* ed, int* label_len, double* score, hipStream_t stream);
+
+/* ---- input pipeline on the GPU ----------------------------------------------------------------
+ * mr_resize_normalize: data/processes/resize_image.py:29-38,48-53 (cv2.resize of the float32 image, INTER_LINEAR;
+ *   modes "resize" and "pad") fused with data/processes/normalize_image.py:8-17 (-= RGB_MEAN in double, /= 255 in f32,
+ *   HWC -> CHW).  src: packed uint8 HWC (3 channel) images; desc: device array of
+ *   struct { long long offset; int h, w, pitch, dst_w; } (mr_sizeof_img_desc() bytes each); dst: f32 [N,3,H,W].
+ * mr_encode_labels: concern/charsets.py:37-58 + data/processes/make_recognition_label.py:11-24.  codepoints: i32
+ *   UTF-32 text of all strings back to back, offsets: i64 [N+1]; table_cp (sorted) / table_id: the charset's
+ *   codepoint -> id map (case folding baked in by the host); label: i32 [N, max_size] zero padded,
+ *   length: i32 [N] = min(len, max_size). */
+int mr_sizeof_img_desc(void);
+int mr_resize_normalize(const unsigned char* src, const void* desc, int N, int H, int W, double mean0, double mean1,
+                        double mean2, float* dst, hipStream_t stream);
+int mr_encode_labels(const int* codepoints, const long long* offsets, int N, int max_size, const int* table_cp,
+                     const int* table_id, int ntab, int unknown, int* label, int* length, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,8 +16,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "megreader_hip.h")
 MR_F32 = 0
 MR_BF16 = 1
 
-_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
-_CODES = {"p": _P, "i": _I, "l": _L, "f": _F, "s": _P}
+_P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_double
+_CODES = {"p": _P, "i": _I, "l": _L, "f": _F, "d": _D, "s": _P}
 
 # name -> argument codes (p pointer, i int, l long long, f float, s hipStream_t)
 SIGNATURES = {
@@ -71,6 +71,11 @@ SIGNATURES = {
     "mr_gru_gates_bwd": "ipppppppiis",
     "mr_nll_step_fwd": "ipiplppppiiiis",
     "mr_nll_step_bwd": "ippplppiiis",
+    "mr_ctc_greedy_decode": "iplll" + "iiiii" + "pps",
+    "mr_ctc2d_greedy_decode": "pllllplll" + "iiiiii" + "pps",
+    "mr_seq_measure": "pipiiiippppps",
+    "mr_resize_normalize": "ppiiidddps",
+    "mr_encode_labels": "ppiippiipps",
     "mr_ctc2d_fwd": "ippppiiiiiipps",
     "mr_ctc2d_bwd": "ippppppppp" + "iiiiiis",
 }
@@ -123,6 +128,8 @@ def load():
     lib.mr_set_lstm_persist.argtypes = [ctypes.c_int]
     lib.mr_lstm_ws_bytes.restype = ctypes.c_longlong
     lib.mr_lstm_ws_bytes.argtypes = [ctypes.c_int] * 4
+    lib.mr_sizeof_img_desc.restype = ctypes.c_int
+    lib.mr_sizeof_img_desc.argtypes = []
     lib.mr_stem_bwd_workspace.restype = ctypes.c_longlong
     lib.mr_stem_bwd_workspace.argtypes = [ctypes.c_int]
     for name, codes in SIGNATURES.items():
@@ -137,7 +144,7 @@ def load():
 
 
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_set_nt_variant", "mr_force_nt_tile",
-             "mr_stem_bwd_workspace", "mr_set_lstm_variant", "mr_set_nt_big", "mr_set_lstm_persist", "mr_lstm_ws_bytes",
+             "mr_stem_bwd_workspace", "mr_set_lstm_variant", "mr_set_nt_big", "mr_set_lstm_persist", "mr_lstm_ws_bytes", "mr_sizeof_img_desc",
              "mr_nt_kernel_code", "mr_set_tn_big", "mr_set_tn_buf", "mr_sizeof_prep_job")  # entry points that take no stream and launch nothing
 
 

@@ -10,6 +10,7 @@ import string
 class EnglishCharset(object):
     blank = 0
     unknown = 1
+    case_sensitive = False
 
     def __init__(self):
         corpus = sorted(set(string.digits + string.ascii_uppercase))
@@ -23,6 +24,14 @@ class EnglishCharset(object):
 
     def is_empty(self, index):
         return index == self.blank or index == self.unknown
+
+    def index(self, x):
+        """concern/charsets.py:37-41"""
+        target = x if self.case_sensitive else x.upper()
+        try:
+            return self._charset.index(target)
+        except ValueError:
+            return self.unknown
 
     def label_to_string(self, label):
         ignore = (self.unknown, self.blank)
