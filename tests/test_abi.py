@@ -39,6 +39,8 @@ def test_signature_table_matches_header():
                 assert "long long" in arg and "*" not in arg, (name, arg)
             elif code == "f":
                 assert arg.startswith("float") and "*" not in arg, (name, arg)
+            elif code == "d":
+                assert arg.startswith("double") and "*" not in arg, (name, arg)
             else:
                 assert arg.startswith("int") and "*" not in arg, (name, arg)
 
