@@ -203,6 +203,8 @@ int mr_lstm_bwd(int dtype, const void* dout, const void* whhT, const float* cbuf
  * on/off switch (default on) */
 long long mr_lstm_ws_bytes(int dtype, int T, int N, int H);
 int mr_set_lstm_persist(int on);
+/* debug hook (host only): non-null -> the persistent backward also writes its reduced recurrent term [T,N,2H] f32 */
+int mr_lstm_debug_buffer(float* p);
 /* tuning knob (host only): column-tile width of the step kernels; 0 = LDS-staged split-K body, else the
  * direct-fragment body.  fwd_bn in {0,32,64}, bwd_bn in {0,16,32,64}; negative leaves the setting unchanged. */
 int mr_set_lstm_variant(int fwd_bn, int bwd_bn);
@@ -311,7 +313,8 @@ int mr_seq_measure(const int* labels, int S, const int* preds, int S2, int N, in
  * mr_resize_normalize: data/processes/resize_image.py:29-38,48-53 (cv2.resize of the float32 image, INTER_LINEAR;
  *   modes "resize" and "pad") fused with data/processes/normalize_image.py:8-17 (-= RGB_MEAN in double, /= 255 in f32,
  *   HWC -> CHW).  src: packed uint8 HWC (3 channel) images; desc: device array of
- *   struct { long long offset; int h, w, pitch, dst_w; } (mr_sizeof_img_desc() bytes each); dst: f32 [N,3,H,W].
+ *   struct { long long offset; int h, w, pitch, dst_w; double scale_x, scale_y; } (mr_sizeof_img_desc() bytes
+ *   each; scale = 1. / ((double)dst / src) as cv2 computes it); dst: f32 [N,3,H,W].
  * mr_encode_labels: concern/charsets.py:37-58 + data/processes/make_recognition_label.py:11-24.  codepoints: i32
  *   UTF-32 text of all strings back to back, offsets: i64 [N+1]; table_cp (sorted) / table_id: the charset's
  *   codepoint -> id map (case folding baked in by the host); label: i32 [N, max_size] zero padded,

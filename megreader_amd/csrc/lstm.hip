@@ -218,6 +218,7 @@ int lstm_fwd_persist(const void* xproj, const void* whh, void* out, float* cbuf,
                      long long ws_bytes, hipStream_t stream);
 int lstm_bwd_persist(const void* dout, const void* whhT, const float* cbuf, void* gates, int T, int N, void* ws,
                      long long ws_bytes, hipStream_t stream);
+void lstm_set_bwd_debug(float* p);
 static int g_lstm_persist = 1;
 
 }  // namespace mr
@@ -234,6 +235,13 @@ int mr_set_lstm_variant(int fwd_bn, int bwd_bn) {
                "mr_set_lstm_variant: bad bwd_bn %d", bwd_bn);
   if (fwd_bn >= 0) g_lstm_fwd_bn = fwd_bn;
   if (bwd_bn >= 0) g_lstm_bwd_bn = bwd_bn;
+  return MR_OK;
+}
+
+// Debug hook (host only, not part of the product path): when non-null the persistent backward kernel also writes the
+// recurrent term dh_rec [T, N, 2H] (f32) it reduced for every step.
+int mr_lstm_debug_buffer(float* p) {
+  lstm_set_bwd_debug(p);
   return MR_OK;
 }
 

@@ -192,6 +192,7 @@ struct LstmPBwd {
   u64* xch;             // [2 dirs][nbg][2 slots][BWD_GRAN]
   unsigned* status;
   int T, N, nbg;
+  float* dbg;           // debug only (null in production): recurrent term dh_rec [T, N, 2H]
 };
 
 __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
@@ -270,8 +271,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
       for (int e = 0; e < 4; ++e) {
         float sum = obuf[wave][e][lane];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) sum += __builtin_bit_cast(float, v[k * 4 + e]);
+        for (int k = 0; k < 3; ++k) sum += __uint_as_float(v[k * 4 + e]);
         dh[e] += sum;
+        if (a.dbg && row_ok) {   // debug dump: [0] total, [1] own partial, [2..4] foreign partials in slab order
+          const long long plane = (long long)a.T * a.N * 2 * H, at = r * 2 * H + dir * H + j0 + e;
+          a.dbg[at] = sum;
+          a.dbg[plane + at] = obuf[wave][e][lane];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) a.dbg[(2 + k) * plane + at] = __uint_as_float(v[k * 4 + e]);
+        }
       }
     }
     // ---- gate algebra (EpiLstmBwd of lstm.hip with dc carried in registers)
@@ -309,13 +317,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) obuf[i][e][lane] = acc[i][e];
     } else {
+      // (__builtin_bit_cast on an ext-vector ELEMENT reads element 0 for every index with this compiler: convert
+      // through a float rvalue instead)
       const int srcidx = g < wave ? g : g - 1;
       u64* dst = xch + (s & 1) * BWD_GRAN + ((long long)wave * (PG - 1) + srcidx) * BWD_GRAN_SLAB + lane;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          gran_store(dst + i * 256 + e * 64, __builtin_bit_cast(unsigned, acc[i][e]), (unsigned)(s + 1));
+          gran_store(dst + i * 256 + e * 64, __float_as_uint((float)acc[i][e]), (unsigned)(s + 1));
     }
     __syncthreads();   // obuf visible; all fragment reads of abuf done before the next step overwrites it
   }
@@ -349,6 +359,9 @@ int lstm_fwd_persist(const void* xproj, const void* whh, void* out, float* cbuf,
   return MR_OK;
 }
 
+static float* g_lstm_bwd_dbg = nullptr;
+void lstm_set_bwd_debug(float* p) { g_lstm_bwd_dbg = p; }
+
 int lstm_bwd_persist(const void* dout, const void* whhT, const float* cbuf, void* gates, int T, int N, void* ws,
                      long long ws_bytes, hipStream_t stream) {
   MR_CHECK_ARG(ws_bytes >= persist_ws_bytes(N), "mr_lstm_bwd: workspace too small (%lld < %lld)", ws_bytes,
@@ -360,7 +373,7 @@ int lstm_bwd_persist(const void* dout, const void* whhT, const float* cbuf, void
     return MR_ERR_LAUNCH;
   }
   LstmPBwd a{(const bf16_t*)dout, (const bf16_t*)whhT, cbuf, (bf16_t*)gates, (u64*)ws,
-             (unsigned*)((char*)ws + xbytes), T, N, nbg};
+             (unsigned*)((char*)ws + xbytes), T, N, nbg, g_lstm_bwd_dbg};
   hipLaunchKernelGGL(lstm_bwd_persist_kernel, dim3(2 * nbg * PG), dim3(256), 0, stream, a);
   MR_CHECK_LAUNCH();
   return MR_OK;

@@ -174,6 +174,8 @@ struct ImgDesc {        // one source image (uint8, HWC, 3 channels)
   long long offset;     // byte offset into the packed source buffer
   int h, w, pitch;      // rows, columns, bytes per row
   int dst_w;            // columns of the resized image inside the canvas (== canvas width for mode "resize")
+  double scale_x, scale_y;  // cv2: scale = 1. / ((double)dsize / ssize), evaluated by the host (one IEEE division
+                            // sequence for the kernel and its oracle; not ssize / dsize, which rounds differently)
 };
 
 // dst[n, c, y, x] = ((double)resize(src_n)[y, x, c] - mean[c]) -> f32, / 255.f ; canvas columns >= dst_w hold the
@@ -183,6 +185,9 @@ struct ImgDesc {        // one source image (uint8, HWC, 3 channels)
 __global__ __launch_bounds__(256) void resize_normalize_kernel(const unsigned char* src, const ImgDesc* desc, int N,
                                                                int Hd, int Wd, double m0, double m1, double m2,
                                                                float* dst) {
+  // bit-exactness against the host arithmetic: every product and sum below is rounded separately (hipcc contracts
+  // a*b + c*d into an fma by default, and HIP's __fmul_rn / __fadd_rn are plain operators that get contracted too)
+#pragma clang fp contract(off)
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long per = (long long)Hd * Wd;
   if (gid >= per * N) return;
@@ -196,9 +201,8 @@ __global__ __launch_bounds__(256) void resize_normalize_kernel(const unsigned ch
 #pragma unroll
       for (int c = 0; c < 3; ++c) v[c] = (float)s[(long long)y * d.pitch + 3 * x + c];
     } else {
-      // cv2: inv_scale = (double)dsize / ssize; scale = 1. / inv_scale  (not ssize / dsize)
-      const double sx_scale = 1.0 / ((double)d.dst_w / (double)d.w), sy_scale = 1.0 / ((double)Hd / (double)d.h);
-      float fx = (float)((x + 0.5) * sx_scale - 0.5);
+      const double sx_scale = d.scale_x, sy_scale = d.scale_y;
+      float fx = (float)((x + 0.5) * sx_scale - 0.5);   // rounded product, then rounded sum (contraction is off)
       int sx = (int)floorf(fx);
       fx -= sx;
       if (sx < 0) { sx = 0; fx = 0.f; }
@@ -214,9 +218,9 @@ __global__ __launch_bounds__(256) void resize_normalize_kernel(const unsigned ch
       const unsigned char* r1 = s + (long long)sy1 * d.pitch;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float top = __fadd_rn(__fmul_rn((float)r0[3 * sx + c], a0), __fmul_rn((float)r0[3 * sx1 + c], a1));
-        const float bot = __fadd_rn(__fmul_rn((float)r1[3 * sx + c], a0), __fmul_rn((float)r1[3 * sx1 + c], a1));
-        v[c] = __fadd_rn(__fmul_rn(top, b0), __fmul_rn(bot, b1));
+        const float top = (float)r0[3 * sx + c] * a0 + (float)r0[3 * sx1 + c] * a1;
+        const float bot = (float)r1[3 * sx + c] * a0 + (float)r1[3 * sx1 + c] * a1;
+        v[c] = top * b0 + bot * b1;
       }
     }
   }

@@ -28,7 +28,7 @@ RGB_MEAN = (122.67891434, 116.66876762, 104.00698793)   # data/processes/normali
 class ImgDesc(ctypes.Structure):
     """struct ImgDesc of csrc/pipeline.hip."""
     _fields_ = [("offset", ctypes.c_longlong), ("h", ctypes.c_int), ("w", ctypes.c_int), ("pitch", ctypes.c_int),
-                ("dst_w", ctypes.c_int)]
+                ("dst_w", ctypes.c_int), ("scale_x", ctypes.c_double), ("scale_y", ctypes.c_double)]
 
 
 def charset_table(charset):
@@ -94,6 +94,9 @@ class DevicePipeline(object):
                 raise TypeError("images must be uint8 HWC with 3 channels (cv2.imread(..., IMREAD_COLOR))")
             descs[i].offset, descs[i].h, descs[i].w, descs[i].pitch = off, im.shape[0], im.shape[1], im.shape[1] * 3
             descs[i].dst_w = W if self.mode == 'resize' else target_width('pad', self.image_size, im.shape)
+            # cv2: inv_scale = (double)dsize / ssize; scale = 1. / inv_scale
+            descs[i].scale_x = 1.0 / (float(descs[i].dst_w) / float(im.shape[1]))
+            descs[i].scale_y = 1.0 / (float(H) / float(im.shape[0]))
             off += (im.shape[0] * im.shape[1] * 3 + 15) // 16 * 16
         pix_bytes = off
         desc_off = pix_bytes
