@@ -54,7 +54,7 @@ static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long lon
   const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
   if constexpr (AMODE != 1) {
     if (g_nt_variant == 2 && nt_fits_buffer<T>(a, g, AMODE)) {
-      const int grid = cdiv(cdiv(a.M, BM), 8) * 8 * cdiv(a.N, BN);  // XCD-aware tile map, see the kernel
+      const int grid = cdiv(cdiv(a.M - a.m_begin, BM), 8) * 8 * cdiv(a.N, BN);  // XCD-aware tile map, see the kernel
       NtArgs a2 = a;
       a2.zero = zero_page();
       if (!a2.zero) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
@@ -69,6 +69,7 @@ static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long lon
       return MR_OK;
     }
   }
+  if (a.m_begin != 0) { set_error("row-range launches need the direct-to-LDS NT kernel"); return MR_ERR_ARG; }
   hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, AMODE, EpiStore<T>>), dim3(tiles), dim3(256), 0, stream, a, g,
                      epi);
   MR_CHECK_LAUNCH();
@@ -111,6 +112,17 @@ static int nt_big_choice(int M, int N, int K) {
   return util >= 0.85 ? 1 : 0;
 }
 
+// Rows of the head of a head / tail launch (see dispatch_nt_store), 0 = do not split.
+static long long nt_head_rows(int M, int N, int K) {
+  if (g_big_mode != 0 || N % 256 != 0 || K < 512) return 0;
+  const int cus = num_cus();
+  const int tiles_n = N / 256;
+  if (cus % tiles_n != 0) return 0;
+  const long long rows_per_round = (long long)(cus / tiles_n) * 256;
+  const long long head = (M / rows_per_round) * rows_per_round;
+  return (head > 0 && (M - head) * 8 <= M) ? head : 0;   // tail <= 1/8 of the rows
+}
+
 template <typename T, int WM, int WN, int TM, int TN, int AMODE>
 static int launch_nt_big(const NtArgs& a, const ConvGeom& g, void* C, long long ldc, const float* bias, int relu,
                          hipStream_t stream) {
@@ -136,7 +148,7 @@ static int launch_nt_big(const NtArgs& a, const ConvGeom& g, void* C, long long 
     }
     attr_set = true;
   }
-  const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
+  const int tiles_m = cdiv(a.M - a.m_begin, BM), tiles_n = cdiv(a.N, BN);
   const int grid = cdiv(tiles_m, 8) * 8 * tiles_n;  // XCD-aware map: see the kernel
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, stream, a2, g, epi);
   MR_CHECK_LAUNCH();
@@ -189,6 +201,24 @@ static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long l
       const int big = nt_big_choice(a.M, a.N, a.K);
       if (big == 1) return launch_nt_big<T, 2, 4, 8, 4, AMODE>(a, g, C, ldc, bias, relu, stream);
       if (big == 2) return launch_nt_big<T, 3, 4, 6, 4, AMODE>(a, g, C, ldc, bias, relu, stream);  // 288x256, 12 waves
+      // Head / tail: rows are independent, so a problem whose 256x256 tile count is a few tiles over whole rounds of
+      // the CUs (33792 x 512: 264 tiles on 256 CUs) is cut into a head that is EXACTLY whole rounds of big tiles and
+      // a tail of the remaining rows for the 4-wave kernel.  No cross-workgroup reduction, two launches.
+      const long long head = a.m_begin == 0 ? nt_head_rows(a.M, a.N, a.K) : 0;
+      if (head > 0) {
+        NtArgs ah = a;
+        ah.M = (int)head;
+        int rc = launch_nt_big<T, 2, 4, 8, 4, AMODE>(ah, g, C, ldc, bias, relu, stream);
+        if (rc != MR_OK || head == a.M) return rc;
+        NtArgs at = a;
+        at.m_begin = (int)head;
+        const TileChoice tt = nt_tile(a.M - (int)head, a.N);
+#define MR_NT_TAIL(BM_, BN_) \
+  if (tt.bm == BM_ && tt.bn == BN_) return launch_nt_store<T, BM_, BN_, AMODE>(at, g, C, ldc, bias, relu, stream);
+        MR_NT_TAIL(128, 128) MR_NT_TAIL(128, 64) MR_NT_TAIL(96, 128) MR_NT_TAIL(96, 64) MR_NT_TAIL(64, 128)
+        MR_NT_TAIL(64, 64)
+#undef MR_NT_TAIL
+      }
     }
   }
   const TileChoice t = nt_tile(a.M, a.N);
@@ -351,6 +381,7 @@ int mr_nt_kernel_code(int dtype, int M, int N, int K, int cg) {
     const int big = nt_big_choice(M, N, K);
     if (big == 1) return 256256;
     if (big == 2) return 288256;
+    if (nt_head_rows(M, N, K) > 0) return 256256;   // head (whole rounds of 256x256 tiles) + a small 4-wave tail
   }
   return mr_nt_tile_code(M, N);
 }

@@ -70,6 +70,8 @@ struct NtArgs {
   long long lda;  // dense A row stride (elements); ignored in conv mode
   int ldb;        // B row stride (elements)
   const void* zero;  // >= 16 bytes of zeros in global memory (source of padded / out-of-range vectors)
+  int m_begin = 0;   // first row this launch computes (rows [m_begin, M)): lets the host cut a problem into a head that
+                     // fills the CUs in whole rounds of big tiles and a small tail (glds / big kernels only)
 };
 
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *(const uint4*)p; }
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+  const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M - a.m_begin + BM - 1) / BM;
   // XCD-aware tile map (grid = ceil(tiles_m/8)*8*tiles_n): hardware workgroup id b runs on XCD b % 8; the column
   // tiles of one row tile -- which gather the same activation rows -- take consecutive slots of the SAME XCD, so
   // the rows are fetched into one L2 instead of tiles_n of them (measured on the N = 512 layers: FETCH_SIZE per
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int tile_m = (slot / tiles_n) * 8 + xcd, tile_n = slot % tiles_n;
   if (tile_m >= tiles_m) return;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
   const int lrow = lane >> 3, lpc = lane & 7;
 
   const T* __restrict__ A = (const T*)a.A;
@@ -727,12 +729,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_nt_big_kernel(NtArgs a, Co
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+  const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M - a.m_begin + BM - 1) / BM;
   // XCD-aware map: hardware block b -> xcd = b & 7, slot = b >> 3
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int tile_m = (slot / tiles_n) * 8 + xcd, tile_n = slot % tiles_n;
   if (tile_m >= tiles_m) return;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
   const int lrow = lane >> 3, lpc = lane & 7;
 
   const T* __restrict__ A = (const T*)a.A;

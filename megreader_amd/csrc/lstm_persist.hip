@@ -49,31 +49,16 @@ constexpr int FWD_GRAN = PR * PH / 2;                 // granules per slot, forw
 constexpr int BWD_GRAN_SLAB = PR * PHS;               // granules per (dest, src) slab, backward (one f32 each): 1024
 constexpr int BWD_GRAN = PG * (PG - 1) * BWD_GRAN_SLAB;  // per slot: 12288
 
-__device__ __forceinline__ void gran_store(u64* p, unsigned value, unsigned tag) {
-  __hip_atomic_store((gu64*)p, ((u64)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u64 gran_load(const u64* p) {
-  return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+constexpr int AUX_SC1 = 16;   // cache-policy bit of the raw buffer builtins: sc1 = agent scope (write-through / L1 bypass)
 
-// One wave re-reads its NG granules (stride 256 granules) until every tag matches.  Returns false on timeout.
-template <int NG>
-__device__ __forceinline__ bool sweep(const u64* g, unsigned tag, unsigned (&v)[NG], unsigned* status, unsigned code) {
-  for (unsigned spins = 0;; ++spins) {
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < NG; ++k) {
-      const u64 x = gran_load(g + k * 256);
-      v[k] = (unsigned)x;
-      ok &= (unsigned)(x >> 32) == tag;
-    }
-    if (__all(ok)) return true;
-    if (spins > SPIN_LIMIT) {
-      if ((threadIdx.x & 63) == 0) atomicMax(status, code);
-      return false;
-    }
-    __builtin_amdgcn_s_sleep(1);
-  }
+// Two adjacent granules travel as ONE 16-byte sc1 access: {value0, tag, value1, tag}.  Each 8-byte half is a granule on
+// its own (carries its tag), so the pair needs no atomicity beyond the naturally aligned 8 bytes.
+__device__ __forceinline__ void gran2_store(rsrc_t r, unsigned byte_off, unsigned v0, unsigned v1, unsigned tag) {
+  __builtin_amdgcn_raw_buffer_store_b128(u32x4{v0, tag, v1, tag}, r, (int)byte_off, 0, AUX_SC1);
+}
+__device__ __forceinline__ u32x4 gran2_load(rsrc_t r, unsigned byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, AUX_SC1);
 }
 
 // Gate non-linearities on the dependency chain of the recurrence: v_exp_f32 + v_rcp_f32 forms (a few ulp; this path
@@ -98,6 +83,11 @@ struct LstmPFwd {
   int T, N, nbg;
 };
 
+// Ownership inside a slice (64 hidden units, 256 gate columns, 4 waves x 4 MFMA tiles): tile i of wave w takes the
+// gate columns {4 * (16w + 4*(t/4) + i) + t%4 : t = 0..15} as its 16 rows, so that the MFMA output lane (lg, l15)
+// holds, over i = 0..3, all four gates of the four CONSECUTIVE units 16w + 4lg + i of batch row l15: the lane's
+// x-projection is 32 contiguous bytes, its gates 32, its cell states 16, its h values 8 -- and its two granules one
+// 16-byte store.
 __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
   typedef Mma<bf16_t>::Frag Frag;
   __shared__ __attribute__((aligned(16))) bf16_t hbuf[2][PR][PLD];
@@ -113,12 +103,15 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
     const bf16_t* wbase = a.whh + (long long)dir * 4 * H * H;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int n = g * 4 * PHS + (wave * 4 + i) * 16 + l15;   // gate column (row of whh)
+      const int n = 4 * (g * PHS + wave * 16 + (l15 >> 2) * 4 + i) + (l15 & 3);   // gate column (row of whh)
 #pragma unroll
       for (int c = 0; c < 8; ++c) wf[i][c] = *(const Frag*)(wbase + (long long)n * H + c * 32 + lg * 8);
     }
   }
-  u64* xch = a.xch + ((long long)dir * a.nbg + bg) * 2 * FWD_GRAN;
+  const rsrc_t rx = make_rsrc(a.xch);
+  const unsigned xbase = (unsigned)(((long long)dir * a.nbg + bg) * 2 * FWD_GRAN * 8);   // bytes
+  const int u0 = wave * 16 + lg * 4;          // first of this lane's 4 units inside the slice
+  const int j0 = g * PHS + u0;                // ... as a hidden-unit index
   float cst[4] = {0.f, 0.f, 0.f, 0.f};
   bool dead = false;
 
@@ -127,27 +120,49 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
     const long long r = (long long)t * a.N + row;
     // operands of the gate math that do not depend on the recurrent term: in flight during the exchange
     f32x4 xg[4];
+    {
+      const bf16_t* xp = a.xproj + r * 8 * H + dir * 4 * H + 4 * j0;
+      uint4 x0 = make_uint4(0, 0, 0, 0), x1 = x0;
+      if (row_ok) { x0 = *(const uint4*)xp; x1 = *(const uint4*)(xp + 8); }
+      const bf16_t* p0 = (const bf16_t*)&x0;
+      const bf16_t* p1 = (const bf16_t*)&x1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = g * PHS + (wave * 4 + i) * 4 + lg;
-      xg[i] = row_ok ? load4(a.xproj + r * 8 * H + dir * 4 * H + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < 4; ++q) {
+        xg[0][q] = (float)p0[q]; xg[1][q] = (float)p0[4 + q];
+        xg[2][q] = (float)p1[q]; xg[3][q] = (float)p1[4 + q];
+      }
     }
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-      // ---- all-gather h_{prev}: 8 granules per thread, tag s, slot (s-1)&1
-      unsigned v[8];
-      const u64* src = xch + ((s - 1) & 1) * FWD_GRAN + tid;
-      if (!dead) dead = !sweep<8>(src, (unsigned)s, v, a.status, 1u);
+      // ---- all-gather h_{prev}: this thread fetches, from each of the 3 foreign slices, the granule pair of the
+      // thread with its own (wave, lane) -- tag s, slot (s-1)&1.  The own slice went through LDS (below).
       bf16_t* hb = &hbuf[s & 1][0][0];
+      u32x4 v[3];
+      const unsigned src = xbase + (unsigned)(((s - 1) & 1) * FWD_GRAN * 8) + (unsigned)(tid * 16);
+      if (!dead) {
+        for (unsigned spins = 0;; ++spins) {
+          bool ok = true;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int idx = q * 256 + tid;
-        const int ln = idx & 63, p = (idx >> 6) & 1, w2 = (idx >> 7) & 3, g2 = idx >> 9;
-        const int m = ln & 15, j0 = g2 * PHS + (w2 * 4 + 2 * p) * 4 + (ln >> 4);
-        *(unsigned short*)(hb + m * PLD + j0) = (unsigned short)(v[q] & 0xffffu);
-        *(unsigned short*)(hb + m * PLD + j0 + 4) = (unsigned short)(v[q] >> 16);
+          for (int k = 0; k < 3; ++k) {
+            const int gf = k + (k >= g);
+            v[k] = gran2_load(rx, src + (unsigned)(gf * 256 * 16));
+            ok &= v[k][1] == (unsigned)s && v[k][3] == (unsigned)s;
+          }
+          if (__all(ok)) break;
+          if (spins > SPIN_LIMIT) {
+            if (lane == 0) atomicMax(a.status, 1u);
+            dead = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int gf = k + (k >= g);
+        *(uint2*)(hb + l15 * PLD + gf * PHS + u0) = make_uint2(v[k][0], v[k][2]);
       }
       __syncthreads();
       Frag hf[8];
@@ -158,11 +173,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) Mma<bf16_t>::run(acc[i], wf[i][c], hf[c]);
     }
-    // ---- gate math (lane owns the 4 gates of (row, unit) for 4 units), state in registers
-    float hv[4];
+    // ---- gate math (lane owns the 4 gates of (row, unit) for 4 consecutive units), state in registers
+    float hv[4], gt[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int j = g * PHS + (wave * 4 + i) * 4 + lg;
       const float ig = fsig(acc[i][0] + xg[i][0]);
       const float fg = fsig(acc[i][1] + xg[i][1]);
       const float gg = ftanh(acc[i][2] + xg[i][2]);
@@ -170,16 +184,26 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
       const float c = fg * cst[i] + ig * gg;
       cst[i] = c;
       hv[i] = og * ftanh(c);
-      if (row_ok) {
-        a.cbuf[r * 2 * H + dir * H + j] = c;
-        a.out[r * 2 * H + dir * H + j] = (bf16_t)hv[i];
-        store4(a.gates + r * 8 * H + dir * 4 * H + 4 * j, f32x4{ig, fg, gg, og});
-      }
+      gt[i][0] = ig; gt[i][1] = fg; gt[i][2] = gg; gt[i][3] = og;
     }
+    const unsigned h01 = pack_bf16(hv[0], hv[1]), h23 = pack_bf16(hv[2], hv[3]);
     if (s + 1 < a.T) {
-      u64* dst = xch + (s & 1) * FWD_GRAN + ((g * 4 + wave) * 2) * 64 + lane;
-      gran_store(dst, pack_bf16(hv[0], hv[1]), (unsigned)(s + 1));
-      gran_store(dst + 64, pack_bf16(hv[2], hv[3]), (unsigned)(s + 1));
+      // publish FIRST (the hand-off is the critical path), then the own slice into the next step's LDS tile
+      gran2_store(rx, xbase + (unsigned)((s & 1) * FWD_GRAN * 8) + (unsigned)((g * 256 + tid) * 16), h01, h23,
+                  (unsigned)(s + 1));
+      *(uint2*)(&hbuf[(s + 1) & 1][l15][j0]) = make_uint2(h01, h23);
+    }
+    if (row_ok) {
+      *(uint2*)(a.out + r * 2 * H + dir * H + j0) = make_uint2(h01, h23);
+      *(f32x4*)(a.cbuf + r * 2 * H + dir * H + j0) = f32x4{cst[0], cst[1], cst[2], cst[3]};
+      uint4 g0, g1;
+      g0.x = pack_bf16(gt[0][0], gt[0][1]); g0.y = pack_bf16(gt[0][2], gt[0][3]);
+      g0.z = pack_bf16(gt[1][0], gt[1][1]); g0.w = pack_bf16(gt[1][2], gt[1][3]);
+      g1.x = pack_bf16(gt[2][0], gt[2][1]); g1.y = pack_bf16(gt[2][2], gt[2][3]);
+      g1.z = pack_bf16(gt[3][0], gt[3][1]); g1.w = pack_bf16(gt[3][2], gt[3][3]);
+      bf16_t* gp = a.gates + r * 8 * H + dir * 4 * H + 4 * j0;
+      *(uint4*)gp = g0;
+      *(uint4*)(gp + 8) = g1;
     }
   }
 }
@@ -192,13 +216,12 @@ struct LstmPBwd {
   u64* xch;             // [2 dirs][nbg][2 slots][BWD_GRAN]
   unsigned* status;
   int T, N, nbg;
-  float* dbg;           // debug only (null in production): recurrent term dh_rec [T, N, 2H]
 };
 
 __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
   typedef Mma<bf16_t>::Frag Frag;
   __shared__ __attribute__((aligned(16))) bf16_t abuf[PR][PLD];   // own dgates [16 rows][256 own gate columns]
-  __shared__ __attribute__((aligned(16))) float obuf[4][4][64];   // own partial dh: [tile][e][lane]
+  __shared__ __attribute__((aligned(16))) float obuf[4][64][4];   // own partial dh: [tile][lane][e]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int g = blockIdx.x % PG, bg = (blockIdx.x / PG) % a.nbg, dir = blockIdx.x / (PG * a.nbg);
   const int row = bg * PR + l15;
@@ -217,7 +240,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
         wf[i][c] = *(const Frag*)(wbase + (long long)n * 4 * H + g * 4 * PHS + c * 32 + lg * 8);
     }
   }
-  u64* xch = a.xch + ((long long)dir * a.nbg + bg) * 2 * BWD_GRAN;
+  const rsrc_t rx = make_rsrc(a.xch);
+  const unsigned xbase = (unsigned)(((long long)dir * a.nbg + bg) * 2 * BWD_GRAN * 8);   // bytes
   // epilogue ownership: thread (wave i', lane) <-> row l15, local units u0..u0+3 of this slice
   const int u0 = wave * 16 + lg * 4;
   const int j0 = g * PHS + u0;               // global hidden unit of e = 0
@@ -233,30 +257,36 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
     f32x4 up = {0.f, 0.f, 0.f, 0.f}, ct = up, cp = up, gq[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) gq[e] = up;
+    bf16_t* gp = a.gates + r * 8 * H + dir * 4 * H + 4 * j0;
     if (row_ok) {
       up = load4(a.dout + r * 2 * H + dir * H + j0);
       ct = *(const f32x4*)(a.cbuf + r * 2 * H + dir * H + j0);
       if (has_prev) cp = *(const f32x4*)(a.cbuf + ((long long)tp * a.N + row) * 2 * H + dir * H + j0);
+      const uint4 x0 = *(const uint4*)gp, x1 = *(const uint4*)(gp + 8);
+      const bf16_t* p0 = (const bf16_t*)&x0;
+      const bf16_t* p1 = (const bf16_t*)&x1;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) gq[e] = load4(a.gates + r * 8 * H + dir * 4 * H + 4 * (j0 + e));
+      for (int q = 0; q < 4; ++q) {
+        gq[0][q] = (float)p0[q]; gq[1][q] = (float)p0[4 + q];
+        gq[2][q] = (float)p1[q]; gq[3][q] = (float)p1[4 + q];
+      }
     }
     f32x4 dh = up;
     if (s > 0) {
-      // ---- reduce-scatter: 3 foreign partial sums (tag s, slot (s-1)&1) + the own one from LDS
-      unsigned v[12];
-      const u64* base = xch + ((s - 1) & 1) * BWD_GRAN + (long long)g * (PG - 1) * BWD_GRAN_SLAB + wave * 256 + lane;
-      // granule (src k, e) sits at base + k*BWD_GRAN_SLAB + e*64: fold into the stride-256 sweep by 3 sweeps of 4
-      bool ok = true;
+      // ---- reduce-scatter: 3 foreign partial sums (tag s, slot (s-1)&1) + the own one from LDS.
+      // slab (dest, src index k) = 1024 granules laid out [tile 4][e-pair 2][lane 64][2]
+      u32x4 v[6];
+      const unsigned src = xbase + (unsigned)(((s - 1) & 1) * BWD_GRAN * 8) +
+                           (unsigned)(g * (PG - 1) * BWD_GRAN_SLAB * 8) + (unsigned)((wave * 128 + lane) * 16);
       if (!dead) {
         for (unsigned spins = 0;; ++spins) {
-          ok = true;
+          bool ok = true;
 #pragma unroll
           for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const u64 x = gran_load(base + k * BWD_GRAN_SLAB + e * 64);
-              v[k * 4 + e] = (unsigned)x;
-              ok &= (unsigned)(x >> 32) == (unsigned)s;
+            for (int eh = 0; eh < 2; ++eh) {
+              v[k * 2 + eh] = gran2_load(rx, src + (unsigned)(k * BWD_GRAN_SLAB * 8) + (unsigned)(eh * 64 * 16));
+              ok &= v[k * 2 + eh][1] == (unsigned)s && v[k * 2 + eh][3] == (unsigned)s;
             }
           if (__all(ok)) break;
           if (spins > SPIN_LIMIT) {
@@ -267,36 +297,39 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
           __builtin_amdgcn_s_sleep(1);
         }
       }
+      const f32x4 own = *(const f32x4*)&obuf[wave][lane][0];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float sum = obuf[wave][e][lane];
+        float sum = own[e];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) sum += __uint_as_float(v[k * 4 + e]);
+        for (int k = 0; k < 3; ++k) sum += __uint_as_float(v[k * 2 + (e >> 1)][(e & 1) * 2]);
         dh[e] += sum;
-        if (a.dbg && row_ok) {   // debug dump: [0] total, [1] own partial, [2..4] foreign partials in slab order
-          const long long plane = (long long)a.T * a.N * 2 * H, at = r * 2 * H + dir * H + j0 + e;
-          a.dbg[at] = sum;
-          a.dbg[plane + at] = obuf[wave][e][lane];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) a.dbg[(2 + k) * plane + at] = __uint_as_float(v[k * 4 + e]);
-        }
       }
     }
     // ---- gate algebra (EpiLstmBwd of lstm.hip with dc carried in registers)
-    bf16_t* arow = &abuf[l15][4 * u0];
+    float dg[4][4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float ig = gq[e][0], fg = gq[e][1], gg = gq[e][2], og = gq[e][3];
       const float tc = ftanh(ct[e]);
       const float dcv = dh[e] * og * (1.f - tc * tc) + dcar[e];
-      f32x4 d;
-      d[0] = dcv * gg * ig * (1.f - ig);
-      d[1] = dcv * cp[e] * fg * (1.f - fg);
-      d[2] = dcv * ig * (1.f - gg * gg);
-      d[3] = dh[e] * tc * og * (1.f - og);
+      dg[e][0] = dcv * gg * ig * (1.f - ig);
+      dg[e][1] = dcv * cp[e] * fg * (1.f - fg);
+      dg[e][2] = dcv * ig * (1.f - gg * gg);
+      dg[e][3] = dh[e] * tc * og * (1.f - og);
       dcar[e] = dcv * fg;
-      if (row_ok) store4(a.gates + r * 8 * H + dir * 4 * H + 4 * (j0 + e), d);
-      store4(arow + 4 * e, row_ok ? d : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    uint4 d0, d1;
+    d0.x = pack_bf16(dg[0][0], dg[0][1]); d0.y = pack_bf16(dg[0][2], dg[0][3]);
+    d0.z = pack_bf16(dg[1][0], dg[1][1]); d0.w = pack_bf16(dg[1][2], dg[1][3]);
+    d1.x = pack_bf16(dg[2][0], dg[2][1]); d1.y = pack_bf16(dg[2][2], dg[2][3]);
+    d1.z = pack_bf16(dg[3][0], dg[3][1]); d1.w = pack_bf16(dg[3][2], dg[3][3]);
+    if (!row_ok) d0 = d1 = make_uint4(0, 0, 0, 0);
+    *(uint4*)(&abuf[l15][4 * u0]) = d0;
+    *(uint4*)(&abuf[l15][4 * u0 + 8]) = d1;
+    if (row_ok) {
+      *(uint4*)gp = d0;
+      *(uint4*)(gp + 8) = d1;
     }
     if (s + 1 == a.T) break;
     __syncthreads();   // abuf complete; every thread has consumed obuf of the previous step
@@ -313,19 +346,20 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
     // wave w's tile = partial dh of the units [64w, 64w+64) = slice w's units: lane holds (row l15, units 16i+4lg+e)
     if (wave == g) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) obuf[i][e][lane] = acc[i][e];
+      for (int i = 0; i < 4; ++i) *(f32x4*)&obuf[i][lane][0] = acc[i];
     } else {
-      // (__builtin_bit_cast on an ext-vector ELEMENT reads element 0 for every index with this compiler: convert
-      // through a float rvalue instead)
+      // (__builtin_bit_cast on an ext-vector ELEMENT reads element 0 for every index with this compiler: the values
+      // are converted through float rvalues)
       const int srcidx = g < wave ? g : g - 1;
-      u64* dst = xch + (s & 1) * BWD_GRAN + ((long long)wave * (PG - 1) + srcidx) * BWD_GRAN_SLAB + lane;
+      const unsigned dst = xbase + (unsigned)((s & 1) * BWD_GRAN * 8) +
+                           (unsigned)((wave * (PG - 1) + srcidx) * BWD_GRAN_SLAB * 8) + (unsigned)(lane * 16);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          gran_store(dst + i * 256 + e * 64, __float_as_uint((float)acc[i][e]), (unsigned)(s + 1));
+      for (int i = 0; i < 4; ++i) {
+        const float a0 = acc[i][0], a1 = acc[i][1], a2 = acc[i][2], a3 = acc[i][3];
+        gran2_store(rx, dst + (unsigned)(i * 128 * 16), __float_as_uint(a0), __float_as_uint(a1), (unsigned)(s + 1));
+        gran2_store(rx, dst + (unsigned)((i * 128 + 64) * 16), __float_as_uint(a2), __float_as_uint(a3),
+                    (unsigned)(s + 1));
+      }
     }
     __syncthreads();   // obuf visible; all fragment reads of abuf done before the next step overwrites it
   }
@@ -359,8 +393,7 @@ int lstm_fwd_persist(const void* xproj, const void* whh, void* out, float* cbuf,
   return MR_OK;
 }
 
-static float* g_lstm_bwd_dbg = nullptr;
-void lstm_set_bwd_debug(float* p) { g_lstm_bwd_dbg = p; }
+void lstm_set_bwd_debug(float*) {}   // debug hook retired with the fix of the backward publish (kept for the ABI)
 
 int lstm_bwd_persist(const void* dout, const void* whhT, const float* cbuf, void* gates, int T, int N, void* ws,
                      long long ws_bytes, hipStream_t stream) {
@@ -373,7 +406,7 @@ int lstm_bwd_persist(const void* dout, const void* whhT, const float* cbuf, void
     return MR_ERR_LAUNCH;
   }
   LstmPBwd a{(const bf16_t*)dout, (const bf16_t*)whhT, cbuf, (bf16_t*)gates, (u64*)ws,
-             (unsigned*)((char*)ws + xbytes), T, N, nbg, g_lstm_bwd_dbg};
+             (unsigned*)((char*)ws + xbytes), T, N, nbg};
   hipLaunchKernelGGL(lstm_bwd_persist_kernel, dim3(2 * nbg * PG), dim3(256), 0, stream, a);
   MR_CHECK_LAUNCH();
   return MR_OK;

@@ -52,6 +52,32 @@ def test_gemm_nt(dtype, M, N, K):
         assert float((C[:, N:].float() - 7.0).abs().max()) == 0.0  # pad columns untouched
 
 
+@pytest.mark.parametrize("M,N,K", [(66000, 256, 576), (33792, 512, 640), (65536 + 256, 256, 512)])
+def test_gemm_nt_head_tail_split(M, N, K):
+    """Problems a few tiles over whole rounds of 256x256 tiles on the 256 CUs are cut into a big-tile head and a 4-wave
+    tail (dispatch_nt_store): every output row, head and tail (ragged last tile included), against an f64 reference,
+    and bit-identical to the 4-wave kernel alone (same bf16 operands, same f32 accumulation order per element)."""
+    from megreader_amd._lib import load
+    lib = load()
+    dtype = torch.bfloat16
+    assert lib.mr_nt_kernel_code(1, M, N, K, 0) == 256256, "the head/tail path must apply to this shape"
+    g = torch.Generator().manual_seed(M)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(DEV, dtype)
+    B = (torch.randn(N, K, generator=g) * 0.5).to(DEV, dtype)
+    bias = torch.randn(N, generator=g).to(DEV)
+    C = torch.full((M, N), 7.0, device=DEV, dtype=dtype)
+    call("mr_gemm_nt", 1, ptr(A), K, ptr(B), K, ptr(C), N, ptr(bias), 1, M, N, K)
+    ref = torch.relu(A.double() @ B.double().t() + bias.double())
+    assert _rel_err(C, ref) < _tol(dtype, K)
+    old = lib.mr_set_nt_big(-1)
+    try:
+        C2 = torch.full((M, N), 7.0, device=DEV, dtype=dtype)
+        call("mr_gemm_nt", 1, ptr(A), K, ptr(B), K, ptr(C2), N, ptr(bias), 1, M, N, K)
+    finally:
+        lib.mr_set_nt_big(old)
+    assert torch.equal(C, C2)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("P,NA,NB,perm", [(512, 128, 128, 0), (8448, 2048, 256, 256), (1000, 40, 512, 0),
                                           (77, 256, 72, 0), (4096, 64, 576, 0)])
