@@ -113,6 +113,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
     ap.add_argument("--force-ddp", action="store_true",
                     help="take the multi-GPU code path even with WORLD_SIZE=1 (single-GPU test of that path)")
+    ap.add_argument("--ddp-mode", default="auto", choices=["auto", "capture", "graph2"],
+                    help="N > 1 with hipGraph replay: 'capture' = the apex-style shim's bucketed RCCL all-reduces are "
+                         "captured INSIDE the step graph on a side stream (overlapped with backward, zero host cost); "
+                         "'graph2' = two graphs with one eager all-reduce between them (not overlapped); 'auto' = "
+                         "capture, falling back to graph2 if the capture fails")
     ap.add_argument("--workload", default="crnn", choices=["crnn", "res50ppm"],
                     help="crnn = BASELINE.json configs[1] (the metric's workload, default); res50ppm = configs[2]: "
                          "ResNet50-dilated-PPM + 2D-CTC on 32x128 crops (secondary line, same JSON shape)")
@@ -178,10 +183,10 @@ def main():
         from megreader_amd.apex.parallel import DistributedDataParallel
         net = DistributedDataParallel(model)
     elif distributed:
-        # graphed data parallel: two hipGraphs per step with one in-place all-reduce of the flat gradient buffer
-        # between them (megreader_amd.runtime); rank 0's weights define the model
-        from megreader_amd.runtime import broadcast_parameters
-        broadcast_parameters(model)
+        # graphed data parallel; rank 0's weights define the model.  The shim is constructed here (it broadcasts) and
+        # used by the 'capture' mode; 'graph2' works on the bare model with an eager flat all-reduce between two graphs
+        from megreader_amd.apex.parallel import DistributedDataParallel
+        ddp_shim = DistributedDataParallel(model)
     if args.workload == "res50ppm":
         batch = synthetic_batch_2d(args.batch, 32, 128, seed=rank, max_len=3)
     else:
@@ -215,9 +220,29 @@ def main():
             loss, _ = net(i, targets=l, lengths=n, train=True)
             return loss.mean()
 
-        sync = data_parallel_grad_sync(opt) if distributed else None
-        graphed = GraphedTrainStep(loss_fn, opt, [img, lab, ln], warmup=max(2, args.warmup if distributed else 2),
-                                   grad_sync=sync)
+        ddp_launch = None
+        if distributed and args.ddp_mode in ("auto", "capture"):
+            # ONE graph: forward, backward with the shim's per-bucket all-reduces on its side stream (captured as a
+            # parallel branch: they overlap the rest of backward), finalisation, fused Adam
+            try:
+                net = ddp_shim
+                graphed = GraphedTrainStep(loss_fn, opt, [img, lab, ln], warmup=max(2, args.warmup), grad_sync=None)
+                ddp_launch = "hipGraph replay with in-graph bucketed RCCL all-reduce (overlapped with backward)"
+            except Exception as e:  # noqa: BLE001 - any capture failure falls back to the two-graph path
+                if args.ddp_mode == "capture":
+                    raise
+                print("in-graph collective capture failed (%s: %s); falling back to --ddp-mode graph2" %
+                      (type(e).__name__, e), file=sys.stderr)
+                torch.cuda.synchronize()
+                net = model
+                graphed = None
+        if graphed is None:
+            net = model
+            sync = data_parallel_grad_sync(opt) if distributed else None
+            graphed = GraphedTrainStep(loss_fn, opt, [img, lab, ln], warmup=max(2, args.warmup if distributed else 2),
+                                       grad_sync=sync)
+            if distributed:
+                ddp_launch = "2 hipGraphs + eager in-place RCCL all-reduce of the flat gradients"
         run = graphed
     else:
         run = step
@@ -307,8 +332,7 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload_name, "global_batch": args.batch * world,
                        "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
-                       "launch": ("hipGraph replay" if not distributed else
-                                  "2 hipGraphs + eager in-place RCCL all-reduce of the flat gradients") if use_graph
+                       "launch": ("hipGraph replay" if not distributed else ddp_launch) if use_graph
                        else ("eager" if not distributed else "eager, apex-style DDP shim (bucketed, overlapped)"),
                        "train_flops_per_image": 3 * fwd_flops},
             "final_loss": final_loss,

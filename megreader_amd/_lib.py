@@ -122,6 +122,8 @@ def load():
     lib.mr_set_tn_big.argtypes = [ctypes.c_int]
     lib.mr_set_nt_big.restype = ctypes.c_int
     lib.mr_set_nt_big.argtypes = [ctypes.c_int]
+    lib.mr_set_nt_p8.restype = ctypes.c_int
+    lib.mr_set_nt_p8.argtypes = [ctypes.c_int]
     lib.mr_set_lstm_variant.restype = ctypes.c_int
     lib.mr_set_lstm_variant.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mr_set_lstm_persist.restype = ctypes.c_int
@@ -146,7 +148,7 @@ def load():
 
 
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_set_nt_variant", "mr_force_nt_tile",
-             "mr_stem_bwd_workspace", "mr_set_lstm_variant", "mr_set_nt_big", "mr_set_lstm_persist", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_sizeof_img_desc",
+             "mr_stem_bwd_workspace", "mr_set_lstm_variant", "mr_set_nt_big", "mr_set_lstm_persist", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_set_nt_p8", "mr_sizeof_img_desc",
              "mr_nt_kernel_code", "mr_set_tn_big", "mr_set_tn_buf", "mr_sizeof_prep_job")  # entry points that take no stream and launch nothing
 
 

@@ -3,6 +3,7 @@
 // projection on the reference's training path (reference: backbones/crnn.py:44-55,
 // backbones/resnet.py:110-256, decoders/crnn.py:8-24).
 #include "igemm_core.h"
+#include "igemm_p8.h"
 #include "../../include/megreader_hip.h"
 
 #include <mutex>
@@ -155,6 +156,44 @@ static int launch_nt_big(const NtArgs& a, const ConvGeom& g, void* C, long long 
   return MR_OK;
 }
 
+// Phased-schedule 256x256 kernel (igemm_p8.h); g_use_p8: 1 = use it wherever the 8-wave 256x256 kernel would run.
+static int g_use_p8 = 1;
+template <typename T, int AMODE>
+static int launch_nt_p8(const NtArgs& a, const ConvGeom& g, void* C, long long ldc, const float* bias, int relu,
+                        hipStream_t stream) {
+  if constexpr (sizeof(T) != 2) {
+    return launch_nt_big<T, 2, 4, 8, 4, AMODE>(a, g, C, ldc, bias, relu, stream);
+  } else {
+    if (!g_use_p8) return launch_nt_big<T, 2, 4, 8, 4, AMODE>(a, g, C, ldc, bias, relu, stream);
+    EpiStore<T> epi;
+    epi.C = (T*)C;
+    epi.ldc = ldc;
+    epi.bias = bias;
+    epi.relu = relu;
+    epi.M = a.M;
+    epi.N = a.N;
+    epi.vec_ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
+    NtArgs a2 = a;
+    a2.zero = zero_page();
+    if (!a2.zero) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
+    constexpr size_t lds = 2 * (size_t)(256 + 256) * 128;
+    auto kern = igemm_nt_p8_kernel<AMODE, EpiStore<T>>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
+        return MR_ERR_LAUNCH;
+      }
+      attr_set = true;
+    }
+    const int tiles_m = cdiv(a.M - a.m_begin, 256), tiles_n = cdiv(a.N, 256);
+    const int grid = cdiv(tiles_m, 8) * 8 * tiles_n;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a2, g, epi);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+  }
+}
+
 // Tile selection shared by every NT launch.  Candidates BM in {128, 96, 64} x BN in {128, 64}; pick the one with
 // the smallest modelled time = rounds(tiles / resident slots) * tile work / tile efficiency.  The model exists
 // for wave quantisation: e.g. M = 33792 (264 row tiles of 128) x N = 512 gives 1056 tiles on 512 slots = 3 rounds
@@ -199,7 +238,7 @@ static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long l
     if (g_nt_variant == 2 && !g_forced_tile.bm && (AMODE == 0 || (g.Cg % BK) == 0) && aligned16(C) &&
         nt_fits_buffer<T>(a, g, AMODE)) {
       const int big = nt_big_choice(a.M, a.N, a.K);
-      if (big == 1) return launch_nt_big<T, 2, 4, 8, 4, AMODE>(a, g, C, ldc, bias, relu, stream);
+      if (big == 1) return launch_nt_p8<T, AMODE>(a, g, C, ldc, bias, relu, stream);
       if (big == 2) return launch_nt_big<T, 3, 4, 6, 4, AMODE>(a, g, C, ldc, bias, relu, stream);  // 288x256, 12 waves
       // Head / tail: rows are independent, so a problem whose 256x256 tile count is a few tiles over whole rounds of
       // the CUs (33792 x 512: 264 tiles on 256 CUs) is cut into a head that is EXACTLY whole rounds of big tiles and
@@ -208,7 +247,7 @@ static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long l
       if (head > 0) {
         NtArgs ah = a;
         ah.M = (int)head;
-        int rc = launch_nt_big<T, 2, 4, 8, 4, AMODE>(ah, g, C, ldc, bias, relu, stream);
+        int rc = launch_nt_p8<T, AMODE>(ah, g, C, ldc, bias, relu, stream);
         if (rc != MR_OK || head == a.M) return rc;
         NtArgs at = a;
         at.m_begin = (int)head;
@@ -333,6 +372,14 @@ int mr_init(void) {
 int mr_set_nt_variant(int v) {
   const int old = g_nt_variant;
   if (v == 1 || v == 2) g_nt_variant = v;
+  return old;
+}
+
+// 1 (default) = the phased-schedule 256x256 kernel (igemm_p8.h) serves the big-tile launches, 0 = the v3 kernel.
+// Returns the previous setting.
+int mr_set_nt_p8(int on) {
+  const int old = g_use_p8;
+  g_use_p8 = on != 0;
   return old;
 }
 

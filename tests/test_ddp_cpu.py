@@ -92,3 +92,103 @@ def test_two_rank_gradient_average(delay):
             continue
         assert torch.allclose(g0, g1, atol=0, rtol=0), k           # identical on both ranks
         assert torch.allclose(g0, p.grad, atol=1e-6, rtol=1e-5), k  # == full-batch gradient
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The zero-copy bucket path: gradients living in ONE flat buffer (what megreader_amd.optim.FusedAdam sets up on the
+# GPU) are all-reduced IN PLACE over the bucket's span.  Hand-built on CPU: a flat buffer with alignment padding, and
+# -- in the second layout -- a foreign, rank-dependent slot (a frozen parameter's stale gradient) sitting INSIDE the
+# span.  Reducing that span in place would average the foreign slot across ranks (and a slot belonging to another
+# bucket would be reduced twice); the shim must notice that the bucket does not tile its span and stage instead.
+# ---------------------------------------------------------------------------------------------------------------
+class FlatNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(8, 16, bias=False)     # 128 elements
+        self.b = torch.nn.Linear(16, 12, bias=False)    # 192
+        self.c = torch.nn.Linear(12, 4, bias=False)     # 48
+
+    def forward(self, x):
+        return self.c(torch.relu(self.b(torch.relu(self.a(x))))).sum(dim=1)
+
+
+def _flat_worker(rank, world, port, foreign_gap, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from megreader_amd.apex import parallel as shim
+    torch.manual_seed(5)
+    net = FlatNet()
+    params = [net.a.weight, net.b.weight, net.c.weight]
+    # flat layout: a | pad to 64 | [foreign slot of 200 elements] | b | pad | c
+    offs, total = [], 0
+    for i, p in enumerate(params):
+        if i == 1 and foreign_gap:
+            total += 256                               # the foreign region (200 used) between a and b
+        offs.append(total)
+        total += (p.numel() + 63) // 64 * 64
+    flat = torch.zeros(total)
+    sentinel = None
+    if foreign_gap:
+        sentinel = flat[128:128 + 200]
+        sentinel.fill_(5.0 * (rank + 1))               # rank-dependent: an in-place reduce of the span would change it
+    for p, off in zip(params, offs):
+        p.grad = flat[off:off + p.numel()].view(p.shape)
+    used = {"flat": 0, "staged": 0}
+    orig = shim.DistributedDataParallel._flat_view
+
+    def spy(self, bucket):
+        r = orig(self, bucket)
+        used["flat" if r is not None else "staged"] += 1
+        return r
+    shim.DistributedDataParallel._flat_view = spy
+    ddp = shim.DistributedDataParallel(net, message_size=1 << 20)       # one bucket: a, b, c
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(8, 8, generator=g)
+    xs = X[rank * 4:(rank + 1) * 4]
+    for _ in range(2):
+        for p in params:
+            p.grad.zero_()
+        ddp(xs).mean().backward()
+    views_ok = all(p.grad.data_ptr() == flat.data_ptr() + off * 4 for p, off in zip(params, offs))
+    q.put((rank, [p.grad.detach().numpy().copy() for p in params],
+           None if sentinel is None else sentinel.numpy().copy(), dict(used), views_ok,
+           flat.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("foreign_gap", [False, True])
+def test_flat_buffer_bucket_in_place_vs_foreign_gap(foreign_gap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_worker, args=(r, 2, port, foreign_gap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        item = q.get(timeout=120)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(5)
+    ref = FlatNet()
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(8, 8, generator=g)
+    ref(X).mean().backward()
+    want = [ref.a.weight.grad, ref.b.weight.grad, ref.c.weight.grad]
+    for rank in (0, 1):
+        grads, sentinel, used, views_ok, flat = res[rank]
+        assert views_ok, "gradients must stay views of the flat buffer"
+        for got, w in zip(grads, want):
+            assert torch.allclose(torch.from_numpy(got), w, atol=1e-6, rtol=1e-5)
+        if foreign_gap:
+            assert used["flat"] == 0 and used["staged"] > 0, used       # span not tiled -> staged path
+            assert (sentinel == 5.0 * (rank + 1)).all(), "foreign slot inside the span was reduced"
+        else:
+            assert used["flat"] > 0 and used["staged"] == 0, used       # tiled span -> zero-copy in-place path
+            # alignment padding (after c: elements 368..383 of the 384-element buffer) stays zero
+            assert flat.shape[0] == 384 and float(abs(flat[368:]).sum()) == 0.0

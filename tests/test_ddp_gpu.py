@@ -100,3 +100,50 @@ def test_ddp_shim_single_rank_rccl_matches_plain_run():
             assert float((state[k] - ref_state[k]).abs().max()) <= 2 * 1e-3 * 3 + 1e-4 * scale, k
         else:
             assert torch.equal(state[k], ref_state[k]), k
+
+
+def test_graphed_train_step_with_grad_sync_single_rank_rccl():
+    """The N > 1 bench path (megreader_amd.runtime): rank-0 parameter broadcast, [zero_grad, forward, backward] and
+    [Adam + weight-image refresh] as two hipGraphs with ONE eager in-place RCCL all-reduce of the flat gradient buffer
+    between them -- on a 1-rank "nccl" group (identity collective) its loss trajectory must equal the single-graph
+    run's.  Also pushes a learning-rate change between replays (the captured update reads lr from a device slot)."""
+    from megreader_amd.runtime import GraphedTrainStep, broadcast_parameters, data_parallel_grad_sync
+    mr.set_compute_dtype(torch.bfloat16)
+    batch = synthetic_batch(16, 32, 128, seed=1)
+    img, lab, ln = batch['image'].to(DEV), batch['label'].to(DEV), batch['length'].to(DEV).long()
+
+    def run(distributed):
+        torch.manual_seed(0)
+        model = BasicModel().to(DEV).train()
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        opt.zero_grad()
+        if distributed:
+            broadcast_parameters(model)
+
+        def loss_fn(i, l, n):
+            loss, _ = model(i, targets=l, lengths=n, train=True)
+            return loss.mean()
+
+        step = GraphedTrainStep(loss_fn, opt, [img, lab, ln], warmup=2,
+                                grad_sync=data_parallel_grad_sync(opt) if distributed else None)
+        losses = []
+        for it in range(6):
+            if it == 3:
+                for gp in opt.param_groups:
+                    gp['lr'] = 1e-4          # scheduler step on the host: must reach the captured update kernel
+            losses.append(float(step()))
+        torch.cuda.synchronize()
+        return losses, float(opt._flat[0]['hyper'][0])
+
+    ref, lr_ref = run(False)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        got, lr_got = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert abs(lr_ref - 1e-4) < 1e-10 and abs(lr_got - 1e-4) < 1e-10, "lr change did not reach the device slot"
+    for a, b in zip(got, ref):
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), (got, ref)      # bf16, f32 atomics order differs run to run
+    assert ref[-1] < ref[0] and got[-1] < got[0]
