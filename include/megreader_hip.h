@@ -44,7 +44,8 @@ int mr_force_nt_tile(int bm, int bn);
 /* big-tile (8-wave, 256x256 / 288x256) NT kernel policy: 0 automatic, -1 never, 1 / 2 force (tuning override);
  * returns the previous setting */
 int mr_set_nt_big(int mode);
-/* host only: 1 (default) = phased-schedule 256x256 NT kernel for the big-tile launches, 0 = the v3 kernel */
+/* host only: 1 = phased-schedule 256x256 NT kernel (igemm_p8.h) for the big-tile launches, 0 (default) = the v3
+ * kernel; 2..4 = timing-only ablations (no LDS-DMA / no fragment reads / MFMA + barriers only; wrong results) */
 int mr_set_nt_p8(int on);
 /* experimental wide-tile TN (weight-gradient) kernels: 1 = 256x256, 2 = 128x256, 0 / -1 = never (default; they are
  * currently slower, see gemm_conv.hip:launch_tn); returns the previous setting */

@@ -157,7 +157,11 @@ static int launch_nt_big(const NtArgs& a, const ConvGeom& g, void* C, long long 
 }
 
 // Phased-schedule 256x256 kernel (igemm_p8.h); g_use_p8: 1 = use it wherever the 8-wave 256x256 kernel would run.
-static int g_use_p8 = 1;
+// Measured equal to the v3 kernel (850-900 TF/s on conv3 / conv5, gpurun r2j) -- the schedule is not what bounds the
+// tile: its ablation ladder (mr_set_nt_p8(2..4), tools/microbench_conv.py --p8) gives 1.16-1.21 PF for the bare
+// MFMA + barrier skeleton incl. prologue / epilogue, 1.03 PF with the fragment reads, 0.85-0.90 with the LDS-DMA
+// issue on top.  Default: the v3 kernel.
+static int g_use_p8 = 0;
 template <typename T, int AMODE>
 static int launch_nt_p8(const NtArgs& a, const ConvGeom& g, void* C, long long ldc, const float* bias, int relu,
                         hipStream_t stream) {
@@ -177,18 +181,27 @@ static int launch_nt_p8(const NtArgs& a, const ConvGeom& g, void* C, long long l
     a2.zero = zero_page();
     if (!a2.zero) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
     constexpr size_t lds = 2 * (size_t)(256 + 256) * 128;
-    auto kern = igemm_nt_p8_kernel<AMODE, EpiStore<T>>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
-        return MR_ERR_LAUNCH;
-      }
-      attr_set = true;
-    }
     const int tiles_m = cdiv(a.M - a.m_begin, 256), tiles_n = cdiv(a.N, 256);
     const int grid = cdiv(tiles_m, 8) * 8 * tiles_n;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a2, g, epi);
+#define MR_P8_LAUNCH(ABL_)                                                                                        \
+  {                                                                                                               \
+    auto kern = igemm_nt_p8_kernel<AMODE, EpiStore<T>, ABL_>;                                                     \
+    static bool attr_set = false;                                                                                 \
+    if (!attr_set) {                                                                                              \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=         \
+          hipSuccess) {                                                                                           \
+        set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);                                      \
+        return MR_ERR_LAUNCH;                                                                                     \
+      }                                                                                                           \
+      attr_set = true;                                                                                            \
+    }                                                                                                             \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a2, g, epi);                                     \
+  }
+    if (g_use_p8 == 2) MR_P8_LAUNCH(1)          // measurement-only ablations (mr_set_nt_p8(2..4))
+    else if (g_use_p8 == 3) MR_P8_LAUNCH(2)
+    else if (g_use_p8 == 4) MR_P8_LAUNCH(3)
+    else MR_P8_LAUNCH(0)
+#undef MR_P8_LAUNCH
     MR_CHECK_LAUNCH();
     return MR_OK;
   }
@@ -375,11 +388,12 @@ int mr_set_nt_variant(int v) {
   return old;
 }
 
-// 1 (default) = the phased-schedule 256x256 kernel (igemm_p8.h) serves the big-tile launches, 0 = the v3 kernel.
+// 1 = the phased-schedule 256x256 kernel (igemm_p8.h) serves the big-tile launches, 0 (default) = the v3 kernel,
+// 2..4 = timing-only ablations of the phased kernel (wrong results).
 // Returns the previous setting.
 int mr_set_nt_p8(int on) {
   const int old = g_use_p8;
-  g_use_p8 = on != 0;
+  g_use_p8 = (on >= 0 && on <= 4) ? on : 1;   // 2..4: ablation variants of the phased kernel (timing only)
   return old;
 }
 

@@ -34,7 +34,10 @@
 
 namespace mr {
 
-template <int AMODE, typename Epi>
+// ABL (measurement only, results are wrong for ABL != 0): 1 = no LDS-DMA inside the K loop (stage once), 2 = no
+// fragment reads inside the K loop, 3 = both (MFMAs + barriers only) -- the ablation ladder behind DESIGN.md's
+// "what bounds the big-tile kernel".
+template <int AMODE, typename Epi, int ABL = 0>
 __global__ __launch_bounds__(512) void igemm_nt_p8_kernel(NtArgs a, ConvGeom g, Epi epi) {
   typedef bf16_t T;
   typedef Mma<T>::Frag Frag;
@@ -203,17 +206,20 @@ __global__ __launch_bounds__(512) void igemm_nt_p8_kernel(NtArgs a, ConvGeom g, 
   // one K-tile; S = its LDS stage (compile-time in the unrolled-by-2 loop below)
   auto ktile = [&](int c, int S) {
     const uint4* st = smem + S * STAGE_VECS;
-    const bool more1 = c + 1 < nk, more2 = c + 2 < nk;
+    const bool more1 = (ABL & 1) ? false : c + 1 < nk, more2 = (ABL & 1) ? false : c + 2 < nk;
+    const bool rd = (ABL & 2) ? c == 0 : true;           // ablation: read the fragments of K-tile 0 only
     // ---- q0
+    if (rd) {
     read_a(st, 0, fa0);
     read_b(st, 0, fb0);
     read_b(st, 1, fb1);                                  // prefetch for q1
+    }
     if (more1) stage_b(S ^ 1, 0, (c + 1) * BK);          // BH0 of K-tile c+1 (overwrites BH0 of K-tile c-1)
     MR_P8_SCHED();
     mma_quad(0, 0, fa0, fb0);
     MR_P8_SCHED();
     // ---- q1
-    read_a(st, 1, fa1);                                  // prefetch for q2
+    if (rd) read_a(st, 1, fa1);                          // prefetch for q2
     if (more1) stage_b(S ^ 1, 1, (c + 1) * BK);          // BH1 of K-tile c+1
     MR_P8_SCHED();
     mma_quad(0, 1, fa0, fb1);
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(512) void igemm_nt_p8_kernel(NtArgs a, ConvGeom g, 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of AH(c) are retired
     __builtin_amdgcn_s_barrier();
     // ---- q2
-    read_b(st, 0, fb0);                                  // B0 again, for q3
+    if (rd) read_b(st, 0, fb0);                          // B0 again, for q3
     if (more2) stage_a(S, 0);                            // AH0 of K-tile c+2 (overwrites AH0 of K-tile c)
     MR_P8_SCHED();
     mma_quad(1, 1, fa1, fb1);

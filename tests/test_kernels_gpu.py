@@ -77,7 +77,7 @@ def test_gemm_nt_head_tail_split(M, N, K):
         lib.mr_set_nt_big(old)
     assert torch.equal(C, C2)
     # the v3 (2-phase) and the phased (igemm_p8.h) 256x256 kernels: same operands, same per-element k order
-    oldp = lib.mr_set_nt_p8(0)
+    oldp = lib.mr_set_nt_p8(1)
     try:
         C3 = torch.full((M, N), 7.0, device=DEV, dtype=dtype)
         call("mr_gemm_nt", 1, ptr(A), K, ptr(B), K, ptr(C3), N, ptr(bias), 1, M, N, K)

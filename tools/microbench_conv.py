@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--tnbuf", type=int, default=0, help="TN kernel staging through buffer resources (0/1)")
     ap.add_argument("--tnbig", type=int, default=0, help="big-tile TN kernel: 0 auto, -1 never, 1 always")
     ap.add_argument("--big", type=int, default=0, help="big-tile NT kernel: 0 auto, -1 never, 1 256x256, 2 288x256")
-    ap.add_argument("--p8", type=int, default=1, help="phased-schedule 256x256 kernel for the big-tile launches (0/1)")
+    ap.add_argument("--p8", type=int, default=0, help="phased-schedule 256x256 kernel for the big-tile launches (0/1)")
     a = ap.parse_args()
     from megreader_amd import _lib
     _lib.load().mr_set_nt_variant(a.variant)
