@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the ResNet50-PPM-2D-CTC secondary measurement of the default single-GPU run")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
     ap.add_argument("--force-ddp", action="store_true",
@@ -138,217 +140,232 @@ def main():
     if args.gpus != world:
         print("warning: --gpus %d but WORLD_SIZE %d (using WORLD_SIZE)" % (args.gpus, world), file=sys.stderr)
 
-    import megreader_amd as mr
-    from megreader_amd import _lib
-    from megreader_amd.backbones import crnn_backbone
-    from megreader_amd.decoders import CRNNDecoder
-    from megreader_amd.optim import FusedAdam
-    from megreader_amd.synthetic import recognition_batch as synthetic_batch  # BASELINE.md §3 value distributions
+    def measure(workload, steps, warmup, with_cpu):
+        """One workload: build, warm up, time `steps` steps; returns the result dict on rank 0 (None elsewhere)."""
+        import megreader_amd as mr
+        from megreader_amd import _lib
+        from megreader_amd.backbones import crnn_backbone
+        from megreader_amd.decoders import CRNNDecoder
+        from megreader_amd.optim import FusedAdam
+        from megreader_amd.synthetic import recognition_batch as synthetic_batch  # BASELINE.md §3 value distributions
 
-    lib = _lib.load()
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    mr.set_compute_dtype(dtype)
+        lib = _lib.load()
+        dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        mr.set_compute_dtype(dtype)
 
-    class BasicModel(torch.nn.Module):  # reference structure/model.py:16-24
-        def __init__(self):
-            super().__init__()
-            self.backbone = crnn_backbone()
-            self.decoder = CRNNDecoder(in_channels=512, inner_channels=256)
-
-        def forward(self, data, *a, **k):
-            return self.decoder(self.backbone(data), *a, **k)
-
-    if args.workload == "res50ppm":
-        from megreader_amd.backbones import resnet50dilated_ppm
-        from megreader_amd.decoders import CTCDecoder2D
-        from megreader_amd.synthetic import recognition_batch_2d as synthetic_batch_2d
-
-        class BasicModel(torch.nn.Module):  # noqa: F811  res50-ppm-2d-ctc.yaml: resnet50dilated_ppm + CTCDecoder2D
+        class BasicModel(torch.nn.Module):  # reference structure/model.py:16-24
             def __init__(self):
                 super().__init__()
-                self.backbone = resnet50dilated_ppm()
-                self.decoder = CTCDecoder2D(in_channels=256)
+                self.backbone = crnn_backbone()
+                self.decoder = CRNNDecoder(in_channels=512, inner_channels=256)
 
             def forward(self, data, *a, **k):
                 return self.decoder(self.backbone(data), *a, **k)
 
-    torch.manual_seed(0)
-    model = BasicModel().to(dev).train()
-    opt = FusedAdam(model.parameters(), lr=1e-3)  # experiments/recognition/crnn.yaml:82-89 (both YAMLs use Adam)
-    opt.zero_grad()
-    net = model
-    use_graph = not args.no_graph
-    if distributed and not use_graph:
-        # eager data parallel: the apex-style shim (bucketed all-reduce overlapped with backward)
-        from megreader_amd.apex.parallel import DistributedDataParallel
-        net = DistributedDataParallel(model)
-    elif distributed:
-        # graphed data parallel; rank 0's weights define the model.  The shim is constructed here (it broadcasts) and
-        # used by the 'capture' mode; 'graph2' works on the bare model with an eager flat all-reduce between two graphs
-        from megreader_amd.apex.parallel import DistributedDataParallel
-        ddp_shim = DistributedDataParallel(model)
-    if args.workload == "res50ppm":
-        batch = synthetic_batch_2d(args.batch, 32, 128, seed=rank, max_len=3)
-    else:
-        batch = synthetic_batch(args.batch, 32, 128, seed=rank)
-    img = batch['image'].to(dev)
-    lab = batch['label'].to(dev)
-    ln = batch['length'].to(dev).long()
+        if workload == "res50ppm":
+            from megreader_amd.backbones import resnet50dilated_ppm
+            from megreader_amd.decoders import CTCDecoder2D
+            from megreader_amd.synthetic import recognition_batch_2d as synthetic_batch_2d
 
-    def step():
+            class BasicModel(torch.nn.Module):  # noqa: F811  res50-ppm-2d-ctc.yaml: resnet50dilated_ppm + CTCDecoder2D
+                def __init__(self):
+                    super().__init__()
+                    self.backbone = resnet50dilated_ppm()
+                    self.decoder = CTCDecoder2D(in_channels=256)
+
+                def forward(self, data, *a, **k):
+                    return self.decoder(self.backbone(data), *a, **k)
+
+        torch.manual_seed(0)
+        model = BasicModel().to(dev).train()
+        opt = FusedAdam(model.parameters(), lr=1e-3)  # experiments/recognition/crnn.yaml:82-89 (both YAMLs use Adam)
         opt.zero_grad()
-        loss, _ = net(img, targets=lab, lengths=ln, train=True)
-        loss = loss.mean()
-        loss.backward()
-        opt.step()
-        return loss
+        net = model
+        use_graph = not args.no_graph
+        if distributed and not use_graph:
+            # eager data parallel: the apex-style shim (bucketed all-reduce overlapped with backward)
+            from megreader_amd.apex.parallel import DistributedDataParallel
+            net = DistributedDataParallel(model)
+        elif distributed:
+            # graphed data parallel; rank 0's weights define the model.  The shim is constructed here (it broadcasts) and
+            # used by the 'capture' mode; 'graph2' works on the bare model with an eager flat all-reduce between two graphs
+            from megreader_amd.apex.parallel import DistributedDataParallel
+            ddp_shim = DistributedDataParallel(model)
+        if workload == "res50ppm":
+            batch = synthetic_batch_2d(args.batch, 32, 128, seed=rank, max_len=3)
+        else:
+            batch = synthetic_batch(args.batch, 32, 128, seed=rank)
+        img = batch['image'].to(dev)
+        lab = batch['label'].to(dev)
+        ln = batch['length'].to(dev).long()
 
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def step():
+            opt.zero_grad()
+            loss, _ = net(img, targets=lab, lengths=ln, train=True)
+            loss = loss.mean()
+            loss.backward()
+            opt.step()
+            return loss
 
-    for _ in range(args.warmup if not (distributed and use_graph) else 0):
-        step()
-    graphed = None
-    if use_graph:
-        # the whole step (zero_grad, forward, CTC, backward, fused Adam) as ONE captured hipGraph; the timed region
-        # replays it.  Same kernels, same work -- only the ~150 host-side launches per step are gone.
-        from megreader_amd.runtime import GraphedTrainStep, data_parallel_grad_sync
-
-        def loss_fn(i, l, n):
-            loss, _ = net(i, targets=l, lengths=n, train=True)
-            return loss.mean()
-
-        ddp_launch = None
-        if distributed and args.ddp_mode in ("auto", "capture"):
-            # ONE graph: forward, backward with the shim's per-bucket all-reduces on its side stream (captured as a
-            # parallel branch: they overlap the rest of backward), finalisation, fused Adam
-            try:
-                net = ddp_shim
-                graphed = GraphedTrainStep(loss_fn, opt, [img, lab, ln], warmup=max(2, args.warmup), grad_sync=None)
-                ddp_launch = "hipGraph replay with in-graph bucketed RCCL all-reduce (overlapped with backward)"
-            except Exception as e:  # noqa: BLE001 - any capture failure falls back to the two-graph path
-                if args.ddp_mode == "capture":
-                    raise
-                print("in-graph collective capture failed (%s: %s); falling back to --ddp-mode graph2" %
-                      (type(e).__name__, e), file=sys.stderr)
-                torch.cuda.synchronize()
-                net = model
-                graphed = None
-        if graphed is None:
-            net = model
-            sync = data_parallel_grad_sync(opt) if distributed else None
-            graphed = GraphedTrainStep(loss_fn, opt, [img, lab, ln], warmup=max(2, args.warmup if distributed else 2),
-                                       grad_sync=sync)
+        def barrier():
             if distributed:
-                ddp_launch = "2 hipGraphs + eager in-place RCCL all-reduce of the flat gradients"
-        run = graphed
-    else:
-        run = step
-    timer = None
-    if not args.no_kernel_timer and not use_graph:
-        timer = _lib.KernelTimer(["mr_conv2d_fwd", "mr_conv2d_dgrad", "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab"])
-        _lib.TIMER = timer
-    barrier()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = run()
-    host_enqueue = time.perf_counter() - t0   # host time to enqueue all steps (GPU still running)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    _lib.TIMER = None
-    final_loss = float(last.detach())
-    if use_graph and not args.no_kernel_timer:
-        # HIP events cannot bracket kernels inside a graph replay: measure the dominant kernel's launch durations
-        # on the same stream with the same tensors in an eager pass right after the timed region
-        timer = _lib.KernelTimer(["mr_conv2d_fwd", "mr_conv2d_dgrad", "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab"])
-        _lib.TIMER = timer
-        timer_steps = min(args.steps, 10)
-        for _ in range(timer_steps):
-            step()
-        torch.cuda.synchronize()
-        _lib.TIMER = None
-    else:
-        timer_steps = args.steps
-    if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    if rank == 0:
-        ms = 1e3 * elapsed / args.steps
-        images = args.batch * world * args.steps
-        # ---- roofline of the dominant MFMA kernel from the live HIP-event records
-        roofline = None
-        kernels = {}
-        if timer is not None:
-            agg = {}
-            algo_bytes = {}
-            for name, cargs, t_ms in timer.results():
-                label = kernel_label(lib, name, cargs, args.dtype)
-                fl, pix, cout, cin = conv_flops(name, cargs)
-                # algorithmic bytes of the launch: both activation tensors once + the weights once (2-byte elements)
-                es = 2 if args.dtype == "bf16" else 4
-                algo_bytes[label] = algo_bytes.get(label, 0.0) + es * (pix * cout + pix * cin) + es * fl / (2.0 * pix)
-                a = agg.setdefault(label, [0.0, 0.0, 0])
-                a[0] += fl
-                a[1] += t_ms
-                a[2] += 1
-            for label, (fl, t_ms, n) in agg.items():
-                kernels[label] = {"launches_per_step": n / timer_steps, "avg_us": round(1e3 * t_ms / n, 2),
-                                  "tflops": round(fl / (t_ms * 1e-3) / 1e12, 1),
-                                  "ms_per_step": round(t_ms / timer_steps, 4)}
-            if agg:
-                dom = max(agg, key=lambda k: agg[k][1])
-                fl, t_ms, n = agg[dom]
-                ach = fl / (t_ms * 1e-3) / 1e12
-                peak = MFMA_PEAK_TFLOPS[args.dtype]
-                # the committed PMC passes are of the CRNN workload
-                traffic, traffic_src = pmc_traffic(dom) if args.workload == "crnn" else (None, None)
-                roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                            "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
-                            "algorithmic_bytes_per_launch": round(algo_bytes[dom] / n) if dom in algo_bytes else None,
-                            "avg_launch_us": round(1e3 * t_ms / n, 2), "launches": n,
-                            "flops_per_launch": fl / n,
-                            "measured": "HIP events around every launch, %s" %
-                                        ("eager pass after the graph-replayed timed region" if use_graph
-                                         else "inside the timed region")}
-        if args.workload == "res50ppm":
-            metric_name = "training images/sec, ResNet50-PPM-2D-CTC 32x128 crops, batch %d per GPU" % args.batch
-            workload_name = ("ResNet50-dilated-PPM + 2D-CTC training step (BASELINE.json configs[2]): 32x128 crops, "
-                             "T=16 H=4 C=38, Adam")
-            fwd_flops = 6.02e9  # forward FLOPs per 32x128 image
+        for _ in range(warmup if not (distributed and use_graph) else 0):
+            step()
+        graphed = None
+        if use_graph:
+            # the whole step (zero_grad, forward, CTC, backward, fused Adam) as ONE captured hipGraph; the timed region
+            # replays it.  Same kernels, same work -- only the ~150 host-side launches per step are gone.
+            from megreader_amd.runtime import GraphedTrainStep, data_parallel_grad_sync
+
+            def loss_fn(i, l, n):
+                loss, _ = net(i, targets=l, lengths=n, train=True)
+                return loss.mean()
+
+            ddp_launch = None
+            if distributed and args.ddp_mode in ("auto", "capture"):
+                # ONE graph: forward, backward with the shim's per-bucket all-reduces on its side stream (captured as a
+                # parallel branch: they overlap the rest of backward), finalisation, fused Adam
+                try:
+                    net = ddp_shim
+                    graphed = GraphedTrainStep(loss_fn, opt, [img, lab, ln], warmup=max(2, warmup), grad_sync=None)
+                    ddp_launch = "hipGraph replay with in-graph bucketed RCCL all-reduce (overlapped with backward)"
+                except Exception as e:  # noqa: BLE001 - any capture failure falls back to the two-graph path
+                    if args.ddp_mode == "capture":
+                        raise
+                    print("in-graph collective capture failed (%s: %s); falling back to --ddp-mode graph2" %
+                          (type(e).__name__, e), file=sys.stderr)
+                    torch.cuda.synchronize()
+                    net = model
+                    graphed = None
+            if graphed is None:
+                net = model
+                sync = data_parallel_grad_sync(opt) if distributed else None
+                graphed = GraphedTrainStep(loss_fn, opt, [img, lab, ln], warmup=max(2, warmup if distributed else 2),
+                                           grad_sync=sync)
+                if distributed:
+                    ddp_launch = "2 hipGraphs + eager in-place RCCL all-reduce of the flat gradients"
+            run = graphed
         else:
-            metric_name = "training images/sec, CRNN-CTC 32x128 crops, batch 256 per GPU"
-            workload_name = "CRNN + 1D-CTC training step (BASELINE.json configs[1]): 32x128 crops, T=33, C=38, Adam"
-            fwd_flops = 1.80e9
-        out = {
-            "metric": metric_name,
-            "value": round(images / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": workload_name, "global_batch": args.batch * world,
-                       "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
-                       "launch": ("hipGraph replay" if not distributed else ddp_launch) if use_graph
-                       else ("eager" if not distributed else "eager, apex-style DDP shim (bucketed, overlapped)"),
-                       "train_flops_per_image": 3 * fwd_flops},
-            "final_loss": final_loss,
-            "roofline": roofline,
-            "kernels": kernels,
-        }
-        step_tflops = 3 * fwd_flops * args.batch / (ms * 1e-3) / 1e12
-        out["step_tflops_per_gpu"] = round(step_tflops, 2)
-        out["host_enqueue_ms_per_step"] = round(1e3 * host_enqueue / args.steps, 3)
-        if world == 1 and not args.no_cpu_baseline and args.workload == "crnn":
-            out["cpu_baseline"] = cpu_baseline()
+            run = step
+        timer = None
+        if not args.no_kernel_timer and not use_graph:
+            timer = _lib.KernelTimer(["mr_conv2d_fwd", "mr_conv2d_dgrad", "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab"])
+            _lib.TIMER = timer
+        barrier()
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(steps):
+            last = run()
+        host_enqueue = time.perf_counter() - t0   # host time to enqueue all steps (GPU still running)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        _lib.TIMER = None
+        final_loss = float(last.detach())
+        if use_graph and not args.no_kernel_timer:
+            # HIP events cannot bracket kernels inside a graph replay: measure the dominant kernel's launch durations
+            # on the same stream with the same tensors in an eager pass right after the timed region
+            timer = _lib.KernelTimer(["mr_conv2d_fwd", "mr_conv2d_dgrad", "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab"])
+            _lib.TIMER = timer
+            timer_steps = min(steps, 10)
+            for _ in range(timer_steps):
+                step()
+            torch.cuda.synchronize()
+            _lib.TIMER = None
         else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
+            timer_steps = steps
+        if distributed:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t)
+
+        if rank == 0:
+            ms = 1e3 * elapsed / steps
+            images = args.batch * world * steps
+            # ---- roofline of the dominant MFMA kernel from the live HIP-event records
+            roofline = None
+            kernels = {}
+            if timer is not None:
+                agg = {}
+                algo_bytes = {}
+                for name, cargs, t_ms in timer.results():
+                    label = kernel_label(lib, name, cargs, args.dtype)
+                    fl, pix, cout, cin = conv_flops(name, cargs)
+                    # algorithmic bytes of the launch: both activation tensors once + the weights once (2-byte elements)
+                    es = 2 if args.dtype == "bf16" else 4
+                    algo_bytes[label] = algo_bytes.get(label, 0.0) + es * (pix * cout + pix * cin) + es * fl / (2.0 * pix)
+                    a = agg.setdefault(label, [0.0, 0.0, 0])
+                    a[0] += fl
+                    a[1] += t_ms
+                    a[2] += 1
+                for label, (fl, t_ms, n) in agg.items():
+                    kernels[label] = {"launches_per_step": n / timer_steps, "avg_us": round(1e3 * t_ms / n, 2),
+                                      "tflops": round(fl / (t_ms * 1e-3) / 1e12, 1),
+                                      "ms_per_step": round(t_ms / timer_steps, 4)}
+                if agg:
+                    dom = max(agg, key=lambda k: agg[k][1])
+                    fl, t_ms, n = agg[dom]
+                    ach = fl / (t_ms * 1e-3) / 1e12
+                    peak = MFMA_PEAK_TFLOPS[args.dtype]
+                    # the committed PMC passes are of the CRNN workload
+                    traffic, traffic_src = pmc_traffic(dom) if workload == "crnn" else (None, None)
+                    roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                                "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
+                                "algorithmic_bytes_per_launch": round(algo_bytes[dom] / n) if dom in algo_bytes else None,
+                                "avg_launch_us": round(1e3 * t_ms / n, 2), "launches": n,
+                                "flops_per_launch": fl / n,
+                                "measured": "HIP events around every launch, %s" %
+                                            ("eager pass after the graph-replayed timed region" if use_graph
+                                             else "inside the timed region")}
+            if workload == "res50ppm":
+                metric_name = "training images/sec, ResNet50-PPM-2D-CTC 32x128 crops, batch %d per GPU" % args.batch
+                workload_name = ("ResNet50-dilated-PPM + 2D-CTC training step (BASELINE.json configs[2]): 32x128 crops, "
+                                 "T=16 H=4 C=38, Adam")
+                fwd_flops = 6.02e9  # BASELINE.md: forward FLOPs per 32x128 image
+            else:
+                metric_name = "training images/sec, CRNN-CTC 32x128 crops, batch 256 per GPU"
+                workload_name = "CRNN + 1D-CTC training step (BASELINE.json configs[1]): 32x128 crops, T=33, C=38, Adam"
+                fwd_flops = 1.80e9
+            out = {
+                "metric": metric_name,
+                "value": round(images / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": steps,
+                "warmup": warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": workload_name, "global_batch": args.batch * world,
+                           "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
+                           "launch": ("hipGraph replay" if not distributed else ddp_launch) if use_graph
+                           else ("eager" if not distributed else "eager, apex-style DDP shim (bucketed, overlapped)"),
+                           "train_flops_per_image": 3 * fwd_flops},
+                "final_loss": final_loss,
+                "roofline": roofline,
+                "kernels": kernels,
+            }
+            step_tflops = 3 * fwd_flops * args.batch / (ms * 1e-3) / 1e12
+            out["step_tflops_per_gpu"] = round(step_tflops, 2)
+            out["host_enqueue_ms_per_step"] = round(1e3 * host_enqueue / steps, 3)
+            if world == 1 and with_cpu and workload == "crnn":
+                out["cpu_baseline"] = cpu_baseline()
+            else:
+                out["cpu_baseline"] = None
+        else:
+            out = None
+        return out
+
+    out = measure(args.workload, args.steps, args.warmup, not args.no_cpu_baseline)
+    if out is not None and world == 1 and not distributed and args.workload == "crnn" and not args.no_secondary:
+        # BASELINE.json north_star target #2 (configs[2]) rides along in the default single-GPU line
+        sec = measure("res50ppm", min(args.steps, 10), min(args.warmup, 3), False)
+        for k in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "cpu_baseline"):
+            sec.pop(k, None)
+        out["secondary"] = sec
     if distributed:
-        dist.destroy_process_group()
+        dist.destroy_process_group()   # RCCL prints its version banner here: keep the JSON line the LAST line
+    if out is not None:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

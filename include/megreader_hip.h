@@ -274,6 +274,19 @@ int mr_dcn2_col2im(int dtype, const void* gcol, const float* offset, long long o
                    long long msk_bs, float* dx, int N, int H, int W, int C, int kh, int kw, int stride, int pad,
                    int dil, int Ho, int Wo, hipStream_t stream);
 
+/* single-call forms (replace modulated_deform_conv_cuda_forward / _backward,
+ * assets/ops/dcn/src/deform_conv_cuda.cpp:486-679).  Caller owns all buffers incl. the column workspace
+ * col_ws [N*Ho*Wo, kh*kw*C] (`dtype`); w_n [Co][kh*kw*C] / w_t [kh*kw*C][Co] are the mr_prep_matrix images of the KRSC
+ * weight; dx32 / doffset / dmask pre-zeroed (accumulated / partially written), dw f32 [Co][kh*kw*C] and dbias f32 [Co]
+ * accumulated; dx32, dw, dbias may be null. */
+int mr_dcn2_fwd(int dtype, const void* x, const void* w_n, const float* bias, const float* offset, long long off_bs,
+                const float* mask, long long msk_bs, void* y, void* col_ws, int N, int H, int W, int C, int Co, int kh,
+                int kw, int stride, int pad, int dil, int Ho, int Wo, hipStream_t stream);
+int mr_dcn2_bwd(int dtype, const void* dy, const void* x, const void* w_t, const float* offset, long long off_bs,
+                const float* mask, long long msk_bs, void* col_ws, float* dx32, float* doffset, float* dmask, float* dw,
+                float* dbias, int N, int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int Ho,
+                int Wo, hipStream_t stream);
+
 /* ---- Attention-GRU decoder step kernels (decoders/attention_decoder.py:146-231; the GEMMs use mr_gemm_nt/tn) ----- */
 int mr_attn_step_fwd(int dtype, const void* hproj, const void* eproj, const float* v, const void* enc, float* weights,
                      void* context, int N, int T, int Hd, int Ep, hipStream_t stream);
@@ -290,6 +303,12 @@ int mr_nll_step_fwd(int dtype, const void* logits, int ldl, const long long* tar
                     int softmax_out, hipStream_t stream);
 int mr_nll_step_bwd(int dtype, const float* gloss, const float* lp, const long long* target, long long tstride,
                     const float* mask, void* dlogits, int ldd, int N, int C, hipStream_t stream);
+/* word embedding of the attention decoder (decoders/attention_decoder.py:187-193): out[n, :D] = table[idx[n]] cast to
+ * `dtype`, columns D..ldo-1 zeroed; backward scatter-adds into the f32 table gradient */
+int mr_embed_rows_fwd(int dtype, const long long* idx, const float* table, void* out, int N, int V, int D, int ldo,
+                      hipStream_t stream);
+int mr_embed_rows_bwd(int dtype, const long long* idx, const void* dout, float* dtable, int N, int V, int D, int ldo,
+                      hipStream_t stream);
 /* eval head: softmax over classes of logits [T,N,C] -> f32 [N,C,1,T] (decoders/crnn.py:101-104) */
 int mr_softmax_nc1t(int dtype, const void* logits, int ldl, float* out, int T, int N, int C, hipStream_t stream);
 

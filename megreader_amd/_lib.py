@@ -65,10 +65,14 @@ SIGNATURES = {
     "mr_dcn2_im2col": "ipplplp" + "i" * 11 + "s",
     "mr_dcn2_coord_grad": "ippplplpp" + "i" * 11 + "s",
     "mr_dcn2_col2im": "ipplplp" + "i" * 11 + "s",
+    "mr_dcn2_fwd": "ippp" + "plpl" + "pp" + "i" * 12 + "s",
+    "mr_dcn2_bwd": "ippp" + "plpl" + "pppppp" + "i" * 12 + "s",
     "mr_attn_step_fwd": "ipppppp" + "iiii" + "s",
     "mr_attn_step_bwd": "ippppppppppp" + "iiii" + "s",
     "mr_gru_gates_fwd": "ippppppiis",
     "mr_gru_gates_bwd": "ipppppppiis",
+    "mr_embed_rows_fwd": "ipppiiiis",
+    "mr_embed_rows_bwd": "ipppiiiis",
     "mr_nll_step_fwd": "ipiplppppiiiis",
     "mr_nll_step_bwd": "ippplppiiis",
     "mr_ctc_greedy_decode": "iplll" + "iiiii" + "pps",

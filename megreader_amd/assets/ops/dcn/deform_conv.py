@@ -52,11 +52,10 @@ class ModulatedDeformConvFunction(Function):
         w_n = torch.empty((Co, K), dtype=dtype, device=xi.device)
         w_t = torch.empty((K, Co), dtype=dtype, device=xi.device)
         call("mr_prep_matrix", dt, ptr(wk), K, ptr(w_n), K, ptr(w_t), Co, Co, K, 0)
-        col = torch.empty((N * Ho * Wo, K), dtype=dtype, device=xi.device)
-        call("mr_dcn2_im2col", dt, ptr(xi), ptr(off), off_bs, ptr(msk), msk_bs, ptr(col), N, H, W, C, kh, kw,
-             stride, padding, dilation, Ho, Wo)
+        col = torch.empty((N * Ho * Wo, K), dtype=dtype, device=xi.device)      # the reference's `columns` scratch
         y = torch.empty((N, Ho, Wo, Co), dtype=dtype, device=xi.device)
-        call("mr_gemm_nt", dt, ptr(col), K, ptr(w_n), K, ptr(y), Co, ptr(bias), 0, N * Ho * Wo, Co, K)
+        call("mr_dcn2_fwd", dt, ptr(xi), ptr(w_n), ptr(bias), ptr(off), off_bs, ptr(msk), msk_bs, ptr(y), ptr(col), N, H,
+             W, C, Co, kh, kw, stride, padding, dilation, Ho, Wo)
         ctx.save_for_backward(xi, off, msk, w_t)
         ctx.geom = (N, H, W, C, Co, kh, kw, stride, padding, dilation, Ho, Wo, off_bs, msk_bs)
         ctx.with_bias = bias is not None
@@ -76,32 +75,28 @@ class ModulatedDeformConvFunction(Function):
         K = kh * kw * C
         P = N * Ho * Wo
         g = _grad_internal(grad_output, dtype)
-        gcol = torch.empty((P, K), dtype=dtype, device=dev)
-        call("mr_gemm_nt", dt, ptr(g), Co, ptr(w_t), Co, ptr(gcol), K, 0, 0, P, K, Co)
-        geo = (N, H, W, C, kh, kw, stride, padding, dilation, Ho, Wo)
+        col = torch.empty((P, K), dtype=dtype, device=dev)      # dy * W, then the recomputed column matrix
         grad_offset = torch.zeros_like(off)
         grad_mask = torch.zeros_like(msk)
-        call("mr_dcn2_coord_grad", dt, ptr(gcol), ptr(xi), ptr(off), off_bs, ptr(msk), msk_bs, ptr(grad_offset),
-             ptr(grad_mask), *geo)
+        want_dx = ctx.needs_input_grad[0]
+        want_dw = ctx.needs_input_grad[3]
+        want_db = ctx.with_bias and ctx.needs_input_grad[4]
+        dx32 = torch.zeros((N, H, W, C), dtype=torch.float32, device=dev) if want_dx else None
+        gw = torch.zeros((Co, kh, kw, C), dtype=torch.float32, device=dev) if want_dw else None
+        gb = torch.zeros((Co,), dtype=torch.float32, device=dev) if want_db else None
+        call("mr_dcn2_bwd", dt, ptr(g), ptr(xi), ptr(w_t), ptr(off), off_bs, ptr(msk), msk_bs, ptr(col), ptr(dx32),
+             ptr(grad_offset), ptr(grad_mask), ptr(gw), ptr(gb), N, H, W, C, Co, kh, kw, stride, padding, dilation, Ho,
+             Wo)
         grad_input = None
-        if ctx.needs_input_grad[0]:
-            dx32 = torch.zeros((N, H, W, C), dtype=torch.float32, device=dev)
-            call("mr_dcn2_col2im", dt, ptr(gcol), ptr(off), off_bs, ptr(msk), msk_bs, ptr(dx32), *geo)
+        if want_dx:
             if dtype == torch.float32:
                 dxi = dx32
             else:
                 dxi = torch.empty((N, H, W, C), dtype=dtype, device=dev)
                 call("mr_cast", 0, ptr(dx32), dt, ptr(dxi), dx32.numel())
             grad_input = dxi.permute(0, 3, 1, 2)
-        grad_weight = grad_bias = None
-        if ctx.needs_input_grad[3] or (ctx.with_bias and ctx.needs_input_grad[4]):
-            col = gcol  # reuse the buffer: recompute the forward column matrix (the reference does the same)
-            call("mr_dcn2_im2col", dt, ptr(xi), ptr(off), off_bs, ptr(msk), msk_bs, ptr(col), *geo)
-            gw = torch.zeros((Co, kh, kw, C), dtype=torch.float32, device=dev)
-            gb = torch.zeros((Co,), dtype=torch.float32, device=dev) if ctx.with_bias else None
-            call("mr_gemm_tn", dt, ptr(g), Co, ptr(col), K, ptr(gw), K, P, Co, K, 0, ptr(gb))
-            grad_weight = gw.permute(0, 3, 1, 2)
-            grad_bias = gb
+        grad_weight = gw.permute(0, 3, 1, 2) if want_dw else None
+        grad_bias = gb
         oshape, odtype, mshape, mdtype = ctx.off_meta
         return (grad_input, grad_offset.to(odtype), grad_mask.to(mdtype), grad_weight, grad_bias, None, None, None,
                 None, None)
@@ -170,14 +165,85 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
                                      self.dilation, self.groups, self.deformable_groups)
 
 
-def deform_conv(*a, **k):
-    raise NotImplementedError("DeformConv v1 is exported by the reference but used by no model (SURVEY.md §2b)")
+class DeformConvFunction(Function):
+    """DCN v1 (reference functions/deform_conv.py:10-105; kernels deform_conv_cuda_kernel.cu:189-464): the v2 kernels with
+    a mask of ones -- same flat offset indexing, same validity rule (deform_conv_cuda_kernel.cu:254-263 / 617).
+    groups = deformable_groups = 1; `im2col_step` only tiles the reference's per-image loop and is ignored."""
+
+    @staticmethod
+    def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
+                im2col_step=64):
+        if input is not None and input.dim() != 4:
+            raise ValueError("Expected 4D tensor as input, got {}D tensor instead.".format(input.dim()))
+        stride, padding, dilation = _pair(stride)[0], _pair(padding)[0], _pair(dilation)[0]
+        kh, kw = weight.shape[2:4]
+        Ho = (input.shape[2] + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
+        Wo = (input.shape[3] + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+        if not (Ho > 0 and Wo > 0):
+            raise ValueError("convolution input is too small (output would be {}x{})".format(Ho, Wo))
+        ones = torch.ones((input.shape[0], kh * kw, Ho, Wo), dtype=torch.float32, device=input.device)
+        return ModulatedDeformConvFunction.apply(input, offset, ones, weight, None, stride, padding, dilation, groups,
+                                                 deformable_groups)
+
+    @staticmethod
+    def backward(ctx, *g):  # pragma: no cover - forward returns the v2 Function's graph
+        raise RuntimeError("unreachable")
+
+
+def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, im2col_step=64):
+    return DeformConvFunction.forward(None, input, offset, weight, stride, padding, dilation, groups, deformable_groups,
+                                      im2col_step)
 
 
 class DeformConv(nn.Module):
-    def __init__(self, *a, **k):
-        super().__init__()
-        raise NotImplementedError("DeformConv v1 is exported by the reference but used by no model (SURVEY.md §2b)")
+    """reference modules/deform_conv.py:11-57"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super(DeformConv, self).__init__()
+        assert not bias
+        assert in_channels % groups == 0 and out_channels % groups == 0
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = _pair(stride)
+        self.padding = _pair(padding)
+        self.dilation = _pair(dilation)
+        self.groups = groups
+        self.deformable_groups = deformable_groups
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // self.groups, *self.kernel_size))
+        self.reset_parameters()
+        self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)  # physical KRSC
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                           self.deformable_groups)
 
 
-DeformConvPack = DeformConv
+class DeformConvPack(DeformConv):
+    """reference modules/deform_conv.py:60-81"""
+
+    def __init__(self, *args, **kwargs):
+        super(DeformConvPack, self).__init__(*args, **kwargs)
+        from ....nn import Conv2d
+        self.conv_offset = Conv2d(self.in_channels,
+                                  self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
+                                  kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding),
+                                  bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        offset = self.conv_offset(x)
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                           self.deformable_groups)

@@ -6,6 +6,7 @@ reference succeed.
   anyconfig.load(path)  -> yaml.safe_load            (reference concern/config.py:12-14)
   munch.munchify(d)     -> attribute dict            (reference concern/config.py:14)
   editdistance.eval     -> plain DP edit distance    (reference structure/measurers/sequence_recognition_measurer.py)
+  tensorboardX.SummaryWriter -> no-op writer          (reference concern/log.py:75)
   everything else       -> inert placeholder modules that raise on use
 """
 import importlib
@@ -59,8 +60,9 @@ def _edit_distance(a, b):
     return prev[-1]
 
 
-PLACEHOLDERS = ["tensorboardX", "cv2", "imgaug", "imgaug.augmenters", "shapely", "shapely.geometry", "pyclipper",
-                "hanziconv", "ipdb", "gevent", "gevent.pywsgi", "lmdb", "redis", "boto3", "torchvision",
+PLACEHOLDERS = ["cv2", "imgaug", "imgaug.augmenters", "shapely", "shapely.geometry", "pyclipper",
+                "hanziconv", "ipdb", "gevent", "gevent.pywsgi", "lmdb", "redis", "boto3", "botocore", "botocore.exceptions",
+                "torchvision",
                 "torchvision.transforms", "torchvision.datasets", "nori2", "fire", "geventwebsocket",
                 "geventwebsocket.handler"]
 
@@ -94,6 +96,20 @@ def install():
         m = types.ModuleType("editdistance")
         m.eval = _edit_distance
         sys.modules["editdistance"] = m
+    if missing("tensorboardX"):
+        m = types.ModuleType("tensorboardX")
+
+        class SummaryWriter(object):
+            """No-op stand-in (concern/log.py:75 constructs one unconditionally): every add_* call is accepted and dropped."""
+
+            def __init__(self, *a, **k):
+                pass
+
+            def __getattr__(self, name):
+                return lambda *a, **k: None
+
+        m.SummaryWriter = SummaryWriter
+        sys.modules["tensorboardX"] = m
     for name in PLACEHOLDERS:
         if missing(name.split(".")[0]) or (name in sys.modules and isinstance(sys.modules[name], _Placeholder)) \
                 or (name.split(".")[0] in sys.modules and isinstance(sys.modules[name.split(".")[0]], _Placeholder)):

@@ -223,6 +223,32 @@ static inline int grid_for(long long n, int block, int max_blocks = 8192) {
   return (int)b;
 }
 
+// Word embedding of the attention decoder (decoders/attention_decoder.py:187-193, nn.Embedding(V, V) initialised to
+// the identity and TRAINABLE): out[n, 0:D] = table[idx[n], :] in the compute dtype, columns D..ldo-1 zero (the padded
+// input of word_linear); backward scatter-adds dout rows into the f32 table gradient (several samples usually pick
+// the same row: atomics).
+template <typename T>
+__global__ void embed_rows_fwd_kernel(const long long* __restrict__ idx, const float* __restrict__ table, T* __restrict__ out,
+                                      int N, int V, int D, int ldo) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= N * ldo) return;
+  const int n = gid / ldo, c = gid - n * ldo;
+  const long long r = idx[n];
+  float v = 0.f;
+  if (c < D && r >= 0 && r < V) v = table[r * D + c];
+  out[gid] = from_f32<T>(v);
+}
+
+template <typename T>
+__global__ void embed_rows_bwd_kernel(const long long* __restrict__ idx, const T* __restrict__ dout, float* __restrict__ dtable,
+                                      int N, int V, int D, int ldo) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= N * D) return;
+  const int n = gid / D, c = gid - n * D;
+  const long long r = idx[n];
+  if (r >= 0 && r < V) atomicAdd(dtable + r * D + c, to_f32(dout[(long long)n * ldo + c]));
+}
+
 }  // namespace mr
 
 using namespace mr;
@@ -288,6 +314,26 @@ int mr_nll_step_bwd(int dtype, const float* gloss, const float* lp, const long l
                     const float* mask, void* dlogits, int ldd, int N, int C, hipStream_t stream) {
   DISPATCH_T(dtype, hipLaunchKernelGGL((nll_step_bwd_kernel<T>), dim3(grid_for((long long)N * C, 256)), dim3(256), 0,
                                        stream, gloss, lp, target, tstride, mask, (T*)dlogits, ldd, N, C));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+// out: [N, ldo] (`dtype`), table f32 [V, D] row-major, idx i64 [N]
+int mr_embed_rows_fwd(int dtype, const long long* idx, const float* table, void* out, int N, int V, int D, int ldo,
+                      hipStream_t stream) {
+  MR_CHECK_ARG(N > 0 && V > 0 && D > 0 && ldo >= D, "mr_embed_rows_fwd: bad shape N=%d V=%d D=%d ldo=%d", N, V, D, ldo);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((embed_rows_fwd_kernel<T>), dim3(grid_for((long long)N * ldo, 256)), dim3(256), 0,
+                                       stream, idx, table, (T*)out, N, V, D, ldo));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+// dtable f32 [V, D] is ACCUMULATED into (atomics)
+int mr_embed_rows_bwd(int dtype, const long long* idx, const void* dout, float* dtable, int N, int V, int D, int ldo,
+                      hipStream_t stream) {
+  MR_CHECK_ARG(N > 0 && V > 0 && D > 0 && ldo >= D, "mr_embed_rows_bwd: bad shape N=%d V=%d D=%d ldo=%d", N, V, D, ldo);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((embed_rows_bwd_kernel<T>), dim3(grid_for((long long)N * D, 256)), dim3(256), 0,
+                                       stream, idx, (const T*)dout, dtable, N, V, D, ldo));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

@@ -236,4 +236,49 @@ int mr_dcn2_col2im(int dtype, const void* gcol, const float* offset, long long o
   return MR_OK;
 }
 
+// ---- single-call forms: what `modulated_deform_conv_cuda_forward / _backward`
+// (assets/ops/dcn/src/deform_conv_cuda.cpp:486-679) are to the reference's python Function.  The caller owns every
+// buffer, including the column workspace (the reference passes `columns` the same way, functions/deform_conv.py:135).
+// x / y / dy NHWC in `dtype`; w_n [Co][kh*kw*C] and w_t [kh*kw*C][Co] in `dtype` (mr_prep_matrix images of the KRSC
+// weight); col_ws [N*Ho*Wo, kh*kw*C] in `dtype`.
+int mr_dcn2_fwd(int dtype, const void* x, const void* w_n, const float* bias, const float* offset, long long off_bs,
+                const float* mask, long long msk_bs, void* y, void* col_ws, int N, int H, int W, int C, int Co, int kh,
+                int kw, int stride, int pad, int dil, int Ho, int Wo, hipStream_t stream) {
+  int rc = mr_dcn2_im2col(dtype, x, offset, off_bs, mask, msk_bs, col_ws, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo,
+                          stream);
+  if (rc) return rc;
+  const int K = kh * kw * C;
+  return mr_gemm_nt(dtype, col_ws, K, w_n, K, y, Co, bias, 0, N * Ho * Wo, Co, K, stream);
+}
+
+// dx32 (nullable): f32 NHWC, pre-zeroed, accumulated; doffset / dmask: f32, shaped like offset / mask, pre-zeroed;
+// dw (nullable): f32 [Co][kh*kw*C] accumulated; dbias (nullable): f32 [Co] accumulated.  col_ws is used twice (dy * W,
+// then the recomputed column matrix for dW), exactly like `columns` in deform_conv_cuda.cpp:611-665.
+int mr_dcn2_bwd(int dtype, const void* dy, const void* x, const void* w_t, const float* offset, long long off_bs,
+                const float* mask, long long msk_bs, void* col_ws, float* dx32, float* doffset, float* dmask, float* dw,
+                float* dbias, int N, int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int Ho,
+                int Wo, hipStream_t stream) {
+  const int K = kh * kw * C, P = N * Ho * Wo;
+  int rc = mr_gemm_nt(dtype, dy, Co, w_t, Co, col_ws, K, nullptr, 0, P, K, Co, stream);   // gcol = dy * W
+  if (rc) return rc;
+  rc = mr_dcn2_coord_grad(dtype, col_ws, x, offset, off_bs, mask, msk_bs, doffset, dmask, N, H, W, C, kh, kw, stride,
+                          pad, dil, Ho, Wo, stream);
+  if (rc) return rc;
+  if (dx32) {
+    rc = mr_dcn2_col2im(dtype, col_ws, offset, off_bs, mask, msk_bs, dx32, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo,
+                        stream);
+    if (rc) return rc;
+  }
+  if (dw || dbias) {
+    rc = mr_dcn2_im2col(dtype, x, offset, off_bs, mask, msk_bs, col_ws, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo,
+                        stream);
+    if (rc) return rc;
+    if (dw)
+      rc = mr_gemm_tn(dtype, dy, Co, col_ws, K, dw, K, P, Co, K, 0, dbias, stream);
+    else
+      rc = mr_colsum(dtype, dy, dbias, P, Co, Co, 0, stream);
+  }
+  return rc;
+}
+
 }  // extern "C"

@@ -155,6 +155,32 @@ class _GruGatesFn(Function):
         return dgi, dgi, dgh, dh, None
 
 
+class _EmbedRowsFn(Function):
+    """emb = embedding(word_idx) as the padded compute-dtype input of word_linear (attention_decoder.py:187-193, 203):
+    one gather kernel forward, one scatter-add (f32 atomics into the table gradient) backward."""
+
+    @staticmethod
+    def forward(ctx, idx, table, ldo, dtype):
+        idx = idx.to(torch.int64).contiguous()
+        tab = table if (table.dtype == torch.float32 and table.is_contiguous()) else table.float().contiguous()
+        N, (V, D) = idx.shape[0], tab.shape
+        out = torch.empty((N, ldo), dtype=dtype, device=idx.device)
+        call("mr_embed_rows_fwd", dtype_code(dtype), ptr(idx), ptr(tab), ptr(out), N, V, D, ldo)
+        ctx.save_for_backward(idx)
+        ctx.meta = (V, D, ldo, dtype, table.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        V, D, ldo, dtype, tdtype = ctx.meta
+        if g.dtype != dtype or not g.is_contiguous():
+            g = g.to(dtype).contiguous()
+        dtab = torch.zeros((V, D), dtype=torch.float32, device=g.device)
+        call("mr_embed_rows_bwd", dtype_code(dtype), ptr(idx), ptr(g), ptr(dtab), idx.shape[0], V, D, ldo)
+        return None, dtab.to(tdtype), None, None
+
+
 class _NllStepFn(Function):
     """loss[n] = NLLLoss(log_softmax(logits), target)[n] * mask[n]; also returns argmax (attention_decoder.py:95-106)."""
 
@@ -305,8 +331,7 @@ class AttentionDecoder(nn.Module):
             first = t == 0
             # embedding is a trainable [V, V] table initialised to the identity (attention_decoder.py:190-191): look
             # the row up (tiny gather, torch) and run word_linear on it
-            emb = torch.nn.functional.embedding(word_idx, cell.embedding.weight)
-            word = lin_word(torch.nn.functional.pad(emb, (0, Cp - C)).to(dtype))
+            word = lin_word(_EmbedRowsFn.apply(word_idx, cell.embedding.weight, Cp, dtype))
             w, context = _AttnStepFn.apply(lin_h(hidden), eproj, enc, cell.attn.v, att_state, first)
             hnew = _GruGatesFn.apply(lin_iw(word), lin_ic(context), lin_hh(hidden), hidden, dtype)
             return lin_out(hnew), hnew, w

@@ -27,14 +27,25 @@ OVERRIDES = {
 }
 
 
-def install(reference_root=None):
+def install(reference_root=None, level="plugin"):
+    """level="plugin" (default): the reference's `ops` package is replaced by megreader_amd.ops (our CTCLoss2DFunction).
+    level="extension": the reference's OWN `ops/ctc_2d/ctc_loss_2d.py` is used unchanged and only the pybind11 module it
+    binds (`ops.ctc_2d.ctc_2d_csrc`, ops/ctc_2d/ctc_loss_2d.py:3) resolves to the HIP implementation
+    (megreader_amd.ops.ctc_2d.ctc_2d_csrc) -- the boundary SURVEY.md §8 b2 names.  Needs the reference tree on the path.
+    """
     from . import compat
     compat.install()
     from . import apex as _apex
     sys.modules["apex"] = _apex
     sys.modules["apex.parallel"] = _apex.parallel
     from . import ops as _ops
-    sys.modules.setdefault("ops", _ops)
+    if level == "extension":
+        from .ops.ctc_2d import ctc_2d_csrc as _csrc
+        sys.modules["ops.ctc_2d.ctc_2d_csrc"] = _csrc
+        if sys.modules.get("ops") is _ops:
+            del sys.modules["ops"]
+    else:
+        sys.modules.setdefault("ops", _ops)
     # `from assets.ops.dcn import ModulatedDeformConv` (backbones/resnet.py:59-64,129-134): the reference's package
     # imports its CUDA extension at import time, so the HIP mirror is registered under the same dotted name
     from .assets.ops import dcn as _dcn

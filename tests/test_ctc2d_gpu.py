@@ -98,3 +98,29 @@ def test_errors_like_reference():
     with pytest.raises(RuntimeError):
         ctc_loss_2d(lpd, torch.zeros(1, 2, dtype=torch.long, device=DEV), torch.tensor([4], device=DEV),
                     torch.tensor([1], device=DEV), 7)
+
+
+def test_extension_level_ctc_2d_csrc_calling_sequence():
+    """`ops.ctc_2d.ctc_2d_csrc.ctc2d_forward / ctc2d_backward` (csrc/ctc2d.h:7-43) driven exactly as the reference's
+    own Function does (ops/ctc_2d/ctc_loss_2d.py:15-16,30-35; tests/test_b6_dropin_cpu.py shows that file binding this
+    module): forward returns (nll, log_alpha), backward consumes them."""
+    from megreader_amd.ops.ctc_2d import ctc_2d_csrc
+    T, H, N, C, S = 16, 4, 5, 38, 32
+    rng = np.random.RandomState(11)
+    tg, tl = _targets(N, S, C, rng, 1, 6)
+    il = np.full(N, T, dtype=np.int64)
+    lp, _, _ = synthetic_lp(T, H, N, C, seed=3)
+    go = rng.rand(N) + 0.5
+    ref = ctc2d(lp, tg, il, tl, blank=0, grad_out=go)
+    x = torch.from_numpy(lp).to(DEV)
+    args = (torch.from_numpy(tg).to(DEV), torch.from_numpy(il).to(DEV), torch.from_numpy(tl).to(DEV))
+    nll, log_alpha = ctc_2d_csrc.ctc2d_forward(x, *args, 0, torch.finfo().tiny)
+    assert tuple(log_alpha.shape) == (N, T, H, 2 * S + 1)
+    assert np.abs(nll.cpu().numpy() - ref['nll']).max() < 2e-5 * max(1.0, np.abs(ref['nll']).max())
+    grad = ctc_2d_csrc.ctc2d_backward(torch.from_numpy(go).float().to(DEV), x, *args, nll, log_alpha, 0)
+    assert grad.shape == x.shape
+    assert np.abs(grad.cpu().numpy() - ref['grad']).max() < 2e-4 * max(1e-3, np.abs(ref['grad']).max())
+    with pytest.raises(RuntimeError):       # AT_CHECK contiguous (ctc2d_cuda.cu:35)
+        ctc_2d_csrc.ctc2d_forward(x.permute(0, 1, 3, 2), *args, 0, 1e-30)
+    with pytest.raises(RuntimeError):       # blank out of range (ctc2d_cuda.cu:36)
+        ctc_2d_csrc.ctc2d_forward(x, *args, C, 1e-30)

@@ -95,3 +95,95 @@ def test_cpu_raises_like_reference():
     with pytest.raises(NotImplementedError):
         modulated_deform_conv(torch.zeros(1, 8, 4, 4), torch.zeros(1, 18, 4, 4), torch.ones(1, 9, 4, 4),
                               torch.zeros(8, 8, 3, 3))
+
+
+def _reference_function_calling_sequence(dcn_ext, input, offset, mask, weight, bias, stride, padding, dilation, gy):
+    """The body of the reference's ModulatedDeformConvFunction.forward / .backward (assets/ops/dcn/functions/
+    deform_conv.py:110-165) restated call for call against an extension module object: the caller allocates the output and
+    the zeroed gradients and hands over scratch `ones` / `columns` tensors -- what running the reference's own Function
+    file on top of `megreader_amd.assets.ops.dcn.deform_conv_cuda` does (the file itself is not on the GPU box)."""
+    with_bias = bias is not None
+    b = bias if with_bias else input.new_empty(1)
+    kh, kw = weight.shape[2:4]
+    n, co = input.size(0), weight.size(0)
+    ho = (input.shape[2] + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
+    wo = (input.shape[3] + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+    output = input.new_empty((n, co, ho, wo))
+    bufs = [input.new_empty(0), input.new_empty(0)]
+    dcn_ext.modulated_deform_conv_cuda_forward(input, weight, b, bufs[0], offset, mask, output, bufs[1], kh, kw, stride,
+                                               stride, padding, padding, dilation, dilation, 1, 1, with_bias)
+    grad_input, grad_offset, grad_mask = torch.zeros_like(input), torch.zeros_like(offset), torch.zeros_like(mask)
+    grad_weight, grad_bias = torch.zeros_like(weight), torch.zeros_like(b)
+    dcn_ext.modulated_deform_conv_cuda_backward(input, weight, b, bufs[0], offset, mask, bufs[1], grad_input, grad_weight,
+                                                grad_bias, grad_offset, grad_mask, gy, kh, kw, stride, stride, padding,
+                                                padding, dilation, dilation, 1, 1, with_bias)
+    return output, grad_input, grad_offset, grad_mask, grad_weight, (grad_bias if with_bias else None)
+
+
+@pytest.mark.parametrize("case", CASES[:3])
+def test_extension_level_entry_points_vs_oracle(case):
+    """`deform_conv_cuda.modulated_deform_conv_cuda_forward / _backward` (src/deform_conv_cuda.cpp:486-492,566-573): NCHW
+    fp32 in, caller-allocated NCHW outputs / zeroed gradients written in place, the offset passed as the NON-contiguous
+    channel slice of a 27-channel map exactly as backbones/resnet.py:162-164 produces it."""
+    from megreader_amd.assets.ops.dcn import deform_conv_cuda
+    N, C, Co, H, W, stride, pad, dil, omap, oscale = case
+    mr.set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(C + H + 1)
+    Ho = (H + 2 * pad - (dil * 2 + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * 2 + 1)) // stride + 1
+    oh, ow = omap if omap else (Ho, Wo)
+    x = torch.randn(N, C, H, W, generator=g)
+    om = torch.randn(N, 27, oh, ow, generator=g) * oscale
+    om[:, :18] = torch.floor(om[:, :18]) + 0.25 + 0.5 * torch.rand(N, 18, oh, ow, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) * 0.2
+    b = torch.randn(Co, generator=g)
+    gy = torch.randn(N, Co, Ho, Wo, generator=g)
+    omd = om.to(DEV)
+    offset = omd[:, :18]                         # non-contiguous view across the batch
+    mask = torch.sigmoid(omd[:, 18:27])
+    assert not offset.is_contiguous()
+    out = _reference_function_calling_sequence(deform_conv_cuda, x.to(DEV), offset, mask, w.to(DEV), b.to(DEV), stride,
+                                               pad, dil, gy.to(DEV))
+    xr = x.double().requires_grad_(True)
+    offr = om[:, :18].double().contiguous().requires_grad_(True)
+    mskr = torch.sigmoid(om[:, 18:27]).double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    yr = modulated_deform_conv2d(xr, offr, mskr, wr, br, stride, pad, dil)
+    yr.backward(gy.double())
+    for got, want, name in zip(out, (yr, xr.grad, offr.grad, mskr.grad, wr.grad, br.grad),
+                               ("output", "grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias")):
+        assert got.shape == want.shape and got.dtype == torch.float32, name
+        assert _rel(got, want) < (2e-5 if name == "output" else 1e-4), name
+    with pytest.raises(RuntimeError):            # AT_CHECK(input.is_contiguous()), deform_conv_cuda.cpp:493
+        deform_conv_cuda.modulated_deform_conv_cuda_forward(
+            x.to(DEV).permute(0, 1, 3, 2), w.to(DEV), b.to(DEV), x.new_empty(0), offset, mask,
+            torch.empty(N, Co, Ho, Wo, device=DEV), x.new_empty(0), 3, 3, stride, stride, pad, pad, dil, dil, 1, 1, True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dcn_v1_vs_oracle(dtype):
+    """DeformConv (v1, reference functions/deform_conv.py:10-105): the v2 math with mask == 1."""
+    from megreader_amd.assets.ops.dcn import DeformConv, deform_conv
+    mr.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(5)
+    N, C, Co, H, W = 2, 16, 24, 8, 9
+    x = torch.randn(N, C, H, W, generator=g).to(dtype)
+    off = torch.floor(torch.randn(N, 18, H, W, generator=g) * 1.5) + 0.25 + 0.5 * torch.rand(N, 18, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) * 0.2
+    gy = torch.randn(N, Co, H, W, generator=g).to(dtype)
+    xr = x.double().requires_grad_(True)
+    offr = off.double().requires_grad_(True)
+    wr = w.to(dtype).double().requires_grad_(True)
+    yr = modulated_deform_conv2d(xr, offr, torch.ones(N, 9, H, W, dtype=torch.float64), wr, None, 1, 1, 1)
+    yr.backward(gy.double())
+    xd = x.to(DEV).requires_grad_(True)
+    offd = off.to(DEV).requires_grad_(True)
+    wd = w.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = deform_conv(xd, offd, wd, 1, 1, 1, 1, 1)
+    tol, gtol = (2e-5, 1e-4) if dtype == torch.float32 else (2e-2, 3e-2)
+    assert _rel(y, yr) < tol
+    y.backward(gy.to(DEV))
+    assert _rel(xd.grad, xr.grad) < gtol and _rel(offd.grad, offr.grad) < gtol and _rel(wd.grad, wr.grad) < gtol
+    m = DeformConv(C, Co, 3, padding=1).to(DEV)
+    assert m(xd.detach(), offd.detach()).shape == (N, Co, H, W)
