@@ -141,7 +141,7 @@ def test_extension_level_entry_points_vs_oracle(case):
     omd = om.to(DEV)
     offset = omd[:, :18]                         # non-contiguous view across the batch
     mask = torch.sigmoid(omd[:, 18:27])
-    assert not offset.is_contiguous()
+    assert N == 1 or not offset.is_contiguous()
     out = _reference_function_calling_sequence(deform_conv_cuda, x.to(DEV), offset, mask, w.to(DEV), b.to(DEV), stride,
                                                pad, dil, gy.to(DEV))
     xr = x.double().requires_grad_(True)
