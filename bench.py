@@ -120,9 +120,13 @@ def main():
                          "captured INSIDE the step graph on a side stream (overlapped with backward, zero host cost); "
                          "'graph2' = two graphs with one eager all-reduce between them (not overlapped); 'auto' = "
                          "capture, falling back to graph2 if the capture fails")
-    ap.add_argument("--workload", default="crnn", choices=["crnn", "res50ppm"],
+    ap.add_argument("--workload", default="crnn", choices=["crnn", "res50ppm", "fpn_attention", "db"],
                     help="crnn = BASELINE.json configs[1] (the metric's workload, default); res50ppm = configs[2]: "
-                         "ResNet50-dilated-PPM + 2D-CTC on 32x128 crops (secondary line, same JSON shape)")
+                         "ResNet50-dilated-PPM + 2D-CTC on 32x128 crops (secondary line, same JSON shape); "
+                         "fpn_attention = configs[3]: ResNet50-FPN + attention decoder on 64x256 crops, batch 32 per "
+                         "GPU (256 global on 8 GPUs), gt_as_output fixed for determinism; db = configs[4]: the DB detector "
+                         "(deformable ResNet-50 with 13 DCNv2 layers + SegDetector + L1BalanceCELoss, SGD) on 640x640 "
+                         "images, batch 2 per GPU (16 global on 8 GPUs); eager launches (the loss synchronises the host)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,12 +180,46 @@ def main():
                 def forward(self, data, *a, **k):
                     return self.decoder(self.backbone(data), *a, **k)
 
+        if workload == "fpn_attention":
+            from megreader_amd.backbones import Resnet50FPN
+            from megreader_amd.decoders import AttentionDecoder
+
+            class BasicModel(torch.nn.Module):  # noqa: F811  fpn50-attention-decoder.yaml: Resnet50FPN + AttentionDecoder
+                def __init__(self):
+                    super().__init__()
+                    self.backbone = Resnet50FPN(resnet_pretrained=False)     # no network on the box
+                    self.decoder = AttentionDecoder(in_channels=256, gt_as_output=True)
+
+                def forward(self, data, *a, **k):
+                    return self.decoder(self.backbone(data), *a, **k)
+
+        is_db = workload == "db"
+        if is_db:
+            from megreader_amd.backbones import deformable_resnet50
+            from megreader_amd.decoders import L1BalanceCELoss, SegDetector
+            from megreader_amd.optim import FusedSGD
+            from megreader_amd.synthetic import detection_batch
+
+            class BasicModel(torch.nn.Module):  # noqa: F811  seg_detector_db.yaml:47-62 (SegDetectorModel + its loss)
+                def __init__(self):
+                    super().__init__()
+                    self.backbone = deformable_resnet50(pretrained=False)
+                    self.decoder = SegDetector(in_channels=[256, 512, 1024, 2048], adaptive=True, k=50)
+                    self.criterion = L1BalanceCELoss()
+
+                def forward(self, batch):
+                    pred = self.decoder(self.backbone(batch['image']))
+                    return self.criterion(pred, batch)
+
         torch.manual_seed(0)
         model = BasicModel().to(dev).train()
-        opt = FusedAdam(model.parameters(), lr=1e-3)  # experiments/recognition/crnn.yaml:82-89 (both YAMLs use Adam)
+        if is_db:   # seg_detector_db.yaml:85-94: SGD momentum 0.9, weight decay 1e-4, lr 0.007
+            opt = FusedSGD(model.parameters(), lr=0.007, momentum=0.9, weight_decay=1e-4)
+        else:
+            opt = FusedAdam(model.parameters(), lr=1e-3)  # experiments/recognition/crnn.yaml:82-89 (both YAMLs use Adam)
         opt.zero_grad()
         net = model
-        use_graph = not args.no_graph
+        use_graph = not args.no_graph and not is_db   # the DB loss counts positives on the host (reference behaviour)
         if distributed and not use_graph:
             # eager data parallel: the apex-style shim (bucketed all-reduce overlapped with backward)
             from megreader_amd.apex.parallel import DistributedDataParallel
@@ -191,17 +229,28 @@ def main():
             # used by the 'capture' mode; 'graph2' works on the bare model with an eager flat all-reduce between two graphs
             from megreader_amd.apex.parallel import DistributedDataParallel
             ddp_shim = DistributedDataParallel(model)
-        if workload == "res50ppm":
-            batch = synthetic_batch_2d(args.batch, 32, 128, seed=rank, max_len=3)
+        bsz = args.batch
+        if is_db:
+            bsz = args.batch if args.batch != 256 else 2           # configs[4]: 16 global = 2 per GPU on 8 GPUs
+            dbatch = {k: v.to(dev) for k, v in detection_batch(bsz, 640, seed=rank).items()}
+            batch = {'image': dbatch['image'], 'label': torch.zeros(1), 'length': torch.zeros(1)}
+        elif workload == "res50ppm":
+            batch = synthetic_batch_2d(bsz, 32, 128, seed=rank, max_len=3)
+        elif workload == "fpn_attention":
+            bsz = args.batch if args.batch != 256 else 32      # configs[3]: 256 global = 32 per GPU on 8 GPUs
+            batch = synthetic_batch(bsz, 64, 256, seed=rank)
         else:
-            batch = synthetic_batch(args.batch, 32, 128, seed=rank)
+            batch = synthetic_batch(bsz, 32, 128, seed=rank)
         img = batch['image'].to(dev)
         lab = batch['label'].to(dev)
         ln = batch['length'].to(dev).long()
 
         def step():
             opt.zero_grad()
-            loss, _ = net(img, targets=lab, lengths=ln, train=True)
+            if is_db:
+                loss, _ = net(dbatch)
+            else:
+                loss, _ = net(img, targets=lab, lengths=ln, train=True)
             loss = loss.mean()
             loss.backward()
             opt.step()
@@ -283,7 +332,7 @@ def main():
 
         if rank == 0:
             ms = 1e3 * elapsed / steps
-            images = args.batch * world * steps
+            images = bsz * world * steps
             # ---- roofline of the dominant MFMA kernel from the live HIP-event records
             roofline = None
             kernels = {}
@@ -320,7 +369,18 @@ def main():
                                 "measured": "HIP events around every launch, %s" %
                                             ("eager pass after the graph-replayed timed region" if use_graph
                                              else "inside the timed region")}
-            if workload == "res50ppm":
+            if is_db:
+                metric_name = "training images/sec, DB detector (deformable ResNet-50 + SegDetector) 640x640, batch %d per GPU" % bsz
+                workload_name = ("DB text detector training step (BASELINE.json configs[4]): deformable_resnet50 (13 "
+                                 "DCNv2 layers) + SegDetector(adaptive, k=50) + L1BalanceCELoss, SGD momentum 0.9, "
+                                 "640x640 images")
+                fwd_flops = 127.2e9  # 94.03 backbone (24.54 of it DCN GEMMs) + 33.20 head
+            elif workload == "fpn_attention":
+                metric_name = "training images/sec, ResNet50-FPN + attention decoder 64x256 crops, batch %d per GPU" % bsz
+                workload_name = ("ResNet50-FPN + attention GRU decoder training step (BASELINE.json configs[3]): 64x256 "
+                                 "crops, 32 decode steps, teacher forcing fixed (gt_as_output), Adam")
+                fwd_flops = 17.25e9  # 5.01 backbone + 10.97 decoder conv encoder + 1.27 decode loop
+            elif workload == "res50ppm":
                 metric_name = "training images/sec, ResNet50-PPM-2D-CTC 32x128 crops, batch %d per GPU" % args.batch
                 workload_name = ("ResNet50-dilated-PPM + 2D-CTC training step (BASELINE.json configs[2]): 32x128 crops, "
                                  "T=16 H=4 C=38, Adam")
@@ -334,8 +394,8 @@ def main():
                 "value": round(images / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": steps,
                 "warmup": warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                "config": {"workload": workload_name, "global_batch": args.batch * world,
-                           "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
+                "config": {"workload": workload_name, "global_batch": bsz * world,
+                           "per_gpu_batch": bsz, "parallelism": "dp%d" % world,
                            "launch": ("hipGraph replay" if not distributed else ddp_launch) if use_graph
                            else ("eager" if not distributed else "eager, apex-style DDP shim (bucketed, overlapped)"),
                            "train_flops_per_image": 3 * fwd_flops},
@@ -343,7 +403,7 @@ def main():
                 "roofline": roofline,
                 "kernels": kernels,
             }
-            step_tflops = 3 * fwd_flops * args.batch / (ms * 1e-3) / 1e12
+            step_tflops = 3 * fwd_flops * bsz / (ms * 1e-3) / 1e12
             out["step_tflops_per_gpu"] = round(step_tflops, 2)
             out["host_enqueue_ms_per_step"] = round(1e3 * host_enqueue / steps, 3)
             if world == 1 and with_cpu and workload == "crnn":

@@ -53,6 +53,9 @@ int mr_set_tn_big(int mode);
 /* TN kernel operand staging: 1 = raw buffer resources (out-of-range -> zeros), 0 = flat pointers + zero page;
  * returns the previous setting */
 int mr_set_tn_buf(int mode);
+/* host only, timing only: ablation mask of the TN kernel (1 no LDS-DMA, 2 no fragment reads, 4 no atomic epilogue,
+ * 8 no column sums); results are wrong for mask != 0 */
+int mr_set_tn_abl(int mask);
 /* tile (BM*1000+BN) the NT kernels pick for an M x N problem; host-only query used for profiling labels */
 int mr_nt_tile_code(int M, int N);
 /* same, including the big-tile policy (returns 256256 for the 8-wave 256x256 kernel); cg = channels of the gathered
@@ -248,6 +251,12 @@ int mr_bilinear_fwd(int dtype, const void* x, void* y, int N, int H, int W, int 
                     int accumulate, hipStream_t stream);
 int mr_bilinear_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int OH, int OW, int lddy,
                     int coff, hipStream_t stream);
+/* nearest-neighbour upsampling by an integer factor s (decoders/seg_detector.py:22-43): y[n,oh,ow,coff+c] =
+ * x[n,oh/s,ow/s,c] (+ add[n,oh,ow,c], nullable); backward sums the s x s block */
+int mr_nearest_up_fwd(int dtype, const void* x, const void* add, void* y, int N, int H, int W, int C, int s, int ldy,
+                      int coff, hipStream_t stream);
+int mr_nearest_up_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int s, int lddy, int coff,
+                      hipStream_t stream);
 int mr_copy_channels(int dtype, const void* src, int lds, int soff, void* dst, int ldd, int doff, long long P, int C,
                      hipStream_t stream);
 int mr_scale_channels(int dtype, const void* x, const float* scale, void* y, int N, long long HW, int C,

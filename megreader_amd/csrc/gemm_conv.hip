@@ -93,6 +93,7 @@ static int num_cus() {
 // ---- big-tile (8-wave) NT kernel: bf16, dense or fast-gather conv operands ---------------------------------------
 // g_big_mode: 0 = automatic (nt_big_choice), -1 = never, 1 = always 256x256, 2 = always 288x256 (tuning override)
 static int g_big_mode = 0;
+static int g_tn_abl = 0;  // timing-only ablation mask of the TN kernel (mr_set_tn_abl)
 static int g_tn_buf = 1;  // TN kernel staging through buffer resources (mr_set_tn_buf); measured 4 % faster
 static int g_tn_big = 0;  // wide-tile TN kernels: 1 = 256x256, 2 = 128x256 (experimental, see launch_tn), else never
 
@@ -356,7 +357,12 @@ static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
       const long long bytesA = (long long)a.P * a.lda * 2;
       const long long bytesB = BMODE == 0 ? (long long)a.P * a.ldb * 2
                                           : ((long long)a.P / ((long long)g.Hm * g.Wm) + 1) * g.Hg * g.Wg * g.ldg * 2;
-      if (g_tn_buf && bytesA < (1ll << 31) && bytesB < (1ll << 31))
+      if (g_tn_abl && bytesA < (1ll << 31) && bytesB < (1ll << 31)) {   // timing-only ablations (mr_set_tn_abl)
+#define MR_TN_ABL(V_) case V_: hipLaunchKernelGGL((igemm_tn_glds_kernel<BMODE, true, V_>), dim3(tiles * splits), \
+                                                   dim3(256), 0, stream, a, g, z); break;
+        switch (g_tn_abl) { MR_TN_ABL(1) MR_TN_ABL(2) MR_TN_ABL(3) MR_TN_ABL(4) MR_TN_ABL(8) MR_TN_ABL(15) default: break; }
+#undef MR_TN_ABL
+      } else if (g_tn_buf && bytesA < (1ll << 31) && bytesB < (1ll << 31))
         hipLaunchKernelGGL((igemm_tn_glds_kernel<BMODE, true>), dim3(tiles * splits), dim3(256), 0, stream, a, g, z);
       else
         hipLaunchKernelGGL((igemm_tn_glds_kernel<BMODE, false>), dim3(tiles * splits), dim3(256), 0, stream, a, g, z);
@@ -407,6 +413,14 @@ int mr_set_nt_big(int mode) {
 
 // TN kernel operand staging: 1 = raw buffer resources (OOB -> zeros, 32-bit offsets), 0 = flat pointers + zero page.
 // Operands must be < 2 GiB in buffer mode.  Returns the previous setting.
+// timing-only: ablation mask of igemm_tn_glds_kernel (1 no LDS-DMA, 2 no fragment reads, 4 no atomic epilogue,
+// 8 no column sums; supported: 0, 1, 2, 3, 4, 8, 15).  Wrong results for mask != 0.
+int mr_set_tn_abl(int mask) {
+  const int old = g_tn_abl;
+  g_tn_abl = mask;
+  return old;
+}
+
 int mr_set_tn_buf(int mode) {
   const int old = g_tn_buf;
   if (mode == 0 || mode == 1) g_tn_buf = mode;

@@ -1233,7 +1233,9 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
 // instruction = 4 full 256-byte rows), the swizzle is applied to the SOURCE column of each lane.
 // ---------------------------------------------------------------------------------------------
 // BUF: stage through raw buffer resources (glds16_buf) instead of flat pointers + zero page
-template <int BMODE, bool BUF = false>
+// ABL (timing only, wrong results): bit 0 = no LDS-DMA in the loop, bit 1 = no fragment reads in the loop,
+// bit 2 = no atomic epilogue, bit 3 = no column sums.
+template <int BMODE, bool BUF = false, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeom g, const void* zero) {
   typedef bf16_t T;
   constexpr int BP = 64, ROW_BYTES = 256, TILE_BYTES = BP * ROW_BYTES;
@@ -1399,8 +1401,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
     offB[t] = TILE_BYTES + rbase + (((wb * 4 + t) ^ hsh) << 5);
   }
 
+  bf16x8 fa_keep[2][4], fb_keep[2][4];   // ABL bit 1: fragments of the first step, reused
+  bool first_compute = true;
   auto compute = [&](const unsigned char* st) {
-    if (do_colsum) {  // bias gradient: column sums of the A tile, re-read from LDS by the lane that staged it
+    if (do_colsum && !(ABL & 8)) {  // bias gradient: column sums of the A tile, re-read from LDS by the lane that staged it
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const uint4 v = *(const uint4*)(st + (wave * 4 + jj) * 1024 + lane * 16);
@@ -1427,6 +1431,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
         typedef short s16x8_t __attribute__((ext_vector_type(8)));
         fa[t] = __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(x[0], x[1], 0, 1, 2, 3, 4, 5, 6, 7));
         fb[t] = __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(y[0], y[1], 0, 1, 2, 3, 4, 5, 6, 7));
+        if (ABL & 2) {
+          if (first_compute) { fa_keep[kk][t] = fa[t]; fb_keep[kk][t] = fb[t]; }
+          else { fa[t] = fa_keep[kk][t]; fb[t] = fb_keep[kk][t]; }
+        }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -1434,6 +1442,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
+    if (ABL & 2) first_compute = false;
   };
 
   const int nsteps = (p_end - p_begin + BP - 1) / BP;
@@ -1443,10 +1452,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
   int st = 0;
   for (; st + 1 < nsteps; st += 2) {
     __syncthreads();
-    stage(st1, p_begin + (st + 1) * BP);
+    if (!(ABL & 1)) stage(st1, p_begin + (st + 1) * BP);
     compute(st0);
     __syncthreads();
-    if (st + 2 < nsteps) stage(st0, p_begin + (st + 2) * BP);
+    if (!(ABL & 1) && st + 2 < nsteps) stage(st0, p_begin + (st + 2) * BP);
     compute(st1);
   }
   if (st < nsteps) {
@@ -1454,7 +1463,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
     compute(st0);
   }
 
-  if (do_colsum) {  // block-level reduction of the per-lane partial column sums with LDS float atomics
+  if (do_colsum && !(ABL & 8)) {  // block-level reduction of the per-lane partial column sums with LDS float atomics
     __syncthreads();
     float* red = (float*)smem;
     if (tid < 128) red[tid] = 0.f;
@@ -1478,6 +1487,15 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
   }
 
   // epilogue: atomic accumulation (see igemm_tn_kernel)
+  if (ABL & 4) {   // keep the accumulators alive without the atomics
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (keep == 123.456f) a.C[0] = keep;
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll

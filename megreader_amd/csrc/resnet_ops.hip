@@ -270,6 +270,67 @@ __global__ void ctc2d_head_bwd_kernel(const float* __restrict__ g, const float* 
   }
 }
 
+// Nearest-neighbour upsampling by an integer factor (nn.Upsample(scale_factor=s, mode='nearest') of the DB head,
+// decoders/seg_detector.py:22-43): y[n, oh, ow, coff + c] = x[n, oh / s, ow / s, c] (+ add[n, oh, ow, c]); 16-byte vectors.
+template <typename T>
+__global__ void nearest_up_fwd_kernel(const T* __restrict__ x, const T* __restrict__ add, T* __restrict__ y, int N, int H,
+                                      int W, int C, int s, int ldy, int coff) {
+  constexpr int VEC = VecOf<T>::N;
+  const int cv = C / VEC, OH = H * s, OW = W * s;
+  const long long total = (long long)N * OH * OW * cv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    long long q = i / cv;
+    const int ow = (int)(q % OW);
+    q /= OW;
+    const int oh = (int)(q % OH);
+    const int n = (int)(q / OH);
+    uint4 v = *(const uint4*)(x + (((long long)n * H + oh / s) * W + ow / s) * C + c);
+    if (add) {
+      const uint4 a = *(const uint4*)(add + (((long long)n * OH + oh) * OW + ow) * C + c);
+      const T* pa = (const T*)&a;
+      T* pv = (T*)&v;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) pv[j] = from_f32<T>(to_f32(pv[j]) + to_f32(pa[j]));
+    }
+    *(uint4*)(y + (((long long)n * OH + oh) * OW + ow) * ldy + coff + c) = v;
+  }
+}
+
+// dx[n, h, w, c] = sum over the s x s block of dy[n, h*s + i, w*s + j, coff + c]   (gather form, no atomics)
+template <typename T>
+__global__ void nearest_up_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C, int s,
+                                      int lddy, int coff) {
+  constexpr int VEC = VecOf<T>::N;
+  const int cv = C / VEC, OW = W * s, OH = H * s;
+  const long long total = (long long)N * H * W * cv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    long long q = i / cv;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H);
+    const int n = (int)(q / H);
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int a = 0; a < s; ++a)
+      for (int b = 0; b < s; ++b) {
+        const uint4 v = *(const uint4*)(dy + (((long long)n * OH + h * s + a) * OW + w * s + b) * lddy + coff + c);
+        const T* pv = (const T*)&v;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += to_f32(pv[j]);
+      }
+    uint4 o;
+    T* po = (T*)&o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) po[j] = from_f32<T>(acc[j]);
+    *(uint4*)(dx + (((long long)n * H + h) * W + w) * C + c) = o;
+  }
+}
+
 }  // namespace mr
 
 using namespace mr;
@@ -358,6 +419,31 @@ int mr_ctc2d_head_bwd(int dtype, const float* grad_lp, const float* mask_prob, c
   DISPATCH_T(dtype, hipLaunchKernelGGL((ctc2d_head_bwd_kernel<T>), dim3(cdiv(N * W, 4)), dim3(256), 0, stream,
                                        grad_lp, mask_prob, cls_prob, (T*)dmask, ldda, (T*)dcls, lddz, N, H, W, C,
                                        tiny));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+// nearest upsampling x [N,H,W,C] -> y [N,H*s,W*s, ld = ldy] channel slice [coff, coff+C); add (nullable) [N,H*s,W*s,C]
+int mr_nearest_up_fwd(int dtype, const void* x, const void* add, void* y, int N, int H, int W, int C, int s, int ldy,
+                      int coff, hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(s >= 1 && C % vec == 0 && ldy % vec == 0 && coff % vec == 0 && ldy >= coff + C,
+               "mr_nearest_up_fwd: bad shape C=%d ldy=%d coff=%d s=%d", C, ldy, coff, s);
+  const long long total = (long long)N * H * s * W * s * (C / vec);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((nearest_up_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
+                                       (const T*)x, (const T*)add, (T*)y, N, H, W, C, s, ldy, coff));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_nearest_up_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int s, int lddy, int coff,
+                      hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(s >= 1 && C % vec == 0 && lddy % vec == 0 && coff % vec == 0 && lddy >= coff + C,
+               "mr_nearest_up_bwd: bad shape C=%d lddy=%d coff=%d s=%d", C, lddy, coff, s);
+  const long long total = (long long)N * H * W * (C / vec);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((nearest_up_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
+                                       (const T*)dy, (T*)dx, N, H, W, C, s, lddy, coff));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

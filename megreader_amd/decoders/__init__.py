@@ -2,3 +2,5 @@
 from .crnn import CRNNDecoder  # noqa: F401
 from .ctc_decoder2d import CTCDecoder2D  # noqa: F401
 from .attention_decoder import AttentionDecoder  # noqa: F401
+from .seg_detector import SegDetector  # noqa: F401
+from .seg_detector_loss import (BalanceCrossEntropyLoss, DiceLoss, L1BalanceCELoss, MaskL1Loss)  # noqa: F401

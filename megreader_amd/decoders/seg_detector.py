@@ -1,0 +1,114 @@
+"""DB detection head on the HIP layers -- mirror of reference decoders/seg_detector.py:7-147 (`SegDetector`, the decoder
+of experiments/seg_detector/seg_detector_db.yaml: adaptive=True, k=50).  Same constructor, same module / parameter names
+and shapes (in5..in2, out5..out2, binarize.{0,1,3,4,6}, thresh.{0,1,3,4,6}) and the same initialisation
+(kaiming_normal_ on every conv / deconv weight, BatchNorm weight 1 / bias 1e-4), so checkpoints interchange.
+
+The 1x1 / 3x3 convolutions and BatchNorms run on the MFMA / HIP kernels; nn.Upsample(nearest) (+ the top-down add) is
+mr_nearest_up_fwd / _bwd; ConvTranspose2d(k=2, s=2) is a GEMM (one output pixel quad = a [Cin] x [Cin, 4*Cout] product,
+megreader_amd.nn.functional.linear) followed by a depth-to-space view.  The final sigmoid and the differentiable
+binarisation 1 / (1 + exp(-k (x - y))) are elementwise torch ops on 1-channel maps.
+`smooth=True` / `serial=True` are not used by any reference YAML and raise NotImplementedError."""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from ..nn import BatchNorm2d, Conv2d, FusedReLU
+from ..nn import functional as F
+
+
+class ConvTranspose2x2(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d(cin, cout, 2, 2) (weight [cin, cout, 2, 2], bias [cout]) computed as a GEMM:
+    out[n, co, 2h+i, 2w+j] = sum_ci x[n, ci, h, w] * W[ci, co, i, j] + b[co]."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__(in_channels, out_channels, 2, 2)
+
+    def forward(self, x):
+        N, C, H, W = x.shape
+        co = self.out_channels
+        xs = x.permute(0, 2, 3, 1).reshape(N * H * W, C)                       # NHWC rows (a view for HIP-layer outputs)
+        wmat = self.weight.permute(2, 3, 1, 0).reshape(4 * co, C)              # row (i, j, co)
+        bias = self.bias.repeat(4) if self.bias is not None else None
+        y = F.linear(xs, wmat, bias)                                           # [N*H*W, 4*co]
+        y = y.reshape(N, H, W, 2, 2, co).permute(0, 5, 1, 3, 2, 4).reshape(N, co, 2 * H, 2 * W)
+        return y
+
+
+class _Up(nn.Upsample):
+    def forward(self, x):
+        return F.upsample_nearest(x, int(self.scale_factor))
+
+
+class SegDetector(nn.Module):
+    def __init__(self, in_channels=[64, 128, 256, 512], inner_channels=256, k=10, bias=False, adaptive=False,
+                 smooth=False, serial=False, *args, **kwargs):
+        super(SegDetector, self).__init__()
+        if smooth or serial:
+            raise NotImplementedError("SegDetector(smooth / serial) is not used by any reference experiment")
+        self.k = k
+        self.serial = serial
+        self.up5 = _Up(scale_factor=2, mode='nearest')
+        self.up4 = _Up(scale_factor=2, mode='nearest')
+        self.up3 = _Up(scale_factor=2, mode='nearest')
+        self.in5 = Conv2d(in_channels[-1], inner_channels, 1, bias=bias)
+        self.in4 = Conv2d(in_channels[-2], inner_channels, 1, bias=bias)
+        self.in3 = Conv2d(in_channels[-3], inner_channels, 1, bias=bias)
+        self.in2 = Conv2d(in_channels[-4], inner_channels, 1, bias=bias)
+        q = inner_channels // 4
+        self.out5 = nn.Sequential(Conv2d(inner_channels, q, 3, padding=1, bias=bias), _Up(scale_factor=8, mode='nearest'))
+        self.out4 = nn.Sequential(Conv2d(inner_channels, q, 3, padding=1, bias=bias), _Up(scale_factor=4, mode='nearest'))
+        self.out3 = nn.Sequential(Conv2d(inner_channels, q, 3, padding=1, bias=bias), _Up(scale_factor=2, mode='nearest'))
+        self.out2 = Conv2d(inner_channels, q, 3, padding=1, bias=bias)
+        self.binarize = self._head(inner_channels, bias)
+        self.binarize.apply(self.weights_init)
+        self.adaptive = adaptive
+        if adaptive:
+            self.thresh = self._head(inner_channels, bias)
+            self.thresh.apply(self.weights_init)
+        for m in (self.in5, self.in4, self.in3, self.in2, self.out5, self.out4, self.out3, self.out2):
+            m.apply(self.weights_init)
+
+    @staticmethod
+    def _head(inner_channels, bias):
+        q = inner_channels // 4
+        return nn.Sequential(Conv2d(inner_channels, q, 3, padding=1, bias=bias), BatchNorm2d(q, fuse_relu=True),
+                             FusedReLU(), ConvTranspose2x2(q, q), BatchNorm2d(q, fuse_relu=True), FusedReLU(),
+                             ConvTranspose2x2(q, 1), nn.Sigmoid())
+
+    def weights_init(self, m):
+        classname = m.__class__.__name__
+        if classname.find('Conv') != -1:
+            # same random stream as the reference: draw into a row-major tensor (the HIP Conv2d keeps its weight in
+            # channels_last memory, where normal_() takes another CPU kernel and consumes the generator differently)
+            w = torch.empty(m.weight.shape, dtype=m.weight.dtype)
+            nn.init.kaiming_normal_(w)
+            m.weight.data.copy_(w)
+        elif classname.find('BatchNorm') != -1:
+            m.weight.data.fill_(1.)
+            m.bias.data.fill_(1e-4)
+
+    def forward(self, features, gt=None, masks=None, training=False):
+        c2, c3, c4, c5 = features
+        in5 = self.in5(c5)
+        in4 = self.in4(c4)
+        in3 = self.in3(c3)
+        in2 = self.in2(c2)
+        out4 = F.upsample_nearest(in5, 2, in4)    # self.up5(in5) + in4, 1/16
+        out3 = F.upsample_nearest(out4, 2, in3)   # 1/8
+        out2 = F.upsample_nearest(out3, 2, in2)   # 1/4
+        p5 = self.out5(in5)
+        p4 = self.out4(out4)
+        p3 = self.out3(out3)
+        p2 = self.out2(out2)
+        fuse = F.cat_channels([p5, p4, p3, p2])
+        binary = self.binarize(fuse).float()
+        result = OrderedDict(binary=binary)
+        if self.adaptive:
+            thresh = self.thresh(fuse).float()
+            thresh_binary = self.step_function(binary, thresh)
+            result.update(thresh=thresh, thresh_binary=thresh_binary)
+        return result
+
+    def step_function(self, x, y):
+        return torch.reciprocal(1 + torch.exp(-self.k * (x - y)))

@@ -1,0 +1,72 @@
+"""Losses of the DB detector -- restatement of reference decoders/seg_detector_loss.py:157-185 (`L1BalanceCELoss`),
+balance_cross_entropy_loss.py:29-56, l1_loss.py:5-11 (MaskL1Loss) and dice_loss.py:28-42 (DiceLoss): elementwise /
+reduction torch ops on the 1-channel 640 x 640 maps (they are not MFMA or kernel material: one pass over 3 x 6.5 MB), with
+the reference's host-synchronising hard-negative count (`int(positive.float().sum())`) kept as is."""
+import torch
+import torch.nn as nn
+
+
+class BalanceCrossEntropyLoss(nn.Module):
+    def __init__(self, negative_ratio=3.0, eps=1e-6):
+        super().__init__()
+        self.negative_ratio = negative_ratio
+        self.eps = eps
+
+    def forward(self, pred, gt, mask, return_origin=False):
+        positive = (gt * mask).byte()
+        negative = ((1 - gt) * mask).byte()
+        positive_count = int(positive.float().sum())
+        negative_count = min(int(negative.float().sum()), int(positive_count * self.negative_ratio))
+        loss = nn.functional.binary_cross_entropy(pred, gt, reduction='none')[:, 0, :, :]
+        positive_loss = loss * positive.float()
+        negative_loss = loss * negative.float()
+        negative_loss, _ = torch.topk(negative_loss.view(-1), negative_count)
+        balance_loss = (positive_loss.sum() + negative_loss.sum()) / (positive_count + negative_count + self.eps)
+        if return_origin:
+            return balance_loss, loss
+        return balance_loss
+
+
+class MaskL1Loss(nn.Module):
+    def forward(self, pred, gt, mask):
+        loss = (torch.abs(pred[:, 0] - gt) * mask).sum() / mask.sum()
+        return loss, dict(l1_loss=loss)
+
+
+class DiceLoss(nn.Module):
+    def __init__(self, eps=1e-6):
+        super().__init__()
+        self.eps = eps
+
+    def forward(self, pred, gt, mask, weights=None):
+        assert pred.dim() == 4, pred.dim()
+        pred = pred[:, 0, :, :]
+        gt = gt[:, 0, :, :]
+        assert pred.shape == gt.shape and pred.shape == mask.shape
+        if weights is not None:
+            mask = weights * mask
+        intersection = (pred * gt * mask).sum()
+        union = (pred * mask).sum() + (gt * mask).sum() + self.eps
+        return 1 - 2.0 * intersection / union
+
+
+class L1BalanceCELoss(nn.Module):
+    """Balanced cross entropy on `binary`, masked L1 on `thresh`, Dice on `thresh_binary`."""
+
+    def __init__(self, eps=1e-6, l1_scale=10, bce_scale=5):
+        super().__init__()
+        self.dice_loss = DiceLoss(eps=eps)
+        self.l1_loss = MaskL1Loss()
+        self.bce_loss = BalanceCrossEntropyLoss()
+        self.l1_scale = l1_scale
+        self.bce_scale = bce_scale
+
+    def forward(self, pred, batch):
+        bce_loss = self.bce_loss(pred['binary'], batch['gt'], batch['mask'])
+        metrics = dict(bce_loss=bce_loss)
+        l1_loss, l1_metric = self.l1_loss(pred['thresh'], batch['thresh_map'], batch['thresh_mask'])
+        dice_loss = self.dice_loss(pred['thresh_binary'], batch['gt'], batch['mask'])
+        metrics['thresh_loss'] = dice_loss
+        loss = dice_loss + self.l1_scale * l1_loss + bce_loss * self.bce_scale
+        metrics.update(**l1_metric)
+        return loss, metrics

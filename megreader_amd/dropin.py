@@ -23,7 +23,7 @@ OVERRIDES = {
                                               "resnet152", "deformable_resnet50", "resnet50dilated_ppm",
                                               "Resnet18FPN", "Resnet34FPN", "Resnet50FPN", "Resnet101FPN",
                                               "Resnet152FPN"]),
-    "decoders": ("megreader_amd.decoders", ["CRNNDecoder", "CTCDecoder2D", "AttentionDecoder"]),
+    "decoders": ("megreader_amd.decoders", ["CRNNDecoder", "CTCDecoder2D", "AttentionDecoder", "SegDetector"]),
 }
 
 

@@ -934,6 +934,39 @@ def upsample_add(x, y):
     return UpsampleAddFn.apply(x, y)
 
 
+class NearestUpFn(Function):
+    """nn.Upsample(scale_factor=s, mode='nearest')(x) (+ y): the DB head's top-down path and its x2 / x4 / x8 output
+    branches (decoders/seg_detector.py:22-43,121-128).  With `into` = (buffer NHWC, channel offset) the result is written
+    straight into a channel slice of a concatenation buffer (torch.cat((p5, p4, p3, p2), 1), seg_detector.py:130)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, add):
+        require_cuda(x)
+        dtype = get_compute_dtype()
+        dt = dtype_code(dtype)
+        xi = to_internal(x, dtype)
+        N, H, W, C = xi.shape
+        ai = to_internal(add, dtype) if add is not None else None
+        out = torch.empty((N, H * scale, W * scale, C), dtype=dtype, device=xi.device)
+        call("mr_nearest_up_fwd", dt, ptr(xi), ptr(ai), ptr(out), N, H, W, C, int(scale), C, 0)
+        ctx.geom = (N, H, W, C, int(scale))
+        ctx.dtype = dtype
+        ctx.has_add = add is not None
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        N, H, W, C, s = ctx.geom
+        g = _grad_internal(g_out, ctx.dtype)
+        dx = torch.empty((N, H, W, C), dtype=ctx.dtype, device=g.device)
+        call("mr_nearest_up_bwd", dtype_code(ctx.dtype), ptr(g), ptr(dx), N, H, W, C, s, C, 0)
+        return dx.permute(0, 3, 1, 2), None, (g_out if ctx.has_add else None)
+
+
+def upsample_nearest(x, scale, add=None):
+    return NearestUpFn.apply(x, scale, add)
+
+
 class CatChannelsFn(Function):
     """torch.cat(tensors, 1) for NHWC-internal tensors whose channel counts are multiples of one vector."""
 

@@ -68,3 +68,41 @@ def test_product_mirrors_share_the_reference_state_dicts(golden_dir):
         _check_state(m, g)
         for k, v in m.state_dict().items():
             assert tuple(v.shape) == g['state_shapes'][k], k
+
+
+def test_seg_detector_oracle_and_mirror_vs_reference():
+    """DB head + loss: the oracle restatement is bit-identical to the unmodified reference SegDetector / L1BalanceCELoss
+    on CPU (same seeded init); the HIP mirror has the same state_dict keys, shapes and initial values, and its restated
+    loss module equals the reference's."""
+    from oracle import refimport
+    if not refimport.available():
+        pytest.skip("reference tree not present")
+    refimport.import_reference()
+    from decoders.seg_detector import SegDetector as RefSeg
+    from decoders.seg_detector_loss import L1BalanceCELoss as RefLoss
+    from megreader_amd.decoders import L1BalanceCELoss, SegDetector
+    from megreader_amd.synthetic import detection_batch
+    from oracle.seg_detector import SegDetectorOracle, l1_balance_ce_loss
+    chans = [16, 32, 64, 128]
+    torch.manual_seed(3)
+    ref = RefSeg(in_channels=chans, inner_channels=64, k=50, adaptive=True)
+    torch.manual_seed(3)
+    ora = SegDetectorOracle(in_channels=chans, inner_channels=64, k=50, adaptive=True)
+    torch.manual_seed(3)
+    ours = SegDetector(in_channels=chans, inner_channels=64, k=50, adaptive=True)
+    rs = ref.state_dict()
+    assert list(rs.keys()) == list(ora.state_dict().keys()) == list(ours.state_dict().keys())
+    for k, v in rs.items():
+        assert torch.equal(v, ora.state_dict()[k]), k
+        assert v.shape == ours.state_dict()[k].shape and torch.equal(v, ours.state_dict()[k]), k
+    g = torch.Generator().manual_seed(0)
+    feats = [torch.randn(2, c, 64 // s, 64 // s, generator=g) for c, s in zip(chans, (1, 2, 4, 8))]
+    ref.train()
+    ora.train()
+    pr, po = ref(feats), ora(feats)
+    for k in pr:
+        assert torch.equal(pr[k], po[k]), k
+    batch = detection_batch(2, 256, seed=1, boxes=3)
+    lr_, _ = RefLoss()(pr, batch)
+    lm_, _ = L1BalanceCELoss()(pr, batch)
+    assert torch.equal(lr_, lm_) and torch.equal(lr_, l1_balance_ce_loss(po, batch))

@@ -28,12 +28,14 @@ def main():
     ap.add_argument("--tnbuf", type=int, default=0, help="TN kernel staging through buffer resources (0/1)")
     ap.add_argument("--tnbig", type=int, default=0, help="big-tile TN kernel: 0 auto, -1 never, 1 always")
     ap.add_argument("--big", type=int, default=0, help="big-tile NT kernel: 0 auto, -1 never, 1 256x256, 2 288x256")
+    ap.add_argument("--tnabl", type=int, default=0, help="timing-only ablation mask of the TN kernel")
     ap.add_argument("--p8", type=int, default=0, help="phased-schedule 256x256 kernel for the big-tile launches (0/1)")
     a = ap.parse_args()
     from megreader_amd import _lib
     _lib.load().mr_set_nt_variant(a.variant)
     _lib.load().mr_set_nt_big(a.big)
     _lib.load().mr_set_nt_p8(a.p8)
+    _lib.load().mr_set_tn_abl(a.tnabl)
     _lib.load().mr_set_tn_big(a.tnbig)
     _lib.load().mr_set_tn_buf(a.tnbuf)
     if a.tile:
