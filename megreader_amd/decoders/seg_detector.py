@@ -28,7 +28,7 @@ class ConvTranspose2x2(nn.ConvTranspose2d):
         N, C, H, W = x.shape
         co = self.out_channels
         xs = x.permute(0, 2, 3, 1).reshape(N * H * W, C)                       # NHWC rows (a view for HIP-layer outputs)
-        wmat = self.weight.permute(2, 3, 1, 0).reshape(4 * co, C)              # row (i, j, co)
+        wmat = self.weight.permute(2, 3, 1, 0).reshape(4 * co, C).contiguous()  # row (i, j, co)
         bias = self.bias.repeat(4) if self.bias is not None else None
         y = F.linear(xs, wmat, bias)                                           # [N*H*W, 4*co]
         y = y.reshape(N, H, W, 2, 2, co).permute(0, 5, 1, 3, 2, 4).reshape(N, co, 2 * H, 2 * W)

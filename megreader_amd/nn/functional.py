@@ -554,6 +554,9 @@ class LinearFn(Function):
         M = x2.shape[0]
         Nout = weight.shape[0]
         Np = _ceil_to(Nout, v)
+        if weight.dim() != 2 or weight.stride() != (K, 1):
+            raise RuntimeError("linear: weight must be a dense row-major [out_features, in_features] tensor "
+                               "(got strides %s); call .contiguous() on views" % (tuple(weight.stride()),))
         if K % v:
             raise RuntimeError("Linear: in_features (%d) must be a multiple of %d" % (K, v))
         def build(old):

@@ -22,38 +22,109 @@ def _reset_dtype():
 
 
 def _rel(a, b):
-    a, b = a.double().cpu(), b.double().cpu()
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
+def _relu_masks(head_modules):
+    """Forward hooks on the ReLU slots (indices 2 and 5) of the binarize / thresh heads: the sign pattern decides which
+    elements pass gradient, and an element whose pre-activation is within rounding of zero takes a different side in
+    float32 and float64 -- one such element moves dbeta of a 16-channel BN by 1/sqrt(elements per channel) ~ 5e-3."""
+    masks, hooks = [], []
+    for seq in head_modules:
+        for i in (2, 5):
+            hooks.append(seq[i].register_forward_hook(lambda m, a, out: masks.append((out.detach() > 0).cpu())))
+    return masks, hooks
+
+
 def test_seg_detector_fp32_vs_oracle():
+    """Forward maps, loss and every parameter / input gradient against the oracle in FLOAT64.  The inputs are the first
+    seed whose four head ReLU sign patterns agree between the float64 oracle and the HIP float32 run (see
+    _relu_masks): with equal masks every operator is smooth and the bar is float32 rounding, 2e-5 of the tensor's max (measured 2e-6)
+    for a linear functional of the maps; for the loss (hard-negative top-k of the balanced BCE, k = 50 step function)
+    the yardstick is the oracle's own float32 run: 4x its error, floor 5e-5 (measured 2e-6)."""
+    import copy
     mr.set_compute_dtype(torch.float32)
     chans = [16, 32, 64, 128]
     torch.manual_seed(3)
-    ora = SegDetectorOracle(in_channels=chans, inner_channels=64, k=50, adaptive=True).double().train()
+    ora32 = SegDetectorOracle(in_channels=chans, inner_channels=64, k=50, adaptive=True).train()
+    ora64 = copy.deepcopy(ora32).double().train()
     model = SegDetector(in_channels=chans, inner_channels=64, k=50, adaptive=True)
-    model.load_state_dict({k: v.float() for k, v in ora.state_dict().items()}, strict=True)
+    model.load_state_dict(ora32.state_dict(), strict=True)
     model.to(DEV).train()
-    g = torch.Generator().manual_seed(0)
-    feats = [torch.randn(2, c, 64 // s, 64 // s, generator=g) for c, s in zip(chans, (1, 2, 4, 8))]
     batch = detection_batch(2, 256, seed=1, boxes=3)
-    fo = [f.double().requires_grad_(True) for f in feats]
-    po = ora(fo)
-    lo = l1_balance_ce_loss(po, {k: v.double() for k, v in batch.items()})
-    lo.backward()
-    fd = [f.to(DEV).requires_grad_(True) for f in feats]
-    pd = model(fd)
-    for k in po:
-        assert pd[k].shape == po[k].shape and _rel(pd[k], po[k]) < 2e-4, k
-    ld, _ = L1BalanceCELoss()(pd, {k: v.to(DEV) for k, v in batch.items()})
-    assert abs(float(ld) - float(lo)) < 1e-4 * max(1.0, abs(float(lo)))
-    ld.backward()
-    for a, b in zip(fd, fo):
-        assert _rel(a.grad, b.grad) < 2e-3
-    op = dict(ora.named_parameters())
-    for k, p in model.named_parameters():
-        assert p.grad is not None, k
-        assert _rel(p.grad, op[k].grad) < 5e-3, (k, _rel(p.grad, op[k].grad))
+
+    def run_oracle(ora, dt, feats, functional):
+        ora.zero_grad()
+        f = [x.detach().clone().to(dt).requires_grad_(True) for x in feats]
+        p = ora(f)
+        l = functional(p, dt, "cpu")
+        l.backward()
+        return p, l, f, {k: v.grad.clone() for k, v in ora.named_parameters()}
+
+    def loss_fn(p, dt, dev):
+        if dev == "cpu":
+            return l1_balance_ce_loss(p, {k: v.to(dt) for k, v in batch.items()})
+        return L1BalanceCELoss()(p, {k: v.to(dev) for k, v in batch.items()})[0]
+
+    gw = torch.Generator().manual_seed(5)
+    ws = {k: torch.randn(2, 1, 256, 256, generator=gw) for k in ("binary", "thresh")}
+
+    def lin_fn(p, dt, dev):
+        return sum((p[k] * ws[k].to(device=dev, dtype=dt)).sum() for k in ws)
+
+    chosen = None
+    for seed in range(8):
+        g = torch.Generator().manual_seed(seed)
+        feats = [torch.randn(2, c, 64 // s, 64 // s, generator=g) for c, s in zip(chans, (1, 2, 4, 8))]
+        m_o, h_o = _relu_masks([ora64.binarize, ora64.thresh])
+        m_d, h_d = _relu_masks([model.binarize, model.thresh])
+        with torch.no_grad():
+            ora64([f.double() for f in feats])
+            model([f.to(DEV) for f in feats])
+        for h in h_o + h_d:
+            h.remove()
+        if all(torch.equal(a, b) for a, b in zip(m_o, m_d)):
+            chosen = feats
+            break
+    assert chosen is not None, "no seed in 0..7 with agreeing ReLU sign patterns"
+    feats = chosen
+    print("SegDetector fp32: inputs seed %d" % seed)
+
+    failures, worst = [], {}
+    for name, fn, floor in (("linear", lin_fn, 2e-5), ("loss", loss_fn, 5e-5)):
+        p64, l64, f64, w64 = run_oracle(ora64, torch.float64, feats, fn)
+        p32, l32, f32, w32 = run_oracle(ora32, torch.float32, feats, fn)
+        model.zero_grad()
+        fd = [f.detach().to(DEV).requires_grad_(True) for f in feats]
+        pd = model(fd)
+        for k in p64:
+            assert pd[k].shape == p64[k].shape and _rel(pd[k], p64[k]) < 2e-4, k
+        ld = fn(pd, torch.float32, DEV)
+        assert abs(float(ld) - float(l64)) < 1e-4 * max(1.0, abs(float(l64))), (name, float(ld), float(l64))
+        ld.backward()
+        worst[name] = 0.0
+        # the deconvolution biases in front of a BatchNorm (x.3.bias) have a mathematically zero gradient: compare
+        # them on the scale of the deconvolution's weight gradient instead of their own
+        pairs = [("feature c%d" % (i + 2), a.grad, b.grad, c.grad, None) for i, (a, b, c) in
+                 enumerate(zip(fd, f64, f32))]
+        for k, p in model.named_parameters():
+            assert p.grad is not None, k
+            scale = w64[k.replace(".bias", ".weight")].abs().max() if k.endswith(".3.bias") else None
+            pairs.append((k, p.grad, w64[k], w32[k], scale))
+        for k, a, b, c, scale in pairs:
+            if scale is not None:
+                e_hip = float((a.double().cpu() - b).abs().max() / scale)
+                e_cpu = float((c.double() - b).abs().max() / scale)
+            else:
+                e_hip, e_cpu = _rel(a, b), _rel(c, b)
+            worst[name] = max(worst[name], e_hip)
+            bar = floor if name == "linear" else max(4 * e_cpu, floor)
+            if not e_hip < bar:
+                failures.append((name, k, "hip %.2e" % e_hip, "cpu f32 %.2e" % e_cpu))
+    print("SegDetector fp32: worst gradient error vs f64 / max|g|: linear %.2e, loss %.2e"
+          % (worst["linear"], worst["loss"]))
+    assert not failures, failures
 
 
 def test_db_detector_training_step_bf16():
