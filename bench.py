@@ -56,19 +56,20 @@ def kernel_label(lib, name, args, dtype_name):
     return "igemm_tn_kernel<%s,conv>" % dtype_name
 
 
-def pmc_traffic(label):
-    """HBM-side bytes per launch of `label` from the committed PMC passes (profiles/r01_pmc_traffic.json, produced
-    by tools/final_profile.sh + tools/pmc_to_json.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
-    same command, FETCH_SIZE doubled for gfx950).  PMC counters cannot be read inside this process."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+def pmc_traffic(label, workload="crnn"):
+    """HBM-side bytes per launch of `label` from the committed PMC passes (profiles/r02_pmc_traffic_<workload>.json,
+    produced by tools/profile_r02.sh + tools/pmc_to_json.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
+    this same command, FETCH_SIZE doubled for gfx950).  PMC counters cannot be read inside this process."""
+    name = "r02_pmc_traffic_%s.json" % workload
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
     try:
         data = json.load(open(path))
     except (OSError, ValueError):
         return None, None
     if label not in data:
         return None, None
-    return data[label]["bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, %d launches)" % \
-        data[label]["launches"]
+    return data[label]["bytes_per_launch"], "profiles/%s (rocprofv3 --pmc, %d launches)" % \
+        (name, data[label]["launches"])
 
 
 def cpu_baseline(batch_size=64, budget_s=20.0):
@@ -358,8 +359,7 @@ def main():
                     fl, t_ms, n = agg[dom]
                     ach = fl / (t_ms * 1e-3) / 1e12
                     peak = MFMA_PEAK_TFLOPS[args.dtype]
-                    # the committed PMC passes are of the CRNN workload
-                    traffic, traffic_src = pmc_traffic(dom) if workload == "crnn" else (None, None)
+                    traffic, traffic_src = pmc_traffic(dom, workload)
                     roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                                 "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,

@@ -53,6 +53,8 @@ int mr_set_tn_big(int mode);
 /* TN kernel operand staging: 1 = raw buffer resources (out-of-range -> zeros), 0 = flat pointers + zero page;
  * returns the previous setting */
 int mr_set_tn_buf(int mode);
+int mr_set_tn_model(int m);    /* A/B: 1 = conv wgrad uses the dense-GEMM split model too */
+int mr_set_tn_splits(int n);   /* tuning only: P-split override of the TN kernels, 0 = automatic */
 /* host only, timing only: ablation mask of the TN kernel (1 no LDS-DMA, 2 no fragment reads, 4 no atomic epilogue,
  * 8 no column sums); results are wrong for mask != 0 */
 int mr_set_tn_abl(int mask);

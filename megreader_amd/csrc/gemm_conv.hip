@@ -94,6 +94,8 @@ static int num_cus() {
 // g_big_mode: 0 = automatic (nt_big_choice), -1 = never, 1 = always 256x256, 2 = always 288x256 (tuning override)
 static int g_big_mode = 0;
 static int g_tn_abl = 0;  // timing-only ablation mask of the TN kernel (mr_set_tn_abl)
+static int g_tn_model = 0;   // 1: the dense-GEMM split model for the conv wgrad launches too (mr_set_tn_model, A/B)
+static int g_tn_splits = 0;  // > 0: split count override of launch_tn (mr_set_tn_splits, tuning only)
 static int g_tn_buf = 1;  // TN kernel staging through buffer resources (mr_set_tn_buf); measured 4 % faster
 static int g_tn_big = 0;  // wide-tile TN kernels: 1 = 256x256, 2 = 128x256 (experimental, see launch_tn), else never
 
@@ -330,9 +332,15 @@ static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
   for (int s = 1; s <= 1024 && 2 * s <= total_steps + 1; ++s) {
     const long long blocks = (long long)tiles * s;
     const long long rounds = (blocks + 2 * cus - 1) / (2 * cus);
-    const double cost = (double)rounds * (cdiv(total_steps, s) + 8.0);
+    double cost = (double)rounds * (cdiv(total_steps, s) + 8.0);
+    // dense GEMMs (LSTM / Linear weight gradients: 4..64 output tiles) were measured per split count
+    // (tools/microbench_tn_dense.py): launch + prologue + atomic epilogue cost ~20 p-steps, not 8, and a workgroup
+    // that shares its CU with a second one runs its p-steps ~1.3x slower -- so "one workgroup per CU" wins over
+    // "two per CU with half the steps" (dW_hh: 21 us at 16 splits vs 32 us at the 32 the old model chose)
+    if (BMODE == 0 || g_tn_model == 1) cost = (double)rounds * (cdiv(total_steps, s) + 20.0) * (blocks > cus ? 1.3 : 1.0);
     if (cost < best) { best = cost; splits = s; }
   }
+  if (g_tn_splits > 0) splits = g_tn_splits < total_steps ? g_tn_splits : total_steps;
   if constexpr (sizeof(T) == 2) {
     // wide-tile variants (mode 1: 256x256, mode 2: 128x256; one 8-wave workgroup per CU): they cut the L2 -> LDS
     // operand traffic of the 128x128 kernel to 0.5x / 0.75x.  EXPERIMENTAL, opt-in only (mr_set_tn_big): both are
@@ -418,6 +426,20 @@ int mr_set_nt_big(int mode) {
 int mr_set_tn_abl(int mask) {
   const int old = g_tn_abl;
   g_tn_abl = mask;
+  return old;
+}
+
+// A/B: 1 = the conv wgrad launches use the dense-GEMM split model as well.  Returns the previous setting.
+int mr_set_tn_model(int m) {
+  const int old = g_tn_model;
+  g_tn_model = m ? 1 : 0;
+  return old;
+}
+
+// tuning only: force the P-split count of the TN kernels (0 = the makespan model).  Returns the previous setting.
+int mr_set_tn_splits(int n) {
+  const int old = g_tn_splits;
+  g_tn_splits = n > 0 ? n : 0;
   return old;
 }
 

@@ -125,6 +125,38 @@ class _Side(object):
         _Side.queued = False
 
 
+class _Fan(object):
+    """Fork/join of INDEPENDENT launches inside one autograd Function: the weight-gradient GEMMs of an LSTM / Linear
+    layer (dense TN GEMMs with 16..64 output tiles: each alone leaves most CUs with one latency-bound workgroup or none,
+    tools/microbench_tn_dense.py) run on side HIP streams beside each other and beside the layer's input-gradient GEMM,
+    and are joined before the Function returns -- nothing outlives the call, unlike _Side.  Inside a hipGraph capture the
+    event waits become parallel branches of the graph."""
+    streams = {}
+    enabled = os.environ.get("MEGREADER_FAN", "1") == "1"
+
+    @staticmethod
+    def run(fns):
+        """fns[0] runs on the current stream, fns[1:] on side streams; returns after the current stream waits for all."""
+        fns = [f for f in fns if f is not None]
+        if not fns:
+            return
+        if not _Fan.enabled or len(fns) == 1:
+            for f in fns:
+                f()
+            return
+        main = torch.cuda.current_stream()
+        pool = _Fan.streams.setdefault(main.device, [])
+        while len(pool) < len(fns) - 1:
+            pool.append(torch.cuda.Stream(device=main.device))
+        for st, f in zip(pool, fns[1:]):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                f()
+        fns[0]()
+        for st in pool[:len(fns) - 1]:
+            main.wait_stream(st)
+
+
 def accumulate_multi(pairs):
     """dst += src for a list of (dst, src) dense f32 tensor pairs, 8 pairs per launch (mr_accumulate_multi)."""
     for i in range(0, len(pairs), 8):
@@ -593,9 +625,10 @@ class LinearFn(Function):
         else:
             gp = g2 if (g2.dtype == dtype and g2.is_contiguous()) else g2.to(dtype).contiguous()
         dx = dw = db = None
+        dx_fn = None
         if ctx.needs_input_grad[0]:
             dx2 = torch.empty((M, K), dtype=dtype, device=gy.device)
-            call("mr_gemm_nt", dt, ptr(gp), Np, ptr(w_t), Np, ptr(dx2), K, 0, 0, M, K, Np)
+            dx_fn = lambda: call("mr_gemm_nt", dt, ptr(gp), Np, ptr(w_t), Np, ptr(dx2), K, 0, 0, M, K, Np)
             dx = dx2.view(*ctx.lead, K)
         weight_p, bias_p = ctx.params
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
@@ -610,17 +643,23 @@ class LinearFn(Function):
             overlap = (w_sink is not None and (gb is None or b_sink is not None) and _Side.enabled and
                        not getattr(weight_p, "_mr_grad_ready_hooks", None))
             if overlap:
+                if dx_fn is not None:
+                    dx_fn()
                 with torch.cuda.stream(_Side.fork()):
                     call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, Np, K, 0, ptr(gb))
                 _Side.pending.extend((gp, x2))
-            else:
-                call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, Np, K, 0, ptr(gb))
+            else:   # input-gradient and weight-gradient GEMMs are independent: side by side (_Fan)
+                _Fan.run([dx_fn, lambda: call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, Np, K, 0,
+                                              ptr(gb))])
+            dx_fn = None
             if w_sink is not None:
                 notify_grad_ready(weight_p)
             else:
                 dw = gw[:Nout]
         elif want_db:
             call("mr_colsum", dt, ptr(gp), ptr(gb), M, Np, Np, 0)
+        if dx_fn is not None:
+            dx_fn()
         if want_db:
             if b_sink is not None:
                 notify_grad_ready(bias_p)
@@ -726,30 +765,40 @@ class BiLSTMFn(Function):
         overlap = (use_sinks and _Side.enabled and
                    not any(getattr(p, "_mr_grad_ready_hooks", None) for p in ctx.params))
         side = _Side.fork() if overlap else None
-        dx = None
+        dx = dx_fn = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((T, N, I), dtype=dtype, device=dev)
-            call("mr_gemm_nt", dt, ptr(dgates), 8 * H, ptr(wcat_t), 8 * H, ptr(dx), I, 0, 0, T * N, I, 8 * H)
+            dx_fn = lambda: call("mr_gemm_nt", dt, ptr(dgates), 8 * H, ptr(wcat_t), 8 * H, ptr(dx), I, 0, 0, T * N, I,
+                                 8 * H)
+        if overlap and dx_fn is not None:
+            dx_fn()
         with torch.cuda.stream(side) if overlap else contextlib.nullcontext():
             # one zeroed scratch: [2,4H,I] input-weight gradients (both directions from ONE GEMM) + [2,4H] bias sums
             scratch = torch.zeros((2 * 4 * H * (I + 1),), dtype=torch.float32, device=dev)
             gw_ih = scratch[:2 * 4 * H * I].view(2, 4 * H, I)
             gb = scratch[2 * 4 * H * I:].view(2, 4 * H)
-            # bias gradient = column sums of dgates, fused into the same pass
-            call("mr_gemm_tn", dt, ptr(dgates), 8 * H, ptr(x), I, ptr(gw_ih), I, T * N, 8 * H, I, H, ptr(gb))
             if use_sinks:   # recurrent-weight gradients accumulate straight into the flat gradient buffer
                 g_hh = (sinks[1], sinks[5])
             else:
                 gw_hh = torch.zeros((2, 4 * H, H), dtype=torch.float32, device=dev)
                 g_hh = (gw_hh[0], gw_hh[1])
-            if T > 1:
-                P = (T - 1) * N
+            P = (T - 1) * N
+            fns = [
+                # bias gradient = column sums of dgates, fused into the same pass
+                lambda: call("mr_gemm_tn", dt, ptr(dgates), 8 * H, ptr(x), I, ptr(gw_ih), I, T * N, 8 * H, I, H,
+                             ptr(gb)),
                 # forward direction: dgates[t] (t>=1) with h[t-1]
-                call("mr_gemm_tn", dt, ptr(dgates) + N * 8 * H * es, 8 * H, ptr(out), 2 * H, ptr(g_hh[0]), H, P,
-                     4 * H, H, H, 0)
+                (lambda: call("mr_gemm_tn", dt, ptr(dgates) + N * 8 * H * es, 8 * H, ptr(out), 2 * H, ptr(g_hh[0]),
+                              H, P, 4 * H, H, H, 0)) if T > 1 else None,
                 # reverse direction: dgates[t] (t<=T-2) with h[t+1]
-                call("mr_gemm_tn", dt, ptr(dgates) + 4 * H * es, 8 * H, ptr(out) + (N * 2 * H + H) * es, 2 * H,
-                     ptr(g_hh[1]), H, P, 4 * H, H, H, 0)
+                (lambda: call("mr_gemm_tn", dt, ptr(dgates) + 4 * H * es, 8 * H, ptr(out) + (N * 2 * H + H) * es,
+                              2 * H, ptr(g_hh[1]), H, P, 4 * H, H, H, 0)) if T > 1 else None]
+            if overlap:
+                for f in fns:
+                    if f is not None:
+                        f()
+            else:   # the four GEMMs (dx + three weight gradients) are independent: side by side (_Fan)
+                _Fan.run([dx_fn] + fns)
             if use_sinks:
                 # w_ih, b_ih, b_hh of both directions: one launch folds the scratch into the six sinks
                 accumulate_multi([(sinks[0], gw_ih[0]), (sinks[4], gw_ih[1]), (sinks[2], gb[0]), (sinks[3], gb[0]),

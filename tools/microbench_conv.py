@@ -25,13 +25,17 @@ def main():
     ap.add_argument("--layers", default="")
     ap.add_argument("--tile", default="", help="force NT tile, e.g. 96x128")
     ap.add_argument("--variant", type=int, default=2, help="NT kernel: 2 direct-to-LDS, 1 register staged")
-    ap.add_argument("--tnbuf", type=int, default=0, help="TN kernel staging through buffer resources (0/1)")
+    ap.add_argument("--tnbuf", type=int, default=1, help="TN kernel staging through buffer resources (0/1)")
     ap.add_argument("--tnbig", type=int, default=0, help="big-tile TN kernel: 0 auto, -1 never, 1 always")
     ap.add_argument("--big", type=int, default=0, help="big-tile NT kernel: 0 auto, -1 never, 1 256x256, 2 288x256")
     ap.add_argument("--tnabl", type=int, default=0, help="timing-only ablation mask of the TN kernel")
     ap.add_argument("--p8", type=int, default=0, help="phased-schedule 256x256 kernel for the big-tile launches (0/1)")
+    ap.add_argument("--tnmodel", type=int, default=0, help="1: dense-GEMM split model for conv wgrad too")
+    ap.add_argument("--tnsplits", type=int, default=0, help="force the TN P-split count (0 = model)")
     a = ap.parse_args()
     from megreader_amd import _lib
+    _lib.load().mr_set_tn_model(a.tnmodel)
+    _lib.load().mr_set_tn_splits(a.tnsplits)
     _lib.load().mr_set_nt_variant(a.variant)
     _lib.load().mr_set_nt_big(a.big)
     _lib.load().mr_set_nt_p8(a.p8)
