@@ -298,6 +298,20 @@ int mr_dcn2_bwd(int dtype, const void* dy, const void* x, const void* w_t, const
                 float* dbias, int N, int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int Ho,
                 int Wo, hipStream_t stream);
 
+/* ---- Deformable PS-RoI pooling (assets/ops/dcn/src/deform_pool_cuda.cpp:30-77 deform_psroi_pooling_cuda_forward /
+ * _backward; kernels deform_pool_cuda_kernel.cu:52-143, 146-268).  data [B][C][H][W] f32, rois [R][5] (batch index, x1,
+ * y1, x2, y2), trans [R][channels_trans][part][part] (ignored when no_trans), out / top_count / out_grad
+ * [R][output_dim][P][P]; all caller-allocated.  bwd ACCUMULATES into data_diff / trans_diff (caller zero-fills, as
+ * functions/deform_pool.py:57-59 does). */
+int mr_deform_psroi_fwd(const float* data, const float* rois, const float* trans, float* out, float* top_count, int B,
+                        int C, int H, int W, int R, int channels_trans, int no_trans, float spatial_scale,
+                        int output_dim, int group_size, int pooled_size, int part_size, int sample_per_part,
+                        float trans_std, hipStream_t stream);
+int mr_deform_psroi_bwd(const float* out_grad, const float* data, const float* rois, const float* trans,
+                        const float* top_count, float* data_diff, float* trans_diff, int B, int C, int H, int W, int R,
+                        int channels_trans, int no_trans, float spatial_scale, int output_dim, int group_size,
+                        int pooled_size, int part_size, int sample_per_part, float trans_std, hipStream_t stream);
+
 /* ---- Attention-GRU decoder step kernels (decoders/attention_decoder.py:146-231; the GEMMs use mr_gemm_nt/tn) ----- */
 int mr_attn_step_fwd(int dtype, const void* hproj, const void* eproj, const float* v, const void* enc, float* weights,
                      void* context, int N, int T, int Hd, int Ep, hipStream_t stream);

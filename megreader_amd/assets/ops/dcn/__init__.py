@@ -4,31 +4,17 @@ Implemented: ModulatedDeformConv / modulated_deform_conv / ModulatedDeformConvPa
 reference model uses: backbones/resnet.py:295-309 `deformable_resnet50`) and DeformConv / DeformConvPack / deform_conv
 (v1, on the v2 kernels with a mask of ones).  `deform_conv_cuda` is the extension-level module
 (src/deform_conv_cuda.cpp entry points) for the reference's own functions/deform_conv.py.  The deformable PS-RoI pooling
-modules are exported by the reference but used by no backbone, decoder or YAML: they raise
-NotImplementedError here.
+modules (exported by the reference, used by no backbone, decoder or YAML -- SURVEY.md §8 f4) run on csrc/deform_pool.hip;
+`deform_pool_cuda` is their extension-level module.
 """
 from .deform_conv import (ModulatedDeformConv, ModulatedDeformConvPack, ModulatedDeformConvFunction,  # noqa: F401
                           modulated_deform_conv, DeformConv, DeformConvPack, deform_conv)
 from . import deform_conv_cuda  # noqa: F401  (extension-level boundary)
 
 
-def _unused(name):
-    class _Unused(object):
-        def __init__(self, *a, **k):
-            raise NotImplementedError("%s is exported by the reference's assets.ops.dcn but used by no model; it is "
-                                      "out of scope of the MI355X hot path (SURVEY.md §2b)" % name)
-    _Unused.__name__ = name
-    return _Unused
-
-
-DeformRoIPooling = _unused("DeformRoIPooling")
-DeformRoIPoolingPack = _unused("DeformRoIPoolingPack")
-ModulatedDeformRoIPoolingPack = _unused("ModulatedDeformRoIPoolingPack")
-
-
-def deform_roi_pooling(*a, **k):
-    raise NotImplementedError("deform_roi_pooling is not on the hot path (SURVEY.md §2b)")
-
+from .deform_pool import (DeformRoIPooling, DeformRoIPoolingPack, ModulatedDeformRoIPoolingPack,  # noqa: F401,E402
+                          DeformRoIPoolingFunction, deform_roi_pooling)
+from . import deform_pool_cuda  # noqa: F401,E402  (extension-level boundary)
 
 __all__ = ['DeformConv', 'DeformConvPack', 'ModulatedDeformConv', 'ModulatedDeformConvPack', 'DeformRoIPooling',
            'DeformRoIPoolingPack', 'ModulatedDeformRoIPoolingPack', 'deform_conv', 'modulated_deform_conv',

@@ -130,9 +130,12 @@ class _Fan(object):
     layer (dense TN GEMMs with 16..64 output tiles: each alone leaves most CUs with one latency-bound workgroup or none,
     tools/microbench_tn_dense.py) run on side HIP streams beside each other and beside the layer's input-gradient GEMM,
     and are joined before the Function returns -- nothing outlives the call, unlike _Side.  Inside a hipGraph capture the
-    event waits become parallel branches of the graph."""
+    event waits become parallel branches of the graph.
+    MEASURED SLOWER on the CRNN step (3.31 ms with, 3.17 ms without; gpurun_out r2p): the four GEMMs compete for the
+    same CUs and lose their XCD-local tile maps; the per-launch fix that did pay is the split model in
+    gemm_conv.hip:launch_tn.  Off unless MEGREADER_FAN=1."""
     streams = {}
-    enabled = os.environ.get("MEGREADER_FAN", "1") == "1"
+    enabled = os.environ.get("MEGREADER_FAN", "0") == "1"
 
     @staticmethod
     def run(fns):
