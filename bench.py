@@ -43,16 +43,22 @@ def conv_flops(name, args, true_cin0=3):
     return 2.0 * N * Ho * Wo * Cout * R * S * Cin, N * Ho * Wo, Cout, Cin
 
 
+COMPOSITE = "+tail (2 launches)"   # a C-ABI call that launches the 256x256 head kernel AND a 4-wave tail kernel
+
+
 def kernel_label(lib, name, args, dtype_name):
     dt = 1 if dtype_name == "bf16" else 0
+
+    def nt(code):
+        if code == 256257:   # head / tail split (gemm_conv.hip:nt_head_rows): the event bracket spans two kernels
+            return "igemm_nt_kernel<%s,256,256,conv>%s" % (dtype_name, COMPOSITE)
+        return "igemm_nt_kernel<%s,%d,%d,conv>" % (dtype_name, code // 1000, code % 1000)
     if name == "mr_conv2d_fwd":
         N, H, W, Cin, _ldx, Cout, _ldy, R, S = args[6:15]
-        code = lib.mr_nt_kernel_code(dt, N * args[21] * args[22], Cout, R * S * Cin, Cin)
-        return "igemm_nt_kernel<%s,%d,%d,conv>" % (dtype_name, code // 1000, code % 1000)
+        return nt(lib.mr_nt_kernel_code(dt, N * args[21] * args[22], Cout, R * S * Cin, Cin))
     if name == "mr_conv2d_dgrad":
         N, H, W, Cin, _ld1, Cout, _ld2, R, S = args[4:13]
-        code = lib.mr_nt_kernel_code(dt, N * H * W, Cin, R * S * Cout, Cout)
-        return "igemm_nt_kernel<%s,%d,%d,conv>" % (dtype_name, code // 1000, code % 1000)
+        return nt(lib.mr_nt_kernel_code(dt, N * H * W, Cin, R * S * Cout, Cout))
     return "igemm_tn_kernel<%s,conv>" % dtype_name
 
 
@@ -355,7 +361,10 @@ def main():
                                       "tflops": round(fl / (t_ms * 1e-3) / 1e12, 1),
                                       "ms_per_step": round(t_ms / timer_steps, 4)}
                 if agg:
-                    dom = max(agg, key=lambda k: agg[k][1])
+                    # the roofline block is ONE kernel (its rocprofv3 average must agree with the event average):
+                    # event brackets that span two launches stay in `kernels` but cannot be the dominant kernel
+                    single = {k: v for k, v in agg.items() if not k.endswith(COMPOSITE)} or agg
+                    dom = max(single, key=lambda k: single[k][1])
                     fl, t_ms, n = agg[dom]
                     ach = fl / (t_ms * 1e-3) / 1e12
                     peak = MFMA_PEAK_TFLOPS[args.dtype]

@@ -142,7 +142,7 @@ __global__ void ctc_reduce_kernel(const double* __restrict__ nll, const void* tg
   double s = 0;
   for (int b = threadIdx.x; b < N; b += blockDim.x) {
     double v = nll[b];
-    if (zero_infinity && v == INFINITY) v = 0;
+    if ((zero_infinity & 1) && v == INFINITY) v = 0;
     long long L = load_idx(tg_len, b, len64);
     if (L > S) L = S;
     if (L < 1) L = 1;
@@ -183,8 +183,10 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
   if (L > S) L = S;
   const int SP = 2 * L + 1;
   const double nll = nll_in[b];
-  const bool dead = (zero_infinity && nll == INFINITY) || Tb <= 0;
-  const double k = dead ? 0.0 : grad_out[0] / ((double)N * (double)(L < 1 ? 1 : L));
+  // zero_infinity bit 1: per-sample losses nll_b / L_b (reference decoders/ctc_loss.py:118-122), grad_out is [N]
+  const bool per_sample = (zero_infinity & 2) != 0;
+  const bool dead = ((zero_infinity & 1) && nll == INFINITY) || Tb <= 0;
+  const double k = dead ? 0.0 : (per_sample ? grad_out[b] : grad_out[0] / (double)N) / (double)(L < 1 ? 1 : L);
   const bool valid = t < Tn;
   const bool active = valid && t < Tb;
   double* ab = ab_all + wave * SPmax;

@@ -478,7 +478,7 @@ int mr_nt_kernel_code(int dtype, int M, int N, int K, int cg) {
     const int big = nt_big_choice(M, N, K);
     if (big == 1) return 256256;
     if (big == 2) return 288256;
-    if (nt_head_rows(M, N, K) > 0) return 256256;   // head (whole rounds of 256x256 tiles) + a small 4-wave tail
+    if (nt_head_rows(M, N, K) > 0) return 256257;   // TWO launches: head (whole rounds of 256x256 tiles) + a 4-wave tail
   }
   return mr_nt_tile_code(M, N);
 }

@@ -1377,6 +1377,9 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
 
   const int wa = wave & 1, wb = wave >> 1;
   const int l15 = lane & 15, lg = lane >> 4;
+  // bias gradient (column sums of the A tile): done by the tile_b == 0 workgroup of every (tile_a, split) row.  Dealing
+  // its p-steps round-robin over the tiles_b workgroups (each stages the same A rows) was measured SLOWER (conv wgrad
+  // 727 -> 745 us per step: every workgroup then pays the LDS-atomic reduction and 128 global atomics of the epilogue).
   const bool do_colsum = a.colsum != nullptr && tile_b == 0;
   float csum[2][8];
 #pragma unroll
@@ -1403,7 +1406,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
 
   bf16x8 fa_keep[2][4], fb_keep[2][4];   // ABL bit 1: fragments of the first step, reused
   bool first_compute = true;
-  auto compute = [&](const unsigned char* st) {
+  auto compute = [&](const unsigned char* st, int step) {
     if (do_colsum && !(ABL & 8)) {  // bias gradient: column sums of the A tile, re-read from LDS by the lane that staged it
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
@@ -1453,14 +1456,14 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
   for (; st + 1 < nsteps; st += 2) {
     __syncthreads();
     if (!(ABL & 1)) stage(st1, p_begin + (st + 1) * BP);
-    compute(st0);
+    compute(st0, st);
     __syncthreads();
     if (!(ABL & 1) && st + 2 < nsteps) stage(st0, p_begin + (st + 2) * BP);
-    compute(st1);
+    compute(st1, st + 1);
   }
   if (st < nsteps) {
     __syncthreads();
-    compute(st0);
+    compute(st0, st);
   }
 
   if (do_colsum && !(ABL & 8)) {  // block-level reduction of the per-lane partial column sums with LDS float atomics

@@ -860,6 +860,8 @@ class CTCLossFn(Function):
         ctx.dims = (T, N, C, S, int(blank), int(zero_infinity), t64)
         ctx.dtype = dtype
         ctx.mark_non_differentiable(lp)
+        if int(zero_infinity) & 2:   # per-sample losses nll_b / L_b (reference decoders/ctc_loss.py:118-122)
+            return nll / target_lengths.to(torch.float64), lp
         return loss, lp
 
     @staticmethod
@@ -878,9 +880,12 @@ class CTCLossFn(Function):
         return grad[..., :C], None, None, None, None, None
 
 
-def ctc_loss_logits(logits, targets, input_lengths, target_lengths, blank=0, zero_infinity=True):
-    """mean-reduced CTC loss of log_softmax(logits) (fused); returns (loss, log_probs)."""
-    return CTCLossFn.apply(logits, targets, input_lengths, target_lengths, blank, zero_infinity)
+def ctc_loss_logits(logits, targets, input_lengths, target_lengths, blank=0, zero_infinity=True, per_sample=False):
+    """CTC loss of log_softmax(logits) (fused); returns (loss, log_probs).  Default: nn.CTCLoss(reduction='mean')
+    semantics (f64 scalar).  per_sample=True: the [N] vector nll_b / L_b of the reference's own python CTCLoss
+    (decoders/ctc_loss.py:118-122, reduction='mean' there means "divide by the target length", no batch mean)."""
+    flags = int(bool(zero_infinity)) | (2 if per_sample else 0)
+    return CTCLossFn.apply(logits, targets, input_lengths, target_lengths, blank, flags)
 
 
 def softmax_eval_nc1t(logits):

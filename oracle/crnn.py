@@ -53,12 +53,30 @@ class _BiLSTMHead(nn.Module):
 
 
 class CRNNDecoderOracle(nn.Module):
-    def __init__(self, num_classes=38, inner_channels=256, in_channels=512):
+    """decoders/crnn.py:27-104.  need_reduce / reduce_func (:42-46, :52-68): 'conv' = three conv-BN-ReLU + max-pool stages
+    that halve the height ((2,2) then (2,1) twice), 'pooling' = max over the height.  loss_func != 'pytorch' selects the
+    reference's own python CTC (decoders/ctc_loss.py), restated here as what it computes: per-sample nll / target length
+    (its 'mean' reduction, :118-122), no zero_infinity."""
+
+    def __init__(self, num_classes=38, inner_channels=256, in_channels=512, need_reduce=False, reduce_func=None,
+                 loss_func='pytorch'):
         super().__init__()
-        self.rnn = nn.Sequential(_BiLSTMHead(in_channels, inner_channels, inner_channels),
+        rnn_input = inner_channels if need_reduce else in_channels
+        self.rnn = nn.Sequential(_BiLSTMHead(rnn_input, inner_channels, inner_channels),
                                  _BiLSTMHead(inner_channels, inner_channels, num_classes))
+        if need_reduce and reduce_func == 'conv':
+            def cbr(i, o):
+                return nn.Sequential(nn.Conv2d(i, o, 3, 1, 1), nn.BatchNorm2d(o), nn.ReLU(inplace=True))
+            self.fpn2rnn = nn.Sequential(cbr(in_channels, inner_channels), nn.MaxPool2d((2, 2), (2, 2), (0, 0)),
+                                         cbr(inner_channels, inner_channels), nn.MaxPool2d((2, 1), (2, 1), (0, 0)),
+                                         cbr(inner_channels, inner_channels), nn.MaxPool2d((2, 1), (2, 1), (0, 0)))
+        elif need_reduce and reduce_func == 'pooling':
+            self.fpn2rnn = nn.AdaptiveMaxPool2d((1, None))
+        self.per_sample_loss = loss_func != 'pytorch'
 
     def logits(self, feature):
+        if feature.shape[2] > 1:
+            feature = self.fpn2rnn(feature)
         assert feature.shape[2] == 1
         return self.rnn(feature.squeeze(2).permute(2, 0, 1))  # [W, N, classes]
 
@@ -68,6 +86,9 @@ class CRNNDecoderOracle(nn.Module):
             logp = F.log_softmax(pred, dim=2).to(torch.float64)
             t, b = logp.shape[0], logp.shape[1]
             in_len = torch.full((b,), t, dtype=torch.int32)
+            if self.per_sample_loss:
+                nll = F.ctc_loss(logp, targets, in_len, lengths, blank=0, reduction='none', zero_infinity=False)
+                return nll / lengths.to(torch.float64), logp
             loss = F.ctc_loss(logp, targets, in_len, lengths, blank=0, reduction='mean', zero_infinity=True)
             return loss, logp
         return F.softmax(pred.permute(1, 2, 0).unsqueeze(2), dim=1)

@@ -221,3 +221,48 @@ def test_full_size_batch_runs_and_learns():
         losses.append(float(loss))
     assert all(l == l and abs(l) < 1e4 for l in losses), losses
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("reduce_func,loss_func", [("conv", "pytorch"), ("pooling", "custom"), ("conv", "custom")])
+def test_decoder_variants_need_reduce_and_python_ctc(reduce_func, loss_func):
+    """CRNNDecoder(need_reduce=True, reduce_func='conv'|'pooling') and loss_func != 'pytorch' (reference decoders/
+    crnn.py:36-50, decoders/ctc_loss.py) against oracle/crnn.py:CRNNDecoderOracle, which tests/test_oracle_models.py pins
+    to the unmodified reference.  fp32: loss / log-probabilities 1e-4, every gradient within 2e-3 of its max."""
+    from oracle.crnn import CRNNDecoderOracle
+    mr.set_compute_dtype(torch.float32)
+    try:
+        cin = 48 if reduce_func == "conv" else 32
+        kw = dict(inner_channels=32, in_channels=cin, need_reduce=True, reduce_func=reduce_func, loss_func=loss_func)
+        torch.manual_seed(5)
+        ora = CRNNDecoderOracle(num_classes=38, **kw).train()
+        model = CRNNDecoder(**kw)
+        model.load_state_dict(ora.state_dict(), strict=True)
+        model.to("cuda").train()
+        g = torch.Generator().manual_seed(1)
+        feat = torch.randn(4, cin, 8, 20, generator=g)
+        labels = torch.randint(2, 38, (4, 6), generator=g, dtype=torch.int32)
+        lengths = torch.tensor([6, 3, 4, 1], dtype=torch.int32)
+        fo = feat.clone().requires_grad_(True)
+        lo, po = ora(fo, targets=labels, lengths=lengths, train=True)
+        lo.mean().backward()
+        fd = feat.to("cuda").requires_grad_(True)
+        ld, pd = model(fd, targets=labels.to("cuda"), lengths=lengths.to("cuda"), train=True)
+        assert ld.shape == lo.shape and ld.dtype == lo.dtype == torch.float64
+        assert (ld.cpu() - lo).abs().max() < 1e-4 * max(1.0, float(lo.abs().max()))
+        assert (pd.cpu() - po).abs().max() < 1e-4
+        ld.mean().backward()
+
+        def rel(a, b):
+            return float((a.double().cpu() - b.double()).abs().max() / (b.double().abs().max() + 1e-12))
+        assert rel(fd.grad, fo.grad) < 2e-3
+        op = dict(ora.named_parameters())
+        for k, p in model.named_parameters():
+            assert p.grad is not None, k
+            if ".0.bias" in k and "fpn2rnn" in k:     # conv bias in front of a BatchNorm: mathematically zero gradient
+                continue
+            assert rel(p.grad, op[k].grad) < 2e-3, (k, rel(p.grad, op[k].grad))
+        model.eval(), ora.eval()
+        with torch.no_grad():
+            assert (model(fd).cpu() - ora(feat)).abs().max() < 1e-4
+    finally:
+        mr.set_compute_dtype(torch.bfloat16)

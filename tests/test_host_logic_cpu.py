@@ -108,3 +108,24 @@ def test_synthetic_batches_match_the_oracle_generators():
     assert all(torch.equal(a[k], b[k]) for k in a)
     a, b = recognition_batch_2d(5, 32, 128, seed=4, max_len=3), synthetic_batch_2d(5, 32, 128, seed=4, max_len=3)
     assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_msgpack_record_unpack_follows_the_reference_rules():
+    """data/unpack_msgpack_data.py:27-52: b'img' -> decoded image (RGB -> BGR in mode 'BGR'), other bytes -> str,
+    containers recurse, byte keys decoded.  The image stays uint8 here (the float conversion runs on the GPU)."""
+    import io
+    import msgpack
+    import numpy as np
+    from PIL import Image
+    from megreader_amd.data import UnpackMsgpackData
+    rgb = np.random.default_rng(0).integers(0, 256, (7, 11, 3), dtype=np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(rgb).save(buf, format='PNG')
+    rec = msgpack.dumps({b'img': buf.getvalue(), b'gt': 'Hello'.encode(), b'lines': [b'a', {b'poly': [1, 2.5]}],
+                         b'n': 3}, use_bin_type=False)
+    out = UnpackMsgpackData()(rec, data_id='id0')
+    assert out['gt'] == 'Hello' and out['lines'] == ['a', {'poly': [1, 2.5]}] and out['n'] == 3
+    assert out['data_id'] == 'id0'
+    assert out['img'].dtype == np.uint8 and out['img'].flags['C_CONTIGUOUS']
+    assert np.array_equal(out['img'], rgb[:, :, ::-1])
+    assert np.array_equal(UnpackMsgpackData(mode='RGB').convert(rec)['img'], rgb)

@@ -60,7 +60,7 @@ def test_gemm_nt_head_tail_split(M, N, K):
     from megreader_amd._lib import load
     lib = load()
     dtype = torch.bfloat16
-    assert lib.mr_nt_kernel_code(1, M, N, K, 0) == 256256, "the head/tail path must apply to this shape"
+    assert lib.mr_nt_kernel_code(1, M, N, K, 0) == 256257, "the head/tail path must apply to this shape"
     g = torch.Generator().manual_seed(M)
     A = (torch.randn(M, K, generator=g) * 0.5).to(DEV, dtype)
     B = (torch.randn(N, K, generator=g) * 0.5).to(DEV, dtype)

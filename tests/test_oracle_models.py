@@ -106,3 +106,42 @@ def test_seg_detector_oracle_and_mirror_vs_reference():
     lr_, _ = RefLoss()(pr, batch)
     lm_, _ = L1BalanceCELoss()(pr, batch)
     assert torch.equal(lr_, lm_) and torch.equal(lr_, l1_balance_ce_loss(po, batch))
+
+
+@pytest.mark.parametrize("reduce_func,loss_func", [("conv", "pytorch"), ("pooling", "custom")])
+def test_crnn_decoder_variants_oracle_vs_reference(reduce_func, loss_func):
+    """CRNNDecoder(need_reduce=True, reduce_func=...) and loss_func != 'pytorch' (decoders/crnn.py:36-50): the oracle
+    equals the unmodified reference on CPU -- state_dict keys and seeded init, training loss and log-probabilities
+    (the reference's python CTCLoss, decoders/ctc_loss.py, against its restatement as per-sample nll / length: 1e-9),
+    eval softmax -- and the HIP mirror has the same state_dict."""
+    from oracle import refimport
+    if not refimport.available():
+        pytest.skip("reference tree not present")
+    refimport.import_reference()
+    from decoders.crnn import CRNNDecoder as RefDecoder
+    from megreader_amd.decoders import CRNNDecoder
+    from megreader_amd.charsets import DefaultCharset
+    from oracle.crnn import CRNNDecoderOracle
+    # 'pooling' keeps the channel count while the LSTM expects inner_channels: the reference only works with equal counts
+    cin = 48 if reduce_func == "conv" else 32
+    kw = dict(inner_channels=32, in_channels=cin, need_reduce=True, reduce_func=reduce_func, loss_func=loss_func)
+    torch.manual_seed(5)
+    ref = RefDecoder(**kw)
+    torch.manual_seed(5)
+    ora = CRNNDecoderOracle(num_classes=len(DefaultCharset()), **kw)
+    torch.manual_seed(5)
+    ours = CRNNDecoder(**kw)
+    assert list(ref.state_dict()) == list(ora.state_dict()) == list(ours.state_dict())
+    for k, v in ref.state_dict().items():
+        assert torch.equal(v, ora.state_dict()[k]) and torch.equal(v, ours.state_dict()[k]), k
+    g = torch.Generator().manual_seed(1)
+    feat = torch.randn(3, cin, 8, 20, generator=g)
+    labels = torch.randint(2, 38, (3, 6), generator=g, dtype=torch.int32)
+    lengths = torch.tensor([6, 3, 4], dtype=torch.int32)
+    ref.train(), ora.train()
+    lr_, pr = ref(feat, targets=labels, lengths=lengths, train=True)
+    lo, po = ora(feat, targets=labels, lengths=lengths, train=True)
+    assert torch.equal(pr, po)
+    assert lr_.shape == lo.shape and (lr_.detach().double() - lo.detach()).abs().max() < 1e-9 * max(1.0, float(lo.detach().abs().max()))
+    ref.eval(), ora.eval()
+    assert torch.equal(ref(feat), ora(feat))
