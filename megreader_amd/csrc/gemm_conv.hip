@@ -304,6 +304,7 @@ static int launch_tn_big(TnArgs a, const ConvGeom& g, int total_steps, hipStream
   }
   a.p_chunk = cdiv(cdiv(a.P, bsplits), 64) * 64;
   bsplits = cdiv(a.P, a.p_chunk);
+  if (g_tn_abl & 8) a.colsum = nullptr;   // timing-only: no fused column sums (wrong bias gradient)
   constexpr int lds = 2 * (SA + 2) * 64 * 256 + 1024;  // 2 stages x [A.. | B0 | B1] x 16 KB + column-sum accumulator
   auto kern = igemm_tn_big_kernel<BMODE, SA>;
   static bool attr_set = false;
@@ -350,9 +351,14 @@ static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
     // cause is elsewhere (one barrier-coupled workgroup per CU with only 32 MFMAs per wave between barriers cannot
     // hide the load latency that two independent 4-wave workgroups hide) -- left for a counter-based look.
     if (g_nt_variant == 2 && g_tn_big > 0) {
-      const int rc = g_tn_big == 2 ? launch_tn_big<BMODE, 1>(a, g, total_steps, stream)
-                                   : launch_tn_big<BMODE, 2>(a, g, total_steps, stream);
-      return rc;
+      const long long bytesA0 = (long long)a.P * a.lda * 2;
+      const long long bytesB0 = BMODE == 0 ? (long long)a.P * a.ldb * 2
+                                           : ((long long)a.P / ((long long)g.Hm * g.Wm) + 1) * g.Hg * g.Wg * g.ldg * 2;
+      if (bytesA0 < (1ll << 31) && bytesB0 < (1ll << 31)) {   // buffer-resource staging
+        const int rc = g_tn_big == 2 ? launch_tn_big<BMODE, 1>(a, g, total_steps, stream)
+                                     : launch_tn_big<BMODE, 2>(a, g, total_steps, stream);
+        return rc;
+      }
     }
   }
   a.p_chunk = cdiv(cdiv(a.P, splits), BP) * BP;
@@ -591,7 +597,7 @@ int mr_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw_krsc, fl
 int mr_conv2d_wgrad_tab(int dtype, const void* dy, const void* x, float* dw_krsc, float* dbias, int Nimg, int H,
                         int W, int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw,
                         int dh, int dw, int Ho, int Wo, void* rowtab, int build, hipStream_t stream) {
-  if (rowtab == nullptr || dtype != MR_BF16 || R * S > 32 || g_nt_variant != 2 || g_tn_big > 0)
+  if (rowtab == nullptr || dtype != MR_BF16 || R * S > 32 || g_nt_variant != 2)
     return mr_conv2d_wgrad(dtype, dy, x, dw_krsc, dbias, Nimg, H, W, Cin, ldx, Cout, lddy, R, S, sh, sw, ph, pw, dh,
                            dw, Ho, Wo, stream);
   MR_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && Cout % 8 == 0 && lddy % 8 == 0,

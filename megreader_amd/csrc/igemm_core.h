@@ -1531,7 +1531,13 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
 // 8 column blocks), B sub-tile wb>>1, column blocks (wb&1)*4 .. +3.
 // ---------------------------------------------------------------------------------------------
 // SA = number of 128-column A sub-tiles: 2 -> 256x256 tile (wave tile 128x64), 1 -> 128 (NA) x 256 (NB) tile (wave
-// tile 64x64, 64 accumulator registers: no spills; L2 operand traffic 0.75x of the 128x128 kernel).
+// tile 64x64; L2 operand traffic 0.75x of the 128x128 kernel).
+// Round-2 rewrite: (1) operand staging is the 128x128 kernel's (32-bit element offsets advanced by additions, row table
+// for BMODE 2, raw buffer resources: out-of-range -> zeros) -- the first version still carried the 64-bit multiplies
+// and zero-page selects; (2) the A fragments are read ONE ROW TILE AHEAD of the MFMAs that consume them: the first
+// version read each A fragment inside the row-tile loop right before its 4 MFMAs, so every row tile paid a full LDS
+// read latency with nothing to hide it behind (two waves per SIMD) -- measured 3-4x slower than the 128x128 kernel.
+// Operands must be < 2 GiB each (buffer-resource num_records); the launcher checks.
 template <int BMODE, int SA>
 __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g, const void* zero) {
   typedef bf16_t T;
@@ -1540,6 +1546,7 @@ __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g,
   constexpr int TA = 128 * SA, TI = 4 * SA;                            // tile rows (NA), A column blocks per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_tn_big[];
   unsigned char* smem = smem_tn_big;
+  (void)zero;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1562,7 +1569,8 @@ __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g,
   const T* __restrict__ B = (const T*)a.B;
   const int lrow = lane >> 4, pc16 = lane & 15, pp = pc16 >> 1, half = pc16 & 1;
 
-  int colA[2], colB[2], tr[2], ts[2], tc[2], dho[2], dwo[2];
+  // staging state: see igemm_tn_glds_kernel (same lane mapping inside a 128-column sub-tile)
+  int colA[2], colB[2], tapoff[2], dho[2], dwo[2], tapbit[2];
   bool okA[2], okB[2];
 #pragma unroll
   for (int h2 = 0; h2 < 2; ++h2) {
@@ -1572,60 +1580,88 @@ __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g,
     colB[h2] = nb0 + col;
     okA[h2] = colA[h2] < a.NA && sub < SA;
     okB[h2] = colB[h2] < a.NB;
-    tr[h2] = ts[h2] = 0;
-    tc[h2] = colB[h2];
+    tapoff[h2] = colB[h2];
     dho[h2] = dwo[h2] = 0;
-    if (BMODE == 1) {
+    tapbit[h2] = 0;
+    if (BMODE != 0) {
       const int tap = colB[h2] / g.Cg;
-      tc[h2] = colB[h2] - tap * g.Cg;
-      tr[h2] = tap / g.S;
-      ts[h2] = tap - tr[h2] * g.S;
-      dho[h2] = tr[h2] * g.dh - g.ph;
-      dwo[h2] = ts[h2] * g.dw - g.pw;
+      const int tc = colB[h2] - tap * g.Cg;
+      const int tr = tap / g.S, ts = tap - tr * g.S;
+      dho[h2] = tr * g.dh - g.ph;
+      dwo[h2] = ts * g.dw - g.pw;
+      tapoff[h2] = (dho[h2] * g.Wg + dwo[h2]) * g.ldg + tc;
+      tapbit[h2] = tap;
     }
   }
-  // pixel coordinates of this lane's FIRST staged row (jj = 0) of the next p-step; rows jj = 1..3 are 4, 8, 12
-  // pixels further and are derived on the fly (keeps 9 registers out of the 256-register budget)
-  int q_n = 0, q_h = 0, q_w = 0;
-  if (BMODE == 1) {
-    const int p = p_begin + (w4 * 4) * 4 + lrow;
-    q_w = p % g.Wm;
-    const int t = p / g.Wm;
-    q_h = t % g.Hm;
-    q_n = t / g.Hm;
+  const int ro0 = w4 * 16 + lrow;   // staged rows of this lane: ro0 + 4*jj
+  int soffA[4], soffB[4], q_h[4], q_w[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int p = p_begin + ro0 + 4 * jj;
+    soffA[jj] = (int)((long long)p * a.lda) + colA[jj >> 1];
+    q_h[jj] = q_w[jj] = 0;
+    if (BMODE == 0) {
+      soffB[jj] = (int)((long long)p * a.ldb) + colB[jj >> 1];
+    } else if (BMODE == 2) {
+      soffB[jj] = 0;
+    } else {
+      q_w[jj] = p % g.Wm;
+      const int t = p / g.Wm;
+      q_h[jj] = t % g.Hm;
+      const int qn = t / g.Hm;
+      soffB[jj] = (int)((((long long)qn * g.Hg + q_h[jj] * g.sh) * g.Wg + q_w[jj] * g.sw) * g.ldg);
+    }
   }
+  const int stepA = BP * (int)a.lda;
+  const int stepB = BMODE == 0 ? BP * (int)a.ldb : BP * g.sw * g.ldg;
+  int2 ent[4];
+  auto fetch_entries = [&](int p0) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int p = p0 + ro0 + 4 * jj;
+      ent[jj] = p < p_end ? a.rowtab[p] : make_int2(0, 0);
+    }
+  };
+  if (BMODE == 2) fetch_entries(p_begin);
+  const int wrap_w = BMODE == 1 ? (g.sh * g.Wg - g.Wm * g.sw) * g.ldg : 0;
+  const int wrap_h = BMODE == 1 ? (g.Hg - g.Hm * g.sh) * g.Wg * g.ldg : 0;
+  const rsrc_t rsA = make_rsrc(A), rsB = make_rsrc(B);
 
   auto stage = [&](unsigned char* st, int p0) {
     unsigned char* sA = st + sub * SUB_BYTES;
     unsigned char* sB = st + (SA + sub) * SUB_BYTES;
+    const int rows_left = p_end - p0;  // uniform
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int h2 = jj >> 1;
-      const int p = p0 + (w4 * 4 + jj) * 4 + lrow;
-      const bool pv = p < p_end;
-      if (SA == 2 || sub == 0)
-        glds16(sel_ptr(pv && okA[h2], A + (long long)p * a.lda + colA[h2], zero), sA + (w4 * 4 + jj) * 1024);
+      const bool pv = ro0 + 4 * jj < rows_left;
+      if (SA == 2 || sub == 0) {
+        glds16_buf(rsA, pv && okA[h2], soffA[jj], 1, sA + (w4 * 4 + jj) * 1024);
+        soffA[jj] += stepA;
+      }
       if (BMODE == 0) {
-        glds16(sel_ptr(pv && okB[h2], B + (long long)p * a.ldb + colB[h2], zero), sB + (w4 * 4 + jj) * 1024);
+        glds16_buf(rsB, pv && okB[h2], soffB[jj], 1, sB + (w4 * 4 + jj) * 1024);
+        soffB[jj] += stepB;
+      } else if (BMODE == 2) {
+        const bool v = okB[h2] && ((ent[jj].y >> tapbit[h2]) & 1);
+        glds16_buf(rsB, v, ent[jj].x + tapoff[h2], 1, sB + (w4 * 4 + jj) * 1024);
       } else {
-        int jn = q_n, jh = q_h, jw = q_w + 4 * jj;
-        while (jw >= g.Wm) {
-          jw -= g.Wm;
-          if (++jh == g.Hm) { jh = 0; ++jn; }
-        }
-        const int hi = jh * g.sh + dho[h2], wi = jw * g.sw + dwo[h2];
+        const int hi = q_h[jj] * g.sh + dho[h2], wi = q_w[jj] * g.sw + dwo[h2];
         const bool v = pv && okB[h2] && (unsigned)hi < (unsigned)g.Hg && (unsigned)wi < (unsigned)g.Wg;
-        const long long off = ((long long)(jn * g.Hg + hi) * g.Wg + wi) * g.ldg + tc[h2];
-        glds16(sel_ptr(v, B + off, zero), sB + (w4 * 4 + jj) * 1024);
+        glds16_buf(rsB, v, soffB[jj] + tapoff[h2], 1, sB + (w4 * 4 + jj) * 1024);
+        q_w[jj] += BP;
+        soffB[jj] += stepB;
+        while (q_w[jj] >= g.Wm) {
+          q_w[jj] -= g.Wm;
+          soffB[jj] += wrap_w;
+          if (++q_h[jj] == g.Hm) {
+            q_h[jj] = 0;
+            soffB[jj] += wrap_h;
+          }
+        }
       }
     }
-    if (BMODE == 1) {
-      q_w += BP;
-      while (q_w >= g.Wm) {
-        q_w -= g.Wm;
-        if (++q_h == g.Hm) { q_h = 0; ++q_n; }
-      }
-    }
+    if (BMODE == 2) fetch_entries(p0 + BP);
   };
 
   const int wa = wave & 1, wb = wave >> 1;  // compute role: 2 x 4 waves, wave tile (64*SA) (NA) x 64 (NB)
@@ -1641,12 +1677,28 @@ __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g,
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // fragment addresses: byte offset of column block `blk` is ((blk ^ hsh) << 5) + rbase.  rbase has bits 5..7 clear, so
+  // that equals (rbase | hsh << 5) ^ (blk << 5): ONE lane constant per operand and a v_xor with an immediate per
+  // fragment instead of 12 precomputed offsets held in registers across the loop (the 256x256 variant spilled).
   const int hsh = (l15 >> 2) | ((lg & 1) << 2);
-  const int rbase = (lg * 8 + (l15 >> 2)) * ROW_BYTES + (l15 & 3) * 8;
-  const int baseA = (SA == 2 ? wa : 0) * SUB_BYTES + rbase;
+  const int rbase = ((lg * 8 + (l15 >> 2)) * ROW_BYTES + (l15 & 3) * 8) | (hsh << 5);
+  const int baseA = (SA == 2 ? wa : 0) * SUB_BYTES + rbase;   // sub-tile bases are multiples of 16 KB: XOR-safe
   const int baseB = (SA + (wb >> 1)) * SUB_BYTES + rbase;
   const int cb0 = (wb & 1) * 4;
   const int ca0 = SA == 2 ? 0 : wa * 4;  // first A column block of this wave
+
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  auto frag = [&](const unsigned char* stg, int base, int blk, int kk) -> bf16x8 {
+    // volatile: hipcc otherwise hoists all 12 XORs out of the p-loop as loop invariants and, at 256 registers,
+    // SPILLS them -- each reload then sits behind an s_waitcnt vmcnt(0) that also waits for the LDS-DMA prefetch
+    int off;
+    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(off) : "v"(base), "v"(blk << 5));
+    const unsigned char* q = stg + off + kk * 32 * ROW_BYTES;
+    const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(q));
+    const s16x4 x1 =
+        __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(q + 4 * ROW_BYTES));
+    return __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
 
   auto compute = [&](const unsigned char* st) {
     if (cs_lane) {
@@ -1668,24 +1720,16 @@ __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g,
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 fb[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        union { s16x4 h[2]; bf16x8 v; } ub;
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-          ub.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(
-              st + baseB + (((cb0 + t) ^ hsh) << 5) + kk * 32 * ROW_BYTES + hh * 4 * ROW_BYTES));
-        fb[t] = ub.v;
-      }
+      for (int t = 0; t < 4; ++t) fb[t] = frag(st, baseB, cb0 + t, kk);
+      bf16x8 fa = frag(st, baseA, ca0, kk);
 #pragma unroll
       for (int i = 0; i < TI; ++i) {
-        union { s16x4 h[2]; bf16x8 v; } ua;
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-          ua.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(
-              st + baseA + (((ca0 + i) ^ hsh) << 5) + kk * 32 * ROW_BYTES + hh * 4 * ROW_BYTES));
+        bf16x8 fn = fa;
+        if (i + 1 < TI) fn = frag(st, baseA, ca0 + i + 1, kk);   // one row tile ahead of its MFMAs
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+        fa = fn;
       }
     }
   };

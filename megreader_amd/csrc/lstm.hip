@@ -219,6 +219,7 @@ int lstm_fwd_persist(const void* xproj, const void* whh, void* out, float* cbuf,
 int lstm_bwd_persist(const void* dout, const void* whhT, const float* cbuf, void* gates, int T, int N, void* ws,
                      long long ws_bytes, hipStream_t stream);
 void lstm_set_bwd_debug(float* p);
+int lstm_set_xcd_map(int on);
 static int g_lstm_persist = 1;
 
 }  // namespace mr
@@ -245,9 +246,11 @@ int mr_lstm_debug_buffer(float* p) {
   return MR_OK;
 }
 
-// Host-only switch: 1 (default) = persistent one-launch recurrence where applicable, 0 = per-step launches.
+// Host-only switch: 1 (default) = persistent one-launch recurrence where applicable, 0 = per-step launches,
+// 2 = persistent without the XCD-colocating block map (A/B: every hand-off then crosses XCDs through sc1 stores).
 int mr_set_lstm_persist(int on) {
   g_lstm_persist = on != 0;
+  lstm_set_xcd_map(on != 2);
   return MR_OK;
 }
 

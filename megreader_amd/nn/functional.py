@@ -679,6 +679,7 @@ def linear(x, weight, bias=None):
 # Bidirectional LSTM.  reference: nn.LSTM(nIn, nHidden, bidirectional=True) at decoders/crnn.py:13
 # --------------------------------------------------------------------------------------------------
 LSTM_STATUS = None   # tests set this to a list: status words of the persistent-recurrence workspaces handed out
+LSTM_LOCAL = None    # ... and this one to a list of word 1 (workgroups that found their batch group on one XCD)
 
 
 def _lstm_workspace(dt, T, N, H, dev):
@@ -691,6 +692,8 @@ def _lstm_workspace(dt, T, N, H, dev):
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     if LSTM_STATUS is not None:
         LSTM_STATUS.append(ws[nbytes - 256:nbytes - 252])
+    if LSTM_LOCAL is not None:
+        LSTM_LOCAL.append(ws[nbytes - 252:nbytes - 248])
     return ws
 
 

@@ -518,6 +518,16 @@ def test_big_tile_tn_kernel_matches_128_tile_kernel(mode):
             return gw, gb
 
         (w0, b0), (w1, b1) = both(wgrad)
+        tab = torch.empty(Nb * Ho * Wo, 2, dtype=torch.int32, device=DEV)
+
+        def wgrad_tab():   # the row-table path (what the training step uses) through the wide-tile kernel
+            gw = torch.zeros(Kc, k, k, C, device=DEV)
+            gb = torch.zeros(Kc, device=DEV)
+            call("mr_conv2d_wgrad_tab", dt, ptr(dy), ptr(x), ptr(gw), ptr(gb), Nb, H, W, C, C, Kc, Kc, k, k, 1, 1, p, p,
+                 1, 1, Ho, Wo, ptr(tab), 1)
+            return gw, gb
+
+        (_, _), (w2, b2) = both(wgrad_tab)
         xr = x.double().cpu().permute(0, 3, 1, 2)
         wr = torch.zeros(Kc, C, k, k, dtype=torch.float64, requires_grad=True)
         TF.conv2d(xr, wr, None, 1, p).backward(dy.double().cpu().permute(0, 3, 1, 2))
@@ -525,6 +535,7 @@ def test_big_tile_tn_kernel_matches_128_tile_kernel(mode):
         assert _rel_err(w1, want) < 2e-5 and _rel_err(w0, want) < 2e-5, (Nb, H, W)
         bsum = dy.double().cpu().sum(dim=(0, 1, 2))
         assert _rel_err(b1, bsum) < 2e-5 and _rel_err(b0, bsum) < 2e-5
+        assert _rel_err(w2, want) < 2e-5 and _rel_err(b2, bsum) < 2e-5, ("row table", Nb, H, W)
 
 
 def test_conv_wgrad_row_table_matches_plain_wgrad():

@@ -28,7 +28,7 @@ def main():
     mr.set_compute_dtype(dtype)
     T, N, H = 33, 256, 256
     variants = [(0, 0), (0, 16), (0, 32), (0, 64), (32, 32), (64, 32)] if "--sweep" in sys.argv else [(-1, -1)]
-    persist = 0 if "--no-persist" in sys.argv else 1
+    persist = 0 if "--no-persist" in sys.argv else (2 if "--no-xcd" in sys.argv else 1)
     load().mr_set_lstm_persist(persist)
     for fv, bv in variants:
       load().mr_set_lstm_variant(fv, bv)
@@ -60,6 +60,12 @@ def main():
                 fn()
             return gr.replay
 
+        F.LSTM_LOCAL = []
+        fwdbwd()
+        torch.cuda.synchronize()
+        print("  workgroups that found their batch group on one XCD (fwd, bwd): %s of %d" %
+              ([int(w.view(torch.int32).item()) for w in F.LSTM_LOCAL], 2 * ((N + 15) // 16) * 4))
+        F.LSTM_LOCAL = None
         tf = timeit(graphed(fwd))
         tfb = timeit(graphed(fwdbwd))
         print("  BiLSTM I=%d: fwd %.1f us, fwd+bwd %.1f us (bwd ~%.1f us)" % (I, tf, tfb, tfb - tf))
