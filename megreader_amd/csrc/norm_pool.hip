@@ -356,6 +356,60 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char
   }
 }
 
+// Same gather with the window geometry as template constants (the CRNN / ResNet pools: 2x2 stride (2,2) and (2,1),
+// 3x3 stride 2): no runtime divisions (the generic kernel spends ~40 integer instructions per element on them and ran
+// at 1.7 TB/s), the window loops unrolled, one 8-byte load for the arg-max codes, one (n, h) row per blockIdx.y.
+template <typename T, int KH, int KW, int SH, int SW>
+__global__ __launch_bounds__(256) void maxpool_bwd_fixed_kernel(const T* __restrict__ dy,
+                                                                 const unsigned char* __restrict__ idx,
+                                                                 const T* __restrict__ relu_y, T* __restrict__ dx,
+                                                                 int H, int W, int cv, int ph, int pw, int Ho,
+                                                                 int Wo) {
+  constexpr int VEC = VecOf<T>::N;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= W * cv) return;
+  const int w = t / cv, c = t - w * cv;      // cv is small: one division per thread, not per window tap
+  const int n = blockIdx.y / H, h = blockIdx.y - n * H;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < KH; ++i) {
+    const int hn = h + ph - i;
+    const int ho = hn / SH;
+    if (hn < 0 || ho * SH != hn || ho >= Ho) continue;
+#pragma unroll
+    for (int jx = 0; jx < KW; ++jx) {
+      const int wn = w + pw - jx;
+      const int wo = wn / SW;
+      if (wn < 0 || wo * SW != wn || wo >= Wo) continue;
+      const long long o = (((long long)n * Ho + ho) * Wo + wo) * cv + c;
+      const uint4 g = ((const uint4*)dy)[o];
+      const T* pg = (const T*)&g;
+      unsigned char code[8];
+      if (VEC == 8) *(uint2*)code = *(const uint2*)(idx + o * VEC);
+      else *(unsigned*)code = *(const unsigned*)(idx + o * VEC);
+      const unsigned char want = (unsigned char)(i * KW + jx);
+      if (relu_y) {
+        const uint4 yv = ((const uint4*)relu_y)[o];
+        const T* py = (const T*)&yv;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          if (code[j] == want && to_f32(py[j]) > 0.f) acc[j] += to_f32(pg[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          if (code[j] == want) acc[j] += to_f32(pg[j]);
+      }
+    }
+  }
+  uint4 out;
+  T* po = (T*)&out;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) po[j] = from_f32<T>(acc[j]);
+  ((uint4*)dx)[((long long)blockIdx.y * W + w) * cv + c] = out;
+}
+
 static inline int grid_for(long long n, int block, int max_blocks = 16384) {
   long long b = (n + block - 1) / block;
   if (b > max_blocks) b = max_blocks;
@@ -488,6 +542,20 @@ int mr_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, const vo
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(C % vec == 0, "mr_maxpool_bwd: C (%d) must be a multiple of %d", C, vec);
   const long long total = (long long)N * H * W * (C / vec);
+  const int cv = C / vec;
+  if ((long long)N * H <= 65535) {   // one (n, h) row per blockIdx.y
+    const dim3 grid(cdiv(W * cv, 256), N * H);
+#define MR_POOL_FIXED(KH_, KW_, SH_, SW_)                                                                            \
+  if (kh == KH_ && kw == KW_ && sh == SH_ && sw == SW_) {                                                            \
+    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_fixed_kernel<T, KH_, KW_, SH_, SW_>), grid, dim3(256), 0,       \
+                                         stream, (const T*)dy, idx, (const T*)relu_y, (T*)dx, H, W, cv, ph, pw, Ho,  \
+                                         Wo));                                                                       \
+    MR_CHECK_LAUNCH();                                                                                               \
+    return MR_OK;                                                                                                    \
+  }
+    MR_POOL_FIXED(2, 2, 2, 2) MR_POOL_FIXED(2, 2, 2, 1) MR_POOL_FIXED(3, 3, 2, 2)
+#undef MR_POOL_FIXED
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
                                        (const T*)dy, idx, (const T*)relu_y, (T*)dx, N, H, W, C, kh, kw, sh, sw, ph,
                                        pw, Ho, Wo));

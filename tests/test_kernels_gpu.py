@@ -189,8 +189,12 @@ def test_batchnorm(dtype, relu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("k,s,p", [((2, 2), (2, 2), (0, 0)), ((2, 2), (2, 1), (0, 1)), ((3, 3), (2, 2), (1, 1))])
-def test_maxpool(dtype, k, s, p):
+@pytest.mark.parametrize("relu_input", [False, True])
+@pytest.mark.parametrize("k,s,p", [((2, 2), (2, 2), (0, 0)), ((2, 2), (2, 1), (0, 1)), ((3, 3), (2, 2), (1, 1)),
+                                   ((3, 2), (1, 2), (1, 0))])
+def test_maxpool(dtype, k, s, p, relu_input):
+    """Forward bit-exact (first-max rule on ties); backward in the fixed-geometry kernels (2x2/2, 2x2/(2,1), 3x3/2) and the
+    generic one (3x2/(1,2)); relu_input=True also applies the mask of the ReLU that produced the pool input."""
     mr.set_compute_dtype(dtype)
     g = torch.Generator().manual_seed(11)
     x = torch.randn(3, 16, 10, 14, generator=g).to(dtype)
@@ -200,10 +204,11 @@ def test_maxpool(dtype, k, s, p):
     gy = torch.randn(yr.shape, generator=g).to(dtype)
     yr.backward(gy.double())
     xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    y = F.max_pool2d(xd, k, s, p)
+    y = F.max_pool2d(xd, k, s, p, relu_input=relu_input)
     assert torch.equal(y.float().cpu(), yr.float())
     y.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
-    assert _rel_err(xd.grad, xr.grad) < (1e-6 if dtype == torch.float32 else 1e-2)
+    want = xr.grad * (x.double() > 0) if relu_input else xr.grad
+    assert _rel_err(xd.grad, want) < (1e-6 if dtype == torch.float32 else 1e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
