@@ -159,6 +159,9 @@ int mr_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
 int mr_sgd_step(float* p, const float* g, float* buf, long long n, float* hyper, hipStream_t stream);
 
 /* ---- BatchNorm2d / MaxPool2d (backbones/crnn.py:17-31,49-52; backbones/resnet.py:26-30,199) ------------- */
+/* doubles of reduction scratch mr_bn_fwd_train / mr_bn_bwd want for C channels (several accumulator copies: fewer
+ * same-address atomics; the backward keeps 2*C f32 per-channel means behind them) */
+long long mr_bn_scratch_doubles(int C);
 int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* save_mean, float* save_rstd, double* sums, const void* residual,
                     int relu, long long P, int C, float eps, float momentum, long long* num_batches_tracked,

@@ -4,6 +4,8 @@
 #include "common.h"
 #include "../../include/megreader_hip.h"
 
+#define MR_BN_COPIES 8   /* accumulator copies of the forward statistics pass (see bn_reduce_vec_kernel) */
+
 namespace mr {
 
 // ------------------------------------------------------------------ BN statistics
@@ -45,9 +47,13 @@ __global__ __launch_bounds__(256) void bn_reduce_vec_kernel(const T* __restrict_
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             double* __restrict__ sums, int relu, int P, int C,
-                                                            int rows_per_block) {
+                                                            int rows_per_block, int ncopy) {
   constexpr int VEC = VecOf<T>::N;
   __shared__ float red[2][256 * VEC];  // [s|q][group][C] with groups * C == 256 * VEC
+  // ncopy > 1: the blocks spread their 2C f64 atomics over `ncopy` copies of the accumulator (block b -> copy b % ncopy;
+  // bn_finalize_kernel adds the copies).  512 blocks x 2C atomics on 2C addresses serialise in L2: the statistics pass
+  // of a 16384 x 256 map took 16.7 us for 8 MB (1.3 TB/s) with one copy.
+  sums += (size_t)(blockIdx.x % ncopy) * 2 * C;
   const int cv = C / VEC;
   const int groups = 256 / cv;  // >= 1
   const int g = threadIdx.x / cv, v = threadIdx.x - g * cv;
@@ -114,15 +120,20 @@ __global__ __launch_bounds__(256) void bn_reduce_vec_kernel(const T* __restrict_
 }
 
 // mean / rstd from sums, running-stat update (PyTorch: running = (1-mom)*running + mom*stat, unbiased var)
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int P, int C, float eps, float momentum,
-                                   float* __restrict__ mean, float* __restrict__ rstd,
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int ncopy, int P, int C, float eps,
+                                   float momentum, float* __restrict__ mean, float* __restrict__ rstd,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    long long* __restrict__ num_batches_tracked) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;  // nn.BatchNorm2d's step counter (one launch saved)
   if (c >= C) return;
-  const double m = sums[c] / P;
-  double var = sums[C + c] / P - m * m;
+  double s1 = 0, s2 = 0;
+  for (int k = 0; k < ncopy; ++k) {
+    s1 += sums[(size_t)k * 2 * C + c];
+    s2 += sums[(size_t)k * 2 * C + C + c];
+  }
+  const double m = s1 / P;
+  double var = s2 / P - m * m;
   if (var < 0) var = 0;
   mean[c] = (float)m;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -194,24 +205,37 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
   }
 }
 
-// dx = gamma*rstd*(dy' - mean(dy') - xhat*mean(dy'*xhat)); also emits dgamma/dbeta (block 0) and the
-// relu-masked dy' as residual gradient when dres != null.
+// backward finalize: adds the accumulator copies, emits dgamma / dbeta and the two per-channel means the apply pass
+// needs as f32 (sbg[c] = mean(dy'), sbg[C + c] = mean(dy' * xhat)) -- the apply pass used to convert 16 doubles per
+// 16-byte vector
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int ncopy, long long P, int C,
+                                       float* __restrict__ sbg, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int k = 0; k < ncopy; ++k) {
+    s1 += sums[(size_t)k * 2 * C + c];
+    s2 += sums[(size_t)k * 2 * C + C + c];
+  }
+  const float invP = 1.f / (float)P;
+  sbg[c] = (float)s1 * invP;
+  sbg[C + c] = (float)s2 * invP;
+  // accumulate: dgamma / dbeta are gradient sinks (views of the optimizer's flat gradient buffer)
+  dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+  dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+}
+
+// dx = gamma*rstd*(dy' - mean(dy') - xhat*mean(dy'*xhat)); also writes the relu-masked dy' as residual gradient when
+// dres != null.
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                    const float* __restrict__ gamma, const double* __restrict__ sums,
-                                    T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, int relu, int accumulate, long long P, int C) {
+                                    const float* __restrict__ gamma, const float* __restrict__ sbg,
+                                    T* __restrict__ dx, T* __restrict__ dres, int relu, long long P, int C) {
   constexpr int VEC = VecOf<T>::N;
   const int cv = C / VEC;
   const long long total = P * cv;
-  const float invP = 1.f / (float)P;
-  if (blockIdx.x == 0)
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      // accumulate: dgamma / dbeta are gradient sinks (views of the optimizer's flat gradient buffer)
-      dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sums[c];
-      dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sums[C + c];
-    }
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c0 = (int)(i % cv) * VEC;
@@ -231,7 +255,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
       if (relu && !(to_f32(po[j]) > 0.f)) gv = 0.f;
       pg[j] = from_f32<T>(gv);
       const float xh = (to_f32(pa[j]) - mean[c]) * rstd[c];
-      const float sb = (float)sums[c] * invP, sg = (float)sums[C + c] * invP;
+      const float sb = sbg[c], sg = sbg[C + c];
       pout[j] = from_f32<T>(gamma[c] * rstd[c] * (gv - sb - xh * sg));
     }
     ((uint4*)dx)[i] = out;
@@ -448,7 +472,11 @@ static int split_rows_vec(int P, int cv, int& rpb) {
 
 extern "C" {
 
-// Training-mode forward.  sums: scratch double[2*C] (zeroed here).  Saves mean/rstd (f32[C]) for backward.
+// Training-mode forward.  sums: scratch double[mr_bn_scratch_doubles(C)] (MR_BN_COPIES accumulator copies of 2*C ...)
+// (zeroed here unless flags bit 2 says the caller hands it over zeroed).  Saves mean/rstd (f32[C]) for backward.
+long long mr_bn_scratch_doubles(int C) { return 2ll * C * MR_BN_COPIES + C; }   // + [2C] f32 of per-channel means (bwd)
+
+
 int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* save_mean, float* save_rstd, double* sums, const void* residual,
                     int relu, long long P, int C, float eps, float momentum, long long* num_batches_tracked,
@@ -458,19 +486,20 @@ int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const
   MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_fwd_train: bad P");
   const int presum_zero = (relu >> 2) & 1;  // flags bit 2: the caller hands over an already zeroed `sums`
   relu &= 1;
-  if (!presum_zero) (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream);
-  int rpb;
+  if (!presum_zero) (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * MR_BN_COPIES, stream);
+  int rpb, ncopy = 1;
   if (C / vec <= 256 && 256 % (C / vec) == 0) {
     const int splits = split_rows_vec((int)P, C / vec, rpb);
+    ncopy = MR_BN_COPIES;
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_vec_kernel<T, 0>), dim3(splits), dim3(256), 0, stream,
                                          (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
-                                         (const float*)nullptr, sums, 0, (int)P, C, rpb));
+                                         (const float*)nullptr, sums, 0, (int)P, C, rpb, ncopy));
   } else {
     const int splits = split_rows((int)P, C, rpb);
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(cdiv(C, 64), splits), dim3(256), 0, stream,
                                          (const T*)x, sums, (int)P, C, (long long)C, rpb));
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const double*)sums, (int)P, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const double*)sums, ncopy, (int)P, C,
                      eps, momentum, save_mean, save_rstd, running_mean, running_var, num_batches_tracked);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(P * (C / vec), 256)), dim3(256), 0,
                                        stream, (const T*)x, (T*)y, (const float*)save_mean, (const float*)save_rstd,
@@ -502,22 +531,26 @@ int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const flo
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(C % vec == 0, "mr_bn_bwd: C (%d) must be a multiple of %d", C, vec);
   MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_bwd: bad P");
-  if (!presum_zero) (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream);
-  int rpb;
+  if (!presum_zero) (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * MR_BN_COPIES, stream);
+  int rpb, ncopy = 1;
   if (C / vec <= 256 && 256 % (C / vec) == 0) {
     const int splits = split_rows_vec((int)P, C / vec, rpb);
+    ncopy = MR_BN_COPIES;
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_vec_kernel<T, 1>), dim3(splits), dim3(256), 0, stream,
                                          (const T*)dy, (const T*)x, (const T*)y, save_mean, save_rstd, sums, relu,
-                                         (int)P, C, rpb));
+                                         (int)P, C, rpb, ncopy));
   } else {
     const int splits = split_rows((int)P, C, rpb);
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(cdiv(C, 64), splits), dim3(256), 0, stream,
                                          (const T*)dy, (const T*)x, (const T*)y, save_mean, save_rstd, sums, relu,
                                          (int)P, C, rpb));
   }
+  float* sbg = (float*)(sums + (size_t)2 * C * MR_BN_COPIES);   // [2C] f32 behind the accumulator copies
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const double*)sums, ncopy, P, C,
+                     sbg, dgamma, dbeta, accumulate);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(P * (C / vec), 256)), dim3(256), 0,
                                        stream, (const T*)dy, (const T*)x, (const T*)y, save_mean, save_rstd, gamma,
-                                       (const double*)sums, (T*)dx, (T*)dres, dgamma, dbeta, relu, accumulate, P, C));
+                                       (const float*)sbg, (T*)dx, (T*)dres, relu, P, C));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

@@ -62,12 +62,12 @@ def notify_grad_ready(param):
 
 
 class ZeroArena(object):
-    """Pre-zeroed f64 scratch for the per-channel reduction buffers of BatchNorm (2C doubles per call, forward and
-    backward).  Each call used to zero its own buffer with a memset (120 tiny launches per ResNet-50 step).  Slices
+    """Pre-zeroed f64 scratch for the per-channel reduction buffers of BatchNorm (mr_bn_scratch_doubles(C) per call,
+    forward and backward).  Each call used to zero its own buffer with a memset (120 tiny launches per ResNet-50 step).  Slices
     are handed out once per zeroing by a bump pointer; `reset()` -- called by the fused optimizers' `zero_grad()` --
     re-zeroes the used prefix with ONE fill and rewinds.  When the arena is exhausted (nobody calls reset: eval
     loops, foreign optimizers) `take` returns None and the caller falls back to its own memset."""
-    SIZE = 1 << 20  # doubles (8 MB)
+    SIZE = 1 << 22  # doubles (32 MB: ResNet-50 takes ~34 doubles per BN channel per step, ~1 M)
     arenas = {}
 
     def __init__(self, device):
@@ -363,10 +363,11 @@ class BatchNormFn(Function):
         mean = torch.empty((C,), dtype=torch.float32, device=x.device)
         rstd = torch.empty((C,), dtype=torch.float32, device=x.device)
         if training:
-            sums = ZeroArena.take(x.device, 2 * C)
+            nsum = load().mr_bn_scratch_doubles(C)   # several accumulator copies (fewer same-address atomics)
+            sums = ZeroArena.take(x.device, nsum)
             prezeroed = sums is not None
             if not prezeroed:
-                sums = torch.empty((2 * C,), dtype=torch.float64, device=x.device)
+                sums = torch.empty((nsum,), dtype=torch.float64, device=x.device)
             call("mr_bn_fwd_train", dt, ptr(xi), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean),
                  ptr(running_var), ptr(mean), ptr(rstd), ptr(sums), ptr(ri), int(relu) | (4 if prezeroed else 0), P, C,
                  float(eps), float(momentum), ptr(num_batches_tracked))
@@ -393,10 +394,11 @@ class BatchNormFn(Function):
         P = N * H * W
         dx = torch.empty_like(xi)
         dres = torch.empty_like(xi) if ctx.has_res else None
-        sums = ZeroArena.take(g.device, 2 * C)
+        nsum = load().mr_bn_scratch_doubles(C)
+        sums = ZeroArena.take(g.device, nsum)
         prezeroed = sums is not None
         if not prezeroed:
-            sums = torch.empty((2 * C,), dtype=torch.float64, device=g.device)
+            sums = torch.empty((nsum,), dtype=torch.float64, device=g.device)
         gamma_p, beta_p = ctx.params
         g_sink, b_sink = grad_sink(gamma_p, (C,)), grad_sink(beta_p, (C,))
         sunk = g_sink is not None and b_sink is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
