@@ -127,6 +127,7 @@ def main():
                          "captured INSIDE the step graph on a side stream (overlapped with backward, zero host cost); "
                          "'graph2' = two graphs with one eager all-reduce between them (not overlapped); 'auto' = "
                          "capture, falling back to graph2 if the capture fails")
+    ap.add_argument("--tn-model", type=int, default=-1, help="A/B: mr_set_tn_model (wgrad split model), -1 = default")
     ap.add_argument("--workload", default="crnn", choices=["crnn", "res50ppm", "fpn_attention", "db"],
                     help="crnn = BASELINE.json configs[1] (the metric's workload, default); res50ppm = configs[2]: "
                          "ResNet50-dilated-PPM + 2D-CTC on 32x128 crops (secondary line, same JSON shape); "
@@ -141,6 +142,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (there is no CPU product path)")
+    if args.tn_model >= 0:
+        from megreader_amd import _lib as _l
+        _l.load().mr_set_tn_model(args.tn_model)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or args.force_ddp

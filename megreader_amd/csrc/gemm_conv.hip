@@ -94,7 +94,7 @@ static int num_cus() {
 // g_big_mode: 0 = automatic (nt_big_choice), -1 = never, 1 = always 256x256, 2 = always 288x256 (tuning override)
 static int g_big_mode = 0;
 static int g_tn_abl = 0;  // timing-only ablation mask of the TN kernel (mr_set_tn_abl)
-static int g_tn_model = 0;   // 1: the dense-GEMM split model for the conv wgrad launches too (mr_set_tn_model, A/B)
+static int g_tn_model = 1;   // 1 (default): the measured split model for the conv wgrad launches too; 0: the old one (A/B)
 static int g_tn_splits = 0;  // > 0: split count override of launch_tn (mr_set_tn_splits, tuning only)
 static int g_tn_buf = 1;  // TN kernel staging through buffer resources (mr_set_tn_buf); measured 4 % faster
 static int g_tn_big = 0;  // wide-tile TN kernels: 1 = 256x256, 2 = 128x256 (experimental, see launch_tn), else never
@@ -435,7 +435,8 @@ int mr_set_tn_abl(int mask) {
   return old;
 }
 
-// A/B: 1 = the conv wgrad launches use the dense-GEMM split model as well.  Returns the previous setting.
+// A/B: 1 (default) = the conv wgrad launches use the measured split model as well (CRNN: neutral, Res50-PPM-2D-CTC:
+// wgrad 62 -> 57 us per launch, step 14.30 -> 14.01 ms), 0 = the round-1 model.  Returns the previous setting.
 int mr_set_tn_model(int m) {
   const int old = g_tn_model;
   g_tn_model = m ? 1 : 0;
