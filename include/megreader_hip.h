@@ -293,6 +293,7 @@ int mr_dcn2_col2im(int dtype, const void* gcol, const float* offset, long long o
  * col_ws [N*Ho*Wo, kh*kw*C] (`dtype`); w_n [Co][kh*kw*C] / w_t [kh*kw*C][Co] are the mr_prep_matrix images of the KRSC
  * weight; dx32 / doffset / dmask pre-zeroed (accumulated / partially written), dw f32 [Co][kh*kw*C] and dbias f32 [Co]
  * accumulated; dx32, dw, dbias may be null. */
+int mr_set_dcn_v1_bwd(int on);   /* A/B (host only): 1 = round-1 DCN backward kernels */
 int mr_dcn2_fwd(int dtype, const void* x, const void* w_n, const float* bias, const float* offset, long long off_bs,
                 const float* mask, long long msk_bs, void* y, void* col_ws, int N, int H, int W, int C, int Co, int kh,
                 int kw, int stride, int pad, int dil, int Ho, int Wo, hipStream_t stream);

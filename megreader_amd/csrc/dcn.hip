@@ -160,6 +160,166 @@ __global__ void dcn2_col2im_kernel(const T* __restrict__ gcol, const float* __re
   }
 }
 
+// ---- round-2 backward kernel experiments (off by default: measured slower / equal, see mr_set_dcn_v1_bwd) -----------
+// coord v2: 8 lanes per (pixel, tap) item, each lane a 16-byte channel vector of gcol and of the four corners (the
+// first version put one WAVE on an item with 2-byte loads per lane: 295 us per layer at batch 16).  The three sums are
+// reduced over the 8 lanes with three shuffle steps.  C must be a multiple of 8 * VEC (64 for bf16).
+template <typename T>
+__global__ __launch_bounds__(256) void dcn2_coord_vec_kernel(const T* __restrict__ gcol, const T* __restrict__ x,
+                                                              const float* __restrict__ offset,
+                                                              const float* __restrict__ mask,
+                                                              float* __restrict__ doffset, float* __restrict__ dmask,
+                                                              DcnGeom g) {
+  constexpr int VEC = VecOf<T>::N;
+  const int taps = g.kh * g.kw;
+  const int lv = threadIdx.x & 7;
+  const long long item = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 3;
+  const long long items = (long long)g.N * g.Ho * g.Wo * taps;
+  const bool live = item < items;
+  const long long it = live ? item : 0;
+  const int tap = (int)(it % taps);
+  const long long p = it / taps;
+  const int wo = (int)(p % g.Wo);
+  const long long r = p / g.Wo;
+  const int ho = (int)(r % g.Ho);
+  const int n = (int)(r / g.Ho);
+  float ph, pw;
+  const bool valid = live && dcn_point(g, offset + n * g.off_bs, tap, ho, wo, ph, pw);
+  float dm = 0.f, dh = 0.f, dw = 0.f;
+  if (valid) {
+    const float m = mask[n * g.msk_bs + ((long long)tap * g.Ho + ho) * g.Wo + wo];
+    const int hl = (int)floorf(ph), wl = (int)floorf(pw);
+    const float lh = ph - (float)hl, lw = pw - (float)wl;
+    const int hh = hl + 1, wh = wl + 1;
+    const bool o1 = hl >= 0 && wl >= 0, o2 = hl >= 0 && wh <= g.W - 1, o3 = hh <= g.H - 1 && wl >= 0,
+               o4 = hh <= g.H - 1 && wh <= g.W - 1;
+    const float a1 = (1.f - lh) * (1.f - lw), a2 = (1.f - lh) * lw, a3 = lh * (1.f - lw), a4 = lh * lw;
+    const T* xb = x + (long long)n * g.H * g.W * g.C;
+    const T* gp = gcol + p * ((long long)taps * g.C) + (long long)tap * g.C;
+    const T* c1 = xb + ((long long)hl * g.W + wl) * g.C;
+    const T* c2 = xb + ((long long)hl * g.W + wh) * g.C;
+    const T* c3 = xb + ((long long)hh * g.W + wl) * g.C;
+    const T* c4 = xb + ((long long)hh * g.W + wh) * g.C;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int c = lv * VEC; c < g.C; c += 8 * VEC) {
+      const uint4 gq = *(const uint4*)(gp + c);
+      const uint4 q1 = o1 ? *(const uint4*)(c1 + c) : z, q2 = o2 ? *(const uint4*)(c2 + c) : z;
+      const uint4 q3 = o3 ? *(const uint4*)(c3 + c) : z, q4 = o4 ? *(const uint4*)(c4 + c) : z;
+      const T* pg = (const T*)&gq;
+      const T *p1 = (const T*)&q1, *p2 = (const T*)&q2, *p3 = (const T*)&q3, *p4 = (const T*)&q4;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float gv = to_f32(pg[j]);
+        const float v1 = to_f32(p1[j]), v2 = to_f32(p2[j]), v3 = to_f32(p3[j]), v4 = to_f32(p4[j]);
+        dm += gv * (a1 * v1 + a2 * v2 + a3 * v3 + a4 * v4);
+        dh += gv * m * (-(1.f - lw) * v1 - lw * v2 + (1.f - lw) * v3 + lw * v4);
+        dw += gv * m * (-(1.f - lh) * v1 + (1.f - lh) * v2 - lh * v3 + lh * v4);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) {
+    dm += __shfl_xor(dm, o, 64);
+    dh += __shfl_xor(dh, o, 64);
+    dw += __shfl_xor(dw, o, 64);
+  }
+  if (live && lv == 0) {
+    const long long hw = (long long)g.Ho * g.Wo, o = (long long)ho * g.Wo + wo;
+    doffset[n * g.off_bs + (2 * tap) * hw + o] = dh;
+    doffset[n * g.off_bs + (2 * tap + 1) * hw + o] = dw;
+    dmask[n * g.msk_bs + tap * hw + o] = dm;
+  }
+}
+
+// col2im v2: LDS pre-reduction.  The first version issued one f32 global atomic per (pixel, tap, channel, corner):
+// 36 atomics land on every input element (9 taps x 4 corners) -- 814 us per layer at batch 16, 55 % of the DCN backward.
+// A workgroup now owns a TH x TW tile of output pixels of one image and a chunk of CC channels, accumulates all their
+// contributions into an LDS image of the input patch the tile can reach with offsets up to +-R pixels (ds_add_f32, lanes
+// of one item on distinct banks), and flushes the patch with ONE coalesced global atomic per touched element.  Samples
+// that fall outside the patch (offsets beyond R) go straight to global memory as before, so any offset stays correct.
+constexpr int C2I_TH = 8, C2I_TW = 8, C2I_R = 2;
+template <typename T>
+__global__ __launch_bounds__(256) void dcn2_col2im_lds_kernel(const T* __restrict__ gcol,
+                                                               const float* __restrict__ offset,
+                                                               const float* __restrict__ mask, float* __restrict__ dx,
+                                                               DcnGeom g, int CC, int PH, int PW, int tiles_h,
+                                                               int tiles_w) {
+  constexpr int VEC = VecOf<T>::N;
+  extern __shared__ float c2i_patch[];   // [PH * PW][CC + 1]: the odd pixel stride spreads different pixels over the banks
+  const int PS = CC + 1;                 // (with stride CC every item of a wave hit the same 8 banks: 8-way conflicts)
+  const int taps = g.kh * g.kw;
+  const int cchunks = g.C / CC;
+  int b = blockIdx.x;
+  const int cc = b % cchunks; b /= cchunks;
+  const int tw = b % tiles_w; b /= tiles_w;
+  const int th = b % tiles_h;
+  const int n = b / tiles_h;
+  const int ho0 = th * C2I_TH, wo0 = tw * C2I_TW;
+  const int h0 = ho0 * g.stride - g.pad - C2I_R, w0 = wo0 * g.stride - g.pad - C2I_R;   // patch origin (input coords)
+  const int npatch = PH * PW * PS;
+  for (int i = threadIdx.x; i < npatch; i += 256) c2i_patch[i] = 0.f;
+  __syncthreads();
+  const int cvv = CC / VEC;                      // channel vectors of this chunk per (pixel, tap)
+  const int nitems = C2I_TH * C2I_TW * taps * cvv;
+  const float* off_b = offset + n * g.off_bs;
+  float* dxn = dx + (long long)n * g.H * g.W * g.C + cc * CC;
+  for (int it = threadIdx.x; it < nitems; it += 256) {
+    const int lv = it % cvv;
+    int q = it / cvv;
+    const int tap = q % taps; q /= taps;
+    const int tx = q % C2I_TW, ty = q / C2I_TW;
+    const int ho = ho0 + ty, wo = wo0 + tx;
+    if (ho >= g.Ho || wo >= g.Wo) continue;
+    float ph, pw;
+    if (!dcn_point(g, off_b, tap, ho, wo, ph, pw)) continue;
+    const float m = mask[n * g.msk_bs + ((long long)tap * g.Ho + ho) * g.Wo + wo];
+    const long long p = ((long long)n * g.Ho + ho) * g.Wo + wo;
+    const uint4 gq = *(const uint4*)(gcol + p * ((long long)taps * g.C) + (long long)tap * g.C + cc * CC + lv * VEC);
+    const T* pg = (const T*)&gq;
+    const int hl = (int)floorf(ph), wl = (int)floorf(pw);
+    const float lh = ph - (float)hl, lw = pw - (float)wl;
+    const int hh = hl + 1, wh = wl + 1;
+    const float wgt[4] = {(1.f - lh) * (1.f - lw) * m, (1.f - lh) * lw * m, lh * (1.f - lw) * m, lh * lw * m};
+    const int ch[4] = {hl, hl, hh, hh}, cw[4] = {wl, wh, wl, wh};
+    const bool inpatch = hl >= h0 && hh < h0 + PH && wl >= w0 && wh < w0 + PW;
+    // lanes lv and lv + 4 of an item would share banks: the upper four walk their channels rotated by half a vector.
+    // Both candidate indices are compile-time constants and a select picks one: a run-time index into the register
+    // vector (pg[(j + rot) & 7]) sent it to SCRATCH memory -- 32 scratch loads per item, 1.46 ms per layer.
+    const bool hi = (lv & 4) != 0;
+    float val[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) val[j] = to_f32(pg[j]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (ch[k] < 0 || ch[k] > g.H - 1 || cw[k] < 0 || cw[k] > g.W - 1) continue;   // corner outside the image
+      if (inpatch) {
+        float* d = c2i_patch + ((ch[k] - h0) * PW + (cw[k] - w0)) * PS + lv * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          constexpr int HALF = VEC / 2;
+          const int j1 = (j + HALF) & (VEC - 1);
+          atomicAdd(d + (hi ? j1 : j), (hi ? val[j1] : val[j]) * wgt[k]);
+        }
+      } else {
+        float* d = dxn + ((long long)ch[k] * g.W + cw[k]) * g.C + lv * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) atomicAdd(d + j, val[j] * wgt[k]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < npatch; i += 256) {
+    const float v = c2i_patch[i];
+    if (v == 0.f) continue;
+    const int c = i % PS, px = (i / PS) % PW, py = i / (PS * PW);
+    const int h = h0 + py, w = w0 + px;
+    if (c >= CC || h < 0 || h > g.H - 1 || w < 0 || w > g.W - 1) continue;
+    atomicAdd(dxn + ((long long)h * g.W + w) * g.C + c, v);
+  }
+}
+
+static int g_dcn_v1_bwd = 1;   // 1 (default): round-1 backward kernels; 0: the round-2 experiments (mr_set_dcn_v1_bwd)
+
 static inline int grid_for(long long n, int block, int max_blocks = 32768) {
   long long b = (n + block - 1) / block;
   if (b > max_blocks) b = max_blocks;
@@ -216,6 +376,13 @@ int mr_dcn2_coord_grad(int dtype, const void* gcol, const void* x, const float* 
   int rc = make_geom(g, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo, off_bs, msk_bs);
   if (rc) return rc;
   const long long items = (long long)N * Ho * Wo * kh * kw;
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  if (C % (8 * vec) == 0 && !g_dcn_v1_bwd) {   // 8 lanes x one 16-byte vector per item
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_coord_vec_kernel<T>), dim3((unsigned)cdivll(items * 8, 256)), dim3(256), 0,
+                                         stream, (const T*)gcol, (const T*)x, offset, mask, doffset, dmask, g));
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_coord_kernel<T>), dim3((unsigned)cdivll(items, 4)), dim3(256), 0, stream,
                                        (const T*)gcol, (const T*)x, offset, mask, doffset, dmask, g));
   MR_CHECK_LAUNCH();
@@ -230,10 +397,46 @@ int mr_dcn2_col2im(int dtype, const void* gcol, const float* offset, long long o
   int rc = make_geom(g, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo, off_bs, msk_bs);
   if (rc) return rc;
   const long long total = (long long)N * Ho * Wo * kh * kw * C;
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  // LDS-tiled form: patch of the inputs an 8 x 8 output tile reaches with offsets up to +-R, CC channels, <= 64 KB
+  const int PH = (C2I_TH - 1) * stride + (kh - 1) * dil + 2 + 2 * C2I_R;
+  const int PW = (C2I_TW - 1) * stride + (kw - 1) * dil + 2 + 2 * C2I_R;
+  int CC = 64;
+  while (CC > vec && (long long)PH * PW * (CC + 1) * 4 > 64 * 1024) CC >>= 1;
+  if (!g_dcn_v1_bwd && C % CC == 0 && CC % vec == 0 && (long long)PH * PW * (CC + 1) * 4 <= 64 * 1024) {
+    const int tiles_h = cdiv(Ho, C2I_TH), tiles_w = cdiv(Wo, C2I_TW);
+    const long long blocks = (long long)N * tiles_h * tiles_w * (C / CC);
+    MR_CHECK_ARG(blocks < (1ll << 31), "mr_dcn2_col2im: grid too large");
+    const size_t lds = (size_t)PH * PW * (CC + 1) * 4;
+    DISPATCH_T(dtype, {
+      auto kern = dcn2_col2im_lds_kernel<T>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, (const T*)gcol, offset, mask, dx, g, CC,
+                         PH, PW, tiles_h, tiles_w);
+    });
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_col2im_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
                                        (const T*)gcol, offset, mask, dx, g));
   MR_CHECK_LAUNCH();
   return MR_OK;
+}
+
+// A/B: 1 (default) = the round-1 backward kernels (one wave per coordinate item, one global atomic per corner and
+// channel); 0 = the round-2 experiments.  MEASURED (tools/microbench_dcn.py, 13 layers, batch 16): LDS-tiled col2im
+// 1460 us per layer vs 830 us for direct global atomics -- ds_add_f32 sustains well under one lane-operation per clock
+// per CU on gfx950 (the same cliff as the LDS-atomic column sums of the wide-tile TN kernel), independent of bank
+// conflicts (stride 64 vs 65 floats: same time); vectorised coordinate gradient 302 vs 295 us (both bound by the 36x
+// re-read of the input corners from L2, not by the access width).
+int mr_set_dcn_v1_bwd(int on) {
+  const int old = g_dcn_v1_bwd;
+  g_dcn_v1_bwd = on ? 1 : 0;
+  return old;
 }
 
 // ---- single-call forms: what `modulated_deform_conv_cuda_forward / _backward`

@@ -29,6 +29,11 @@ CASES = [  # N, C, Co, H, W, stride, pad, dil, offset-map size (None = output gr
     (2, 32, 32, 12, 10, 2, 1, 1, (12, 10), 1.5),   # stride-2 conv, stride-1 offset map (quirk Q10)
     (1, 16, 16, 9, 8, 1, 2, 2, None, 1.0),          # dilated
     (3, 8, 8, 5, 6, 1, 1, 1, None, 4.0),            # large offsets: many invalid samples / border touches
+    # C a multiple of 64 (also what the opt-in round-2 backward kernels need: test_round2_backward_kernels)
+    (2, 64, 32, 19, 21, 1, 1, 1, None, 1.0),        # tiles ragged in both directions, offsets inside the LDS patch
+    (1, 128, 64, 20, 18, 2, 1, 1, (20, 18), 1.5),   # stride 2 (32-channel chunks), larger offset map
+    (2, 64, 64, 11, 13, 1, 1, 1, None, 5.0),        # offsets beyond the patch margin: the direct-atomic path
+    (1, 64, 64, 17, 16, 1, 2, 2, None, 1.0),        # dilated
 ]
 
 
@@ -187,3 +192,38 @@ def test_dcn_v1_vs_oracle(dtype):
     assert _rel(xd.grad, xr.grad) < gtol and _rel(offd.grad, offr.grad) < gtol and _rel(wd.grad, wr.grad) < gtol
     m = DeformConv(C, Co, 3, padding=1).to(DEV)
     assert m(xd.detach(), offd.detach()).shape == (N, Co, H, W)
+
+
+@pytest.mark.parametrize("case", CASES[4:])
+def test_round2_backward_kernels(case):
+    """The opt-in round-2 backward kernels (8-lane vectorised coordinate gradient, LDS-tiled col2im; measured slower, kept
+    behind mr_set_dcn_v1_bwd(0)) produce the same gradients as the default kernels."""
+    from megreader_amd._lib import load
+    N, C, Co, H, W, stride, pad, dil, omap, oscale = case
+    mr.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(C + H)
+    Ho = (H + 2 * pad - (dil * 2 + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * 2 + 1)) // stride + 1
+    oh, ow = omap if omap else (Ho, Wo)
+    x = torch.randn(N, C, H, W, generator=g).bfloat16()
+    off = torch.floor(torch.randn(N, 18, oh, ow, generator=g) * oscale) + 0.25 + 0.5 * torch.rand(N, 18, oh, ow, generator=g)
+    msk = torch.rand(N, 9, oh, ow, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) * 0.2
+    gy = torch.randn(N, Co, Ho, Wo, generator=g).bfloat16()
+
+    def run():
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        offd, mskd = off.to(DEV).requires_grad_(True), msk.to(DEV).requires_grad_(True)
+        wd = w.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        modulated_deform_conv(xd, offd, mskd, wd, None, stride, pad, dil, 1, 1).backward(
+            gy.to(DEV).contiguous(memory_format=torch.channels_last))
+        return xd.grad, offd.grad, mskd.grad
+
+    ref = run()
+    old = load().mr_set_dcn_v1_bwd(0)
+    try:
+        got = run()
+    finally:
+        load().mr_set_dcn_v1_bwd(old)
+    for a, b in zip(got, ref):
+        assert _rel(a, b) < 2e-3      # f32 atomics in a different order
