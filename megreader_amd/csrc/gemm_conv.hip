@@ -510,8 +510,11 @@ int mr_gemm_tn(int dtype, const void* A, long long lda, const void* B, long long
   MR_CHECK_ARG(dtype == MR_F32 || dtype == MR_BF16, "mr_gemm_tn: bad dtype %d", dtype);
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(P > 0 && NA > 0 && NB > 0, "mr_gemm_tn: bad shape P=%d NA=%d NB=%d", P, NA, NB);
-  MR_CHECK_ARG(NA % vec == 0 && NB % vec == 0 && lda % vec == 0 && ldb % vec == 0,
-               "mr_gemm_tn: NA/NB/lda/ldb must be multiples of %d", vec);
+  // NA need not be a vector multiple as long as the rows of A are (lda >= NA rounded up): the last 16-byte chunk of a row
+  // then reads A's padding columns, whose products land in output rows >= NA, which are never stored (a Linear layer
+  // with 38 outputs keeps its gradient rows in a 40-column buffer and accumulates straight into the [38, K] sink)
+  MR_CHECK_ARG(NB % vec == 0 && lda % vec == 0 && ldb % vec == 0 && lda >= (NA + vec - 1) / vec * vec,
+               "mr_gemm_tn: NB/lda/ldb must be multiples of %d and lda >= NA rounded up to it", vec);
   MR_CHECK_ARG(aligned16(A) && aligned16(B), "mr_gemm_tn: A and B must be 16-byte aligned");
   MR_CHECK_ARG(row_perm_h == 0 || NA % (4 * row_perm_h) == 0, "mr_gemm_tn: NA must be a multiple of 4*row_perm_h");
   TnArgs a;

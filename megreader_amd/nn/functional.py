@@ -637,8 +637,11 @@ class LinearFn(Function):
             dx = dx2.view(*ctx.lead, K)
         weight_p, bias_p = ctx.params
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        w_sink = grad_sink(weight_p, (Nout, K)) if (ctx.needs_input_grad[1] and Np == Nout) else None
-        b_sink = grad_sink(bias_p, (Nout,)) if (want_db and Np == Nout) else None
+        # sinks also when the output width is padded (38 classes in a 40-column buffer): the GEMM is then asked for
+        # NA = Nout rows of A^T B with lda = Np -- the padding columns feed output rows that are never stored
+        w_sink = grad_sink(weight_p, (Nout, K)) if ctx.needs_input_grad[1] else None
+        b_sink = grad_sink(bias_p, (Nout,)) if (want_db and (w_sink is not None or not ctx.needs_input_grad[1])) else None
+        NA = Nout if (w_sink is not None or (not ctx.needs_input_grad[1] and b_sink is not None)) else Np
         gb = None
         if want_db:
             gb = b_sink if b_sink is not None else torch.zeros((Np,), dtype=torch.float32, device=gy.device)
@@ -651,10 +654,10 @@ class LinearFn(Function):
                 if dx_fn is not None:
                     dx_fn()
                 with torch.cuda.stream(_Side.fork()):
-                    call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, Np, K, 0, ptr(gb))
+                    call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, NA, K, 0, ptr(gb))
                 _Side.pending.extend((gp, x2))
             else:   # input-gradient and weight-gradient GEMMs are independent: side by side (_Fan)
-                _Fan.run([dx_fn, lambda: call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, Np, K, 0,
+                _Fan.run([dx_fn, lambda: call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, NA, K, 0,
                                               ptr(gb))])
             dx_fn = None
             if w_sink is not None:
@@ -662,7 +665,7 @@ class LinearFn(Function):
             else:
                 dw = gw[:Nout]
         elif want_db:
-            call("mr_colsum", dt, ptr(gp), ptr(gb), M, Np, Np, 0)
+            call("mr_colsum", dt, ptr(gp), ptr(gb), M, NA, Np, 0)
         if dx_fn is not None:
             dx_fn()
         if want_db:
@@ -782,7 +785,10 @@ class BiLSTMFn(Function):
             dx_fn()
         with torch.cuda.stream(side) if overlap else contextlib.nullcontext():
             # one zeroed scratch: [2,4H,I] input-weight gradients (both directions from ONE GEMM) + [2,4H] bias sums
-            scratch = torch.zeros((2 * 4 * H * (I + 1),), dtype=torch.float32, device=dev)
+            nfl = 2 * 4 * H * (I + 1)
+            arena = None if overlap else ZeroArena.take(dev, (nfl + 1) // 2)   # pre-zeroed: saves a fill launch
+            scratch = (arena.view(torch.float32)[:nfl] if arena is not None else
+                       torch.zeros((nfl,), dtype=torch.float32, device=dev))
             gw_ih = scratch[:2 * 4 * H * I].view(2, 4 * H, I)
             gb = scratch[2 * 4 * H * I:].view(2, 4 * H)
             if use_sinks:   # recurrent-weight gradients accumulate straight into the flat gradient buffer

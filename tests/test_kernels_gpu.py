@@ -576,3 +576,22 @@ def test_conv_wgrad_row_table_matches_plain_wgrad():
         wr = torch.zeros(Kc, C, R, S, dtype=torch.float64, requires_grad=True)
         TF.conv2d(xr, wr, None, (sh, sw), (ph, pw), (dh, dw)).backward(dy.double().cpu().permute(0, 3, 1, 2))
         assert _rel_err(w1, wr.grad.permute(0, 2, 3, 1)) < 2e-5, case
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_tn_row_count_not_a_vector_multiple(dtype):
+    """mr_gemm_tn with NA = 38 rows of A^T B taken from a 40-column A (a Linear layer with 38 outputs accumulating
+    straight into its [38, K] gradient sink): rows 38, 39 of the padded product are never stored, the fused column sums
+    stop at 38 as well."""
+    dt = dtype_code(dtype)
+    g = torch.Generator().manual_seed(5)
+    P, NA, lda, NB = 777, 38, 40, 64
+    A = torch.randn(P, lda, generator=g).to(DEV, dtype)
+    B = torch.randn(P, NB, generator=g).to(DEV, dtype)
+    C = torch.full((NA + 2, NB), 3.0, device=DEV)      # two guard rows behind the sink
+    cs = torch.full((NA + 2,), 5.0, device=DEV)
+    call("mr_gemm_tn", dt, ptr(A), lda, ptr(B), NB, ptr(C), NB, P, NA, NB, 0, ptr(cs))
+    ref = A[:, :NA].double().cpu().t() @ B.double().cpu() + 3.0
+    assert _rel_err(C[:NA], ref) < (2e-5 if dtype == torch.float32 else 2e-5)
+    assert torch.equal(C[NA:].cpu(), torch.full((2, NB), 3.0)) and torch.equal(cs[NA:].cpu(), torch.full((2,), 5.0))
+    assert _rel_err(cs[:NA], A[:, :NA].double().cpu().sum(0) + 5.0) < 2e-5
