@@ -316,6 +316,15 @@ int mr_deform_psroi_bwd(const float* out_grad, const float* data, const float* r
                         int channels_trans, int no_trans, float spatial_scale, int output_dim, int group_size,
                         int pooled_size, int part_size, int sample_per_part, float trans_std, hipStream_t stream);
 
+/* ---- DB detector post-processing (structure/representers/seg_detector_representer.py:63-168): the per-pixel stages.
+ * mr_db_components: prob f32 [N][H][W] thresholded (> thresh) -> labels i32 [N][H][W] (root pixel index of the
+ * 8-connected component, -1 background) and the run end points of every component, points int4 [cap] = (n, root, x, y),
+ * *count = their number (zero on entry; may exceed cap).  mr_db_box_scores: boxes f32 [B][9] = image index + 4 vertices
+ * in order; out f32 [B][2] = (sum of prob, pixel count) over the pixels inside or on the border of each box. */
+int mr_db_components(const float* prob, float thresh, int* labels, void* points, int* count, int cap, int N, int H, int W,
+                     hipStream_t stream);
+int mr_db_box_scores(const float* prob, const float* boxes, float* out, int B, int N, int H, int W, hipStream_t stream);
+
 /* ---- Attention-GRU decoder step kernels (decoders/attention_decoder.py:146-231; the GEMMs use mr_gemm_nt/tn) ----- */
 int mr_attn_step_fwd(int dtype, const void* hproj, const void* eproj, const float* v, const void* enc, float* weights,
                      void* context, int N, int T, int Hd, int Ep, hipStream_t stream);
