@@ -24,6 +24,11 @@ OVERRIDES = {
                                               "Resnet18FPN", "Resnet34FPN", "Resnet50FPN", "Resnet101FPN",
                                               "Resnet152FPN"]),
     "decoders": ("megreader_amd.decoders", ["CRNNDecoder", "CTCDecoder2D", "AttentionDecoder", "SegDetector"]),
+    # evaluation side: the YAMLs name these classes through `package: [structure.representers,
+    # structure.measurers, ...]` + `class: CTCRepresenter` (concern/config.py:28-29,57-60), resolved with getattr
+    "structure.representers": ("megreader_amd.structure", ["CTCRepresenter", "CTCRepresenter2D",
+                                                           "SegDetectorRepresenter"]),
+    "structure.measurers": ("megreader_amd.structure", ["SequenceRecognitionMeasurer"]),
 }
 
 

@@ -22,7 +22,9 @@ class AverageMeter(object):
 
 
 class SequenceRecognitionMeasurer(object):
-    def __init__(self, charset=None, blank=0, unknown=1, **kwargs):
+    def __init__(self, charset=None, blank=0, unknown=1, cmd=None, **kwargs):
+        from . import member_from_config
+        charset = member_from_config(charset, cmd)
         self.blank, self.unknown = blank, unknown
         self.fold = None
         if charset is not None and hasattr(charset, "_charset"):

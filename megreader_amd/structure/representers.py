@@ -9,7 +9,9 @@ from ..ops.decode import ctc2d_greedy_decode, ctc_greedy_decode
 
 
 class _Base(object):
-    def __init__(self, charset=None, **kwargs):
+    def __init__(self, charset=None, cmd=None, **kwargs):
+        from . import member_from_config
+        charset = member_from_config(charset, cmd)     # built from the YAML by the reference's config system
         self.charset = charset if charset is not None else EnglishCharset()
 
     def label_to_string(self, label):

@@ -55,6 +55,8 @@ def test_yaml_to_trainer_train_step_reaches_the_hip_op(tmp_path):
         import megreader_amd.dropin as dropin
         installed = dropin.install(%r)
         assert "crnn_backbone" in installed["backbones"] and "CRNNDecoder" in installed["decoders"]
+        assert "CTCRepresenter" in installed["structure.representers"]
+        assert "SequenceRecognitionMeasurer" in installed["structure.measurers"]
         import torch
         from concern.config import Configurable, Config
         from experiment import Structure, TrainSettings, ValidationSettings, Experiment   # tagged YAML classes (train.py:11)
@@ -74,6 +76,12 @@ def test_yaml_to_trainer_train_step_reaches_the_hip_op(tmp_path):
         assert type(net.backbone).__module__ == "megreader_amd.backbones.crnn", type(net.backbone)
         assert type(net.decoder).__module__ == "megreader_amd.decoders.crnn", type(net.decoder)
         assert sum(p.numel() for p in model.parameters()) == 8332966                          # SURVEY.md §8b [probe]
+        # evaluation side of the YAML (crnn.yaml:58-62): representer / measurer resolve to the GPU mirrors, built by the
+        # reference's config system with the charset object it constructed from `^charset`
+        rep, mea = experiment.structure.representer, experiment.structure.measurer
+        assert type(rep).__module__ == "megreader_amd.structure.representers" and type(rep).__name__ == "CTCRepresenter"
+        assert type(mea).__module__ == "megreader_amd.structure.measurers"
+        assert type(rep.charset).__name__ == "EnglishCharset" and len(rep.charset) == 38
         optimizer = experiment.train.scheduler.create_optimizer(model.parameters())           # trainer.py:67-68
         assert type(optimizer).__name__ == "Adam"
         trainer.update_learning_rate(optimizer, 0, 0)
