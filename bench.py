@@ -59,6 +59,9 @@ def kernel_label(lib, name, args, dtype_name):
     if name == "mr_conv2d_dgrad":
         N, H, W, Cin, _ld1, Cout, _ld2, R, S = args[4:13]
         return nt(lib.mr_nt_kernel_code(dt, N * H * W, Cin, R * S * Cout, Cout))
+    # wgrad: (dtype, dy, x, dw, dbias, N, H, W, Cin, ldx, Cout, lddy, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo[, tab, build])
+    if name == "mr_conv2d_wgrad_tab" and dt == 1 and args[22] and lib.mr_tn_taps_would_run(*[int(v) for v in args[5:22]]):
+        return "igemm_tn_taps_kernel<bf16,3x3>"   # all-taps kernel (csrc/tn_taps.hip)
     return "igemm_tn_kernel<%s,conv>" % dtype_name
 
 

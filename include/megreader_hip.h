@@ -53,6 +53,21 @@ int mr_set_tn_big(int mode);
 /* TN kernel operand staging: 1 = raw buffer resources (out-of-range -> zeros), 0 = flat pointers + zero page;
  * returns the previous setting */
 int mr_set_tn_buf(int mode);
+/* all-taps weight-gradient kernel for 3x3 / stride 1 / padding == dilation layers (csrc/tn_taps.hip): 1 = use it
+ * through mr_conv2d_wgrad_tab where the geometry allows, 0 = never; returns the previous setting.  The row table passed
+ * to mr_conv2d_wgrad_tab has a different format for the two kernels: rebuild it (build = 1) after changing this. */
+int mr_set_tn_taps(int mode);
+/* workspace of the all-taps kernel's in-launch split reduction: device memory zeroed once by the caller (16 KB of
+ * tickets + 147456 B per workgroup of the largest launch = 2 * CUs slabs); NULL / 0 withdraws it (f32 atomics only).
+ * Launches that use it must be stream-ordered with each other. */
+int mr_set_tn_taps_workspace(void* ws, long long bytes);
+int mr_set_tn_taps_group(int g);    /* tuning: 0 automatic, 1 atomics only, > 1 forced group size */
+int mr_set_tn_taps_w8(int on);      /* 1: 8-wave workgroup variant (one per CU, half the partial tiles) */
+int mr_set_tn_taps_abl(int mask);   /* host only, timing only: ablation mask of the all-taps kernel (wrong results) */
+/* host only: 1 when mr_conv2d_wgrad_tab (bf16, non-NULL row table) would run the all-taps kernel for this geometry
+ * under the current mr_set_tn_taps setting */
+int mr_tn_taps_would_run(int N, int H, int W, int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw,
+                         int ph, int pw, int dh, int dw, int Ho, int Wo);
 int mr_set_tn_model(int m);    /* A/B: 1 = conv wgrad uses the dense-GEMM split model too */
 int mr_set_tn_splits(int n);   /* tuning only: P-split override of the TN kernels, 0 = automatic */
 /* host only, timing only: ablation mask of the TN kernel (1 no LDS-DMA, 2 no fragment reads, 4 no atomic epilogue,

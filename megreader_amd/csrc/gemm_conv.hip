@@ -4,6 +4,7 @@
 // backbones/resnet.py:110-256, decoders/crnn.py:8-24).
 #include "igemm_core.h"
 #include "igemm_p8.h"
+#include "tn_taps.h"
 #include "../../include/megreader_hip.h"
 
 #include <mutex>
@@ -97,6 +98,7 @@ static int g_tn_abl = 0;  // timing-only ablation mask of the TN kernel (mr_set_
 static int g_tn_model = 1;   // 1 (default): the measured split model for the conv wgrad launches too; 0: the old one (A/B)
 static int g_tn_splits = 0;  // > 0: split count override of launch_tn (mr_set_tn_splits, tuning only)
 static int g_tn_buf = 1;  // TN kernel staging through buffer resources (mr_set_tn_buf); measured 4 % faster
+static int g_tn_taps = 1;  // all-taps wgrad kernel for 3x3 / stride 1 / pad == dilation layers (tn_taps.hip, mr_set_tn_taps)
 static int g_tn_big = 0;  // wide-tile TN kernels: 1 = 256x256, 2 = 128x256 (experimental, see launch_tn), else never
 
 // 0 = use the 4-wave kernels, 1 = 256x256 (8 waves), 2 = 288x256 (12 waves; tuning only).  The big tiles run one
@@ -450,6 +452,41 @@ int mr_set_tn_splits(int n) {
   return old;
 }
 
+// All-taps wgrad kernel (tn_taps.hip): 1 = use it where taps_eligible() says so, 0 = never.  The caller-owned row table
+// has a different format for the two kernels: callers must rebuild their tables (build = 1) after changing this.
+int mr_set_tn_taps(int mode) {
+  const int old = g_tn_taps;
+  if (mode == 0 || mode == 1) g_tn_taps = mode;
+  return old;
+}
+
+// Workspace of the all-taps kernel's in-launch split reduction: `bytes` of device memory (16 KB of tickets + 147456 B
+// per workgroup of the largest launch, i.e. 2 * CUs slabs), ZEROED by the caller once; NULL / 0 withdraws it (the
+// kernel then reduces with f32 atomics only).  Launches that use it must be stream-ordered with each other.
+int mr_set_tn_taps_workspace(void* ws, long long bytes) {
+  MR_CHECK_ARG((ws == nullptr) == (bytes == 0) && bytes >= 0 && (((uintptr_t)ws) & 15) == 0,
+               "mr_set_tn_taps_workspace: bad workspace");
+  taps_set_workspace(ws, bytes);
+  return MR_OK;
+}
+// tuning: group size of that reduction (0 automatic, 1 atomics only); returns the previous setting
+int mr_set_tn_taps_group(int g) { return taps_set_group(g); }
+
+// 1 = 8-wave workgroup variant of the all-taps kernel (one per CU, half the partial tiles); returns the previous setting
+int mr_set_tn_taps_w8(int on) { return taps_set_w8(on); }
+
+// host only, timing only: ablation mask of the all-taps kernel (results are wrong for mask != 0)
+int mr_set_tn_taps_abl(int mask) { return taps_set_abl(mask); }
+
+// host only: 1 when mr_conv2d_wgrad_tab would run the all-taps kernel for this geometry (bf16, row table of
+// N*Ho*Wo*8 bytes) under the current mr_set_tn_taps setting, else 0
+int mr_tn_taps_would_run(int Nimg, int H, int W, int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw,
+                         int ph, int pw, int dh, int dw, int Ho, int Wo) {
+  return (g_tn_taps && g_nt_variant == 2 &&
+          taps_eligible(Nimg, H, W, Cin, ldx, Cout, lddy, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo,
+                        (long long)Nimg * Ho * Wo * 8)) ? 1 : 0;
+}
+
 int mr_set_tn_buf(int mode) {
   const int old = g_tn_buf;
   if (mode == 0 || mode == 1) g_tn_buf = mode;
@@ -607,6 +644,13 @@ int mr_conv2d_wgrad_tab(int dtype, const void* dy, const void* x, float* dw_krsc
   MR_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && Cout % 8 == 0 && lddy % 8 == 0,
                "mr_conv2d_wgrad_tab: Cin/ldx/Cout/lddy must be multiples of 8");
   MR_CHECK_ARG(aligned16(dy) && aligned16(x) && ((uintptr_t)rowtab & 7) == 0, "mr_conv2d_wgrad_tab: alignment");
+  if (g_tn_taps && taps_eligible(Nimg, H, W, Cin, ldx, Cout, lddy, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo,
+                                 (long long)Nimg * Ho * Wo * 8)) {
+    TapsProblem tp;
+    tp.dy = dy; tp.x = x; tp.dw = dw_krsc; tp.dbias = dbias; tp.tab = (int*)rowtab; tp.build = build;
+    tp.N = Nimg; tp.H = H; tp.W = W; tp.Cin = Cin; tp.ldx = ldx; tp.Cout = Cout; tp.lddy = lddy; tp.dil = dh;
+    return launch_tn_taps(tp, g_tn_splits, stream);
+  }
   TnArgs a;
   a.A = dy; a.B = x; a.C = dw_krsc; a.P = Nimg * Ho * Wo; a.NA = Cout; a.NB = R * S * Cin; a.lda = lddy;
   a.ldb = 0; a.ldc = R * S * Cin; a.p_chunk = 0; a.row_perm_h = 0; a.colsum = dbias; a.rowtab = (const int2*)rowtab;

@@ -221,6 +221,35 @@ def _wgrad_rowtab(device, geom):
     return tab, 1
 
 
+_TAPS_WS = {}
+
+
+def ensure_tn_taps_workspace(device):
+    """Register (once per device) the workspace of the all-taps wgrad kernel's in-launch split reduction
+    (mr_set_tn_taps_workspace): 16 KB of tickets + one 147456-byte slab per workgroup of a full launch (2 per CU)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _TAPS_WS.get(idx)
+    if ws is None:
+        from .._lib import load
+        cus = torch.cuda.get_device_properties(idx).multi_processor_count
+        nbytes = 16384 + (2 * cus + 64) * 147456
+        ws = _TAPS_WS[idx] = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device("cuda", idx))
+        rc = load().mr_set_tn_taps_workspace(ws.data_ptr(), nbytes)
+        if rc != 0:
+            raise RuntimeError("mr_set_tn_taps_workspace failed: %s" % load().mr_last_error().decode())
+    return ws
+
+
+def set_tn_taps(mode):
+    """Switch the all-taps wgrad kernel (csrc/tn_taps.hip) on / off.  The cached row tables are dropped: the two kernels
+    read different table formats.  Returns the previous setting."""
+    from .._lib import load
+    old = load().mr_set_tn_taps(int(mode))
+    _ROWTABS.clear()
+    return old
+
+
 def _conv_operands(weight, bias, dtype, Cp, Kp, need_dx):
     """Compute-dtype images of a conv weight: KRSC (forward / wgrad layout), CRSK (dgrad) and the padded bias.
     Persistent buffers, regenerated only when the parameter changes (megreader_amd.nn.prep)."""
@@ -315,6 +344,8 @@ class Conv2dFn(Function):
             tab, build = (None, 0)
             if dtype == torch.bfloat16 and R * S <= 32:
                 tab, build = _wgrad_rowtab(g.device, (N, H, W, Cp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo))
+                if R == 3 and S == 3:
+                    ensure_tn_taps_workspace(g.device)
             call("mr_conv2d_wgrad_tab", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, Kp,
                  Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo, ptr(tab), build)
             if w_sink is not None:

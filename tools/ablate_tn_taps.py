@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Timing-only ablation ladder of the all-taps wgrad kernel (mr_set_tn_taps_abl): which ingredient costs what."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import megreader_amd as mr  # noqa: E402,F401
+from megreader_amd import _lib  # noqa: E402
+from megreader_amd._lib import call, dtype_code, ptr  # noqa: E402
+from microbench_tn_taps import bench  # noqa: E402
+
+CASES = [("crnn.conv5", 4, 33, 512, 512, 8), ("crnn.conv3", 8, 32, 256, 256, 32), ("crnn.conv4", 4, 33, 256, 512, 16)]
+NAMES = {0: "full", 1: "no DMA", 2: "no x-fragment reads", 4: "no masks", 8: "no atomic epilogue", 16: "no barrier",
+         32: "plain stores instead of atomics", 64: "a third of the atomics", 128: "atomics from 2 of 4 waves",
+         256: "atomics from half the workgroups", 6: "no x reads, no masks", 7: "no DMA/x reads/masks", 15: "MFMAs + dy reads + barrier", 31: "MFMAs + dy reads"}
+
+
+def main():
+    lib = _lib.load()
+    dt = dtype_code(torch.bfloat16)
+    N = 256
+    lib.mr_set_tn_taps(1)
+    lib.mr_set_tn_taps_group(1)
+    for name, H, W, C, K, splits in CASES:
+        x = torch.randn(N, H, W, C, device="cuda").bfloat16()
+        dy = torch.randn(N, H, W, K, device="cuda").bfloat16()
+        gw = torch.zeros(K, 3, 3, C, device="cuda")
+        gb = torch.zeros(K, device="cuda")
+        tab = torch.empty(N * H * W, 2, dtype=torch.int32, device="cuda")
+        flops = 2.0 * N * H * W * K * 9 * C
+        lib.mr_set_tn_splits(splits)
+        run = lambda b=0: call("mr_conv2d_wgrad_tab", dt, ptr(dy), ptr(x), ptr(gw), ptr(gb), N, H, W, C, C, K, K, 3, 3, 1, 1,
+                               1, 1, 1, 1, H, W, ptr(tab), b)
+        run(1)
+        print("%s (splits %d)" % (name, splits))
+        for m in (0, 8, 32, 64, 128, 256):
+            lib.mr_set_tn_taps_abl(m)
+            us = bench(run, 20)
+            print("   %-28s %7.1f us %6.0f TF/s" % (NAMES[m], us, flops / us * 1e-6), flush=True)
+        lib.mr_set_tn_taps_abl(0)
+    lib.mr_set_tn_splits(0)
+    lib.mr_set_tn_taps(0)
+
+
+if __name__ == "__main__":
+    main()
