@@ -101,7 +101,8 @@ static int g_tn_buf = 1;  // TN kernel staging through buffer resources (mr_set_
 static int g_tn_taps = 1;  // all-taps wgrad kernel for 3x3 / stride 1 / pad == dilation layers (tn_taps.hip, mr_set_tn_taps)
 static int g_tn_big = 0;  // wide-tile TN kernels: 1 = 256x256, 2 = 128x256 (experimental, see launch_tn), else never
 
-// 0 = use the 4-wave kernels, 1 = 256x256 (8 waves), 2 = 288x256 (12 waves; tuning only).  The big tiles run one
+// 0 = use the 4-wave kernels, 1 = 256x256 (8 waves), 3 = 272x256 (8 waves as 1x8); 2 (288x256, spills), 4 / 5 (160x128 with 4 /
+// 8 waves) are tuning overrides only.  The big tiles run one
 // workgroup per CU, so they only pay when the tile count fills whole rounds of the CUs.  Measured on MI355X (bf16,
 // tools/microbench_conv.py --big): 65536x256 (256 tiles, one exact round) K=2304: 653 -> 804 TF/s forward,
 // 724 -> 888 TF/s dgrad; 33792x512 is 264 tiles of 256x256 (two rounds, the second 3 % full): 742 -> 604 TF/s, and
@@ -115,7 +116,25 @@ static int nt_big_choice(int M, int N, int K) {
   const long long tiles = (long long)cdiv(M, 256) * (N / 256);
   const long long rounds = (tiles + cus - 1) / cus;
   const double util = (double)M * N / ((double)rounds * cus * 256 * 256);
-  return util >= 0.85 ? 1 : 0;
+  if (util >= 0.85) return 1;
+  // 272-row tiles (8 waves as 1x8, 17x2 MFMA tiles per wave): 33792 x 512 is 264 tiles of 256 rows (one round + 8
+  // tiles) but 250 tiles of 272 rows -- ONE round, 0.6 % padding.  Measured against the head / tail split
+  // (tools/microbench_conv.py --big 3): conv4 fwd 108.8 -> 95.6 us, conv5 fwd 176.6 -> 159.9, conv5 dgrad 167.4 ->
+  // 152.8; the tail launch costs ~0.22 of a 256-row round, i.e. ~57 rows of tile height.
+  const long long tiles272 = (long long)cdiv(M, 272) * (N / 256);
+  const long long rounds272 = (tiles272 + cus - 1) / cus;
+  const double util272 = (double)M * N / ((double)rounds272 * cus * 272 * 256);
+  if (util272 >= 0.85) {
+    const int tiles_n = N / 256;
+    double alt = 1e300;   // head / tail cost in rows of tile height, if that split exists
+    if (cus % tiles_n == 0) {
+      const long long rows_per_round = (long long)(cus / tiles_n) * 256;
+      const long long head = (M / rows_per_round) * rows_per_round;
+      if (head > 0 && (M - head) * 8 <= M) alt = (double)(head / rows_per_round) * 256 + (head == M ? 0 : 57);
+    }
+    if ((double)rounds272 * 272 < alt) return 3;
+  }
+  return 0;
 }
 
 // Rows of the head of a head / tail launch (see dispatch_nt_store), 0 = do not split.
@@ -257,7 +276,10 @@ static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long l
         nt_fits_buffer<T>(a, g, AMODE)) {
       const int big = nt_big_choice(a.M, a.N, a.K);
       if (big == 1) return launch_nt_p8<T, AMODE>(a, g, C, ldc, bias, relu, stream);
-      if (big == 2) return launch_nt_big<T, 3, 4, 6, 4, AMODE>(a, g, C, ldc, bias, relu, stream);  // 288x256, 12 waves
+      if (big == 2) return launch_nt_big<T, 2, 4, 9, 4, AMODE>(a, g, C, ldc, bias, relu, stream);   // 288x256, 8 waves (2x4)
+      if (big == 3) return launch_nt_big<T, 1, 8, 17, 2, AMODE>(a, g, C, ldc, bias, relu, stream);  // 272x256, 8 waves (1x8)
+      if (big == 4) return launch_nt_big<T, 2, 2, 5, 4, AMODE>(a, g, C, ldc, bias, relu, stream);   // 160x128, 4 waves (2x2)
+      if (big == 5) return launch_nt_big<T, 2, 4, 5, 2, AMODE>(a, g, C, ldc, bias, relu, stream);   // 160x128, 8 waves (2x4)
       // Head / tail: rows are independent, so a problem whose 256x256 tile count is a few tiles over whole rounds of
       // the CUs (33792 x 512: 264 tiles on 256 CUs) is cut into a head that is EXACTLY whole rounds of big tiles and
       // a tail of the remaining rows for the 4-wave kernel.  No cross-workgroup reduction, two launches.
@@ -423,7 +445,7 @@ int mr_set_nt_p8(int on) {
 // callers; a tuning / A-B override).  Returns the previous setting.
 int mr_set_nt_big(int mode) {
   const int old = g_big_mode;
-  if (mode >= -1 && mode <= 2) g_big_mode = mode;
+  if (mode >= -1 && mode <= 5) g_big_mode = mode;
   return old;
 }
 
@@ -522,6 +544,8 @@ int mr_nt_kernel_code(int dtype, int M, int N, int K, int cg) {
     const int big = nt_big_choice(M, N, K);
     if (big == 1) return 256256;
     if (big == 2) return 288256;
+    if (big == 3) return 272256;
+    if (big == 4 || big == 5) return 160128;
     if (nt_head_rows(M, N, K) > 0) return 256257;   // TWO launches: head (whole rounds of 256x256 tiles) + a 4-wave tail
   }
   return mr_nt_tile_code(M, N);

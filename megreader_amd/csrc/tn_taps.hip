@@ -204,7 +204,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void igemm_tn_taps_kern
     if (!(ABL & 16)) __syncthreads();
     if (!(ABL & 1)) {
       stage(c + HALO + 1, c + HALO + 1 < c_end);
-      fetch_entries(c + HALO + 2);
+      fetch_entries((ABL & 2048) ? c_begin : c + HALO + 2);   // ABL 2048, timing only: always the same (L2-hot) rows
     }
     const int bA = sA + (c & 3) * CHB;
 #pragma unroll
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void igemm_tn_taps_kern
       const int ticket = *bc;
       if (ticket != gsize - 1) return;
       if (tid8 == 0) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-      for (int j = 0; worker && j < gsize; ++j) {
+      for (int j = 0; worker && j < gsize && !(ABL & 512); ++j) {   // ABL 512, timing only: no slab reads
         const int vbj = (g0 + j) * ntiles + tile;
         if (vbj == vb) continue;
         const int sj = vbj * (int)TAPS_SLAB_BYTES;
@@ -321,6 +321,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void igemm_tn_taps_kern
     }
   }
   if (!worker) return;
+  if (ABL & 1024) return;   // timing only: no final atomics (group phase only)
   if ((ABL & 128) && wave >= 2) return;              // timing only: half the waves issue atomics
   if ((ABL & 256) && (blockIdx.x >> 3) & 1) return;   // timing only: half the workgroups issue atomics
 #pragma unroll
@@ -452,7 +453,7 @@ int launch_tn_taps(const TapsProblem& p, int splits_override, hipStream_t stream
       (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
       hipLaunchKernelGGL(k2, dim3(tiles * splits), dim3(256), lds, stream, a); } break;
     switch (g_taps_abl) { MR_TAPS_ABL(1) MR_TAPS_ABL(2) MR_TAPS_ABL(4) MR_TAPS_ABL(8) MR_TAPS_ABL(16) MR_TAPS_ABL(6)
-      MR_TAPS_ABL(7) MR_TAPS_ABL(15) MR_TAPS_ABL(31) MR_TAPS_ABL(32) MR_TAPS_ABL(64) MR_TAPS_ABL(128) MR_TAPS_ABL(256)
+      MR_TAPS_ABL(7) MR_TAPS_ABL(15) MR_TAPS_ABL(31) MR_TAPS_ABL(32) MR_TAPS_ABL(64) MR_TAPS_ABL(128) MR_TAPS_ABL(256) MR_TAPS_ABL(512) MR_TAPS_ABL(1024) MR_TAPS_ABL(1536) MR_TAPS_ABL(2048) MR_TAPS_ABL(2056) MR_TAPS_ABL(9)
       default: break; }
 #undef MR_TAPS_ABL
     MR_CHECK_LAUNCH();

@@ -52,15 +52,17 @@ def test_gemm_nt(dtype, M, N, K):
         assert float((C[:, N:].float() - 7.0).abs().max()) == 0.0  # pad columns untouched
 
 
-@pytest.mark.parametrize("M,N,K", [(66000, 256, 576), (33792, 512, 640), (65536 + 256, 256, 512)])
-def test_gemm_nt_head_tail_split(M, N, K):
-    """Problems a few tiles over whole rounds of 256x256 tiles on the 256 CUs are cut into a big-tile head and a 4-wave
-    tail (dispatch_nt_store): every output row, head and tail (ragged last tile included), against an f64 reference,
-    and bit-identical to the 4-wave kernel alone (same bf16 operands, same f32 accumulation order per element)."""
+@pytest.mark.parametrize("M,N,K,code", [(70000, 256, 576, 256257), (66000, 256, 576, 272256), (33792, 512, 640, 272256),
+                                        (65536 + 256, 256, 512, 272256)])
+def test_gemm_nt_head_tail_split(M, N, K, code):
+    """Problems a few tiles over whole rounds of 256x256 tiles on the 256 CUs either run as ONE round of 272-row tiles
+    (when that covers them: 33792 x 512 = 250 tiles) or are cut into a big-tile head and a 4-wave tail
+    (dispatch_nt_store): every output row (ragged last tile included) against an f64 reference, and bit-identical to
+    the 4-wave kernel alone (same bf16 operands, same f32 accumulation order per element)."""
     from megreader_amd._lib import load
     lib = load()
     dtype = torch.bfloat16
-    assert lib.mr_nt_kernel_code(1, M, N, K, 0) == 256257, "the head/tail path must apply to this shape"
+    assert lib.mr_nt_kernel_code(1, M, N, K, 0) == code, "unexpected kernel choice for this shape"
     g = torch.Generator().manual_seed(M)
     A = (torch.randn(M, K, generator=g) * 0.5).to(DEV, dtype)
     B = (torch.randn(N, K, generator=g) * 0.5).to(DEV, dtype)
@@ -404,9 +406,9 @@ def test_conv_relu_pool_fused_backward(dtype):
     assert _rel_err(bd.grad, br.grad) < tol
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_big_tile_nt_kernel_bit_identical_to_4wave_kernel(mode):
-    """The 8/12-wave 256x256 / 288x256 NT kernel (picked automatically for CU-filling shapes) against the 4-wave
+    """The 8-wave 256x256 / 288x256 / 272x256 NT kernel (picked automatically for CU-filling shapes) against the 4-wave
     kernel on the same operands: same MFMA instruction, same k order per output element -> bit-identical results.
     Covers dense GEMM, conv forward and conv dgrad operands, ragged last row tiles and two column tiles."""
     from megreader_amd._lib import load

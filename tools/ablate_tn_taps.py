@@ -14,7 +14,9 @@ from microbench_tn_taps import bench  # noqa: E402
 CASES = [("crnn.conv5", 4, 33, 512, 512, 8), ("crnn.conv3", 8, 32, 256, 256, 32), ("crnn.conv4", 4, 33, 256, 512, 16)]
 NAMES = {0: "full", 1: "no DMA", 2: "no x-fragment reads", 4: "no masks", 8: "no atomic epilogue", 16: "no barrier",
          32: "plain stores instead of atomics", 64: "a third of the atomics", 128: "atomics from 2 of 4 waves",
-         256: "atomics from half the workgroups", 6: "no x reads, no masks", 7: "no DMA/x reads/masks", 15: "MFMAs + dy reads + barrier", 31: "MFMAs + dy reads"}
+         256: "atomics from half the workgroups", 512: "group: no slab reads", 1024: "group: no final atomics",
+         1536: "group: slab stores + ticket only", 2048: "DMA of L2-hot rows", 2056: "DMA of L2-hot rows, no epilogue",
+         9: "no DMA, no epilogue", 6: "no x reads, no masks", 7: "no DMA/x reads/masks", 15: "MFMAs + dy reads + barrier", 31: "MFMAs + dy reads"}
 
 
 def main():
@@ -22,7 +24,9 @@ def main():
     dt = dtype_code(torch.bfloat16)
     N = 256
     lib.mr_set_tn_taps(1)
-    lib.mr_set_tn_taps_group(1)
+    lib.mr_set_tn_taps_group(4)
+    from megreader_amd.nn import functional as F
+    F.ensure_tn_taps_workspace('cuda')
     for name, H, W, C, K, splits in CASES:
         x = torch.randn(N, H, W, C, device="cuda").bfloat16()
         dy = torch.randn(N, H, W, K, device="cuda").bfloat16()
@@ -35,7 +39,7 @@ def main():
                                1, 1, 1, 1, H, W, ptr(tab), b)
         run(1)
         print("%s (splits %d)" % (name, splits))
-        for m in (0, 8, 32, 64, 128, 256):
+        for m in (0, 8, 2048, 2056, 9):
             lib.mr_set_tn_taps_abl(m)
             us = bench(run, 20)
             print("   %-28s %7.1f us %6.0f TF/s" % (NAMES[m], us, flops / us * 1e-6), flush=True)

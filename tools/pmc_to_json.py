@@ -28,6 +28,8 @@ def label(name):
         return "igemm_nt_kernel<bf16,256,256,conv>"
     if re.search(r"igemm_tn_glds_kernel<[12]", name) or re.search(r"igemm_tn_glds_kernelILi[12]E", name):
         return "igemm_tn_kernel<bf16,conv>"
+    if "igemm_nt_big_kernelIDF16bLi1ELi8ELi17ELi2ELi2E" in name:
+        return "igemm_nt_kernel<bf16,272,256,conv>"
     if "igemm_tn_taps_kernel" in name:
         return "igemm_tn_taps_kernel<bf16,3x3>"
     return None
