@@ -267,6 +267,28 @@ static TileChoice nt_tile(int M, int N) {
   return best;
 }
 
+// 288x128 tile (8 waves as 2x4, 9x2 MFMA tiles per wave) for problems the 4-wave tiles quantise badly and the 256-column
+// big tiles cannot fill: conv4 dgrad of the CRNN (33792 x 256, K = 4608) is 704 tiles of 96x128 = 2 rounds of 512 slots
+// with the second 37 % full, but 236 tiles of 288x128 = one round at 92 %: 110.4 -> 92.2 us.  At equal utilisation the
+// 4-wave 128x128 kernel (two workgroups per CU) is faster (conv2 dgrad 49.9 vs 55.7 us), hence the quantisation test.
+static bool nt_use_288x128(int M, int N, int K) {
+  if (g_big_mode != 0 || N % 128 != 0 || K < 2048) return false;
+  const int cus = num_cus();
+  const long long tiles = (long long)cdiv(M, 288) * (N / 128);
+  const long long rounds = (tiles + cus - 1) / cus;
+  const double util = (double)M * N / ((double)rounds * cus * 288 * 128);
+  if (util < 0.85) return false;
+  const TileChoice t = nt_tile(M, N);
+  const long long t4 = (long long)cdiv(M, t.bm) * cdiv(N, t.bn);
+  int per_cu = (160 * 1024) / (2 * (t.bm + t.bn) * 128);
+  if (per_cu > 3) per_cu = 3;
+  long long c = (t4 + cus - 1) / cus;
+  if (c > per_cu) c = per_cu;
+  const long long r4 = (t4 + cus * c - 1) / (cus * c);
+  const double quant = (double)t4 / ((double)r4 * cus * c);
+  return quant < 0.8;
+}
+
 template <typename T, int AMODE>
 static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long long ldc, const float* bias,
                              int relu, hipStream_t stream) {
@@ -280,10 +302,14 @@ static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long l
       if (big == 3) return launch_nt_big<T, 1, 8, 17, 2, AMODE>(a, g, C, ldc, bias, relu, stream);  // 272x256, 8 waves (1x8)
       if (big == 4) return launch_nt_big<T, 2, 2, 5, 4, AMODE>(a, g, C, ldc, bias, relu, stream);   // 160x128, 4 waves (2x2)
       if (big == 5) return launch_nt_big<T, 2, 4, 5, 2, AMODE>(a, g, C, ldc, bias, relu, stream);   // 160x128, 8 waves (2x4)
+      if (big == 6) return launch_nt_big<T, 2, 4, 8, 2, AMODE>(a, g, C, ldc, bias, relu, stream);   // 256x128, 8 waves (2x4)
+      if (big == 7) return launch_nt_big<T, 2, 4, 9, 2, AMODE>(a, g, C, ldc, bias, relu, stream);   // 288x128, 8 waves (2x4)
       // Head / tail: rows are independent, so a problem whose 256x256 tile count is a few tiles over whole rounds of
       // the CUs (33792 x 512: 264 tiles on 256 CUs) is cut into a head that is EXACTLY whole rounds of big tiles and
       // a tail of the remaining rows for the 4-wave kernel.  No cross-workgroup reduction, two launches.
       const long long head = a.m_begin == 0 ? nt_head_rows(a.M, a.N, a.K) : 0;
+      if (head == 0 && a.m_begin == 0 && nt_use_288x128(a.M, a.N, a.K))
+        return launch_nt_big<T, 2, 4, 9, 2, AMODE>(a, g, C, ldc, bias, relu, stream);
       if (head > 0) {
         NtArgs ah = a;
         ah.M = (int)head;
@@ -445,7 +471,7 @@ int mr_set_nt_p8(int on) {
 // callers; a tuning / A-B override).  Returns the previous setting.
 int mr_set_nt_big(int mode) {
   const int old = g_big_mode;
-  if (mode >= -1 && mode <= 5) g_big_mode = mode;
+  if (mode >= -1 && mode <= 7) g_big_mode = mode;
   return old;
 }
 
@@ -546,7 +572,10 @@ int mr_nt_kernel_code(int dtype, int M, int N, int K, int cg) {
     if (big == 2) return 288256;
     if (big == 3) return 272256;
     if (big == 4 || big == 5) return 160128;
+    if (big == 6) return 256128;
+    if (big == 7) return 288128;
     if (nt_head_rows(M, N, K) > 0) return 256257;   // TWO launches: head (whole rounds of 256x256 tiles) + a 4-wave tail
+    if (nt_use_288x128(M, N, K)) return 288128;
   }
   return mr_nt_tile_code(M, N);
 }

@@ -406,7 +406,7 @@ def test_conv_relu_pool_fused_backward(dtype):
     assert _rel_err(bd.grad, br.grad) < tol
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 6, 7])
 def test_big_tile_nt_kernel_bit_identical_to_4wave_kernel(mode):
     """The 8-wave 256x256 / 288x256 / 272x256 NT kernel (picked automatically for CU-filling shapes) against the 4-wave
     kernel on the same operands: same MFMA instruction, same k order per output element -> bit-identical results.

@@ -1,7 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out
-for b in 0 4 5; do
-  echo "== --big $b"
-  timeout 200 python tools/microbench_conv.py --layers 6 --only fwd,dgrad --big $b 2>&1 | grep -v amdgpu.ids
-done | tee gpurun_out/nt_big_variants2.log
-echo "== auto, layers 4,5"; timeout 200 python tools/microbench_conv.py --layers 4,5 --only fwd,dgrad 2>&1 | grep -v amdgpu.ids
+timeout 300 python -m pytest tests/test_kernels_gpu.py -x -q -k "big_tile or head_tail" 2>&1 | tail -3
+timeout 200 python tools/microbench_conv.py --layers 2,4 --only fwd,dgrad 2>&1 | grep -v amdgpu.ids

@@ -30,6 +30,8 @@ def label(name):
         return "igemm_tn_kernel<bf16,conv>"
     if "igemm_nt_big_kernelIDF16bLi1ELi8ELi17ELi2ELi2E" in name:
         return "igemm_nt_kernel<bf16,272,256,conv>"
+    if "igemm_nt_big_kernelIDF16bLi2ELi4ELi9ELi2ELi2E" in name:
+        return "igemm_nt_kernel<bf16,288,128,conv>"
     if "igemm_tn_taps_kernel" in name:
         return "igemm_tn_taps_kernel<bf16,3x3>"
     return None
