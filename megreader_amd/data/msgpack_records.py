@@ -7,9 +7,9 @@ in mode 'BGR', swaps the channels with cv2.cvtColor -> float32 HWC for the host-
 stays **uint8 HWC** (4x fewer bytes over PCIe) and goes straight into `DevicePipeline.pack`, whose kernels do the
 float conversion, resize and normalisation on the GPU; the channel swap is a numpy view (no cv2).
 
-The container formats around the records (LMDB `image` / `extra` databases, data/lmdb_dataset.py:59-88; nori) are NOT
-read here: neither the `lmdb` module nor any LMDB file exists in the build image to pin a reader against
-(DESIGN.md §8)."""
+The LMDB container around the records (`image` / `extra` named databases, data/lmdb_dataset.py:59-88) is read by
+`megreader_amd.data.lmdb_reader` (pure-Python reader of the on-disk format; parity unpinned, see its header); nori is a
+Megvii-internal store and is not read."""
 import io
 
 import msgpack

@@ -129,3 +129,90 @@ def test_msgpack_record_unpack_follows_the_reference_rules():
     assert out['img'].dtype == np.uint8 and out['img'].flags['C_CONTIGUOUS']
     assert np.array_equal(out['img'], rgb[:, :, ::-1])
     assert np.array_equal(UnpackMsgpackData(mode='RGB').convert(rec)['img'], rgb)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LMDB container reader (megreader_amd/data/lmdb_reader.py; SURVEY.md §8 f3, reference data/lmdb_dataset.py:59-88)
+# ---------------------------------------------------------------------------------------------------------------
+def _lmdb_records(n, seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    recs = {}
+    for i in range(n):
+        size = int(rng.choice([0, 1, 7, 100, 2029, 2030, 2031, 5000, 70000]))   # in-page and overflow (BIGDATA) values
+        recs[("image-%09d" % i).encode()] = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+    return recs
+
+
+def test_lmdb_reader_roundtrip_named_databases(tmp_path):
+    """Writer -> reader over named databases (what `env.open_db(b'image')` opens), 3-level trees, values on overflow
+    pages, missing keys, key order of the cursor, and the format constants the reader relies on."""
+    import struct
+
+    from megreader_amd.data import lmdb_reader as L
+    img = _lmdb_records(3000, 1)
+    extra = {b"k%d" % i: b"v" * (i % 50) for i in range(10)}
+    path = str(tmp_path / "db")
+    fname = L.write_environment(path, {b"image": img, b"extra": extra})
+    raw = open(fname, "rb").read()
+    assert struct.unpack_from("<I", raw, 16)[0] == 0xBEEFC0DE and struct.unpack_from("<I", raw, 20)[0] == 1
+    assert struct.unpack_from("<H", raw, 10)[0] == L.P_META and len(raw) % 4096 == 0
+    env = L.open(path, max_dbs=1, lock=False)
+    assert env.psize == 4096 and env.stat()["entries"] == 2          # two named databases in MAIN
+    txn = env.begin(db=env.open_db(b"image"))
+    assert txn.stat()["entries"] == len(img) and txn.stat()["depth"] >= 2
+    for k, v in img.items():
+        assert txn.get(k) == v
+    assert txn.get(b"image-999999999") is None and txn.get(b"") is None and txn.get(b"zzz", b"dflt") == b"dflt"
+    keys = [k for k, _ in txn.cursor()]
+    assert keys == sorted(img) and len(keys) == len(img)
+    t2 = env.begin(db=env.open_db(b"extra"))
+    assert dict(t2.cursor()) == extra
+    import pytest
+    with pytest.raises(L.Error):
+        env.open_db(b"nope")
+    env.close()
+
+
+def test_lmdb_reader_unnamed_db_small_pages_and_key_order(tmp_path):
+    """MAIN-database records, 512-byte pages (deep tree), and memcmp key order with shorter-first ties."""
+    from megreader_amd.data import lmdb_reader as L
+    recs = {b"a": b"1", b"ab": b"2", b"b": b"3", b"a\x00": b"4", b"\xff": b"5", b"num-samples": b"5"}
+    recs.update({b"key-%05d" % i: (b"%d" % i) * (i % 40) for i in range(2000)})
+    path = str(tmp_path / "db2")
+    L.write_environment(path, {None: recs}, psize=512)
+    with L.open(path) as env:
+        assert env.psize == 512
+        txn = env.begin()
+        assert txn.stat()["depth"] >= 3
+        for k, v in recs.items():
+            assert txn.get(k) == v
+        assert [k for k, _ in txn.cursor()] == sorted(recs)
+
+
+def test_lmdb_image_store_mirrors_reference_usage(tmp_path):
+    """`LMDBImageStore` = the reference's prepare / search_image / default_unpack sequence on top of the reader."""
+    import io
+
+    import numpy as np
+    from PIL import Image
+
+    from megreader_amd.data import lmdb_reader as L
+    rng = np.random.default_rng(0)
+    imgs, recs = {}, {}
+    for i in range(5):
+        a = rng.integers(0, 256, (32, 100 + i, 3), dtype=np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(a).save(buf, format="PNG")
+        imgs["id%d" % i] = a
+        recs[("id%d" % i).encode()] = buf.getvalue()
+    path = str(tmp_path / "imgdb")
+    L.write_environment(path, {b"image": recs})
+    store = L.LMDBImageStore([path])
+    for k, a in imgs.items():
+        meta = store.default_unpack(k, {"db_path": path})
+        assert meta["image"].dtype == np.uint8 and np.array_equal(meta["image"], a[:, :, ::-1])
+    import pytest
+    with pytest.raises(AssertionError):
+        store.search_image("missing", path)
+    store.close()
