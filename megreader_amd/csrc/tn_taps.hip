@@ -386,7 +386,7 @@ static int g_taps_grp = 0;   // 0 = automatic, 1 = atomics only, > 1 = forced gr
 void taps_set_workspace(void* p, long long bytes) { g_taps_ws = p; g_taps_ws_bytes = p ? bytes : 0; }
 int taps_set_group(int g) { const int old = g_taps_grp; if (g >= 0) g_taps_grp = g; return old; }
 
-static int g_taps_w8 = 0;    // 1: 8-wave workgroups (two reduction halves share one partial tile), one per CU
+static int g_taps_w8 = 1;    // 1 (default: same time, half the partial-tile traffic): 8-wave workgroups (two reduction halves share one partial tile), one per CU
 int taps_set_w8(int on) { const int old = g_taps_w8; if (on == 0 || on == 1) g_taps_w8 = on; return old; }
 
 static int g_taps_abl = 0;

@@ -24,6 +24,7 @@ def main():
     dt = dtype_code(torch.bfloat16)
     N = 256
     lib.mr_set_tn_taps(1)
+    lib.mr_set_tn_taps_w8(0)   # the ablation variants exist for the 4-wave kernel only
     lib.mr_set_tn_taps_group(4)
     from megreader_amd.nn import functional as F
     F.ensure_tn_taps_workspace('cuda')
