@@ -510,7 +510,8 @@ int mr_set_tn_taps(int mode) {
 
 // Workspace of the all-taps kernel's in-launch split reduction: `bytes` of device memory (16 KB of tickets + 147456 B
 // per workgroup of the largest launch, i.e. 2 * CUs slabs), ZEROED by the caller once; NULL / 0 withdraws it (the
-// kernel then reduces with f32 atomics only).  Launches that use it must be stream-ordered with each other.
+// kernel then reduces with f32 atomics only).  One workspace per device (the current device at the time of the call).
+// Launches that use it must be stream-ordered with each other.
 int mr_set_tn_taps_workspace(void* ws, long long bytes) {
   MR_CHECK_ARG((ws == nullptr) == (bytes == 0) && bytes >= 0 && (((uintptr_t)ws) & 15) == 0,
                "mr_set_tn_taps_workspace: bad workspace");

@@ -380,10 +380,21 @@ int taps_eligible(int N, int H, int W, int Cin, int ldx, int Cout, int lddy, int
   return 1;
 }
 
-static void* g_taps_ws = nullptr;
-static long long g_taps_ws_bytes = 0;
+// one workspace per device (one process may drive several GPUs): indexed by the current device at set / launch time
+static void* g_taps_ws_dev[64] = {nullptr};
+static long long g_taps_ws_bytes_dev[64] = {0};
 static int g_taps_grp = 0;   // 0 = automatic, 1 = atomics only, > 1 = forced group size
-void taps_set_workspace(void* p, long long bytes) { g_taps_ws = p; g_taps_ws_bytes = p ? bytes : 0; }
+static int taps_cur_dev() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  return dev;
+}
+void taps_set_workspace(void* p, long long bytes) {
+  const int dev = taps_cur_dev();
+  if (dev < 0) return;
+  g_taps_ws_dev[dev] = p;
+  g_taps_ws_bytes_dev[dev] = p ? bytes : 0;
+}
 int taps_set_group(int g) { const int old = g_taps_grp; if (g >= 0) g_taps_grp = g; return old; }
 
 static int g_taps_w8 = 1;    // 1 (default: same time, half the partial-tile traffic): 8-wave workgroups (two reduction halves share one partial tile), one per CU
@@ -428,6 +439,9 @@ int launch_tn_taps(const TapsProblem& p, int splits_override, hipStream_t stream
   splits = cdiv(a.nchunks, a.cps * halves);
   // group reduction: needs the registered workspace (tickets + one slab per workgroup) and unique tickets
   a.grp = 1;
+  const int dev = taps_cur_dev();
+  void* const g_taps_ws = dev >= 0 ? g_taps_ws_dev[dev] : nullptr;
+  const long long g_taps_ws_bytes = dev >= 0 ? g_taps_ws_bytes_dev[dev] : 0;
   a.ws = g_taps_ws;
   {
     int want = g_taps_grp ? g_taps_grp : (splits >= 4 ? 4 : (splits >= 2 ? 2 : 1));

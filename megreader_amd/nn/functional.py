@@ -235,7 +235,8 @@ def ensure_tn_taps_workspace(device):
         cus = torch.cuda.get_device_properties(idx).multi_processor_count
         nbytes = 16384 + (2 * cus + 64) * 147456
         ws = _TAPS_WS[idx] = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device("cuda", idx))
-        rc = load().mr_set_tn_taps_workspace(ws.data_ptr(), nbytes)
+        with torch.cuda.device(idx):   # the library keeps one workspace per device, keyed by the current device
+            rc = load().mr_set_tn_taps_workspace(ws.data_ptr(), nbytes)
         if rc != 0:
             raise RuntimeError("mr_set_tn_taps_workspace failed: %s" % load().mr_last_error().decode())
     return ws

@@ -39,12 +39,18 @@ def label(name):
 
 def main():
     fetch, write = parse(sys.argv[1]), parse(sys.argv[2])
-    out = {}
+    acc = {}
     for name, (fkb, n) in fetch.items():
         lab = label(name)
         if lab is None or name not in write:
             continue
-        wkb = write[name][0]
+        a = acc.setdefault(lab, [0.0, 0.0, 0])   # launch-weighted sums over every instantiation that maps to the label
+        a[0] += fkb * n
+        a[1] += write[name][0] * n
+        a[2] += n
+    out = {}
+    for lab, (fsum, wsum, n) in acc.items():
+        fkb, wkb = fsum / n, wsum / n
         out[lab] = {"fetch_size_kb_mean": fkb, "write_size_kb_mean": wkb, "launches": n,
                     "bytes_per_launch": 2.0 * fkb * 1024 + wkb * 1024,
                     "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes, mean per launch"}
