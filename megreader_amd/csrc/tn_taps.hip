@@ -397,7 +397,10 @@ void taps_set_workspace(void* p, long long bytes) {
 }
 int taps_set_group(int g) { const int old = g_taps_grp; if (g >= 0) g_taps_grp = g; return old; }
 
-static int g_taps_w8 = 1;    // 1 (default: same time, half the partial-tile traffic): 8-wave workgroups (two reduction halves share one partial tile), one per CU
+// 1: 8-wave workgroups (two reduction halves share one partial tile), one per CU.  Opt-in: it halves the partial-tile
+// traffic (HBM-side bytes per launch 209 -> 144 MB) and ties in the microbenchmark, but inside the training step it is
+// ~10 % slower (rocprofv3 average 122.6 vs 111.2 us per launch: one barrier-coupled 8-wave workgroup per CU)
+static int g_taps_w8 = 0;
 int taps_set_w8(int on) { const int old = g_taps_w8; if (on == 0 || on == 1) g_taps_w8 = on; return old; }
 
 static int g_taps_abl = 0;

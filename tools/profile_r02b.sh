@@ -29,3 +29,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY S
 done
 grep -A9 "igemm_tn_taps\|igemm_nt_big_kernelIDF16bLi1ELi8" $O/pmc_sq_pass1.txt | head -40
 cat $O/pmc_traffic_crnn.json | head -60
+for m in capture graph2; do
+  RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 timeout 300 python bench.py --force-ddp --ddp-mode $m --no-cpu-baseline --no-secondary > $O/force_ddp_$m.log 2>&1; tail -1 $O/force_ddp_$m.log > $O/bench_force_ddp_$m.json; cut -c1-160 $O/bench_force_ddp_$m.json
+done
