@@ -142,6 +142,8 @@ def load():
     lib.mr_set_tn_taps.argtypes = [ctypes.c_int]
     lib.mr_set_tn_taps_workspace.restype = ctypes.c_int
     lib.mr_set_tn_taps_workspace.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+    lib.mr_set_tn_group.restype = ctypes.c_int
+    lib.mr_set_tn_group.argtypes = [ctypes.c_int]
     lib.mr_set_tn_taps_group.restype = ctypes.c_int
     lib.mr_set_tn_taps_group.argtypes = [ctypes.c_int]
     lib.mr_set_tn_taps_w8.restype = ctypes.c_int
@@ -181,7 +183,7 @@ def load():
 
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_set_nt_variant", "mr_force_nt_tile",
              "mr_stem_bwd_workspace", "mr_set_lstm_variant", "mr_set_nt_big", "mr_set_lstm_persist", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_set_nt_p8", "mr_set_tn_abl", "mr_set_tn_splits", "mr_set_tn_model", "mr_set_dcn_v1_bwd", "mr_bn_scratch_doubles", "mr_sizeof_img_desc",
-             "mr_nt_kernel_code", "mr_set_tn_taps", "mr_tn_taps_would_run", "mr_set_tn_taps_abl", "mr_set_tn_taps_w8", "mr_set_tn_taps_workspace", "mr_set_tn_taps_group", "mr_set_tn_big", "mr_set_tn_buf", "mr_sizeof_prep_job")  # entry points that take no stream and launch nothing
+             "mr_nt_kernel_code", "mr_set_tn_taps", "mr_tn_taps_would_run", "mr_set_tn_taps_abl", "mr_set_tn_taps_w8", "mr_set_tn_taps_workspace", "mr_set_tn_taps_group", "mr_set_tn_group", "mr_set_tn_big", "mr_set_tn_buf", "mr_sizeof_prep_job")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):
@@ -219,10 +221,41 @@ class KernelTimer(object):
 
 TIMER = None  # set to a KernelTimer to enable
 
+_TN_WS = {}
+_TN_WS_CALLS = frozenset(("mr_gemm_tn", "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab"))
+
+
+def ensure_tn_workspace(device=None):
+    """Register (once per device) the workspace of the weight-gradient kernels' in-launch split reduction
+    (mr_set_tn_taps_workspace): 16 KB of tickets + one 147456-byte slab per workgroup of a full launch (2 per CU).
+    Launches that use it must be stream-ordered with each other: MEGREADER_FAN / MEGREADER_OVERLAP (weight-gradient
+    GEMMs forked onto side streams) switch the reduction back to plain atomics."""
+    if device is None:
+        idx = torch.cuda.current_device()
+    else:
+        device = torch.device(device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _TN_WS.get(idx)
+    if ws is None:
+        lib = load()
+        cus = torch.cuda.get_device_properties(idx).multi_processor_count
+        nbytes = 16384 + (2 * cus + 64) * 147456
+        ws = _TN_WS[idx] = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device("cuda", idx))
+        with torch.cuda.device(idx):   # the library keeps one workspace per device, keyed by the current device
+            rc = lib.mr_set_tn_taps_workspace(ws.data_ptr(), nbytes)
+        if rc != 0:
+            raise RuntimeError("mr_set_tn_taps_workspace failed: %s" % lib.mr_last_error().decode())
+        if os.environ.get("MEGREADER_FAN", "0") == "1" or os.environ.get("MEGREADER_OVERLAP", "0") == "1":
+            lib.mr_set_tn_group(1)
+            lib.mr_set_tn_taps_group(1)
+    return ws
+
 
 def call(name, *args):
     """Invoke a C entry point on torch's current HIP stream; raise RuntimeError on a non-zero return code."""
     lib = load()
+    if name in _TN_WS_CALLS and torch.cuda.current_device() not in _TN_WS:
+        ensure_tn_workspace()
     timer = TIMER
     if timer is not None and name in timer.names:
         e0 = torch.cuda.Event(enable_timing=True)

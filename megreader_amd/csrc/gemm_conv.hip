@@ -99,6 +99,7 @@ static int g_tn_model = 1;   // 1 (default): the measured split model for the co
 static int g_tn_splits = 0;  // > 0: split count override of launch_tn (mr_set_tn_splits, tuning only)
 static int g_tn_buf = 1;  // TN kernel staging through buffer resources (mr_set_tn_buf); measured 4 % faster
 static int g_tn_taps = 1;  // all-taps wgrad kernel for 3x3 / stride 1 / pad == dilation layers (tn_taps.hip, mr_set_tn_taps)
+static int g_tn_group = 0;  // GEMM TN kernel split reduction: 0 automatic (slab groups when a workspace is registered), 1 atomics, > 1 forced
 static int g_tn_big = 0;  // wide-tile TN kernels: 1 = 256x256, 2 = 128x256 (experimental, see launch_tn), else never
 
 // 0 = use the 4-wave kernels, 1 = 256x256 (8 waves), 3 = 272x256 (8 waves as 1x8); 2 (288x256, spills), 4 / 5 (160x128 with 4 /
@@ -415,6 +416,22 @@ static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
   splits = cdiv(a.P, a.p_chunk);
   if constexpr (sizeof(T) == 2) {
     if (g_nt_variant == 2) {
+      // in-launch reduction of the split partials through the all-taps kernel's workspace (TnArgs.grp)
+      // Measured (tools/gpu_r2_tn.sh): the publish + ticket round costs ~8 us of latency, the atomics it removes scale with
+      // the split count -- conv1 wgrad (5 tiles x ~100 splits) 92.6 -> 80.1 us, but conv6 wgrad (16 splits... of 64 tiles)
+      // 44.2 -> 46.8 and the LSTM / Linear weight gradients (4 splits) +-2 us: automatic = only from 16 splits up.
+      if (g_tn_group != 1 && splits > 1 && (g_tn_group > 1 || splits >= 16)) {
+        void* ws = nullptr;
+        long long ws_bytes = 0;
+        taps_get_workspace(&ws, &ws_bytes);
+        int want = g_tn_group > 1 ? g_tn_group : 4;
+        if (want > splits) want = splits;
+        const long long need = TN_TICKETS * 4ll + (long long)tiles * splits * 65536;
+        if (ws && need <= ws_bytes && need < (1ll << 31) && (long long)tiles * cdiv(splits, want) <= TN_TICKETS) {
+          a.grp = want;
+          a.ws = ws;
+        }
+      }
       const void* z = zero_page();
       if (!z) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
       // buffer-resource staging needs every byte offset below the descriptor's 2 GiB num_records
@@ -520,6 +537,8 @@ int mr_set_tn_taps_workspace(void* ws, long long bytes) {
 }
 // tuning: group size of that reduction (0 automatic, 1 atomics only); returns the previous setting
 int mr_set_tn_taps_group(int g) { return taps_set_group(g); }
+// same for the 128x128 TN GEMM kernel (conv wgrad of the other geometries, Linear / LSTM weight gradients)
+int mr_set_tn_group(int g) { const int old = g_tn_group; if (g >= 0) g_tn_group = g; return old; }
 
 // 1 = 8-wave workgroup variant of the all-taps kernel (one per CU, half the partial tiles); returns the previous setting
 int mr_set_tn_taps_w8(int on) { return taps_set_w8(on); }
@@ -610,7 +629,7 @@ int mr_gemm_tn(int dtype, const void* A, long long lda, const void* B, long long
   MR_CHECK_ARG(row_perm_h == 0 || NA % (4 * row_perm_h) == 0, "mr_gemm_tn: NA must be a multiple of 4*row_perm_h");
   TnArgs a;
   a.A = A; a.B = B; a.C = C; a.P = P; a.NA = NA; a.NB = NB; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-  a.p_chunk = 0; a.row_perm_h = row_perm_h; a.colsum = colsum; a.rowtab = nullptr;
+  a.p_chunk = 0; a.row_perm_h = row_perm_h; a.colsum = colsum; a.rowtab = nullptr; a.grp = 1; a.ws = nullptr;
   ConvGeom g = {};
   if (dtype == MR_F32) return launch_tn<float, 0>(a, g, stream);
   return launch_tn<bf16_t, 0>(a, g, stream);
@@ -678,7 +697,7 @@ int mr_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw_krsc, fl
   MR_CHECK_ARG(aligned16(dy) && aligned16(x), "mr_conv2d_wgrad: dy and x must be 16-byte aligned");
   TnArgs a;
   a.A = dy; a.B = x; a.C = dw_krsc; a.P = Nimg * Ho * Wo; a.NA = Cout; a.NB = R * S * Cin; a.lda = lddy;
-  a.ldb = 0; a.ldc = R * S * Cin; a.p_chunk = 0; a.row_perm_h = 0; a.colsum = dbias; a.rowtab = nullptr;
+  a.ldb = 0; a.ldc = R * S * Cin; a.p_chunk = 0; a.row_perm_h = 0; a.colsum = dbias; a.rowtab = nullptr; a.grp = 1; a.ws = nullptr;
   ConvGeom g;
   fill_geom(g, 1, H, W, Cin, ldx, Ho, Wo, R, S, sh, sw, ph, pw, dh, dw);
   if (dtype == MR_F32) return launch_tn<float, 1>(a, g, stream);
@@ -707,7 +726,7 @@ int mr_conv2d_wgrad_tab(int dtype, const void* dy, const void* x, float* dw_krsc
   }
   TnArgs a;
   a.A = dy; a.B = x; a.C = dw_krsc; a.P = Nimg * Ho * Wo; a.NA = Cout; a.NB = R * S * Cin; a.lda = lddy;
-  a.ldb = 0; a.ldc = R * S * Cin; a.p_chunk = 0; a.row_perm_h = 0; a.colsum = dbias; a.rowtab = (const int2*)rowtab;
+  a.ldb = 0; a.ldc = R * S * Cin; a.p_chunk = 0; a.row_perm_h = 0; a.colsum = dbias; a.rowtab = (const int2*)rowtab; a.grp = 1; a.ws = nullptr;
   ConvGeom g;
   fill_geom(g, 1, H, W, Cin, ldx, Ho, Wo, R, S, sh, sw, ph, pw, dh, dw);
   if (build) {

@@ -970,7 +970,14 @@ struct TnArgs {
   int row_perm_h;
   float* colsum;  // optional [NA]: += sum_p A[p, na] (bias gradient), accumulated by the tile_b == 0 blocks
   const int2* rowtab;  // BMODE 2: per output pixel {element offset of its window's top-left input pixel, tap mask}
+  // igemm_tn_glds_kernel only -- in-launch reduction of the split partials (see tn_taps.hip, TapArgs.grp): groups of
+  // `grp` consecutive splits publish their 64 KB accumulator slabs (sc1) and take a ticket; the last arriver sums the
+  // group's slabs and stores: plain read-modify-write when the group is ALL the splits of the tile, f32 atomics otherwise.
+  // ws = [TN_TICKETS ints (zero between launches)][gridDim.x slabs x 65536 B]; grp <= 1: atomics only.
+  int grp;
+  void* ws;
 };
+constexpr int TN_TICKETS = 4096;
 
 // Row table of the conv-wgrad gather (one entry per output pixel p = (n, ho, wo)):
 //   .x = ((n*Hg + ho*sh)*Wg + wo*sw) * ldg      (element offset BEFORE the (-ph, -pw) / tap shift, which is a
@@ -1489,6 +1496,43 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
     }
   }
 
+  bool exclusive = false;   // this workgroup holds the tile's complete sum: plain read-modify-write instead of atomics
+  if (a.grp > 1 && !(ABL & 4)) {
+    const int nsplits = total / ntiles;
+    const int g0 = (split / a.grp) * a.grp;
+    const int gsize = min(a.grp, nsplits - g0);
+    if (gsize > 1) {
+      int* tickets = (int*)a.ws;
+      const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((char*)a.ws + TN_TICKETS * 4, (short)0, 0x7fffffff, 0x00020000);
+      const int so = vb * 65536;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, tid * 16, so + (i * 4 + j) * 4096, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      volatile int* bc = (volatile int*)smem;
+      int* tk = tickets + (tile * ((nsplits + a.grp - 1) / a.grp) + split / a.grp) % TN_TICKETS;
+      if (tid == 0) *bc = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int ticket = *bc;
+      if (ticket != gsize - 1) return;
+      if (tid == 0) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      for (int jg = 0; jg < gsize; ++jg) {
+        const int vbj = (g0 + jg) * ntiles + tile;
+        if (vbj == vb) continue;
+        const int sj = vbj * 65536;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, sj + (i * 4 + j) * 4096, 16));
+      }
+      exclusive = gsize == nsplits;
+    }
+  }
+
   // epilogue: atomic accumulation (see igemm_tn_kernel)
   if (ABL & 4) {   // keep the accumulators alive without the atomics
     float keep = 0.f;
@@ -1514,7 +1558,9 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
           const int blk = row / h4, rin = row - blk * h4;
           row = blk * h4 + (rin & 3) * a.row_perm_h + (rin >> 2);
         }
-        atomicAdd(a.C + (long long)row * a.ldc + col, acc[i][j][q]);
+        float* dst = a.C + (long long)row * a.ldc + col;
+        if (exclusive) *dst += acc[i][j][q];
+        else atomicAdd(dst, acc[i][j][q]);
       }
     }
 }

@@ -395,6 +395,11 @@ void taps_set_workspace(void* p, long long bytes) {
   g_taps_ws_dev[dev] = p;
   g_taps_ws_bytes_dev[dev] = p ? bytes : 0;
 }
+void taps_get_workspace(void** p, long long* bytes) {
+  const int dev = taps_cur_dev();
+  *p = dev >= 0 ? g_taps_ws_dev[dev] : nullptr;
+  *bytes = dev >= 0 ? g_taps_ws_bytes_dev[dev] : 0;
+}
 int taps_set_group(int g) { const int old = g_taps_grp; if (g >= 0) g_taps_grp = g; return old; }
 
 // 1: 8-wave workgroups (two reduction halves share one partial tile), one per CU.  Opt-in: it halves the partial-tile

@@ -221,25 +221,7 @@ def _wgrad_rowtab(device, geom):
     return tab, 1
 
 
-_TAPS_WS = {}
-
-
-def ensure_tn_taps_workspace(device):
-    """Register (once per device) the workspace of the all-taps wgrad kernel's in-launch split reduction
-    (mr_set_tn_taps_workspace): 16 KB of tickets + one 147456-byte slab per workgroup of a full launch (2 per CU)."""
-    device = torch.device(device)
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    ws = _TAPS_WS.get(idx)
-    if ws is None:
-        from .._lib import load
-        cus = torch.cuda.get_device_properties(idx).multi_processor_count
-        nbytes = 16384 + (2 * cus + 64) * 147456
-        ws = _TAPS_WS[idx] = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device("cuda", idx))
-        with torch.cuda.device(idx):   # the library keeps one workspace per device, keyed by the current device
-            rc = load().mr_set_tn_taps_workspace(ws.data_ptr(), nbytes)
-        if rc != 0:
-            raise RuntimeError("mr_set_tn_taps_workspace failed: %s" % load().mr_last_error().decode())
-    return ws
+from .._lib import ensure_tn_workspace as ensure_tn_taps_workspace  # noqa: E402,F401  (kept under its first name)
 
 
 def set_tn_taps(mode):
@@ -345,8 +327,6 @@ class Conv2dFn(Function):
             tab, build = (None, 0)
             if dtype == torch.bfloat16 and R * S <= 32:
                 tab, build = _wgrad_rowtab(g.device, (N, H, W, Cp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo))
-                if R == 3 and S == 3:
-                    ensure_tn_taps_workspace(g.device)
             call("mr_conv2d_wgrad_tab", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, Kp,
                  Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo, ptr(tab), build)
             if w_sink is not None:

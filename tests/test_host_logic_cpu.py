@@ -216,3 +216,17 @@ def test_lmdb_image_store_mirrors_reference_usage(tmp_path):
     with pytest.raises(AssertionError):
         store.search_image("missing", path)
     store.close()
+
+
+def test_tn_taps_kernel_index_arithmetic_emulation():
+    """Lane-level numpy replay of csrc/tn_taps.hip (stream table, LDS-DMA image + swizzle, ds_read_b64_tr_b16 gather, ring
+    wrap, edge masks, MFMA operand layout, split map) against a direct convolution weight gradient: exact on integers."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "emulate_tn_taps", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "emulate_tn_taps.py"))
+    emu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(emu)
+    emu.check(3, 4, 9, 64, 64, 1, 1)       # one chunk range, one tile
+    emu.check(3, 4, 33, 64, 72, 1, 2)      # CRNN conv4/5 geometry, ragged Cout tile, two splits
+    emu.check(2, 6, 10, 64, 64, 2, 2)      # dilation 2

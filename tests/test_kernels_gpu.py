@@ -597,3 +597,64 @@ def test_gemm_tn_row_count_not_a_vector_multiple(dtype):
     assert _rel_err(C[:NA], ref) < (2e-5 if dtype == torch.float32 else 2e-5)
     assert torch.equal(C[NA:].cpu(), torch.full((2, NB), 3.0)) and torch.equal(cs[NA:].cpu(), torch.full((2,), 5.0))
     assert _rel_err(cs[:NA], A[:, :NA].double().cpu().sum(0) + 5.0) < 2e-5
+
+
+@pytest.mark.parametrize("group", [0, 1, 2, 3, 4, 16])
+@pytest.mark.parametrize("P,NA,NB,splits", [(8448, 256, 512, 4), (8448, 256, 512, 7), (4096, 40, 136, 3), (33000, 128, 128, 16)])
+def test_gemm_tn_split_group_reduction_exact(group, P, NA, NB, splits):
+    """In-launch reduction of the TN GEMM kernel's split partials (TnArgs.grp: sc1 slabs + ticket, the last arriver sums; plain
+    read-modify-write when one group holds all the splits, atomics otherwise).  Integer operands: every partial sum is
+    exact, so C (accumulate semantics, starts at 1) and the column sums must EQUAL the float64 result for any grouping,
+    and a second launch (tickets reset by the first) must add the same amount again."""
+    from megreader_amd import _lib
+    lib = _lib.load()
+    _lib.ensure_tn_workspace(DEV)
+    g = torch.Generator().manual_seed(P + NA + group)
+    A = torch.randint(-3, 4, (P, NA), generator=g).float()
+    B = torch.randint(-3, 4, (P, NB), generator=g).float()
+    lda = (NA + 7) // 8 * 8
+    Ad = torch.zeros(P, lda).copy_(torch.nn.functional.pad(A, (0, lda - NA))).to(DEV, torch.bfloat16)
+    Bd = B.to(DEV, torch.bfloat16)
+    C = torch.ones(NA, NB, device=DEV)
+    cs = torch.zeros(NA, device=DEV)
+    oldg, olds = lib.mr_set_tn_group(group), lib.mr_set_tn_splits(splits)
+    try:
+        for _ in range(2):
+            call("mr_gemm_tn", 1, ptr(Ad), lda, ptr(Bd), NB, ptr(C), NB, P, NA, NB, 0, ptr(cs))
+        torch.cuda.synchronize()
+    finally:
+        lib.mr_set_tn_group(oldg)
+        lib.mr_set_tn_splits(olds)
+    ref = 1 + 2 * (A.double().t() @ B.double())
+    assert torch.equal(C.cpu().double(), ref), float((C.cpu().double() - ref).abs().max())
+    assert torch.equal(cs.cpu().double(), 2 * A.double().sum(0))
+
+
+def test_conv_wgrad_gemm_kernel_group_reduction_exact():
+    """Same through the conv wgrad entry for geometries the all-taps kernel does not take (2x2 head, strided 3x3, W = 64)."""
+    from megreader_amd import _lib
+    lib = _lib.load()
+    _lib.ensure_tn_workspace(DEV)
+    for (N, H, W, C, K, k, st, p) in [(16, 2, 34, 64, 64, 2, 1, 0), (8, 8, 32, 64, 128, 3, 2, 1), (4, 16, 64, 64, 128, 3, 1, 1)]:
+        Ho, Wo = (H + 2 * p - k) // st + 1, (W + 2 * p - k) // st + 1
+        g = torch.Generator().manual_seed(N + H)
+        x = torch.randint(-3, 4, (N, H, W, C), generator=g).float()
+        dy = torch.randint(-3, 4, (N, Ho, Wo, K), generator=g).float()
+        wref = torch.zeros(K, C, k, k, dtype=torch.float64, requires_grad=True)
+        TF.conv2d(x.permute(0, 3, 1, 2).double(), wref, None, st, p).backward(dy.permute(0, 3, 1, 2).double())
+        ref = wref.grad.permute(0, 2, 3, 1)
+        assert lib.mr_tn_taps_would_run(N, H, W, C, C, K, K, k, k, st, st, p, p, 1, 1, Ho, Wo) == 0
+        xd, dyd = x.to(DEV, torch.bfloat16), dy.to(DEV, torch.bfloat16)
+        for group in (0, 1, 2):
+            old = lib.mr_set_tn_group(group)
+            try:
+                gw = torch.zeros(K, k, k, C, device=DEV)
+                gb = torch.zeros(K, device=DEV)
+                tab = torch.empty(N * Ho * Wo, 2, dtype=torch.int32, device=DEV)
+                call("mr_conv2d_wgrad_tab", 1, ptr(dyd), ptr(xd), ptr(gw), ptr(gb),
+                     N, H, W, C, C, K, K, k, k, st, st, p, p, 1, 1, Ho, Wo, ptr(tab), 1)
+                torch.cuda.synchronize()
+            finally:
+                lib.mr_set_tn_group(old)
+            assert torch.equal(gw.cpu().double(), ref), (group, float((gw.cpu().double() - ref).abs().max()))
+            assert torch.equal(gb.cpu().double(), dy.double().sum((0, 1, 2)))

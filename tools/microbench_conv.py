@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--layers", default="")
     ap.add_argument("--tile", default="", help="force NT tile, e.g. 96x128")
     ap.add_argument("--variant", type=int, default=2, help="NT kernel: 2 direct-to-LDS, 1 register staged")
+    ap.add_argument("--tngroup", type=int, default=0, help="TN GEMM kernel split reduction: 0 auto, 1 atomics")
     ap.add_argument("--tnbuf", type=int, default=1, help="TN kernel staging through buffer resources (0/1)")
     ap.add_argument("--tnbig", type=int, default=0, help="big-tile TN kernel: 0 auto, -1 never, 1 always")
     ap.add_argument("--big", type=int, default=0, help="big-tile NT kernel: 0 auto, -1 never, 1 256x256, 2 288x256")
@@ -42,6 +43,7 @@ def main():
     _lib.load().mr_set_tn_abl(a.tnabl)
     _lib.load().mr_set_tn_big(a.tnbig)
     _lib.load().mr_set_tn_buf(a.tnbuf)
+    _lib.load().mr_set_tn_group(a.tngroup)
     if a.tile:
         bm, bn = [int(v) for v in a.tile.split("x")]
         assert _lib.load().mr_force_nt_tile(bm, bn) == 0
