@@ -178,6 +178,8 @@ int mr_sgd_step(float* p, const float* g, float* buf, long long n, float* hyper,
 /* doubles of reduction scratch mr_bn_fwd_train / mr_bn_bwd want for C channels (several accumulator copies: fewer
  * same-address atomics; the backward keeps 2*C f32 per-channel means behind them) */
 long long mr_bn_scratch_doubles(int C);
+/* 1 (default): training-mode BN folds its finalize kernels into the apply passes (C % 64 == 0); 0: separate launches */
+int mr_set_bn_fused(int on);
 int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* save_mean, float* save_rstd, double* sums, const void* residual,
                     int relu, long long P, int C, float eps, float momentum, long long* num_batches_tracked,

@@ -263,6 +263,142 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused "finalize + apply" passes (training forward and backward), C % 64 == 0.  The separate bn_finalize /
+// bn_bwd_finalize launches are 1-block kernels whose cost is pure launch latency (4.8 us each, 6 per CRNN step, 120 per
+// ResNet50-PPM step = 0.58 ms).  Here every workgroup owns a slab of 64 channels (blockIdx.y) and re-derives that slab's
+// statistics from the accumulator copies in its prologue (64 x 2 x ncopy doubles = 8 KB from L2), so the per-channel
+// arithmetic -- the same double-precision expressions as the finalize kernels, hence bit-identical outputs -- costs no
+// launch; the blockIdx.x == 0 workgroups also write what the finalize kernels wrote (saved mean / rstd, running
+// statistics, dgamma / dbeta).  Rows are strided over blockIdx.x; a wave reads 8 rows x 128 contiguous bytes (bf16).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_fused_kernel(
+    const T* __restrict__ x, T* __restrict__ y, const double* __restrict__ sums, int ncopy, float eps, float momentum,
+    float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ running_mean,
+    float* __restrict__ running_var, long long* __restrict__ num_batches_tracked, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const T* __restrict__ residual, int relu, int P, int C) {
+  constexpr int VEC = VecOf<T>::N, LANES = 64 / VEC, ROWS = 256 / LANES;
+  __shared__ float s_mean[64], s_rstd[64], s_gamma[64], s_beta[64];
+  const int cbase = blockIdx.y * 64;
+  if (threadIdx.x < 64) {
+    const int c = cbase + threadIdx.x;
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < ncopy; ++k) {
+      s1 += sums[(size_t)k * 2 * C + c];
+      s2 += sums[(size_t)k * 2 * C + C + c];
+    }
+    const double m = s1 / P;
+    double var = s2 / P - m * m;
+    if (var < 0) var = 0;
+    const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
+    s_mean[threadIdx.x] = mf;
+    s_rstd[threadIdx.x] = rf;
+    s_gamma[threadIdx.x] = gamma[c];
+    s_beta[threadIdx.x] = beta[c];
+    if (blockIdx.x == 0) {
+      if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+      save_mean[c] = mf;
+      save_rstd[c] = rf;
+      if (running_mean) {
+        const double unb = P > 1 ? var * ((double)P / (P - 1)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+      }
+    }
+  }
+  __syncthreads();
+  const int v = threadIdx.x % LANES, r0 = threadIdx.x / LANES;
+  const int cv = C / VEC;
+  float mu[VEC], rs[VEC], ga[VEC], be[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    mu[j] = s_mean[v * VEC + j];
+    rs[j] = s_rstd[v * VEC + j];
+    ga[j] = s_gamma[v * VEC + j];
+    be[j] = s_beta[v * VEC + j];
+  }
+  for (int p = blockIdx.x * ROWS + r0; p < P; p += gridDim.x * ROWS) {
+    const long long i = (long long)p * cv + blockIdx.y * LANES + v;
+    uint4 a = ((const uint4*)x)[i];
+    T* pa = (T*)&a;
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (residual) r = ((const uint4*)residual)[i];
+    const T* pr = (const T*)&r;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float val = (to_f32(pa[j]) - mu[j]) * rs[j] * ga[j] + be[j];
+      if (residual) val += to_f32(pr[j]);
+      if (relu) val = fmaxf(val, 0.f);
+      pa[j] = from_f32<T>(val);
+    }
+    ((uint4*)y)[i] = a;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(
+    const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const double* __restrict__ sums, int ncopy,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, T* __restrict__ dx, T* __restrict__ dres,
+    int relu, int P, int C) {
+  constexpr int VEC = VecOf<T>::N, LANES = 64 / VEC, ROWS = 256 / LANES;
+  __shared__ float s_mean[64], s_k[64], s_rstd[64], s_sb[64], s_sg[64];
+  const int cbase = blockIdx.y * 64;
+  if (threadIdx.x < 64) {
+    const int c = cbase + threadIdx.x;
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < ncopy; ++k) {
+      s1 += sums[(size_t)k * 2 * C + c];
+      s2 += sums[(size_t)k * 2 * C + C + c];
+    }
+    const float invP = 1.f / (float)P;
+    s_sb[threadIdx.x] = (float)s1 * invP;
+    s_sg[threadIdx.x] = (float)s2 * invP;
+    s_mean[threadIdx.x] = mean[c];
+    s_rstd[threadIdx.x] = rstd[c];
+    s_k[threadIdx.x] = gamma[c] * rstd[c];
+    if (blockIdx.x == 0) {
+      dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+      dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+    }
+  }
+  __syncthreads();
+  const int v = threadIdx.x % LANES, r0 = threadIdx.x / LANES;
+  const int cv = C / VEC;
+  float mu[VEC], rs[VEC], kk[VEC], sb[VEC], sg[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    mu[j] = s_mean[v * VEC + j];
+    rs[j] = s_rstd[v * VEC + j];
+    kk[j] = s_k[v * VEC + j];
+    sb[j] = s_sb[v * VEC + j];
+    sg[j] = s_sg[v * VEC + j];
+  }
+  for (int p = blockIdx.x * ROWS + r0; p < P; p += gridDim.x * ROWS) {
+    const long long i = (long long)p * cv + blockIdx.y * LANES + v;
+    uint4 g = ((const uint4*)dy)[i];
+    uint4 a = ((const uint4*)x)[i];
+    uint4 o = make_uint4(0, 0, 0, 0);
+    if (relu) o = ((const uint4*)y)[i];
+    T* pg = (T*)&g;
+    const T* pa = (const T*)&a;
+    const T* po = (const T*)&o;
+    uint4 out;
+    T* pout = (T*)&out;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float gv = to_f32(pg[j]);
+      if (relu && !(to_f32(po[j]) > 0.f)) gv = 0.f;
+      pg[j] = from_f32<T>(gv);
+      const float xh = (to_f32(pa[j]) - mu[j]) * rs[j];
+      pout[j] = from_f32<T>(kk[j] * (gv - sb[j] - xh * sg[j]));
+    }
+    ((uint4*)dx)[i] = out;
+    if (dres) ((uint4*)dres)[i] = g;
+  }
+}
+
 // eval-mode BN: y = (x - running_mean) / sqrt(running_var + eps) * gamma + beta
 __global__ void bn_eval_coeff_kernel(const float* __restrict__ rm, const float* __restrict__ rv, float eps,
                                      float* __restrict__ mean, float* __restrict__ rstd, int C) {
@@ -434,6 +570,16 @@ __global__ __launch_bounds__(256) void maxpool_bwd_fixed_kernel(const T* __restr
   ((uint4*)dx)[((long long)blockIdx.y * W + w) * cv + c] = out;
 }
 
+static int g_bn_fused = 1;   // 1: fold the finalize kernels into the apply passes (mr_set_bn_fused)
+// blocks along the rows of a fused apply pass: ~8 row groups per block, at most ~16 blocks per CU in total
+static inline int bn_fused_grid_x(long long P, int rows, int slabs) {
+  long long gx = (P + (long long)rows * 8 - 1) / ((long long)rows * 8);
+  const long long cap = 4096 / slabs > 1 ? 4096 / slabs : 1;
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  return (int)gx;
+}
+
 static inline int grid_for(long long n, int block, int max_blocks = 16384) {
   long long b = (n + block - 1) / block;
   if (b > max_blocks) b = max_blocks;
@@ -477,6 +623,14 @@ extern "C" {
 long long mr_bn_scratch_doubles(int C) { return 2ll * C * MR_BN_COPIES + C; }   // + [2C] f32 of per-channel means (bwd)
 
 
+// 1 (default): the training-mode passes fold bn_finalize / bn_bwd_finalize into their apply kernels (C % 64 == 0);
+// 0: separate finalize launches.  Returns the previous setting.
+int mr_set_bn_fused(int on) {
+  const int old = g_bn_fused;
+  if (on == 0 || on == 1) g_bn_fused = on;
+  return old;
+}
+
 int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* save_mean, float* save_rstd, double* sums, const void* residual,
                     int relu, long long P, int C, float eps, float momentum, long long* num_batches_tracked,
@@ -498,6 +652,16 @@ int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const
     const int splits = split_rows((int)P, C, rpb);
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(cdiv(C, 64), splits), dim3(256), 0, stream,
                                          (const T*)x, sums, (int)P, C, (long long)C, rpb));
+  }
+  if (g_bn_fused && C % 64 == 0) {   // finalize folded into the apply pass (bn_apply_fused_kernel)
+    const int rows = 256 / (64 / vec);
+    const dim3 grid(bn_fused_grid_x(P, rows, C / 64), C / 64);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_fused_kernel<T>), grid, dim3(256), 0, stream, (const T*)x, (T*)y,
+                                         (const double*)sums, ncopy, eps, momentum, save_mean, save_rstd, running_mean,
+                                         running_var, num_batches_tracked, gamma, beta, (const T*)residual, relu,
+                                         (int)P, C));
+    MR_CHECK_LAUNCH();
+    return MR_OK;
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const double*)sums, ncopy, (int)P, C,
                      eps, momentum, save_mean, save_rstd, running_mean, running_var, num_batches_tracked);
@@ -544,6 +708,15 @@ int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const flo
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(cdiv(C, 64), splits), dim3(256), 0, stream,
                                          (const T*)dy, (const T*)x, (const T*)y, save_mean, save_rstd, sums, relu,
                                          (int)P, C, rpb));
+  }
+  if (g_bn_fused && C % 64 == 0) {   // finalize folded into the apply pass (bn_bwd_apply_fused_kernel)
+    const int rows = 256 / (64 / vec);
+    const dim3 grid(bn_fused_grid_x(P, rows, C / 64), C / 64);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<T>), grid, dim3(256), 0, stream, (const T*)dy,
+                                         (const T*)x, (const T*)y, save_mean, save_rstd, gamma, (const double*)sums, ncopy,
+                                         dgamma, dbeta, accumulate, (T*)dx, (T*)dres, relu, (int)P, C));
+    MR_CHECK_LAUNCH();
+    return MR_OK;
   }
   float* sbg = (float*)(sums + (size_t)2 * C * MR_BN_COPIES);   // [2C] f32 behind the accumulator copies
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const double*)sums, ncopy, P, C,

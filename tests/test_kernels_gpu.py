@@ -658,3 +658,38 @@ def test_conv_wgrad_gemm_kernel_group_reduction_exact():
                 lib.mr_set_tn_group(old)
             assert torch.equal(gw.cpu().double(), ref), (group, float((gw.cpu().double() - ref).abs().max()))
             assert torch.equal(gb.cpu().double(), dy.double().sum((0, 1, 2)))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,C,H,W,relu,res", [(4, 64, 6, 9, True, False), (16, 256, 4, 33, True, False), (3, 512, 5, 7, False, True),
+                                              (8, 128, 8, 32, True, True), (2, 2048, 2, 3, False, False)])
+def test_batchnorm_fused_finalize_bit_identical(dtype, N, C, H, W, relu, res):
+    """Training-mode BN with the finalize kernels folded into the apply passes (mr_set_bn_fused(1), the default) against
+    the separate-launch path on the same inputs: outputs, saved / running statistics, step counter, dx, the residual
+    gradient, dgamma and dbeta must be bit-identical (same double-precision per-channel expressions, same f32 maps)."""
+    from megreader_amd._lib import load
+    lib = load()
+    mr.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(C + H)
+    x0 = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+    r0 = torch.randn(N, C, H, W, generator=g).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last) if res else None
+    gy = torch.randn(N, C, H, W, generator=g).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+    w0, b0 = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    outs = []
+    for mode in (1, 0):
+        old = lib.mr_set_bn_fused(mode)
+        try:
+            xd = x0.clone().requires_grad_(True)
+            rd = r0.clone().requires_grad_(True) if res else None
+            gamma, beta = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+            y = F.batch_norm(xd, gamma, beta, rm, rv, True, 0.1, 1e-5, relu=relu, residual=rd, num_batches_tracked=nbt)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            outs.append([y.detach(), rm, rv, nbt, xd.grad, gamma.grad, beta.grad] + ([rd.grad] if res else []))
+        finally:
+            lib.mr_set_bn_fused(old)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert int(outs[0][3]) == 1
