@@ -63,6 +63,7 @@ int mr_set_tn_taps(int mode);
 int mr_set_tn_taps_workspace(void* ws, long long bytes);
 int mr_set_tn_taps_group(int g);    /* tuning: 0 automatic, 1 atomics only, > 1 forced group size */
 int mr_set_tn_group(int g);         /* same for the 128x128 TN GEMM kernel (uses the same workspace) */
+int mr_set_tn_taps_fin(int on);     /* 1: group sums added into dw by a finalize launch (measured equal), 0 (default): leaders' atomics */
 int mr_set_tn_taps_w8(int on);      /* 1: 8-wave workgroup variant (one per CU, half the partial tiles) */
 int mr_set_tn_taps_abl(int mask);   /* host only, timing only: ablation mask of the all-taps kernel (wrong results) */
 /* host only: 1 when mr_conv2d_wgrad_tab (bf16, non-NULL row table) would run the all-taps kernel for this geometry

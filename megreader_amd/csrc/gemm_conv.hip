@@ -540,6 +540,9 @@ int mr_set_tn_taps_group(int g) { return taps_set_group(g); }
 // same for the 128x128 TN GEMM kernel (conv wgrad of the other geometries, Linear / LSTM weight gradients)
 int mr_set_tn_group(int g) { const int old = g_tn_group; if (g >= 0) g_tn_group = g; return old; }
 
+// 1 (opt-in, measured equal) = the all-taps kernel's group sums are added into dw by a second, tiny launch instead of the leaders' atomics
+int mr_set_tn_taps_fin(int on) { return taps_set_fin(on); }
+
 // 1 = 8-wave workgroup variant of the all-taps kernel (one per CU, half the partial tiles); returns the previous setting
 int mr_set_tn_taps_w8(int on) { return taps_set_w8(on); }
 

@@ -46,6 +46,11 @@ struct TapArgs {
   // the only one that issues the f32 atomics.  ws = [4096 int tickets (zero between launches)][gridDim slabs x 147456 B].
   int grp;
   void* ws;
+  // fin != 0 (needs grp > 1): the group leaders do NOT add into dw; they leave the group's sum in the slab of the group's
+  // first split and taps_finalize_kernel (a second, tiny launch over ALL the CUs) adds the groups' slabs into dw with plain
+  // read-modify-writes.  Why: the leaders' f32 atomics are issued per lane (~1 per clock per CU) and cost ~20 us of tail
+  // during which the other CUs idle.
+  int fin;
 };
 
 constexpr int TAPS_TICKETS = 4096;
@@ -286,10 +291,10 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void igemm_tn_taps_kern
     const int nsplits = total / ntiles;
     const int g0 = (split / a.grp) * a.grp;
     const int gsize = min(a.grp, nsplits - g0);
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((char*)a.ws + TAPS_TICKETS * 4, (short)0, 0x7fffffff,
+                                                       0x00020000);
     if (gsize > 1) {
       int* tickets = (int*)a.ws;
-      const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((char*)a.ws + TAPS_TICKETS * 4, (short)0, 0x7fffffff,
-                                                         0x00020000);
       const int so = vb * (int)TAPS_SLAB_BYTES;
       if (worker) {
 #pragma unroll
@@ -319,6 +324,18 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void igemm_tn_taps_kern
             acc[i][t] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, sj + (i * 9 + t) * 4096, 16));
       }
     }
+    if (a.fin) {   // leave the group's sum in the slab of its first split; taps_finalize_kernel adds it into dw
+      if (worker) {
+        const int sg = (g0 * ntiles + tile) * (int)TAPS_SLAB_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][t]), rs, tid * 16,
+                                                   sg + (i * 9 + t) * 4096, 16);
+      }
+      return;
+    }
   }
   if (!worker) return;
   if (ABL & 1024) return;   // timing only: no final atomics (group phase only)
@@ -337,6 +354,27 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void igemm_tn_taps_kern
           else atomicAdd(a.C + (long long)row * a.ldc + col, acc[i][t][q]);
         }
       }
+  }
+}
+
+// dw += sum over the groups of their slab (see TapArgs.fin).  One workgroup per (tile, accumulator tile k = i*9 + t);
+// thread tid of the slab order = thread tid of the producing workgroup, so its f32x4 is rows lg*4 .. +3 of column
+// (wave*16 + l15) of the 16 x 64 block (i, t).
+static __global__ __launch_bounds__(256) void taps_finalize_kernel(const f32x4* __restrict__ slabs, float* __restrict__ C,
+                                                                  int ntiles, int tiles_b, int nsplits, int grp, int NA,
+                                                                  int Cg, int ldc) {
+  const int tile = blockIdx.x / 36, k = blockIdx.x - tile * 36;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  for (int g0 = 0; g0 < nsplits; g0 += grp)
+    sum += slabs[((long long)g0 * ntiles + tile) * (36 * 256) + k * 256 + tid];
+  const int tile_b = tile % tiles_b, tile_a = tile / tiles_b;
+  const int i = k / 9, t = k - i * 9;
+  const int col = t * Cg + tile_b * 64 + wave * 16 + l15;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = tile_a * 64 + i * 16 + lg * 4 + q;
+    if (row < NA) C[(long long)row * ldc + col] += sum[q];
   }
 }
 
@@ -408,6 +446,11 @@ int taps_set_group(int g) { const int old = g_taps_grp; if (g >= 0) g_taps_grp =
 static int g_taps_w8 = 0;
 int taps_set_w8(int on) { const int old = g_taps_w8; if (on == 0 || on == 1) g_taps_w8 = on; return old; }
 
+// 1: finalize launch instead of the group leaders' atomics (TapArgs.fin).  Opt-in: measured equal (conv2..5 wgrad 445 vs 445 us
+// per step at group 4, 436 at group 2: the second launch + its 19 MB of slab reads cost what the leaders' atomics cost)
+static int g_taps_fin = 0;
+int taps_set_fin(int on) { const int old = g_taps_fin; if (on == 0 || on == 1) g_taps_fin = on; return old; }
+
 static int g_taps_abl = 0;
 int taps_set_abl(int mask) { const int old = g_taps_abl; g_taps_abl = mask; return old; }
 
@@ -459,6 +502,7 @@ int launch_tn_taps(const TapsProblem& p, int splits_override, hipStream_t stream
         (long long)tiles * cdiv(splits, want) <= TAPS_TICKETS)
       a.grp = want;
   }
+  a.fin = (a.grp > 1 && g_taps_fin) ? 1 : 0;
   const int lds = w8 ? 147456 : (4 + 4) * 64 * 128 + 4096;
   const int threads = w8 ? 512 : 256;
   static bool attr_set[2] = {false, false};
@@ -471,6 +515,7 @@ int launch_tn_taps(const TapsProblem& p, int splits_override, hipStream_t stream
     attr_set[w8] = true;
   }
   if (g_taps_abl && !w8) {
+    a.fin = 0;
 #define MR_TAPS_ABL(V_) case V_: { auto k2 = igemm_tn_taps_kernel<2, 1, V_>; \
       (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
       hipLaunchKernelGGL(k2, dim3(tiles * splits), dim3(256), lds, stream, a); } break;
@@ -486,6 +531,12 @@ int launch_tn_taps(const TapsProblem& p, int splits_override, hipStream_t stream
   else
     hipLaunchKernelGGL((igemm_tn_taps_kernel<2, 1, 0, false>), dim3(tiles * splits), dim3(threads), lds, stream, a);
   MR_CHECK_LAUNCH();
+  if (a.fin) {
+    hipLaunchKernelGGL(taps_finalize_kernel, dim3(tiles * 36), dim3(256), 0, stream,
+                       (const f32x4*)((const char*)a.ws + TAPS_TICKETS * 4), a.C, tiles, p.Cin / 64, splits, a.grp, a.NA,
+                       a.Cg, a.ldc);
+    MR_CHECK_LAUNCH();
+  }
   return MR_OK;
 }
 

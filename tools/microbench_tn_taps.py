@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--sweep", type=int, default=1)
     ap.add_argument("--layers", default="")
+    ap.add_argument("--fin", type=int, default=0, help="1: finalize launch instead of the leaders' atomics")
     ap.add_argument("--w8", type=int, default=0, help="1: 8-wave workgroup variant")
     ap.add_argument("--group", type=int, default=0, help="group size of the in-launch split reduction (0 auto, 1 atomics)")
     a = ap.parse_args()
@@ -48,6 +49,7 @@ def main():
     F.ensure_tn_taps_workspace("cuda")
     lib.mr_set_tn_taps_group(a.group)
     lib.mr_set_tn_taps_w8(a.w8)
+    lib.mr_set_tn_taps_fin(a.fin)
     total = {0: 0.0, 1: 0.0}
     for name, H, W, C, K in LAYERS:
         if a.layers and name not in a.layers.split(","):
