@@ -198,12 +198,25 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void igemm_tn_taps_kern
     *(__attribute__((address_space(3))) u32x4*)(lds_byte_t*)(uintptr_t)(unsigned)(sM + e * 32) = mt;
     *(__attribute__((address_space(3))) u32x4*)(lds_byte_t*)(uintptr_t)(unsigned)(sM + e * 32 + 16) = mb;
   }
+  {   // all the prologue's table entries first (one L2 round trip), then its LDS-DMAs
+    int pe[2 * HALO + 1][2];
 #pragma unroll
-  for (int cc = -HALO; cc <= HALO; ++cc) {
-    fetch_entries(c_begin + cc);
-    stage(c_begin + cc, cc >= 0 && c_begin + cc < c_end);
+    for (int cc = -HALO; cc <= HALO; ++cc) {
+      fetch_entries(c_begin + cc);
+      pe[cc + HALO][0] = ent[0];
+      pe[cc + HALO][1] = ent[1];
+    }
+    fetch_entries(c_begin + HALO + 1);
+    const int e0 = ent[0], e1 = ent[1];
+#pragma unroll
+    for (int cc = -HALO; cc <= HALO; ++cc) {
+      ent[0] = pe[cc + HALO][0];
+      ent[1] = pe[cc + HALO][1];
+      stage(c_begin + cc, cc >= 0 && c_begin + cc < c_end);
+    }
+    ent[0] = e0;
+    ent[1] = e1;
   }
-  fetch_entries(c_begin + HALO + 1);
 
   for (int c = c_begin; c < c_end; ++c) {
     if (!(ABL & 16)) __syncthreads();
