@@ -39,9 +39,14 @@ __device__ __forceinline__ bool conv_src(const ConvGeom& g, int hm, int wm, int 
     int hn = hm + g.ph - r * g.dh;
     int wn = wm + g.pw - s * g.dw;
     if (hn < 0 || wn < 0) return false;
-    hi = hn / g.sh;
-    wi = wn / g.sw;
-    if (hi * g.sh != hn || wi * g.sw != wn) return false;
+    if (g.sh == 1 && g.sw == 1) {   // uniform fast path: every stride-1 layer skips two runtime integer divisions per
+      hi = hn;                      // (row, tap) of the tile prologue (18 per staged row for a 3x3 filter)
+      wi = wn;
+    } else {
+      hi = hn / g.sh;
+      wi = wn / g.sw;
+      if (hi * g.sh != hn || wi * g.sw != wn) return false;
+    }
   }
   return (unsigned)hi < (unsigned)g.Hg && (unsigned)wi < (unsigned)g.Wg;
 }
