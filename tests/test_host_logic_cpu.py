@@ -230,3 +230,35 @@ def test_tn_taps_kernel_index_arithmetic_emulation():
     emu.check(3, 4, 9, 64, 64, 1, 1)       # one chunk range, one tile
     emu.check(3, 4, 33, 64, 72, 1, 2)      # CRNN conv4/5 geometry, ragged Cout tile, two splits
     emu.check(2, 6, 10, 64, 64, 2, 2)      # dilation 2
+
+
+def test_kernel_choice_host_logic():
+    """Host-side dispatch rules of the conv kernels (no GPU needed: the queries launch nothing; 256 CUs assumed when no device
+    is visible): the 272x256 one-round tile for 33792 x 512, the 288x128 tile for the badly quantised N = 256 dgrad, head / tail
+    where neither fits, and the all-taps wgrad eligibility (3x3, stride 1, padding == dilation, Cin % 64 == 0, W <= 62)."""
+    from megreader_amd import _lib
+    lib = _lib.load()
+    code = lib.mr_nt_kernel_code
+    assert code(1, 65536, 256, 2304, 256) == 256256          # conv3 fwd: exactly one round of 256x256 tiles
+    assert code(1, 33792, 512, 4608, 512) == 272256          # conv5: 250 tiles of 272 rows, one round
+    assert code(1, 33792, 256, 4608, 512) == 288128          # conv4 dgrad: 236 tiles of 288x128
+    assert code(1, 70000, 256, 576, 0) == 256257             # head (one round) + 4-wave tail
+    assert code(1, 262144, 128, 576, 64) == 128128           # conv1 fwd: 4-wave tile
+    assert code(0, 33792, 512, 4608, 512) // 1000 <= 128     # f32: never the bf16 big tiles
+    run = lib.mr_tn_taps_would_run
+    old = lib.mr_set_tn_taps(1)
+    try:
+        #          N   H   W  Cin ldx Cout lddy R  S sh sw ph pw dh dw Ho  Wo
+        assert run(256, 4, 33, 512, 512, 512, 512, 3, 3, 1, 1, 1, 1, 1, 1, 4, 33) == 1      # conv5
+        assert run(256, 8, 32, 128, 128, 256, 256, 3, 3, 1, 1, 1, 1, 1, 1, 8, 32) == 1      # conv2
+        assert run(256, 16, 64, 64, 64, 128, 128, 3, 3, 1, 1, 1, 1, 1, 1, 16, 64) == 0      # conv1: W = 64 > 62
+        assert run(256, 2, 34, 512, 512, 512, 512, 2, 2, 1, 1, 0, 0, 1, 1, 1, 33) == 0      # conv6: 2x2
+        assert run(64, 8, 32, 64, 64, 128, 128, 3, 3, 2, 2, 1, 1, 1, 1, 4, 16) == 0         # strided
+        assert run(64, 8, 32, 48, 48, 128, 128, 3, 3, 1, 1, 1, 1, 1, 1, 8, 32) == 0         # Cin % 64 != 0
+        assert run(64, 8, 24, 64, 64, 64, 64, 3, 3, 1, 1, 2, 2, 2, 2, 8, 24) == 1           # dilation 2 == padding 2
+        assert run(64, 8, 32, 64, 64, 64, 64, 3, 3, 1, 1, 2, 2, 2, 2, 8, 32) == 0           # ... but 2*(32+2)+2 > 64 rows of halo
+        assert run(64, 8, 32, 64, 64, 64, 64, 3, 3, 1, 1, 1, 1, 2, 2, 6, 30) == 0           # padding != dilation
+        lib.mr_set_tn_taps(0)
+        assert run(256, 4, 33, 512, 512, 512, 512, 3, 3, 1, 1, 1, 1, 1, 1, 4, 33) == 0
+    finally:
+        lib.mr_set_tn_taps(old)
