@@ -120,11 +120,51 @@ def modulated_deform_conv_cuda_backward(input, weight, bias, ones, offset, mask,
         grad_bias.add_(gb.to(grad_bias.dtype))
 
 
-def _v1(*a, **k):
-    raise NotImplementedError("deform_conv_cuda v1 entry points: use megreader_amd.assets.ops.dcn.deform_conv "
-                              "(DCN v1 runs on the v2 kernels with a mask of ones)")
+# ---------------------------------------------------------------------------------------------------------------------
+# DCN v1 entry points (deform_conv_cuda.cpp:151-156,258-264,374-381; called from functions/deform_conv.py:46-51,70-86):
+# the v2 kernels with a mask of ones (same flat offset indexing and validity rule, deform_conv_cuda_kernel.cu:254-263 vs
+# 617).  NOTE the reference's argument order: kW, kH, dW, dH, padW, padH, dilationW, dilationH (width first).
+# ---------------------------------------------------------------------------------------------------------------------
+def _v1_ones(offset, kh, kw):
+    N, _, Ho, Wo = offset.shape
+    return torch.ones((N, kh * kw, Ho, Wo), dtype=torch.float32, device=offset.device)
 
 
-deform_conv_forward_cuda = _v1
-deform_conv_backward_input_cuda = _v1
-deform_conv_backward_parameters_cuda = _v1
+def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH, dilationW,
+                             dilationH, group, deformable_group, im2col_step):
+    """output <- deformable convolution of `input` (no bias); `output` is allocated by the caller and written in place."""
+    modulated_deform_conv_cuda_forward(input, weight, None, ones, offset, _v1_ones(offset, kH, kW), output, columns, kH, kW,
+                                       dH, dW, padH, padW, dilationH, dilationW, group, deformable_group, False)
+    return 1
+
+
+def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH, dW, dH, padW,
+                                    padH, dilationW, dilationH, group, deformable_group, im2col_step):
+    """gradInput / gradOffset (caller-allocated, zero-initialised: functions/deform_conv.py:62-63) <- the data and offset
+    gradients."""
+    gw = torch.zeros_like(weight, dtype=torch.float32)
+    gm = torch.zeros((offset.shape[0], kH * kW, offset.shape[2], offset.shape[3]), dtype=torch.float32, device=offset.device)
+    gi = torch.zeros_like(gradInput)
+    go = torch.zeros_like(gradOffset)
+    modulated_deform_conv_cuda_backward(input, weight, None, None, offset, _v1_ones(offset, kH, kW), columns, gi, gw, None, go,
+                                        gm, gradOutput, kH, kW, dH, dW, padH, padW, dilationH, dilationW, group,
+                                        deformable_group, False)
+    gradInput.copy_(gi)
+    gradOffset.copy_(go)
+    return 1
+
+
+def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, columns, ones, kW, kH, dW, dH, padW, padH,
+                                         dilationW, dilationH, group, deformable_group, scale, im2col_step):
+    """gradWeight += scale * weight gradient (deform_conv_cuda.cpp:466-470 accumulates with `addmm_`).  The weight values
+    do not enter the weight gradient, so a zero weight of the right shape feeds the shared backward call."""
+    w0 = torch.zeros_like(gradWeight, dtype=torch.float32).contiguous()
+    gw = torch.zeros_like(w0)
+    gi = torch.zeros_like(input, dtype=torch.float32)
+    go = torch.zeros_like(offset, dtype=torch.float32)
+    gm = torch.zeros((offset.shape[0], kH * kW, offset.shape[2], offset.shape[3]), dtype=torch.float32, device=offset.device)
+    modulated_deform_conv_cuda_backward(input, w0, None, None, offset, _v1_ones(offset, kH, kW), columns, gi, gw, None, go, gm,
+                                        gradOutput, kH, kW, dH, dW, padH, padW, dilationH, dilationW, group,
+                                        deformable_group, False)
+    gradWeight.add_((gw * float(scale)).to(gradWeight.dtype))
+    return 1

@@ -194,6 +194,41 @@ def test_dcn_v1_vs_oracle(dtype):
     assert m(xd.detach(), offd.detach()).shape == (N, Co, H, W)
 
 
+def test_dcn_v1_extension_entry_points_vs_oracle():
+    """`deform_conv_cuda.deform_conv_forward_cuda / _backward_input_cuda / _backward_parameters_cuda`
+    (src/deform_conv_cuda.cpp:151-156,258-264,374-381) called exactly as the reference's DeformConvFunction does
+    (assets/ops/dcn/functions/deform_conv.py:36-89: caller-allocated output, zeroed gradInput / gradOffset / gradWeight,
+    width-first kW, kH, dW, dH, padW, padH, dilationW, dilationH argument order, scale = 1, im2col_step)."""
+    from megreader_amd.assets.ops.dcn import deform_conv_cuda as ext
+    mr.set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(11)
+    N, C, Co, H, W, stride, pad, dil = 2, 16, 24, 9, 8, 1, 1, 1
+    x = torch.randn(N, C, H, W, generator=g)
+    off = torch.floor(torch.randn(N, 18, H, W, generator=g) * 1.5) + 0.25 + 0.5 * torch.rand(N, 18, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) * 0.2
+    gy = torch.randn(N, Co, H, W, generator=g)
+    xr, offr, wr = x.double().requires_grad_(True), off.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = modulated_deform_conv2d(xr, offr, torch.ones(N, 9, H, W, dtype=torch.float64), wr, None, stride, pad, dil)
+    yr.backward(gy.double())
+    input, offset, weight, grad_output = x.to(DEV), off.to(DEV), w.to(DEV), gy.to(DEV)
+    output = input.new_empty((N, Co, H, W))
+    bufs = [input.new_empty(0), input.new_empty(0)]
+    step = N
+    assert ext.deform_conv_forward_cuda(input, weight, offset, output, bufs[0], bufs[1], weight.size(3), weight.size(2), stride,
+                                        stride, pad, pad, dil, dil, 1, 1, step) == 1
+    grad_input, grad_offset = torch.zeros_like(input), torch.zeros_like(offset)
+    ext.deform_conv_backward_input_cuda(input, offset, grad_output, grad_input, grad_offset, weight, bufs[0], weight.size(3),
+                                        weight.size(2), stride, stride, pad, pad, dil, dil, 1, 1, step)
+    grad_weight = torch.zeros_like(weight)
+    ext.deform_conv_backward_parameters_cuda(input, offset, grad_output, grad_weight, bufs[0], bufs[1], weight.size(3),
+                                             weight.size(2), stride, stride, pad, pad, dil, dil, 1, 1, 1, step)
+    ext.deform_conv_backward_parameters_cuda(input, offset, grad_output, grad_weight, bufs[0], bufs[1], weight.size(3),
+                                             weight.size(2), stride, stride, pad, pad, dil, dil, 1, 1, 0.5, step)   # accumulates
+    assert _rel(output, yr) < 2e-5
+    assert _rel(grad_input, xr.grad) < 1e-4 and _rel(grad_offset, offr.grad) < 1e-4
+    assert _rel(grad_weight, 1.5 * wr.grad) < 1e-4
+
+
 @pytest.mark.parametrize("case", CASES[4:])
 def test_round2_backward_kernels(case):
     """The opt-in round-2 backward kernels (8-lane vectorised coordinate gradient, LDS-tiled col2im; measured slower, kept
