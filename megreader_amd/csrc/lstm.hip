@@ -262,12 +262,14 @@ long long mr_lstm_ws_bytes(int dtype, int T, int N, int H) {
 
 // Recurrent part of the forward pass (input projection done by mr_gemm_nt beforehand).
 // ws / ws_bytes: exchange workspace of the persistent kernel (mr_lstm_ws_bytes; zeroed by the call itself) or
-// null / 0 for the per-step launches.
+// null / 0 for the per-step launches.  ws_bytes < 0: the workspace is |ws_bytes| long and the caller hands it over ALREADY
+// ZEROED (a slice of a buffer it zeroes once per training step): the per-call memset (one launch of ~5 us, four per CRNN
+// step) is skipped.
 int mr_lstm_fwd(int dtype, const void* xproj, const void* whh, void* out, float* cbuf, void* gates, int T, int N,
                 int H, void* ws, long long ws_bytes, hipStream_t stream) {
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(T > 0 && N > 0 && H > 0 && H % vec == 0, "mr_lstm_fwd: bad shape T=%d N=%d H=%d", T, N, H);
-  if (ws && ws_bytes > 0 && g_lstm_persist && lstm_persist_ok(dtype, T, N, H))
+  if (ws && ws_bytes != 0 && g_lstm_persist && lstm_persist_ok(dtype, T, N, H))
     return lstm_fwd_persist(xproj, whh, out, cbuf, gates, T, N, ws, ws_bytes, stream);
   if (dtype == MR_F32) return lstm_fwd_impl<float>(xproj, whh, out, cbuf, gates, T, N, H, stream);
   if (dtype == MR_BF16) return lstm_fwd_impl<bf16_t>(xproj, whh, out, cbuf, gates, T, N, H, stream);
@@ -281,7 +283,7 @@ int mr_lstm_bwd(int dtype, const void* dout, const void* whhT, const float* cbuf
                 int N, int H, void* ws, long long ws_bytes, hipStream_t stream) {
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(T > 0 && N > 0 && H > 0 && H % vec == 0 && H % 4 == 0, "mr_lstm_bwd: bad shape T=%d N=%d H=%d", T, N, H);
-  if (ws && ws_bytes > 0 && g_lstm_persist && lstm_persist_ok(dtype, T, N, H))
+  if (ws && ws_bytes != 0 && g_lstm_persist && lstm_persist_ok(dtype, T, N, H))
     return lstm_bwd_persist(dout, whhT, cbuf, gates, T, N, ws, ws_bytes, stream);
   if (dtype == MR_F32) return lstm_bwd_impl<float>(dout, whhT, cbuf, gates, dc, T, N, H, stream);
   if (dtype == MR_BF16) return lstm_bwd_impl<bf16_t>(dout, whhT, cbuf, gates, dc, T, N, H, stream);

@@ -464,11 +464,13 @@ bool lstm_persist_ok(int dtype, int T, int N, int H) {
 
 int lstm_fwd_persist(const void* xproj, const void* whh, void* out, float* cbuf, void* gates, int T, int N,
                      void* ws, long long ws_bytes, hipStream_t stream) {
+  const bool prezeroed = ws_bytes < 0;   // the caller zeroed it (see mr_lstm_fwd)
+  if (prezeroed) ws_bytes = -ws_bytes;
   MR_CHECK_ARG(ws_bytes >= persist_ws_bytes(N), "mr_lstm_fwd: workspace too small (%lld < %lld)", ws_bytes,
                persist_ws_bytes(N));
   const int nbg = cdiv(N, PR);
   const long long xbytes = persist_ws_bytes(N) - 256 - persist_hello_bytes(N), hbytes = persist_hello_bytes(N);
-  if (hipMemsetAsync(ws, 0, (size_t)persist_ws_bytes(N), stream) != hipSuccess) {
+  if (!prezeroed && hipMemsetAsync(ws, 0, (size_t)persist_ws_bytes(N), stream) != hipSuccess) {
     set_error("mr_lstm_fwd: memset of the exchange buffer failed");
     return MR_ERR_LAUNCH;
   }
@@ -483,11 +485,13 @@ void lstm_set_bwd_debug(float*) {}   // debug hook retired with the fix of the b
 
 int lstm_bwd_persist(const void* dout, const void* whhT, const float* cbuf, void* gates, int T, int N, void* ws,
                      long long ws_bytes, hipStream_t stream) {
+  const bool prezeroed = ws_bytes < 0;   // the caller zeroed it (see mr_lstm_fwd)
+  if (prezeroed) ws_bytes = -ws_bytes;
   MR_CHECK_ARG(ws_bytes >= persist_ws_bytes(N), "mr_lstm_bwd: workspace too small (%lld < %lld)", ws_bytes,
                persist_ws_bytes(N));
   const int nbg = cdiv(N, PR);
   const long long xbytes = persist_ws_bytes(N) - 256 - persist_hello_bytes(N), hbytes = persist_hello_bytes(N);
-  if (hipMemsetAsync(ws, 0, (size_t)persist_ws_bytes(N), stream) != hipSuccess) {
+  if (!prezeroed && hipMemsetAsync(ws, 0, (size_t)persist_ws_bytes(N), stream) != hipSuccess) {
     set_error("mr_lstm_bwd: memset of the exchange buffer failed");
     return MR_ERR_LAUNCH;
   }

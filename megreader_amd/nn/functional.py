@@ -67,7 +67,8 @@ class ZeroArena(object):
     are handed out once per zeroing by a bump pointer; `reset()` -- called by the fused optimizers' `zero_grad()` --
     re-zeroes the used prefix with ONE fill and rewinds.  When the arena is exhausted (nobody calls reset: eval
     loops, foreign optimizers) `take` returns None and the caller falls back to its own memset."""
-    SIZE = 1 << 22  # doubles (32 MB: ResNet-50 takes ~34 doubles per BN channel per step, ~1 M)
+    SIZE = 1 << 23  # doubles (64 MB: ResNet-50 takes ~34 doubles per BN channel per step, ~1 M; the four persistent-LSTM
+                    # exchange rings of a CRNN step 3.2 M)
     arenas = {}
 
     def __init__(self, device):
@@ -700,18 +701,25 @@ LSTM_LOCAL = None    # ... and this one to a list of word 1 (workgroups that fou
 
 
 def _lstm_workspace(dt, T, N, H, dev):
-    """Exchange buffer of the persistent (one launch per layer and pass) recurrence, or None when the library runs one
-    launch per step for this problem (mr_lstm_ws_bytes == 0).  Allocated per call from torch's caching allocator --
-    inside a hipGraph capture it belongs to the graph's pool; the C call zeroes it (memset node) before the kernel."""
+    """(exchange buffer, size argument) of the persistent (one launch per layer and pass) recurrence, or (None, 0) when the
+    library runs one launch per step for this problem (mr_lstm_ws_bytes == 0).  The buffer has to be zero at launch: it comes
+    from the pre-zeroed arena (re-zeroed once per step by the fused optimizers' zero_grad; size passed NEGATIVE = "already
+    zeroed") or, when the arena is exhausted, from torch's allocator (the C call then zeroes it with its own memset node)."""
     nbytes = load().mr_lstm_ws_bytes(dt, T, N, H)
     if nbytes <= 0:
-        return None
-    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        return None, 0
+    size = nbytes
+    arena = ZeroArena.take(dev, (nbytes + 7) // 8)
+    if arena is not None:
+        ws = arena.view(torch.uint8)[:nbytes]
+        size = -nbytes
+    else:
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     if LSTM_STATUS is not None:
         LSTM_STATUS.append(ws[nbytes - 256:nbytes - 252])
     if LSTM_LOCAL is not None:
         LSTM_LOCAL.append(ws[nbytes - 252:nbytes - 248])
-    return ws
+    return ws, size
 
 
 class BiLSTMFn(Function):
@@ -756,9 +764,8 @@ class BiLSTMFn(Function):
         out = torch.empty((T, N, 2 * H), dtype=dtype, device=dev)
         cbuf = torch.empty((T, N, 2 * H), dtype=torch.float32, device=dev)
         gates = torch.empty((T, N, 8 * H), dtype=dtype, device=dev)
-        ws = _lstm_workspace(dt, T, N, H, dev)
-        call("mr_lstm_fwd", dt, ptr(xproj), ptr(whh), ptr(out), ptr(cbuf), ptr(gates), T, N, H, ptr(ws),
-             0 if ws is None else ws.numel())
+        ws, ws_size = _lstm_workspace(dt, T, N, H, dev)
+        call("mr_lstm_fwd", dt, ptr(xproj), ptr(whh), ptr(out), ptr(cbuf), ptr(gates), T, N, H, ptr(ws), ws_size)
         ctx.save_for_backward(x, wcat_t, whh_t, out, cbuf, gates)
         ctx.params = sources
         ctx.dims = (T, N, I, H)
@@ -775,11 +782,10 @@ class BiLSTMFn(Function):
         dev = gout.device
         if gout.dtype != dtype or not gout.is_contiguous():
             gout = gout.to(dtype).contiguous()
-        ws = _lstm_workspace(dt, T, N, H, dev)
+        ws, ws_size = _lstm_workspace(dt, T, N, H, dev)
         dc = torch.empty((N, 2 * H), dtype=torch.float32, device=dev) if ws is None else None
         # NOTE: `gates` is rewritten in place with the pre-activation gradients (single backward pass only)
-        call("mr_lstm_bwd", dt, ptr(gout), ptr(whh_t), ptr(cbuf), ptr(gates), ptr(dc), T, N, H, ptr(ws),
-             0 if ws is None else ws.numel())
+        call("mr_lstm_bwd", dt, ptr(gout), ptr(whh_t), ptr(cbuf), ptr(gates), ptr(dc), T, N, H, ptr(ws), ws_size)
         dgates = gates
         sinks = [grad_sink(p, tuple(p.shape)) for p in ctx.params]
         use_sinks = all(s is not None for s in sinks)
