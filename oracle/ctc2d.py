@@ -9,10 +9,16 @@ Follows ops/ctc_2d/csrc/cuda/ctc2d_cuda_kernel.cu:
              (exp(lp) - exp(G + nll - lp)) * grad_out  -- NOT d nll / d lp  
 Caller contract: decoders/ctc_decoder2d.py:37-51 (lp = log(max(mask*classify, tiny)) laid out [W, H, N, C]).
 
-PARITY STATUS: the reference has no CPU implementation and no tests of this op ("parity unpinned" by the reference);
-this restatement is anchored by (tests/test_oracle_ctc2d.py): H = 1 == torch.nn.functional.ctc_loss; agreement
-with the reference's own pure-python `decoders/ctc_loss2d.py::CTCLoss2D` in its valid (NLL <~ 80) regime, captured
-as golden vectors by oracle/gen_golden.py; sum over (h, s) of exp(alpha+beta-lp+nll) == 1 for every t.
+PARITY STATUS: PINNED (forward and gradient) to the reference's own differentiable pure-python implementation
+`decoders/ctc_loss2d.py::CTCLoss2D` in its valid (NLL <~ 80) regime -- oracle/gen_golden.py::ctc2d_fixture runs it on a
+peaked batch and refuses to write tests/golden/ctc2d_golden.pt unless (a) nll agrees to 2e-5 (f32 class) and (b) the
+gradient convention agrees: autograd of the python class w.r.t. log-classify is -occupancy, and
+exp(lp) - oracle.grad == occupancy to 1e-6 (float64) wherever the oracle's gradient is non-zero, with the oracle
+exactly 0 wherever the reference occupancy is 0 (tests/test_oracle_ctc2d.py::test_gradient_pinned_to_reference_...).
+What the python class cannot pin (it has no such term): the additive exp(lp) on extended-target classes and the
+"-inf -> 0" rule are the CUDA collect kernel's (ctc2d_cuda_kernel.cu:498-515), restated from the source.
+Further anchors: H = 1 == torch.nn.functional.ctc_loss; sum over (h, s) of exp(alpha+beta-lp+nll) == 1 for every t;
+finite differences of nll.
 """
 import numpy as np
 

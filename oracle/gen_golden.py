@@ -132,15 +132,35 @@ def ctc2d_fixture():
         ref = CTCLoss2D(reduction='none')
         nll_ref = ref(torch.from_numpy(log_mask), torch.from_numpy(log_cls), torch.from_numpy(tg),
                       torch.from_numpy(il), torch.from_numpy(tl))
+        # ---- gradient pin (VERDICT r2 "missing" 1): the python class is plain differentiable torch, so autograd of it
+        # w.r.t. the log-classify input is  -occupancy[t,h,n,c]  (posterior probability that the path is at pixel
+        # (t,h) emitting class c) and w.r.t. log-mask  -sum_c occupancy.  Run in float64 (module buffers converted)
+        # so the pin is not limited by f32 round-off.  ctc2d_cuda_kernel.cu:498-515 returns exp(lp) - occupancy on
+        # the classes of the extended target whose collected log(alpha*beta) is finite, and 0 elsewhere.
+        ref64 = CTCLoss2D(reduction='none').double()
+        lm = torch.from_numpy(log_mask).double().requires_grad_()
+        lc = torch.from_numpy(log_cls).double().requires_grad_()
+        nll64 = ref64(lm, lc, torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl))
+        nll64.sum().backward()
+    occ_ref = (-lc.grad).numpy()
+    occ_mask_ref = (-lm.grad).numpy()
     o = ctc2d(lp, tg, il, tl)
     diff = float(np.abs(nll_ref.numpy() - o['nll']).max())
     assert float(o['nll'].max()) < 60 and diff < 2e-5, (o['nll'], nll_ref, diff)
+    nz = o['grad'] != 0
+    recon = np.where(nz, np.exp(lp.astype(np.float64)) - o['grad'], 0.0)
+    gdiff = float(np.abs(recon - occ_ref).max())
+    assert gdiff < 1e-6, "oracle gradient convention != exp(lp) - occupancy of the reference: %g" % gdiff
+    assert float(np.abs(occ_ref[~nz]).max()) == 0.0, "reference occupancy is non-zero where the oracle returns 0"
+    assert float(np.abs(recon.sum(axis=3) - occ_mask_ref).max()) < 1e-6
     out = {'lp': torch.from_numpy(lp), 'targets': torch.from_numpy(tg), 'input_lengths': torch.from_numpy(il),
            'target_lengths': torch.from_numpy(tl), 'nll_reference_python': nll_ref.float(),
+           'occupancy_reference_python': torch.from_numpy(occ_ref),
+           'mask_occupancy_reference_python': torch.from_numpy(occ_mask_ref),
            'nll_oracle': torch.from_numpy(o['nll']), 'grad_oracle': torch.from_numpy(o['grad'])}
     path = os.path.join(GOLDEN, "ctc2d_golden.pt")
     torch.save(out, path)
-    print("wrote", path, os.path.getsize(path), "bytes; max |oracle - reference python| =", diff)
+    print("wrote", path, os.path.getsize(path), "bytes; max |oracle - reference python| nll", diff, "occupancy", gdiff)
 
 
 def res50ppm_fixture():

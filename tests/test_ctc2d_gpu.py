@@ -68,6 +68,18 @@ def test_golden_from_reference_python_ctcloss2d(golden_dir):
     assert float((nll.cpu().double() - g['nll_oracle']).abs().max()) < 1e-4
     nll.backward(torch.ones_like(nll))
     assert float((x.grad.cpu().double() - g['grad_oracle']).abs().max()) < 1e-4
+    # the gradient PIN to the reference itself: autograd of the reference's python CTCLoss2D w.r.t. log-classify is
+    # -occupancy (oracle/gen_golden.py::ctc2d_fixture, float64); the HIP op returns exp(lp) - occupancy on the
+    # extended-target classes with finite log(alpha*beta) and exactly 0 elsewhere (ctc2d_cuda_kernel.cu:498-515)
+    gr = x.grad.cpu().double()
+    occ_ref = g['occupancy_reference_python']
+    nz = gr != 0
+    recon = torch.where(nz, torch.exp(g['lp'].double()) - gr, torch.zeros_like(gr))
+    err = float((recon - occ_ref).abs().max())
+    print("2D-CTC gradient vs the reference's autograd occupancy: max|d| %.2e" % err)
+    assert err < 2e-5
+    assert float(occ_ref[~nz].abs().max()) == 0.0, "HIP gradient is zero where the reference occupancy is not"
+    assert bool((nz == (g['grad_oracle'] != 0)).all()), "zero pattern differs from the pinned oracle"
 
 
 def test_full_size_properties():

@@ -42,6 +42,31 @@ def test_golden_from_reference_python(golden_dir):
     assert np.abs(o['grad'] - g['grad_oracle'].numpy()).max() < 1e-12
 
 
+def test_gradient_pinned_to_reference_python_autograd(golden_dir):
+    """The gradient PIN: autograd of the reference's differentiable python CTCLoss2D (decoders/ctc_loss2d.py:86-154,
+    run in float64 by oracle/gen_golden.py) w.r.t. log-classify is -occupancy; the CUDA op returns
+    exp(lp) - occupancy on the extended-target classes whose log(alpha*beta) is finite and 0 elsewhere
+    (ctc2d_cuda_kernel.cu:498-515).  The oracle's gradient must reproduce the reference occupancy element-wise."""
+    g = torch.load(os.path.join(golden_dir, "ctc2d_golden.pt"), weights_only=False)
+    lp = g['lp'].numpy()
+    tg, tl = g['targets'].numpy(), g['target_lengths'].numpy()
+    o = ctc2d(lp, tg, g['input_lengths'].numpy(), tl)
+    occ = g['occupancy_reference_python'].numpy()
+    nz = o['grad'] != 0
+    recon = np.where(nz, np.exp(lp.astype(np.float64)) - o['grad'], 0.0)
+    assert np.abs(recon - occ).max() < 1e-6
+    assert np.abs(occ[~nz]).max() == 0.0                 # the oracle is zero exactly where the reference occupancy is
+    assert np.abs(recon.sum(axis=3) - g['mask_occupancy_reference_python'].numpy()).max() < 1e-6
+    # classes outside the extended target: occupancy 0 in the reference, gradient 0 in the op ("0 elsewhere")
+    N, C = lp.shape[2], lp.shape[3]
+    for b in range(N):
+        ext = set([0] + [int(v) for v in tg[b, :int(tl[b])]])
+        for c in range(C):
+            if c not in ext:
+                assert not nz[:, :, b, c].any() and np.abs(occ[:, :, b, c]).max() == 0.0
+    assert occ.max() > 0.5 and nz.mean() > 0.1           # the batch is peaked: the pin is not vacuous
+
+
 def test_occupancy_sums_to_one_and_gradient_convention():
     lp, tg, il, tl = _case()
     o = ctc2d(lp, tg, il, tl)
