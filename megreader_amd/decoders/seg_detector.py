@@ -5,7 +5,7 @@ and shapes (in5..in2, out5..out2, binarize.{0,1,3,4,6}, thresh.{0,1,3,4,6}) and 
 
 The 1x1 / 3x3 convolutions and BatchNorms run on the MFMA / HIP kernels; nn.Upsample(nearest) (+ the top-down add) is
 mr_nearest_up_fwd / _bwd; ConvTranspose2d(k=2, s=2) is a GEMM (one output pixel quad = a [Cin] x [Cin, 4*Cout] product,
-megreader_amd.nn.functional.linear) followed by a depth-to-space view.  The final sigmoid and the differentiable
+megreader_amd.nn.functional.linear) followed by a depth-to-space view.  The final sigmoid (always float32, `_SigmoidF32`) and the differentiable
 binarisation 1 / (1 + exp(-k (x - y))) are elementwise torch ops on 1-channel maps.
 `smooth=True` / `serial=True` are not used by any reference YAML and raise NotImplementedError."""
 from collections import OrderedDict
@@ -33,6 +33,16 @@ class ConvTranspose2x2(nn.ConvTranspose2d):
         y = F.linear(xs, wmat, bias)                                           # [N*H*W, 4*co]
         y = y.reshape(N, H, W, 2, 2, co).permute(0, 5, 1, 3, 2, 4).reshape(N, co, 2 * H, 2 * W)
         return y
+
+
+class _SigmoidF32(nn.Module):
+    """The heads' final nn.Sigmoid of the reference (seg_detector.py:77-79), evaluated in float32 whatever the compute
+    dtype: in bf16 sigmoid(x) rounds to exactly 1.0 from x ~ 6.2 (fp32: ~17), which puts confident pixels on BCE's
+    log(1 - p) clamp (loss 100 per pixel, zero gradient through y * (1 - y)) and quantises `binary` / `thresh` to 2^-8
+    in front of the k = 50 step function.  The maps have one channel: the cost is nil."""
+
+    def forward(self, x):
+        return torch.sigmoid(x.float())
 
 
 class _Up(nn.Upsample):
@@ -74,7 +84,7 @@ class SegDetector(nn.Module):
         q = inner_channels // 4
         return nn.Sequential(Conv2d(inner_channels, q, 3, padding=1, bias=bias), BatchNorm2d(q, fuse_relu=True),
                              FusedReLU(), ConvTranspose2x2(q, q), BatchNorm2d(q, fuse_relu=True), FusedReLU(),
-                             ConvTranspose2x2(q, 1), nn.Sigmoid())
+                             ConvTranspose2x2(q, 1), _SigmoidF32())
 
     def weights_init(self, m):
         classname = m.__class__.__name__

@@ -1,0 +1,56 @@
+"""Shared helpers of the full-size parity tests (tests/test_fullsize_parity_gpu.py, tests/test_published_configs_gpu.py).
+
+Ground truth for gradients is the CPU oracle run in FLOAT64; the bar is "HIP-f32 is as close to it as the reference's own
+f32 arithmetic (the oracle in f32)": for every parameter
+    max|g_hip - g_64| <= max(4 * max|g_cpu32 - g_64|, 1e-2 * max|g_64|)        element-wise
+    ||g_hip - g_64||_2 <= max(4 * ||g_cpu32 - g_64||_2, 2e-3 * ||g_64||_2)
+(the 1e-2 floor is the size of ONE discontinuity event -- a ReLU / max-pool / top-k decision that rounds to the other side
+in one precision; an indexing or layout bug moves elements by O(max|g|)).  Every parameter's errors are recorded in
+`REPORT` and printed; the measured maxima go into DESIGN.md's parity table.
+"""
+import copy
+
+import torch
+
+REPORT = {}   # what -> {"worst_elem": (name, e_hip, e_cpu), "worst_l2": (name, l_hip, l_cpu), "params": n}
+
+
+def f64_grads(ora32, forward):
+    """`forward(model, dtype)` -> scalar loss.  Returns the float64 oracle's gradients (weights converted exactly)."""
+    ora64 = copy.deepcopy(ora32).double().train()
+    ora64.zero_grad()
+    forward(ora64, torch.float64).backward()
+    return {k: p.grad.detach().clone() for k, p in ora64.named_parameters() if p.grad is not None}
+
+
+def grad_report(named_params, grads32, grads64, what, elem_floor=1e-2, l2_floor=2e-3, top=25):
+    rows, bad = [], []
+    for k, p in named_params:
+        g64 = grads64[k].double()
+        assert p.grad is not None, (what, k, "no HIP gradient")
+        g = p.grad.double().cpu()
+        assert g.shape == g64.shape, k
+        scale = float(g64.abs().max())
+        if scale < 1e-7:
+            # conv biases in front of a BatchNorm: mathematically zero gradient (pure round-off on every side)
+            assert float(g.abs().max()) < 1e-3, (k, "zero-gradient parameter has a large HIP gradient")
+            continue
+        g32 = grads32[k].double()
+        e_hip = float((g - g64).abs().max()) / scale
+        e_cpu = float((g32 - g64).abs().max()) / scale
+        l_hip = float((g - g64).norm() / g64.norm())
+        l_cpu = float((g32 - g64).norm() / g64.norm())
+        rows.append((k, scale, e_hip, e_cpu, l_hip, l_cpu))
+        if e_hip > max(4 * e_cpu, elem_floor) or l_hip > max(4 * l_cpu, l2_floor):
+            bad.append((k, e_hip, e_cpu, l_hip, l_cpu))
+    print("%s: element-wise gradient error / max|g_f64|   (HIP f32 | CPU f32 oracle)   rel. L2 (HIP | CPU)" % what)
+    shown = rows if len(rows) <= 60 else sorted(rows, key=lambda r: -r[2])[:top]
+    for k, scale, e_hip, e_cpu, l_hip, l_cpu in shown:
+        print("   %-56s max|g| %.3e   %.2e | %.2e    %.2e | %.2e" % (k, scale, e_hip, e_cpu, l_hip, l_cpu))
+    if rows:
+        we = max(rows, key=lambda r: r[2])
+        wl = max(rows, key=lambda r: r[4])
+        REPORT[what] = {"worst_elem": (we[0], we[2], we[3]), "worst_l2": (wl[0], wl[4], wl[5]), "params": len(rows)}
+        print("%s: %d parameters; worst element-wise %.2e (%s; CPU f32 %.2e); worst L2 %.2e (%s; CPU f32 %.2e)" %
+              (what, len(rows), we[2], we[0], we[3], wl[4], wl[0], wl[5]))
+    assert not bad, (what, bad[:5])

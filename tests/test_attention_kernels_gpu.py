@@ -1,0 +1,201 @@
+"""Kernel-level tests of the attention decoder's step kernels (csrc/attention.hip, called through the C ABI) against
+float64 torch restatements of the reference ops they replace (decoders/attention_decoder.py):
+
+  mr_attn_step_fwd/bwd   Attn.forward :146-177 (energy = v . tanh(W[h; enc] + b), softmax over positions) + the context
+                         bmm :207-209 -- with the Linear(1057 -> 512) split into its hidden / encoder halves
+  mr_gru_gates_fwd/bwd   nn.GRUCell :192, gate order r, z, n
+  mr_nll_step_fwd/bwd    log_softmax + NLLLoss(reduction='none') * mask + argmax :95-106
+  mr_embed_rows_fwd/bwd  nn.Embedding(V, V) lookup :187-193, 203 and its scatter-add gradient
+
+Sizes are the published configuration's (N = 32, T = 32, Hd = 512, Ep = 552 = 545 padded, C = 38) plus ragged ones.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from megreader_amd._lib import call, dtype_code, ptr  # noqa: E402
+
+DEV = "cuda"
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def _tol(dtype, f32, bf16):
+    return f32 if dtype == torch.float32 else bf16
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,Tn,Hd,Ep", [(32, 32, 512, 552), (5, 17, 64, 40), (3, 64, 128, 72)])
+def test_attn_step_fwd_bwd_vs_f64(dtype, N, Tn, Hd, Ep):
+    g = torch.Generator().manual_seed(N * 1000 + Tn)
+    hproj = (torch.randn(N, Hd, generator=g) * 0.7).to(dtype)
+    eproj = (torch.randn(N, Tn, Hd, generator=g) * 0.7).to(dtype)
+    enc = torch.randn(N, Tn, Ep, generator=g).to(dtype)
+    v = torch.randn(Hd, generator=g) * (Hd ** -0.5) * 4
+    gctx = torch.randn(N, Ep, generator=g).to(dtype)
+    gw = torch.randn(N, Tn, generator=g)
+
+    h64 = hproj.double().requires_grad_(True)
+    e64 = eproj.double().requires_grad_(True)
+    c64 = enc.double().requires_grad_(True)
+    v64 = v.double().requires_grad_(True)
+    energy = torch.tanh(h64.unsqueeze(1) + e64) @ v64
+    w64 = torch.softmax(energy, dim=1)
+    ctx64 = torch.bmm(w64.unsqueeze(1), c64).squeeze(1)
+    (ctx64 * gctx.double()).sum().add((w64 * gw.double()).sum()).backward()
+
+    hp, ep, en, vd = hproj.to(DEV), eproj.to(DEV).contiguous(), enc.to(DEV).contiguous(), v.to(DEV)
+    w = torch.empty((N, Tn), dtype=torch.float32, device=DEV)
+    ctx = torch.empty((N, Ep), dtype=dtype, device=DEV)
+    call("mr_attn_step_fwd", dtype_code(dtype), ptr(hp), ptr(ep), ptr(vd), ptr(en), ptr(w), ptr(ctx), N, Tn, Hd, Ep)
+    assert _rel(w, w64) < _tol(dtype, 2e-6, 2e-6) * 50          # inputs are identical (already rounded): f32 softmax
+    assert _rel(ctx, ctx64) < _tol(dtype, 1e-5, 1e-2)
+    assert float((w.sum(dim=1) - 1).abs().max()) < 1e-5
+
+    deproj = torch.full((N, Tn, Hd), 0.5, dtype=torch.float32, device=DEV)    # += semantics: pre-filled
+    denc = torch.full((N, Tn, Ep), -0.25, dtype=torch.float32, device=DEV)
+    dv = torch.full((Hd,), 2.0, dtype=torch.float32, device=DEV)
+    dh = torch.empty((N, Hd), dtype=dtype, device=DEV)
+    gc, gwd = gctx.to(DEV), gw.to(DEV)
+    call("mr_attn_step_bwd", dtype_code(dtype), ptr(gc), ptr(gwd), ptr(hp), ptr(ep), ptr(vd), ptr(en), ptr(w), ptr(dh),
+         ptr(deproj), ptr(dv), ptr(denc), N, Tn, Hd, Ep)
+    torch.cuda.synchronize()
+    assert _rel(dh, h64.grad) < _tol(dtype, 2e-5, 2e-2)
+    assert _rel(deproj - 0.5, e64.grad) < 2e-5
+    assert _rel(denc + 0.25, c64.grad) < 2e-5
+    assert _rel(dv - 2.0, v64.grad) < 2e-5
+    # without an upstream gradient on the attention map (dweights = NULL)
+    deproj.zero_(); denc.zero_(); dv.zero_()
+    for t in (h64, e64, c64, v64):
+        t.grad = None
+    energy = torch.tanh(h64.unsqueeze(1) + e64) @ v64
+    ctx64 = torch.bmm(torch.softmax(energy, dim=1).unsqueeze(1), c64).squeeze(1)
+    (ctx64 * gctx.double()).sum().backward()
+    call("mr_attn_step_bwd", dtype_code(dtype), ptr(gc), 0, ptr(hp), ptr(ep), ptr(vd), ptr(en), ptr(w), ptr(dh),
+         ptr(deproj), ptr(dv), ptr(denc), N, Tn, Hd, Ep)
+    assert _rel(dh, h64.grad) < _tol(dtype, 2e-5, 2e-2)
+    assert _rel(deproj, e64.grad) < 2e-5 and _rel(dv, v64.grad) < 2e-5 and _rel(denc, c64.grad) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,H,two_inputs", [(32, 512, True), (7, 96, False), (256, 512, True)])
+def test_gru_gates_vs_f64_grucell(dtype, N, H, two_inputs):
+    """h' of nn.GRUCell given the three projections; the f64 reference IS torch.nn.GRUCell (weights = identity blocks so
+    that gi / gh are the cell's pre-activations)."""
+    g = torch.Generator().manual_seed(N + H)
+    gi_a = torch.randn(N, 3 * H, generator=g).to(dtype)
+    gi_b = (torch.randn(N, 3 * H, generator=g) * 0.5).to(dtype) if two_inputs else None
+    gh = torch.randn(N, 3 * H, generator=g).to(dtype)
+    h = torch.randn(N, H, generator=g).to(dtype)
+    gout = torch.randn(N, H, generator=g).to(dtype)
+
+    a64 = gi_a.double().requires_grad_(True)
+    b64 = gi_b.double().requires_grad_(True) if two_inputs else None
+    gh64 = gh.double().requires_grad_(True)
+    h64 = h.double().requires_grad_(True)
+    gi = a64 + b64 if two_inputs else a64
+    r = torch.sigmoid(gi[:, :H] + gh64[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh64[:, H:2 * H])
+    nn_ = torch.tanh(gi[:, 2 * H:] + r * gh64[:, 2 * H:])
+    hn64 = (1 - z) * nn_ + z * h64
+    # cross-check the restatement against torch.nn.GRUCell itself (x = gi through an identity weight_ih)
+    cell = torch.nn.GRUCell(3 * H, H).double()
+    with torch.no_grad():
+        cell.weight_ih.copy_(torch.eye(3 * H, dtype=torch.float64))
+        cell.bias_ih.zero_()
+        cell.bias_hh.zero_()
+        whh = torch.randn(3 * H, H, generator=g).double() * 0.1
+        cell.weight_hh.copy_(whh)
+    hh = torch.randn(4, H, generator=g).double()
+    xi = torch.randn(4, 3 * H, generator=g).double()
+    ghc = hh @ whh.t()
+    rr = torch.sigmoid(xi[:, :H] + ghc[:, :H]); zz = torch.sigmoid(xi[:, H:2 * H] + ghc[:, H:2 * H])
+    nc = torch.tanh(xi[:, 2 * H:] + rr * ghc[:, 2 * H:])
+    assert float((cell(xi, hh) - ((1 - zz) * nc + zz * hh)).abs().max()) < 1e-12
+    (hn64 * gout.double()).sum().backward()
+
+    ad, ghd, hd = gi_a.to(DEV), gh.to(DEV), h.to(DEV)
+    bd = gi_b.to(DEV) if two_inputs else None
+    hnew = torch.empty_like(hd)
+    save = torch.empty((N, 3 * H), dtype=torch.float32, device=DEV)
+    call("mr_gru_gates_fwd", dtype_code(dtype), ptr(ad), ptr(bd), ptr(ghd), ptr(hd), ptr(hnew), ptr(save), N, H)
+    assert _rel(hnew, hn64) < _tol(dtype, 2e-6, 1e-2)
+    dgi = torch.empty((N, 3 * H), dtype=dtype, device=DEV)
+    dgh = torch.empty((N, 3 * H), dtype=dtype, device=DEV)
+    dh = torch.empty_like(hd)
+    gd = gout.to(DEV)
+    call("mr_gru_gates_bwd", dtype_code(dtype), ptr(gd), ptr(save), ptr(ghd), ptr(hd), ptr(dgi), ptr(dgh), ptr(dh), N, H)
+    tol = _tol(dtype, 1e-5, 2e-2)
+    assert _rel(dgi, a64.grad) < tol
+    if two_inputs:
+        assert _rel(dgi, b64.grad) < tol
+    assert _rel(dgh, gh64.grad) < tol
+    assert _rel(dh, h64.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,ld", [(32, 38, 40), (9, 38, 38), (130, 100, 104)])
+def test_nll_step_vs_f64(dtype, N, C, ld):
+    g = torch.Generator().manual_seed(N + C)
+    logits = torch.zeros(N, ld)
+    logits[:, :C] = torch.randn(N, C, generator=g) * 3
+    logits[:, C:] = 1e4                       # padding columns must be ignored
+    logits = logits.to(dtype)
+    logits[1, :C] = logits[1, 0]              # an all-ties row: first index wins the arg-max
+    target = torch.randint(0, C, (N, 3), generator=g)          # read with a stride (targets[:, t] view)
+    mask = (torch.rand(N, generator=g) > 0.3).float()
+    gl = torch.randn(N, generator=g)
+
+    x64 = logits[:, :C].double().requires_grad_(True)
+    lp64 = torch.log_softmax(x64, dim=1)
+    loss64 = torch.nn.functional.nll_loss(lp64, target[:, 1], reduction='none') * mask.double()
+    (loss64 * gl.double()).sum().backward()
+
+    ld_, td, md = logits.to(DEV), target.to(DEV), mask.to(DEV)
+    tcol = td[:, 1]
+    lp = torch.empty((N, C), dtype=torch.float32, device=DEV)
+    loss = torch.empty((N,), dtype=torch.float32, device=DEV)
+    am = torch.empty((N,), dtype=torch.int64, device=DEV)
+    call("mr_nll_step_fwd", dtype_code(dtype), ptr(ld_), ld, ptr(tcol), tcol.stride(0), ptr(md), ptr(lp), ptr(loss),
+         ptr(am), N, C, 0, 0)
+    assert float((lp.cpu().double() - lp64.detach()).abs().max()) < 2e-5
+    assert float((loss.cpu().double() - loss64.detach()).abs().max()) < 2e-5
+    assert torch.equal(am.cpu(), logits[:, :C].float().argmax(dim=1)) and int(am[1]) == 0
+    # accumulate = 1 adds to the loss buffer; softmax_out = 1 writes probabilities (eval path)
+    call("mr_nll_step_fwd", dtype_code(dtype), ptr(ld_), ld, ptr(tcol), tcol.stride(0), ptr(md), ptr(lp), ptr(loss),
+         ptr(am), N, C, 1, 1)
+    assert float((loss.cpu().double() - 2 * loss64.detach()).abs().max()) < 4e-5
+    assert float((lp.cpu().double() - lp64.detach().exp()).abs().max()) < 2e-6
+    call("mr_nll_step_fwd", dtype_code(dtype), ptr(ld_), ld, ptr(tcol), tcol.stride(0), ptr(md), ptr(lp), ptr(loss),
+         ptr(am), N, C, 0, 0)
+    d = torch.full((N, ld), 7.0, dtype=dtype, device=DEV)
+    gld = gl.to(DEV)
+    call("mr_nll_step_bwd", dtype_code(dtype), ptr(gld), ptr(lp), ptr(tcol), tcol.stride(0), ptr(md), ptr(d), ld, N, C)
+    assert _rel(d[:, :C], x64.grad) < _tol(dtype, 1e-5, 1e-2)
+    assert bool((d[:, C:] == 7.0).all())      # padding columns are the caller's (the Function pre-zeroes them)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed_rows_vs_f64(dtype):
+    N, V, ldo = 64, 38, 40
+    g = torch.Generator().manual_seed(5)
+    table = torch.eye(V) + 0.1 * torch.randn(V, V, generator=g)       # trainable, initialised to the identity (:190-191)
+    idx = torch.randint(0, V, (N,), generator=g)
+    idx[:8] = 3                                                       # many samples on one row: the atomics path
+    gout = torch.randn(N, ldo, generator=g).to(dtype)
+    t64 = table.double().requires_grad_(True)
+    emb64 = torch.nn.functional.embedding(idx, t64)
+    (emb64 * gout[:, :V].double()).sum().backward()
+    td, idd = table.to(DEV), idx.to(DEV)
+    out = torch.full((N, ldo), 9.0, dtype=dtype, device=DEV)
+    call("mr_embed_rows_fwd", dtype_code(dtype), ptr(idd), ptr(td), ptr(out), N, V, V, ldo)
+    assert _rel(out[:, :V], emb64) < _tol(dtype, 1e-7, 4e-3)
+    assert bool((out[:, V:] == 0).all())                              # padded input columns of word_linear are zero
+    dt = torch.full((V, V), 1.0, dtype=torch.float32, device=DEV)     # accumulated into
+    gd = gout.to(DEV)
+    call("mr_embed_rows_bwd", dtype_code(dtype), ptr(idd), ptr(gd), ptr(dt), N, V, V, ldo)
+    assert _rel(dt - 1.0, t64.grad) < 1e-5

@@ -84,6 +84,62 @@ def test_forward_backward_vs_oracle(dtype, case):
         assert float(flat[:, 18 * Ho * Wo:].abs().max()) == 0.0
 
 
+# The 13 deformable layers of deformable_resnet50 at the DB detector's 640 x 640 input (backbones/resnet.py:113-181,
+# 295-309; experiments/seg_detector/seg_detector_db.yaml:53): planes 128 / 256 / 512 at strides 8 / 16 / 32, the first block
+# of every stage stride-2 with a stride-1 (input-sized) offset map read flat (quirk Q10).  (name, count, C, H, W, stride)
+REAL_LAYERS = [
+    ("layer2.0", 1, 128, 160, 160, 2), ("layer2.1-3", 3, 128, 80, 80, 1),
+    ("layer3.0", 1, 256, 80, 80, 2), ("layer3.1-5", 5, 256, 40, 40, 1),
+    ("layer4.0", 1, 512, 40, 40, 2), ("layer4.1-2", 2, 512, 20, 20, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layer", REAL_LAYERS, ids=[l[0] for l in REAL_LAYERS])
+def test_real_layer_shapes_vs_oracle(dtype, layer):
+    """DCNv2 forward + all five gradients at the real layer shapes of the published DB configuration (batch 2 per GPU),
+    offsets ~ N(0, 1.5 px) kept off the integer grid, against the float64 autograd oracle.  These are the sizes at which
+    the library picks its big-tile / split kernels and where the stride-2 blocks index a 4x larger offset map flat."""
+    name, _count, C, H, W, stride = layer
+    N, Co, pad, dil, oscale = 2, C, 1, 1, 1.5
+    mr.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(C + H + stride)
+    Ho = (H + 2 * pad - 3) // stride + 1
+    Wo = (W + 2 * pad - 3) // stride + 1
+    oh, ow = H, W                             # conv2_offset has stride 1 ALWAYS (backbones/resnet.py:136-142)
+    x = torch.randn(N, C, H, W, generator=g).to(dtype)
+    off = torch.floor(torch.randn(N, 18, oh, ow, generator=g) * oscale) + 0.25 + 0.5 * torch.rand(N, 18, oh, ow, generator=g)
+    msk = torch.sigmoid(torch.randn(N, 9, oh, ow, generator=g))
+    w = torch.randn(Co, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+    gy = torch.randn(N, Co, Ho, Wo, generator=g).to(dtype)
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads() or 1)))
+    xr = x.double().requires_grad_(True)
+    offr = off.double().requires_grad_(True)
+    mskr = msk.double().requires_grad_(True)
+    wr = w.to(dtype).double().requires_grad_(True)
+    yr = modulated_deform_conv2d(xr, offr, mskr, wr, None, stride, pad, dil)
+    yr.backward(gy.double())
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    offd = off.to(DEV).requires_grad_(True)
+    mskd = msk.to(DEV).requires_grad_(True)
+    wd = w.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = modulated_deform_conv(xd, offd, mskd, wd, None, stride, pad, dil, 1, 1)
+    assert y.shape == yr.shape
+    errs = {"y": _rel(y, yr)}
+    y.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
+    errs.update(dx=_rel(xd.grad, xr.grad), dw=_rel(wd.grad, wr.grad), doff=_rel(offd.grad, offr.grad),
+                dmask=_rel(mskd.grad, mskr.grad))
+    print("DCN %s C=%d %dx%d s%d %s: " % (name, C, H, W, stride, str(dtype).split('.')[-1]) +
+          ", ".join("%s %.2e" % kv for kv in errs.items()))
+    tol, gtol = (2e-5, 1e-4) if dtype == torch.float32 else (2e-2, 3e-2)
+    assert errs["y"] < tol
+    for k in ("dx", "dw", "doff", "dmask"):
+        assert errs[k] < gtol, (k, errs[k])
+    if stride == 2:   # entries outside the flat [18,Ho,Wo] / [9,Ho,Wo] windows get exactly zero gradient
+        assert float(offd.grad.reshape(N, -1)[:, 18 * Ho * Wo:].abs().max()) == 0.0
+        assert float(mskd.grad.reshape(N, -1)[:, 9 * Ho * Wo:].abs().max()) == 0.0
+
+
 def test_zero_offset_module_equals_conv():
     mr.set_compute_dtype(torch.float32)
     torch.manual_seed(0)
