@@ -137,7 +137,7 @@ def main():
                          "fpn_attention = configs[3]: ResNet50-FPN + attention decoder on 64x256 crops, batch 32 per "
                          "GPU (256 global on 8 GPUs), gt_as_output fixed for determinism; db = configs[4]: the DB detector "
                          "(deformable ResNet-50 with 13 DCNv2 layers + SegDetector + L1BalanceCELoss, SGD) on 640x640 "
-                         "images, batch 2 per GPU (16 global on 8 GPUs); eager launches (the loss synchronises the host)")
+                         "images, batch 2 per GPU (16 global on 8 GPUs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -233,7 +233,7 @@ def main():
             opt = FusedAdam(model.parameters(), lr=1e-3)  # experiments/recognition/crnn.yaml:82-89 (both YAMLs use Adam)
         opt.zero_grad()
         net = model
-        use_graph = not args.no_graph and not is_db   # the DB loss counts positives on the host (reference behaviour)
+        use_graph = not args.no_graph   # the DB loss keeps its hard-negative count on the device (seg_detector_loss.py)
         if distributed and not use_graph:
             # eager data parallel: the apex-style shim (bucketed all-reduce overlapped with backward)
             from megreader_amd.apex.parallel import DistributedDataParallel
@@ -284,6 +284,9 @@ def main():
             from megreader_amd.runtime import GraphedTrainStep, data_parallel_grad_sync
 
             def loss_fn(i, l, n):
+                if is_db:
+                    loss, _ = net(dbatch)
+                    return loss.mean()
                 loss, _ = net(i, targets=l, lengths=n, train=True)
                 return loss.mean()
 

@@ -293,8 +293,13 @@ int mr_ctc2d_head_bwd(int dtype, const float* grad_lp, const float* mask_prob, c
 
 /* ---- Modulated deformable conv v2 (replaces assets/ops/dcn: src/deform_conv_cuda.cpp:486-679 and
  *      src/deform_conv_cuda_kernel.cu:569-766; python API functions/deform_conv.py:108-177) --------------------------
- * forward  = mr_dcn2_im2col (whole batch) + mr_gemm_nt(col, w_krsc, bias)
- * backward = mr_gemm_nt(dy, w^T) -> gcol; mr_dcn2_coord_grad; mr_dcn2_col2im; mr_dcn2_im2col + mr_gemm_tn (dW, dbias)
+ * Fused path (csrc/dcn_fused.hip; C % 64 == 0, Co % 64 == 0, kh*kw <= 9 -- every DCN layer of deformable_resnet50): the column
+ *   matrix never exists.  forward = sample -> LDS -> MFMA; backward = offset / mask gradients from gcol tiles kept in the MFMA
+ *   accumulators, input gradient as a CSR-inverted GATHER-GEMM (no f32 atomics), dW / dbias by a TN GEMM whose operand is
+ *   sampled on the fly.
+ * General path (any C % vector == 0): the three piecewise kernels below around mr_gemm_nt / mr_gemm_tn:
+ *   forward  = mr_dcn2_im2col (whole batch) + mr_gemm_nt(col, w_krsc, bias)
+ *   backward = mr_gemm_nt(dy, w^T) -> gcol; mr_dcn2_coord_grad; mr_dcn2_col2im; mr_dcn2_im2col + mr_gemm_tn (dW, dbias)
  * offset / mask are f32 and indexed per sample as FLAT [2*kh*kw][Ho][Wo] / [kh*kw][Ho][Wo] arrays from the sample's
  * base (per-sample strides off_bs / msk_bs), exactly like deform_conv_cuda_kernel.cu:599-612. */
 int mr_dcn2_im2col(int dtype, const void* x, const float* offset, long long off_bs, const float* mask,
@@ -308,10 +313,14 @@ int mr_dcn2_col2im(int dtype, const void* gcol, const float* offset, long long o
                    int dil, int Ho, int Wo, hipStream_t stream);
 
 /* single-call forms (replace modulated_deform_conv_cuda_forward / _backward,
- * assets/ops/dcn/src/deform_conv_cuda.cpp:486-679).  Caller owns all buffers incl. the column workspace
- * col_ws [N*Ho*Wo, kh*kw*C] (`dtype`); w_n [Co][kh*kw*C] / w_t [kh*kw*C][Co] are the mr_prep_matrix images of the KRSC
- * weight; dx32 / doffset / dmask pre-zeroed (accumulated / partially written), dw f32 [Co][kh*kw*C] and dbias f32 [Co]
- * accumulated; dx32, dw, dbias may be null. */
+ * assets/ops/dcn/src/deform_conv_cuda.cpp:486-679).  Caller owns all buffers incl. the workspace col_ws (the reference passes
+ * `columns` the same way, functions/deform_conv.py:135) of mr_dcn2_ws_bytes(..., backward) bytes -- 0 for the fused forward
+ * (col_ws may be NULL), the CSR of the scatter pattern for the fused backward, the column matrix [N*Ho*Wo, kh*kw*C] otherwise.
+ * w_n [Co][kh*kw*C] / w_t [kh*kw*C][Co] are the mr_prep_matrix images of the KRSC weight; dx32 / doffset / dmask are ACCUMULATED
+ * into and must arrive zeroed (the reference's Function allocates them with zeros_like, functions/deform_conv.py:150-154);
+ * dw f32 [Co][kh*kw*C] and dbias f32 [Co] accumulated; dx32, dw, dbias may be null. */
+long long mr_dcn2_ws_bytes(int dtype, int N, int H, int W, int C, int Co, int kh, int kw, int Ho, int Wo, int backward);
+int mr_set_dcn_fused(int on);    /* A/B (host only): 0 = general kernels for every shape; returns the old value */
 int mr_set_dcn_v1_bwd(int on);   /* A/B (host only): 1 = round-1 DCN backward kernels */
 int mr_dcn2_fwd(int dtype, const void* x, const void* w_n, const float* bias, const float* offset, long long off_bs,
                 const float* mask, long long msk_bs, void* y, void* col_ws, int N, int H, int W, int C, int Co, int kh,

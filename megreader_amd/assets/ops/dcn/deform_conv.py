@@ -6,9 +6,11 @@ deform_conv.py:130-131), no shape check on offset / mask (the v2 host code has n
 reference's stride-2 blocks work on a larger offset map -- SURVEY.md §3.3; this implementation indexes the maps the
 same flat way).  groups = deformable_groups = 1 only (all the reference's models).
 
-Forward: deformable im2col over the whole batch (one launch) + one MFMA GEMM against KRSC weights.
-Backward: gcol = dy * W (MFMA GEMM), offset/mask gradient kernel (wave reduction over channels), input gradient
-scatter (f32 atomics), and dW/dbias with the transpose-read wgrad GEMM on a recomputed column matrix.
+Channels that are multiples of 64 (every DCN layer of deformable_resnet50) take the fused kernels of csrc/dcn_fused.hip:
+forward = sample -> LDS -> MFMA without a column matrix; backward = offset / mask gradients from gcol tiles kept in the
+MFMA accumulators, input gradient as a CSR-inverted gather-GEMM (no f32 atomics), dW / dbias by a TN GEMM sampled on the fly.
+Other shapes: deformable im2col over the whole batch + one MFMA GEMM forward; gcol = dy * W, offset/mask gradient kernel,
+input gradient scatter (f32 atomics), dW/dbias on a recomputed column matrix backward.
 """
 import math
 
@@ -18,7 +20,7 @@ from torch.autograd import Function
 from torch.nn.modules.utils import _pair
 
 from .... import get_compute_dtype
-from ...._lib import call, dtype_code, ptr, vec_of
+from ...._lib import call, dcn_workspace, dtype_code, ptr, vec_of
 from ....nn.functional import to_internal, _grad_internal
 
 
@@ -52,7 +54,7 @@ class ModulatedDeformConvFunction(Function):
         w_n = torch.empty((Co, K), dtype=dtype, device=xi.device)
         w_t = torch.empty((K, Co), dtype=dtype, device=xi.device)
         call("mr_prep_matrix", dt, ptr(wk), K, ptr(w_n), K, ptr(w_t), Co, Co, K, 0)
-        col = torch.empty((N * Ho * Wo, K), dtype=dtype, device=xi.device)      # the reference's `columns` scratch
+        col = dcn_workspace(dtype, N, H, W, C, Co, kh, kw, Ho, Wo, False, xi.device)   # the reference's `columns` scratch
         y = torch.empty((N, Ho, Wo, Co), dtype=dtype, device=xi.device)
         call("mr_dcn2_fwd", dt, ptr(xi), ptr(w_n), ptr(bias), ptr(off), off_bs, ptr(msk), msk_bs, ptr(y), ptr(col), N, H,
              W, C, Co, kh, kw, stride, padding, dilation, Ho, Wo)
@@ -75,7 +77,7 @@ class ModulatedDeformConvFunction(Function):
         K = kh * kw * C
         P = N * Ho * Wo
         g = _grad_internal(grad_output, dtype)
-        col = torch.empty((P, K), dtype=dtype, device=dev)      # dy * W, then the recomputed column matrix
+        col = dcn_workspace(dtype, N, H, W, C, Co, kh, kw, Ho, Wo, True, dev)   # CSR of the scatter / column matrix
         grad_offset = torch.zeros_like(off)
         grad_mask = torch.zeros_like(msk)
         want_dx = ctx.needs_input_grad[0]

@@ -12,7 +12,7 @@ groups = deformable_groups = 1 (all the reference's models)."""
 import torch
 
 from .... import get_compute_dtype
-from ...._lib import call, dtype_code, ptr, vec_of
+from ...._lib import dcn_workspace, call, dtype_code, ptr, vec_of
 
 
 def _check(input, weight, offset, mask, group, deformable_group):
@@ -74,7 +74,7 @@ def modulated_deform_conv_cuda_forward(input, weight, bias, ones, offset, mask, 
     w_n, _ = _weight_images(weight, dtype)
     off = offset.detach().float().contiguous()      # per-sample FLAT [2*kh*kw][Ho][Wo] indexing from each sample's base
     msk = mask.detach().float().contiguous()
-    col = torch.empty((N * Ho * Wo, kh * kw * C), dtype=dtype, device=input.device)
+    col = dcn_workspace(dtype, N, H, W, C, Co, kh, kw, Ho, Wo, False, input.device)
     y = torch.empty((N, Ho, Wo, Co), dtype=dtype, device=input.device)
     b = bias.detach().float().contiguous() if with_bias else None
     call("mr_dcn2_fwd", dt, ptr(xi), ptr(w_n), ptr(b), ptr(off), off[0].numel(), ptr(msk), msk[0].numel(), ptr(y), ptr(col),
@@ -101,7 +101,7 @@ def modulated_deform_conv_cuda_backward(input, weight, bias, ones, offset, mask,
     off = offset.detach().float().contiguous()
     msk = mask.detach().float().contiguous()
     dev = input.device
-    col = torch.empty((N * Ho * Wo, kh * kw * C), dtype=dtype, device=dev)
+    col = dcn_workspace(dtype, N, H, W, C, Co, kh, kw, Ho, Wo, True, dev)
     dx32 = torch.zeros((N, H, W, C), dtype=torch.float32, device=dev)
     doff = torch.zeros_like(off)
     dmsk = torch.zeros_like(msk)

@@ -9,24 +9,19 @@
 // does: per sample, as FLAT [2*9][Ho][Wo] / [9][Ho][Wo] f32 arrays from the base of that sample's (possibly
 // larger) NCHW buffer (reference quirk Q10) -- their gradients are written back the same way.
 // All three kernels are HBM / L2-bound gather-scatter work; groups = deformable_groups = 1.
-#include "common.h"
+#include "dcn_geom.h"
 #include "../../include/megreader_hip.h"
 
 namespace mr {
 
-struct DcnGeom {
-  int N, H, W, C, Ho, Wo, kh, kw, stride, pad, dil;
-  long long off_bs, msk_bs;  // per-sample strides (elements) of the offset / mask buffers
-};
-
-__device__ __forceinline__ bool dcn_point(const DcnGeom& g, const float* off_b, int tap, int ho, int wo, float& ph,
-                                          float& pw) {
-  const int i = tap / g.kw, j = tap - i * g.kw;
-  const long long o = ((long long)(2 * tap) * g.Ho + ho) * g.Wo + wo;
-  ph = (float)(ho * g.stride - g.pad + i * g.dil) + off_b[o];
-  pw = (float)(wo * g.stride - g.pad + j * g.dil) + off_b[o + (long long)g.Ho * g.Wo];
-  return ph > -1.f && pw > -1.f && ph < (float)g.H && pw < (float)g.W;
-}
+// fused kernels (dcn_fused.hip): no column matrix, no floating-point atomics on the input gradient
+bool dcn_fused_ok(int dtype, int H, int W, int C, int Co, int kh, int kw);
+long long dcn_fused_ws_bytes(int N, int H, int W, int Ho, int Wo, int taps);
+int dcn_fused_fwd(int dtype, const void* x, const void* w_n, const float* bias, const float* offset, const float* mask,
+                  void* y, const DcnGeom& g, int Co, hipStream_t stream);
+int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, const float* offset, const float* mask,
+                  void* ws, float* dx32, float* doffset, float* dmask, float* dw, float* dbias, const DcnGeom& g, int Co,
+                  hipStream_t stream);
 
 // col[p, tap*C + c] = valid ? mask * bilinear(x[n,:,:,c], p_tap) : 0     thread = (p, tap, 16-byte channel vector)
 template <typename T>
@@ -439,6 +434,13 @@ int mr_set_dcn_v1_bwd(int on) {
   return old;
 }
 
+// bytes of the caller-owned workspace `col_ws` of mr_dcn2_fwd (backward = 0) / mr_dcn2_bwd (backward = 1) for this shape:
+// fused path: nothing forward, the CSR of the scatter pattern backward; general path: the column matrix.
+long long mr_dcn2_ws_bytes(int dtype, int N, int H, int W, int C, int Co, int kh, int kw, int Ho, int Wo, int backward) {
+  if (dcn_fused_ok(dtype, H, W, C, Co, kh, kw)) return backward ? dcn_fused_ws_bytes(N, H, W, Ho, Wo, kh * kw) : 0;
+  return (long long)N * Ho * Wo * kh * kw * C * (dtype == MR_F32 ? 4 : 2);
+}
+
 // ---- single-call forms: what `modulated_deform_conv_cuda_forward / _backward`
 // (assets/ops/dcn/src/deform_conv_cuda.cpp:486-679) are to the reference's python Function.  The caller owns every
 // buffer, including the column workspace (the reference passes `columns` the same way, functions/deform_conv.py:135).
@@ -447,6 +449,13 @@ int mr_set_dcn_v1_bwd(int on) {
 int mr_dcn2_fwd(int dtype, const void* x, const void* w_n, const float* bias, const float* offset, long long off_bs,
                 const float* mask, long long msk_bs, void* y, void* col_ws, int N, int H, int W, int C, int Co, int kh,
                 int kw, int stride, int pad, int dil, int Ho, int Wo, hipStream_t stream) {
+  if (dcn_fused_ok(dtype, H, W, C, Co, kh, kw)) {   // sample -> LDS -> MFMA, no column matrix (col_ws unused, may be NULL)
+    DcnGeom g;
+    int rcg = make_geom(g, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo, off_bs, msk_bs);
+    if (rcg) return rcg;
+    return dcn_fused_fwd(dtype, x, w_n, bias, offset, mask, y, g, Co, stream);
+  }
+  MR_CHECK_ARG(col_ws != nullptr, "mr_dcn2_fwd: this shape needs a column workspace (mr_dcn2_ws_bytes)");
   int rc = mr_dcn2_im2col(dtype, x, offset, off_bs, mask, msk_bs, col_ws, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo,
                           stream);
   if (rc) return rc;
@@ -461,6 +470,13 @@ int mr_dcn2_bwd(int dtype, const void* dy, const void* x, const void* w_t, const
                 const float* mask, long long msk_bs, void* col_ws, float* dx32, float* doffset, float* dmask, float* dw,
                 float* dbias, int N, int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int Ho,
                 int Wo, hipStream_t stream) {
+  if (dcn_fused_ok(dtype, H, W, C, Co, kh, kw)) {
+    DcnGeom g;
+    int rcg = make_geom(g, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo, off_bs, msk_bs);
+    if (rcg) return rcg;
+    return dcn_fused_bwd(dtype, dy, x, w_t, offset, mask, col_ws, dx32, doffset, dmask, dw, dbias, g, Co, stream);
+  }
+  MR_CHECK_ARG(col_ws != nullptr, "mr_dcn2_bwd: workspace missing (mr_dcn2_ws_bytes)");
   const int K = kh * kw * C, P = N * Ho * Wo;
   int rc = mr_gemm_nt(dtype, dy, Co, w_t, Co, col_ws, K, nullptr, 0, P, K, Co, stream);   // gcol = dy * W
   if (rc) return rc;

@@ -1,0 +1,848 @@
+// Fused DCNv2 kernels for gfx950: the column matrix of the reference (assets/ops/dcn/src/deform_conv_cuda_kernel.cu:569-632
+// modulated im2col, :634-692 col2im, :694-766 col2im_coord; host GEMM loop deform_conv_cuda.cpp:486-679) never exists in HBM.
+//
+//   forward   y[p, co]        = sum_{tap, c} sample(x)[p, tap, c] * W[co, tap, c]        dcn2_fwd_fused_kernel
+//             sample -> registers -> LDS -> MFMA: the A operand of the implicit GEMM is produced by the bilinear blend
+//             of four 16-byte NHWC corner vectors (issued one k-step ahead, blended after the MFMAs of the current one)
+//   d offset / d mask          dcn2_coord_fused_kernel
+//             gcol[p, (tap, c)] = dy[p, :] . W[:, tap, c] is an MFMA tile that stays in the accumulators; the epilogue dots it
+//             with the four corner vectors of x, reduces over the channels of the tile (registers -> 2 shuffles) and adds
+//             the three per-(pixel, tap) results into the offset / mask gradients
+//   d x       dx[q, c]         = sum_{tap} ( sum_{e in L(q,tap)} w_e dy[p_e, :] ) . W[:, tap, c]   dcn2_dx_fused_kernel
+//             the scatter of the reference's col2im (36 f32 atomics on every input element) is inverted once per call into
+//             a CSR list per (input pixel, tap) -- the pattern does not depend on the channel -- and the input gradient
+//             becomes a GATHER-GEMM: rows of dy are gathered with their bilinear * mask weights into the A tile, the MFMA
+//             contracts with W.  No floating-point atomics, no gcol.
+//   d W, d bias  dW[co, (tap,c)] = sum_p dy[p, co] * sample(x)[p, tap, c]                 dcn2_wgrad_fused_kernel
+//             transpose-read TN GEMM whose B tile is sampled on the fly; split over pixels, f32 atomics on dW (9*C*Co).
+//
+// Layouts: x / y / dy NHWC in T (bf16 or f32); w_n [Co][taps*C], w_t [taps*C][Co] in T; offsets / mask f32, flat per sample.
+// Preconditions of the fused path (host: dcn_fused_ok): C % 64 == 0, Co % 64 == 0, kh*kw <= 9, H, W < 32768.  Other shapes
+// take the general kernels of dcn.hip.  MFMA tile code (LDS image, fragment reads) follows igemm_nt_body / igemm_tn_kernel.
+#include "dcn_geom.h"
+#include "igemm_core.h"
+#include "../../include/megreader_hip.h"
+
+namespace mr {
+
+constexpr int DCN_MAX_TAPS = 9;
+
+template <typename T> __device__ __forceinline__ uint4 pack_vec(const float* v);
+template <> __device__ __forceinline__ uint4 pack_vec<float>(const float* v) {
+  uint4 o;
+  float* po = (float*)&o;
+  po[0] = v[0]; po[1] = v[1]; po[2] = v[2]; po[3] = v[3];
+  return o;
+}
+template <> __device__ __forceinline__ uint4 pack_vec<bf16_t>(const float* v) {
+  uint4 o;
+  bf16_t* po = (bf16_t*)&o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) po[j] = (bf16_t)v[j];
+  return o;
+}
+
+// 64 x BN output tile, 4 waves (2 x 2), BK = 8 vectors of 16 bytes; LDS image [8 k-chunks][ROWS][16 B], slot(row, kc) =
+// kc*ROWS + (row ^ kc) (conflict-free ds_write_b128 / ds_read_b128, see igemm_core.h)
+template <typename T, int BN>
+struct DcnNt {
+  static constexpr int BM = 64;
+  static constexpr int VEC = VecOf<T>::N, BK = 8 * VEC, AI = BM / 32, BI = BN / 32;
+  static constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
+  typedef typename Mma<T>::Frag Frag;
+
+  static __device__ __forceinline__ void store(uint4* sA, uint4* sB, const uint4* ra, const uint4* rb, int kc, int r0) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) sA[kc * BM + ((r0 + 32 * i) ^ kc)] = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) sB[kc * BN + ((r0 + 32 * i) ^ kc)] = rb[i];
+  }
+  static __device__ __forceinline__ void mma(const uint4* sA, const uint4* sB, f32x4 (&acc)[TN][TM], int wm_, int wn_,
+                                             int l15, int lg) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kcr = ks * 4 + lg;
+      Frag fa[TM], fb[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) fa[j] = *(const Frag*)&sA[kcr * BM + ((wm_ * WTM + j * 16 + l15) ^ kcr)];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fb[i] = *(const Frag*)&sB[kcr * BN + ((wn_ * WTN + i * 16 + l15) ^ kcr)];
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) Mma<T>::run(acc[i][j], fb[i], fa[j]);   // D[n][m]: lane = 4 consecutive n of one m
+    }
+  }
+};
+
+struct DcnFusedArgs {
+  const void* x;
+  const void* w;       // fwd: w_n [Co][taps*C]; coord / dx: w_t [taps*C][Co]
+  const void* dy;
+  const float* bias;
+  const float* offset;
+  const float* mask;
+  void* y;
+  float* doffset;
+  float* dmask;
+  float* dx;
+  const int* start;      // CSR row starts, [Q*taps + 1]
+  const int2* entries;   // CSR entries {output pixel p, bits of the bilinear * mask weight}
+  DcnGeom g;
+  int Co, P, Q;
+};
+
+// blend of the four corner vectors in the reference's corner order (top-left, top-right, bottom-left, bottom-right)
+template <typename T>
+__device__ __forceinline__ uint4 dcn_blend(const uint4 (&raw)[4], const DcnDesc& d) {
+  constexpr int VEC = VecOf<T>::N;
+  const float wgt[4] = {(1.f - d.lh) * (1.f - d.lw) * d.m, (1.f - d.lh) * d.lw * d.m, d.lh * (1.f - d.lw) * d.m,
+                        d.lh * d.lw * d.m};
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const T* pv = (const T*)&raw[k];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] += wgt[k] * to_f32(pv[j]);
+  }
+  return pack_vec<T>(acc);
+}
+
+// issue the four corner loads of one sample (16-byte channel vector at channel c); corners outside the image read as 0
+template <typename T>
+__device__ __forceinline__ void dcn_corner_loads(uint4 (&raw)[4], const T* __restrict__ X, const DcnGeom& g, int pixbase,
+                                                 const DcnDesc& d, int c) {
+  const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int h = d.hl + (k >> 1), w = d.wl + (k & 1);
+    raw[k] = z;
+    if (dcn_inside(g, h, w)) raw[k] = ldg16(X + ((long long)(pixbase + h * g.W + w)) * g.C + c);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void dcn2_fwd_fused_kernel(DcnFusedArgs a) {
+  typedef DcnNt<T, BN> Nt;
+  constexpr int BM = Nt::BM, VEC = Nt::VEC, BK = Nt::BK, AI = Nt::AI, BI = Nt::BI, TM = Nt::TM, TN = Nt::TN;
+  __shared__ uint4 smem[8 * (BM + BN)];
+  __shared__ float4 sdesc[DCN_MAX_TAPS * BM];
+  __shared__ int spix[BM];
+  uint4* sA = smem;
+  uint4* sB = smem + 8 * BM;
+  const DcnGeom& g = a.g;
+  const int taps = g.kh * g.kw, K = taps * g.C;
+  const int tid = threadIdx.x;
+  const int tiles_n = (a.Co + BN - 1) / BN;
+  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kc = tid & 7, r0 = tid >> 3;
+  const T* __restrict__ X = (const T*)a.x;
+  const T* __restrict__ Wn = (const T*)a.w;
+
+  for (int idx = tid; idx < BM * taps; idx += 256) {
+    const int row = idx % BM, tap = idx / BM;
+    const int p = m0 + row;
+    DcnDesc d;
+    d.m = 0.f; d.lh = 0.f; d.lw = 0.f; d.hl = -2; d.wl = -2;
+    int pb = 0;
+    if (p < a.P) {
+      const int wo = p % g.Wo, r = p / g.Wo;
+      const int ho = r % g.Ho, n = r / g.Ho;
+      d = dcn_desc(g, a.offset, a.mask, n, tap, ho, wo);
+      pb = n * g.H * g.W;
+    }
+    sdesc[tap * BM + row] = dcn_pack(d);
+    if (tap == 0) spix[row] = pb;
+  }
+  __syncthreads();
+
+  uint4 raw[AI][4], ra[AI], rb[BI];
+  auto issue = [&](int k0) {
+    const int tap = k0 / g.C;
+    const int c = k0 - tap * g.C + kc * VEC;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int row = r0 + 32 * i;
+      const DcnDesc d = dcn_unpack(sdesc[tap * BM + row]);
+      dcn_corner_loads<T>(raw[i], X, g, spix[row], d, c);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int n = n0 + r0 + 32 * i;
+      rb[i] = make_uint4(0, 0, 0, 0);
+      if (n < a.Co) rb[i] = ldg16(Wn + (long long)n * K + k0 + kc * VEC);
+    }
+  };
+  auto finish = [&](int k0) {
+    const int tap = k0 / g.C;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) ra[i] = dcn_blend<T>(raw[i], dcn_unpack(sdesc[tap * BM + r0 + 32 * i]));
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm_ = wave & 1, wn_ = wave >> 1;
+  const int l15 = lane & 15, lg = lane >> 4;
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    finish(k0);
+    Nt::store(sA, sB, ra, rb, kc, r0);
+    __syncthreads();
+    if (k0 + BK < K) issue(k0 + BK);   // corner / weight loads stay in flight under the MFMAs
+    Nt::mma(sA, sB, acc, wm_, wn_, l15, lg);
+    __syncthreads();
+  }
+
+  T* __restrict__ Y = (T*)a.y;
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int m = m0 + wm_ * Nt::WTM + j * 16 + l15;
+      const int n = n0 + wn_ * Nt::WTN + i * 16 + lg * 4;
+      if (m >= a.P || n >= a.Co) continue;
+      f32x4 v = acc[i][j];
+      if (a.bias) {
+        const f32x4 b = *(const f32x4*)(a.bias + n);
+        v += b;
+      }
+      store4(Y + (long long)m * a.Co + n, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ d offset / d mask
+// GEMM: gcol[p, n] = sum_co dy[p, co] * w_t[n][co], n = tap*C + c; a BN-column tile lies inside ONE tap (C % BN == 0).
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void dcn2_coord_fused_kernel(DcnFusedArgs a) {
+  typedef DcnNt<T, BN> Nt;
+  constexpr int BM = Nt::BM, VEC = Nt::VEC, BK = Nt::BK, AI = Nt::AI, BI = Nt::BI, TM = Nt::TM, TN = Nt::TN;
+  __shared__ uint4 smem[8 * (BM + BN)];
+  uint4* sA = smem;
+  uint4* sB = smem + 8 * BM;
+  const DcnGeom& g = a.g;
+  const int taps = g.kh * g.kw, NB = taps * g.C, K = a.Co;
+  const int tid = threadIdx.x;
+  const int tiles_n = NB / BN;
+  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kc = tid & 7, r0 = tid >> 3;
+  const T* __restrict__ DY = (const T*)a.dy;
+  const T* __restrict__ WT = (const T*)a.w;
+  const T* __restrict__ X = (const T*)a.x;
+
+  uint4 ra[AI], rb[BI];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int p = m0 + r0 + 32 * i;
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (p < a.P) ra[i] = ldg16(DY + (long long)p * K + k0 + kc * VEC);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) rb[i] = ldg16(WT + (long long)(n0 + r0 + 32 * i) * K + k0 + kc * VEC);
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm_ = wave & 1, wn_ = wave >> 1;
+  const int l15 = lane & 15, lg = lane >> 4;
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    Nt::store(sA, sB, ra, rb, kc, r0);
+    __syncthreads();
+    if (k0 + BK < K) load(k0 + BK);
+    Nt::mma(sA, sB, acc, wm_, wn_, l15, lg);
+    __syncthreads();
+  }
+
+  // epilogue: lane (l15, lg) holds gcol[pixel m][4 channels] per (i, j).  S_k = sum_c gcol * x[corner k]; the three
+  // gradients are linear combinations of S_1..S_4 (deform_conv_cuda_kernel.cu:694-766 restated per corner).
+  const int tap = n0 / g.C, cbase = n0 - tap * g.C;
+  const long long hw = (long long)g.Ho * g.Wo;
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + wm_ * Nt::WTM + j * 16 + l15;
+    const bool live = m < a.P;
+    int n_img = 0, ho = 0, wo = 0;
+    DcnDesc d;
+    d.m = 0.f; d.lh = 0.f; d.lw = 0.f; d.hl = -2; d.wl = -2;
+    if (live) {
+      wo = m % g.Wo;
+      const int r = m / g.Wo;
+      ho = r % g.Ho;
+      n_img = r / g.Ho;
+      d = dcn_desc(g, a.offset, a.mask, n_img, tap, ho, wo);
+    }
+    const int pb = n_img * g.H * g.W;
+    float S[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int h = d.hl + (k >> 1), w = d.wl + (k & 1);
+      if (!dcn_inside(g, h, w)) continue;
+      const T* xp = X + ((long long)(pb + h * g.W + w)) * g.C + cbase + wn_ * Nt::WTN + lg * 4;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const f32x4 xv = load4(xp + i * 16);
+        const f32x4 gv = acc[i][j];
+        S[k] += gv[0] * xv[0] + gv[1] * xv[1] + gv[2] * xv[2] + gv[3] * xv[3];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      S[k] += __shfl_xor(S[k], 16, 64);
+      S[k] += __shfl_xor(S[k], 32, 64);
+    }
+    if (lg == 0 && live && d.hl != -2) {
+      const float lh = d.lh, lw = d.lw;
+      const float dm = (1.f - lh) * (1.f - lw) * S[0] + (1.f - lh) * lw * S[1] + lh * (1.f - lw) * S[2] + lh * lw * S[3];
+      const float dh = d.m * (-(1.f - lw) * S[0] - lw * S[1] + (1.f - lw) * S[2] + lw * S[3]);
+      const float dw = d.m * (-(1.f - lh) * S[0] + (1.f - lh) * S[1] - lh * S[2] + lh * S[3]);
+      const long long o = (long long)ho * g.Wo + wo;
+      atomicAdd(a.doffset + n_img * g.off_bs + (2 * tap) * hw + o, dh);
+      atomicAdd(a.doffset + n_img * g.off_bs + (2 * tap + 1) * hw + o, dw);
+      atomicAdd(a.dmask + n_img * g.msk_bs + tap * hw + o, dm);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ d x (gather-GEMM)
+// rows = input pixels q; A[q, tap*Co + co] = sum_{e in L(q,tap)} w_e dy[p_e, co]; B[c][tap*Co + co] = w_t[(tap*C + c)][co]
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void dcn2_dx_fused_kernel(DcnFusedArgs a) {
+  typedef DcnNt<T, BN> Nt;
+  constexpr int BM = Nt::BM, VEC = Nt::VEC, BK = Nt::BK, AI = Nt::AI, BI = Nt::BI, TM = Nt::TM, TN = Nt::TN;
+  __shared__ uint4 smem[8 * (BM + BN)];
+  uint4* sA = smem;
+  uint4* sB = smem + 8 * BM;
+  const DcnGeom& g = a.g;
+  const int taps = g.kh * g.kw, Co = a.Co, K = taps * Co;
+  const int tid = threadIdx.x;
+  const int tiles_n = g.C / BN;
+  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kc = tid & 7, r0 = tid >> 3;
+  const T* __restrict__ DY = (const T*)a.dy;
+  const T* __restrict__ WT = (const T*)a.w;
+
+  uint4 ra[AI], rb[BI];
+  auto load_b = [&](int k0) {
+    const int tap = k0 / Co;
+    const int co = k0 - tap * Co + kc * VEC;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) rb[i] = ldg16(WT + ((long long)(tap * g.C + n0 + r0 + 32 * i)) * Co + co);
+  };
+  auto gather_a = [&](int k0) {
+    const int tap = k0 / Co;
+    const int co = k0 - tap * Co + kc * VEC;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int q = m0 + r0 + 32 * i;
+      float accv[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) accv[j] = 0.f;
+      if (q < a.Q) {
+        const int key = q * taps + tap;
+        const int s = a.start[key], e = a.start[key + 1];
+        for (int idx = s; idx < e; ++idx) {
+          const int2 ent = a.entries[idx];
+          const float w = __int_as_float(ent.y);
+          const uint4 v = ldg16(DY + (long long)ent.x * Co + co);
+          const T* pv = (const T*)&v;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) accv[j] += w * to_f32(pv[j]);
+        }
+      }
+      ra[i] = pack_vec<T>(accv);
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm_ = wave & 1, wn_ = wave >> 1;
+  const int l15 = lane & 15, lg = lane >> 4;
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_b(0);
+  gather_a(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    Nt::store(sA, sB, ra, rb, kc, r0);
+    __syncthreads();
+    const bool more = k0 + BK < K;
+    if (more) load_b(k0 + BK);
+    Nt::mma(sA, sB, acc, wm_, wn_, l15, lg);
+    if (more) gather_a(k0 + BK);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int q = m0 + wm_ * Nt::WTM + j * 16 + l15;
+      const int n = n0 + wn_ * Nt::WTN + i * 16 + lg * 4;
+      if (q >= a.Q) continue;
+      float* dst = a.dx + (long long)q * g.C + n;
+      f32x4 v = *(const f32x4*)dst;      // accumulate semantics (the caller hands a zeroed buffer, like the reference)
+      v += acc[i][j];
+      *(f32x4*)dst = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ CSR of the scatter
+// key = q * taps + tap (q = input pixel index over the whole batch); an entry = (output pixel p, bilinear * mask weight).
+// Corners outside the image and zero weights (integer sample positions, zero masks) produce no entry.
+template <bool FILL>
+__global__ __launch_bounds__(256) void dcn_csr_kernel(const float* __restrict__ offset, const float* __restrict__ mask,
+                                                      int* __restrict__ count, const int* __restrict__ start,
+                                                      int2* __restrict__ entries, DcnGeom g, int P) {
+  const int taps = g.kh * g.kw;
+  const long long t = blockIdx.x * 256ll + threadIdx.x;
+  if (t >= (long long)P * taps) return;
+  const int p = (int)(t % P), tap = (int)(t / P);
+  const int wo = p % g.Wo, r = p / g.Wo;
+  const int ho = r % g.Ho, n = r / g.Ho;
+  const DcnDesc d = dcn_desc(g, offset, mask, n, tap, ho, wo);
+  if (d.hl == -2) return;
+  const float wgt[4] = {(1.f - d.lh) * (1.f - d.lw) * d.m, (1.f - d.lh) * d.lw * d.m, d.lh * (1.f - d.lw) * d.m,
+                        d.lh * d.lw * d.m};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int h = d.hl + (k >> 1), w = d.wl + (k & 1);
+    if (!dcn_inside(g, h, w) || wgt[k] == 0.f) continue;
+    const int key = ((n * g.H + h) * g.W + w) * taps + tap;
+    if (!FILL) {
+      atomicAdd(count + key, 1);
+    } else {
+      const int slot = atomicSub(count + key, 1) - 1;     // count returns to zero: the workspace cleans itself
+      entries[start[key] + slot] = make_int2(p, __float_as_int(wgt[k]));
+    }
+  }
+}
+
+// exclusive scan of `n` ints in three launches (2048 items per block)
+constexpr int SCAN_ITEMS = 8, SCAN_BLOCK = 256 * SCAN_ITEMS;
+
+__device__ __forceinline__ int block_excl_scan(int v, int* sh, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) sh[wave] = incl;
+  __syncthreads();
+  int woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int s = sh[w];
+    if (w < wave) woff += s;
+    tot += s;
+  }
+  __syncthreads();
+  total = tot;
+  return woff + incl - v;
+}
+
+__global__ __launch_bounds__(256) void scan_sums_kernel(const int* __restrict__ in, int* __restrict__ bsum, int n) {
+  __shared__ int sh[4];
+  const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j)
+    if (base + j < n) s += in[base + j];
+  int total;
+  block_excl_scan(s, sh, total);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void scan_blocks_kernel(int* __restrict__ bsum, int nb) {
+  __shared__ int sh[4];
+  int running = 0;
+  for (int c = 0; c < nb; c += 256) {
+    const int i = c + threadIdx.x;
+    const int v = i < nb ? bsum[i] : 0;
+    int total;
+    const int ex = block_excl_scan(v, sh, total);
+    if (i < nb) bsum[i] = running + ex;
+    running += total;
+  }
+}
+
+__global__ __launch_bounds__(256) void scan_write_kernel(const int* __restrict__ in, const int* __restrict__ bofs,
+                                                         int* __restrict__ out, int n) {
+  __shared__ int sh[4];
+  const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    v[j] = base + j < n ? in[base + j] : 0;
+    s += v[j];
+  }
+  int total;
+  int run = bofs[blockIdx.x] + block_excl_scan(s, sh, total);
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    const int idx = base + j;
+    if (idx < n) {
+      out[idx] = run;
+      run += v[j];
+      if (idx == n - 1) out[n] = run;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ d W (+ d bias)
+// C[co, nb] += sum_{p in split} dy[p, co] * sample(x)[p, nb],  nb = tap*C + c.  128 x 128 tile, 4 waves of 64 x 64,
+// LDS image / ds_read_b64_tr_b16 fragment reads of igemm_tn_kernel; the B vectors are blended from four corner loads.
+struct DcnWgradArgs {
+  const void* dy;
+  const void* x;
+  const float* offset;
+  const float* mask;
+  float* dw;       // [Co][taps*C] f32, accumulated
+  float* dbias;    // nullable [Co], accumulated by the tile_b == 0 workgroups
+  DcnGeom g;
+  int Co, P, p_chunk;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void dcn2_wgrad_fused_kernel(DcnWgradArgs a) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int BP = TnCfg<T>::BP;
+  constexpr int ROW_VECS = TnCfg<T>::ROW_VECS;
+  constexpr int ROW_BYTES = TnCfg<T>::ROW_BYTES;
+  constexpr int ROWS_PER_PASS = 256 / ROW_VECS;
+  constexpr int NI = BP / ROWS_PER_PASS;
+  constexpr bool IS_BF16 = (sizeof(T) == 2);
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BP * ROW_BYTES];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + BP * ROW_BYTES;
+  const DcnGeom& g = a.g;
+  const int taps = g.kh * g.kw, NB = taps * g.C, NA = a.Co;
+  const int tid = threadIdx.x;
+  const int tiles_b = NB / 128 + (NB % 128 != 0);
+  const int tile_b = blockIdx.x % tiles_b, tile_a = blockIdx.x / tiles_b;
+  const int na0 = tile_a * 128, nb0 = tile_b * 128;
+  const int p_begin = blockIdx.z * a.p_chunk;
+  const int p_end = min(a.P, p_begin + a.p_chunk);
+  if (p_begin >= p_end) return;
+  const T* __restrict__ A = (const T*)a.dy;
+  const T* __restrict__ X = (const T*)a.x;
+
+  const int cc = tid % ROW_VECS, rr = tid / ROW_VECS;
+  const int ca = na0 + cc * VEC, cb = nb0 + cc * VEC;
+  const bool ca_ok = ca < NA, cb_ok = cb < NB;
+  const int tap = cb_ok ? cb / g.C : 0;
+  const int tc = cb - tap * g.C;
+
+  auto lds_off = [&](int p) -> int {
+    if (IS_BF16) {
+      const int cp = cc >> 1;
+      return p * ROW_BYTES + ((cp ^ tn_hash(p)) << 5) + (cc & 1) * 16;
+    } else {
+      return p * ROW_BYTES + cc * 16;
+    }
+  };
+
+  uint4 ra[NI], rb[NI], raw[NI][4];
+  DcnDesc ds[NI];
+  const bool do_colsum = a.dbias != nullptr && tile_b == 0;
+  typedef typename std::conditional<IS_BF16, float, double>::type CsT;
+  CsT csum[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) csum[j] = 0;
+  int q_n[NI], q_h[NI], q_w[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int p = p_begin + rr + ROWS_PER_PASS * i;
+    q_w[i] = p % g.Wo;
+    const int t = p / g.Wo;
+    q_h[i] = t % g.Ho;
+    q_n[i] = t / g.Ho;
+  }
+  auto issue = [&](int p0) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = p0 + rr + ROWS_PER_PASS * i;
+      ra[i] = make_uint4(0, 0, 0, 0);
+      ds[i].m = 0.f; ds[i].lh = 0.f; ds[i].lw = 0.f; ds[i].hl = -2; ds[i].wl = -2;
+      if (p < p_end) {
+        if (ca_ok) ra[i] = ldg16(A + (long long)p * NA + ca);
+        if (cb_ok) ds[i] = dcn_desc(g, a.offset, a.mask, q_n[i], tap, q_h[i], q_w[i]);
+      }
+      dcn_corner_loads<T>(raw[i], X, g, q_n[i] * g.H * g.W, ds[i], tc);
+      q_w[i] += BP;
+      while (q_w[i] >= g.Wo) {
+        q_w[i] -= g.Wo;
+        if (++q_h[i] == g.Ho) { q_h[i] = 0; ++q_n[i]; }
+      }
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wa = wave & 1, wb = wave >> 1;
+  const int l15 = lane & 15, lg = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue(p_begin);
+  for (int p0 = p_begin; p0 < p_end; p0 += BP) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int pl = rr + ROWS_PER_PASS * i;
+      rb[i] = dcn_blend<T>(raw[i], ds[i]);
+      *(uint4*)(sA + lds_off(pl)) = ra[i];
+      *(uint4*)(sB + lds_off(pl)) = rb[i];
+      if (do_colsum) {
+        const T* pv = (const T*)&ra[i];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) csum[j] += to_f32(pv[j]);
+      }
+    }
+    __syncthreads();
+    if (p0 + BP < p_end) issue(p0 + BP);
+
+    if constexpr (IS_BF16) {
+#pragma unroll
+      for (int kk = 0; kk < BP / 32; ++kk) {
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int cpa = (wa * 64 + t * 16) >> 4;
+          const int cpb = (wb * 64 + t * 16) >> 4;
+          s16x4 x[2], y[2];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const int p = kk * 32 + lg * 8 + hh * 4 + (l15 >> 2);
+            const int h = tn_hash(p);
+            const int oa = p * ROW_BYTES + ((cpa ^ h) << 5) + (l15 & 3) * 8;
+            const int ob = p * ROW_BYTES + ((cpb ^ h) << 5) + (l15 & 3) * 8;
+            x[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(sA + oa));
+            y[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(sB + ob));
+          }
+          union { s16x4 h[2]; bf16x8 v; } ua, ub;
+          ua.h[0] = x[0]; ua.h[1] = x[1];
+          ub.h[0] = y[0]; ub.h[1] = y[1];
+          fa[t] = ua.v;
+          fb[t] = ub.v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BP / 4; ++ks) {
+        const int p = ks * 4 + lg;
+        float fa[4], fb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          fa[t] = *(const float*)(sA + p * ROW_BYTES + (wa * 64 + t * 16 + l15) * 4);
+          fb[t] = *(const float*)(sB + p * ROW_BYTES + (wb * 64 + t * 16 + l15) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  if (do_colsum) {
+    CsT* red = (CsT*)smem;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[rr * 128 + cc * VEC + j] = csum[j];
+    __syncthreads();
+    if (tid < 128 && na0 + tid < NA) {
+      CsT sum = 0;
+      for (int r = 0; r < ROWS_PER_PASS; ++r) sum += red[r * 128 + tid];
+      atomicAdd(a.dbias + na0 + tid, (float)sum);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = nb0 + wb * 64 + j * 16 + l15;
+      if (col >= NB) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = na0 + wa * 64 + i * 16 + lg * 4 + q;
+        if (row >= NA) continue;
+        atomicAdd(a.dw + (long long)row * NB + col, acc[i][j][q]);
+      }
+    }
+}
+
+static int g_dcn_fused = 1;   // mr_set_dcn_fused: 0 forces the general kernels of dcn.hip (A/B and tests)
+
+}  // namespace mr
+
+using namespace mr;
+
+namespace mr {
+
+bool dcn_fused_ok(int dtype, int H, int W, int C, int Co, int kh, int kw) {
+  (void)dtype;
+  return g_dcn_fused && C % 64 == 0 && Co % 64 == 0 && kh * kw <= DCN_MAX_TAPS && H < 32768 && W < 32768;
+}
+
+static inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+// workspace of the fused backward: [count: Q*taps ints][start: Q*taps + 1 ints][block sums][entries: 4*P*taps int2]
+struct DcnWs {
+  int* count;
+  int* start;
+  int* bsum;
+  int2* entries;
+  size_t bytes;
+  int nkeys, nblocks;
+};
+static DcnWs dcn_ws_layout(void* base, long long Q, long long P, int taps) {
+  DcnWs w;
+  const long long nkeys = Q * taps;
+  w.nkeys = (int)nkeys;
+  w.nblocks = (int)((nkeys + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  size_t o = 0;
+  unsigned char* b = (unsigned char*)base;
+  w.count = (int*)(b + o); o += align16((size_t)nkeys * 4);
+  w.start = (int*)(b + o); o += align16((size_t)(nkeys + 1) * 4);
+  w.bsum = (int*)(b + o); o += align16((size_t)w.nblocks * 4);
+  w.entries = (int2*)(b + o); o += align16((size_t)P * taps * 4 * 8);
+  w.bytes = o;
+  return w;
+}
+
+#define DISPATCH_T(dtype, ...)                                   \
+  if ((dtype) == MR_F32) { typedef float T; __VA_ARGS__; }       \
+  else if ((dtype) == MR_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+  else { mr::set_error("bad dtype %d", (dtype)); return MR_ERR_DTYPE; }
+
+int dcn_fused_fwd(int dtype, const void* x, const void* w_n, const float* bias, const float* offset, const float* mask,
+                  void* y, const DcnGeom& g, int Co, hipStream_t stream) {
+  DcnFusedArgs a = {};
+  a.x = x; a.w = w_n; a.bias = bias; a.offset = offset; a.mask = mask; a.y = y; a.g = g; a.Co = Co;
+  a.P = g.N * g.Ho * g.Wo;
+  MR_CHECK_ARG((long long)g.N * g.H * g.W * g.C < (1ll << 31) && (long long)a.P * Co < (1ll << 40), "dcn: tensor too large");
+  const int tiles_m = cdiv(a.P, 64);
+  if (Co % 128 == 0) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_fwd_fused_kernel<T, 128>), dim3(tiles_m * (Co / 128)), dim3(256), 0, stream, a));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_fwd_fused_kernel<T, 64>), dim3(tiles_m * (Co / 64)), dim3(256), 0, stream, a));
+  }
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+long long dcn_fused_ws_bytes(int N, int H, int W, int Ho, int Wo, int taps) {
+  return (long long)dcn_ws_layout(nullptr, (long long)N * H * W, (long long)N * Ho * Wo, taps).bytes;
+}
+
+int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, const float* offset, const float* mask,
+                  void* ws, float* dx32, float* doffset, float* dmask, float* dw, float* dbias, const DcnGeom& g, int Co,
+                  hipStream_t stream) {
+  const int taps = g.kh * g.kw;
+  const long long Q = (long long)g.N * g.H * g.W, P = (long long)g.N * g.Ho * g.Wo;
+  MR_CHECK_ARG(Q * taps < (1ll << 31) - SCAN_BLOCK && P * taps * 4 < (1ll << 31) && Q * g.C < (1ll << 31),
+               "dcn backward: tensor too large for 32-bit indices");
+  DcnFusedArgs a = {};
+  a.x = x; a.w = w_t; a.dy = dy; a.offset = offset; a.mask = mask; a.doffset = doffset; a.dmask = dmask; a.dx = dx32;
+  a.g = g; a.Co = Co; a.P = (int)P; a.Q = (int)Q;
+  const int tiles_p = cdiv((int)P, 64);
+  // ---- offset / mask gradients (gcol tiles stay in registers)
+  if (g.C % 128 == 0) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_coord_fused_kernel<T, 128>), dim3(tiles_p * (taps * g.C / 128)), dim3(256), 0,
+                                         stream, a));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_coord_fused_kernel<T, 64>), dim3(tiles_p * (taps * g.C / 64)), dim3(256), 0,
+                                         stream, a));
+  }
+  MR_CHECK_LAUNCH();
+  // ---- input gradient: CSR of the scatter pattern, then the gather-GEMM
+  if (dx32) {
+    MR_CHECK_ARG(ws != nullptr, "dcn backward: workspace missing (mr_dcn2_ws_bytes)");
+    DcnWs w = dcn_ws_layout(ws, Q, P, taps);
+    if (hipMemsetAsync(w.count, 0, (size_t)w.nkeys * 4, stream) != hipSuccess) {
+      mr::set_error("dcn backward: hipMemsetAsync failed");
+      return MR_ERR_LAUNCH;
+    }
+    const unsigned items = (unsigned)cdivll(P * taps, 256);
+    hipLaunchKernelGGL((dcn_csr_kernel<false>), dim3(items), dim3(256), 0, stream, offset, mask, w.count,
+                       (const int*)nullptr, (int2*)nullptr, g, (int)P);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(w.nblocks), dim3(256), 0, stream, (const int*)w.count, w.bsum, w.nkeys);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, stream, w.bsum, w.nblocks);
+    hipLaunchKernelGGL(scan_write_kernel, dim3(w.nblocks), dim3(256), 0, stream, (const int*)w.count, (const int*)w.bsum,
+                       w.start, w.nkeys);
+    hipLaunchKernelGGL((dcn_csr_kernel<true>), dim3(items), dim3(256), 0, stream, offset, mask, w.count,
+                       (const int*)w.start, w.entries, g, (int)P);
+    MR_CHECK_LAUNCH();
+    a.start = w.start;
+    a.entries = w.entries;
+    const int tiles_q = cdiv((int)Q, 64);
+    if (g.C % 128 == 0) {
+      DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_dx_fused_kernel<T, 128>), dim3(tiles_q * (g.C / 128)), dim3(256), 0, stream, a));
+    } else {
+      DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_dx_fused_kernel<T, 64>), dim3(tiles_q * (g.C / 64)), dim3(256), 0, stream, a));
+    }
+    MR_CHECK_LAUNCH();
+  }
+  // ---- weight / bias gradients
+  if (dw) {
+    DcnWgradArgs wa = {};
+    wa.dy = dy; wa.x = x; wa.offset = offset; wa.mask = mask; wa.dw = dw; wa.dbias = dbias; wa.g = g; wa.Co = Co;
+    wa.P = (int)P;
+    const int BP = dtype == MR_BF16 ? 64 : 16;
+    const int tiles = cdiv(Co, 128) * cdiv(taps * g.C, 128);
+    int splits = cdiv(512, tiles);                         // ~2 workgroups per CU
+    const int max_splits = (int)cdivll(P, 2 * BP);         // at least two p-steps per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int p_chunk = cdiv(cdiv((int)P, splits), BP) * BP;
+    splits = cdiv((int)P, p_chunk);
+    wa.p_chunk = p_chunk;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_wgrad_fused_kernel<T>), dim3(tiles, 1, splits), dim3(256), 0, stream, wa));
+    MR_CHECK_LAUNCH();
+  } else if (dbias) {
+    return mr_colsum(dtype, dy, dbias, (int)P, Co, Co, 0, stream);
+  }
+  return MR_OK;
+}
+
+}  // namespace mr
+
+extern "C" {
+
+// A/B switch (tests, tools/microbench_dcn.py): 0 = the general kernels of dcn.hip for every shape.  Returns the old value.
+int mr_set_dcn_fused(int on) {
+  const int old = g_dcn_fused;
+  g_dcn_fused = on ? 1 : 0;
+  return old;
+}
+
+}  // extern "C"

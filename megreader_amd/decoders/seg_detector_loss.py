@@ -1,27 +1,40 @@
 """Losses of the DB detector -- restatement of reference decoders/seg_detector_loss.py:157-185 (`L1BalanceCELoss`),
 balance_cross_entropy_loss.py:29-56, l1_loss.py:5-11 (MaskL1Loss) and dice_loss.py:28-42 (DiceLoss): elementwise /
-reduction torch ops on the 1-channel 640 x 640 maps (they are not MFMA or kernel material: one pass over 3 x 6.5 MB), with
-the reference's host-synchronising hard-negative count (`int(positive.float().sum())`) kept as is."""
+reduction torch ops on the 1-channel 640 x 640 maps (they are not MFMA or kernel material: one pass over 3 x 6.5 MB).
+The reference counts positives / negatives on the HOST (`int(positive.float().sum())`, a device synchronisation per step
+that also makes the step impossible to capture in a hipGraph); on GPU tensors the same quantities stay on the device:
+the hard-negative top-k with its data-dependent k becomes "sort descending, sum the first k" with k a device scalar --
+the same set of elements, the same loss and gradient (ties inside the sort carry equal values)."""
 import torch
 import torch.nn as nn
 
 
 class BalanceCrossEntropyLoss(nn.Module):
-    def __init__(self, negative_ratio=3.0, eps=1e-6):
+    def __init__(self, negative_ratio=3.0, eps=1e-6, host_counts=None):
         super().__init__()
         self.negative_ratio = negative_ratio
         self.eps = eps
+        self.host_counts = host_counts   # None: host counts for CPU tensors (the reference's code path), device counts on GPU
 
     def forward(self, pred, gt, mask, return_origin=False):
         positive = (gt * mask).byte()
         negative = ((1 - gt) * mask).byte()
-        positive_count = int(positive.float().sum())
-        negative_count = min(int(negative.float().sum()), int(positive_count * self.negative_ratio))
         loss = nn.functional.binary_cross_entropy(pred, gt, reduction='none')[:, 0, :, :]
         positive_loss = loss * positive.float()
         negative_loss = loss * negative.float()
-        negative_loss, _ = torch.topk(negative_loss.view(-1), negative_count)
-        balance_loss = (positive_loss.sum() + negative_loss.sum()) / (positive_count + negative_count + self.eps)
+        host = (not pred.is_cuda) if self.host_counts is None else self.host_counts
+        if host:   # balance_cross_entropy_loss.py:38-52 verbatim
+            positive_count = int(positive.float().sum())
+            negative_count = min(int(negative.float().sum()), int(positive_count * self.negative_ratio))
+            negative_loss, _ = torch.topk(negative_loss.view(-1), negative_count)
+            balance_loss = (positive_loss.sum() + negative_loss.sum()) / (positive_count + negative_count + self.eps)
+        else:
+            pc = positive.float().sum()
+            nc = torch.minimum(negative.float().sum(), torch.floor(pc * self.negative_ratio))
+            flat = negative_loss.view(-1)
+            srt, _ = torch.sort(flat, descending=True)
+            take = (torch.arange(flat.numel(), device=flat.device, dtype=torch.float32) < nc).to(srt.dtype)
+            balance_loss = (positive_loss.sum() + (srt * take).sum()) / (pc + nc + self.eps)
         if return_origin:
             return balance_loss, loss
         return balance_loss

@@ -99,7 +99,7 @@ class AttentionDecoderOracle(nn.Module):
         ex = self.onehot_embedding_x(ix).permute(2, 0, 1).unsqueeze(0).expand(N, -1, -1, -1)
         ey = self.onehot_embedding_y(iy).permute(2, 0, 1).unsqueeze(0).expand(N, -1, -1, -1)
         dec_in = torch.cat([seq, ey, ex], 1).reshape(N, -1, self.height * self.max_size).permute(2, 0, 1)  # [T,N,545]
-        hidden = torch.zeros(N, self.inner)
+        hidden = torch.zeros(N, self.inner, dtype=feature.dtype)
         word = torch.full((N,), self.blank, dtype=torch.long)
         if self.training:
             targets = targets.long()

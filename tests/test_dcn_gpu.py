@@ -310,11 +310,63 @@ def test_round2_backward_kernels(case):
             gy.to(DEV).contiguous(memory_format=torch.channels_last))
         return xd.grad, offd.grad, mskd.grad
 
-    ref = run()
-    old = load().mr_set_dcn_v1_bwd(0)
+    fused = load().mr_set_dcn_fused(0)      # these channel counts would otherwise take the fused kernels
     try:
-        got = run()
+        ref = run()
+        old = load().mr_set_dcn_v1_bwd(0)
+        try:
+            got = run()
+        finally:
+            load().mr_set_dcn_v1_bwd(old)
     finally:
-        load().mr_set_dcn_v1_bwd(old)
+        load().mr_set_dcn_fused(fused)
     for a, b in zip(got, ref):
         assert _rel(a, b) < 2e-3      # f32 atomics in a different order
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES[4:] + [(2, 256, 128, 14, 15, 1, 1, 1, None, 0.0), (1, 128, 192, 23, 9, 2, 1, 1, (23, 9), 8.0)])
+def test_fused_path_equals_general_path(dtype, case):
+    """The fused kernels (csrc/dcn_fused.hip: sample -> LDS -> MFMA forward, register-resident gcol for the offset / mask
+    gradients, CSR gather-GEMM input gradient, sampled TN wgrad) against the general im2col / col2im kernels on the same
+    inputs: Co != C, Co = 192 (64-column tiles), zero offsets (integer sample points: zero-weight corners produce no CSR
+    entry), offsets far outside the image (invalid samples, empty CSR rows), stride 2 with the larger offset map."""
+    from megreader_amd._lib import load
+    N, C, Co, H, W, stride, pad, dil, omap, oscale = case
+    mr.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(C + H + 3)
+    Ho = (H + 2 * pad - (dil * 2 + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * 2 + 1)) // stride + 1
+    oh, ow = omap if omap else (Ho, Wo)
+    x = torch.randn(N, C, H, W, generator=g).to(dtype)
+    off = torch.randn(N, 18, oh, ow, generator=g) * oscale
+    msk = torch.rand(N, 9, oh, ow, generator=g)
+    msk[:, 4, ::3] = 0.0                              # exact zero masks: dropped from the CSR, still get a mask gradient
+    w = torch.randn(Co, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(Co, generator=g)
+    gy = torch.randn(N, Co, Ho, Wo, generator=g).to(dtype)
+
+    def run():
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        offd, mskd = off.to(DEV).requires_grad_(True), msk.to(DEV).requires_grad_(True)
+        wd = w.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        bd = b.to(DEV).requires_grad_(True)
+        y = modulated_deform_conv(xd, offd, mskd, wd, bd, stride, pad, dil, 1, 1)
+        y.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
+        return y.detach(), xd.grad, offd.grad, mskd.grad, wd.grad, bd.grad
+
+    lib = load()
+    assert lib.mr_dcn2_ws_bytes(1 if dtype == torch.bfloat16 else 0, N, H, W, C, Co, 3, 3, Ho, Wo, 0) == 0   # fused forward
+    got = run()
+    old = lib.mr_set_dcn_fused(0)
+    try:
+        ref = run()
+    finally:
+        lib.mr_set_dcn_fused(old)
+    names = ("y", "dx", "doffset", "dmask", "dw", "dbias")
+    # same products, different summation order; in bf16 the general path also rounds gcol to bf16 before using it
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for a, r, nm in zip(got, ref, names):
+        assert a.shape == r.shape, nm
+        e = _rel(a, r)
+        assert e < tol, (nm, e)

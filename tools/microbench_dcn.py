@@ -37,16 +37,19 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--offscale", type=float, default=0.5, help="std of the random offsets in pixels")
-    ap.add_argument("--v1", type=int, default=1, help="1 (default): round-1 backward kernels, 0: round-2 experiments")
+    ap.add_argument("--v1", type=int, default=1, help="general path: 1 = round-1 backward kernels, 0 = round-2 experiments")
+    ap.add_argument("--fused", type=int, default=1, help="1 (default): fused kernels (csrc/dcn_fused.hip), 0: general path")
     a = ap.parse_args()
     dtype, dt, es = torch.bfloat16, 1, 2
     mr.set_compute_dtype(dtype)
     from megreader_amd._lib import load
     load().mr_set_dcn_v1_bwd(a.v1)
+    load().mr_set_dcn_fused(a.fused)
+    from megreader_amd._lib import dcn_workspace
     N = a.batch
     tot = {"fwd": 0.0, "bwd": 0.0}
     print("DCNv2 3x3, batch %d, bf16 activations / f32 offsets+mask, offsets ~ N(0, %.1f px), backward kernels %s; "
-          "rooflines %.0f TB/s, %.0f TFLOP/s" % (N, a.offscale, "round 1" if a.v1 else "round 2", HBM_TBS, MFMA_TFS))
+          "rooflines %.0f TB/s, %.0f TFLOP/s" % (N, a.offscale, "fused (round 3)" if a.fused else ("round 1" if a.v1 else "round 2"), HBM_TBS, MFMA_TFS))
     for name, count, C, H, s in LAYERS:
         W, Co, k, pad = H, C, 3, 1
         Ho = Wo = (H + 2 * pad - k) // s + 1
@@ -57,7 +60,7 @@ def main():
         off = torch.randn(N, 2 * k * k, Ho, Wo, device="cuda", generator=g) * a.offscale
         msk = torch.rand(N, k * k, Ho, Wo, device="cuda", generator=g)
         y = torch.empty(N, Ho, Wo, Co, device="cuda", dtype=dtype)
-        col = torch.empty(N * Ho * Wo, k * k * C, device="cuda", dtype=dtype)
+        col = dcn_workspace(dtype, N, H, W, C, Co, k, k, Ho, Wo, True, "cuda")      # >= the forward's need on both paths
         gy = torch.randn(N, Ho, Wo, Co, device="cuda", generator=g).to(dtype)
         dx32 = torch.zeros(N, H, W, C, device="cuda")
         doff, dmsk = torch.zeros_like(off), torch.zeros_like(msk)
@@ -79,7 +82,7 @@ def main():
         bw = es * Co * k * k * C
         alg_f = bx + boff + bw + by
         alg_b = alg_f + (4 * N * H * W * C) + boff + 4 * Co * k * k * C      # + dx (f32), doffset/dmask, dw (f32)
-        colb = es * P * k * k * C
+        colb = 0 if a.fused else es * P * k * k * C
         print("%-11s x%d C=%3d %3dx%-3d s%d | fwd %7.1f us: %6.1f TFLOP/s (%.3f of MFMA), alg %6.2f MB -> %5.2f TB/s "
               "(%.3f of HBM); col matrix +%6.1f MB | bwd %7.1f us: %6.1f TFLOP/s (%.3f), alg %6.2f MB -> %5.2f TB/s (%.3f)"
               % (name, count, C, H, W, s, tf, flops / tf / 1e6, flops / tf / 1e6 / MFMA_TFS, alg_f / 1e6,

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r3c1; mkdir -p $O
 nproc > $O/host.txt; free -g >> $O/host.txt
-timeout 1500 python -m pytest tests/test_attention_kernels_gpu.py tests/test_ctc2d_gpu.py tests/test_dcn_gpu.py tests/test_published_configs_gpu.py -m gpu -q -s --durations=15 > $O/pytest_new.log 2>&1
+timeout 900 python -m pytest tests/test_attention_kernels_gpu.py tests/test_ctc2d_gpu.py tests/test_dcn_gpu.py tests/test_published_configs_gpu.py -m gpu -q -s --durations=15 > $O/pytest_new.log 2>&1
 tail -40 $O/pytest_new.log
 for w in fpn_attention db; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$w -- python bench.py --workload $w --no-cpu-baseline --steps 10 --warmup 3 > $O/trace_$w.log 2>&1
