@@ -45,7 +45,7 @@ int mr_force_nt_tile(int bm, int bn);
  * returns the previous setting */
 int mr_set_nt_big(int mode);
 /* host only: 1 = phased-schedule 256x256 NT kernel (igemm_p8.h) for the big-tile launches, 0 (default) = the v3
- * kernel; 2..4 = timing-only ablations (no LDS-DMA / no fragment reads / MFMA + barriers only; wrong results) */
+ * kernel (the timing-only ablation variants 2..4 exist only in the -DMR_ABLATION tools build) */
 int mr_set_nt_p8(int on);
 /* experimental wide-tile TN (weight-gradient) kernels: 1 = 256x256, 2 = 128x256, 0 / -1 = never (default; they are
  * currently slower, see gemm_conv.hip:launch_tn); returns the previous setting */
@@ -65,16 +65,17 @@ int mr_set_tn_taps_group(int g);    /* tuning: 0 automatic, 1 atomics only, > 1 
 int mr_set_tn_group(int g);         /* same for the 128x128 TN GEMM kernel (uses the same workspace) */
 int mr_set_tn_taps_fin(int on);     /* 1: group sums added into dw by a finalize launch (measured equal), 0 (default): leaders' atomics */
 int mr_set_tn_taps_w8(int on);      /* 1: 8-wave workgroup variant (one per CU, half the partial tiles) */
-int mr_set_tn_taps_abl(int mask);   /* host only, timing only: ablation mask of the all-taps kernel (wrong results) */
 /* host only: 1 when mr_conv2d_wgrad_tab (bf16, non-NULL row table) would run the all-taps kernel for this geometry
  * under the current mr_set_tn_taps setting */
 int mr_tn_taps_would_run(int N, int H, int W, int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw,
                          int ph, int pw, int dh, int dw, int Ho, int Wo);
 int mr_set_tn_model(int m);    /* A/B: 1 = conv wgrad uses the dense-GEMM split model too */
 int mr_set_tn_splits(int n);   /* tuning only: P-split override of the TN kernels, 0 = automatic */
-/* host only, timing only: ablation mask of the TN kernel (1 no LDS-DMA, 2 no fragment reads, 4 no atomic epilogue,
- * 8 no column sums); results are wrong for mask != 0 */
-int mr_set_tn_abl(int mask);
+/* The process-global mr_set_* / mr_force_* switches in this header are TEST / TUNING hooks (A/B comparisons of kernels that
+ * all compute the same result): they are not thread-safe and are not meant to be flipped while a training step is in flight.
+ * The timing-only ABLATION switches whose kernels produce WRONG results by construction (mr_set_tn_abl, mr_set_tn_taps_abl,
+ * mr_set_nt_p8(2..4)) are not part of this library: they are declared in include/megreader_hip_ablation.h and exist only in
+ * the separate `make ablation` build (libmegreader_hip_abl.so, -DMR_ABLATION) that tools/ablate_*.py load. */
 /* tile (BM*1000+BN) the NT kernels pick for an M x N problem; host-only query used for profiling labels */
 int mr_nt_tile_code(int M, int N);
 /* same, including the big-tile policy (returns 256256 for the 8-wave 256x256 kernel); cg = channels of the gathered
@@ -375,6 +376,27 @@ int mr_embed_rows_fwd(int dtype, const long long* idx, const float* table, void*
                       hipStream_t stream);
 int mr_embed_rows_bwd(int dtype, const long long* idx, const void* dout, float* dtable, int N, int V, int D, int ldo,
                       hipStream_t stream);
+/* round-3 decode loop (one autograd Function for the 32 steps, megreader_amd/decoders/attention_decoder.py): the same math as
+ * the step kernels above with strided operands -- hproj / gh are column slices (leading dimensions ldh / ldgh) of ONE stacked
+ * GEMM output per step, gi_a rows are gathered from a [classes, 3H] table through idx (nullable), the three consumers of h'
+ * are summed inside mr_gru_bwd2 (dh_a / dh_b / dh_c nullable), mr_attn_bwd2 runs on a (N, Hd/64) grid and leaves the
+ * encoder-side gradient to ONE mr_attn_denc launch after the loop (denc[n,t,c] = sum_s weights[s,n,t] * dcontext[s,n,c]),
+ * mr_rows_scatter_add is the gradient of the table gather (f32 atomics into dtable [V][D]). */
+int mr_attn_fwd2(int dtype, const void* hproj, long long ldh, const void* eproj, const float* v, const void* enc,
+                 float* weights, void* context, int N, int Tn, int Hd, int Ep, hipStream_t stream);
+int mr_attn_bwd2(int dtype, const void* dcontext, const float* dweights, long long ldw, const void* hproj, long long ldh,
+                 const void* eproj, const float* v, const void* enc, const float* weights, void* dhproj, long long lddh,
+                 float* deproj, float* dv, int N, int Tn, int Hd, int Ep, hipStream_t stream);
+int mr_attn_denc(int dtype, const float* weights, const void* dcontext, void* denc, int S, int N, int Tn, int Ep,
+                 hipStream_t stream);
+int mr_gru_fwd2(int dtype, const void* gi_a, long long lda, const long long* idx, const void* gi_b, const void* gh,
+                long long ldgh, const void* h, void* hnew, float* save, int N, int H, hipStream_t stream);
+int mr_gru_bwd2(int dtype, const void* dh_a, const void* dh_b, const void* dh_c, const float* save, const void* gh,
+                long long ldgh, const void* h, void* dgi, void* dgh, long long lddgh, void* dh_prev, int N, int H,
+                hipStream_t stream);
+int mr_rows_scatter_add(int dtype, const long long* idx, const void* rows, long long ldr, float* dtable, int R, int V,
+                        int D, hipStream_t stream);
+
 /* eval head: softmax over classes of logits [T,N,C] -> f32 [N,C,1,T] (decoders/crnn.py:101-104) */
 int mr_softmax_nc1t(int dtype, const void* logits, int ldl, float* out, int T, int N, int C, hipStream_t stream);
 

@@ -10,7 +10,8 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmegreader_hip.so")
+LIB_PATH = os.environ.get("MEGREADER_HIP_LIB") or os.path.join(_HERE, "csrc", "libmegreader_hip.so")   # tools/ablate_*.py
+# point MEGREADER_HIP_LIB at the separate -DMR_ABLATION build
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "megreader_hip.h")
 
 MR_F32 = 0
@@ -79,6 +80,12 @@ SIGNATURES = {
     "mr_gru_gates_bwd": "ipppppppiis",
     "mr_embed_rows_fwd": "ipppiiiis",
     "mr_embed_rows_bwd": "ipppiiiis",
+    "mr_attn_fwd2": "iplpppppiiiis",
+    "mr_attn_bwd2": "ipplplppppplppiiiis",
+    "mr_attn_denc": "ipppiiiis",
+    "mr_gru_fwd2": "iplppplpppiis",
+    "mr_gru_bwd2": "ippppplppplpiis",
+    "mr_rows_scatter_add": "ipplpiiis",
     "mr_nll_step_fwd": "ipiplppppiiiis",
     "mr_nll_step_bwd": "ippplppiiis",
     "mr_ctc_greedy_decode": "iplll" + "iiiii" + "pps",
@@ -140,8 +147,11 @@ def load():
     lib.mr_set_tn_model.argtypes = [ctypes.c_int]
     lib.mr_set_tn_splits.restype = ctypes.c_int
     lib.mr_set_tn_splits.argtypes = [ctypes.c_int]
-    lib.mr_set_tn_abl.restype = ctypes.c_int
-    lib.mr_set_tn_abl.argtypes = [ctypes.c_int]
+    if hasattr(lib, "mr_set_tn_abl"):      # only libmegreader_hip_abl.so (tools build, include/megreader_hip_ablation.h)
+        lib.mr_set_tn_abl.restype = ctypes.c_int
+        lib.mr_set_tn_abl.argtypes = [ctypes.c_int]
+        lib.mr_set_tn_taps_abl.restype = ctypes.c_int
+        lib.mr_set_tn_taps_abl.argtypes = [ctypes.c_int]
     lib.mr_set_tn_taps.restype = ctypes.c_int
     lib.mr_set_tn_taps.argtypes = [ctypes.c_int]
     lib.mr_set_tn_taps_workspace.restype = ctypes.c_int
@@ -156,8 +166,6 @@ def load():
     lib.mr_set_tn_taps_fin.argtypes = [ctypes.c_int]
     lib.mr_set_tn_taps_w8.restype = ctypes.c_int
     lib.mr_set_tn_taps_w8.argtypes = [ctypes.c_int]
-    lib.mr_set_tn_taps_abl.restype = ctypes.c_int
-    lib.mr_set_tn_taps_abl.argtypes = [ctypes.c_int]
     lib.mr_tn_taps_would_run.restype = ctypes.c_int
     lib.mr_tn_taps_would_run.argtypes = [ctypes.c_int] * 17
     lib.mr_set_tn_big.restype = ctypes.c_int
@@ -190,8 +198,8 @@ def load():
 
 
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_set_nt_variant", "mr_force_nt_tile",
-             "mr_stem_bwd_workspace", "mr_set_lstm_variant", "mr_set_nt_big", "mr_set_lstm_persist", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_set_nt_p8", "mr_set_tn_abl", "mr_set_tn_splits", "mr_set_tn_model", "mr_set_dcn_v1_bwd", "mr_set_dcn_fused", "mr_dcn2_ws_bytes", "mr_bn_scratch_doubles", "mr_sizeof_img_desc",
-             "mr_nt_kernel_code", "mr_set_tn_taps", "mr_tn_taps_would_run", "mr_set_tn_taps_abl", "mr_set_tn_taps_w8", "mr_set_tn_taps_fin", "mr_set_tn_taps_workspace", "mr_set_tn_taps_group", "mr_set_tn_group", "mr_set_bn_fused", "mr_set_tn_big", "mr_set_tn_buf", "mr_sizeof_prep_job")  # entry points that take no stream and launch nothing
+             "mr_stem_bwd_workspace", "mr_set_lstm_variant", "mr_set_nt_big", "mr_set_lstm_persist", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_set_nt_p8", "mr_set_tn_splits", "mr_set_tn_model", "mr_set_dcn_v1_bwd", "mr_set_dcn_fused", "mr_dcn2_ws_bytes", "mr_bn_scratch_doubles", "mr_sizeof_img_desc",
+             "mr_nt_kernel_code", "mr_set_tn_taps", "mr_tn_taps_would_run", "mr_set_tn_taps_w8", "mr_set_tn_taps_fin", "mr_set_tn_taps_workspace", "mr_set_tn_taps_group", "mr_set_tn_group", "mr_set_bn_fused", "mr_set_tn_big", "mr_set_tn_buf", "mr_sizeof_prep_job")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

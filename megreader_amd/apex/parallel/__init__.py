@@ -9,8 +9,10 @@ reduced in place with no flatten/unflatten copies; otherwise the bucket is packe
 end-of-backward callback launches incomplete buckets (parameters that received no gradient, e.g. the unused
 ``cbr_deepsup`` / ``fc`` weights listed in SURVEY.md §8a), waits for the side stream and scales by 1/world.
 
-xGMI is a point-to-point mesh: large buckets (default 32 MiB) keep RCCL in its bandwidth regime and let it use all
-seven links; the whole CRNN gradient (33 MB) is a single bucket.
+xGMI is a point-to-point mesh: large buckets keep RCCL in its bandwidth regime and let it use all seven links, but ONE
+bucket means the exchange starts only when the first layer's gradient lands, i.e. after backward.  The bucket size is
+therefore min(message_size, total / MIN_BUCKETS): at least four buckets, so the decoder / LSTM / upper-conv gradients
+(8 MB pieces for the CRNN's 33 MB) travel while the lower convolutions are still in backward.
 """
 import torch
 import torch.distributed as dist
@@ -18,6 +20,7 @@ import torch.nn as nn
 
 
 _PAD = 64  # megreader_amd.optim._ALIGN: parameter slices of the flat buffers start on 64-element boundaries
+MIN_BUCKETS = 4
 
 
 def _engine_callback(fn):
@@ -26,7 +29,7 @@ def _engine_callback(fn):
 
 class DistributedDataParallel(nn.Module):
     def __init__(self, module, message_size=8 * 1024 * 1024, delay_allreduce=False, gradient_average=True,
-                 process_group=None, **_ignored):
+                 process_group=None, min_buckets=MIN_BUCKETS, **_ignored):
         super().__init__()
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised before DistributedDataParallel(...)")
@@ -35,8 +38,9 @@ class DistributedDataParallel(nn.Module):
         self.world_size = dist.get_world_size(process_group)
         self.gradient_average = gradient_average
         self.delay_allreduce = delay_allreduce
-        self.bucket_elems = int(message_size)
         self._params = [p for p in module.parameters() if p.requires_grad]
+        total = sum(p.numel() for p in self._params)
+        self.bucket_elems = max(1, min(int(message_size), -(-total // max(1, int(min_buckets)))))
         self._use_side_stream = len(self._params) > 0 and self._params[0].is_cuda
         self._stream = torch.cuda.Stream() if self._use_side_stream else None
         # rank 0's weights and buffers define the model (apex behaviour)
@@ -57,11 +61,11 @@ class DistributedDataParallel(nn.Module):
         for bi, bucket in enumerate(self._buckets):
             for p in bucket:
                 self._bucket_of[p] = bi
-        self._ready = [set() for _ in self._buckets]
         self._launched = [False] * len(self._buckets)
-        # parameters known to receive more than one gradient contribution per backward (weight sharing): their bucket
-        # is only launched from the end-of-backward callback.  Filled by `mark_shared(param)`.
+        # parameters known to receive more than one gradient contribution per backward (weight sharing), filled by
+        # `mark_shared(param)`: a parameter is complete after `uses` hook firings, a bucket when ALL its parameters are
         self._uses = {}
+        self._fires = {}
         self._pending = []  # (bucket index, flat tensor, staged?, work handle)
         self._callback_queued = False
         for p in self._params:
@@ -76,7 +80,21 @@ class DistributedDataParallel(nn.Module):
     def mark_shared(self, param, uses=2):
         """Declare that `param` is used `uses` times per forward (its gradient is complete only after that many
         accumulations): its bucket is then reduced from the end-of-backward callback instead of the first hook."""
-        self._uses[id(param)] = uses
+        self._uses[id(param)] = int(uses)
+
+    def fold_average_into(self, optimizer):
+        """Let a fused optimizer (megreader_amd.optim) apply the 1 / world_size of the gradient average inside its update
+        kernel: the shim then only sums (no `flat.mul_` pass over the reduced buffers).  Every parameter of this module must
+        be owned by `optimizer`."""
+        owned = {id(p) for group in optimizer.param_groups for p in group['params']}
+        if not all(id(p) in owned for p in self._params):
+            raise ValueError("fold_average_into: the optimizer does not own every parameter of the wrapped module")
+        if self.gradient_average:
+            optimizer.set_grad_scale(1.0 / self.world_size)
+            self.gradient_average = False
+
+    def _bucket_complete(self, bi):
+        return all(self._fires.get(id(p), 0) >= self._uses.get(id(p), 1) for p in self._buckets[bi])
 
     # ------------------------------------------------------------------ hooks
     def _make_hook(self):
@@ -87,10 +105,10 @@ class DistributedDataParallel(nn.Module):
             if self.delay_allreduce:
                 return
             bi = self._bucket_of[param]
-            # readiness is tracked per parameter: a module used twice in one forward fires its sink hook twice
-            self._ready[bi].add(id(param))
-            if len(self._ready[bi]) == len(self._buckets[bi]) and not self._launched[bi] and \
-                    self._uses.get(id(param), 1) <= 1:
+            # readiness is counted per parameter: a shared parameter (mark_shared) is complete only after `uses` firings,
+            # and the bucket is launched by whichever parameter completes it LAST (not only by the shared one)
+            self._fires[id(param)] = self._fires.get(id(param), 0) + 1
+            if not self._launched[bi] and self._bucket_complete(bi):
                 self._launch(bi)
         return hook
 
@@ -149,7 +167,7 @@ class DistributedDataParallel(nn.Module):
             work.wait()  # RCCL: the current (main) stream waits for the collective; host does not block
             self._finish_bucket(bucket, flat, staged, scale)
         self._pending = []
-        self._ready = [set() for _ in self._buckets]
+        self._fires = {}
         self._launched = [False] * len(self._buckets)
         self._callback_queued = False
 

@@ -249,6 +249,217 @@ __global__ void embed_rows_bwd_kernel(const long long* __restrict__ idx, const T
   if (r >= 0 && r < V) atomicAdd(dtable + r * D + c, to_f32(dout[(long long)n * ldo + c]));
 }
 
+
+// =====================================================================================================================
+// Round-3 decode-loop kernels (megreader_amd/decoders/attention_decoder.py:_DecodeLoopFn): the 32-step loop runs as ONE
+// autograd Function with 6 launches per step forward and 6 backward (11 / ~20 + ATen adds before).  What changed for the
+// kernels: operands are column slices of wider per-step buffers (leading dimensions instead of contiguous tensors: hproj and
+// the hidden GRU projection come out of ONE GEMM against the stacked [W_attn_h; W_hh]), the word path is a row gather from a
+// precomputed [classes, 3H] table, the backward attention kernel is parallel over (sample, 64-unit slice) instead of one
+// workgroup per sample (76.8 us per launch at N = 32, profiles/r03_fpn_attention_kernel_stats_v0_baseline.csv), and the
+// encoder-side gradient sum_s w_s dcontext_s is ONE kernel after the loop instead of a read-modify-write per step.
+// =====================================================================================================================
+
+// energy / softmax / context of one decode step; hproj rows have leading dimension ldh.  512 threads per sample.
+template <typename T>
+__global__ __launch_bounds__(512) void attn_fwd2_kernel(const T* __restrict__ hproj, long long ldh,
+                                                        const T* __restrict__ eproj, const float* __restrict__ v,
+                                                        const T* __restrict__ enc, float* __restrict__ weights,
+                                                        T* __restrict__ context, int Tn, int Hd, int Ep) {
+  __shared__ float en[64];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T* hp = hproj + (long long)n * ldh;
+  for (int t = wave; t < Tn; t += 8) {
+    const T* ep = eproj + ((long long)n * Tn + t) * Hd;
+    float s = 0.f;
+    for (int j = lane; j < Hd; j += 64) s += v[j] * tanhf(to_f32(hp[j]) + to_f32(ep[j]));
+    s = wave_sum(s);
+    if (lane == 0) en[t] = s;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float e = lane < Tn ? en[lane] : -INFINITY;
+    const float mx = wave_max(e);
+    float ex = lane < Tn ? expf(e - mx) : 0.f;
+    const float sm = wave_sum(ex);
+    if (lane < Tn) {
+      en[lane] = ex / sm;
+      weights[(long long)n * Tn + lane] = ex / sm;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < Ep; c += 512) {
+    float s = 0.f;
+    for (int t = 0; t < Tn; ++t) s += en[t] * to_f32(enc[((long long)n * Tn + t) * Ep + c]);
+    context[(long long)n * Ep + c] = from_f32<T>(s);
+  }
+}
+
+// backward of one step, grid (N, Hd / 64): every workgroup redoes the cheap part (dw = dcontext . enc, softmax backward)
+// and owns a 64-unit slice of the tanh chain: dhproj (written, leading dimension lddh), deproj (+=), dv (atomics).
+// The encoder-side gradient (denc) is NOT touched here: attn_denc_kernel sums it over the steps after the loop.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd2_kernel(const T* __restrict__ dcontext,
+                                                        const float* __restrict__ dweights, long long ldw,
+                                                        const T* __restrict__ hproj, long long ldh,
+                                                        const T* __restrict__ eproj, const float* __restrict__ v,
+                                                        const T* __restrict__ enc, const float* __restrict__ weights,
+                                                        T* __restrict__ dhproj, long long lddh,
+                                                        float* __restrict__ deproj, float* __restrict__ dv, int Tn,
+                                                        int Hd, int Ep) {
+  __shared__ float dw[64], de[64], red[4][64], redv[4][64];
+  const int n = blockIdx.x, js = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int t = wave; t < Tn; t += 4) {
+    float s = 0.f;
+    for (int c = lane; c < Ep; c += 64)
+      s += to_f32(dcontext[(long long)n * Ep + c]) * to_f32(enc[((long long)n * Tn + t) * Ep + c]);
+    s = wave_sum(s);
+    if (lane == 0) dw[t] = s + (dweights ? dweights[(long long)n * ldw + t] : 0.f);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float w = lane < Tn ? weights[(long long)n * Tn + lane] : 0.f;
+    const float d = lane < Tn ? dw[lane] : 0.f;
+    const float dot = wave_sum(w * d);
+    if (lane < Tn) de[lane] = w * (d - dot);
+  }
+  __syncthreads();
+  // unit j = js*64 + lane; wave w handles the positions t = w, w+4, ...
+  const int j = js * 64 + lane;
+  float dh = 0.f, dvj = 0.f;
+  if (j < Hd) {
+    const float hj = to_f32(hproj[(long long)n * ldh + j]);
+    const float vj = v[j];
+    for (int t = wave; t < Tn; t += 4) {
+      const long long o = ((long long)n * Tn + t) * Hd + j;
+      const float th = tanhf(hj + to_f32(eproj[o]));
+      const float gg = de[t] * vj * (1.f - th * th);
+      dh += gg;
+      deproj[o] += gg;
+      dvj += de[t] * th;
+    }
+  }
+  red[wave][lane] = dh;
+  redv[wave][lane] = dvj;
+  __syncthreads();
+  if (wave == 0 && j < Hd) {
+    dhproj[(long long)n * lddh + j] = from_f32<T>(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    atomicAdd(dv + j, redv[0][lane] + redv[1][lane] + redv[2][lane] + redv[3][lane]);
+  }
+}
+
+// denc[n, t, c] = sum_s weights[s, n, t] * dcontext[s, n, c]   (one launch after the loop; grid (N, ceil(Ep / 256)))
+template <typename T>
+__global__ __launch_bounds__(256) void attn_denc_kernel(const float* __restrict__ weights, const T* __restrict__ dcontext,
+                                                        T* __restrict__ denc, int S, int N, int Tn, int Ep) {
+  extern __shared__ float wsh[];   // [S][Tn]
+  const int n = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+  for (int i = threadIdx.x; i < S * Tn; i += 256) {
+    const int s = i / Tn, t = i - s * Tn;
+    wsh[i] = weights[((long long)s * N + n) * Tn + t];
+  }
+  __syncthreads();
+  if (c >= Ep) return;
+  for (int t0 = 0; t0 < Tn; t0 += 32) {
+    float acc[32];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) acc[t] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float d = to_f32(dcontext[((long long)s * N + n) * Ep + c]);
+#pragma unroll
+      for (int t = 0; t < 32; ++t)
+        if (t0 + t < Tn) acc[t] += wsh[s * Tn + t0 + t] * d;
+    }
+#pragma unroll
+    for (int t = 0; t < 32; ++t)
+      if (t0 + t < Tn) denc[((long long)n * Tn + t0 + t) * Ep + c] = from_f32<T>(acc[t]);
+  }
+}
+
+// GRU gates with strided operands: gi_a row = idx ? idx[n] : n (row gather from the word table), gh with leading dimension
+// ldgh (a column slice of the stacked hidden projection).
+template <typename T>
+__global__ void gru_fwd2_kernel(const T* __restrict__ gi_a, long long lda, const long long* __restrict__ idx,
+                                const T* __restrict__ gi_b, const T* __restrict__ gh, long long ldgh,
+                                const T* __restrict__ h, T* __restrict__ hnew, float* __restrict__ save, int N, int H) {
+  const long long total = (long long)N * H;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % H);
+    const long long n = i / H;
+    const T* ga = gi_a + (idx ? idx[n] : n) * lda;
+    const T* gb = gi_b ? gi_b + n * 3 * H : nullptr;
+    const T* hh = gh + n * ldgh;
+    float ir = to_f32(ga[j]), iz = to_f32(ga[H + j]), in_ = to_f32(ga[2 * H + j]);
+    if (gb) {
+      ir += to_f32(gb[j]);
+      iz += to_f32(gb[H + j]);
+      in_ += to_f32(gb[2 * H + j]);
+    }
+    const float hr = to_f32(hh[j]), hz = to_f32(hh[H + j]), hn = to_f32(hh[2 * H + j]);
+    const float r = sigmoidf_(ir + hr), z = sigmoidf_(iz + hz);
+    const float nn_ = tanhf_(in_ + r * hn);
+    const float hp = to_f32(h[i]);
+    hnew[i] = from_f32<T>((1.f - z) * nn_ + z * hp);
+    const long long b3 = n * 3 * H;
+    save[b3 + j] = r;
+    save[b3 + H + j] = z;
+    save[b3 + 2 * H + j] = nn_;
+  }
+}
+
+// dh' = dh_a + dh_b + dh_c (nullable parts: the three consumers of h' -- output layer, next step's stacked projection, next
+// step's z * h path -- are summed here instead of by separate add kernels); dgi [N,3H] contiguous, dgh with leading dimension
+// lddgh, dh_prev [N,H] = dh' * z.
+template <typename T>
+__global__ void gru_bwd2_kernel(const T* __restrict__ dh_a, const T* __restrict__ dh_b, const T* __restrict__ dh_c,
+                                const float* __restrict__ save, const T* __restrict__ gh, long long ldgh,
+                                const T* __restrict__ h, T* __restrict__ dgi, T* __restrict__ dgh, long long lddgh,
+                                T* __restrict__ dh_prev, int N, int H) {
+  const long long total = (long long)N * H;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % H);
+    const long long n = i / H;
+    const long long b3 = n * 3 * H;
+    const float r = save[b3 + j], z = save[b3 + H + j], nn_ = save[b3 + 2 * H + j];
+    const float hn = to_f32(gh[n * ldgh + 2 * H + j]);
+    const float hp = to_f32(h[i]);
+    float g = 0.f;
+    if (dh_a) g += to_f32(dh_a[i]);
+    if (dh_b) g += to_f32(dh_b[i]);
+    if (dh_c) g += to_f32(dh_c[i]);
+    const float dn = g * (1.f - z);
+    const float dz = g * (hp - nn_);
+    const float dpre_n = dn * (1.f - nn_ * nn_);
+    const float dr = dpre_n * hn;
+    const float dpre_r = dr * r * (1.f - r);
+    const float dpre_z = dz * z * (1.f - z);
+    dgi[b3 + j] = from_f32<T>(dpre_r);
+    dgi[b3 + H + j] = from_f32<T>(dpre_z);
+    dgi[b3 + 2 * H + j] = from_f32<T>(dpre_n);
+    T* dg = dgh + n * lddgh;
+    dg[j] = from_f32<T>(dpre_r);
+    dg[H + j] = from_f32<T>(dpre_z);
+    dg[2 * H + j] = from_f32<T>(dpre_n * r);
+    dh_prev[i] = from_f32<T>(g * z);
+  }
+}
+
+// dtable[idx[r], :] += rows[r, :]   (f32 atomics; R rows of D columns, row stride ldr) -- gradient of the word-table gather
+template <typename T>
+__global__ void rows_scatter_add_kernel(const long long* __restrict__ idx, const T* __restrict__ rows, long long ldr,
+                                        float* __restrict__ dtable, int R, int V, int D) {
+  const long long total = (long long)R * D;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D);
+    const long long r = i / D;
+    const long long t = idx[r];
+    if (t >= 0 && t < V) atomicAdd(dtable + t * D + c, to_f32(rows[r * ldr + c]));
+  }
+}
+
 }  // namespace mr
 
 using namespace mr;
@@ -334,6 +545,66 @@ int mr_embed_rows_bwd(int dtype, const long long* idx, const void* dout, float* 
   MR_CHECK_ARG(N > 0 && V > 0 && D > 0 && ldo >= D, "mr_embed_rows_bwd: bad shape N=%d V=%d D=%d ldo=%d", N, V, D, ldo);
   DISPATCH_T(dtype, hipLaunchKernelGGL((embed_rows_bwd_kernel<T>), dim3(grid_for((long long)N * D, 256)), dim3(256), 0,
                                        stream, idx, (const T*)dout, dtable, N, V, D, ldo));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+// ---- round-3 decode-loop entry points (kernels documented above; strided operands, see include/megreader_hip.h)
+int mr_attn_fwd2(int dtype, const void* hproj, long long ldh, const void* eproj, const float* v, const void* enc,
+                 float* weights, void* context, int N, int Tn, int Hd, int Ep, hipStream_t stream) {
+  MR_CHECK_ARG(N > 0 && Tn > 0 && Tn <= 64 && Hd > 0 && Ep > 0 && ldh >= Hd, "mr_attn_fwd2: bad shape (T must be <= 64)");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((attn_fwd2_kernel<T>), dim3(N), dim3(512), 0, stream, (const T*)hproj, ldh,
+                                       (const T*)eproj, v, (const T*)enc, weights, (T*)context, Tn, Hd, Ep));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_attn_bwd2(int dtype, const void* dcontext, const float* dweights, long long ldw, const void* hproj, long long ldh,
+                 const void* eproj, const float* v, const void* enc, const float* weights, void* dhproj, long long lddh,
+                 float* deproj, float* dv, int N, int Tn, int Hd, int Ep, hipStream_t stream) {
+  MR_CHECK_ARG(N > 0 && Tn > 0 && Tn <= 64 && ldh >= Hd && lddh >= Hd, "mr_attn_bwd2: bad shape");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((attn_bwd2_kernel<T>), dim3(N, cdiv(Hd, 64)), dim3(256), 0, stream,
+                                       (const T*)dcontext, dweights, ldw, (const T*)hproj, ldh, (const T*)eproj, v,
+                                       (const T*)enc, weights, (T*)dhproj, lddh, deproj, dv, Tn, Hd, Ep));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_attn_denc(int dtype, const float* weights, const void* dcontext, void* denc, int S, int N, int Tn, int Ep,
+                 hipStream_t stream) {
+  MR_CHECK_ARG(S > 0 && N > 0 && Tn > 0 && (long long)S * Tn * 4 <= 48 * 1024, "mr_attn_denc: bad shape (S*T*4 must fit 48 KB)");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((attn_denc_kernel<T>), dim3(N, cdiv(Ep, 256)), dim3(256), (size_t)S * Tn * 4, stream,
+                                       weights, (const T*)dcontext, (T*)denc, S, N, Tn, Ep));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_gru_fwd2(int dtype, const void* gi_a, long long lda, const long long* idx, const void* gi_b, const void* gh,
+                long long ldgh, const void* h, void* hnew, float* save, int N, int H, hipStream_t stream) {
+  MR_CHECK_ARG(N > 0 && H > 0 && lda >= 3 * H && ldgh >= 3 * H, "mr_gru_fwd2: bad shape");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((gru_fwd2_kernel<T>), dim3(grid_for((long long)N * H, 256)), dim3(256), 0, stream,
+                                       (const T*)gi_a, lda, idx, (const T*)gi_b, (const T*)gh, ldgh, (const T*)h,
+                                       (T*)hnew, save, N, H));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_gru_bwd2(int dtype, const void* dh_a, const void* dh_b, const void* dh_c, const float* save, const void* gh,
+                long long ldgh, const void* h, void* dgi, void* dgh, long long lddgh, void* dh_prev, int N, int H,
+                hipStream_t stream) {
+  MR_CHECK_ARG(N > 0 && H > 0 && ldgh >= 3 * H && lddgh >= 3 * H, "mr_gru_bwd2: bad shape");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((gru_bwd2_kernel<T>), dim3(grid_for((long long)N * H, 256)), dim3(256), 0, stream,
+                                       (const T*)dh_a, (const T*)dh_b, (const T*)dh_c, save, (const T*)gh, ldgh,
+                                       (const T*)h, (T*)dgi, (T*)dgh, lddgh, (T*)dh_prev, N, H));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_rows_scatter_add(int dtype, const long long* idx, const void* rows, long long ldr, float* dtable, int R, int V,
+                        int D, hipStream_t stream) {
+  MR_CHECK_ARG(R > 0 && V > 0 && D > 0 && ldr >= D, "mr_rows_scatter_add: bad shape");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((rows_scatter_add_kernel<T>), dim3(grid_for((long long)R * D, 256)), dim3(256), 0,
+                                       stream, idx, (const T*)rows, ldr, dtable, R, V, D));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

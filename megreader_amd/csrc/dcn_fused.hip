@@ -160,27 +160,26 @@ __global__ __launch_bounds__(256) void dcn2_fwd_fused_kernel(DcnFusedArgs a) {
   }
   __syncthreads();
 
-  uint4 raw[AI][4], ra[AI], rb[BI];
-  auto issue = [&](int k0) {
+  // two k-steps of corner / weight loads are in flight (slots 0 / 1): a step's loads are issued two steps before their
+  // blend, so they have a whole MFMA + blend + barrier round to land (one step ahead measured latency-bound: 1.7 us per
+  // k-step, profiles/r03_dcn_microbench_b16_fused_kernel_stats_v1.csv)
+  uint4 raw[2][AI][4], rbq[2][BI], ra[AI];
+  auto issue = [&](int k0, auto slot_c) {
+    constexpr int SL = decltype(slot_c)::value;
     const int tap = k0 / g.C;
     const int c = k0 - tap * g.C + kc * VEC;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int row = r0 + 32 * i;
       const DcnDesc d = dcn_unpack(sdesc[tap * BM + row]);
-      dcn_corner_loads<T>(raw[i], X, g, spix[row], d, c);
+      dcn_corner_loads<T>(raw[SL][i], X, g, spix[row], d, c);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int n = n0 + r0 + 32 * i;
-      rb[i] = make_uint4(0, 0, 0, 0);
-      if (n < a.Co) rb[i] = ldg16(Wn + (long long)n * K + k0 + kc * VEC);
+      rbq[SL][i] = make_uint4(0, 0, 0, 0);
+      if (n < a.Co) rbq[SL][i] = ldg16(Wn + (long long)n * K + k0 + kc * VEC);
     }
-  };
-  auto finish = [&](int k0) {
-    const int tap = k0 / g.C;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) ra[i] = dcn_blend<T>(raw[i], dcn_unpack(sdesc[tap * BM + r0 + 32 * i]));
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -192,14 +191,24 @@ __global__ __launch_bounds__(256) void dcn2_fwd_fused_kernel(DcnFusedArgs a) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    finish(k0);
-    Nt::store(sA, sB, ra, rb, kc, r0);
+  auto step = [&](int k0, auto slot_c) {
+    constexpr int SL = decltype(slot_c)::value;
+    const int tap = k0 / g.C;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) ra[i] = dcn_blend<T>(raw[SL][i], dcn_unpack(sdesc[tap * BM + r0 + 32 * i]));
+    Nt::store(sA, sB, ra, rbq[SL], kc, r0);
     __syncthreads();
-    if (k0 + BK < K) issue(k0 + BK);   // corner / weight loads stay in flight under the MFMAs
+    if (k0 + 2 * BK < K) issue(k0 + 2 * BK, slot_c);   // refill the slot just consumed
     Nt::mma(sA, sB, acc, wm_, wn_, l15, lg);
     __syncthreads();
+  };
+  typedef std::integral_constant<int, 0> S0;
+  typedef std::integral_constant<int, 1> S1;
+  issue(0, S0());
+  if (BK < K) issue(BK, S1());
+  for (int k0 = 0; k0 < K; k0 += 2 * BK) {
+    step(k0, S0());
+    if (k0 + BK < K) step(k0 + BK, S1());
   }
 
   T* __restrict__ Y = (T*)a.y;
@@ -260,7 +269,50 @@ __global__ __launch_bounds__(256) void dcn2_coord_fused_kernel(DcnFusedArgs a) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // the epilogue's sample descriptors (three dependent f32 loads per pixel) are fetched BEFORE the GEMM loop, which hides them
+  const int tap = n0 / g.C, cbase = n0 - tap * g.C;
+  const long long hw = (long long)g.Ho * g.Wo;
+  DcnDesc dsc[TM];
+  int e_n[TM], e_ho[TM], e_wo[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + wm_ * Nt::WTM + j * 16 + l15;
+    dsc[j] = dcn_desc_invalid();
+    e_n[j] = 0; e_ho[j] = 0; e_wo[j] = 0;
+    if (m < a.P) {
+      e_wo[j] = m % g.Wo;
+      const int r = m / g.Wo;
+      e_ho[j] = r % g.Ho;
+      e_n[j] = r / g.Ho;
+      dsc[j] = dcn_desc(g, a.offset, a.mask, e_n[j], tap, e_ho[j], e_wo[j]);
+    }
+  }
+
   load(0);
+  // bf16: the epilogue's corner vectors of x (4 corners x TN x 8 bytes per pixel) are requested now as well and land while the
+  // GEMM loop runs (f32 would need 128 registers for them: fetched in the epilogue instead)
+  constexpr bool PREFETCH_X = sizeof(T) == 2;
+  typedef typename std::conditional<sizeof(T) == 2, uint2, uint4>::type XV;   // 4 channels of T
+  XV xq[PREFETCH_X ? TM : 1][4][TN];
+  auto corner_ptr = [&](int j, int k) -> const T* {
+    const int h = dsc[j].hl + (k >> 1), w = dsc[j].wl + (k & 1);
+    if (!dcn_inside(g, h, w)) return nullptr;
+    return X + ((long long)(e_n[j] * g.H * g.W + h * g.W + w)) * g.C + cbase + wn_ * Nt::WTN + lg * 4;
+  };
+  if constexpr (PREFETCH_X) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const T* xp = corner_ptr(j, k);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          XV z;
+          __builtin_memset(&z, 0, sizeof(z));
+          xq[j][k][i] = xp ? *(const XV*)(xp + i * 16) : z;
+        }
+      }
+  }
   for (int k0 = 0; k0 < K; k0 += BK) {
     Nt::store(sA, sB, ra, rb, kc, r0);
     __syncthreads();
@@ -271,32 +323,26 @@ __global__ __launch_bounds__(256) void dcn2_coord_fused_kernel(DcnFusedArgs a) {
 
   // epilogue: lane (l15, lg) holds gcol[pixel m][4 channels] per (i, j).  S_k = sum_c gcol * x[corner k]; the three
   // gradients are linear combinations of S_1..S_4 (deform_conv_cuda_kernel.cu:694-766 restated per corner).
-  const int tap = n0 / g.C, cbase = n0 - tap * g.C;
-  const long long hw = (long long)g.Ho * g.Wo;
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int m = m0 + wm_ * Nt::WTM + j * 16 + l15;
     const bool live = m < a.P;
-    int n_img = 0, ho = 0, wo = 0;
-    DcnDesc d;
-    d.m = 0.f; d.lh = 0.f; d.lw = 0.f; d.hl = -2; d.wl = -2;
-    if (live) {
-      wo = m % g.Wo;
-      const int r = m / g.Wo;
-      ho = r % g.Ho;
-      n_img = r / g.Ho;
-      d = dcn_desc(g, a.offset, a.mask, n_img, tap, ho, wo);
-    }
-    const int pb = n_img * g.H * g.W;
+    const int n_img = e_n[j], ho = e_ho[j], wo = e_wo[j];
+    const DcnDesc d = dsc[j];
     float S[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int h = d.hl + (k >> 1), w = d.wl + (k & 1);
-      if (!dcn_inside(g, h, w)) continue;
-      const T* xp = X + ((long long)(pb + h * g.W + w)) * g.C + cbase + wn_ * Nt::WTN + lg * 4;
+      const T* xp = PREFETCH_X ? nullptr : corner_ptr(j, k);
+      if (!PREFETCH_X && !xp) continue;
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
-        const f32x4 xv = load4(xp + i * 16);
+        f32x4 xv;
+        if constexpr (PREFETCH_X) {
+          const T* pv = (const T*)&xq[j][k][i];
+          xv[0] = to_f32(pv[0]); xv[1] = to_f32(pv[1]); xv[2] = to_f32(pv[2]); xv[3] = to_f32(pv[3]);
+        } else {
+          xv = load4(xp + i * 16);
+        }
         const f32x4 gv = acc[i][j];
         S[k] += gv[0] * xv[0] + gv[1] * xv[1] + gv[2] * xv[2] + gv[3] * xv[3];
       }
@@ -321,11 +367,25 @@ __global__ __launch_bounds__(256) void dcn2_coord_fused_kernel(DcnFusedArgs a) {
 
 // ------------------------------------------------------------------------------------------------ d x (gather-GEMM)
 // rows = input pixels q; A[q, tap*Co + co] = sum_{e in L(q,tap)} w_e dy[p_e, co]; B[c][tap*Co + co] = w_t[(tap*C + c)][co]
+//
+// The CSR keys are tap-major (key = tap*Q + q), so the entry lists of the 64 rows of a tile for one tap form ONE contiguous
+// segment of the entry array.  A k-step (tap, 64-wide co chunk) therefore runs a BALANCED gather: the 256 threads load the
+// segment's entries and dy vectors in lock step (entry e -> threads 8e..8e+7, 16 bytes each) into an LDS stage, and only then
+// does every (row, chunk) thread sum its row's slice of the stage -- LDS latency, not global latency, multiplied by the
+// longest list.  (One thread walking its own row's list against global memory measured 445-600 us per layer with 71 % of the
+// wave cycles in s_waitcnt / barrier: the k-step of a workgroup costs max-over-64-rows dependent load pairs.)
+// Pipeline: the entries of step s+2 and the dy vectors of step s+1 are in flight while step s runs its MFMAs.
+constexpr int DX_LCAP = 256;   // entries staged per round (32 KB of LDS at 128 B per entry)
+
 template <typename T, int BN>
 __global__ __launch_bounds__(256) void dcn2_dx_fused_kernel(DcnFusedArgs a) {
   typedef DcnNt<T, BN> Nt;
   constexpr int BM = Nt::BM, VEC = Nt::VEC, BK = Nt::BK, AI = Nt::AI, BI = Nt::BI, TM = Nt::TM, TN = Nt::TN;
+  constexpr int GJ = DX_LCAP / 32;
   __shared__ uint4 smem[8 * (BM + BN)];
+  __shared__ uint4 sG[DX_LCAP * 8];
+  __shared__ int2 sE[DX_LCAP];
+  __shared__ int sstart[DCN_MAX_TAPS * (BM + 1)];
   uint4* sA = smem;
   uint4* sB = smem + 8 * BM;
   const DcnGeom& g = a.g;
@@ -338,36 +398,67 @@ __global__ __launch_bounds__(256) void dcn2_dx_fused_kernel(DcnFusedArgs a) {
   const T* __restrict__ DY = (const T*)a.dy;
   const T* __restrict__ WT = (const T*)a.w;
 
-  uint4 ra[AI], rb[BI];
+  for (int idx = tid; idx < taps * (BM + 1); idx += 256) {
+    const int tap = idx / (BM + 1), r = idx - tap * (BM + 1);
+    const int q = min(m0 + r, a.Q);
+    sstart[idx] = a.start[(long long)tap * a.Q + q];
+  }
+  __syncthreads();
+
+  uint4 ra[AI], rb[BI], gq[GJ];
+  int2 entC[GJ], entN[GJ];
   auto load_b = [&](int k0) {
     const int tap = k0 / Co;
     const int co = k0 - tap * Co + kc * VEC;
 #pragma unroll
     for (int i = 0; i < BI; ++i) rb[i] = ldg16(WT + ((long long)(tap * g.C + n0 + r0 + 32 * i)) * Co + co);
   };
-  auto gather_a = [&](int k0) {
+  // entries [base, base + cnt) of the tile's segment for the tap of k-step k0: entry e is handled by threads 8e .. 8e+7
+  auto load_entries = [&](int2 (&ent)[GJ], int base, int cnt) {
+#pragma unroll
+    for (int j = 0; j < GJ; ++j) {
+      const int e = r0 + 32 * j;
+      ent[j] = make_int2(-1, 0);
+      if (e < cnt) ent[j] = a.entries[base + e];
+    }
+  };
+  auto load_dy = [&](const int2 (&ent)[GJ], int k0) {
     const int tap = k0 / Co;
     const int co = k0 - tap * Co + kc * VEC;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int q = m0 + r0 + 32 * i;
-      float accv[VEC];
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) accv[j] = 0.f;
-      if (q < a.Q) {
-        const int key = q * taps + tap;
-        const int s = a.start[key], e = a.start[key + 1];
-        for (int idx = s; idx < e; ++idx) {
-          const int2 ent = a.entries[idx];
-          const float w = __int_as_float(ent.y);
-          const uint4 v = ldg16(DY + (long long)ent.x * Co + co);
-          const T* pv = (const T*)&v;
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) accv[j] += w * to_f32(pv[j]);
-        }
-      }
-      ra[i] = pack_vec<T>(accv);
+    for (int j = 0; j < GJ; ++j) {
+      gq[j] = make_uint4(0, 0, 0, 0);
+      if (ent[j].x >= 0) gq[j] = ldg16(DY + (long long)ent[j].x * Co + co);
     }
+  };
+  auto stage = [&](const int2 (&ent)[GJ]) {
+#pragma unroll
+    for (int j = 0; j < GJ; ++j) {
+      const int e = r0 + 32 * j;
+      sG[e * 8 + kc] = gq[j];
+      if (kc == 0) sE[e] = ent[j];
+    }
+  };
+  float accv[AI][VEC];
+  auto reduce_rows = [&](int tap, int base, int cnt) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int row = r0 + 32 * i;
+      const int lo = min(max(sstart[tap * (BM + 1) + row] - base, 0), cnt);
+      const int hi = min(max(sstart[tap * (BM + 1) + row + 1] - base, 0), cnt);
+      for (int idx = lo; idx < hi; ++idx) {
+        const float w = __int_as_float(sE[idx].y);
+        const uint4 v = sG[idx * 8 + kc];
+        const T* pv = (const T*)&v;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) accv[i][j] += w * to_f32(pv[j]);
+      }
+    }
+  };
+  auto seg_base = [&](int k0) { return sstart[(k0 / Co) * (BM + 1)]; };
+  auto seg_cnt = [&](int k0) {
+    const int t = k0 / Co;
+    return min(sstart[t * (BM + 1) + BM] - sstart[t * (BM + 1)], DX_LCAP);   // first round only
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -379,15 +470,43 @@ __global__ __launch_bounds__(256) void dcn2_dx_fused_kernel(DcnFusedArgs a) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  load_entries(entC, seg_base(0), seg_cnt(0));
   load_b(0);
-  gather_a(0);
+  load_dy(entC, 0);
+  if (BK < K) load_entries(entN, seg_base(BK), seg_cnt(BK));
   for (int k0 = 0; k0 < K; k0 += BK) {
+    const int tap = k0 / Co;
+    const int s0 = sstart[tap * (BM + 1)], s1 = sstart[tap * (BM + 1) + BM];
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) accv[i][j] = 0.f;
+    // round 0: the stage registers were filled while the previous step's MFMAs ran
+    stage(entC);
+    __syncthreads();
+    reduce_rows(tap, s0, min(s1 - s0, DX_LCAP));
+    for (int base = s0 + DX_LCAP; base < s1; base += DX_LCAP) {   // segments longer than the stage (rare): unpipelined rounds
+      const int cnt = min(s1 - base, DX_LCAP);
+      int2 ent[GJ];
+      load_entries(ent, base, cnt);
+      load_dy(ent, k0);
+      __syncthreads();            // everybody is done reading the previous round's stage
+      stage(ent);
+      __syncthreads();
+      reduce_rows(tap, base, cnt);
+    }
+#pragma unroll
+    for (int i = 0; i < AI; ++i) ra[i] = pack_vec<T>(accv[i]);
     Nt::store(sA, sB, ra, rb, kc, r0);
     __syncthreads();
-    const bool more = k0 + BK < K;
-    if (more) load_b(k0 + BK);
+    if (k0 + BK < K) {
+#pragma unroll
+      for (int j = 0; j < GJ; ++j) entC[j] = entN[j];
+      load_dy(entC, k0 + BK);
+      load_b(k0 + BK);
+      if (k0 + 2 * BK < K) load_entries(entN, seg_base(k0 + 2 * BK), seg_cnt(k0 + 2 * BK));
+    }
     Nt::mma(sA, sB, acc, wm_, wn_, l15, lg);
-    if (more) gather_a(k0 + BK);
     __syncthreads();
   }
 
@@ -406,7 +525,9 @@ __global__ __launch_bounds__(256) void dcn2_dx_fused_kernel(DcnFusedArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ CSR of the scatter
-// key = q * taps + tap (q = input pixel index over the whole batch); an entry = (output pixel p, bilinear * mask weight).
+// key = tap * Q + q (q = input pixel index over the whole batch; tap-major, so that the neighbouring pixels a wave handles
+// hit neighbouring counters -- pixel-major keys measured 28 G atomics/s, one cache line per atomic); an entry = (output
+// pixel p, bilinear * mask weight).
 // Corners outside the image and zero weights (integer sample positions, zero masks) produce no entry.
 template <bool FILL>
 __global__ __launch_bounds__(256) void dcn_csr_kernel(const float* __restrict__ offset, const float* __restrict__ mask,
@@ -426,7 +547,7 @@ __global__ __launch_bounds__(256) void dcn_csr_kernel(const float* __restrict__ 
   for (int k = 0; k < 4; ++k) {
     const int h = d.hl + (k >> 1), w = d.wl + (k & 1);
     if (!dcn_inside(g, h, w) || wgt[k] == 0.f) continue;
-    const int key = ((n * g.H + h) * g.W + w) * taps + tap;
+    const long long key = (long long)tap * ((long long)g.N * g.H * g.W) + ((n * g.H + h) * g.W + w);   // tap-major
     if (!FILL) {
       atomicAdd(count + key, 1);
     } else {
@@ -570,7 +691,17 @@ __global__ __launch_bounds__(256) void dcn2_wgrad_fused_kernel(DcnWgradArgs a) {
   CsT csum[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) csum[j] = 0;
-  int q_n[NI], q_h[NI], q_w[NI];
+  // three-stage software pipeline over the p-steps (one stage measured 10 us per p-step: the corner loads wait for the
+  // offset / mask loads they depend on, and the MFMAs queue behind both):
+  //   stage_a(s + 2): offset (dh, dw) and mask floats of the rows of step s + 2
+  //   stage_b(s + 1): descriptors from the floats fetched a step ago, then the dy vector + four corner loads
+  //   step s        : blend -> LDS -> MFMAs
+  int q_n[NI], q_h[NI], q_w[NI];        // pixel of stage_a's next call
+  int b_n[NI], b_h[NI], b_w[NI];        // pixel + raw floats handed from stage_a to stage_b
+  float b_oh[NI], b_ow[NI], b_m[NI];
+  bool b_ok[NI];
+  int pa = p_begin;                     // first row of stage_a's next call
+  int pbq = p_begin;                    // first row of stage_b's next call
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int p = p_begin + rr + ROWS_PER_PASS * i;
@@ -579,23 +710,39 @@ __global__ __launch_bounds__(256) void dcn2_wgrad_fused_kernel(DcnWgradArgs a) {
     q_h[i] = t % g.Ho;
     q_n[i] = t / g.Ho;
   }
-  auto issue = [&](int p0) {
+  const long long hwo = (long long)g.Ho * g.Wo;
+  auto stage_a = [&]() {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int p = p0 + rr + ROWS_PER_PASS * i;
-      ra[i] = make_uint4(0, 0, 0, 0);
-      ds[i].m = 0.f; ds[i].lh = 0.f; ds[i].lw = 0.f; ds[i].hl = -2; ds[i].wl = -2;
-      if (p < p_end) {
-        if (ca_ok) ra[i] = ldg16(A + (long long)p * NA + ca);
-        if (cb_ok) ds[i] = dcn_desc(g, a.offset, a.mask, q_n[i], tap, q_h[i], q_w[i]);
+      const int p = pa + rr + ROWS_PER_PASS * i;
+      b_n[i] = q_n[i]; b_h[i] = q_h[i]; b_w[i] = q_w[i];
+      b_ok[i] = p < p_end && cb_ok;
+      b_oh[i] = 0.f; b_ow[i] = 0.f; b_m[i] = 0.f;
+      if (b_ok[i]) {
+        const long long o = (long long)q_h[i] * g.Wo + q_w[i];
+        const float* ob = a.offset + q_n[i] * g.off_bs + (2 * tap) * hwo + o;
+        b_oh[i] = ob[0];
+        b_ow[i] = ob[hwo];
+        b_m[i] = a.mask[q_n[i] * g.msk_bs + tap * hwo + o];
       }
-      dcn_corner_loads<T>(raw[i], X, g, q_n[i] * g.H * g.W, ds[i], tc);
       q_w[i] += BP;
       while (q_w[i] >= g.Wo) {
         q_w[i] -= g.Wo;
         if (++q_h[i] == g.Ho) { q_h[i] = 0; ++q_n[i]; }
       }
     }
+    pa += BP;
+  };
+  auto stage_b = [&]() {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = pbq + rr + ROWS_PER_PASS * i;
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (p < p_end && ca_ok) ra[i] = ldg16(A + (long long)p * NA + ca);
+      ds[i] = b_ok[i] ? dcn_desc_from(g, tap, b_h[i], b_w[i], b_oh[i], b_ow[i], b_m[i]) : dcn_desc_invalid();
+      dcn_corner_loads<T>(raw[i], X, g, b_n[i] * g.H * g.W, ds[i], tc);
+    }
+    pbq += BP;
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -607,7 +754,9 @@ __global__ __launch_bounds__(256) void dcn2_wgrad_fused_kernel(DcnWgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  issue(p_begin);
+  stage_a();
+  stage_b();
+  stage_a();
   for (int p0 = p_begin; p0 < p_end; p0 += BP) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -622,7 +771,10 @@ __global__ __launch_bounds__(256) void dcn2_wgrad_fused_kernel(DcnWgradArgs a) {
       }
     }
     __syncthreads();
-    if (p0 + BP < p_end) issue(p0 + BP);
+    if (p0 + BP < p_end) {
+      stage_b();     // rows of step s + 1: their offset / mask floats were requested a step ago
+      stage_a();     // floats of step s + 2
+    }
 
     if constexpr (IS_BF16) {
 #pragma unroll

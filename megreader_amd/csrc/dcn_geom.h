@@ -29,26 +29,40 @@ struct DcnDesc {
   int hl, wl;
 };
 
+__device__ __forceinline__ DcnDesc dcn_desc_invalid() {
+  DcnDesc d;
+  d.m = 0.f; d.lh = 0.f; d.lw = 0.f; d.hl = -2; d.wl = -2;
+  return d;
+}
+
+// descriptor from already-loaded offset (dh, dw) and mask values -- lets a kernel fetch the three floats a pipeline stage
+// ahead of the corner loads that depend on them
+__device__ __forceinline__ DcnDesc dcn_desc_from(const DcnGeom& g, int tap, int ho, int wo, float off_h, float off_w,
+                                                 float m) {
+  const int i = tap / g.kw, j = tap - i * g.kw;
+  const float ph = (float)(ho * g.stride - g.pad + i * g.dil) + off_h;
+  const float pw = (float)(wo * g.stride - g.pad + j * g.dil) + off_w;
+  if (!(ph > -1.f && pw > -1.f && ph < (float)g.H && pw < (float)g.W)) return dcn_desc_invalid();
+  DcnDesc d;
+  const float fh = floorf(ph), fw = floorf(pw);
+  d.m = m;
+  d.hl = (int)fh;
+  d.wl = (int)fw;
+  d.lh = ph - fh;
+  d.lw = pw - fw;
+  return d;
+}
+
 __device__ __forceinline__ DcnDesc dcn_desc(const DcnGeom& g, const float* __restrict__ offset,
                                             const float* __restrict__ mask, int n, int tap, int ho, int wo) {
-  DcnDesc d;
-  float ph, pw;
-  if (dcn_point(g, offset + n * g.off_bs, tap, ho, wo, ph, pw)) {
-    d.m = mask[n * g.msk_bs + ((long long)tap * g.Ho + ho) * g.Wo + wo];
-    const float fh = floorf(ph), fw = floorf(pw);
-    d.hl = (int)fh;
-    d.wl = (int)fw;
-    d.lh = ph - fh;
-    d.lw = pw - fw;
-  } else {
-    d.m = 0.f; d.lh = 0.f; d.lw = 0.f; d.hl = -2; d.wl = -2;
-  }
-  return d;
+  const long long hw = (long long)g.Ho * g.Wo, o = (long long)ho * g.Wo + wo;
+  const float* ob = offset + n * g.off_bs + (2 * tap) * hw + o;
+  return dcn_desc_from(g, tap, ho, wo, ob[0], ob[hw], mask[n * g.msk_bs + tap * hw + o]);
 }
 
 // packed 16-byte form for LDS tables
 __device__ __forceinline__ float4 dcn_pack(const DcnDesc& d) {
-  const int hw = (d.hl & 0xffff) | (d.wl << 16);
+  const int hw = (d.hl & 0xffff) | (int)((unsigned)d.wl << 16);
   return make_float4(d.lh, d.lw, d.m, __int_as_float(hw));
 }
 __device__ __forceinline__ DcnDesc dcn_unpack(const float4& v) {

@@ -356,6 +356,9 @@ __global__ void accumulate_multi_kernel(AccumSegs segs) {
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, const float* __restrict__ hyper) {
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], step = hyper[5];
+  // hyper[6]: scale applied to the raw gradient (data parallel: 1 / world size folded into the update instead of a
+  // separate pass over the flat gradient buffer after the all-reduce); 0 = unset = 1
+  const float gs = hyper[6] != 0.f ? hyper[6] : 1.f;
   const float bc1 = 1.f - powf(b1, step);
   const float bc2 = 1.f - powf(b2, step);
   const float step_size = lr / bc1;
@@ -366,7 +369,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float gr = gg[j];
+      float gr = gg[j] * gs;
       if (wd != 0.f) gr += wd * pp[j];
       mm[j] = b1 * mm[j] + (1.f - b1) * gr;
       vv[j] = b2 * vv[j] + (1.f - b2) * gr * gr;
@@ -379,7 +382,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)
     for (long long i = nv * 4; i < n; ++i) {
-      float gr = g[i];
+      float gr = g[i] * gs;
       if (wd != 0.f) gr += wd * p[i];
       m[i] = b1 * m[i] + (1.f - b1) * gr;
       v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
@@ -393,12 +396,29 @@ __global__ void adam_tick_kernel(float* hyper) { hyper[5] += 1.f; }
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long long n,
                            const float* __restrict__ hyper) {
   const float lr = hyper[0], mu = hyper[1], wd = hyper[4], step = hyper[5];
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float gr = g[i] + wd * p[i];
-    float b = (step <= 1.f) ? gr : mu * buf[i] + gr;
-    buf[i] = b;
-    p[i] -= lr * b;
+  const float gs = hyper[6] != 0.f ? hyper[6] : 1.f;   // gradient scale (1 / world size), see adam_kernel
+  const bool first = step <= 1.f;
+  const long long nv = n / 4;      // the flat buffers are 256-byte aligned and padded to 64 elements (optim.py)
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 pp = ((f32x4*)p)[i], bb = ((f32x4*)buf)[i];
+    const f32x4 gg = ((const f32x4*)g)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = gg[j] * gs + wd * pp[j];
+      const float b = first ? gr : mu * bb[j] + gr;
+      bb[j] = b;
+      pp[j] -= lr * b;
+    }
+    ((f32x4*)buf)[i] = bb;
+    ((f32x4*)p)[i] = pp;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long long i = nv * 4; i < n; ++i) {
+      const float gr = g[i] * gs + wd * p[i];
+      const float b = first ? gr : mu * buf[i] + gr;
+      buf[i] = b;
+      p[i] -= lr * b;
+    }
 }
 
 }  // namespace mr
@@ -568,7 +588,7 @@ int mr_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
 
 int mr_sgd_step(float* p, const float* g, float* buf, long long n, float* hyper, hipStream_t stream) {
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, hyper);
-  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, p, g, buf, n,
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, p, g, buf, n,
                      (const float*)hyper);
   MR_CHECK_LAUNCH();
   return MR_OK;

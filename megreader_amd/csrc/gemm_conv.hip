@@ -94,7 +94,9 @@ static int num_cus() {
 // ---- big-tile (8-wave) NT kernel: bf16, dense or fast-gather conv operands ---------------------------------------
 // g_big_mode: 0 = automatic (nt_big_choice), -1 = never, 1 = always 256x256, 2 = always 288x256 (tuning override)
 static int g_big_mode = 0;
+#ifdef MR_ABLATION
 static int g_tn_abl = 0;  // timing-only ablation mask of the TN kernel (mr_set_tn_abl)
+#endif
 static int g_tn_model = 1;   // 1 (default): the measured split model for the conv wgrad launches too; 0: the old one (A/B)
 static int g_tn_splits = 0;  // > 0: split count override of launch_tn (mr_set_tn_splits, tuning only)
 static int g_tn_buf = 1;  // TN kernel staging through buffer resources (mr_set_tn_buf); measured 4 % faster
@@ -222,10 +224,13 @@ static int launch_nt_p8(const NtArgs& a, const ConvGeom& g, void* C, long long l
     }                                                                                                             \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a2, g, epi);                                     \
   }
-    if (g_use_p8 == 2) MR_P8_LAUNCH(1)          // measurement-only ablations (mr_set_nt_p8(2..4))
+#ifdef MR_ABLATION   // measurement-only ablations (mr_set_nt_p8(2..4)); wrong results: tools-only build
+    if (g_use_p8 == 2) MR_P8_LAUNCH(1)
     else if (g_use_p8 == 3) MR_P8_LAUNCH(2)
     else if (g_use_p8 == 4) MR_P8_LAUNCH(3)
-    else MR_P8_LAUNCH(0)
+    else
+#endif
+    MR_P8_LAUNCH(0)
 #undef MR_P8_LAUNCH
     MR_CHECK_LAUNCH();
     return MR_OK;
@@ -355,7 +360,9 @@ static int launch_tn_big(TnArgs a, const ConvGeom& g, int total_steps, hipStream
   }
   a.p_chunk = cdiv(cdiv(a.P, bsplits), 64) * 64;
   bsplits = cdiv(a.P, a.p_chunk);
+#ifdef MR_ABLATION
   if (g_tn_abl & 8) a.colsum = nullptr;   // timing-only: no fused column sums (wrong bias gradient)
+#endif
   constexpr int lds = 2 * (SA + 2) * 64 * 256 + 1024;  // 2 stages x [A.. | B0 | B1] x 16 KB + column-sum accumulator
   auto kern = igemm_tn_big_kernel<BMODE, SA>;
   static bool attr_set = false;
@@ -438,12 +445,15 @@ static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
       const long long bytesA = (long long)a.P * a.lda * 2;
       const long long bytesB = BMODE == 0 ? (long long)a.P * a.ldb * 2
                                           : ((long long)a.P / ((long long)g.Hm * g.Wm) + 1) * g.Hg * g.Wg * g.ldg * 2;
+#ifdef MR_ABLATION
       if (g_tn_abl && bytesA < (1ll << 31) && bytesB < (1ll << 31)) {   // timing-only ablations (mr_set_tn_abl)
 #define MR_TN_ABL(V_) case V_: hipLaunchKernelGGL((igemm_tn_glds_kernel<BMODE, true, V_>), dim3(tiles * splits), \
                                                    dim3(256), 0, stream, a, g, z); break;
         switch (g_tn_abl) { MR_TN_ABL(1) MR_TN_ABL(2) MR_TN_ABL(3) MR_TN_ABL(4) MR_TN_ABL(8) MR_TN_ABL(15) default: break; }
 #undef MR_TN_ABL
-      } else if (g_tn_buf && bytesA < (1ll << 31) && bytesB < (1ll << 31))
+      } else
+#endif
+      if (g_tn_buf && bytesA < (1ll << 31) && bytesB < (1ll << 31))
         hipLaunchKernelGGL((igemm_tn_glds_kernel<BMODE, true>), dim3(tiles * splits), dim3(256), 0, stream, a, g, z);
       else
         hipLaunchKernelGGL((igemm_tn_glds_kernel<BMODE, false>), dim3(tiles * splits), dim3(256), 0, stream, a, g, z);
@@ -480,7 +490,11 @@ int mr_set_nt_variant(int v) {
 // Returns the previous setting.
 int mr_set_nt_p8(int on) {
   const int old = g_use_p8;
+#ifdef MR_ABLATION
   g_use_p8 = (on >= 0 && on <= 4) ? on : 1;   // 2..4: ablation variants of the phased kernel (timing only)
+#else
+  g_use_p8 = on ? 1 : 0;                      // the wrong-result ablation variants exist only in the MR_ABLATION build
+#endif
   return old;
 }
 
@@ -496,11 +510,13 @@ int mr_set_nt_big(int mode) {
 // Operands must be < 2 GiB in buffer mode.  Returns the previous setting.
 // timing-only: ablation mask of igemm_tn_glds_kernel (1 no LDS-DMA, 2 no fragment reads, 4 no atomic epilogue,
 // 8 no column sums; supported: 0, 1, 2, 3, 4, 8, 15).  Wrong results for mask != 0.
+#ifdef MR_ABLATION
 int mr_set_tn_abl(int mask) {
   const int old = g_tn_abl;
   g_tn_abl = mask;
   return old;
 }
+#endif
 
 // A/B: 1 (default) = the conv wgrad launches use the measured split model as well (CRNN: neutral, Res50-PPM-2D-CTC:
 // wgrad 62 -> 57 us per launch, step 14.30 -> 14.01 ms), 0 = the round-1 model.  Returns the previous setting.
@@ -547,7 +563,9 @@ int mr_set_tn_taps_fin(int on) { return taps_set_fin(on); }
 int mr_set_tn_taps_w8(int on) { return taps_set_w8(on); }
 
 // host only, timing only: ablation mask of the all-taps kernel (results are wrong for mask != 0)
+#ifdef MR_ABLATION
 int mr_set_tn_taps_abl(int mask) { return taps_set_abl(mask); }
+#endif
 
 // host only: 1 when mr_conv2d_wgrad_tab would run the all-taps kernel for this geometry (bf16, row table of
 // N*Ho*Wo*8 bytes) under the current mr_set_tn_taps setting, else 0

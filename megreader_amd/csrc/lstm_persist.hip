@@ -27,7 +27,8 @@
 // (global_load_dwordx2 sc1): placement-independent, no dependence on dispatch order beyond co-residency of the 4
 // members of a group.  tag = step + 1 (never 0); the exchange buffer is zeroed by a memset node ahead of every launch;
 // two slots alternate (a producer can run at most one step ahead of its slowest consumer).  Every spin is bounded:
-// on timeout the workgroup records a code in the status word and stops waiting (results garbage, no hang).
+// on timeout the workgroup records a code in the status word, stops waiting (no hang) and POISONS its outputs with NaN, so
+// the failure reaches the loss / the gradients instead of silently corrupting a training run.
 #include "common.h"
 #include "igemm_core.h"
 #include "../../include/megreader_hip.h"
@@ -253,6 +254,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
       hv[i] = og * ftanh(c);
       gt[i][0] = ig; gt[i][1] = fg; gt[i][2] = gg; gt[i][3] = og;
     }
+    // a timed-out hand-off must never pass as a result: poison this workgroup's hidden state with NaN from here on, so the
+    // layer output, the loss and every gradient of the step are NaN and any training loop sees it (the status
+    // word alone is only read by tests)
+    if (dead) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hv[i] = __builtin_nanf("");
+    }
     const unsigned h01 = pack_bf16(hv[0], hv[1]), h23 = pack_bf16(hv[2], hv[3]);
     if (s + 1 < a.T) {
       // publish FIRST (the hand-off is the critical path), then the own slice into the next step's LDS tile
@@ -378,6 +386,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
         for (int k = 0; k < 3; ++k) sum += __uint_as_float(v[k * 2 + (e >> 1)][(e & 1) * 2]);
         dh[e] += sum;
       }
+    }
+    // a timed-out hand-off poisons the gradients of this workgroup's rows with NaN (see the forward kernel)
+    if (dead) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dh[e] = __builtin_nanf("");
     }
     // ---- gate algebra (EpiLstmBwd of lstm.hip with dc carried in registers)
     float dg[4][4];

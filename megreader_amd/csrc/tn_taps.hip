@@ -464,8 +464,10 @@ int taps_set_w8(int on) { const int old = g_taps_w8; if (on == 0 || on == 1) g_t
 static int g_taps_fin = 0;
 int taps_set_fin(int on) { const int old = g_taps_fin; if (on == 0 || on == 1) g_taps_fin = on; return old; }
 
+#ifdef MR_ABLATION
 static int g_taps_abl = 0;
 int taps_set_abl(int mask) { const int old = g_taps_abl; g_taps_abl = mask; return old; }
+#endif
 
 int launch_tn_taps(const TapsProblem& p, int splits_override, hipStream_t stream) {
   const TapsLayout l = taps_layout(p.N, p.H, p.W, p.dil);
@@ -527,6 +529,7 @@ int launch_tn_taps(const TapsProblem& p, int splits_override, hipStream_t stream
     }
     attr_set[w8] = true;
   }
+#ifdef MR_ABLATION
   if (g_taps_abl && !w8) {
     a.fin = 0;
 #define MR_TAPS_ABL(V_) case V_: { auto k2 = igemm_tn_taps_kernel<2, 1, V_>; \
@@ -539,6 +542,7 @@ int launch_tn_taps(const TapsProblem& p, int splits_override, hipStream_t stream
     MR_CHECK_LAUNCH();
     return MR_OK;
   }
+#endif
   if (w8)
     hipLaunchKernelGGL((igemm_tn_taps_kernel<2, 1, 0, true>), dim3(tiles * splits), dim3(threads), lds, stream, a);
   else

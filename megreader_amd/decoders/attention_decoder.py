@@ -6,7 +6,15 @@ initialisation order, same forward contract (training: `(loss[N], attention[N, m
 eval: `pred[N, max_size] int32`), same teacher-forcing coin (`np.random.rand() < 0.5` unless `gt_as_output` is set,
 quirk Q16) and the same loss mask `timestep <= lengths`.
 
-What runs where: the 7-conv encoder uses the HIP conv/BN/pool layers; each decode step is
+What runs where: the 7-conv encoder uses the HIP conv/BN/pool layers.  TRAINING runs the 32 decode steps inside ONE autograd
+Function (`_DecodeLoopFn`, round 3): per step forward
+  [GEMM h -> (hproj | gh)] -> attn_fwd2 -> [GEMM context -> gi_c] -> gru_fwd2 (word part gathered from a table) -> [GEMM out] -> nll
+(6 launches; 11 before) and 6 launches backward (about 20 plus autograd's ATen adds before): the word path
+embedding -> word_linear -> W_ih[:, :H] only depends on the class index, so it is a [classes, 3H] table computed once per
+forward; W_attn[:, :H] and W_hh share their input and are one stacked GEMM; every weight gradient is ONE transpose-read
+GEMM over all 32 steps after the loop (per-step inputs / output gradients live in [S, N, .] buffers that the step kernels
+write in place); the encoder-side attention gradient is one kernel after the loop.  Eval (greedy decode with early stop)
+keeps the per-step path:
   [GEMM word] -> [GEMM hproj] -> attn_step -> [GEMMs gi_w, gi_c, gh] -> gru_gates -> [GEMM out] -> nll_step
 with the GEMMs on the MFMA NT/TN kernels.  The reference's per-step Linear(1057 -> 512) over cat([hidden x T, enc])
 is split algebraically into hidden and encoder halves, so the encoder half (eproj) is one GEMM per sequence.
@@ -209,6 +217,121 @@ class _NllStepFn(Function):
         return d, None, None, None
 
 
+class _DecodeLoopFn(Function):
+    """All `S` steps of AttentionRNNCell (reference decoders/attention_decoder.py:84-118, 146-231) forward and backward.
+
+    inputs : G [C, 3H] word table (dtype), eproj [N,T,H], enc [N,T,Ep] (dtype), v [H], w_ah = attn.attn.weight[:, :H],
+             w_hh, b_hh, w_ic = rnn.weight_ih[:, H:H+E], w_out, b_out, targets_t [S,N] i64, lengths [N], flags (S bools:
+             teacher forcing per step), meta = (dtype, C, blank)
+    outputs: loss [N] f32 = sum_s NLL_s * (s <= length);  attention [N, S, T] f32"""
+
+    @staticmethod
+    def forward(ctx, G, eproj, enc, v, w_ah, w_hh, b_hh, w_ic, w_out, b_out, targets_t, lengths, flags, meta):
+        dtype, C, blank = meta
+        dt = dtype_code(dtype)
+        es = 2 if dtype == torch.bfloat16 else 4
+        N, T, Hd = eproj.shape
+        Ep = enc.shape[2]
+        S = targets_t.shape[0]
+        dev = enc.device
+        H3 = 3 * Hd
+        HC = Hd + H3
+        cat = _SeqLinear(torch.cat([w_ah.detach(), w_hh.detach()], 0),
+                         torch.cat([torch.zeros((Hd,), dtype=torch.float32, device=dev), b_hh.detach().float()]), Hd, dtype)
+        ic = _SeqLinear(w_ic.detach(), None, Ep, dtype)
+        out = _SeqLinear(w_out.detach(), b_out.detach(), Hd, dtype)
+        assert cat.np_ == HC and ic.np_ == H3 and G.shape[1] >= H3 and G.is_contiguous() and G.dtype == dtype
+        eproj = eproj if eproj.is_contiguous() else eproj.contiguous()
+        vf = v.detach().float().contiguous()
+        H_all = torch.empty((S + 1, N, Hd), dtype=dtype, device=dev)
+        H_all[0].zero_()
+        HC_all = torch.empty((S, N, HC), dtype=dtype, device=dev)
+        W_att = torch.empty((S, N, T), dtype=torch.float32, device=dev)
+        CTX_all = torch.empty((S, N, Ep), dtype=dtype, device=dev)
+        SAVE_all = torch.empty((S, N, H3), dtype=torch.float32, device=dev)
+        LP_all = torch.empty((S, N, C), dtype=torch.float32, device=dev)
+        gic = torch.empty((N, H3), dtype=dtype, device=dev)
+        logits = torch.zeros((N, out.np_), dtype=dtype, device=dev)
+        loss = torch.empty((N,), dtype=torch.float32, device=dev)
+        am_all = torch.empty((S, N), dtype=torch.int64, device=dev)
+        idx_all = torch.empty((S, N), dtype=torch.int64, device=dev)
+        idx_all[0].fill_(int(blank))
+        mask_all = (torch.arange(S, device=dev).view(S, 1) <= lengths.view(1, N)).to(torch.float32).contiguous()
+        ldG = G.shape[1]
+        for s in range(S):
+            call("mr_gemm_nt", dt, ptr(H_all[s]), Hd, ptr(cat.w_n), Hd, ptr(HC_all[s]), HC, ptr(cat.bias_d), 0, N, HC, Hd)
+            call("mr_attn_fwd2", dt, ptr(HC_all[s]), HC, ptr(eproj), ptr(vf), ptr(enc), ptr(W_att[s]), ptr(CTX_all[s]), N, T,
+                 Hd, Ep)
+            call("mr_gemm_nt", dt, ptr(CTX_all[s]), Ep, ptr(ic.w_n), Ep, ptr(gic), H3, 0, 0, N, H3, Ep)
+            call("mr_gru_fwd2", dt, ptr(G), ldG, ptr(idx_all[s]), ptr(gic), ptr(HC_all[s]) + Hd * es, HC, ptr(H_all[s]),
+                 ptr(H_all[s + 1]), ptr(SAVE_all[s]), N, Hd)
+            call("mr_gemm_nt", dt, ptr(H_all[s + 1]), Hd, ptr(out.w_n), Hd, ptr(logits), out.np_, ptr(out.bias_d), 0, N, C,
+                 Hd)
+            call("mr_nll_step_fwd", dt, ptr(logits), out.np_, ptr(targets_t[s]), 1, ptr(mask_all[s]), ptr(LP_all[s]),
+                 ptr(loss), ptr(am_all[s]), N, C, 1 if s else 0, 0)
+            if s + 1 < S:   # attention_decoder.py:107-110: the next input is the target (teacher forcing) or the arg-max
+                idx_all[s + 1].copy_(targets_t[s] if flags[s] else am_all[s])
+        ctx.save_for_backward(G, eproj, enc, vf, H_all, HC_all, W_att, CTX_all, SAVE_all, LP_all, idx_all, mask_all,
+                              targets_t)
+        ctx.lin = (cat, ic, out)
+        ctx.meta = (dtype, C, N, T, Hd, Ep, S, w_ic.shape[1])
+        att = W_att.permute(1, 0, 2).contiguous()
+        return loss, att
+
+    @staticmethod
+    def backward(ctx, gloss, gatt):
+        (G, eproj, enc, vf, H_all, HC_all, W_att, CTX_all, SAVE_all, LP_all, idx_all, mask_all,
+         targets_t) = ctx.saved_tensors
+        cat, ic, out = ctx.lin
+        dtype, C, N, T, Hd, Ep, S, E = ctx.meta
+        dt = dtype_code(dtype)
+        es = 2 if dtype == torch.bfloat16 else 4
+        dev = enc.device
+        H3, HC = 3 * Hd, 4 * Hd
+        gl = gloss.to(torch.float32).contiguous()
+        ga = None
+        if gatt is not None:
+            ga = gatt.to(torch.float32).contiguous()          # [N, S, T]
+        DL_all = torch.zeros((S, N, out.np_), dtype=dtype, device=dev)
+        DGI_all = torch.empty((S, N, H3), dtype=dtype, device=dev)
+        DHC_all = torch.empty((S, N, HC), dtype=dtype, device=dev)
+        DCTX_all = torch.empty((S, N, Ep), dtype=dtype, device=dev)
+        deproj = torch.zeros((N, T, Hd), dtype=torch.float32, device=dev)
+        dv = torch.zeros((Hd,), dtype=torch.float32, device=dev)
+        dh_a = torch.empty((N, Hd), dtype=dtype, device=dev)     # from the next step's stacked projection
+        dh_b = torch.empty((N, Hd), dtype=dtype, device=dev)     # from the next step's z * h path
+        dh_c = torch.empty((N, Hd), dtype=dtype, device=dev)     # from this step's output layer
+        for s in range(S - 1, -1, -1):
+            last = s == S - 1
+            call("mr_nll_step_bwd", dt, ptr(gl), ptr(LP_all[s]), ptr(targets_t[s]), 1, ptr(mask_all[s]), ptr(DL_all[s]),
+                 out.np_, N, C)
+            call("mr_gemm_nt", dt, ptr(DL_all[s]), out.np_, ptr(out.w_t), out.np_, ptr(dh_c), Hd, 0, 0, N, Hd, out.np_)
+            call("mr_gru_bwd2", dt, 0 if last else ptr(dh_a), 0 if last else ptr(dh_b), ptr(dh_c), ptr(SAVE_all[s]),
+                 ptr(HC_all[s]) + Hd * es, HC, ptr(H_all[s]), ptr(DGI_all[s]), ptr(DHC_all[s]) + Hd * es, HC, ptr(dh_b), N,
+                 Hd)
+            call("mr_gemm_nt", dt, ptr(DGI_all[s]), H3, ptr(ic.w_t), H3, ptr(DCTX_all[s]), Ep, 0, 0, N, Ep, H3)
+            call("mr_attn_bwd2", dt, ptr(DCTX_all[s]), (ptr(ga) + s * T * 4) if ga is not None else 0, S * T,
+                 ptr(HC_all[s]), HC, ptr(eproj), ptr(vf), ptr(enc), ptr(W_att[s]), ptr(DHC_all[s]), HC, ptr(deproj),
+                 ptr(dv), N, T, Hd, Ep)
+            if s > 0:
+                call("mr_gemm_nt", dt, ptr(DHC_all[s]), HC, ptr(cat.w_t), HC, ptr(dh_a), Hd, 0, 0, N, Hd, HC)
+        P = S * N
+        dWcat = torch.zeros((HC, Hd), dtype=torch.float32, device=dev)
+        dbcat = torch.zeros((HC,), dtype=torch.float32, device=dev)
+        call("mr_gemm_tn", dt, ptr(DHC_all), HC, ptr(H_all), Hd, ptr(dWcat), Hd, P, HC, Hd, 0, ptr(dbcat))
+        dWic = torch.zeros((H3, Ep), dtype=torch.float32, device=dev)
+        call("mr_gemm_tn", dt, ptr(DGI_all), H3, ptr(CTX_all), Ep, ptr(dWic), Ep, P, H3, Ep, 0, 0)
+        dWout = torch.zeros((out.np_, Hd), dtype=torch.float32, device=dev)
+        dbout = torch.zeros((out.np_,), dtype=torch.float32, device=dev)
+        call("mr_gemm_tn", dt, ptr(DL_all), out.np_, ptr(H_all[1]), Hd, ptr(dWout), Hd, P, out.np_, Hd, 0, ptr(dbout))
+        dG = torch.zeros((G.shape[0], G.shape[1]), dtype=torch.float32, device=dev)
+        call("mr_rows_scatter_add", dt, ptr(idx_all), ptr(DGI_all), H3, ptr(dG), P, G.shape[0], G.shape[1])
+        denc = torch.empty((N, T, Ep), dtype=dtype, device=dev)
+        call("mr_attn_denc", dt, ptr(W_att), ptr(DCTX_all), ptr(denc), S, N, T, Ep)
+        return (dG.to(dtype), deproj.to(dtype), denc, dv, dWcat[:Hd], dWcat[Hd:], dbcat[Hd:], dWic[:, :E], dWout[:C],
+                dbout[:C], None, None, None, None)
+
+
 class Attn(nn.Module):
     """parameter holder with the reference's names / init (attention_decoder.py:134-144)."""
 
@@ -313,16 +436,32 @@ class AttentionDecoder(nn.Module):
         dev = enc.device
         Wa = cell.attn.attn.weight
         lin_e = _SeqLinear(Wa[:, Hd:Hd + E], cell.attn.attn.bias, Ep, dtype)
-        lin_h = _SeqLinear(Wa[:, :Hd], None, Hd, dtype)
         lin_iw = _SeqLinear(cell.rnn.weight_ih[:, :Hd], cell.rnn.bias_ih, Hd, dtype)
-        lin_ic = _SeqLinear(cell.rnn.weight_ih[:, Hd:Hd + E], None, Ep, dtype)
-        lin_hh = _SeqLinear(cell.rnn.weight_hh, cell.rnn.bias_hh, Hd, dtype)
-        lin_out = _SeqLinear(cell.out.weight, cell.out.bias, Hd, dtype)
         Cp = _ceil_to(C, vec_of(dtype))
         lin_word = _SeqLinear(cell.word_linear.weight, cell.word_linear.bias, Cp, dtype)
         eproj = lin_e(enc.view(N * T, Ep))[:, :Hd].reshape(N, T, Hd)
         if not eproj.is_contiguous():
             eproj = eproj.contiguous()
+        if self.training:
+            targets = targets.to(device=dev, dtype=torch.long)
+            lengths_d = lengths.to(dev)
+            S = self.max_size
+            # the word path depends on the class index only: table G[c] = W_ih[:, :H] (word_linear(embedding[c])) + b_ih
+            rows = _EmbedRowsFn.apply(torch.arange(C, device=dev), cell.embedding.weight, Cp, dtype)
+            G = lin_iw(lin_word(rows))
+            # teacher-forcing coins of the S steps, drawn in the reference's order (one np.random.rand() per step, :107)
+            flags = [bool(self._get_gt_as_output()) for _ in range(S)]
+            targets_t = targets[:, :S].t().contiguous()
+            loss, att = _DecodeLoopFn.apply(G, eproj, enc, cell.attn.v, Wa[:, :Hd], cell.rnn.weight_hh, cell.rnn.bias_hh,
+                                            cell.rnn.weight_ih[:, Hd:Hd + E], cell.out.weight, cell.out.bias, targets_t,
+                                            lengths_d, flags, (dtype, C, int(self.charset.blank)))
+            return loss, att.view(N, -1, self.height, self.max_size)
+
+        # ---- eval: greedy decode, one step at a time (arg-max feedback, early stop when every sample emitted a blank)
+        lin_h = _SeqLinear(Wa[:, :Hd], None, Hd, dtype)
+        lin_ic = _SeqLinear(cell.rnn.weight_ih[:, Hd:Hd + E], None, Ep, dtype)
+        lin_hh = _SeqLinear(cell.rnn.weight_hh, cell.rnn.bias_hh, Hd, dtype)
+        lin_out = _SeqLinear(cell.out.weight, cell.out.bias, Hd, dtype)
         att_state = {'dtype': dtype}
         hidden = torch.zeros((N, Hd), dtype=dtype, device=dev)
         timestep_input = torch.full((N,), int(self.charset.blank), dtype=torch.int64, device=dev)
@@ -336,31 +475,16 @@ class AttentionDecoder(nn.Module):
             hnew = _GruGatesFn.apply(lin_iw(word), lin_ic(context), lin_hh(hidden), hidden, dtype)
             return lin_out(hnew), hnew, w
 
-        if self.training:
-            targets = targets.to(device=dev, dtype=torch.long)
-            lengths_d = lengths.to(dev)
-            loss = None
-            atts = []
+        pred = torch.full((N, self.max_size), int(self.charset.blank), dtype=torch.int32, device=dev)
+        probs = torch.empty((N, C), dtype=torch.float32, device=dev)
+        am = torch.empty((N,), dtype=torch.int64, device=dev)
+        with torch.no_grad():
             for timestep in range(self.max_size):
                 logits, hidden, w = step(timestep, timestep_input, hidden)
-                mask = (timestep <= lengths_d).type(torch.float)
-                l, am = _NllStepFn.apply(logits, targets[:, timestep], mask, C)
-                loss = l if loss is None else loss + l
-                atts.append(w.unsqueeze(1))
-                timestep_input = targets[:, timestep] if self._get_gt_as_output() else am
-            attention_pred = torch.cat(atts, dim=1)
-            return loss, attention_pred.view(N, -1, self.height, self.max_size)
-        else:
-            pred = torch.full((N, self.max_size), int(self.charset.blank), dtype=torch.int32, device=dev)
-            probs = torch.empty((N, C), dtype=torch.float32, device=dev)
-            am = torch.empty((N,), dtype=torch.int64, device=dev)
-            with torch.no_grad():
-                for timestep in range(self.max_size):
-                    logits, hidden, w = step(timestep, timestep_input, hidden)
-                    call("mr_nll_step_fwd", dtype_code(dtype), ptr(logits), logits.stride(0), 0, 0, 0, ptr(probs), 0,
-                         ptr(am), N, C, 0, 1)
-                    timestep_input = am.clone()
-                    pred[:, timestep] = am
-                    if bool((am == self.charset.blank).all()):
-                        break
-            return pred
+                call("mr_nll_step_fwd", dtype_code(dtype), ptr(logits), logits.stride(0), 0, 0, 0, ptr(probs), 0,
+                     ptr(am), N, C, 0, 1)
+                timestep_input = am.clone()
+                pred[:, timestep] = am
+                if bool((am == self.charset.blank).all()):
+                    break
+        return pred

@@ -111,6 +111,17 @@ class _FlatOptimizer(torch.optim.Optimizer):
             f['hyper'][:5].copy_(torch.tensor(vals, dtype=torch.float32), non_blocking=False)
             f['hyper_host'] = vals
 
+    def set_grad_scale(self, scale):
+        """Scale applied to the raw gradients inside the update kernel (device slot hyper[6]).  Data parallel: the DDP shim
+        (megreader_amd.apex.parallel.DistributedDataParallel.fold_average_into) sets 1 / world_size here and stops
+        scaling the all-reduced flat buffer itself -- one pass over the gradients less per step."""
+        if self._flat is None:
+            self._materialize()
+        self._grad_scale = float(scale)
+        for f in self._flat:
+            if f is not None:
+                f['hyper'][6:7].fill_(float(scale))
+
     def push_hyper(self):
         """Copy changed hyper-parameters (lr schedule: trainer.py:43-47,81 `update_learning_rate`) to their device
         slots.  `step()` does this itself; a captured hipGraph replay (megreader_amd.runtime.GraphedTrainStep) never

@@ -112,7 +112,6 @@ def test_real_layer_shapes_vs_oracle(dtype, layer):
     msk = torch.sigmoid(torch.randn(N, 9, oh, ow, generator=g))
     w = torch.randn(Co, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
     gy = torch.randn(N, Co, Ho, Wo, generator=g).to(dtype)
-    torch.set_num_threads(max(1, min(32, torch.get_num_threads() or 1)))
     xr = x.double().requires_grad_(True)
     offr = off.double().requires_grad_(True)
     mskr = msk.double().requires_grad_(True)
@@ -356,7 +355,8 @@ def test_fused_path_equals_general_path(dtype, case):
         return y.detach(), xd.grad, offd.grad, mskd.grad, wd.grad, bd.grad
 
     lib = load()
-    assert lib.mr_dcn2_ws_bytes(1 if dtype == torch.bfloat16 else 0, N, H, W, C, Co, 3, 3, Ho, Wo, 0) == 0   # fused forward
+    fused = C % 64 == 0 and Co % 64 == 0          # (case 4 has Co = 32: it stays on the general path, both runs equal)
+    assert (lib.mr_dcn2_ws_bytes(1 if dtype == torch.bfloat16 else 0, N, H, W, C, Co, 3, 3, Ho, Wo, 0) == 0) == fused
     got = run()
     old = lib.mr_set_dcn_fused(0)
     try:

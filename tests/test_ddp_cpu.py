@@ -143,7 +143,7 @@ def _flat_worker(rank, world, port, foreign_gap, q):
         used["flat" if r is not None else "staged"] += 1
         return r
     shim.DistributedDataParallel._flat_view = spy
-    ddp = shim.DistributedDataParallel(net, message_size=1 << 20)       # one bucket: a, b, c
+    ddp = shim.DistributedDataParallel(net, message_size=1 << 20, min_buckets=1)       # one bucket: a, b, c
     g = torch.Generator().manual_seed(11)
     X = torch.randn(8, 8, generator=g)
     xs = X[rank * 4:(rank + 1) * 4]
@@ -192,3 +192,119 @@ def test_flat_buffer_bucket_in_place_vs_foreign_gap(foreign_gap):
             assert used["flat"] > 0 and used["staged"] == 0, used       # tiled span -> zero-copy in-place path
             # alignment padding (after c: elements 368..383 of the 384-element buffer) stays zero
             assert flat.shape[0] == 384 and float(abs(flat[368:]).sum()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Shared parameters (mark_shared) and the bucket plan.  ADVICE r2: the launch guard used to look only at the parameter whose
+# hook happened to complete the bucket -- a shared parameter P (2 uses) firing its FIRST hook early and another parameter Q of
+# the same bucket arriving last launched the all-reduce before P's second accumulation.  Here `shared` is used twice (once
+# late, once early in the graph) and sits in one bucket with `tail`, whose gradient is the LAST to arrive.
+# ---------------------------------------------------------------------------------------------------------------
+class SharedNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.tail = torch.nn.Linear(6, 6, bias=False)      # first layer: its gradient arrives last
+        self.shared = torch.nn.Linear(6, 6, bias=False)    # applied twice
+        self.head = torch.nn.Linear(6, 3, bias=False)
+
+    def forward(self, x):
+        h = torch.tanh(self.shared(torch.tanh(self.tail(x))))
+        return self.head(torch.tanh(self.shared(h))).sum(dim=1)
+
+
+def _shared_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from megreader_amd.apex import parallel as shim
+    torch.manual_seed(3)
+    net = SharedNet()
+    launches = []
+    orig = shim.DistributedDataParallel._launch
+
+    def spy(self, bi):
+        launches.append((bi, {id(p): self._fires.get(id(p), 0) for p in self._buckets[bi]}))
+        return orig(self, bi)
+    shim.DistributedDataParallel._launch = spy
+    # buckets over reversed registration order with 40-element pieces: [head (18), shared (36)] and [tail (36)] would
+    # separate them -- use one bucket for shared + tail: message_size 60 -> [head, shared] = 54 < 60 -> + tail
+    ddp = shim.DistributedDataParallel(net, message_size=60, min_buckets=1)
+    assert len(ddp._buckets) == 1 and len(ddp._buckets[0]) == 3
+    ddp.mark_shared(net.shared.weight, uses=2)
+    # the manual hook protocol of the gradient sinks: a shared module fires once per use (nn/functional.py notify_grad_ready)
+    fired = []
+    h = net.shared.weight._mr_grad_ready_hooks[-1]
+    g = torch.Generator().manual_seed(13)
+    X = torch.randn(8, 6, generator=g)
+    xs = X[rank * 4:(rank + 1) * 4]
+    for _ in range(2):
+        net.zero_grad()
+        launches.clear()
+        ddp(xs).mean().backward()
+        # autograd's post-accumulate hook fires ONCE for the shared weight (after both contributions were summed by the
+        # engine); a sink-style op fires per use.  Emulate the second firing protocol explicitly in the next block.
+    grads = {k: p.grad.numpy().copy() for k, p in net.named_parameters()}
+    # ---- sink-style protocol: fire the shared parameter's hook early (first use done), then the other parameters; the bucket
+    # must NOT launch until the shared parameter fired twice
+    ddp._fires = {}
+    ddp._launched = [False]
+    ddp._callback_queued = True           # no engine callback outside backward
+    launches.clear()
+    h(net.shared.weight)                  # first use complete
+    h(net.head.weight)
+    h(net.tail.weight)                    # the LAST parameter of the bucket arrives: must not launch yet
+    early = len(launches)
+    h(net.shared.weight)                  # second use: now the bucket is complete
+    late = len(launches)
+    for _b, _f, _s, work in ddp._pending:
+        work.wait()
+    ddp._pending = []
+    q.put((rank, grads, early, late))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shared_parameter_not_last_to_arrive():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        item = q.get(timeout=120)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(3)
+    ref = SharedNet()
+    g = torch.Generator().manual_seed(13)
+    ref(torch.randn(8, 6, generator=g)).mean().backward()
+    for rank in (0, 1):
+        grads, early, late = res[rank]
+        assert early == 0, "bucket launched before the shared parameter's second accumulation"
+        assert late == 1
+        for k, p in ref.named_parameters():
+            assert torch.allclose(torch.from_numpy(grads[k]), p.grad, atol=1e-6, rtol=1e-5), k
+
+
+def test_default_bucket_plan_has_at_least_four_buckets():
+    """CRNN-sized plan without a process group: the default message_size (8 M elements) used to swallow the CRNN's 8.33 M
+    parameters in ONE bucket; the plan is min(message_size, total / 4)."""
+    from megreader_amd.apex.parallel import MIN_BUCKETS
+    sizes = [64 * 27, 128 * 576, 256 * 1152, 256 * 2304, 512 * 2304, 512 * 4608, 512 * 2048,   # CRNN convs
+             2048 * 512, 2048 * 256, 256 * 512, 2048 * 256, 2048 * 256, 38 * 512]              # LSTMs + linears
+    total = sum(sizes)
+    bucket = max(1, min(8 * 1024 * 1024, -(-total // MIN_BUCKETS)))
+    buckets, cur = [], 0
+    for n in reversed(sizes):
+        cur += n
+        if cur >= bucket:
+            buckets.append(cur)
+            cur = 0
+    if cur:
+        buckets.append(cur)
+    assert MIN_BUCKETS >= 4 and len(buckets) >= 3 and max(buckets) < 0.6 * total

@@ -5,7 +5,15 @@ Golden vectors come from the unmodified reference graph code with the CUDA-only 
 oracle module (oracle/gen_golden.py deformable_resnet).  At random initialisation this network doubles any
 perturbation per block (offsets are computed from features, BatchNorm uses batch statistics), so f32 round-off of
 1e-6 after the stem becomes ~1e-2 at layer4: the whole-network comparison is therefore loose, and the strict check is
-block-wise (each HIP block on the oracle's own block input, forward and backward)."""
+block-wise (each HIP block on the oracle's own block input, forward and backward).
+
+The block-wise gradient check is exact only while no sample point sits on a kink of the bilinear kernel: the sampling offsets
+are themselves computed (conv2_offset) in float32 on both sides, and a point within ~1e-6 of an integer row / column takes
+floor() to different sides -- the forward value is continuous there (y still agrees to 1e-6) but d/d(offset) and the set of
+input pixels that receive gradient are not.  Seen in round 3 with the block input the oracle produces under
+torch.set_num_threads(32) (layer4.0: bn2.bias 25 % off in BOTH DCN code paths, fused and general, while the float32 and
+float64 oracles agree to 3e-6); with the default thread count of the box no point is that close.  Tests that change the
+thread count must restore it."""
 import os
 
 import pytest
@@ -85,10 +93,11 @@ def test_block_parity(golden, block):
     rel = lambda a, b: float((a.double().cpu() - b.double()).abs().max() / (b.double().abs().max() + 1e-12))  # noqa: E731
     assert rel(ym, yo) < 1e-4, rel(ym, yo)
     ym.backward(g.to(DEV).contiguous(memory_format=torch.channels_last))
-    assert rel(xm.grad, xo.grad) < 1e-3
     po = dict(mod_o.named_parameters())
-    for k, p in mod_m.named_parameters():
-        scale = float(po[k].grad.abs().max())
-        if scale < 1e-7:
-            continue
-        assert rel(p.grad, po[k].grad) < 2e-3, (k, rel(p.grad, po[k].grad))
+    errs = {k: rel(p.grad, po[k].grad) for k, p in mod_m.named_parameters() if float(po[k].grad.abs().max()) >= 1e-7}
+    errs["input"] = rel(xm.grad, xo.grad)
+    print("block %s: input-gradient error %.2e, worst parameter-gradient error %.2e (%s)" %
+          (block, errs["input"], max(v for k, v in errs.items() if k != "input"),
+           max((v, k) for k, v in errs.items() if k != "input")[1]))
+    bad = {k: v for k, v in errs.items() if v >= (1e-3 if k == "input" else 2e-3)}
+    assert not bad, bad

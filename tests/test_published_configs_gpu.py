@@ -25,8 +25,12 @@ DEV = "cuda"
 
 @pytest.fixture(autouse=True)
 def _reset_dtype():
+    # the CPU oracle's summation order (hence its last-bit results) depends on the thread count: restore it, so that the
+    # tests that run later in the same process see the oracle they were written against
+    threads = torch.get_num_threads()
     yield
     mr.set_compute_dtype(torch.bfloat16)
+    torch.set_num_threads(threads)
 
 
 def _threads():

@@ -1,11 +1,15 @@
 #!/usr/bin/env python
-"""Timing-only ablation ladder of the all-taps wgrad kernel (mr_set_tn_taps_abl): which ingredient costs what."""
+"""Timing-only ablation ladder of the all-taps wgrad kernel (mr_set_tn_taps_abl): which ingredient costs what.
+Needs the separate ablation build (wrong results by construction, not part of the product library):
+    make -C megreader_amd/csrc ablation      # -> libmegreader_hip_abl.so (-DMR_ABLATION)"""
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("MEGREADER_HIP_LIB", os.path.join(_REPO, "megreader_amd", "csrc", "libmegreader_hip_abl.so"))
+sys.path.insert(0, _REPO)
 import megreader_amd as mr  # noqa: E402,F401
 from megreader_amd import _lib  # noqa: E402
 from megreader_amd._lib import call, dtype_code, ptr  # noqa: E402

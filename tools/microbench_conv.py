@@ -40,7 +40,11 @@ def main():
     _lib.load().mr_set_nt_variant(a.variant)
     _lib.load().mr_set_nt_big(a.big)
     _lib.load().mr_set_nt_p8(a.p8)
-    _lib.load().mr_set_tn_abl(a.tnabl)
+    if a.tnabl or a.p8 > 1:   # wrong-result ablations: only in the `make ablation` build (MEGREADER_HIP_LIB=...abl.so)
+        if not hasattr(_lib.load(), "mr_set_tn_abl"):
+            raise SystemExit("--tnabl / --p8 > 1 need libmegreader_hip_abl.so: make -C megreader_amd/csrc ablation and "
+                             "set MEGREADER_HIP_LIB to it")
+        _lib.load().mr_set_tn_abl(a.tnabl)
     _lib.load().mr_set_tn_big(a.tnbig)
     _lib.load().mr_set_tn_buf(a.tnbuf)
     _lib.load().mr_set_tn_group(a.tngroup)

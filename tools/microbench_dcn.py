@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--offscale", type=float, default=0.5, help="std of the random offsets in pixels")
     ap.add_argument("--v1", type=int, default=1, help="general path: 1 = round-1 backward kernels, 0 = round-2 experiments")
+    ap.add_argument("--layers", default="", help="comma-separated substrings of layer names to run (default: all)")
     ap.add_argument("--fused", type=int, default=1, help="1 (default): fused kernels (csrc/dcn_fused.hip), 0: general path")
     a = ap.parse_args()
     dtype, dt, es = torch.bfloat16, 1, 2
@@ -51,6 +52,8 @@ def main():
     print("DCNv2 3x3, batch %d, bf16 activations / f32 offsets+mask, offsets ~ N(0, %.1f px), backward kernels %s; "
           "rooflines %.0f TB/s, %.0f TFLOP/s" % (N, a.offscale, "fused (round 3)" if a.fused else ("round 1" if a.v1 else "round 2"), HBM_TBS, MFMA_TFS))
     for name, count, C, H, s in LAYERS:
+        if a.layers and not any(k in name for k in a.layers.split(",")):
+            continue
         W, Co, k, pad = H, C, 3, 1
         Ho = Wo = (H + 2 * pad - k) // s + 1
         g = torch.Generator(device="cuda").manual_seed(0)
