@@ -32,8 +32,144 @@ OVERRIDES = {
 }
 
 
-def install(reference_root=None, level="plugin"):
-    """level="plugin" (default): the reference's `ops` package is replaced by megreader_amd.ops (our CTCLoss2DFunction).
+def fuse_optimizers():
+    """`getattr(torch.optim, 'Adam')(parameters, **args)` (reference training/optimizer_scheduler.py:17-22) -> the fused
+    flat-buffer optimizers of megreader_amd.optim when every parameter is an fp32 CUDA tensor and the options are ones they
+    implement; anything else falls through to torch's own class.  Idempotent.  Returns the names that were aliased."""
+    import torch
+    from . import optim as _optim
+
+    def _factory(orig, fused, unsupported):
+        if getattr(orig, "_mr_fused_factory", False):
+            return orig
+
+        def make(params, *args, **kwargs):
+            params = list(params)
+            flat = [p for g in params for p in g["params"]] if params and isinstance(params[0], dict) else params
+            ok = bool(flat) and all(p.is_cuda and p.dtype == torch.float32 for p in flat) and not args
+            ok = ok and not any(kwargs.get(k) for k in unsupported)
+            ok = ok and set(kwargs) <= set(fused.__init__.__code__.co_varnames)
+            return fused(params, **kwargs) if ok else orig(params, *args, **kwargs)
+        make._mr_fused_factory = True
+        make._mr_original = orig
+        make.__name__ = orig.__name__
+        return make
+
+    torch.optim.Adam = _factory(torch.optim.Adam, _optim.FusedAdam, ("amsgrad", "foreach", "fused", "capturable",
+                                                                     "maximize", "differentiable"))
+    torch.optim.SGD = _factory(torch.optim.SGD, _optim.FusedSGD, ("dampening", "nesterov", "foreach", "fused", "maximize",
+                                                                  "differentiable"))
+    return ["Adam", "SGD"]
+
+
+class _GraphedTrainStep(object):
+    """Replacement of `Trainer.train_step` (reference trainer.py:114-143: zero_grad / model.forward(batch, training=True) /
+    l.mean() / backward / optimizer.step() / logging every log_interval steps) that replays ONE hipGraph per step.
+
+    The first `eager_steps` calls run the original method (real training steps: they also create every lazily allocated
+    buffer); the next call copies the batch into static device tensors and captures the same sequence of calls -- the
+    model's own forward, with its `.to(device)` calls now no-ops -- with megreader_amd.runtime.GraphedTrainStep; from then on
+    a step is: H2D copies of the batch into the static tensors + one graph replay.  The logging block of the original method
+    is re-run on the replayed loss / metrics.  Batches whose shapes differ from the captured ones (last batch of an epoch)
+    and optimizers that are not megreader_amd fused ones take the original method."""
+
+    def __init__(self, original, eager_steps=3):
+        self.original = original
+        self.eager_steps = eager_steps
+        self.calls = 0
+        self.state = None     # (signature, static batch, graphed step, holder)
+        self.disabled = False
+
+    @staticmethod
+    def _signature(batch):
+        import torch
+        return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()) if isinstance(v, torch.Tensor))
+
+    def __call__(self, trainer, model, optimizer, batch, epoch, step, **kwargs):
+        import torch
+        from . import optim as _optim
+        from .runtime import GraphedTrainStep
+        self.calls += 1
+        usable = (not self.disabled and isinstance(optimizer, _optim._FlatOptimizer) and isinstance(batch, dict)
+                  and torch.cuda.is_available() and model.training)
+        if not usable or self.calls <= self.eager_steps:
+            return self.original(trainer, model, optimizer, batch, epoch=epoch, step=step, **kwargs)
+        sig = self._signature(batch)
+        if self.state is not None and self.state[0] != sig:
+            return self.original(trainer, model, optimizer, batch, epoch=epoch, step=step, **kwargs)
+        if self.state is None:
+            device = getattr(trainer, "device", torch.device("cuda"))
+            static = {k: (v.to(device).clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+            holder = {}
+
+            def loss_fn():
+                results = model.forward(static, training=True)
+                metrics = {}
+                if isinstance(results, (tuple, list)) and len(results) == 2:
+                    l, _pred = results
+                elif isinstance(results, (tuple, list)) and len(results) == 3:
+                    l, _pred, metrics = results
+                else:
+                    l = results
+                holder["metrics"] = metrics
+                return l.mean()
+            try:
+                optimizer.push_hyper()     # no host->device copy may happen inside the capture
+                graphed = GraphedTrainStep(loss_fn, optimizer, [], warmup=0)
+            except Exception as e:  # noqa: BLE001 - a model that cannot be captured keeps training eagerly
+                torch.cuda.synchronize()
+                self.disabled = True
+                print("megreader_amd.dropin: hipGraph capture of the training step failed (%s: %s); staying eager" %
+                      (type(e).__name__, e), file=sys.stderr)
+                return self.original(trainer, model, optimizer, batch, epoch=epoch, step=step, **kwargs)
+            self.state = (sig, static, graphed, holder)
+        _sig, static, graphed, holder = self.state
+        for k, v in batch.items():
+            if isinstance(v, torch.Tensor):
+                static[k].copy_(v, non_blocking=True)
+        loss = graphed()
+        self._log(trainer, loss, holder.get("metrics", {}), epoch, step)
+        return loss
+
+    @staticmethod
+    def _log(trainer, loss, metrics, epoch, step):
+        exp = getattr(trainer, "experiment", None)
+        interval = getattr(getattr(exp, "logger", None), "log_interval", None) if exp is not None else None
+        if not interval or step % interval != 0:
+            return
+        logger = trainer.logger
+        if getattr(trainer, "is_main", True):   # trainer.py:133-143 (single-process form: reduce() is the identity there)
+            logger.info('step: %6d, epoch: %3d, loss: %.6f, lr: %f' % (step, epoch, loss.mean().item(),
+                                                                       getattr(trainer, "current_lr", 0.0)))
+            logger.add_scalar('loss', loss, step)
+            logger.add_scalar('learning_rate', getattr(trainer, "current_lr", 0.0), step)
+            for name, metric in metrics.items():
+                logger.add_scalar(name, metric.mean(), step)
+                logger.info('%s: %6f' % (name, metric.mean()))
+            logger.report_time('Logging')
+
+
+def accelerate_trainer(trainer_cls, eager_steps=3):
+    """Patch `trainer_cls.train_step` (reference trainer.py:114) with the graphed step above.  Returns the wrapper."""
+    original = trainer_cls.train_step
+    if isinstance(getattr(original, "_mr_graphed", None), _GraphedTrainStep):
+        return original._mr_graphed
+    wrapper = _GraphedTrainStep(original, eager_steps)
+
+    def train_step(self, model, optimizer, batch, epoch=0, step=0, **kwargs):
+        return wrapper(self, model, optimizer, batch, epoch, step, **kwargs)
+    train_step._mr_graphed = wrapper
+    trainer_cls.train_step = train_step
+    return wrapper
+
+
+def install(reference_root=None, level="plugin", fused_optimizer=False, graph_step=False):
+    """fused_optimizer=True: torch.optim.Adam / SGD resolve to the fused flat-buffer optimizers (fuse_optimizers()).
+    graph_step=True: the reference's `trainer.Trainer.train_step` replays one captured hipGraph per step
+    (accelerate_trainer(); needs fused_optimizer and the reference tree on the path; distributed runs keep the eager step).
+    Together they give the unchanged `train.py` the step bench.py measures.
+
+    level="plugin" (default): the reference's `ops` package is replaced by megreader_amd.ops (our CTCLoss2DFunction).
     level="extension": the reference's OWN `ops/ctc_2d/ctc_loss_2d.py` is used unchanged and only the pybind11 module it
     binds (`ops.ctc_2d.ctc_2d_csrc`, ops/ctc_2d/ctc_loss_2d.py:3) resolves to the HIP implementation
     (megreader_amd.ops.ctc_2d.ctc_2d_csrc) -- the boundary SURVEY.md §8 b2 names.  Needs the reference tree on the path.
@@ -85,4 +221,14 @@ def install(reference_root=None, level="plugin"):
             if hasattr(our_mod, name):
                 setattr(ref_mod, name, getattr(our_mod, name))
                 installed.setdefault(pkg, []).append(name)
+    if fused_optimizer:
+        installed["torch.optim"] = fuse_optimizers()
+    if graph_step:
+        try:
+            trainer_mod = importlib.import_module("trainer")     # the reference's trainer.py (needs the tree on sys.path)
+            accelerate_trainer(trainer_mod.Trainer)
+            installed["trainer"] = ["Trainer.train_step"]
+        except ImportError as e:
+            print("megreader_amd.dropin: graph_step requested but the reference's trainer module is not importable (%s)"
+                  % e, file=sys.stderr)
     return installed

@@ -199,3 +199,118 @@ def test_embed_rows_vs_f64(dtype):
     gd = gout.to(DEV)
     call("mr_embed_rows_bwd", dtype_code(dtype), ptr(idd), ptr(gd), ptr(dt), N, V, V, ldo)
     assert _rel(dt - 1.0, t64.grad) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round-3 decode-loop kernels (strided operands, table gather, (N, Hd/64)-parallel backward, deferred denc)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,Tn,Hd,Ep,S", [(32, 32, 512, 552, 3), (5, 17, 64, 40, 2), (3, 64, 128, 72, 4)])
+def test_attn_fwd2_bwd2_denc_vs_f64(dtype, N, Tn, Hd, Ep, S):
+    """S steps sharing eproj / enc: hproj is a column slice (leading dimension 4*Hd) of a wider buffer, deproj / dv accumulate
+    over the steps inside mr_attn_bwd2, the encoder gradient comes from ONE mr_attn_denc call; reference = float64 autograd of
+    Attn.forward + the context bmm (decoders/attention_decoder.py:146-177, 207-209)."""
+    g = torch.Generator().manual_seed(N * 100 + Tn + S)
+    ld = 4 * Hd
+    hc = (torch.randn(S, N, ld, generator=g) * 0.7).to(dtype)          # hproj = hc[..., :Hd]
+    eproj = (torch.randn(N, Tn, Hd, generator=g) * 0.7).to(dtype)
+    enc = torch.randn(N, Tn, Ep, generator=g).to(dtype)
+    v = torch.randn(Hd, generator=g) * (Hd ** -0.5) * 4
+    gctx = torch.randn(S, N, Ep, generator=g).to(dtype)
+    gw = torch.randn(N, S, Tn, generator=g)                               # upstream gradient of the returned attention map
+
+    h64 = hc[..., :Hd].double().requires_grad_(True)
+    e64 = eproj.double().requires_grad_(True)
+    c64 = enc.double().requires_grad_(True)
+    v64 = v.double().requires_grad_(True)
+    tot = 0
+    w_ref, ctx_ref = [], []
+    for s in range(S):
+        w = torch.softmax(torch.tanh(h64[s].unsqueeze(1) + e64) @ v64, dim=1)
+        ctx = torch.bmm(w.unsqueeze(1), c64).squeeze(1)
+        w_ref.append(w.detach())
+        ctx_ref.append(ctx.detach())
+        tot = tot + (ctx * gctx[s].double()).sum() + (w * gw[:, s].double()).sum()
+    tot.backward()
+
+    hcd, ep, en, vd = hc.to(DEV), eproj.to(DEV), enc.to(DEV), v.to(DEV)
+    W = torch.empty((S, N, Tn), dtype=torch.float32, device=DEV)
+    CTX = torch.empty((S, N, Ep), dtype=dtype, device=DEV)
+    dt = dtype_code(dtype)
+    for s in range(S):
+        call("mr_attn_fwd2", dt, ptr(hcd[s]), ld, ptr(ep), ptr(vd), ptr(en), ptr(W[s]), ptr(CTX[s]), N, Tn, Hd, Ep)
+        assert _rel(W[s], w_ref[s]) < 1e-4 and _rel(CTX[s], ctx_ref[s]) < _tol(dtype, 1e-5, 1e-2)
+    deproj = torch.zeros((N, Tn, Hd), dtype=torch.float32, device=DEV)
+    dv = torch.zeros((Hd,), dtype=torch.float32, device=DEV)
+    dhc = torch.full((S, N, ld), 3.0, dtype=dtype, device=DEV)             # only the [:Hd] slice may be written
+    gc, gwd = gctx.to(DEV), gw.to(DEV).contiguous()
+    for s in range(S - 1, -1, -1):
+        call("mr_attn_bwd2", dt, ptr(gc[s]), ptr(gwd) + s * Tn * 4, S * Tn, ptr(hcd[s]), ld, ptr(ep), ptr(vd), ptr(en),
+             ptr(W[s]), ptr(dhc[s]), ld, ptr(deproj), ptr(dv), N, Tn, Hd, Ep)
+    denc = torch.empty((N, Tn, Ep), dtype=dtype, device=DEV)
+    call("mr_attn_denc", dt, ptr(W), ptr(gc), ptr(denc), S, N, Tn, Ep)
+    torch.cuda.synchronize()
+    assert _rel(dhc[..., :Hd], h64.grad) < _tol(dtype, 2e-5, 2e-2)
+    assert bool((dhc[..., Hd:] == 3.0).all())
+    assert _rel(deproj, e64.grad) < 2e-5 and _rel(dv, v64.grad) < 2e-5
+    assert _rel(denc, c64.grad) < _tol(dtype, 2e-5, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,H,V", [(32, 512, 38), (7, 96, 5)])
+def test_gru2_table_gather_strided_vs_f64(dtype, N, H, V):
+    """mr_gru_fwd2 / mr_gru_bwd2: gi_a rows gathered from a [V, 3H] table through idx, gh a column slice (leading dimension
+    4H, offset H) of the stacked projection, dh' = dh_a + dh_b + dh_c."""
+    g = torch.Generator().manual_seed(N + H)
+    table = torch.randn(V, 3 * H, generator=g).to(dtype)
+    idx = torch.randint(0, V, (N,), generator=g)
+    gi_b = (torch.randn(N, 3 * H, generator=g) * 0.5).to(dtype)
+    hc = torch.randn(N, 4 * H, generator=g).to(dtype)                    # gh = hc[:, H:]
+    h = torch.randn(N, H, generator=g).to(dtype)
+    parts = [torch.randn(N, H, generator=g).to(dtype) for _ in range(3)]
+
+    t64 = table.double().requires_grad_(True)
+    b64 = gi_b.double().requires_grad_(True)
+    hc64 = hc.double().requires_grad_(True)
+    h64 = h.double().requires_grad_(True)
+    gi = t64[idx] + b64
+    gh = hc64[:, H:]
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    nn_ = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    hn64 = (1 - z) * nn_ + z * h64
+    gout = sum(p.double() for p in parts)
+    (hn64 * gout).sum().backward()
+
+    dt = dtype_code(dtype)
+    es = 2 if dtype == torch.bfloat16 else 4
+    td, idd, bd, hcd, hd = table.to(DEV), idx.to(DEV), gi_b.to(DEV), hc.to(DEV), h.to(DEV)
+    hnew = torch.empty_like(hd)
+    save = torch.empty((N, 3 * H), dtype=torch.float32, device=DEV)
+    call("mr_gru_fwd2", dt, ptr(td), 3 * H, ptr(idd), ptr(bd), ptr(hcd) + H * es, 4 * H, ptr(hd), ptr(hnew), ptr(save), N, H)
+    assert _rel(hnew, hn64) < _tol(dtype, 2e-6, 1e-2)
+    dgi = torch.empty((N, 3 * H), dtype=dtype, device=DEV)
+    dhc = torch.full((N, 4 * H), 5.0, dtype=dtype, device=DEV)
+    dhp = torch.empty((N, H), dtype=dtype, device=DEV)
+    pd = [p.to(DEV) for p in parts]
+    call("mr_gru_bwd2", dt, ptr(pd[0]), ptr(pd[1]), ptr(pd[2]), ptr(save), ptr(hcd) + H * es, 4 * H, ptr(hd), ptr(dgi),
+         ptr(dhc) + H * es, 4 * H, ptr(dhp), N, H)
+    tol = _tol(dtype, 1e-5, 2e-2)
+    assert _rel(dgi, b64.grad) < tol
+    assert _rel(dhc[:, H:], hc64.grad[:, H:]) < tol and bool((dhc[:, :H] == 5.0).all())
+    assert _rel(dhp, h64.grad) < tol
+    # nullable parts: only dh_c
+    call("mr_gru_bwd2", dt, 0, 0, ptr(pd[2]), ptr(save), ptr(hcd) + H * es, 4 * H, ptr(hd), ptr(dgi), ptr(dhc) + H * es,
+         4 * H, ptr(dhp), N, H)
+    for t in (t64, b64, hc64, h64):
+        t.grad = None
+    gi = t64[idx] + b64
+    gh = hc64[:, H:]
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H]); z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    nn_ = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    (((1 - z) * nn_ + z * h64) * parts[2].double()).sum().backward()
+    assert _rel(dgi, b64.grad) < tol and _rel(dhp, h64.grad) < tol
+    # gradient of the table gather: rows scatter-added with atomics
+    dtab = torch.full((V, 3 * H), 1.0, dtype=torch.float32, device=DEV)
+    call("mr_rows_scatter_add", dt, ptr(idd), ptr(dgi), 3 * H, ptr(dtab), N, V, 3 * H)
+    assert _rel(dtab - 1.0, t64.grad) < _tol(dtype, 1e-5, 2e-2)
