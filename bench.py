@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- training images/s of CRNN + 1-D CTC (BASELINE.json configs[1]) on N MI355X GPUs.
 
-    python bench.py --gpus 1 --steps 30 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -65,16 +65,33 @@ def kernel_label(lib, name, args, dtype_name):
     return "igemm_tn_kernel<%s,conv>" % dtype_name
 
 
+def kernel_source_hash():
+    """sha256 over megreader_amd/csrc/*.hip, *.h (same function as tools/pmc_to_json.py, which stamps it into the PMC file)."""
+    import hashlib
+    here = os.path.join(REPO, "megreader_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(here)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(here, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(label, workload="crnn"):
-    """HBM-side bytes per launch of `label` from the committed PMC passes (profiles/r02_pmc_traffic_<workload>.json,
-    produced by tools/profile_r02.sh + tools/pmc_to_json.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
-    this same command, FETCH_SIZE doubled for gfx950).  PMC counters cannot be read inside this process."""
-    name = "r02_pmc_traffic_%s.json" % workload
+    """HBM-side bytes per launch of `label` from the committed PMC passes (profiles/r03_pmc_traffic_<workload>.json,
+    produced by tools/profile_r03.sh + tools/pmc_to_json.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
+    this same command, FETCH_SIZE doubled for gfx950).  PMC counters cannot be read inside this process, so the file is
+    stamped with a hash of the kernel sources it was measured on: a stale file (kernels edited since) yields traffic = null
+    instead of a number that no longer describes the code."""
+    name = "r03_pmc_traffic_%s.json" % workload
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
     try:
         data = json.load(open(path))
     except (OSError, ValueError):
         return None, None
+    if data.get("_kernel_source_hash") != kernel_source_hash():
+        return None, "profiles/%s is stale (measured on kernel sources %s, current %s)" % \
+            (name, data.get("_kernel_source_hash"), kernel_source_hash())
     if label not in data:
         return None, None
     return data[label]["bytes_per_launch"], "profiles/%s (rocprofv3 --pmc, %d launches)" % \
@@ -114,8 +131,8 @@ def cpu_baseline(batch_size=64, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)     # >= 50 timed steps after >= 10 warm-up
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -238,11 +255,13 @@ def main():
             # eager data parallel: the apex-style shim (bucketed all-reduce overlapped with backward)
             from megreader_amd.apex.parallel import DistributedDataParallel
             net = DistributedDataParallel(model)
+            net.fold_average_into(opt)     # 1 / world applied inside the fused update kernel (no flat.mul_ pass)
         elif distributed:
             # graphed data parallel; rank 0's weights define the model.  The shim is constructed here (it broadcasts) and
             # used by the 'capture' mode; 'graph2' works on the bare model with an eager flat all-reduce between two graphs
             from megreader_amd.apex.parallel import DistributedDataParallel
             ddp_shim = DistributedDataParallel(model)
+            ddp_shim.fold_average_into(opt)
         bsz = args.batch
         if is_db:
             bsz = args.batch if args.batch != 256 else 2           # configs[4]: 16 global = 2 per GPU on 8 GPUs

@@ -39,6 +39,10 @@ int mr_set_nt_variant(int v);
 /* C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]);  A,B,C of `dtype`, bias f32 (nullable), relu 0/1 */
 int mr_gemm_nt(int dtype, const void* A, long long lda, const void* B, int ldb, void* C, long long ldc,
                const float* bias, int relu, int M, int N, int K, hipStream_t stream);
+/* M <= 32 problems (the decode-loop GEMMs of the attention decoder) take a latency-optimised kernel (csrc/gemm_skinny.hip:
+ * 16 output columns per workgroup, K split over the four waves, operands fetched as MFMA fragments straight from global
+ * memory).  A/B switch (host only): 0 = the general tiled kernels; returns the previous setting. */
+int mr_set_gemm_skinny(int on);
 /* tuning override: force one NT tile shape (bm 128|96|64, bn 128|64); bm = 0 restores the cost model */
 int mr_force_nt_tile(int bm, int bn);
 /* big-tile (8-wave, 256x256 / 288x256) NT kernel policy: 0 automatic, -1 never, 1 / 2 force (tuning override);

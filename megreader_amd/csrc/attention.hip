@@ -260,21 +260,67 @@ __global__ void embed_rows_bwd_kernel(const long long* __restrict__ idx, const T
 // encoder-side gradient sum_s w_s dcontext_s is ONE kernel after the loop instead of a read-modify-write per step.
 // =====================================================================================================================
 
+// 16-byte vector of T as floats
+template <typename T> struct AttVec;
+template <> struct AttVec<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const bf16_t* p, float* f) {
+    const uint4 v = *(const uint4*)p;
+    const bf16_t* q = (const bf16_t*)&v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (float)q[j];
+  }
+};
+template <> struct AttVec<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float* f) {
+    const f32x4 v = *(const f32x4*)p;
+    f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+  }
+};
+
 // energy / softmax / context of one decode step; hproj rows have leading dimension ldh.  512 threads per sample.
+// Vector path (Hd, Ep, ldh multiples of the 16-byte vector): a wave takes a position t and its lanes 16-byte slices of the
+// Hd units; the context sum runs over (position group, channel vector) pairs and is reduced through LDS.
 template <typename T>
 __global__ __launch_bounds__(512) void attn_fwd2_kernel(const T* __restrict__ hproj, long long ldh,
                                                         const T* __restrict__ eproj, const float* __restrict__ v,
                                                         const T* __restrict__ enc, float* __restrict__ weights,
                                                         T* __restrict__ context, int Tn, int Hd, int Ep) {
+  constexpr int VEC = AttVec<T>::N;
   __shared__ float en[64];
+  extern __shared__ float part[];     // [groups][Ep] partial context sums (vector path)
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T* hp = hproj + (long long)n * ldh;
-  for (int t = wave; t < Tn; t += 8) {
-    const T* ep = eproj + ((long long)n * Tn + t) * Hd;
-    float s = 0.f;
-    for (int j = lane; j < Hd; j += 64) s += v[j] * tanhf(to_f32(hp[j]) + to_f32(ep[j]));
-    s = wave_sum(s);
-    if (lane == 0) en[t] = s;
+  const bool vec_ok = (Hd % VEC == 0) && (Ep % VEC == 0) && (ldh % VEC == 0);
+  if (vec_ok) {
+    for (int t = wave; t < Tn; t += 8) {
+      const T* ep = eproj + ((long long)n * Tn + t) * Hd;
+      float s = 0.f;
+      for (int j = lane * VEC; j < Hd; j += 64 * VEC) {
+        float a[VEC], b[VEC];
+        AttVec<T>::load(hp + j, a);
+        AttVec<T>::load(ep + j, b);
+        const f32x4 v0 = *(const f32x4*)(v + j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += v0[q] * tanhf(a[q] + b[q]);
+        if (VEC == 8) {
+          const f32x4 v1 = *(const f32x4*)(v + j + 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s += v1[q] * tanhf(a[4 + q] + b[4 + q]);
+        }
+      }
+      s = wave_sum(s);
+      if (lane == 0) en[t] = s;
+    }
+  } else {
+    for (int t = wave; t < Tn; t += 8) {
+      const T* ep = eproj + ((long long)n * Tn + t) * Hd;
+      float s = 0.f;
+      for (int j = lane; j < Hd; j += 64) s += v[j] * tanhf(to_f32(hp[j]) + to_f32(ep[j]));
+      s = wave_sum(s);
+      if (lane == 0) en[t] = s;
+    }
   }
   __syncthreads();
   if (wave == 0) {
@@ -288,16 +334,44 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const T* __restrict__ hp
     }
   }
   __syncthreads();
-  for (int c = tid; c < Ep; c += 512) {
-    float s = 0.f;
-    for (int t = 0; t < Tn; ++t) s += en[t] * to_f32(enc[((long long)n * Tn + t) * Ep + c]);
-    context[(long long)n * Ep + c] = from_f32<T>(s);
+  if (vec_ok) {
+    const int nv = Ep / VEC;                       // channel vectors
+    const int groups = max(1, min(512 / nv, Tn));   // position groups that fit the block
+    if (tid < groups * nv) {
+      const int gidx = tid / nv, cv = tid - gidx * nv;
+      float acc[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+      for (int t = gidx; t < Tn; t += groups) {
+        float f[VEC];
+        AttVec<T>::load(enc + ((long long)n * Tn + t) * Ep + cv * VEC, f);
+        const float w = en[t];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] += w * f[q];
+      }
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) part[gidx * Ep + cv * VEC + q] = acc[q];
+    }
+    __syncthreads();
+    for (int c = tid; c < Ep; c += 512) {
+      float s = 0.f;
+      for (int gi = 0; gi < groups; ++gi) s += part[gi * Ep + c];
+      context[(long long)n * Ep + c] = from_f32<T>(s);
+    }
+  } else {
+    for (int c = tid; c < Ep; c += 512) {
+      float s = 0.f;
+      for (int t = 0; t < Tn; ++t) s += en[t] * to_f32(enc[((long long)n * Tn + t) * Ep + c]);
+      context[(long long)n * Ep + c] = from_f32<T>(s);
+    }
   }
 }
 
 // backward of one step, grid (N, Hd / 64): every workgroup redoes the cheap part (dw = dcontext . enc, softmax backward)
 // and owns a 64-unit slice of the tanh chain: dhproj (written, leading dimension lddh), deproj (+=), dv (atomics).
 // The encoder-side gradient (denc) is NOT touched here: attn_denc_kernel sums it over the steps after the loop.
+// dw: all positions at once -- 8 lanes per position, 16-byte vectors (one wave per position with 2-byte loads measured
+// 27 us per launch at N = 32).
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd2_kernel(const T* __restrict__ dcontext,
                                                         const float* __restrict__ dweights, long long ldw,
@@ -307,14 +381,37 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(const T* __restrict__ dc
                                                         T* __restrict__ dhproj, long long lddh,
                                                         float* __restrict__ deproj, float* __restrict__ dv, int Tn,
                                                         int Hd, int Ep) {
+  constexpr int VEC = AttVec<T>::N;
   __shared__ float dw[64], de[64], red[4][64], redv[4][64];
   const int n = blockIdx.x, js = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int t = wave; t < Tn; t += 4) {
-    float s = 0.f;
-    for (int c = lane; c < Ep; c += 64)
-      s += to_f32(dcontext[(long long)n * Ep + c]) * to_f32(enc[((long long)n * Tn + t) * Ep + c]);
-    s = wave_sum(s);
-    if (lane == 0) dw[t] = s + (dweights ? dweights[(long long)n * ldw + t] : 0.f);
+  if (Ep % VEC == 0) {
+    for (int t0 = 0; t0 < Tn; t0 += 32) {
+      const int t = t0 + (tid >> 3), part8 = tid & 7;
+      float s = 0.f;
+      if (t < Tn) {
+        const T* er = enc + ((long long)n * Tn + t) * Ep;
+        const T* dr = dcontext + (long long)n * Ep;
+        for (int c = part8 * VEC; c < Ep; c += 8 * VEC) {
+          float a[VEC], b[VEC];
+          AttVec<T>::load(dr + c, a);
+          AttVec<T>::load(er + c, b);
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) s += a[q] * b[q];
+        }
+      }
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if (t < Tn && part8 == 0) dw[t] = s + (dweights ? dweights[(long long)n * ldw + t] : 0.f);
+    }
+  } else {
+    for (int t = wave; t < Tn; t += 4) {
+      float s = 0.f;
+      for (int c = lane; c < Ep; c += 64)
+        s += to_f32(dcontext[(long long)n * Ep + c]) * to_f32(enc[((long long)n * Tn + t) * Ep + c]);
+      s = wave_sum(s);
+      if (lane == 0) dw[t] = s + (dweights ? dweights[(long long)n * ldw + t] : 0.f);
+    }
   }
   __syncthreads();
   if (wave == 0) {
@@ -553,7 +650,16 @@ int mr_embed_rows_bwd(int dtype, const long long* idx, const void* dout, float* 
 int mr_attn_fwd2(int dtype, const void* hproj, long long ldh, const void* eproj, const float* v, const void* enc,
                  float* weights, void* context, int N, int Tn, int Hd, int Ep, hipStream_t stream) {
   MR_CHECK_ARG(N > 0 && Tn > 0 && Tn <= 64 && Hd > 0 && Ep > 0 && ldh >= Hd, "mr_attn_fwd2: bad shape (T must be <= 64)");
-  DISPATCH_T(dtype, hipLaunchKernelGGL((attn_fwd2_kernel<T>), dim3(N), dim3(512), 0, stream, (const T*)hproj, ldh,
+  // dynamic LDS: [position groups][Ep] floats of partial context sums (vector path: groups = min(512 / (Ep / VEC), Tn))
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  const int nv = Ep % vec == 0 ? Ep / vec : Ep;
+  int groups = 512 / (nv > 0 ? nv : 1);
+  if (groups > Tn) groups = Tn;
+  if (groups < 1) groups = 1;
+  const size_t lds = (size_t)groups * Ep * sizeof(float);
+  MR_CHECK_ARG(lds <= 48 * 1024 && (Ep % vec != 0 || nv <= 512), "mr_attn_fwd2: Ep too large (%d)", Ep);
+  MR_CHECK_ARG(((uintptr_t)v & 15) == 0, "mr_attn_fwd2: v must be 16-byte aligned");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((attn_fwd2_kernel<T>), dim3(N), dim3(512), lds, stream, (const T*)hproj, ldh,
                                        (const T*)eproj, v, (const T*)enc, weights, (T*)context, Tn, Hd, Ep));
   MR_CHECK_LAUNCH();
   return MR_OK;

@@ -470,6 +470,11 @@ static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
 
 using namespace mr;
 
+namespace mr {
+bool gemm_nt_skinny(int dtype, const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc,
+                    const float* bias, int relu, int M, int N, int K, hipStream_t stream);
+}
+
 extern "C" {
 
 // Eagerly create per-device state (the zero page).  Call once per device before capturing a hipGraph.
@@ -629,6 +634,10 @@ int mr_gemm_nt(int dtype, const void* A, long long lda, const void* B, int ldb, 
   MR_CHECK_ARG(K % vec == 0 && lda % vec == 0 && ldb % vec == 0,
                "mr_gemm_nt: K/lda/ldb must be multiples of %d (K=%d lda=%lld ldb=%d)", vec, K, lda, ldb);
   MR_CHECK_ARG(aligned16(A) && aligned16(B), "mr_gemm_nt: A and B must be 16-byte aligned");
+  if (mr::gemm_nt_skinny(dtype, A, lda, B, ldb, C, ldc, bias, relu, M, N, K, stream)) {   // M <= 32: gemm_skinny.hip
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+  }
   NtArgs a;
   a.A = A; a.B = B; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.zero = nullptr;
   ConvGeom g = {};

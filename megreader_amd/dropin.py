@@ -23,7 +23,7 @@ OVERRIDES = {
                                               "resnet152", "deformable_resnet50", "resnet50dilated_ppm",
                                               "Resnet18FPN", "Resnet34FPN", "Resnet50FPN", "Resnet101FPN",
                                               "Resnet152FPN"]),
-    "decoders": ("megreader_amd.decoders", ["CRNNDecoder", "CTCDecoder2D", "AttentionDecoder", "SegDetector"]),
+    "decoders": ("megreader_amd.decoders", ["CRNNDecoder", "CTCDecoder", "CTCDecoder2D", "AttentionDecoder", "SegDetector"]),
     # evaluation side: the YAMLs name these classes through `package: [structure.representers,
     # structure.measurers, ...]` + `class: CTCRepresenter` (concern/config.py:28-29,57-60), resolved with getattr
     "structure.representers": ("megreader_amd.structure", ["CTCRepresenter", "CTCRepresenter2D",
@@ -124,12 +124,40 @@ class _GraphedTrainStep(object):
                 return self.original(trainer, model, optimizer, batch, epoch=epoch, step=step, **kwargs)
             self.state = (sig, static, graphed, holder)
         _sig, static, graphed, holder = self.state
-        for k, v in batch.items():
-            if isinstance(v, torch.Tensor):
-                static[k].copy_(v, non_blocking=True)
+        self._upload(batch, static)
         loss = graphed()
         self._log(trainer, loss, holder.get("metrics", {}), epoch, step)
-        return loss
+        return loss.detach().clone()     # the graph's loss tensor is overwritten by the next replay
+
+    def _upload(self, batch, static):
+        """Host batch -> the graph's static tensors without stalling the host: H2D into one of two staging sets on a copy
+        stream (it overlaps the previous step's replay, which is still running), then a device-to-device copy on the
+        main stream right in front of the replay.  (The DataLoader of the reference pins its batches, data_loader.py:46;
+        pageable batches work too, their H2D copy is just synchronous.)"""
+        import torch
+        if not hasattr(self, "_copy_stream"):
+            self._copy_stream = torch.cuda.Stream()
+            self._staging = [{k: torch.empty_like(v) for k, v in static.items() if isinstance(v, torch.Tensor)}
+                             for _ in range(2)]
+            self._consumed = [None, None]      # event: the main stream has copied staging set i into the static tensors
+            self._slot = 0
+        i = self._slot
+        self._slot ^= 1
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self._copy_stream):
+            if self._consumed[i] is not None:
+                self._copy_stream.wait_event(self._consumed[i])
+            for k, v in batch.items():
+                if isinstance(v, torch.Tensor):
+                    self._staging[i][k].copy_(v, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self._copy_stream)
+        main.wait_event(ready)
+        for k, st in self._staging[i].items():
+            static[k].copy_(st, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(main)
+        self._consumed[i] = done
 
     @staticmethod
     def _log(trainer, loss, metrics, epoch, step):

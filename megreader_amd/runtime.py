@@ -23,16 +23,22 @@ by bucket, and is what the reference's trainer uses.)
 import torch
 
 
-def data_parallel_grad_sync(optimizer, group=None, average=True):
+def data_parallel_grad_sync(optimizer, group=None, average=True, fold=True):
     """Returns a function that averages the gradients of a fused optimizer across the ranks of `group`: one
-    in-place all-reduce per flat gradient buffer (apex DDP semantics: sum, then divide by the world size)."""
+    in-place all-reduce per flat gradient buffer (apex DDP semantics: sum, then divide by the world size).
+    fold=True (default): the 1 / world factor is applied inside the optimizer's update kernel
+    (`optimizer.set_grad_scale`), not by a separate pass over the reduced buffer."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    scale_here = average and world > 1
+    if scale_here and fold and hasattr(optimizer, "set_grad_scale"):
+        optimizer.set_grad_scale(1.0 / world)
+        scale_here = False
 
     def sync():
         for flat in optimizer.flat_grads():
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-            if average and world > 1:
+            if scale_here:
                 flat.mul_(1.0 / world)
     return sync
 

@@ -308,3 +308,62 @@ def test_default_bucket_plan_has_at_least_four_buckets():
     if cur:
         buckets.append(cur)
     assert MIN_BUCKETS >= 4 and len(buckets) >= 3 and max(buckets) < 0.6 * total
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# runtime.data_parallel_grad_sync (the graphed data-parallel path: one in-place all-reduce per flat gradient buffer between
+# the two captured graphs) on 2 gloo ranks, with a stand-in for the fused optimizer's flat-buffer interface
+# (flat_grads / set_grad_scale; the real FusedAdam is GPU-only): the buffers end up holding the SUM over ranks and the
+# 1 / world factor is handed to the optimizer (fold=True) or applied in place (fold=False).
+# ---------------------------------------------------------------------------------------------------------------
+class _FlatOpt(object):
+    def __init__(self, bufs):
+        self.bufs = bufs
+        self.scale = None
+
+    def flat_grads(self):
+        return self.bufs
+
+    def set_grad_scale(self, s):
+        self.scale = s
+
+
+def _sync_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from megreader_amd.runtime import data_parallel_grad_sync
+    out = {}
+    for fold in (True, False):
+        bufs = [torch.arange(10, dtype=torch.float32) * (rank + 1), torch.full((7,), float(rank + 3))]
+        opt = _FlatOpt(bufs)
+        sync = data_parallel_grad_sync(opt, fold=fold)
+        sync()
+        out[fold] = ([b.numpy().copy() for b in bufs], opt.scale)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graphed_path_grad_sync_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, out = q.get(timeout=120)
+        res[rank] = out
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a_sum = torch.arange(10, dtype=torch.float32) * 3            # rank 0: x1, rank 1: x2
+    b_sum = torch.full((7,), 3.0 + 4.0)
+    for rank in (0, 1):
+        (a, b), scale = res[rank][True]
+        assert scale == 0.5 and torch.equal(torch.from_numpy(a), a_sum) and torch.equal(torch.from_numpy(b), b_sum)
+        (a, b), scale = res[rank][False]
+        assert scale is None and torch.equal(torch.from_numpy(a), a_sum / 2) and torch.equal(torch.from_numpy(b), b_sum / 2)

@@ -145,3 +145,40 @@ def test_crnn_decoder_variants_oracle_vs_reference(reduce_func, loss_func):
     assert lr_.shape == lo.shape and (lr_.detach().double() - lo.detach()).abs().max() < 1e-9 * max(1.0, float(lo.detach().abs().max()))
     ref.eval(), ora.eval()
     assert torch.equal(ref(feat), ora(feat))
+
+
+def test_ctc_decoder_oracle_and_mirror_vs_reference():
+    """decoders.CTCDecoder (decoders/ctc_decoder.py:13-66): the oracle restatement is bit-identical to the unmodified reference
+    module on CPU (state_dict keys + seeded init, training loss / log-probabilities / every gradient, eval softmax) and the HIP
+    mirror has the same state_dict."""
+    from oracle import refimport
+    if not refimport.available():
+        pytest.skip("reference tree not present")
+    refimport.import_reference()
+    from decoders.ctc_decoder import CTCDecoder as RefDecoder
+    from megreader_amd.decoders import CTCDecoder
+    from megreader_amd.charsets import DefaultCharset
+    from oracle.ctc_decoder import CTCDecoderOracle
+    torch.manual_seed(7)
+    ref = RefDecoder(in_channels=24, inner_channels=32)
+    torch.manual_seed(7)
+    ora = CTCDecoderOracle(24, num_classes=len(DefaultCharset()), inner_channels=32)
+    torch.manual_seed(7)
+    ours = CTCDecoder(in_channels=24, inner_channels=32)
+    assert list(ref.state_dict()) == list(ora.state_dict()) == list(ours.state_dict())
+    for k, v in ref.state_dict().items():
+        assert torch.equal(v, ora.state_dict()[k]) and torch.equal(v, ours.state_dict()[k]), k
+    g = torch.Generator().manual_seed(2)
+    feat = torch.randn(3, 24, 16, 64, generator=g)
+    labels = torch.randint(1, 38, (3, 8), generator=g, dtype=torch.long)
+    lengths = torch.tensor([8, 3, 5], dtype=torch.long)
+    ref.train(), ora.train()
+    lr_, pr = ref(feat, targets=labels, lengths=lengths, train=True)
+    lo, po = ora(feat, targets=labels, lengths=lengths, train=True)
+    assert torch.equal(pr, po) and torch.equal(lr_, lo) and lr_.dim() == 0 and pr.shape == (3, 38, 32)
+    lr_.backward()
+    lo.backward()
+    for (k, p), (_, q) in zip(ref.named_parameters(), ora.named_parameters()):
+        assert torch.equal(p.grad, q.grad), k
+    ref.eval(), ora.eval()
+    assert torch.equal(ref(feat), ora(feat))

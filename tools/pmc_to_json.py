@@ -3,9 +3,23 @@
 profiles/r01_pmc_traffic.json: HBM-side bytes per launch of the conv igemm kernels, keyed by bench.py's kernel labels.
 FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled (gfx950 counts 128-byte requests as 64 B, see
 /opt/skills/guides/MI355X_MICROARCH.md "HBM").  Usage: pmc_to_json.py FETCH.txt WRITE.txt OUT.json"""
+import hashlib
 import json
+import os
 import re
 import sys
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources (megreader_amd/csrc/*.hip, *.h): bench.py recomputes it and reports `traffic: null`
+    when the committed PMC file was measured on other kernels (same function there: keep the two in sync)."""
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "megreader_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(here)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(here, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse(path):
@@ -54,6 +68,7 @@ def main():
         out[lab] = {"fetch_size_kb_mean": fkb, "write_size_kb_mean": wkb, "launches": n,
                     "bytes_per_launch": 2.0 * fkb * 1024 + wkb * 1024,
                     "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes, mean per launch"}
+    out["_kernel_source_hash"] = kernel_source_hash()
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
 
