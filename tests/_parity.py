@@ -23,7 +23,7 @@ def f64_grads(ora32, forward):
     return {k: p.grad.detach().clone() for k, p in ora64.named_parameters() if p.grad is not None}
 
 
-def grad_report(named_params, grads32, grads64, what, elem_floor=1e-2, l2_floor=2e-3, top=25):
+def grad_report(named_params, grads32, grads64, what, elem_floor=1e-2, l2_floor=2e-3, top=25, always=()):
     rows, bad = [], []
     for k, p in named_params:
         g64 = grads64[k].double()
@@ -45,6 +45,7 @@ def grad_report(named_params, grads32, grads64, what, elem_floor=1e-2, l2_floor=
             bad.append((k, e_hip, e_cpu, l_hip, l_cpu))
     print("%s: element-wise gradient error / max|g_f64|   (HIP f32 | CPU f32 oracle)   rel. L2 (HIP | CPU)" % what)
     shown = rows if len(rows) <= 60 else sorted(rows, key=lambda r: -r[2])[:top]
+    shown = shown + [r for r in rows if r not in shown and any(a in r[0] for a in always)]
     for k, scale, e_hip, e_cpu, l_hip, l_cpu in shown:
         print("   %-56s max|g| %.3e   %.2e | %.2e    %.2e | %.2e" % (k, scale, e_hip, e_cpu, l_hip, l_cpu))
     if rows:

@@ -177,7 +177,7 @@ def test_fpn_attention_fp32_n32_elementwise():
             "decoder.decoder.out.weight", "decoder.decoder.out.bias")
     have = {k for k, _ in named}
     assert all(k in have for k in must), [k for k in must if k not in have]
-    grad_report(named, grads_o, grads64, "FPN50-attention fp32 64x256 N=32")
+    grad_report(named, grads_o, grads64, "FPN50-attention fp32 64x256 N=32", always=("decoder.decoder.",))
     # ---- greedy decode (eval path: argmax feedback, early stop) at this batch
     ora.eval()
     model.eval()
@@ -270,4 +270,4 @@ def test_db_detector_fp32_640_elementwise():
             assert p.grad is None, k          # fc / smooth
     named = [(k, p) for k, p in model.named_parameters() if k in grads_o]
     assert sum(1 for k, _ in named if "conv2_offset" in k) == 26    # 13 DCN layers: offset-conv weight + bias
-    grad_report(named, grads_o, grads64, "DB detector fp32 640x640 N=2")
+    grad_report(named, grads_o, grads64, "DB detector fp32 640x640 N=2", always=("conv2_offset.weight", "layer4.2.conv2."))
