@@ -18,7 +18,8 @@ namespace mr {
 bool dcn_fused_ok(int dtype, int H, int W, int C, int Co, int kh, int kw);
 long long dcn_fused_ws_bytes(int N, int H, int W, int Ho, int Wo, int taps);
 int dcn_fused_fwd(int dtype, const void* x, const void* w_n, const float* bias, const float* offset, const float* mask,
-                  void* y, const DcnGeom& g, int Co, hipStream_t stream);
+                  void* y, void* ws, const DcnGeom& g, int Co, hipStream_t stream);
+long long dcn_fused_fwd_ws_bytes(int N, int Ho, int Wo, int Co, int taps);
 int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, const float* offset, const float* mask,
                   void* ws, float* dx32, float* doffset, float* dmask, float* dw, float* dbias, const DcnGeom& g, int Co,
                   hipStream_t stream);
@@ -437,7 +438,8 @@ int mr_set_dcn_v1_bwd(int on) {
 // bytes of the caller-owned workspace `col_ws` of mr_dcn2_fwd (backward = 0) / mr_dcn2_bwd (backward = 1) for this shape:
 // fused path: nothing forward, the CSR of the scatter pattern backward; general path: the column matrix.
 long long mr_dcn2_ws_bytes(int dtype, int N, int H, int W, int C, int Co, int kh, int kw, int Ho, int Wo, int backward) {
-  if (dcn_fused_ok(dtype, H, W, C, Co, kh, kw)) return backward ? dcn_fused_ws_bytes(N, H, W, Ho, Wo, kh * kw) : 0;
+  if (dcn_fused_ok(dtype, H, W, C, Co, kh, kw))
+    return backward ? dcn_fused_ws_bytes(N, H, W, Ho, Wo, kh * kw) : dcn_fused_fwd_ws_bytes(N, Ho, Wo, Co, kh * kw);
   return (long long)N * Ho * Wo * kh * kw * C * (dtype == MR_F32 ? 4 : 2);
 }
 
@@ -449,11 +451,11 @@ long long mr_dcn2_ws_bytes(int dtype, int N, int H, int W, int C, int Co, int kh
 int mr_dcn2_fwd(int dtype, const void* x, const void* w_n, const float* bias, const float* offset, long long off_bs,
                 const float* mask, long long msk_bs, void* y, void* col_ws, int N, int H, int W, int C, int Co, int kh,
                 int kw, int stride, int pad, int dil, int Ho, int Wo, hipStream_t stream) {
-  if (dcn_fused_ok(dtype, H, W, C, Co, kh, kw)) {   // sample -> LDS -> MFMA, no column matrix (col_ws unused, may be NULL)
+  if (dcn_fused_ok(dtype, H, W, C, Co, kh, kw)) {   // sample -> LDS -> MFMA, no column matrix (col_ws = f32 accumulator of the tap-split launch for small layers, else unused)
     DcnGeom g;
     int rcg = make_geom(g, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo, off_bs, msk_bs);
     if (rcg) return rcg;
-    return dcn_fused_fwd(dtype, x, w_n, bias, offset, mask, y, g, Co, stream);
+    return dcn_fused_fwd(dtype, x, w_n, bias, offset, mask, y, col_ws, g, Co, stream);
   }
   MR_CHECK_ARG(col_ws != nullptr, "mr_dcn2_fwd: this shape needs a column workspace (mr_dcn2_ws_bytes)");
   int rc = mr_dcn2_im2col(dtype, x, offset, off_bs, mask, msk_bs, col_ws, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo,

@@ -88,8 +88,12 @@ struct DcnFusedArgs {
   float* dx;
   const int* start;      // CSR row starts, [Q*taps + 1]
   const int2* entries;   // CSR entries {output pixel p, bits of the bilinear * mask weight}
+  float* y32;            // fwd with tap splits: f32 [P][Co] accumulator (zeroed), converted by dcn_finish_kernel
   DcnGeom g;
   int Co, P, Q;
+  int tsplit;            // tap groups (grid.y): the k-loop of a workgroup covers taps / tsplit taps; partial results are
+                         // combined with f32 atomics.  Small layers (batch 2 of the DB detector: 52 workgroups running
+                         // 72 dependent k-steps each) are latency chains without it.
 };
 
 // blend of the four corner vectors in the reference's corner order (top-left, top-right, bottom-left, bottom-right)
@@ -124,13 +128,55 @@ __device__ __forceinline__ void dcn_corner_loads(uint4 (&raw)[4], const T* __res
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// 32-bit addressing through buffer resources: a corner is one byte offset (or DCN_OOB, which the hardware answers with zeros:
+// no branch, no 64-bit address arithmetic), computed ONCE per (row, tap) into an LDS table next to the four blend weights.
+// Per k-step a thread then spends one LDS read + one add per corner on addressing (the first version recomputed hl/wl, the
+// inside tests and a 64-bit multiply-add per corner per k-step: 292 VALU instructions per 16 MFMAs, SQ counters in
+// profiles/r03_pmc_sq_dcn_fused_pass{1,2}.txt).
+constexpr unsigned DCN_OOB = 0x80000000u;   // >= num_records of make_rsrc (2 GiB), also after adding a channel offset
+
+__device__ __forceinline__ uint4 buf_ld16(rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
+// byte offsets of the four corners of a sample at channel 0 (DCN_OOB outside the image) and the blend weights (mask folded in)
+template <typename T>
+__device__ __forceinline__ void dcn_corner_table(const DcnGeom& g, int pixbase, const DcnDesc& d, uint4& off, float4& wgt) {
+  unsigned o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int h = d.hl + (k >> 1), w = d.wl + (k & 1);
+    o[k] = dcn_inside(g, h, w) ? (unsigned)((pixbase + h * g.W + w) * g.C) * (unsigned)sizeof(T) : DCN_OOB;
+  }
+  off = make_uint4(o[0], o[1], o[2], o[3]);
+  wgt = make_float4((1.f - d.lh) * (1.f - d.lw) * d.m, (1.f - d.lh) * d.lw * d.m, d.lh * (1.f - d.lw) * d.m,
+                    d.lh * d.lw * d.m);
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 dcn_blend_w(const uint4 (&raw)[4], const float4& w4) {
+  constexpr int VEC = VecOf<T>::N;
+  const float wgt[4] = {w4.x, w4.y, w4.z, w4.w};
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const T* pv = (const T*)&raw[k];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] += wgt[k] * to_f32(pv[j]);
+  }
+  return pack_vec<T>(acc);
+}
+
 template <typename T, int BN>
 __global__ __launch_bounds__(256) void dcn2_fwd_fused_kernel(DcnFusedArgs a) {
   typedef DcnNt<T, BN> Nt;
   constexpr int BM = Nt::BM, VEC = Nt::VEC, BK = Nt::BK, AI = Nt::AI, BI = Nt::BI, TM = Nt::TM, TN = Nt::TN;
+  constexpr unsigned ES = sizeof(T);
   __shared__ uint4 smem[8 * (BM + BN)];
-  __shared__ float4 sdesc[DCN_MAX_TAPS * BM];
-  __shared__ int spix[BM];
+  __shared__ float4 swgt[DCN_MAX_TAPS * BM];
+  __shared__ uint4 soff[DCN_MAX_TAPS * BM];
   uint4* sA = smem;
   uint4* sB = smem + 8 * BM;
   const DcnGeom& g = a.g;
@@ -140,14 +186,12 @@ __global__ __launch_bounds__(256) void dcn2_fwd_fused_kernel(DcnFusedArgs a) {
   const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kc = tid & 7, r0 = tid >> 3;
-  const T* __restrict__ X = (const T*)a.x;
-  const T* __restrict__ Wn = (const T*)a.w;
+  const rsrc_t rX = make_rsrc(a.x), rW = make_rsrc(a.w);
 
   for (int idx = tid; idx < BM * taps; idx += 256) {
     const int row = idx % BM, tap = idx / BM;
     const int p = m0 + row;
-    DcnDesc d;
-    d.m = 0.f; d.lh = 0.f; d.lw = 0.f; d.hl = -2; d.wl = -2;
+    DcnDesc d = dcn_desc_invalid();
     int pb = 0;
     if (p < a.P) {
       const int wo = p % g.Wo, r = p / g.Wo;
@@ -155,31 +199,38 @@ __global__ __launch_bounds__(256) void dcn2_fwd_fused_kernel(DcnFusedArgs a) {
       d = dcn_desc(g, a.offset, a.mask, n, tap, ho, wo);
       pb = n * g.H * g.W;
     }
-    sdesc[tap * BM + row] = dcn_pack(d);
-    if (tap == 0) spix[row] = pb;
+    uint4 off;
+    float4 wgt;
+    dcn_corner_table<T>(g, pb, d, off, wgt);
+    soff[tap * BM + row] = off;
+    swgt[tap * BM + row] = wgt;
+  }
+  // weight rows of this thread: byte offset of (row n, k = kc*VEC), DCN_OOB beyond Co
+  unsigned boff[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int n = n0 + r0 + 32 * i;
+    boff[i] = n < a.Co ? (unsigned)(n * K + kc * VEC) * ES : DCN_OOB;
   }
   __syncthreads();
 
-  // two k-steps of corner / weight loads are in flight (slots 0 / 1): a step's loads are issued two steps before their
-  // blend, so they have a whole MFMA + blend + barrier round to land (one step ahead measured latency-bound: 1.7 us per
-  // k-step, profiles/r03_dcn_microbench_b16_fused_kernel_stats_v1.csv)
-  uint4 raw[2][AI][4], rbq[2][BI], ra[AI];
-  auto issue = [&](int k0, auto slot_c) {
-    constexpr int SL = decltype(slot_c)::value;
-    const int tap = k0 / g.C;
-    const int c = k0 - tap * g.C + kc * VEC;
+  uint4 raw[AI][4], ra[AI], rb[BI];
+  int i_tap = 0, i_c = 0;          // (tap, first channel) of the NEXT k-step to issue
+  auto issue = [&](int k0) {
+    const unsigned cb = (unsigned)(i_c + kc * VEC) * ES;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int row = r0 + 32 * i;
-      const DcnDesc d = dcn_unpack(sdesc[tap * BM + row]);
-      dcn_corner_loads<T>(raw[SL][i], X, g, spix[row], d, c);
+      const uint4 o = soff[i_tap * BM + r0 + 32 * i];
+      raw[i][0] = buf_ld16(rX, o.x + cb);
+      raw[i][1] = buf_ld16(rX, o.y + cb);
+      raw[i][2] = buf_ld16(rX, o.z + cb);
+      raw[i][3] = buf_ld16(rX, o.w + cb);
     }
+    const unsigned kb = (unsigned)k0 * ES;
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int n = n0 + r0 + 32 * i;
-      rbq[SL][i] = make_uint4(0, 0, 0, 0);
-      if (n < a.Co) rbq[SL][i] = ldg16(Wn + (long long)n * K + k0 + kc * VEC);
-    }
+    for (int i = 0; i < BI; ++i) rb[i] = buf_ld16(rW, boff[i] + kb);
+    i_c += BK;
+    if (i_c == g.C) { i_c = 0; ++i_tap; }
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -191,26 +242,36 @@ __global__ __launch_bounds__(256) void dcn2_fwd_fused_kernel(DcnFusedArgs a) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto step = [&](int k0, auto slot_c) {
-    constexpr int SL = decltype(slot_c)::value;
-    const int tap = k0 / g.C;
+  const int tper = taps / a.tsplit;
+  const int k_begin = blockIdx.y * tper * g.C, k_end = k_begin + tper * g.C;
+  i_tap = blockIdx.y * tper;
+  int f_tap = i_tap, f_c = 0;      // (tap, first channel) of the k-step whose loads are in `raw`
+  issue(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
 #pragma unroll
-    for (int i = 0; i < AI; ++i) ra[i] = dcn_blend<T>(raw[SL][i], dcn_unpack(sdesc[tap * BM + r0 + 32 * i]));
-    Nt::store(sA, sB, ra, rbq[SL], kc, r0);
+    for (int i = 0; i < AI; ++i) ra[i] = dcn_blend_w<T>(raw[i], swgt[f_tap * BM + r0 + 32 * i]);
+    f_c += BK;
+    if (f_c == g.C) { f_c = 0; ++f_tap; }
+    Nt::store(sA, sB, ra, rb, kc, r0);
     __syncthreads();
-    if (k0 + 2 * BK < K) issue(k0 + 2 * BK, slot_c);   // refill the slot just consumed
+    if (k0 + BK < k_end) issue(k0 + BK);   // corner / weight loads stay in flight under the MFMAs
     Nt::mma(sA, sB, acc, wm_, wn_, l15, lg);
     __syncthreads();
-  };
-  typedef std::integral_constant<int, 0> S0;
-  typedef std::integral_constant<int, 1> S1;
-  issue(0, S0());
-  if (BK < K) issue(BK, S1());
-  for (int k0 = 0; k0 < K; k0 += 2 * BK) {
-    step(k0, S0());
-    if (k0 + BK < K) step(k0 + BK, S1());
   }
 
+  if (a.tsplit > 1) {   // partial sums of this tap group into the f32 accumulator; dcn_finish_kernel adds the bias and converts
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int m = m0 + wm_ * Nt::WTM + j * 16 + l15;
+        const int n = n0 + wn_ * Nt::WTN + i * 16 + lg * 4;
+        if (m >= a.P || n >= a.Co) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(a.y32 + (long long)m * a.Co + n + e, acc[i][j][e]);
+      }
+    return;
+  }
   T* __restrict__ Y = (T*)a.y;
 #pragma unroll
   for (int j = 0; j < TM; ++j)
@@ -226,6 +287,28 @@ __global__ __launch_bounds__(256) void dcn2_fwd_fused_kernel(DcnFusedArgs a) {
       }
       store4(Y + (long long)m * a.Co + n, v);
     }
+}
+
+// y[m, n] = T(y32[m, n] + bias[n])   (forward with tap splits)
+template <typename T>
+__global__ void dcn_finish_kernel(const float* __restrict__ y32, const float* __restrict__ bias, T* __restrict__ y,
+                                  long long total4, int Co) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 v = ((const f32x4*)y32)[i];
+    if (bias) {
+      const int n = (int)((i * 4) % Co);
+      v += *(const f32x4*)(bias + n);
+    }
+    store4(y + i * 4, v);
+  }
+}
+
+// tap groups for a launch of `tiles` workgroups (taps = 9): only launches that leave most of the chip idle are split -- the
+// partial results meet in f32 atomics (+ a memset and a convert pass forward), which cost more than the shorter k-loop saves
+// once ~100 workgroups exist (measured at batch 2: layer2.1 forward with 200 tiles 29 us unsplit, 87 us split 3-way).
+static int dcn_tap_split(long long tiles, int taps) {
+  if (taps != 9) return 1;
+  return tiles < 96 ? 9 : 1;
 }
 
 // ------------------------------------------------------------------------------------------------ d offset / d mask
@@ -289,9 +372,11 @@ __global__ __launch_bounds__(256) void dcn2_coord_fused_kernel(DcnFusedArgs a) {
   }
 
   load(0);
-  // bf16: the epilogue's corner vectors of x (4 corners x TN x 8 bytes per pixel) are requested now as well and land while the
-  // GEMM loop runs (f32 would need 128 registers for them: fetched in the epilogue instead)
-  constexpr bool PREFETCH_X = sizeof(T) == 2;
+  // optionally the epilogue's corner vectors of x (4 corners x TN x 8 bytes per pixel) are requested now as well and land
+  // while the GEMM loop runs
+  // (measured: prefetching the x corners for bf16 costs 64 registers -> 3 instead of 6 workgroups per CU: 188 us per layer
+  // instead of 144 us; the kernel is latency-bound per tile and lives on occupancy.  Kept as a compile-time switch.)
+  constexpr bool PREFETCH_X = false;
   typedef typename std::conditional<sizeof(T) == 2, uint2, uint4>::type XV;   // 4 channels of T
   XV xq[PREFETCH_X ? TM : 1][4][TN];
   auto corner_ptr = [&](int j, int k) -> const T* {
@@ -470,11 +555,13 @@ __global__ __launch_bounds__(256) void dcn2_dx_fused_kernel(DcnFusedArgs a) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  load_entries(entC, seg_base(0), seg_cnt(0));
-  load_b(0);
-  load_dy(entC, 0);
-  if (BK < K) load_entries(entN, seg_base(BK), seg_cnt(BK));
-  for (int k0 = 0; k0 < K; k0 += BK) {
+  const int tper = taps / a.tsplit;
+  const int k_begin = blockIdx.y * tper * Co, k_end = k_begin + tper * Co;
+  load_entries(entC, seg_base(k_begin), seg_cnt(k_begin));
+  load_b(k_begin);
+  load_dy(entC, k_begin);
+  if (k_begin + BK < k_end) load_entries(entN, seg_base(k_begin + BK), seg_cnt(k_begin + BK));
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
     const int tap = k0 / Co;
     const int s0 = sstart[tap * (BM + 1)], s1 = sstart[tap * (BM + 1) + BM];
 #pragma unroll
@@ -499,12 +586,12 @@ __global__ __launch_bounds__(256) void dcn2_dx_fused_kernel(DcnFusedArgs a) {
     for (int i = 0; i < AI; ++i) ra[i] = pack_vec<T>(accv[i]);
     Nt::store(sA, sB, ra, rb, kc, r0);
     __syncthreads();
-    if (k0 + BK < K) {
+    if (k0 + BK < k_end) {
 #pragma unroll
       for (int j = 0; j < GJ; ++j) entC[j] = entN[j];
       load_dy(entC, k0 + BK);
       load_b(k0 + BK);
-      if (k0 + 2 * BK < K) load_entries(entN, seg_base(k0 + 2 * BK), seg_cnt(k0 + 2 * BK));
+      if (k0 + 2 * BK < k_end) load_entries(entN, seg_base(k0 + 2 * BK), seg_cnt(k0 + 2 * BK));
     }
     Nt::mma(sA, sB, acc, wm_, wn_, l15, lg);
     __syncthreads();
@@ -518,9 +605,14 @@ __global__ __launch_bounds__(256) void dcn2_dx_fused_kernel(DcnFusedArgs a) {
       const int n = n0 + wn_ * Nt::WTN + i * 16 + lg * 4;
       if (q >= a.Q) continue;
       float* dst = a.dx + (long long)q * g.C + n;
-      f32x4 v = *(const f32x4*)dst;      // accumulate semantics (the caller hands a zeroed buffer, like the reference)
-      v += acc[i][j];
-      *(f32x4*)dst = v;
+      if (a.tsplit > 1) {                // several workgroups (tap groups) add into the same elements
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dst + e, acc[i][j][e]);
+      } else {
+        f32x4 v = *(const f32x4*)dst;    // accumulate semantics (the caller hands a zeroed buffer, like the reference)
+        v += acc[i][j];
+        *(f32x4*)dst = v;
+      }
     }
 }
 
@@ -686,6 +778,8 @@ __global__ __launch_bounds__(256) void dcn2_wgrad_fused_kernel(DcnWgradArgs a) {
 
   uint4 ra[NI], rb[NI], raw[NI][4];
   DcnDesc ds[NI];
+  float4 wq[NI];
+  const rsrc_t rX = make_rsrc(a.x);
   const bool do_colsum = a.dbias != nullptr && tile_b == 0;
   typedef typename std::conditional<IS_BF16, float, double>::type CsT;
   CsT csum[VEC];
@@ -740,7 +834,13 @@ __global__ __launch_bounds__(256) void dcn2_wgrad_fused_kernel(DcnWgradArgs a) {
       ra[i] = make_uint4(0, 0, 0, 0);
       if (p < p_end && ca_ok) ra[i] = ldg16(A + (long long)p * NA + ca);
       ds[i] = b_ok[i] ? dcn_desc_from(g, tap, b_h[i], b_w[i], b_oh[i], b_ow[i], b_m[i]) : dcn_desc_invalid();
-      dcn_corner_loads<T>(raw[i], X, g, b_n[i] * g.H * g.W, ds[i], tc);
+      uint4 off;
+      dcn_corner_table<T>(g, b_n[i] * g.H * g.W, ds[i], off, wq[i]);     // 32-bit offsets, DCN_OOB outside: no branches
+      const unsigned cb = (unsigned)tc * (unsigned)sizeof(T);
+      raw[i][0] = buf_ld16(rX, off.x + cb);
+      raw[i][1] = buf_ld16(rX, off.y + cb);
+      raw[i][2] = buf_ld16(rX, off.z + cb);
+      raw[i][3] = buf_ld16(rX, off.w + cb);
     }
     pbq += BP;
   };
@@ -761,7 +861,7 @@ __global__ __launch_bounds__(256) void dcn2_wgrad_fused_kernel(DcnWgradArgs a) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int pl = rr + ROWS_PER_PASS * i;
-      rb[i] = dcn_blend<T>(raw[i], ds[i]);
+      rb[i] = dcn_blend_w<T>(raw[i], wq[i]);
       *(uint4*)(sA + lds_off(pl)) = ra[i];
       *(uint4*)(sB + lds_off(pl)) = rb[i];
       if (do_colsum) {
@@ -865,6 +965,12 @@ bool dcn_fused_ok(int dtype, int H, int W, int C, int Co, int kh, int kw) {
   return g_dcn_fused && C % 64 == 0 && Co % 64 == 0 && kh * kw <= DCN_MAX_TAPS && H < 32768 && W < 32768;
 }
 
+// the kernels address x / dy / the weight images with 32-bit byte offsets through 2 GiB buffer resources
+static bool dcn_fits_32bit(int dtype, long long x_elems, long long dy_elems, long long w_elems) {
+  const long long es = dtype == MR_F32 ? 4 : 2;
+  return x_elems * es < (1ll << 31) && dy_elems * es < (1ll << 31) && w_elems * es < (1ll << 31);
+}
+
 static inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 // workspace of the fused backward: [count: Q*taps ints][start: Q*taps + 1 ints][block sums][entries: 4*P*taps int2]
@@ -897,19 +1003,48 @@ static DcnWs dcn_ws_layout(void* base, long long Q, long long P, int taps) {
   else { mr::set_error("bad dtype %d", (dtype)); return MR_ERR_DTYPE; }
 
 int dcn_fused_fwd(int dtype, const void* x, const void* w_n, const float* bias, const float* offset, const float* mask,
-                  void* y, const DcnGeom& g, int Co, hipStream_t stream) {
+                  void* y, void* ws, const DcnGeom& g, int Co, hipStream_t stream) {
   DcnFusedArgs a = {};
   a.x = x; a.w = w_n; a.bias = bias; a.offset = offset; a.mask = mask; a.y = y; a.g = g; a.Co = Co;
   a.P = g.N * g.Ho * g.Wo;
-  MR_CHECK_ARG((long long)g.N * g.H * g.W * g.C < (1ll << 31) && (long long)a.P * Co < (1ll << 40), "dcn: tensor too large");
+  MR_CHECK_ARG(dcn_fits_32bit(dtype, (long long)g.N * g.H * g.W * g.C, (long long)a.P * Co, (long long)Co * g.kh * g.kw * g.C),
+               "dcn (fused path): x / y / weights must each be smaller than 2 GiB (mr_set_dcn_fused(0) selects the general "
+               "kernels)");
   const int tiles_m = cdiv(a.P, 64);
-  if (Co % 128 == 0) {
-    DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_fwd_fused_kernel<T, 128>), dim3(tiles_m * (Co / 128)), dim3(256), 0, stream, a));
+  const int bn = Co % 128 == 0 ? 128 : 64;
+  a.tsplit = dcn_tap_split((long long)tiles_m * (Co / bn), g.kh * g.kw);
+  if (a.tsplit > 1) {
+    MR_CHECK_ARG(ws != nullptr, "dcn forward: workspace missing (mr_dcn2_ws_bytes)");
+    a.y32 = (float*)ws;
+    if (hipMemsetAsync(ws, 0, (size_t)a.P * Co * 4, stream) != hipSuccess) {
+      mr::set_error("dcn forward: hipMemsetAsync failed");
+      return MR_ERR_LAUNCH;
+    }
+  }
+  if (bn == 128) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_fwd_fused_kernel<T, 128>), dim3(tiles_m * (Co / 128), a.tsplit), dim3(256), 0,
+                                         stream, a));
   } else {
-    DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_fwd_fused_kernel<T, 64>), dim3(tiles_m * (Co / 64)), dim3(256), 0, stream, a));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_fwd_fused_kernel<T, 64>), dim3(tiles_m * (Co / 64), a.tsplit), dim3(256), 0,
+                                         stream, a));
   }
   MR_CHECK_LAUNCH();
+  if (a.tsplit > 1) {
+    const long long total4 = (long long)a.P * Co / 4;
+    long long blocks = (total4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dcn_finish_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                                         (const float*)ws, bias, (T*)y, total4, Co));
+    MR_CHECK_LAUNCH();
+  }
   return MR_OK;
+}
+
+// forward workspace of the fused path: the f32 accumulator of the tap-split launch (small layers), else nothing
+long long dcn_fused_fwd_ws_bytes(int N, int Ho, int Wo, int Co, int taps) {
+  const long long P = (long long)N * Ho * Wo;
+  const int bn = Co % 128 == 0 ? 128 : 64;
+  return dcn_tap_split(((P + 63) / 64) * (Co / bn), taps) > 1 ? P * Co * 4 : 0;
 }
 
 long long dcn_fused_ws_bytes(int N, int H, int W, int Ho, int Wo, int taps) {
@@ -925,7 +1060,7 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
                "dcn backward: tensor too large for 32-bit indices");
   DcnFusedArgs a = {};
   a.x = x; a.w = w_t; a.dy = dy; a.offset = offset; a.mask = mask; a.doffset = doffset; a.dmask = dmask; a.dx = dx32;
-  a.g = g; a.Co = Co; a.P = (int)P; a.Q = (int)Q;
+  a.g = g; a.Co = Co; a.P = (int)P; a.Q = (int)Q; a.tsplit = 1;
   const int tiles_p = cdiv((int)P, 64);
   // ---- offset / mask gradients (gcol tiles stay in registers)
   if (g.C % 128 == 0) {
@@ -957,11 +1092,15 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
     a.start = w.start;
     a.entries = w.entries;
     const int tiles_q = cdiv((int)Q, 64);
+    a.tsplit = dcn_tap_split((long long)tiles_q * (g.C / (g.C % 128 == 0 ? 128 : 64)), taps);
     if (g.C % 128 == 0) {
-      DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_dx_fused_kernel<T, 128>), dim3(tiles_q * (g.C / 128)), dim3(256), 0, stream, a));
+      DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_dx_fused_kernel<T, 128>), dim3(tiles_q * (g.C / 128), a.tsplit), dim3(256), 0,
+                                           stream, a));
     } else {
-      DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_dx_fused_kernel<T, 64>), dim3(tiles_q * (g.C / 64)), dim3(256), 0, stream, a));
+      DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_dx_fused_kernel<T, 64>), dim3(tiles_q * (g.C / 64), a.tsplit), dim3(256), 0,
+                                           stream, a));
     }
+    a.tsplit = 1;
     MR_CHECK_LAUNCH();
   }
   // ---- weight / bias gradients

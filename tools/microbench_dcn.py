@@ -63,7 +63,9 @@ def main():
         off = torch.randn(N, 2 * k * k, Ho, Wo, device="cuda", generator=g) * a.offscale
         msk = torch.rand(N, k * k, Ho, Wo, device="cuda", generator=g)
         y = torch.empty(N, Ho, Wo, Co, device="cuda", dtype=dtype)
-        col = dcn_workspace(dtype, N, H, W, C, Co, k, k, Ho, Wo, True, "cuda")      # >= the forward's need on both paths
+        lib = load()
+        nbytes = max(lib.mr_dcn2_ws_bytes(dt, N, H, W, C, Co, k, k, Ho, Wo, 0), lib.mr_dcn2_ws_bytes(dt, N, H, W, C, Co, k, k, Ho, Wo, 1), 16)
+        col = torch.empty(nbytes, dtype=torch.uint8, device="cuda")      # one workspace for both directions
         gy = torch.randn(N, Ho, Wo, Co, device="cuda", generator=g).to(dtype)
         dx32 = torch.zeros(N, H, W, C, device="cuda")
         doff, dmsk = torch.zeros_like(off), torch.zeros_like(msk)
