@@ -21,6 +21,7 @@ from torch.nn.modules.utils import _pair
 
 from .... import get_compute_dtype
 from ...._lib import call, dcn_workspace, dtype_code, ptr, vec_of
+from ....nn import prep
 from ....nn.functional import to_internal, _grad_internal
 
 
@@ -49,11 +50,23 @@ class ModulatedDeformConvFunction(Function):
         off_bs, msk_bs = off[0].numel(), msk[0].numel()
         K = kh * kw * C
         wk = weight.detach().permute(0, 2, 3, 1)
-        if not wk.is_contiguous():
+        if wk.is_contiguous():
+            # physical KRSC parameter (the modules keep their weight channels_last): the [Co][K] / [K][Co] operand images
+            # live in the prepared-weight cache (nn/prep.py) -- rebuilt only when the parameter changes, and refreshed
+            # together with every other layer's images by the fused optimizers' ONE batched launch per step
+            def build(old):
+                if old is None:
+                    w_n_ = torch.empty((Co, K), dtype=dtype, device=xi.device)
+                    w_t_ = torch.empty((K, Co), dtype=dtype, device=xi.device)
+                else:
+                    w_n_, w_t_ = old
+                return (w_n_, w_t_), [prep.matrix_job(ptr(wk), K, ptr(w_n_), K, ptr(w_t_), Co, Co, K, 0)]
+            w_n, w_t = prep.prepared((weight,), ("dcn", K, Co), build, dtype)
+        else:
             wk = wk.contiguous()   # physical KRSC f32
-        w_n = torch.empty((Co, K), dtype=dtype, device=xi.device)
-        w_t = torch.empty((K, Co), dtype=dtype, device=xi.device)
-        call("mr_prep_matrix", dt, ptr(wk), K, ptr(w_n), K, ptr(w_t), Co, Co, K, 0)
+            w_n = torch.empty((Co, K), dtype=dtype, device=xi.device)
+            w_t = torch.empty((K, Co), dtype=dtype, device=xi.device)
+            call("mr_prep_matrix", dt, ptr(wk), K, ptr(w_n), K, ptr(w_t), Co, Co, K, 0)
         col = dcn_workspace(dtype, N, H, W, C, Co, kh, kw, Ho, Wo, False, xi.device)   # the reference's `columns` scratch
         y = torch.empty((N, Ho, Wo, Co), dtype=dtype, device=xi.device)
         call("mr_dcn2_fwd", dt, ptr(xi), ptr(w_n), ptr(bias), ptr(off), off_bs, ptr(msk), msk_bs, ptr(y), ptr(col), N, H,
@@ -78,14 +91,21 @@ class ModulatedDeformConvFunction(Function):
         P = N * Ho * Wo
         g = _grad_internal(grad_output, dtype)
         col = dcn_workspace(dtype, N, H, W, C, Co, kh, kw, Ho, Wo, True, dev)   # CSR of the scatter / column matrix
-        grad_offset = torch.zeros_like(off)
-        grad_mask = torch.zeros_like(msk)
         want_dx = ctx.needs_input_grad[0]
         want_dw = ctx.needs_input_grad[3]
         want_db = ctx.with_bias and ctx.needs_input_grad[4]
-        dx32 = torch.zeros((N, H, W, C), dtype=torch.float32, device=dev) if want_dx else None
-        gw = torch.zeros((Co, kh, kw, C), dtype=torch.float32, device=dev) if want_dw else None
-        gb = torch.zeros((Co,), dtype=torch.float32, device=dev) if want_db else None
+        # every accumulated output of mr_dcn2_bwd must arrive zeroed: ONE zero-fill for all of them (four separate
+        # torch.zeros were 52 fill launches per DB step)
+        sizes = [off.numel(), msk.numel(), N * H * W * C if want_dx else 0, Co * K if want_dw else 0, Co if want_db else 0]
+        offs = [0]
+        for n_ in sizes:
+            offs.append(offs[-1] + (n_ + 63) // 64 * 64)
+        zbuf = torch.zeros((offs[-1],), dtype=torch.float32, device=dev)
+        grad_offset = zbuf[offs[0]:offs[0] + sizes[0]].view(off.shape)
+        grad_mask = zbuf[offs[1]:offs[1] + sizes[1]].view(msk.shape)
+        dx32 = zbuf[offs[2]:offs[2] + sizes[2]].view(N, H, W, C) if want_dx else None
+        gw = zbuf[offs[3]:offs[3] + sizes[3]].view(Co, kh, kw, C) if want_dw else None
+        gb = zbuf[offs[4]:offs[4] + sizes[4]] if want_db else None
         call("mr_dcn2_bwd", dt, ptr(g), ptr(xi), ptr(w_t), ptr(off), off_bs, ptr(msk), msk_bs, ptr(col), ptr(dx32),
              ptr(grad_offset), ptr(grad_mask), ptr(gw), ptr(gb), N, H, W, C, Co, kh, kw, stride, padding, dilation, Ho,
              Wo)
