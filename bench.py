@@ -441,6 +441,10 @@ def main():
                 "roofline": roofline,
                 "kernels": kernels,
             }
+            shim = net if hasattr(net, "last_backward") else None
+            if shim is not None and shim.last_backward:
+                # all-reduces the last recorded backward issued (= all-reduce nodes of the captured graph in capture mode)
+                out["config"]["ddp"] = dict(shim.last_backward)
             step_tflops = 3 * fwd_flops * bsz / (ms * 1e-3) / 1e12
             out["step_tflops_per_gpu"] = round(step_tflops, 2)
             out["host_enqueue_ms_per_step"] = round(1e3 * host_enqueue / steps, 3)

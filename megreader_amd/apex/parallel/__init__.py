@@ -27,6 +27,29 @@ def _engine_callback(fn):
     torch.autograd.Variable._execution_engine.queue_callback(fn)
 
 
+def plan_buckets(sizes, target):
+    """Bucket plan over REVERSED registration order (~ the order backward produces gradients): lists of indices into
+    `sizes`.  A bucket closes when it reaches `target` elements, or BEFORE a parameter that would push it more than 25 %
+    over (one 2.4 M-element conv weight must not drag 1.5 M elements of LSTM gradients with it); a tail bucket under 10 %
+    of the target is merged into its predecessor (not worth a collective of its own)."""
+    buckets, cur, cur_n = [], [], 0
+    for i in reversed(range(len(sizes))):
+        if cur and cur_n + sizes[i] > 1.25 * target:
+            buckets.append(cur)
+            cur, cur_n = [], 0
+        cur.append(i)
+        cur_n += sizes[i]
+        if cur_n >= target:
+            buckets.append(cur)
+            cur, cur_n = [], 0
+    if cur:
+        if buckets and cur_n < 0.1 * target:
+            buckets[-1].extend(cur)
+        else:
+            buckets.append(cur)
+    return buckets
+
+
 class DistributedDataParallel(nn.Module):
     def __init__(self, module, message_size=8 * 1024 * 1024, delay_allreduce=False, gradient_average=True,
                  process_group=None, min_buckets=MIN_BUCKETS, **_ignored):
@@ -47,21 +70,15 @@ class DistributedDataParallel(nn.Module):
         with torch.no_grad():
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0, group=process_group)
-        # buckets over reversed registration order
-        self._buckets, cur, cur_n = [], [], 0
-        for p in reversed(self._params):
-            cur.append(p)
-            cur_n += p.numel()
-            if cur_n >= self.bucket_elems:
-                self._buckets.append(cur)
-                cur, cur_n = [], 0
-        if cur:
-            self._buckets.append(cur)
+        self._buckets = [[self._params[i] for i in idx] for idx in
+                         plan_buckets([p.numel() for p in self._params], self.bucket_elems)]
         self._bucket_of = {}
         for bi, bucket in enumerate(self._buckets):
             for p in bucket:
                 self._bucket_of[p] = bi
         self._launched = [False] * len(self._buckets)
+        self._n_launched = self._n_staged = 0
+        self.last_backward = None
         # parameters known to receive more than one gradient contribution per backward (weight sharing), filled by
         # `mark_shared(param)`: a parameter is complete after `uses` hook firings, a bucket when ALL its parameters are
         self._uses = {}
@@ -157,6 +174,8 @@ class DistributedDataParallel(nn.Module):
         else:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((bucket, flat, staged, work))
+        self._n_launched += 1
+        self._n_staged += int(staged)
 
     def _finalize(self):
         for bi in range(len(self._buckets)):
@@ -170,6 +189,9 @@ class DistributedDataParallel(nn.Module):
         self._fires = {}
         self._launched = [False] * len(self._buckets)
         self._callback_queued = False
+        # what the last backward did: all-reduces issued, and how many of them went through a staging copy
+        self.last_backward = {"all_reduces": self._n_launched, "staged": self._n_staged, "buckets": len(self._buckets)}
+        self._n_launched = self._n_staged = 0
 
     @staticmethod
     def _finish_bucket(bucket, flat, staged, scale):

@@ -50,6 +50,9 @@ def _worker(rank, world, port, delay, q):
     for _ in range(2):                      # two iterations: bucket state must reset
         net.zero_grad()
         ddp(xs, ims).mean().backward()
+    # what the last backward issued: one all-reduce per bucket (several buckets -> several collectives per step)
+    lb = ddp.last_backward
+    assert lb["buckets"] >= 3 and lb["all_reduces"] == lb["buckets"], lb
     # plain numpy payloads: no shared-memory tensor handles that die with the worker
     grads = {k: p.grad.contiguous().numpy().copy() if p.grad is not None else None
              for k, p in net.named_parameters()}
@@ -227,9 +230,9 @@ def _shared_worker(rank, world, port, q):
         launches.append((bi, {id(p): self._fires.get(id(p), 0) for p in self._buckets[bi]}))
         return orig(self, bi)
     shim.DistributedDataParallel._launch = spy
-    # buckets over reversed registration order with 40-element pieces: [head (18), shared (36)] and [tail (36)] would
-    # separate them -- use one bucket for shared + tail: message_size 60 -> [head, shared] = 54 < 60 -> + tail
-    ddp = shim.DistributedDataParallel(net, message_size=60, min_buckets=1)
+    # buckets over reversed registration order: head (18), shared (36), tail (36).  One bucket for all three (target 90):
+    # a smaller target would close [head, shared] before tail and the guard under test would never be exercised
+    ddp = shim.DistributedDataParallel(net, message_size=90, min_buckets=1)
     assert len(ddp._buckets) == 1 and len(ddp._buckets[0]) == 3
     ddp.mark_shared(net.shared.weight, uses=2)
     # the manual hook protocol of the gradient sinks: a shared module fires once per use (nn/functional.py notify_grad_ready)
@@ -292,22 +295,22 @@ def test_shared_parameter_not_last_to_arrive():
 
 
 def test_default_bucket_plan_has_at_least_four_buckets():
-    """CRNN-sized plan without a process group: the default message_size (8 M elements) used to swallow the CRNN's 8.33 M
-    parameters in ONE bucket; the plan is min(message_size, total / 4)."""
-    from megreader_amd.apex.parallel import MIN_BUCKETS
-    sizes = [64 * 27, 128 * 576, 256 * 1152, 256 * 2304, 512 * 2304, 512 * 4608, 512 * 2048,   # CRNN convs
-             2048 * 512, 2048 * 256, 256 * 512, 2048 * 256, 2048 * 256, 38 * 512]              # LSTMs + linears
+    """CRNN-sized plan (the shim's own planner, no process group needed): the default message_size (8 M elements) used to
+    swallow the CRNN's 8.33 M parameters in ONE bucket; the target is min(message_size, total / 4)
+    and the plan is four balanced buckets in backward order."""
+    from megreader_amd.apex.parallel import MIN_BUCKETS, plan_buckets
+    sizes = [64 * 9, 64, 128 * 576, 128, 256 * 1152, 256, 256 * 2304, 256, 512 * 2304, 512, 512 * 4608, 512,    # CRNN convs
+             512 * 2048, 512, 2048 * 256, 2048 * 256, 2048 * 256, 2048 * 256, 512 * 256, 256,                   # + BiLSTM 1
+             1024 * 256, 1024 * 256, 1024 * 256, 1024 * 256, 38 * 512, 38]                                      # + BiLSTM 2
     total = sum(sizes)
-    bucket = max(1, min(8 * 1024 * 1024, -(-total // MIN_BUCKETS)))
-    buckets, cur = [], 0
-    for n in reversed(sizes):
-        cur += n
-        if cur >= bucket:
-            buckets.append(cur)
-            cur = 0
-    if cur:
-        buckets.append(cur)
-    assert MIN_BUCKETS >= 4 and len(buckets) >= 3 and max(buckets) < 0.6 * total
+    target = max(1, min(8 * 1024 * 1024, -(-total // MIN_BUCKETS)))
+    plan = plan_buckets(sizes, target)
+    assert sorted(i for b in plan for i in b) == list(range(len(sizes)))          # a partition
+    assert [i for b in plan for i in b] == list(reversed(range(len(sizes))))      # in backward order
+    elems = [sum(sizes[i] for i in b) for b in plan]
+    assert MIN_BUCKETS >= 4 and len(plan) >= 4, elems
+    assert max(elems) <= max(1.25 * target, max(sizes)), elems
+    assert min(elems) >= 0.1 * target, elems
 
 
 # ---------------------------------------------------------------------------------------------------------------

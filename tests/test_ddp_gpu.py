@@ -102,6 +102,38 @@ def test_ddp_shim_single_rank_rccl_matches_plain_run():
             assert torch.equal(state[k], ref_state[k]), k
 
 
+def test_default_plan_on_crnn_issues_at_least_four_in_place_all_reduces():
+    """with the DEFAULT message_size the CRNN's 8.33 M parameters used to land in one bucket.  The
+    default plan now gives >= 4 buckets in backward order, each all-reduced in place over its span of FusedAdam's flat
+    gradient buffer (no staging copy) as soon as its last gradient lands."""
+    from megreader_amd.apex.parallel import DistributedDataParallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        model = BasicModel().to(DEV).train()
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        opt.zero_grad()
+        net = DistributedDataParallel(model)
+        net.fold_average_into(opt)
+        batch = synthetic_batch(8, 32, 128, seed=0)
+        img, lab, ln = batch['image'].to(DEV), batch['label'].to(DEV), batch['length'].to(DEV).long()
+        for _ in range(2):
+            opt.zero_grad()
+            loss, _ = net(img, targets=lab, lengths=ln, train=True)
+            loss.mean().backward()
+            opt.step()
+        torch.cuda.synchronize()
+        lb = net.last_backward
+        total = sum(p.numel() for p in model.parameters())
+        sizes = [sum(p.numel() for p in b) for b in net._buckets]
+    finally:
+        dist.destroy_process_group()
+    assert lb["buckets"] >= 4 and lb["all_reduces"] == lb["buckets"] and lb["staged"] == 0, lb
+    assert max(sizes) <= 0.5 * total, sizes      # no bucket holds most of the model (the LSTM matrices are 2 M each)
+
+
 def test_graphed_train_step_with_grad_sync_single_rank_rccl():
     """The N > 1 bench path (megreader_amd.runtime): rank-0 parameter broadcast, [zero_grad, forward, backward] and
     [Adam + weight-image refresh] as two hipGraphs with ONE eager in-place RCCL all-reduce of the flat gradient buffer
