@@ -334,6 +334,16 @@ int mr_dcn2_bwd(int dtype, const void* dy, const void* x, const void* w_t, const
                 const float* mask, long long msk_bs, void* col_ws, float* dx32, float* doffset, float* dmask, float* dw,
                 float* dbias, int N, int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int Ho,
                 int Wo, hipStream_t stream);
+/* Packed offset/mask operand of the deformable ResNet blocks (reference backbones/resnet.py:125-142: offset_mask =
+ * conv2_offset(x); conv2(x, offset_mask[:, :18], offset_mask[:, -9:].sigmoid())).  raw = the offset conv's output, NHWC
+ * [N][HW][ld] in `dtype` (channels n_offset + n_mask <= ld).  mr_dcn_unpack writes the flat f32 NCHW offset [N][n_offset][HW]
+ * and mask = sigmoid(logits) [N][n_mask][HW] that mr_dcn2_fwd / _bwd read; mr_dcn_pack_grad folds their gradients back into
+ * d raw (dmask * m * (1 - m) for the mask logits, zeros in the padding channels).  One launch each: they replace the slice,
+ * cast, contiguous, sigmoid, sigmoid_backward, slice_backward and add launches of the unfused autograd graph. */
+int mr_dcn_unpack(int dtype, const void* raw, int ld, float* offset, float* mask, int N, int HW, int n_offset, int n_mask,
+                  hipStream_t stream);
+int mr_dcn_pack_grad(int dtype, const float* doffset, const float* dmask, const float* mask, void* graw, int ld, int N,
+                     int HW, int n_offset, int n_mask, hipStream_t stream);
 
 /* ---- Deformable PS-RoI pooling (assets/ops/dcn/src/deform_pool_cuda.cpp:30-77 deform_psroi_pooling_cuda_forward /
  * _backward; kernels deform_pool_cuda_kernel.cu:52-143, 146-268).  data [B][C][H][W] f32, rois [R][5] (batch index, x1,

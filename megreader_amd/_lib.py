@@ -70,6 +70,8 @@ SIGNATURES = {
     "mr_dcn2_col2im": "ipplplp" + "i" * 11 + "s",
     "mr_dcn2_fwd": "ippp" + "plpl" + "pp" + "i" * 12 + "s",
     "mr_dcn2_bwd": "ippp" + "plpl" + "pppppp" + "i" * 12 + "s",
+    "mr_dcn_unpack": "ipippiiiis",
+    "mr_dcn_pack_grad": "ippppiiiiis",
     "mr_db_components": "pfpppiiii" + "s",
     "mr_db_box_scores": "pppiiii" + "s",
     "mr_deform_psroi_fwd": "ppppp" + "iiiiiii" + "f" + "iiiii" + "f" + "s",

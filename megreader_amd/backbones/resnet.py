@@ -77,8 +77,9 @@ class BasicBlock(nn.Module):
         if not self.with_dcn:
             out = self.conv2(out)
         elif self.with_modulated_dcn:
-            offset_mask = self.conv2_offset(out)
-            out = self.conv2(out, offset_mask[:, :18, :, :], offset_mask[:, -9:, :, :].sigmoid())
+            # reference: conv2(out, offset_mask[:, :18], offset_mask[:, -9:].sigmoid()) -- the same expression as one fused
+            # autograd node (assets/ops/dcn/deform_conv.py ModulatedDeformConvPackedFunction)
+            out = self.conv2.forward_packed(out, self.conv2_offset(out))
         else:
             out = self.conv2(out, self.conv2_offset(out))
         if self.downsample is not None:
@@ -117,8 +118,9 @@ class Bottleneck(nn.Module):
         if not self.with_dcn:
             out = self.conv2(out)
         elif self.with_modulated_dcn:
-            offset_mask = self.conv2_offset(out)
-            out = self.conv2(out, offset_mask[:, :18, :, :], offset_mask[:, -9:, :, :].sigmoid())
+            # reference: conv2(out, offset_mask[:, :18], offset_mask[:, -9:].sigmoid()) -- the same expression as one fused
+            # autograd node (assets/ops/dcn/deform_conv.py ModulatedDeformConvPackedFunction)
+            out = self.conv2.forward_packed(out, self.conv2_offset(out))
         else:
             out = self.conv2(out, self.conv2_offset(out))
         out = self.bn2(out)

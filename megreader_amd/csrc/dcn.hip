@@ -335,6 +335,50 @@ static int make_geom(DcnGeom& g, int N, int H, int W, int C, int kh, int kw, int
   return MR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Packed offset/mask operand (how the reference's deformable ResNet feeds the op, backbones/resnet.py:125-142:
+// offset_mask = conv2_offset(x); offset = offset_mask[:, :18]; mask = offset_mask[:, -9:].sigmoid()).  The offset conv's
+// output lives here as NHWC [N][HW][ld] in the compute dtype (27 channels padded to ld); the sampling kernels read flat f32
+// NCHW offsets / masks.  One launch each way replaces the slice / cast / contiguous / sigmoid (forward: 5 launches per
+// layer) and sigmoid_backward / slice_backward / add / re-pad (backward: ~10 launches per layer) of the unfused graph.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void dcn_unpack_kernel(const T* __restrict__ raw, int ld, float* __restrict__ off, float* __restrict__ msk,
+                                  int N, int HW, int noff, int nmsk) {
+  const long long total = (long long)N * HW;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(t / HW), p = (int)(t % HW);
+    const T* r = raw + t * ld;
+    float* o = off + (long long)n * noff * HW + p;
+    for (int c = 0; c < noff; ++c) o[(long long)c * HW] = to_f32(r[c]);
+    float* m = msk + (long long)n * nmsk * HW + p;
+    for (int c = 0; c < nmsk; ++c) m[(long long)c * HW] = 1.f / (1.f + expf(-to_f32(r[noff + c])));
+  }
+}
+
+// graw[n][p][c] = doff[n][c][p] (c < noff) | dmsk[n][c-noff][p] * m * (1 - m) (c < noff + nmsk) | 0 (padding up to ld)
+template <typename T>
+__global__ void dcn_pack_grad_kernel(const float* __restrict__ doff, const float* __restrict__ dmsk,
+                                     const float* __restrict__ msk, T* __restrict__ graw, int ld, int N, int HW,
+                                     int noff, int nmsk) {
+  const long long total = (long long)N * HW;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(t / HW), p = (int)(t % HW);
+    T* r = graw + t * ld;
+    const float* o = doff + (long long)n * noff * HW + p;
+    for (int c = 0; c < noff; ++c) r[c] = from_f32<T>(o[(long long)c * HW]);
+    const float* gm = dmsk + (long long)n * nmsk * HW + p;
+    const float* m = msk + (long long)n * nmsk * HW + p;
+    for (int c = 0; c < nmsk; ++c) {
+      const float mv = m[(long long)c * HW];
+      r[noff + c] = from_f32<T>(gm[(long long)c * HW] * mv * (1.f - mv));
+    }
+    for (int c = noff + nmsk; c < ld; ++c) r[c] = from_f32<T>(0.f);
+  }
+}
+
 }  // namespace mr
 
 using namespace mr;
@@ -500,6 +544,30 @@ int mr_dcn2_bwd(int dtype, const void* dy, const void* x, const void* w_t, const
       rc = mr_colsum(dtype, dy, dbias, P, Co, Co, 0, stream);
   }
   return rc;
+}
+
+int mr_dcn_unpack(int dtype, const void* raw, int ld, float* offset, float* mask, int N, int HW, int n_offset, int n_mask,
+                  hipStream_t stream) {
+  MR_CHECK_ARG(raw && offset && mask && N > 0 && HW > 0 && n_offset > 0 && n_mask > 0 && ld >= n_offset + n_mask,
+               "mr_dcn_unpack: bad arguments");
+  const long long items = (long long)N * HW;
+  const int grid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((dcn_unpack_kernel<T>), dim3(grid), dim3(256), 0, stream, (const T*)raw, ld,
+                                       offset, mask, N, HW, n_offset, n_mask));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_dcn_pack_grad(int dtype, const float* doffset, const float* dmask, const float* mask, void* graw, int ld, int N,
+                     int HW, int n_offset, int n_mask, hipStream_t stream) {
+  MR_CHECK_ARG(doffset && dmask && mask && graw && N > 0 && HW > 0 && ld >= n_offset + n_mask,
+               "mr_dcn_pack_grad: bad arguments");
+  const long long items = (long long)N * HW;
+  const int grid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((dcn_pack_grad_kernel<T>), dim3(grid), dim3(256), 0, stream, doffset, dmask, mask,
+                                       (T*)graw, ld, N, HW, n_offset, n_mask));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
 }
 
 }  // extern "C"

@@ -201,6 +201,28 @@ def _grad_internal(g, dtype):
     return to_internal(g, dtype)
 
 
+def mark_zero_padded(t):
+    """Tag an NHWC gradient buffer whose channels beyond the logical count are zero (written that way by the producing
+    kernel).  A consumer that works on channel-padded operands -- Conv2dFn.backward with Kp != K -- recognises a logical
+    NCHW view `t[..., :K].permute(0, 3, 1, 2)` of a tagged buffer and uses the buffer itself instead of re-padding."""
+    t._mr_zero_padded = True
+    return t
+
+
+def _zero_padded_base(gy, shape, dtype):
+    """The tagged NHWC buffer behind the logical-NCHW gradient `gy`, if `gy` is exactly its [..., :K] view; else None."""
+    base = gy._base
+    if base is None or not getattr(base, "_mr_zero_padded", False):
+        return None
+    N, Ho, Wo, Kp = shape
+    if base.dtype != dtype or tuple(base.shape) != (N, Ho, Wo, Kp) or not base.is_contiguous():
+        return None
+    if gy.data_ptr() != base.data_ptr() or gy.shape[0] != N or tuple(gy.shape[2:]) != (Ho, Wo) or \
+            tuple(gy.stride()) != (Ho * Wo * Kp, 1, Wo * Kp, Kp):
+        return None
+    return base
+
+
 def _conv_out(size, k, s, p, d):
     return (size + 2 * p - d * (k - 1) - 1) // s + 1
 
@@ -301,8 +323,10 @@ class Conv2dFn(Function):
         if Kp == K:
             g = _grad_internal(gy, dtype)
         else:  # re-pad the gradient to the padded channel count (small head convolutions only)
-            g = torch.zeros((N, Ho, Wo, Kp), dtype=dtype, device=gy.device)
-            g[..., :K] = gy.permute(0, 2, 3, 1)
+            g = _zero_padded_base(gy, (N, Ho, Wo, Kp), dtype)      # already padded by its producer (DCN offset convs)
+            if g is None:
+                g = torch.zeros((N, Ho, Wo, Kp), dtype=dtype, device=gy.device)
+                g[..., :K] = gy.permute(0, 2, 3, 1)
         if ctx.relu:
             gm = torch.empty_like(g)
             call("mr_relu_bwd", dt, ptr(g), ptr(y), ptr(gm), g.numel())

@@ -372,3 +372,47 @@ def test_fused_path_equals_general_path(dtype, case):
         assert a.shape == r.shape, nm
         e = _rel(a, r)
         assert e < tol, (nm, e)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_packed_operand_equals_unfused_expression(dtype, stride):
+    """The deformable ResNet blocks call conv2(x, offset_mask[:, :18], offset_mask[:, -9:].sigmoid()) (reference
+    backbones/resnet.py:125-142).  `forward_packed` is that expression as one autograd node (mr_dcn_unpack /
+    mr_dcn_pack_grad + the zero-padded gradient hand-over to the offset conv's backward): outputs and every gradient --
+    input, offset-conv weight and bias, DCN weight -- must agree with the unfused graph.  stride 2 = the reference's quirk
+    Q10 (offset conv at stride 1 feeding a stride-2 DCN: a larger map indexed flat)."""
+    from megreader_amd.nn import Conv2d
+    mr.set_compute_dtype(dtype)
+    try:
+        torch.manual_seed(5)
+        N, C, H, W = 2, 64, 12, 20
+        conv_off = Conv2d(C, 27, kernel_size=3, padding=1).to(DEV)
+        with torch.no_grad():
+            conv_off.weight.mul_(3.0)          # offsets of a few pixels, mask logits away from 0
+        dcn = ModulatedDeformConv(C, 64, 3, stride=stride, padding=1, bias=False).to(DEV)
+        x0 = torch.randn(N, C, H, W, device=DEV)
+        gy = None
+        res = []
+        for packed in (False, True):
+            for p in list(conv_off.parameters()) + list(dcn.parameters()):
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            om = conv_off(x)
+            if packed:
+                y = dcn.forward_packed(x, om)
+            else:
+                y = dcn(x, om[:, :18, :, :], om[:, -9:, :, :].sigmoid())
+            if gy is None:
+                gy = torch.randn_like(y)
+            y.backward(gy)
+            res.append([y.detach().float(), x.grad.float(), conv_off.weight.grad.float().clone(),
+                        conv_off.bias.grad.float().clone(), dcn.weight.grad.float().clone()])
+        # f32: same kernels on the same f32 maps -> round-off of the sigmoid only; bf16: the unfused graph rounds the mask
+        # (and its gradient) to bf16 between the launches, the fused one does not
+        tol = 2e-5 if dtype == torch.float32 else 2e-2
+        for name, a, b in zip(("y", "dx", "d offset-conv weight", "d offset-conv bias", "d dcn weight"), res[0], res[1]):
+            err = float((a - b).abs().max()) / (float(a.abs().max()) + 1e-12)
+            assert err < tol, (name, err)
+    finally:
+        mr.set_compute_dtype(torch.bfloat16)

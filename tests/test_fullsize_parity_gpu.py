@@ -34,6 +34,7 @@ from megreader_amd.decoders import CRNNDecoder, CTCDecoder2D  # noqa: E402
 from oracle.crnn import CRNNOracle, synthetic_batch  # noqa: E402
 from oracle.decode import greedy_decode, greedy_decode_2d  # noqa: E402
 from oracle.res50ppm import Res50PPM2DCTCOracle, synthetic_batch_2d  # noqa: E402
+from _parity import REPORT  # noqa: E402
 
 DEV = "cuda"
 
@@ -160,8 +161,13 @@ def test_crnn_fp32_full_batch_elementwise():
     assert bool((margin[flipped] <= 2 * perr).all()), "arg-max differs at a position with a safe margin"
     if not bool(flipped.any()):
         assert np.array_equal(greedy_decode(ev.cpu().numpy()), greedy_decode(ev_o.numpy()))
-    print("CRNN greedy decode: %d of %d positions inside the error margin, decode %s" %
-          (int((margin <= 2 * perr).sum()), margin.numel(), "bit-exact" if not bool(flipped.any()) else "margin-limited"))
+    n_flip, n_unsafe = int(flipped.sum()), int((margin <= 2 * perr).sum())
+    print("CRNN greedy decode: %d of %d positions inside the error margin, %d arg-max flips, decode %s" %
+          (n_unsafe, margin.numel(), n_flip, "bit-exact" if n_flip == 0 else "margin-limited"))
+    REPORT["CRNN fp32 greedy decode"] = {"positions": margin.numel(), "inside_margin": n_unsafe, "flips": n_flip}
+    # the escape hatch is bounded: at most one position in 1000 may sit inside the error margin at all (an untrained net's
+    # near-ties), so a systematic arg-max difference cannot hide behind it
+    assert n_unsafe <= max(1, margin.numel() // 1000) and n_flip <= n_unsafe
 
 
 def test_crnn_bf16_full_batch_elementwise():
@@ -261,6 +267,10 @@ def test_res50ppm_2dctc_fp32_elementwise(height, width, n):
         # rows whose every column has safe margins must still decode identically
         ok_rows = ((row_margin > 2 * herr) & (cls_margin > 2 * herr)).all(dim=1).numpy()
         assert np.array_equal(dec[ok_rows], dec_o[ok_rows])
-    print("2-D greedy decode: %s (%d of %d samples with every margin safe)" %
-          ("bit-exact" if np.array_equal(dec, dec_o) else "margin-limited", int(safe) * n or
-           int(((row_margin > 2 * herr) & (cls_margin > 2 * herr)).all(dim=1).sum()), n))
+    n_safe = int(((row_margin > 2 * herr) & (cls_margin > 2 * herr)).all(dim=1).sum())
+    n_diff = int((dec != dec_o).any(axis=tuple(range(1, dec.ndim))).sum()) if dec.shape == dec_o.shape else n
+    print("2-D greedy decode: %s (%d of %d samples with every margin safe, %d samples decode differently)" %
+          ("bit-exact" if n_diff == 0 else "margin-limited", n_safe, n, n_diff))
+    REPORT["Res50-PPM fp32 2-D greedy decode"] = {"samples": n, "all_margins_safe": n_safe, "differ": n_diff}
+    # bounded escape hatch: only samples with an unsafe margin may differ, and those are at most 2 % of the batch
+    assert n_diff <= n - n_safe and n - n_safe <= max(1, n // 50)
