@@ -96,11 +96,19 @@ int mr_gemm_tn(int dtype, const void* A, long long lda, const void* B, long long
 int mr_conv2d_fwd(int dtype, const void* x, const void* w_krsc, const float* bias, void* y, int relu, int Nimg,
                   int H, int W, int Cin, int ldx, int Cout, int ldy, int R, int S, int sh, int sw, int ph, int pw,
                   int dh, int dw, int Ho, int Wo, hipStream_t stream);
+/* mr_conv2d_fwd (no ReLU, ldy == Cout) that also leaves the BatchNorm batch statistics of y in bn_sums (layout and zeroing as
+ * for mr_bn_stats) -- accumulated in the GEMM epilogue, so the BatchNorm that follows (reference nn.Sequential(conv, bn) at
+ * backbones/resnet.py:39-56,113-181, crnn.py:48-52) skips its reduction pass over y: mr_bn_fwd_train(flags bit 3). */
+int mr_conv2d_fwd_stats(int dtype, const void* x, const void* w_krsc, const float* bias, void* y, double* bn_sums, int Nimg,
+                        int H, int W, int Cin, int ldx, int Cout, int R, int S, int sh, int sw, int ph, int pw, int dh,
+                        int dw, int Ho, int Wo, hipStream_t stream);
 /* w_crsk = weights transposed to [Cin][R][S][Cout] (mr_prep_conv_weight) */
 int mr_conv2d_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, int Nimg, int H, int W, int Cin,
                     int lddx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
                     int Ho, int Wo, hipStream_t stream);
-/* dw_krsc (f32 [Cout][R][S][Cin]) and dbias (nullable, f32[Cout]) are accumulated atomically: zero them first */
+/* dw_krsc (f32 [Cout][R][S][Cin]) and dbias (nullable, f32[Cout]) are accumulated atomically: zero them first.  Cout may be
+ * smaller than lddy and need not be a multiple of the vector width when the channels Cout..lddy-1 of dy are zero padding
+ * (27-channel DCN offset convolutions stored with 32): exactly Cout rows of dw / entries of dbias are written. */
 int mr_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw_krsc, float* dbias, int Nimg, int H, int W,
                     int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh,
                     int dw, int Ho, int Wo, hipStream_t stream);
@@ -190,7 +198,11 @@ int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const
                     float* running_var, float* save_mean, float* save_rstd, double* sums, const void* residual,
                     int relu, long long P, int C, float eps, float momentum, long long* num_batches_tracked,
                     hipStream_t stream); /* num_batches_tracked (nullable): int64 step counter, incremented by one;
-                                          relu: bit0 fused ReLU, bit2 `sums` is already zero (skip the memset) */
+                                          relu: bit0 fused ReLU, bit2 `sums` is already zero (skip the memset), bit3 `sums`
+                                          already HOLDS the statistics (mr_conv2d_fwd_stats / mr_bn_stats): no reduction pass */
+/* the statistics pass on its own: sums (f64 [8][2][C] = the first 16*C doubles of the mr_bn_scratch_doubles(C) scratch, zeroed by
+ * the caller) += per-channel sum / sum of squares of x [P][C] */
+int mr_bn_stats(int dtype, const void* x, double* sums, long long P, int C, hipStream_t stream);
 int mr_bn_fwd_eval(int dtype, const void* x, void* y, const float* gamma, const float* beta,
                    const float* running_mean, const float* running_var, float* tmp_mean, float* tmp_rstd,
                    const void* residual, int relu, long long P, int C, float eps, hipStream_t stream);

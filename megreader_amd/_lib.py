@@ -25,6 +25,8 @@ SIGNATURES = {
     "mr_gemm_nt": "iplpiplpiiiis",
     "mr_gemm_tn": "iplplpiiiiips",
     "mr_conv2d_fwd": "ipppp" + "i" * 18 + "s",
+    "mr_conv2d_fwd_stats": "ippppp" + "i" * 16 + "s",
+    "mr_bn_stats": "ipplis",
     "mr_conv2d_dgrad": "ippp" + "i" * 17 + "s",
     "mr_conv2d_wgrad": "ipppp" + "i" * 17 + "s",
     "mr_conv2d_wgrad_tab": "ipppp" + "i" * 17 + "pis",

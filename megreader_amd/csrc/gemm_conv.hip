@@ -32,6 +32,11 @@ static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 static int g_nt_variant = 2;  // 2 = direct-to-LDS kernel (default), 1 = register-staged kernel (A/B debugging)
 
+// mr_conv2d_fwd_stats: the f64 column-statistics accumulators the NT launches of the current call attach to their epilogue
+// (EpiStore::stats), and whether every launch of the call could (the register-staged fallback kernel cannot)
+static thread_local double* g_epi_stats = nullptr;
+static thread_local bool g_epi_stats_missed = false;
+
 // The direct-to-LDS NT kernels address their operands through buffer resources with 2 GiB of records.
 template <typename T>
 static bool nt_fits_buffer(const NtArgs& a, const ConvGeom& g, int amode) {
@@ -60,6 +65,8 @@ static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long lon
       NtArgs a2 = a;
       a2.zero = zero_page();
       if (!a2.zero) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
+      epi.stats = g_epi_stats;
+      epi.stats_ncopy = MR_BN_COPIES;
       constexpr int BK = 8 * VecOf<T>::N;
       if (AMODE == 2 && (g.Cg % BK) != 0)
         hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, (AMODE == 2 ? 3 : AMODE), EpiStore<T>>), dim3(grid),
@@ -72,6 +79,7 @@ static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long lon
     }
   }
   if (a.m_begin != 0) { set_error("row-range launches need the direct-to-LDS NT kernel"); return MR_ERR_ARG; }
+  if (g_epi_stats) g_epi_stats_missed = true;   // this kernel has no statistics epilogue: the caller reduces y itself
   hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, AMODE, EpiStore<T>>), dim3(tiles), dim3(256), 0, stream, a, g,
                      epi);
   MR_CHECK_LAUNCH();
@@ -163,6 +171,8 @@ static int launch_nt_big(const NtArgs& a, const ConvGeom& g, void* C, long long 
   epi.M = a.M;
   epi.N = a.N;
   epi.vec_ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
+  epi.stats = g_epi_stats;
+  epi.stats_ncopy = MR_BN_COPIES;
   NtArgs a2 = a;
   a2.zero = zero_page();
   if (!a2.zero) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
@@ -204,6 +214,8 @@ static int launch_nt_p8(const NtArgs& a, const ConvGeom& g, void* C, long long l
     epi.M = a.M;
     epi.N = a.N;
     epi.vec_ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
+    epi.stats = g_epi_stats;
+    epi.stats_ncopy = MR_BN_COPIES;
     NtArgs a2 = a;
     a2.zero = zero_page();
     if (!a2.zero) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
@@ -696,6 +708,26 @@ int mr_conv2d_fwd(int dtype, const void* x, const void* w_krsc, const float* bia
   return dispatch_nt_store<bf16_t, 1>(a, g, y, ldy, bias, relu, stream);
 }
 
+// mr_conv2d_fwd + the BatchNorm batch statistics of its output: bn_sums (f64 [MR_BN_COPIES][2][Cout], zeroed by the caller;
+// mr_bn_scratch_doubles(Cout) doubles as handed to mr_bn_fwd_train) receives sum_p y[p][c] and sum_p y[p][c]^2 over the
+// values as stored.  The direct-to-LDS NT kernels accumulate them in their epilogue (no separate pass over y); if a launch
+// had to use the register-staged kernel, one reduction pass over y runs here instead -- the contract is the same either way.
+int mr_conv2d_fwd_stats(int dtype, const void* x, const void* w_krsc, const float* bias, void* y, double* bn_sums,
+                        int Nimg, int H, int W, int Cin, int ldx, int Cout, int R, int S, int sh, int sw, int ph, int pw,
+                        int dh, int dw, int Ho, int Wo, hipStream_t stream) {
+  MR_CHECK_ARG(bn_sums != nullptr, "mr_conv2d_fwd_stats: bn_sums is null");
+  g_epi_stats = bn_sums;
+  g_epi_stats_missed = false;
+  const int rc = mr_conv2d_fwd(dtype, x, w_krsc, bias, y, 0, Nimg, H, W, Cin, ldx, Cout, Cout, R, S, sh, sw, ph, pw, dh, dw,
+                               Ho, Wo, stream);
+  const bool missed = g_epi_stats_missed;
+  g_epi_stats = nullptr;
+  g_epi_stats_missed = false;
+  if (rc != MR_OK) return rc;
+  if (missed) return mr_bn_stats(dtype, y, bn_sums, (long long)Nimg * Ho * Wo, Cout, stream);
+  return MR_OK;
+}
+
 // dx[n,h,w,c] = sum_{r,s,k} dy[n,(h+ph-r*dh)/sh,(w+pw-s*dw)/sw,k] * w[k,r,s,c]; w_crsk = w transposed to [c][r][s][k]
 int mr_conv2d_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, int Nimg, int H, int W, int Cin,
                     int lddx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
@@ -722,8 +754,10 @@ int mr_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw_krsc, fl
                     int dw, int Ho, int Wo, hipStream_t stream) {
   MR_CHECK_ARG(dtype == MR_F32 || dtype == MR_BF16, "mr_conv2d_wgrad: bad dtype %d", dtype);
   const int vec = dtype == MR_F32 ? 4 : 8;
-  MR_CHECK_ARG(Cin % vec == 0 && ldx % vec == 0 && Cout % vec == 0 && lddy % vec == 0,
-               "mr_conv2d_wgrad: Cin/ldx/Cout/lddy must be multiples of %d", vec);
+  // Cout need not be a multiple of the vector width as long as the rows of dy are (lddy): the operand loads then read the
+  // zero padding channels of the last vector, and only Cout rows of dw / entries of dbias are written
+  MR_CHECK_ARG(Cin % vec == 0 && ldx % vec == 0 && lddy % vec == 0 && Cout > 0 && Cout <= lddy,
+               "mr_conv2d_wgrad: Cin/ldx/lddy must be multiples of %d and Cout <= lddy", vec);
   MR_CHECK_ARG(aligned16(dy) && aligned16(x), "mr_conv2d_wgrad: dy and x must be 16-byte aligned");
   TnArgs a;
   a.A = dy; a.B = x; a.C = dw_krsc; a.P = Nimg * Ho * Wo; a.NA = Cout; a.NB = R * S * Cin; a.lda = lddy;
@@ -744,8 +778,8 @@ int mr_conv2d_wgrad_tab(int dtype, const void* dy, const void* x, float* dw_krsc
   if (rowtab == nullptr || dtype != MR_BF16 || R * S > 32 || g_nt_variant != 2)
     return mr_conv2d_wgrad(dtype, dy, x, dw_krsc, dbias, Nimg, H, W, Cin, ldx, Cout, lddy, R, S, sh, sw, ph, pw, dh,
                            dw, Ho, Wo, stream);
-  MR_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && Cout % 8 == 0 && lddy % 8 == 0,
-               "mr_conv2d_wgrad_tab: Cin/ldx/Cout/lddy must be multiples of 8");
+  MR_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && Cout > 0 && Cout <= lddy,
+               "mr_conv2d_wgrad_tab: Cin/ldx/lddy must be multiples of 8 and Cout <= lddy");
   MR_CHECK_ARG(aligned16(dy) && aligned16(x) && ((uintptr_t)rowtab & 7) == 0, "mr_conv2d_wgrad_tab: alignment");
   if (g_tn_taps && taps_eligible(Nimg, H, W, Cin, ldx, Cout, lddy, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo,
                                  (long long)Nimg * Ho * Wo * 8)) {

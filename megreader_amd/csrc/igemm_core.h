@@ -81,6 +81,72 @@ struct NtArgs {
 
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *(const uint4*)p; }
 
+// Column statistics of a wave's output tile, for epilogues that carry a `stats` pointer (EpiStore): the lane that owns
+// the run of 4*CNT channels n.. of rows m = base + 16 j + l15 accumulates sum / sum of squares over its TM rows, the 16
+// lanes of a row group (same lg) are combined with four butterfly steps, lane l15 == 0 adds the result to the f64
+// accumulators.  2 * 4*CNT f64 atomics per (wave, lg): 512 per 128x128 tile against 16384 elements.
+template <typename Epi> struct EpiHasStats { static constexpr bool value = false; };  // specialised for EpiStore below
+template <typename T, int CNT> struct EpiColStats {
+  float s[4 * CNT], q[4 * CNT];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int e = 0; e < 4 * CNT; ++e) s[e] = q[e] = 0.f;
+  }
+  template <typename Epi> __device__ __forceinline__ void add(const Epi& epi, int m, int n, const f32x4* v) {
+    if (m >= epi.M) return;
+#pragma unroll
+    for (int i = 0; i < CNT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = v[i][j];
+        if (epi.bias && n + 4 * i + j < epi.N) t += epi.bias[n + 4 * i + j];
+        t = to_f32(from_f32<T>(t));   // the value the store writes
+        s[4 * i + j] += t;
+        q[4 * i + j] += t * t;
+      }
+  }
+  template <typename Epi> __device__ __forceinline__ void flush(const Epi& epi, int n, int l15) {
+#pragma unroll
+    for (int e = 0; e < 4 * CNT; ++e) {
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        s[e] += __shfl_xor(s[e], d, 64);
+        q[e] += __shfl_xor(q[e], d, 64);
+      }
+    }
+    // every lane of the row group now holds all 2 * 4*CNT totals: lane l15 takes column l15's, so that the wave issues
+    // ONE atomic instruction over 64 (or 2 x 32) consecutive doubles instead of 8*CNT instructions with 4 live lanes
+    double* dst = epi.stats + (size_t)(blockIdx.x % epi.stats_ncopy) * 2 * epi.N;
+    if constexpr (CNT == 4) {
+      float sv = s[0], qv = q[0];
+#pragma unroll
+      for (int e = 1; e < 16; ++e) {
+        sv = l15 == e ? s[e] : sv;
+        qv = l15 == e ? q[e] : qv;
+      }
+      if (n + l15 < epi.N) {
+        atomicAdd(dst + n + l15, (double)sv);
+        atomicAdd(dst + epi.N + n + l15, (double)qv);
+      }
+    } else if constexpr (CNT == 2) {
+      const int c = l15 & 7;
+      float v = l15 < 8 ? s[0] : q[0];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) v = c == e ? (l15 < 8 ? s[e] : q[e]) : v;
+      if (n + c < epi.N) atomicAdd(dst + (l15 < 8 ? 0 : epi.N) + n + c, (double)v);
+    } else {
+      if (l15 != 0) return;
+#pragma unroll
+      for (int e = 0; e < 4 * CNT; ++e)
+        if (n + e < epi.N) {
+          atomicAdd(dst + n + e, (double)s[e]);
+          atomicAdd(dst + epi.N + n + e, (double)q[e]);
+        }
+    }
+  }
+};
+
+
 // ---------------------------------------------------------------------------------------------
 // NT kernel.  AMODE 0: dense A[M,K] (row stride lda).  AMODE 1/2: A is an NHWC tensor gathered
 // im2col-style according to ConvGeom (K = R*S*Cg, k = (r*S+s)*Cg + c).  AMODE 2 is the fast path
@@ -695,13 +761,21 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
   // row block outer, column block inner: the TN stores of one output row land back to back, so its 128-byte line is
   // completed in L2 before it can be evicted half-written (the 256x256 kernel wrote 2.5x its output bytes to HBM
   // with the loops the other way round)
+  EpiColStats<T, TN> cst;
+  bool with_stats = false;
+  if constexpr (EpiHasStats<Epi>::value) with_stats = epi.stats != nullptr;
+  if (with_stats) cst.init();
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     f32x4 run[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) run[i] = acc[i][j];
+    if constexpr (EpiHasStats<Epi>::value)
+      if (with_stats) cst.add(epi, m0 + wm_ * WTM + j * 16 + l15, n0 + wn_ * WTN + lg * (4 * TN), run);
     epi.template store_run<TN>(m0 + wm_ * WTM + j * 16 + l15, n0 + wn_ * WTN + lg * (4 * TN), run);
   }
+  if constexpr (EpiHasStats<Epi>::value)
+    if (with_stats) cst.flush(epi, n0 + wn_ * WTN + lg * (4 * TN), l15);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -889,13 +963,21 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_nt_big_kernel(NtArgs a, Co
   // row block outer, column block inner: the TN stores of one output row land back to back, so its 128-byte line is
   // completed in L2 before it can be evicted half-written (the 256x256 kernel wrote 2.5x its output bytes to HBM
   // with the loops the other way round)
+  EpiColStats<T, TN> cst;
+  bool with_stats = false;
+  if constexpr (EpiHasStats<Epi>::value) with_stats = epi.stats != nullptr;
+  if (with_stats) cst.init();
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     f32x4 run[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) run[i] = acc[i][j];
+    if constexpr (EpiHasStats<Epi>::value)
+      if (with_stats) cst.add(epi, m0 + wm_ * WTM + j * 16 + l15, n0 + wn_ * WTN + lg * (4 * TN), run);
     epi.template store_run<TN>(m0 + wm_ * WTM + j * 16 + l15, n0 + wn_ * WTN + lg * (4 * TN), run);
   }
+  if constexpr (EpiHasStats<Epi>::value)
+    if (with_stats) cst.flush(epi, n0 + wn_ * WTN + lg * (4 * TN), l15);
 }
 
 // Plain epilogue: C = act(acc + bias) stored as T, row-major with leading dim ldc.
@@ -906,6 +988,10 @@ template <typename T> struct EpiStore {
   int relu;
   int M, N;
   int vec_ok;  // ldc % 4 == 0 and C 16-byte aligned
+  // optional BatchNorm batch statistics of the stored matrix (direct-to-LDS kernels only): stats[copy][0][n] += sum_m C[m][n],
+  // stats[copy][1][n] += sum_m C[m][n]^2 over the values AS STORED (rounded to T); copy = workgroup % stats_ncopy
+  double* stats = nullptr;
+  int stats_ncopy = 1;
   __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
     if (m >= M || n >= N) return;
     if (bias) {
@@ -956,6 +1042,9 @@ template <typename T> struct EpiStore {
     }
   }
 };
+#ifndef MR_NO_EPI_STATS   // (A/B build of tools/: the NT kernels compiled without the statistics epilogue)
+template <typename T> struct EpiHasStats<EpiStore<T>> { static constexpr bool value = true; };
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // TN kernel: C[NA,NB] (f32, atomically accumulated) += sum_{p in split} A[p,NA] * Bg[p,NB]

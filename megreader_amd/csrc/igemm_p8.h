@@ -251,13 +251,21 @@ __global__ __launch_bounds__(512) void igemm_nt_p8_kernel(NtArgs a, ConvGeom g, 
   }
   if (c < nk) ktile(c, 0);
 
+  EpiColStats<bf16_t, 4> cst;
+  bool with_stats = false;
+  if constexpr (EpiHasStats<Epi>::value) with_stats = epi.stats != nullptr;
+  if (with_stats) cst.init();
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     f32x4 run[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) run[i] = acc[i][j];
+    if constexpr (EpiHasStats<Epi>::value)
+      if (with_stats) cst.add(epi, m0 + wm_ * 128 + j * 16 + l15, n0 + wn_ * 64 + lg * 16, run);
     epi.template store_run<4>(m0 + wm_ * 128 + j * 16 + l15, n0 + wn_ * 64 + lg * 16, run);
   }
+  if constexpr (EpiHasStats<Epi>::value)
+    if (with_stats) cst.flush(epi, n0 + wn_ * 64 + lg * 16, l15);
 }
 
 }  // namespace mr

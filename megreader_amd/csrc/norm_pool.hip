@@ -4,7 +4,6 @@
 #include "common.h"
 #include "../../include/megreader_hip.h"
 
-#define MR_BN_COPIES 8   /* accumulator copies of the forward statistics pass (see bn_reduce_vec_kernel) */
 
 namespace mr {
 
@@ -631,6 +630,27 @@ int mr_set_bn_fused(int on) {
   return old;
 }
 
+// sums (f64 [MR_BN_COPIES][2][C], zeroed by the caller) += per-channel sum / sum of squares of x [P][C]: the statistics
+// pass of mr_bn_fwd_train on its own (what mr_conv2d_fwd_stats falls back to); follow with mr_bn_fwd_train(flags bit 3).
+int mr_bn_stats(int dtype, const void* x, double* sums, long long P, int C, hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(C % vec == 0, "mr_bn_stats: C (%d) must be a multiple of %d", C, vec);
+  MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_stats: bad P");
+  int rpb;
+  if (C / vec <= 256 && 256 % (C / vec) == 0) {
+    const int splits = split_rows_vec((int)P, C / vec, rpb);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_vec_kernel<T, 0>), dim3(splits), dim3(256), 0, stream,
+                                         (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
+                                         (const float*)nullptr, sums, 0, (int)P, C, rpb, MR_BN_COPIES));
+  } else {
+    const int splits = split_rows((int)P, C, rpb);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(cdiv(C, 64), splits), dim3(256), 0, stream,
+                                         (const T*)x, sums, (int)P, C, (long long)C, rpb));
+  }
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
 int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* save_mean, float* save_rstd, double* sums, const void* residual,
                     int relu, long long P, int C, float eps, float momentum, long long* num_batches_tracked,
@@ -639,10 +659,13 @@ int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const
   MR_CHECK_ARG(C % vec == 0, "mr_bn_fwd_train: C (%d) must be a multiple of %d", C, vec);
   MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_fwd_train: bad P");
   const int presum_zero = (relu >> 2) & 1;  // flags bit 2: the caller hands over an already zeroed `sums`
+  const int have_stats = (relu >> 3) & 1;   // flags bit 3: `sums` already holds the statistics (mr_conv2d_fwd_stats / mr_bn_stats)
   relu &= 1;
-  if (!presum_zero) (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * MR_BN_COPIES, stream);
+  if (!presum_zero && !have_stats) (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * MR_BN_COPIES, stream);
   int rpb, ncopy = 1;
-  if (C / vec <= 256 && 256 % (C / vec) == 0) {
+  if (have_stats) {
+    ncopy = MR_BN_COPIES;
+  } else if (C / vec <= 256 && 256 % (C / vec) == 0) {
     const int splits = split_rows_vec((int)P, C / vec, rpb);
     ncopy = MR_BN_COPIES;
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_vec_kernel<T, 0>), dim3(splits), dim3(256), 0, stream,

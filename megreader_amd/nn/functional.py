@@ -230,10 +230,11 @@ def _conv_out(size, k, s, p, d):
 _ROWTABS = {}
 
 
-def _wgrad_rowtab(device, geom):
+def _wgrad_rowtab(device, geom, vector_k=True):
     """Cached row table of the wgrad gather for one conv geometry (see mr_conv2d_wgrad_tab).  Returns
-    (tensor, build_flag): build_flag is 1 only for the call that has to fill it."""
-    key = (device, geom)
+    (tensor, build_flag): build_flag is 1 only for the call that has to fill it.  vector_k: the output channel count is
+    a whole number of vectors (the all-taps kernel is then eligible, and its table has another format)."""
+    key = (device, geom, bool(vector_k))
     tab = _ROWTABS.get(key)
     if tab is not None:
         return tab, 0
@@ -284,7 +285,7 @@ def _conv_operands(weight, bias, dtype, Cp, Kp, need_dx):
 # --------------------------------------------------------------------------------------------------
 class Conv2dFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation, relu, relu_grad_downstream=False):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, relu, relu_grad_downstream=False, bn_sums=None):
         require_cuda(x, weight, bias)
         dtype = get_compute_dtype()
         dt = dtype_code(dtype)
@@ -304,8 +305,13 @@ class Conv2dFn(Function):
             raise RuntimeError("input gradient requested for a channel-padded convolution input")
         w_krsc, w_crsk, bias_k = _conv_operands(weight, bias, dtype, Cp, Kp, need_dx)
         y = torch.empty((N, Ho, Wo, Kp), dtype=dtype, device=x.device)
-        call("mr_conv2d_fwd", dt, ptr(xi), ptr(w_krsc), ptr(bias_k), ptr(y), int(relu), N, H, W, Cp, Cp, Kp, Kp, R, S,
-             sh, sw, ph, pw, dh, dw, Ho, Wo)
+        if bn_sums is not None and not relu and Kp == K:
+            # the BatchNorm that consumes y gets its batch statistics from this GEMM's epilogue (see conv2d(bn_stats=True))
+            call("mr_conv2d_fwd_stats", dt, ptr(xi), ptr(w_krsc), ptr(bias_k), ptr(y), ptr(bn_sums), N, H, W, Cp, Cp, Kp,
+                 R, S, sh, sw, ph, pw, dh, dw, Ho, Wo)
+        else:
+            call("mr_conv2d_fwd", dt, ptr(xi), ptr(w_krsc), ptr(bias_k), ptr(y), int(relu), N, H, W, Cp, Cp, Kp, Kp, R,
+                 S, sh, sw, ph, pw, dh, dw, Ho, Wo)
         ctx.save_for_backward(xi, w_crsk, y if (relu and not relu_grad_downstream) else None)
         ctx.params = (weight, bias)
         ctx.geom = (N, H, W, Cp, C, K, Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo)
@@ -340,8 +346,11 @@ class Conv2dFn(Function):
         weight_p, bias_p = ctx.params
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         # gradient sinks (see grad_sink): the wgrad / bias kernels accumulate directly into the flat gradient buffer
-        w_sink = grad_sink(weight_p, (K, R, S, C)) if (ctx.needs_input_grad[1] and Cp == C and Kp == K) else None
-        b_sink = grad_sink(bias_p, (K,)) if (want_db and Kp == K) else None
+        # (padded output channels, Kp != K: the wgrad kernel writes exactly K rows / bias entries -- the pad channels of g
+        # are zero -- so the sinks work for the 27-channel DCN offset convolutions too)
+        w_sink = grad_sink(weight_p, (K, R, S, C)) if (ctx.needs_input_grad[1] and Cp == C) else None
+        b_sink = grad_sink(bias_p, (K,)) if want_db else None
+        Kw = K if (w_sink is not None or b_sink is not None) else Kp   # rows of dw / entries of db the kernels write
         if want_db:
             db = b_sink if b_sink is not None else torch.zeros((Kp,), dtype=torch.float32, device=g.device)
         if ctx.needs_input_grad[1]:
@@ -351,8 +360,10 @@ class Conv2dFn(Function):
             # use, then passed to every later step (bf16, R*S <= 32; otherwise the call is plain mr_conv2d_wgrad)
             tab, build = (None, 0)
             if dtype == torch.bfloat16 and R * S <= 32:
-                tab, build = _wgrad_rowtab(g.device, (N, H, W, Cp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo))
-            call("mr_conv2d_wgrad_tab", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, Kp,
+                # (Kw % 8: the all-taps kernel needs whole channel vectors and its table has another format than the GEMM
+                # kernel's -- two layers of one geometry that differ in that must not share a table)
+                tab, build = _wgrad_rowtab(g.device, (N, H, W, Cp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo), Kw % 8 == 0)
+            call("mr_conv2d_wgrad_tab", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, Kw,
                  Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo, ptr(tab), build)
             if w_sink is not None:
                 dwt = None
@@ -362,22 +373,43 @@ class Conv2dFn(Function):
                     gw = gw[:K, :, :, :C]
                 dwt = gw.permute(0, 3, 1, 2)
         elif want_db:
-            call("mr_colsum", dt, ptr(g), ptr(db), N * Ho * Wo, Kp, Kp, 0)
+            call("mr_colsum", dt, ptr(g), ptr(db), N * Ho * Wo, Kw, Kp, 0)
         if want_db:
             if b_sink is not None:
                 db = None
                 notify_grad_ready(bias_p)
             elif Kp != K:
                 db = db[:K]
-        return dx, dwt, db, None, None, None, None, None
+        return dx, dwt, db, None, None, None, None, None, None
+
+
+class BnStatsHandoff(object):
+    """Batch statistics of a conv output that its GEMM epilogue already accumulated (mr_conv2d_fwd_stats): the f64 scratch
+    `sums` (a ZeroArena slice, layout of mr_bn_fwd_train) plus what identifies the tensor they describe."""
+    __slots__ = ("sums", "data_ptr", "dtype", "P", "C")
+
+    def __init__(self, sums, data_ptr, dtype, P, C):
+        self.sums, self.data_ptr, self.dtype, self.P, self.C = sums, data_ptr, dtype, P, C
 
 
 def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), relu=False,
-           relu_grad_downstream=False):
+           relu_grad_downstream=False, bn_stats=False):
     """relu_grad_downstream=True: the only consumer is a max_pool2d(..., relu_input=True), whose backward applies
-    this layer's ReLU mask (saves one pass over the largest activation gradients)."""
-    return Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation), bool(relu),
-                          bool(relu_grad_downstream))
+    this layer's ReLU mask (saves one pass over the largest activation gradients).
+    bn_stats=True: a training-mode BatchNorm consumes the output: its per-channel sum / sum of squares are accumulated in
+    the epilogue of the convolution's GEMM and travel with the returned tensor (`_mr_bn_sums`); batch_norm() then skips its
+    statistics pass.  Ignored (plain convolution) with a fused ReLU, padded output channels or an exhausted ZeroArena."""
+    sums = None
+    if bn_stats and not relu and x.is_cuda:
+        K = weight.shape[0]
+        if K % vec_of(get_compute_dtype()) == 0:
+            sums = ZeroArena.take(x.device, load().mr_bn_scratch_doubles(K))
+    y = Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation), bool(relu),
+                       bool(relu_grad_downstream), sums)
+    if sums is not None:
+        y._mr_bn_sums = BnStatsHandoff(sums, y.data_ptr(), get_compute_dtype(), y.shape[0] * y.shape[2] * y.shape[3],
+                                       y.shape[1])
+    return y
 
 
 # --------------------------------------------------------------------------------------------------
@@ -386,7 +418,7 @@ def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
 class BatchNormFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, residual,
-                num_batches_tracked=None):
+                num_batches_tracked=None, pre=None):
         require_cuda(x, gamma, beta)
         dtype = get_compute_dtype()
         dt = dtype_code(dtype)
@@ -401,13 +433,19 @@ class BatchNormFn(Function):
         rstd = torch.empty((C,), dtype=torch.float32, device=x.device)
         if training:
             nsum = load().mr_bn_scratch_doubles(C)   # several accumulator copies (fewer same-address atomics)
-            sums = ZeroArena.take(x.device, nsum)
-            prezeroed = sums is not None
-            if not prezeroed:
-                sums = torch.empty((nsum,), dtype=torch.float64, device=x.device)
+            have = (pre is not None and pre.data_ptr == xi.data_ptr() and pre.dtype == dtype and pre.P == P and
+                    pre.C == C)                      # statistics already accumulated by the producing convolution
+            if have:
+                sums, prezeroed = pre.sums, True
+            else:
+                sums = ZeroArena.take(x.device, nsum)
+                prezeroed = sums is not None
+                if not prezeroed:
+                    sums = torch.empty((nsum,), dtype=torch.float64, device=x.device)
             call("mr_bn_fwd_train", dt, ptr(xi), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean),
-                 ptr(running_var), ptr(mean), ptr(rstd), ptr(sums), ptr(ri), int(relu) | (4 if prezeroed else 0), P, C,
-                 float(eps), float(momentum), ptr(num_batches_tracked))
+                 ptr(running_var), ptr(mean), ptr(rstd), ptr(sums), ptr(ri),
+                 int(relu) | (4 if prezeroed else 0) | (8 if have else 0), P, C, float(eps), float(momentum),
+                 ptr(num_batches_tracked))
         else:
             call("mr_bn_fwd_eval", dt, ptr(xi), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                  ptr(mean), ptr(rstd), ptr(ri), int(relu), P, C, float(eps))
@@ -451,7 +489,7 @@ class BatchNormFn(Function):
             notify_grad_ready(gamma_p)
             notify_grad_ready(beta_p)
             dgamma = dbeta = None
-        return dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None, gres, None
+        return dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None, gres, None, None
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu=False, residual=None,
@@ -459,8 +497,9 @@ def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, ep
     """num_batches_tracked (int64 scalar tensor, optional): incremented on the device by the statistics kernel."""
     if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not training):
         num_batches_tracked = None
+    pre = getattr(x, "_mr_bn_sums", None) if training else None
     return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, bool(training), momentum, eps, bool(relu),
-                             residual, num_batches_tracked)
+                             residual, num_batches_tracked, pre)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -8,6 +8,10 @@ import torch.nn as nn
 from . import functional as F
 
 
+# A/B switch (tools/): MEGREADER_BN_EPILOGUE=0 keeps BatchNorm's own statistics pass
+BN_EPILOGUE = __import__("os").environ.get("MEGREADER_BN_EPILOGUE", "1") != "0"
+
+
 def _pair(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
@@ -25,9 +29,15 @@ class Conv2d(nn.Conv2d):
         # physical KRSC layout: the wgrad kernel's output is then adopted as .grad without a re-layout
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
+    # set by the BatchNorm2d that consumed this layer's output in training mode (see BatchNorm2d.forward): from the next
+    # forward on, the batch statistics come out of this convolution's GEMM epilogue
+    feeds_batch_norm = False
+
     def forward(self, x):
-        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.fuse_relu,
-                        self.relu_grad_downstream)
+        y = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.fuse_relu,
+                     self.relu_grad_downstream, bn_stats=self.feeds_batch_norm and self.training and BN_EPILOGUE)
+        y._mr_producer = self
+        return y
 
 
 class FusedReLU(nn.Module):
@@ -47,6 +57,13 @@ class BatchNorm2d(nn.BatchNorm2d):
 
     def forward(self, x, residual=None):
         momentum = 0.1 if self.momentum is None else self.momentum
+        if self.training:
+            # conv -> bn fusion is self-configuring: the first training forward marks the producing Conv2d, every later
+            # one receives the batch statistics from that convolution's epilogue (F.conv2d(bn_stats=True)) and skips the
+            # statistics pass over its input
+            producer = getattr(x, "_mr_producer", None)
+            if producer is not None and not producer.feeds_batch_norm and not producer.fuse_relu:
+                producer.feeds_batch_norm = True
         # num_batches_tracked is advanced by the statistics kernel itself (no separate tiny launch per BN layer)
         return F.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, momentum,
                             self.eps, self.fuse_relu, residual,

@@ -93,6 +93,8 @@ def test_pmc_post_processing(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(REPO, "tools", "pmc_to_json.py"), str(fetch), str(write),
                            str(out)], stdout=subprocess.DEVNULL)
     d = json.load(open(out))
+    # the JSON is stamped with the hash of the kernel sources it was measured on (bench.py ignores a stale file)
+    assert len(d.pop("_kernel_source_hash")) >= 8
     assert set(d) == {"igemm_nt_kernel<bf16,96,128,conv>", "igemm_tn_kernel<bf16,conv>"}
     nt = d["igemm_nt_kernel<bf16,96,128,conv>"]
     assert nt["bytes_per_launch"] == 2 * 4.8e4 * 1024 + 2.4e4 * 1024 and nt["launches"] == 30   # FETCH_SIZE doubled

@@ -693,3 +693,92 @@ def test_batchnorm_fused_finalize_bit_identical(dtype, N, C, H, W, relu, res):
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert int(outs[0][3]) == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BatchNorm statistics out of the conv epilogue (mr_conv2d_fwd_stats): every NT kernel family the dispatcher can pick --
+# 64/96/128-row 4-wave tiles, the 256x256 and 272x256 8-wave tiles, head + tail launches -- must leave in `sums` exactly what
+# a reduction over the stored y gives (the apply pass normalises the STORED values), with and without a conv bias, ragged M.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [
+    (3, 7, 9, 64, 64, 3, 1, 1),        # 189 rows: one ragged 64-row tile
+    (16, 16, 32, 64, 128, 1, 0, 1),    # 1x1, 8192 x 128
+    (64, 8, 32, 128, 256, 3, 1, 1),    # 16384 x 256, K = 1152
+    (256, 8, 32, 256, 256, 3, 1, 1),   # 65536 x 256, K = 2304: 256 x 256 big tiles (bf16)
+    (256, 4, 33, 256, 512, 3, 1, 1),   # 33792 x 512: 272-row big tiles (bf16)
+    (40, 16, 32, 64, 256, 1, 0, 2),    # strided 1x1 (ResNet downsample)
+    (9, 20, 20, 64, 64, 3, 2, 2),      # dilated 3x3 (dilated ResNet)
+])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_conv_fwd_stats_epilogue(dtype, shape, with_bias):
+    from megreader_amd._lib import load
+    Nb, H, W, C, Kc, k, p, sd = shape
+    stride, dil = (sd, 1) if k == 1 else (1, sd)
+    Ho = (H + 2 * p - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * p - dil * (k - 1) - 1) // stride + 1
+    dt = dtype_code(dtype)
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(Nb, H, W, C, generator=g) + 0.3).to(DEV, dtype)
+    w = (torch.randn(Kc, k, k, C, generator=g) * 0.05).to(DEV, dtype)
+    cb = (torch.randn(Kc, generator=g) * 2).to(DEV) if with_bias else None
+    nsum = load().mr_bn_scratch_doubles(Kc)
+    y0 = torch.empty(Nb, Ho, Wo, Kc, device=DEV, dtype=dtype)
+    call("mr_conv2d_fwd", dt, ptr(x), ptr(w), ptr(cb), ptr(y0), 0, Nb, H, W, C, C, Kc, Kc, k, k, stride, stride, p, p, dil,
+         dil, Ho, Wo)
+    y1 = torch.empty_like(y0)
+    sums = torch.zeros(nsum, dtype=torch.float64, device=DEV)
+    call("mr_conv2d_fwd_stats", dt, ptr(x), ptr(w), ptr(cb), ptr(y1), ptr(sums), Nb, H, W, C, C, Kc, k, k, stride, stride,
+         p, p, dil, dil, Ho, Wo)
+    assert torch.equal(y0, y1)                      # the statistics epilogue does not touch the stored values
+    got = sums[:16 * Kc].view(8, 2, Kc).sum(dim=0).cpu()
+    yd = y1.double().view(-1, Kc).cpu()
+    want = torch.stack([yd.sum(dim=0), (yd * yd).sum(dim=0)])
+    P = yd.shape[0]
+    # f32 partial sums of <= 17 x 16 rows, f64 across tiles: error ~ 1e-7 * sqrt(P) * rms, far below the bar
+    scale = torch.stack([yd.abs().sum(dim=0), (yd * yd).sum(dim=0)]) + 1e-30
+    assert float(((got - want).abs() / scale).max()) < 2e-6, float(((got - want).abs() / scale).max())
+    # the reduction pass on its own (the fallback of mr_conv2d_fwd_stats, and what mr_bn_fwd_train runs otherwise)
+    sums2 = torch.zeros(nsum, dtype=torch.float64, device=DEV)
+    call("mr_bn_stats", dt, ptr(y1), ptr(sums2), P, Kc)
+    got2 = sums2[:16 * Kc].view(8, 2, Kc).sum(dim=0).cpu()
+    assert float(((got2 - want).abs() / scale).max()) < 2e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_bn_statistics_handoff_equals_separate_pass(dtype):
+    """nn.Conv2d -> nn.BatchNorm2d in training mode: the first forward marks the convolution, from the second on the batch
+    statistics come out of the convolution's epilogue (BatchNorm skips its reduction pass).  Outputs, running statistics
+    and all gradients of a fused iteration must equal those of the same iteration run unfused."""
+    from megreader_amd.nn import BatchNorm2d, Conv2d
+    from megreader_amd.nn.functional import ZeroArena
+    mr.set_compute_dtype(dtype)
+    torch.manual_seed(3)
+    conv = Conv2d(64, 128, 3, padding=1, bias=True).to(DEV)
+    bn = BatchNorm2d(128, fuse_relu=True).to(DEV)
+    x0 = torch.randn(8, 64, 12, 20, device=DEV)
+    gy = torch.randn(8, 128, 12, 20, device=DEV)
+
+    def run(fused):
+        conv.feeds_batch_norm = fused
+        ZeroArena.reset(x0.device)
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0); bn.num_batches_tracked.zero_()
+        for p in list(conv.parameters()) + list(bn.parameters()):
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        h = conv(x)
+        assert (getattr(h, "_mr_bn_sums", None) is not None) == fused
+        y = bn(h)
+        y.backward(gy.to(y.dtype))
+        return [t.detach().float().clone() for t in (y, x.grad, conv.weight.grad, conv.bias.grad, bn.weight.grad,
+                                                     bn.bias.grad, bn.running_mean, bn.running_var)]
+    a = run(False)
+    assert conv.feeds_batch_norm                      # learned from the unfused forward
+    b = run(True)
+    tol = 2e-5 if dtype == torch.float32 else 5e-3    # bf16: one rounding of rstd-scaled values may flip
+    for name, u, v in zip(("y", "dx", "dw", "db", "dgamma", "dbeta", "running_mean", "running_var"), a, b):
+        # a bias in front of a BatchNorm has a mathematically zero gradient (round-off on both sides): measured against dw
+        scale = float(a[2].abs().max()) if name == "db" else float(u.abs().max())
+        err = float((u - v).abs().max()) / (scale + 1e-12)
+        assert err < tol, (name, err)
+    assert int(bn.num_batches_tracked) == 1
