@@ -148,6 +148,9 @@ def main():
                          "'graph2' = two graphs with one eager all-reduce between them (not overlapped); 'auto' = "
                          "capture, falling back to graph2 if the capture fails")
     ap.add_argument("--tn-model", type=int, default=-1, help="A/B: mr_set_tn_model (wgrad split model), -1 = default")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=INT",
+                    help="A/B: call the host-only tuning setter mr_set_NAME(INT) before the run (e.g. --set nt_deep=0); "
+                         "recorded in config.tuning")
     ap.add_argument("--workload", default="crnn", choices=["crnn", "res50ppm", "fpn_attention", "db"],
                     help="crnn = BASELINE.json configs[1] (the metric's workload, default); res50ppm = configs[2]: "
                          "ResNet50-dilated-PPM + 2D-CTC on 32x128 crops (secondary line, same JSON shape); "
@@ -165,6 +168,10 @@ def main():
     if args.tn_model >= 0:
         from megreader_amd import _lib as _l
         _l.load().mr_set_tn_model(args.tn_model)
+    for kv in args.set:
+        from megreader_amd import _lib as _l
+        name, val = kv.split("=")
+        getattr(_l.load(), "mr_set_" + name)(int(val))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or args.force_ddp
@@ -436,7 +443,7 @@ def main():
                            "per_gpu_batch": bsz, "parallelism": "dp%d" % world,
                            "launch": ("hipGraph replay" if not distributed else ddp_launch) if use_graph
                            else ("eager" if not distributed else "eager, apex-style DDP shim (bucketed, overlapped)"),
-                           "train_flops_per_image": 3 * fwd_flops},
+                           "train_flops_per_image": 3 * fwd_flops, **({"tuning": args.set} if args.set else {})},
                 "final_loss": final_loss,
                 "roofline": roofline,
                 "kernels": kernels,

@@ -48,6 +48,10 @@ int mr_force_nt_tile(int bm, int bn);
 /* big-tile (8-wave, 256x256 / 288x256) NT kernel policy: 0 automatic, -1 never, 1 / 2 force (tuning override);
  * returns the previous setting */
 int mr_set_nt_big(int mode);
+/* host only: pipeline depth of the 4-wave direct-to-LDS NT kernel.  1 (default) = launches with at most ~1.5 workgroups per CU
+ * and >= 8 k-steps (bf16) run with 4 LDS stage buffers and 3 k-steps of LDS-DMA in flight across raw barriers; 0 = always the
+ * 2-buffer loop; 2 = always the 4-buffer loop (tests / A-B).  Same results bit for bit.  Returns the previous setting. */
+int mr_set_nt_deep(int mode);
 /* host only: 1 = phased-schedule 256x256 NT kernel (igemm_p8.h) for the big-tile launches, 0 (default) = the v3
  * kernel (the timing-only ablation variants 2..4 exist only in the -DMR_ABLATION tools build) */
 int mr_set_nt_p8(int on);
@@ -115,7 +119,8 @@ int mr_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw_krsc, fl
 /* mr_conv2d_wgrad with a caller-owned row table of the im2col gather: rowtab = N*Ho*Wo entries of 8 bytes
  * ({element offset of the pixel's window in x, validity bit per tap}); build != 0 fills it first, build == 0 trusts
  * it (a layer's geometry is constant: build once, reuse every step).  bf16 and R*S <= 32; otherwise, or with
- * rowtab == NULL, identical to mr_conv2d_wgrad. */
+ * rowtab == NULL, identical to mr_conv2d_wgrad.  build bit 1: the launch may run concurrently with other weight-gradient
+ * launches (another stream): the shared split-reduction workspace (mr_set_tn_taps_workspace) is not used, f32 atomics only. */
 int mr_conv2d_wgrad_tab(int dtype, const void* dy, const void* x, float* dw_krsc, float* dbias, int N, int H, int W,
                         int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh,
                         int dw, int Ho, int Wo, void* rowtab, int build, hipStream_t stream);

@@ -31,6 +31,7 @@ static const void* zero_page() {
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 static int g_nt_variant = 2;  // 2 = direct-to-LDS kernel (default), 1 = register-staged kernel (A/B debugging)
+static int g_nt_deep = 1;     // 4-stage pipeline of the 4-wave NT kernel: 1 = automatic (low-occupancy launches), 0 never, 2 always
 
 // mr_conv2d_fwd_stats: the f64 column-statistics accumulators the NT launches of the current call attach to their epilogue
 // (EpiStore::stats), and whether every launch of the call could (the register-staged fallback kernel cannot)
@@ -46,6 +47,8 @@ static bool nt_fits_buffer(const NtArgs& a, const ConvGeom& g, int amode) {
   const long long bytesB = (long long)a.N * a.ldb * es;
   return bytesA < (1ll << 31) && bytesB < (1ll << 31);
 }
+
+static int num_cus();
 
 template <typename T, int BM, int BN, int AMODE>
 static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long long ldc, const float* bias,
@@ -68,6 +71,32 @@ static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long lon
       epi.stats = g_epi_stats;
       epi.stats_ncopy = MR_BN_COPIES;
       constexpr int BK = 8 * VecOf<T>::N;
+      if constexpr (sizeof(T) == 2) {
+        // low-occupancy launches (about one workgroup per CU or fewer: the small-M layers of the batch-2 detector and the
+        // batch-32 recogniser): 4 stage buffers, 3 k-steps of LDS-DMA in flight across the barriers (igemm_nt_glds_kernel NST)
+        // Only while every workgroup of the launch is still resident at once with the larger LDS footprint (64 KB for 64x64
+        // tiles: two per CU; 96 - 128 KB above: one per CU): 264 tiles of 128x128 on 256 CUs ran 2 % SLOWER with one workgroup
+        // per CU and a second round of 8 than as 264 co-resident 2-buffer workgroups (CRNN conv6).  Measured (40 steps, same
+        // box): FPN-attention 10.75 -> 10.14 ms, DB 11.61 -> 11.21 ms, Res50-PPM 13.23 -> 13.10 ms.
+        const int nk = cdiv(a.K, BK);
+        constexpr int NST = 4;
+        constexpr int lds = NST * (BM + BN) * 128;
+        const bool deep = g_nt_deep == 2 || (g_nt_deep == 1 && tiles <= num_cus() * ((160 * 1024) / lds) && nk >= 8);
+        if (deep && (AMODE == 0 || (g.Cg % BK) == 0)) {
+          auto kern = igemm_nt_glds_kernel<T, BM, BN, AMODE, EpiStore<T>, NST>;
+          static bool attr_set = false;  // per instantiation
+          if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+              set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", lds);
+              return MR_ERR_LAUNCH;
+            }
+            attr_set = true;
+          }
+          hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a2, g, epi);
+          MR_CHECK_LAUNCH();
+          return MR_OK;
+        }
+      }
       if (AMODE == 2 && (g.Cg % BK) != 0)
         hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, (AMODE == 2 ? 3 : AMODE), EpiStore<T>>), dim3(grid),
                            dim3(256), 0, stream, a2, g, epi);
@@ -517,6 +546,12 @@ int mr_set_nt_p8(int on) {
 
 // Big-tile (8-wave) NT kernel policy: 0 automatic, -1 never, 1 always 256x256, 2 always 288x256 (needs N % 256 == 0
 // callers; a tuning / A-B override).  Returns the previous setting.
+int mr_set_nt_deep(int mode) {
+  const int old = g_nt_deep;
+  if (mode >= 0 && mode <= 2) g_nt_deep = mode;
+  return old;
+}
+
 int mr_set_nt_big(int mode) {
   const int old = g_big_mode;
   if (mode >= -1 && mode <= 7) g_big_mode = mode;
@@ -772,9 +807,24 @@ int mr_conv2d_wgrad(int dtype, const void* dy, const void* x, float* dw_krsc, fl
 // tn_rowtab_kernel): build != 0 fills it first (one small kernel), build == 0 trusts its contents -- the geometry of
 // a layer never changes, so callers build it once and pass it to every later step.  bf16, R*S <= 32 only
 // (otherwise, or with rowtab == null, this is mr_conv2d_wgrad).
+static int conv2d_wgrad_tab_impl(int dtype, const void* dy, const void* x, float* dw_krsc, float* dbias, int Nimg, int H,
+                                 int W, int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw,
+                                 int dh, int dw, int Ho, int Wo, void* rowtab, int build, hipStream_t stream);
+// build: bit 0 = fill the row table first; bit 1 = the launch may run CONCURRENTLY with other weight-gradient launches (a side
+// stream): the shared split-reduction workspace is then left alone (f32 atomics only), see mr_set_tn_taps_workspace.
 int mr_conv2d_wgrad_tab(int dtype, const void* dy, const void* x, float* dw_krsc, float* dbias, int Nimg, int H,
                         int W, int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw,
                         int dh, int dw, int Ho, int Wo, void* rowtab, int build, hipStream_t stream) {
+  taps_set_concurrent((build & 2) != 0);
+  const int rc = conv2d_wgrad_tab_impl(dtype, dy, x, dw_krsc, dbias, Nimg, H, W, Cin, ldx, Cout, lddy, R, S, sh, sw, ph, pw, dh,
+                                       dw, Ho, Wo, rowtab, build & 1, stream);
+  taps_set_concurrent(false);
+  return rc;
+}
+
+static int conv2d_wgrad_tab_impl(int dtype, const void* dy, const void* x, float* dw_krsc, float* dbias, int Nimg, int H,
+                                 int W, int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw,
+                                 int dh, int dw, int Ho, int Wo, void* rowtab, int build, hipStream_t stream) {
   if (rowtab == nullptr || dtype != MR_BF16 || R * S > 32 || g_nt_variant != 2)
     return mr_conv2d_wgrad(dtype, dy, x, dw_krsc, dbias, Nimg, H, W, Cin, ldx, Cout, lddy, R, S, sh, sw, ph, pw, dh,
                            dw, Ho, Wo, stream);

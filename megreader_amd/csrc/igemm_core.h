@@ -86,6 +86,15 @@ __device__ __forceinline__ uint4 ldg16(const void* p) { return *(const uint4*)p;
 // lanes of a row group (same lg) are combined with four butterfly steps, lane l15 == 0 adds the result to the f64
 // accumulators.  2 * 4*CNT f64 atomics per (wave, lg): 512 per 128x128 tile against 16384 elements.
 template <typename Epi> struct EpiHasStats { static constexpr bool value = false; };  // specialised for EpiStore below
+__device__ __forceinline__ float row16_sum(float v) {   // total over the lane's 16-lane DPP row, in every lane of it
+#define MR_ROW_ROR(V, N) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), 0x120 + (N), 0xf, 0xf, false))
+  v += MR_ROW_ROR(v, 8);
+  v += MR_ROW_ROR(v, 4);
+  v += MR_ROW_ROR(v, 2);
+  v += MR_ROW_ROR(v, 1);
+#undef MR_ROW_ROR
+  return v;
+}
 template <typename T, int CNT> struct EpiColStats {
   float s[4 * CNT], q[4 * CNT];
   __device__ __forceinline__ void init() {
@@ -106,13 +115,11 @@ template <typename T, int CNT> struct EpiColStats {
       }
   }
   template <typename Epi> __device__ __forceinline__ void flush(const Epi& epi, int n, int l15) {
+    // all-reduce over the 16 lanes of a DPP row (= the row group): four rotate-and-add steps, one v_add_f32_dpp each
 #pragma unroll
     for (int e = 0; e < 4 * CNT; ++e) {
-#pragma unroll
-      for (int d = 1; d < 16; d <<= 1) {
-        s[e] += __shfl_xor(s[e], d, 64);
-        q[e] += __shfl_xor(q[e], d, 64);
-      }
+      s[e] = row16_sum(s[e]);
+      q[e] = row16_sum(q[e]);
     }
     // every lane of the row group now holds all 2 * 4*CNT totals: lane l15 takes column l15's, so that the wave issues
     // ONE atomic instruction over 64 (or 2 x 32) consecutive doubles instead of 8*CNT instructions with 4 live lanes
@@ -575,7 +582,12 @@ __device__ __forceinline__ void glds16_buf(rsrc_t r, bool ok, int elem_off, int 
 
 // AMODE 0: dense A.  AMODE 2: conv, Cg % BK == 0 (every k-step lies inside one tap: the tap state is scalar and
 // advances incrementally).  AMODE 3: conv with small / odd Cg (first layer): per-vector tap arithmetic.
-template <typename T, int BM, int BN, int AMODE, typename Epi>
+// NST = number of LDS stage buffers.  2 (default): one k-step of prefetch, __syncthreads() per k-step -- right when several
+// workgroups share a CU and hide each other's load latency.  NST > 2 (dynamic LDS, NST * (BM + BN) * 128 bytes): NST - 1
+// k-steps of LDS-DMA stay in flight ACROSS the barriers (raw s_barrier + counted s_waitcnt vmcnt; __syncthreads() would drain
+// them) -- for launches with at most ~one workgroup per CU (small-M layers: batch-2 detector, batch-32 recogniser), whose
+// k-step time is otherwise one full L2 / HBM round trip.
+template <typename T, int BM, int BN, int AMODE, typename Epi, int NST = 2>
 __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g, Epi epi) {
   constexpr int VEC = VecOf<T>::N;
   constexpr int BK = 8 * VEC;
@@ -584,7 +596,9 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
   constexpr int TILE_VECS = (BM + BN) * 8;
   typedef typename Mma<T>::Frag Frag;
 
-  __shared__ uint4 smem[2 * TILE_VECS];
+  __shared__ uint4 smem_static[NST == 2 ? 2 * TILE_VECS : 1];
+  extern __shared__ uint4 smem_dynamic[];
+  uint4* const smem = NST == 2 ? smem_static : smem_dynamic;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -740,22 +754,48 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
   };
 
   const int nk = (a.K + BK - 1) / BK;
-  uint4* st0 = smem;
-  uint4* st1 = smem + TILE_VECS;
-  if (nk > 0) stage(st0, 0);
-  // two k-steps per iteration so that the stage base is a compile-time constant in every LDS access
-  int t = 0;
-  for (; t + 1 < nk; t += 2) {
-    __syncthreads();  // k-step t landed (vmcnt drained before the barrier); stage 1 is free
-    stage(st1, (t + 1) * BK);
-    compute(st0);
-    __syncthreads();
-    if (t + 2 < nk) stage(st0, (t + 2) * BK);
-    compute(st1);
-  }
-  if (t < nk) {
-    __syncthreads();
-    compute(st0);
+  if constexpr (NST == 2) {
+    uint4* st0 = smem;
+    uint4* st1 = smem + TILE_VECS;
+    if (nk > 0) stage(st0, 0);
+    // two k-steps per iteration so that the stage base is a compile-time constant in every LDS access
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+      __syncthreads();  // k-step t landed (vmcnt drained before the barrier); stage 1 is free
+      stage(st1, (t + 1) * BK);
+      compute(st0);
+      __syncthreads();
+      if (t + 2 < nk) stage(st0, (t + 2) * BK);
+      compute(st1);
+    }
+    if (t < nk) {
+      __syncthreads();
+      compute(st0);
+    }
+  } else {
+    // NST buffers, NST - 1 k-steps in flight.  Iteration t: wait until this wave's part of k-step t has landed (counted vmcnt:
+    // the younger stages stay in flight), raw barrier (everybody's part landed; everybody is done reading buffer (t-1) % NST),
+    // refill that buffer with k-step t + NST - 1, compute on buffer t % NST.  NST k-steps per trip of the outer loop keep every
+    // LDS base a compile-time constant.
+    constexpr int LPS = AI + BI;   // LDS-DMA instructions per stage and wave
+    static_assert((NST - 2) * LPS <= 63, "vmcnt is a 6-bit counter");
+#pragma unroll
+    for (int u = 0; u < NST - 1; ++u)
+      if (u < nk) stage(smem + u * TILE_VECS, u * BK);
+    for (int t0 = 0; t0 < nk; t0 += NST) {
+#pragma unroll
+      for (int u = 0; u < NST; ++u) {
+        const int t = t0 + u;
+        if (t < nk) {
+          const int younger = min(NST - 2, nk - 1 - t);   // stages issued after k-step t that may stay in flight
+          if (younger >= 2 && NST >= 4) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
+          else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+          if (t + NST - 1 < nk) stage(smem + ((u + NST - 1) % NST) * TILE_VECS, (t + NST - 1) * BK);
+          compute(smem + u * TILE_VECS);
+        }
+      }
+    }
   }
 
   // row block outer, column block inner: the TN stores of one output row land back to back, so its 128-byte line is

@@ -440,6 +440,10 @@ static int taps_cur_dev() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
   return dev;
 }
+// set while a launch may run concurrently with other TN launches on another stream (mr_conv2d_wgrad_tab flags bit 1): the shared
+// split-reduction workspace (tickets + slabs) must then not be used -- its launches have to be stream-ordered with each other
+static thread_local bool g_tn_concurrent = false;
+void taps_set_concurrent(bool on) { g_tn_concurrent = on; }
 void taps_set_workspace(void* p, long long bytes) {
   const int dev = taps_cur_dev();
   if (dev < 0) return;
@@ -448,7 +452,7 @@ void taps_set_workspace(void* p, long long bytes) {
 }
 void taps_get_workspace(void** p, long long* bytes) {
   const int dev = taps_cur_dev();
-  *p = dev >= 0 ? g_taps_ws_dev[dev] : nullptr;
+  *p = (dev >= 0 && !g_tn_concurrent) ? g_taps_ws_dev[dev] : nullptr;
   *bytes = dev >= 0 ? g_taps_ws_bytes_dev[dev] : 0;
 }
 int taps_set_group(int g) { const int old = g_taps_grp; if (g >= 0) g_taps_grp = g; return old; }
@@ -506,7 +510,7 @@ int launch_tn_taps(const TapsProblem& p, int splits_override, hipStream_t stream
   // group reduction: needs the registered workspace (tickets + one slab per workgroup) and unique tickets
   a.grp = 1;
   const int dev = taps_cur_dev();
-  void* const g_taps_ws = dev >= 0 ? g_taps_ws_dev[dev] : nullptr;
+  void* const g_taps_ws = (dev >= 0 && !g_tn_concurrent) ? g_taps_ws_dev[dev] : nullptr;
   const long long g_taps_ws_bytes = dev >= 0 ? g_taps_ws_bytes_dev[dev] : 0;
   a.ws = g_taps_ws;
   {

@@ -94,14 +94,19 @@ def _run(accelerated, batches, steps, dtype):
         pass
     wrapper = dropin.accelerate_trainer(T, eager_steps=3) if accelerated else None
     tr = T()
-    losses, t_tail = [], None
+    # the last 10 steps are timed with events on the main stream and WITHOUT a host synchronisation in front of them: a
+    # sync would let the GPU run dry, and the first timed step would then pay its 25 MB host-to-device copy un-overlapped
+    # (0.5 - 2 ms depending on the box's PCIe link) -- in steady state the host runs ahead and the copy of step s + 1 rides
+    # beside the replay of step s
+    losses = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for s in range(steps):
         if s == steps - 10:
-            torch.cuda.synchronize()
-            t_tail = time.perf_counter()
+            e0.record()
         losses.append(tr.train_step(model, opt, batches[s % len(batches)], epoch=0, step=s).detach())
+    e1.record()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t_tail) / 10
+    dt = 1e-3 * e0.elapsed_time(e1) / 10
     return [float(l) for l in losses], dt, wrapper
 
 

@@ -782,3 +782,60 @@ def test_conv_bn_statistics_handoff_equals_separate_pass(dtype):
         err = float((u - v).abs().max()) / (scale + 1e-12)
         assert err < tol, (name, err)
     assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("shape", [
+    (512, 512, 4608, 0),      # dense, 64 tiles of 64x64 (the automatic choice for a launch this small)
+    (2048, 256, 2304, 0),     # 128 tiles
+    (1000, 136, 520, 0),      # ragged M / N, K not a multiple of 64 (last k-step predicated)
+    (37, 64, 64, 0),          # a single k-step: fewer k-steps than stage buffers
+    (200, 64, 192, 0),        # 3 k-steps
+])
+def test_nt_deep_pipeline_is_bit_identical(shape):
+    """The 4-buffer main loop of the 4-wave NT kernel (3 k-steps of LDS-DMA in flight across raw barriers, mr_set_nt_deep)
+    accumulates in the same order as the 2-buffer loop: dense GEMMs and convolutions (forward / dgrad, 3x3 and 1x1) must
+    come out bit for bit the same, including k-step counts below the pipeline depth and a predicated last k-step."""
+    from megreader_amd._lib import load
+    lib = load()
+    M, N, K, _ = shape
+    dt = dtype_code(torch.bfloat16)
+    g = torch.Generator().manual_seed(17)
+    A = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    B = torch.randn(N, K, generator=g).to(DEV, torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(DEV)
+    outs = []
+    old = lib.mr_set_nt_deep(0)
+    try:
+        for mode in (0, 2):
+            lib.mr_set_nt_deep(mode)
+            C = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+            call("mr_gemm_nt", dt, ptr(A), K, ptr(B), K, ptr(C), N, ptr(bias), 1, M, N, K)
+            outs.append(C)
+        assert torch.equal(outs[0], outs[1])
+        want = torch.relu(A.double().cpu() @ B.double().cpu().t() + bias.double().cpu())
+        assert _rel_err(outs[1], want) < _tol(torch.bfloat16, K)
+        # convolutions through the same kernel (AMODE 2): 3x3 pad 1 and 1x1 stride 2, forward and dgrad, + stats epilogue
+        for (Nb, H, W, Cc, Kc, k, p, st) in [(2, 10, 12, 128, 64, 3, 1, 1), (3, 8, 16, 256, 128, 1, 0, 2)]:
+            Ho, Wo = (H + 2 * p - k) // st + 1, (W + 2 * p - k) // st + 1
+            x = torch.randn(Nb, H, W, Cc, generator=g).to(DEV, torch.bfloat16)
+            w = (torch.randn(Kc, k, k, Cc, generator=g) * 0.05).to(DEV, torch.bfloat16)
+            wt = (torch.randn(Cc, k, k, Kc, generator=g) * 0.05).to(DEV, torch.bfloat16)
+            dy = torch.randn(Nb, Ho, Wo, Kc, generator=g).to(DEV, torch.bfloat16)
+            res = []
+            for mode in (0, 2):
+                lib.mr_set_nt_deep(mode)
+                y = torch.zeros(Nb, Ho, Wo, Kc, device=DEV, dtype=torch.bfloat16)
+                sums = torch.zeros(lib.mr_bn_scratch_doubles(Kc), dtype=torch.float64, device=DEV)
+                call("mr_conv2d_fwd_stats", dt, ptr(x), ptr(w), 0, ptr(y), ptr(sums), Nb, H, W, Cc, Cc, Kc, k, k, st, st, p,
+                     p, 1, 1, Ho, Wo)
+                dx = torch.zeros(Nb, H, W, Cc, device=DEV, dtype=torch.bfloat16)
+                call("mr_conv2d_dgrad", dt, ptr(dy), ptr(wt), ptr(dx), Nb, H, W, Cc, Cc, Kc, Kc, k, k, st, st, p, p, 1, 1,
+                     Ho, Wo)
+                res.append((y, dx, sums[:16 * Kc].view(8, 2, Kc).sum(dim=0)))
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+            assert float((res[0][2] - res[1][2]).abs().max()) <= 1e-9 * float(res[0][2].abs().max())
+            want = TF.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu().permute(0, 3, 1, 2), None, st,
+                             p).permute(0, 2, 3, 1)
+            assert _rel_err(res[1][0], want) < _tol(torch.bfloat16, Cc * k * k)
+    finally:
+        lib.mr_set_nt_deep(old)
