@@ -340,7 +340,8 @@ int mr_dcn2_col2im(int dtype, const void* gcol, const float* offset, long long o
  * (col_ws may be NULL), the CSR of the scatter pattern for the fused backward, the column matrix [N*Ho*Wo, kh*kw*C] otherwise.
  * w_n [Co][kh*kw*C] / w_t [kh*kw*C][Co] are the mr_prep_matrix images of the KRSC weight; dx32 / doffset / dmask are ACCUMULATED
  * into and must arrive zeroed (the reference's Function allocates them with zeros_like, functions/deform_conv.py:150-154);
- * dw f32 [Co][kh*kw*C] and dbias f32 [Co] accumulated; dx32, dw, dbias may be null. */
+ * dw f32 [Co][kh*kw*C] and dbias f32 [Co] accumulated.  Any of the three output groups -- {doffset, dmask}, dx32, {dw, dbias} --
+ * may be null: only the others are computed. */
 long long mr_dcn2_ws_bytes(int dtype, int N, int H, int W, int C, int Co, int kh, int kw, int Ho, int Wo, int backward);
 int mr_set_dcn_fused(int on);    /* A/B (host only): 0 = general kernels for every shape; returns the old value */
 int mr_set_dcn_v1_bwd(int on);   /* A/B (host only): 1 = round-1 DCN backward kernels */

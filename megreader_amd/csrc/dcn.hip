@@ -524,11 +524,16 @@ int mr_dcn2_bwd(int dtype, const void* dy, const void* x, const void* w_t, const
   }
   MR_CHECK_ARG(col_ws != nullptr, "mr_dcn2_bwd: workspace missing (mr_dcn2_ws_bytes)");
   const int K = kh * kw * C, P = N * Ho * Wo;
-  int rc = mr_gemm_nt(dtype, dy, Co, w_t, Co, col_ws, K, nullptr, 0, P, K, Co, stream);   // gcol = dy * W
-  if (rc) return rc;
-  rc = mr_dcn2_coord_grad(dtype, col_ws, x, offset, off_bs, mask, msk_bs, doffset, dmask, N, H, W, C, kh, kw, stride,
-                          pad, dil, Ho, Wo, stream);
-  if (rc) return rc;
+  int rc = MR_OK;
+  if ((doffset && dmask) || dx32) {
+    rc = mr_gemm_nt(dtype, dy, Co, w_t, Co, col_ws, K, nullptr, 0, P, K, Co, stream);   // gcol = dy * W
+    if (rc) return rc;
+  }
+  if (doffset && dmask) {
+    rc = mr_dcn2_coord_grad(dtype, col_ws, x, offset, off_bs, mask, msk_bs, doffset, dmask, N, H, W, C, kh, kw, stride,
+                            pad, dil, Ho, Wo, stream);
+    if (rc) return rc;
+  }
   if (dx32) {
     rc = mr_dcn2_col2im(dtype, col_ws, offset, off_bs, mask, msk_bs, dx32, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo,
                         stream);

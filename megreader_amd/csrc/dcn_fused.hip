@@ -1062,15 +1062,19 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
   a.x = x; a.w = w_t; a.dy = dy; a.offset = offset; a.mask = mask; a.doffset = doffset; a.dmask = dmask; a.dx = dx32;
   a.g = g; a.Co = Co; a.P = (int)P; a.Q = (int)Q; a.tsplit = 1;
   const int tiles_p = cdiv((int)P, 64);
+  // The three parts below are independent of each other (each reads dy / x / w / offset / mask and writes its own outputs):
+  // a caller may ask for any subset by passing null for the outputs of the others, e.g. to run them on parallel streams.
   // ---- offset / mask gradients (gcol tiles stay in registers)
-  if (g.C % 128 == 0) {
-    DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_coord_fused_kernel<T, 128>), dim3(tiles_p * (taps * g.C / 128)), dim3(256), 0,
-                                         stream, a));
-  } else {
-    DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_coord_fused_kernel<T, 64>), dim3(tiles_p * (taps * g.C / 64)), dim3(256), 0,
-                                         stream, a));
+  if (doffset && dmask) {
+    if (g.C % 128 == 0) {
+      DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_coord_fused_kernel<T, 128>), dim3(tiles_p * (taps * g.C / 128)), dim3(256), 0,
+                                           stream, a));
+    } else {
+      DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_coord_fused_kernel<T, 64>), dim3(tiles_p * (taps * g.C / 64)), dim3(256), 0,
+                                           stream, a));
+    }
+    MR_CHECK_LAUNCH();
   }
-  MR_CHECK_LAUNCH();
   // ---- input gradient: CSR of the scatter pattern, then the gather-GEMM
   if (dx32) {
     MR_CHECK_ARG(ws != nullptr, "dcn backward: workspace missing (mr_dcn2_ws_bytes)");

@@ -126,10 +126,6 @@ class _Side(object):
         _Side.queued = False
 
 
-# weight-gradient launches of convolutions up to this many GFLOP go to the side stream (Conv2dFn.backward); 0 = never
-WGRAD_SIDE_GFLOP = float(os.environ.get("MEGREADER_WGRAD_SIDE_GFLOP", "3.0"))
-
-
 class _Fan(object):
     """Fork/join of INDEPENDENT launches inside one autograd Function: the weight-gradient GEMMs of an LSTM / Linear
     layer (dense TN GEMMs with 16..64 output tiles: each alone leaves most CUs with one latency-bound workgroup or none,
@@ -363,26 +359,12 @@ class Conv2dFn(Function):
             # the gather's row table (8 bytes per output pixel) depends only on the layer geometry: built on first
             # use, then passed to every later step (bf16, R*S <= 32; otherwise the call is plain mr_conv2d_wgrad)
             tab, build = (None, 0)
-            # a sunk weight gradient has no consumer inside the backward pass.  Small problems (batch-2 detector, batch-32
-            # recogniser: ~20 us launches that leave most CUs idle) run it on the side stream beside the dgrad -> BatchNorm
-            # backward chain of the layers below (_Side; a parallel branch of the captured graph); large ones (CRNN,
-            # Res50-PPM at batch 256) fill the chip on their own and were measured slower side by side.
-            side = (w_sink is not None and (not want_db or b_sink is not None) and WGRAD_SIDE_GFLOP > 0 and
-                    2e-9 * N * Ho * Wo * K * R * S * C <= WGRAD_SIDE_GFLOP and
-                    not getattr(weight_p, "_mr_grad_ready_hooks", None))
             if dtype == torch.bfloat16 and R * S <= 32:
                 # (Kw % 8: the all-taps kernel needs whole channel vectors and its table has another format than the GEMM
                 # kernel's -- two layers of one geometry that differ in that must not share a table)
                 tab, build = _wgrad_rowtab(g.device, (N, H, W, Cp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo), Kw % 8 == 0)
-            if side and not build:   # (a table is built on the main stream: another layer may share it)
-                with torch.cuda.stream(_Side.fork()):
-                    # flags bit 1: concurrent with other weight-gradient launches -> no shared split-reduction workspace
-                    call("mr_conv2d_wgrad_tab", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp,
-                         Kw, Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo, ptr(tab), 2)
-                _Side.pending.extend((g, xi))
-            else:
-                call("mr_conv2d_wgrad_tab", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, Kw,
-                     Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo, ptr(tab), build)
+            call("mr_conv2d_wgrad_tab", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, Kw,
+                 Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo, ptr(tab), build)
             if w_sink is not None:
                 dwt = None
                 notify_grad_ready(weight_p)

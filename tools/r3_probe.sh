@@ -1,13 +1,8 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r3probe; mkdir -p $O
-run() { # name, args...
-  n=$1; shift
-  for w in crnn res50ppm db fpn_attention; do
-    timeout 300 python bench.py --workload $w --no-cpu-baseline --no-secondary --no-kernel-timer --steps 40 --warmup 5 "$@" > $O/ab_${n}_$w.log 2>&1
-    echo "$n $w $(tail -1 $O/ab_${n}_$w.log | grep -o '"ms_per_step": [0-9.]*')"
-  done
-}
-run deep1 --set nt_deep=1
-run deep0 --set nt_deep=0
-timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -6 $O/pytest.log
+for v in 0 8 0 8; do
+  MEGREADER_DCN_FORK_GFLOP=$v timeout 300 python bench.py --workload db --no-cpu-baseline --no-secondary --no-kernel-timer --steps 40 --warmup 5 > $O/ab_fork$v.log 2>&1
+  echo "fork$v db $(tail -1 $O/ab_fork$v.log | grep -o '"ms_per_step": [0-9.]*') $(grep -c Traceback $O/ab_fork$v.log)"
+done
+MEGREADER_DCN_FORK_GFLOP=8 timeout 600 python -m pytest tests/test_dcn_gpu.py tests/test_deformable_resnet_gpu.py -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
