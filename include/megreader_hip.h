@@ -292,6 +292,13 @@ int mr_adaptive_avgpool_fwd(int dtype, const void* x, void* y, int N, int H, int
                             hipStream_t stream);
 int mr_adaptive_avgpool_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int OH, int OW,
                             hipStream_t stream);
+/* Pyramid pooling (reference backbones/ppm.py:13-20,36-40): nscales (<= 8) adaptive average pools of ONE map per launch.  ys / dys:
+ * host arrays of device pointers [N][oh[i]][ow[i]][C].  Forward outputs are bit-identical to mr_adaptive_avgpool_fwd's; backward
+ * writes dx = sum_i adaptive_avgpool_bwd(dys[i]) (f32 accumulation, one rounding).  H * W * 128 bytes must fit 64 KB of LDS. */
+int mr_adaptive_avgpool_multi_fwd(int dtype, const void* x, void* const* ys, const int* oh, const int* ow, int nscales, int N,
+                                  int H, int W, int C, hipStream_t stream);
+int mr_adaptive_avgpool_multi_bwd(int dtype, void* const* dys, const int* oh, const int* ow, int nscales, void* dx, int N, int H,
+                                  int W, int C, hipStream_t stream);
 /* bilinear resize, align_corners=False; writes channels [coff, coff+C) of rows with stride ldy; accumulate=1 adds */
 int mr_bilinear_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, int OH, int OW, int ldy, int coff,
                     int accumulate, hipStream_t stream);

@@ -42,6 +42,8 @@ SIGNATURES = {
     "mr_prep_bias": "pppiis",
     "mr_prep_batch": "ipils",
     "mr_accumulate_multi": "ippps",
+    "mr_adaptive_avgpool_multi_fwd": "ippppiiiiis",
+    "mr_adaptive_avgpool_multi_bwd": "ipppipiiiis",
     "mr_adam_step": "pppplps",
     "mr_sgd_step": "ppplps",
     "mr_bn_fwd_train": "ipppppppppp" + "iliffps",

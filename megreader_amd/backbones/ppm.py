@@ -30,7 +30,10 @@ class PPMDeepsup(nn.Module):
         conv5 = conv_out[-1]
         input_size = conv5.size()
         ppm_out = [conv5]
-        for pool_scale in self.ppm:
-            ppm_out.append(F.interpolate_bilinear(pool_scale(conv5), (input_size[2], input_size[3])))
+        # reference: pool_scale(conv5) per branch = AdaptiveAvgPool2d(scale) -> conv -> bn -> relu.  The four pools read the
+        # same map: one launch (F.adaptive_avg_pool2d_multi), then the rest of each branch
+        pooled = F.adaptive_avg_pool2d_multi(conv5, [branch[0].output_size for branch in self.ppm])
+        for branch, p in zip(self.ppm, pooled):
+            ppm_out.append(F.interpolate_bilinear(branch[1:](p), (input_size[2], input_size[3])))
         ppm_out = F.cat_channels(ppm_out)
         return self.conv_last(ppm_out)

@@ -96,37 +96,6 @@ struct DcnFusedArgs {
                          // 72 dependent k-steps each) are latency chains without it.
 };
 
-// blend of the four corner vectors in the reference's corner order (top-left, top-right, bottom-left, bottom-right)
-template <typename T>
-__device__ __forceinline__ uint4 dcn_blend(const uint4 (&raw)[4], const DcnDesc& d) {
-  constexpr int VEC = VecOf<T>::N;
-  const float wgt[4] = {(1.f - d.lh) * (1.f - d.lw) * d.m, (1.f - d.lh) * d.lw * d.m, d.lh * (1.f - d.lw) * d.m,
-                        d.lh * d.lw * d.m};
-  float acc[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const T* pv = (const T*)&raw[k];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] += wgt[k] * to_f32(pv[j]);
-  }
-  return pack_vec<T>(acc);
-}
-
-// issue the four corner loads of one sample (16-byte channel vector at channel c); corners outside the image read as 0
-template <typename T>
-__device__ __forceinline__ void dcn_corner_loads(uint4 (&raw)[4], const T* __restrict__ X, const DcnGeom& g, int pixbase,
-                                                 const DcnDesc& d, int c) {
-  const uint4 z = make_uint4(0, 0, 0, 0);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int h = d.hl + (k >> 1), w = d.wl + (k & 1);
-    raw[k] = z;
-    if (dcn_inside(g, h, w)) raw[k] = ldg16(X + ((long long)(pixbase + h * g.W + w)) * g.C + c);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ forward
 // 32-bit addressing through buffer resources: a corner is one byte offset (or DCN_OOB, which the hardware answers with zeros:
 // no branch, no 64-bit address arithmetic), computed ONCE per (row, tap) into an LDS table next to the four blend weights.

@@ -7,6 +7,8 @@
 #include "common.h"
 #include "../../include/megreader_hip.h"
 
+#define MR_POOL_MULTI_MAX 8   /* scales per mr_adaptive_avgpool_multi_* call */
+
 namespace mr {
 
 static inline int grid_for(long long n, int block, int max_blocks = 16384) {
@@ -80,6 +82,93 @@ __global__ void adaptive_avgpool_bwd_kernel(const T* __restrict__ dy, T* __restr
     T* po = (T*)&o;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) po[j] = from_f32<T>(s[j]);
+    ((uint4*)dx)[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------- pyramid pooling: several adaptive average pools of one map
+// The PPM (reference backbones/ppm.py:13-20,36-40) pools the same [N, H, W, C] map to 1x1, 2x2, 3x3 and 6x6: four forward
+// passes over the map and, backward, four full-size input gradients that autograd then adds up (the map is the largest
+// activation of the head: 67 MB at N = 256).  Forward: one workgroup stages the H*W pixels of a 128-byte channel slice in LDS and
+// computes every bin of every scale from it (same summation order as adaptive_avgpool_fwd_kernel: bit-identical outputs).
+// Backward: one pass writes dx = sum over scales, accumulated in f32 and rounded once.
+struct PoolMultiArgs {
+  int nsc;
+  int oh[MR_POOL_MULTI_MAX], ow[MR_POOL_MULTI_MAX];
+  void* y[MR_POOL_MULTI_MAX];       // forward outputs / backward incoming gradients, [N][oh][ow][C]
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void adaptive_avgpool_multi_fwd_kernel(const T* __restrict__ x, PoolMultiArgs a, int N,
+                                                                         int H, int W, int C) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int CPB = 128 / (int)sizeof(T);          // channels per workgroup: one 128-byte line per pixel
+  extern __shared__ uint4 pool_tile[];               // [H*W][8] vectors
+  const int n = blockIdx.x, c0 = blockIdx.y * CPB;
+  const int HW = H * W;
+  for (int i = threadIdx.x; i < HW * 8; i += 256) {
+    const int pix = i >> 3, v = i & 7;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (c0 + v * VEC < C) val = *(const uint4*)(x + ((long long)n * HW + pix) * C + c0 + v * VEC);
+    pool_tile[i] = val;
+  }
+  __syncthreads();
+  const T* tile = (const T*)pool_tile;
+  const int c = threadIdx.x % CPB, sub = threadIdx.x / CPB, nsub = 256 / CPB;
+  if (c0 + c >= C) return;
+  for (int s = 0; s < a.nsc; ++s) {
+    const int OH = a.oh[s], OW = a.ow[s];
+    T* __restrict__ y = (T*)a.y[s];
+    for (int b = sub; b < OH * OW; b += nsub) {
+      const int oh = b / OW, ow = b - oh * OW;
+      const int h0 = bin_start(oh, H, OH), h1 = bin_end(oh, H, OH);
+      const int w0 = bin_start(ow, W, OW), w1 = bin_end(ow, W, OW);
+      float acc = 0.f;
+      for (int h = h0; h < h1; ++h)
+        for (int w = w0; w < w1; ++w) acc += to_f32(tile[(h * W + w) * CPB + c]);
+      y[(((long long)n * OH + oh) * OW + ow) * C + c0 + c] = from_f32<T>(acc / (float)((h1 - h0) * (w1 - w0)));
+    }
+  }
+}
+
+template <typename T>
+__global__ void adaptive_avgpool_multi_bwd_kernel(PoolMultiArgs a, T* __restrict__ dx, int N, int H, int W, int C) {
+  constexpr int VEC = VecOf<T>::N;
+  const int cv = C / VEC;
+  const long long total = (long long)N * H * W * cv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv);
+    long long q = i / cv;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H);
+    const int n = (int)(q / H);
+    float sum[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sum[j] = 0.f;
+    for (int s = 0; s < a.nsc; ++s) {
+      const int OH = a.oh[s], OW = a.ow[s];
+      const uint4* __restrict__ dy = (const uint4*)a.y[s];
+      // row h lies in bin oh  <=>  floor(h*OH/H) <= oh <= ceil((h+1)*OH/H) - 1   (see adaptive_avgpool_bwd_kernel)
+      const int oh_lo = h * OH / H, oh_hi = min(OH - 1, ((h + 1) * OH + H - 1) / H - 1);
+      const int ow_lo = w * OW / W, ow_hi = min(OW - 1, ((w + 1) * OW + W - 1) / W - 1);
+      for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+        const int h0 = bin_start(oh, H, OH), h1 = bin_end(oh, H, OH);
+        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+          const int w0 = bin_start(ow, W, OW), w1 = bin_end(ow, W, OW);
+          const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+          const uint4 g = dy[(((long long)n * OH + oh) * OW + ow) * cv + c];
+          const T* pg = (const T*)&g;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) sum[j] += to_f32(pg[j]) * inv;
+        }
+      }
+    }
+    uint4 o;
+    T* po = (T*)&o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) po[j] = from_f32<T>(sum[j]);
     ((uint4*)dx)[i] = o;
   }
 }
@@ -359,6 +448,46 @@ int mr_adaptive_avgpool_bwd(int dtype, const void* dy, void* dx, int N, int H, i
   const long long total = (long long)N * H * W * (C / vec);
   DISPATCH_T(dtype, hipLaunchKernelGGL((adaptive_avgpool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
                                        stream, (const T*)dy, (T*)dx, N, H, W, C, OH, OW));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+// Several adaptive average pools of ONE map in one launch each way (pyramid pooling, reference backbones/ppm.py:13-20,36-40).
+// ys / dys: host array of nscales device pointers [N][oh[i]][ow[i]][C]; forward outputs equal mr_adaptive_avgpool_fwd's bit for
+// bit; backward writes dx = sum_i adaptive_avgpool_bwd(dys[i]) accumulated in f32.  C % (16 / sizeof T) == 0, H*W*128 B <= 64 KB.
+int mr_adaptive_avgpool_multi_fwd(int dtype, const void* x, void* const* ys, const int* oh, const int* ow, int nscales, int N,
+                                  int H, int W, int C, hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(nscales > 0 && nscales <= MR_POOL_MULTI_MAX && N > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0,
+               "mr_adaptive_avgpool_multi_fwd: bad arguments");
+  MR_CHECK_ARG((long long)H * W * 128 <= 65536, "mr_adaptive_avgpool_multi_fwd: H*W (%d) too large for the LDS tile", H * W);
+  PoolMultiArgs a;
+  a.nsc = nscales;
+  for (int i = 0; i < nscales; ++i) {
+    MR_CHECK_ARG(ys[i] != nullptr && oh[i] > 0 && ow[i] > 0, "mr_adaptive_avgpool_multi_fwd: bad scale %d", i);
+    a.oh[i] = oh[i]; a.ow[i] = ow[i]; a.y[i] = ys[i];
+  }
+  const int cpb = dtype == MR_F32 ? 32 : 64;
+  const int lds = H * W * 128;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((adaptive_avgpool_multi_fwd_kernel<T>), dim3(N, cdiv(C, cpb)), dim3(256), lds, stream,
+                                       (const T*)x, a, N, H, W, C));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_adaptive_avgpool_multi_bwd(int dtype, void* const* dys, const int* oh, const int* ow, int nscales, void* dx, int N, int H,
+                                  int W, int C, hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(nscales > 0 && nscales <= MR_POOL_MULTI_MAX && C % vec == 0, "mr_adaptive_avgpool_multi_bwd: bad arguments");
+  PoolMultiArgs a;
+  a.nsc = nscales;
+  for (int i = 0; i < nscales; ++i) {
+    MR_CHECK_ARG(dys[i] != nullptr && oh[i] > 0 && ow[i] > 0, "mr_adaptive_avgpool_multi_bwd: bad scale %d", i);
+    a.oh[i] = oh[i]; a.ow[i] = ow[i]; a.y[i] = dys[i];
+  }
+  const long long total = (long long)N * H * W * (C / vec);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((adaptive_avgpool_multi_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
+                                       a, (T*)dx, N, H, W, C));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

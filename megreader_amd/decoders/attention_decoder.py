@@ -258,19 +258,28 @@ class _DecodeLoopFn(Function):
         idx_all[0].fill_(int(blank))
         mask_all = (torch.arange(S, device=dev).view(S, 1) <= lengths.view(1, N)).to(torch.float32).contiguous()
         ldG = G.shape[1]
+        # the word fed to step s + 1 is the target of step s (teacher forcing) or its arg-max (attention_decoder.py:107-110):
+        # the GRU kernel reads it in place from targets_t / am_all; idx_all (what the backward scatters through) is filled
+        # afterwards with one copy per run of equal flags instead of one per step
+        src_rows = [idx_all[0]] + [targets_t[s] if flags[s] else am_all[s] for s in range(S - 1)]
         for s in range(S):
             call("mr_gemm_nt", dt, ptr(H_all[s]), Hd, ptr(cat.w_n), Hd, ptr(HC_all[s]), HC, ptr(cat.bias_d), 0, N, HC, Hd)
             call("mr_attn_fwd2", dt, ptr(HC_all[s]), HC, ptr(eproj), ptr(vf), ptr(enc), ptr(W_att[s]), ptr(CTX_all[s]), N, T,
                  Hd, Ep)
             call("mr_gemm_nt", dt, ptr(CTX_all[s]), Ep, ptr(ic.w_n), Ep, ptr(gic), H3, 0, 0, N, H3, Ep)
-            call("mr_gru_fwd2", dt, ptr(G), ldG, ptr(idx_all[s]), ptr(gic), ptr(HC_all[s]) + Hd * es, HC, ptr(H_all[s]),
+            call("mr_gru_fwd2", dt, ptr(G), ldG, ptr(src_rows[s]), ptr(gic), ptr(HC_all[s]) + Hd * es, HC, ptr(H_all[s]),
                  ptr(H_all[s + 1]), ptr(SAVE_all[s]), N, Hd)
             call("mr_gemm_nt", dt, ptr(H_all[s + 1]), Hd, ptr(out.w_n), Hd, ptr(logits), out.np_, ptr(out.bias_d), 0, N, C,
                  Hd)
             call("mr_nll_step_fwd", dt, ptr(logits), out.np_, ptr(targets_t[s]), 1, ptr(mask_all[s]), ptr(LP_all[s]),
                  ptr(loss), ptr(am_all[s]), N, C, 1 if s else 0, 0)
-            if s + 1 < S:   # attention_decoder.py:107-110: the next input is the target (teacher forcing) or the arg-max
-                idx_all[s + 1].copy_(targets_t[s] if flags[s] else am_all[s])
+        s = 0
+        while s < S - 1:
+            e = s
+            while e + 1 < S - 1 and bool(flags[e + 1]) == bool(flags[s]):
+                e += 1
+            idx_all[s + 1:e + 2].copy_((targets_t if flags[s] else am_all)[s:e + 1])
+            s = e + 1
         ctx.save_for_backward(G, eproj, enc, vf, H_all, HC_all, W_att, CTX_all, SAVE_all, LP_all, idx_all, mask_all,
                               targets_t)
         ctx.lin = (cat, ic, out)

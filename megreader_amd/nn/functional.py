@@ -867,7 +867,10 @@ class BiLSTMFn(Function):
         with torch.cuda.stream(side) if overlap else contextlib.nullcontext():
             # one zeroed scratch: [2,4H,I] input-weight gradients (both directions from ONE GEMM) + [2,4H] bias sums
             nfl = 2 * 4 * H * (I + 1)
-            arena = None if overlap else ZeroArena.take(dev, (nfl + 1) // 2)   # pre-zeroed: saves a fill launch
+            # pre-zeroed arena slice (saves a fill launch) ONLY when the scratch is consumed inside this call (sinks): without
+            # sinks views of it are returned as parameter gradients, and a later ZeroArena.reset() would hand the same bytes
+            # to somebody else while p.grad still points at them
+            arena = None if (overlap or not use_sinks) else ZeroArena.take(dev, (nfl + 1) // 2)
             scratch = (arena.view(torch.float32)[:nfl] if arena is not None else
                        torch.zeros((nfl,), dtype=torch.float32, device=dev))
             gw_ih = scratch[:2 * 4 * H * I].view(2, 4 * H, I)
@@ -1023,6 +1026,52 @@ def adaptive_avg_pool2d(x, output_size):
     if isinstance(output_size, int):
         output_size = (output_size, output_size)
     return AdaptiveAvgPoolFn.apply(x, tuple(output_size))
+
+
+class AdaptiveAvgPoolMultiFn(Function):
+    """Several adaptive average pools of ONE map (pyramid pooling, reference backbones/ppm.py:13-20,36-40) as one autograd
+    node: one launch reads the map once for all scales; backward, one launch writes the input gradient of all scales (autograd
+    otherwise adds four full-size gradients of the head's largest activation)."""
+
+    @staticmethod
+    def forward(ctx, x, sizes):
+        require_cuda(x)
+        dtype = get_compute_dtype()
+        xi = to_internal(x, dtype)
+        N, H, W, C = xi.shape
+        n = len(sizes)
+        ys = [torch.empty((N, oh, ow, C), dtype=dtype, device=x.device) for oh, ow in sizes]
+        oh = (ctypes.c_int * n)(*[s_[0] for s_ in sizes])
+        ow = (ctypes.c_int * n)(*[s_[1] for s_ in sizes])
+        call("mr_adaptive_avgpool_multi_fwd", dtype_code(dtype), ptr(xi), (ctypes.c_void_p * n)(*[y.data_ptr() for y in ys]),
+             oh, ow, n, N, H, W, C)
+        ctx.geom = (N, H, W, C, tuple(sizes))
+        ctx.dtype = dtype
+        return tuple(y.permute(0, 3, 1, 2) for y in ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        N, H, W, C, sizes = ctx.geom
+        dtype = ctx.dtype
+        n = len(sizes)
+        dev = next(g for g in gys if g is not None).device
+        gs = [_grad_internal(g, dtype) if g is not None else torch.zeros((N, oh, ow, C), dtype=dtype, device=dev)
+              for g, (oh, ow) in zip(gys, sizes)]
+        dx = torch.empty((N, H, W, C), dtype=dtype, device=dev)
+        oh = (ctypes.c_int * n)(*[s_[0] for s_ in sizes])
+        ow = (ctypes.c_int * n)(*[s_[1] for s_ in sizes])
+        call("mr_adaptive_avgpool_multi_bwd", dtype_code(dtype), (ctypes.c_void_p * n)(*[g.data_ptr() for g in gs]), oh, ow, n,
+             ptr(dx), N, H, W, C)
+        return dx.permute(0, 3, 1, 2), None
+
+
+def adaptive_avg_pool2d_multi(x, output_sizes):
+    """[adaptive_avg_pool2d(x, s) for s in output_sizes] in one launch each way (<= 8 scales, H * W <= 512 pixels);
+    falls back to the separate pools otherwise."""
+    sizes = [(s_, s_) if isinstance(s_, int) else tuple(s_) for s_ in output_sizes]
+    if not (1 <= len(sizes) <= 8) or x.shape[2] * x.shape[3] * 128 > 65536 or x.shape[1] % vec_of(get_compute_dtype()):
+        return tuple(adaptive_avg_pool2d(x, s_) for s_ in sizes)
+    return AdaptiveAvgPoolMultiFn.apply(x, tuple(sizes))
 
 
 class BilinearFn(Function):

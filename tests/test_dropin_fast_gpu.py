@@ -132,14 +132,13 @@ def test_graphed_train_step_equals_eager_trajectory():
     assert fast[-1] < fast[0]
 
 
-def test_graphed_train_step_is_as_fast_as_bench():
-    """bf16, N = 256 (BASELINE.json configs[1]): the drop-in step (pinned host batch in, H2D overlapped with the previous
-    replay) against bench.py's own GraphedTrainStep on a device-resident batch, and against the eager trainer step."""
+def _measure_speed():
+    """eager / graphed drop-in / bench.py-style replay step times (seconds) at bf16, N = 256 (BASELINE.json configs[1])."""
     dropin.fuse_optimizers()
     batches = _pinned_batches(256, 4)
     _, t_eager, _ = _run(False, batches, 24, torch.bfloat16)
     _, t_fast, wrapper = _run(True, batches, 24, torch.bfloat16)
-    assert wrapper.state is not None and not wrapper.disabled, "the step was never captured"
+    captured = wrapper.state is not None and not wrapper.disabled
     from megreader_amd.runtime import GraphedTrainStep
     torch.manual_seed(0)
     model = SequenceRecognitionModel(DEV).train()
@@ -154,9 +153,38 @@ def test_graphed_train_step_is_as_fast_as_bench():
         g()
     torch.cuda.synchronize()
     t_bench = (time.perf_counter() - t0) / 10
+    return {"t_eager": t_eager, "t_fast": t_fast, "t_bench": t_bench, "captured": captured}
+
+
+def test_graphed_train_step_is_as_fast_as_bench():
+    """bf16, N = 256 (BASELINE.json configs[1]): the drop-in step (pinned host batch in, H2D overlapped with the previous
+    replay) against bench.py's own GraphedTrainStep on a device-resident batch, and against the eager trainer step.
+    Measured in a FRESH process, like bench.py itself: late in a long pytest session torch hands out the copy stream from a
+    pool that earlier tests have cycled through, HIP maps it onto the hardware queue the main stream already uses, and the
+    25 MB host-to-device copy then serialises with the replay (+0.25 ms = 12.6 MB at PCIe speed; three suite runs measured
+    3.12-3.15 vs 2.86-2.91 ms, the same test alone 2.875 vs 2.833 ms)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=repo + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--measure"], cwd=repo, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    t_eager, t_fast, t_bench = r["t_eager"], r["t_fast"], r["t_bench"]
+    assert r["captured"], "the step was never captured"
     print("drop-in train_step: eager %.3f ms, graphed %.3f ms (pinned 25 MB host batch per step); bench.py-style replay on a "
           "resident batch %.3f ms" % (1e3 * t_eager, 1e3 * t_fast, 1e3 * t_bench))
     # the H2D copy of the next batch overlaps the replay of the current one: the drop-in step costs what bench.py measures
-    # + a 25 MB device-to-device copy and the loss clone (measured 2.931 vs 2.858 ms = +2.6 %; VERDICT r2 item 7 asks for 5 %)
+    # + a 25 MB device-to-device copy and the loss clone (measured 2.875 vs 2.833 ms = +1.5 %; VERDICT r2 item 7 asks for 5 %)
     assert t_fast < 1.05 * t_bench + 0.05e-3, (t_fast, t_bench)
-    assert t_fast < t_eager, (t_fast, t_eager)     # eager with a fused optimizer and pinned batches: 3.2 ms
+    assert t_fast < t_eager, (t_fast, t_eager)     # eager with a fused optimizer and pinned batches: 3.2 - 3.4 ms
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+    if "--measure" in sys.argv:
+        print(json.dumps(_measure_speed()))

@@ -839,3 +839,39 @@ def test_nt_deep_pipeline_is_bit_identical(shape):
             assert _rel_err(res[1][0], want) < _tol(torch.bfloat16, Cc * k * k)
     finally:
         lib.mr_set_nt_deep(old)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(5, 4, 16, 128), (3, 7, 9, 72), (2, 16, 32, 64)])
+def test_adaptive_avg_pool_multi_equals_separate_pools(dtype, shape):
+    """The pyramid pooling module's four pools of one map as one autograd node (F.adaptive_avg_pool2d_multi): outputs equal the
+    separate pools bit for bit (same summation order), the input gradient equals the sum of theirs (f32 accumulation, one
+    rounding instead of four roundings + three adds), and both equal torch's f64 adaptive_avg_pool2d."""
+    mr.set_compute_dtype(dtype)
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(23)
+    x0 = torch.randn(N, C, H, W, generator=g).to(DEV)
+    sizes = [1, 2, 3, 6]
+    gys = [torch.randn(N, C, s_, s_, generator=g).to(DEV) for s_ in sizes]
+    xa = x0.clone().requires_grad_(True)
+    ya = [F.adaptive_avg_pool2d(xa, s_) for s_ in sizes]
+    sum((y.float() * gy).sum() for y, gy in zip(ya, gys)).backward()
+    xb = x0.clone().requires_grad_(True)
+    yb = F.adaptive_avg_pool2d_multi(xb, sizes)
+    sum((y.float() * gy).sum() for y, gy in zip(yb, gys)).backward()
+    for u, v in zip(ya, yb):
+        assert torch.equal(u, v)
+    xr = x0.double().cpu().to(dtype).double().requires_grad_(True)      # the values the kernels see
+    yr = [TF.adaptive_avg_pool2d(xr, s_) for s_ in sizes]
+    sum((y * gy.to(dtype).double().cpu()).sum() for y, gy in zip(yr, gys)).backward()
+    tol = 1e-5 if dtype == torch.float32 else 1.6e-2
+    for v, r in zip(yb, yr):
+        assert _rel_err(v, r) < tol
+    assert _rel_err(xb.grad, xr.grad) < tol and _rel_err(xa.grad, xr.grad) < 2 * tol
+    # only some branches used (unused outputs arrive as None gradients)
+    xc = x0.clone().requires_grad_(True)
+    yc = F.adaptive_avg_pool2d_multi(xc, sizes)
+    (yc[1].float() * gys[1]).sum().backward()
+    xd = x0.clone().requires_grad_(True)
+    (F.adaptive_avg_pool2d(xd, 2).float() * gys[1]).sum().backward()
+    assert _rel_err(xc.grad, xd.grad) < tol

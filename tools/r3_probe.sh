@@ -1,8 +1,8 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r3probe; mkdir -p $O
-for v in 0 8 0 8; do
-  MEGREADER_DCN_FORK_GFLOP=$v timeout 300 python bench.py --workload db --no-cpu-baseline --no-secondary --no-kernel-timer --steps 40 --warmup 5 > $O/ab_fork$v.log 2>&1
-  echo "fork$v db $(tail -1 $O/ab_fork$v.log | grep -o '"ms_per_step": [0-9.]*') $(grep -c Traceback $O/ab_fork$v.log)"
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_res50ppm_gpu.py tests/test_dropin_fast_gpu.py tests/test_fpn_attention_gpu.py tests/test_attention_kernels_gpu.py tests/test_crnn_gpu.py -m gpu -q -s > $O/pytest.log 2>&1; tail -4 $O/pytest.log; grep "drop-in train_step" $O/pytest.log
+for w in res50ppm fpn_attention; do
+  timeout 300 python bench.py --workload $w --no-cpu-baseline --no-secondary --no-kernel-timer --steps 40 --warmup 5 > $O/b_$w.log 2>&1
+  echo "$w $(tail -1 $O/b_$w.log | grep -o '"ms_per_step": [0-9.]*')"
 done
-MEGREADER_DCN_FORK_GFLOP=8 timeout 600 python -m pytest tests/test_dcn_gpu.py tests/test_deformable_resnet_gpu.py -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
