@@ -27,3 +27,4 @@ for w in fpn_attention db; do
   timeout 400 python bench.py --workload $w --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_$w.log 2>&1; tail -1 $O/bench_$w.log > $O/bench_$w.json; cut -c1-200 $O/bench_$w.json
 done
 timeout 300 python tools/microbench_dcn.py --batch 16 2>&1 | grep -v amdgpu.ids > $O/dcn_microbench_b16.txt; tail -1 $O/dcn_microbench_b16.txt
+timeout 300 python tools/microbench_dcn.py --batch 2 2>&1 | grep -v amdgpu.ids > $O/dcn_microbench_b2.txt; tail -1 $O/dcn_microbench_b2.txt
