@@ -101,3 +101,47 @@ def test_block_parity(golden, block):
            max((v, k) for k, v in errs.items() if k != "input")[1]))
     bad = {k: v for k, v in errs.items() if v >= (1e-3 if k == "input" else 2e-3)}
     assert not bad, bad
+
+
+def test_fast_paths_equal_plain_autograd():
+    """What the benchmarked step runs and the one-step parity tests do not: from the SECOND training forward on, every conv
+    in front of a BatchNorm supplies the batch statistics from its GEMM epilogue, and with a fused optimizer every weight
+    gradient -- incl. the 27-channel offset convolutions (Cout < stored channels) and the DCN weights -- is accumulated
+    straight into the optimizer's flat buffer.  Same layers, same input: those gradients must equal the plain autograd
+    gradients of a first forward without an optimizer (float32; differences = summation order of atomics).
+    layer2 only (four deformable bottlenecks, the first strided with a downsample branch): the whole network amplifies the
+    1e-7 noise of two summation orders to O(0.3) by itself (two identical plain runs differ that much), layer2 to 7e-6."""
+    import copy
+    from megreader_amd.optim import FusedSGD
+    mr.set_compute_dtype(torch.float32)
+    torch.manual_seed(1)
+    full = deformable_resnet50(pretrained=False)
+    perturb_offset_convs(full)                            # non-zero offsets: samples off the bilinear kinks
+    plain = full.layer2.to(DEV).train()
+    fast = copy.deepcopy(plain)
+    x = torch.randn(2, 256, 24, 32, device=DEV)
+
+    def loss_of(model):
+        return (model(x).float() ** 2).mean()
+
+    loss_of(plain).backward()
+    ref = {k: p.grad.detach().clone() for k, p in plain.named_parameters() if p.grad is not None}
+    opt = FusedSGD(fast.parameters(), lr=0.0, momentum=0.0)
+    for it in range(2):                                   # 1st: learns the conv -> bn pairs; 2nd: statistics from the epilogue
+        opt.zero_grad()
+        loss_of(fast).backward()
+    producers = [m for m in fast.modules() if getattr(m, "feeds_batch_norm", False)]
+    assert len(producers) == 9, len(producers)            # conv1 / conv3 of 4 blocks + the downsample conv (conv2 is the DCN)
+    bad, worst = [], (None, 0.0)
+    for k, p in fast.named_parameters():
+        assert k in ref and p.grad is not None and p.grad.data_ptr() == p._mr_grad_sink.data_ptr(), k      # still the sink
+        scale = float(ref[k].abs().max())
+        if scale < 1e-9:
+            continue
+        err = float((p.grad - ref[k]).abs().max()) / scale
+        if err > worst[1]:
+            worst = (k, err)
+        if err > 2e-4:
+            bad.append((k, err))
+    print("fast paths vs plain autograd: worst gradient difference %.2e of max|g| (%s)" % (worst[1], worst[0]))
+    assert not bad, bad[:8]
