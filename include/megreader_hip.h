@@ -71,7 +71,8 @@ int mr_set_tn_taps(int mode);
 int mr_set_tn_taps_workspace(void* ws, long long bytes);
 int mr_set_tn_taps_group(int g);    /* tuning: 0 automatic, 1 atomics only, > 1 forced group size */
 int mr_set_tn_group(int g);         /* same for the 128x128 TN GEMM kernel (uses the same workspace) */
-int mr_set_tn_taps_fin(int on);     /* 1: group sums added into dw by a finalize launch (measured equal), 0 (default): leaders' atomics */
+int mr_set_tn_fin(int mode);        /* 128x128 TN GEMM kernel: 2 = split partials -> slabs (plain stores) + finalize launch (measured slower: opt-in); 0 (default): mr_set_tn_group */
+int mr_set_tn_taps_fin(int on);     /* 0 (default): group leaders' atomics; 1: group sums added into dw by a finalize launch; 2: no in-launch reduction, every workgroup's partial tile goes to its slab and the finalize launch sums the splits (1 and 2 measured within +-1 % of 0: opt-in) */
 int mr_set_tn_taps_w8(int on);      /* 1: 8-wave workgroup variant (one per CU, half the partial tiles) */
 /* host only: 1 when mr_conv2d_wgrad_tab (bf16, non-NULL row table) would run the all-taps kernel for this geometry
  * under the current mr_set_tn_taps setting */

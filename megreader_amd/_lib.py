@@ -207,7 +207,7 @@ def load():
 
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_set_nt_variant", "mr_force_nt_tile",
              "mr_stem_bwd_workspace", "mr_set_lstm_variant", "mr_set_nt_big", "mr_set_nt_deep", "mr_set_lstm_persist", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_set_nt_p8", "mr_set_tn_splits", "mr_set_tn_model", "mr_set_dcn_v1_bwd", "mr_set_gemm_skinny", "mr_set_dcn_fused", "mr_dcn2_ws_bytes", "mr_bn_scratch_doubles", "mr_sizeof_img_desc",
-             "mr_nt_kernel_code", "mr_set_tn_taps", "mr_tn_taps_would_run", "mr_set_tn_taps_w8", "mr_set_tn_taps_fin", "mr_set_tn_taps_workspace", "mr_set_tn_taps_group", "mr_set_tn_group", "mr_set_bn_fused", "mr_set_tn_big", "mr_set_tn_buf", "mr_sizeof_prep_job")  # entry points that take no stream and launch nothing
+             "mr_nt_kernel_code", "mr_set_tn_taps", "mr_tn_taps_would_run", "mr_set_tn_taps_w8", "mr_set_tn_taps_fin", "mr_set_tn_taps_workspace", "mr_set_tn_taps_group", "mr_set_tn_group", "mr_set_tn_fin", "mr_set_bn_fused", "mr_set_tn_big", "mr_set_tn_buf", "mr_sizeof_prep_job")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

@@ -139,6 +139,7 @@ static int g_tn_splits = 0;  // > 0: split count override of launch_tn (mr_set_t
 static int g_tn_buf = 1;  // TN kernel staging through buffer resources (mr_set_tn_buf); measured 4 % faster
 static int g_tn_taps = 1;  // all-taps wgrad kernel for 3x3 / stride 1 / pad == dilation layers (tn_taps.hip, mr_set_tn_taps)
 static int g_tn_group = 0;  // GEMM TN kernel split reduction: 0 automatic (slab groups when a workspace is registered), 1 atomics, > 1 forced
+static int g_tn_fin = 0;    // 2: split partials go to slabs with plain stores, a finalize launch sums them (mr_set_tn_fin); 0 (default): g_tn_group
 static int g_tn_big = 0;  // wide-tile TN kernels: 1 = 256x256, 2 = 128x256 (experimental, see launch_tn), else never
 
 // 0 = use the 4-wave kernels, 1 = 256x256 (8 waves), 3 = 272x256 (8 waves as 1x8); 2 (288x256, spills), 4 / 5 (160x128 with 4 /
@@ -468,7 +469,18 @@ static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
       // Measured (tools/gpu_r2_tn.sh): the publish + ticket round costs ~8 us of latency, the atomics it removes scale with
       // the split count -- conv1 wgrad (5 tiles x ~100 splits) 92.6 -> 80.1 us, but conv6 wgrad (16 splits... of 64 tiles)
       // 44.2 -> 46.8 and the LSTM / Linear weight gradients (4 splits) +-2 us: automatic = only from 16 splits up.
-      if (g_tn_group != 1 && splits > 1 && (g_tn_group > 1 || splits >= 16)) {
+      if (g_tn_fin == 2 && splits > 1) {   // direct slabs + finalize launch (TnArgs.fin)
+        void* ws = nullptr;
+        long long ws_bytes = 0;
+        taps_get_workspace(&ws, &ws_bytes);
+        const long long need = TN_TICKETS * 4ll + (long long)tiles * splits * 65536;
+        if (ws && need <= ws_bytes && need < (1ll << 31)) {
+          a.fin = 2;
+          a.grp = 1;
+          a.ws = ws;
+        }
+      }
+      if (a.fin != 2 && g_tn_group != 1 && splits > 1 && (g_tn_group > 1 || splits >= 16)) {
         void* ws = nullptr;
         long long ws_bytes = 0;
         taps_get_workspace(&ws, &ws_bytes);
@@ -499,6 +511,12 @@ static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
       else
         hipLaunchKernelGGL((igemm_tn_glds_kernel<BMODE, false>), dim3(tiles * splits), dim3(256), 0, stream, a, g, z);
       MR_CHECK_LAUNCH();
+      if (a.fin == 2) {
+        hipLaunchKernelGGL(tn_finalize_kernel, dim3(tiles * 16), dim3(256), 0, stream,
+                           (const f32x4*)((const char*)a.ws + TN_TICKETS * 4), a.C, tiles, cdiv(a.NB, 128), splits, a.NA, a.NB,
+                           a.ldc, a.row_perm_h);
+        MR_CHECK_LAUNCH();
+      }
       return MR_OK;
     }
   }
@@ -607,6 +625,12 @@ int mr_set_tn_taps_workspace(void* ws, long long bytes) {
 int mr_set_tn_taps_group(int g) { return taps_set_group(g); }
 // same for the 128x128 TN GEMM kernel (conv wgrad of the other geometries, Linear / LSTM weight gradients)
 int mr_set_tn_group(int g) { const int old = g_tn_group; if (g >= 0) g_tn_group = g; return old; }
+// 2 = the 128x128 TN GEMM kernel writes its split partials to slabs with plain stores and a finalize launch adds their sum into C
+// (the scheme that is the all-taps kernel's default, mr_set_tn_taps_fin(2)); 0 (default) = in-launch group reduction / atomics
+// (mr_set_tn_group).  Measured SLOWER here, unlike for the all-taps kernel: these launches are 25-40 us with 4-16 splits, and a
+// second launch per layer costs more than their atomics (Res50-PPM 13.26 -> 13.70 ms, FPN-attention 10.00 -> 10.47, DB 11.26 ->
+// 11.96, CRNN equal).  Returns the old value.
+int mr_set_tn_fin(int mode) { const int old = g_tn_fin; if (mode == 0 || mode == 2) g_tn_fin = mode; return old; }
 
 // 1 (opt-in, measured equal) = the all-taps kernel's group sums are added into dw by a second, tiny launch instead of the leaders' atomics
 int mr_set_tn_taps_fin(int on) { return taps_set_fin(on); }

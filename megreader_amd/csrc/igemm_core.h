@@ -1110,6 +1110,9 @@ struct TnArgs {
   // ws = [TN_TICKETS ints (zero between launches)][gridDim.x slabs x 65536 B]; grp <= 1: atomics only.
   int grp;
   void* ws;
+  // fin == 2: no in-launch reduction -- every workgroup stores its 128 x 128 partial tile to its own 64 KB slab with plain
+  // stores and tn_finalize_kernel (a second launch) adds the sum over the splits into C.  0: groups / atomics as above.
+  int fin = 0;
 };
 constexpr int TN_TICKETS = 4096;
 
@@ -1630,6 +1633,16 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
     }
   }
 
+  if (a.fin == 2) {   // partial tile -> own slab (register order: element (k, tid) = acc tile k of thread tid); tn_finalize_kernel sums
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((char*)a.ws + TN_TICKETS * 4, (short)0, 0x7fffffff, 0x00020000);
+    const int so = vb * 65536;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, tid * 16, so + (i * 4 + j) * 4096, 0);
+    return;
+  }
   bool exclusive = false;   // this workgroup holds the tile's complete sum: plain read-modify-write instead of atomics
   if (a.grp > 1 && !(ABL & 4)) {
     const int nsplits = total / ntiles;
@@ -1697,6 +1710,34 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
         else atomicAdd(dst, acc[i][j][q]);
       }
     }
+}
+
+// C += sum over the splits of a tile's slabs (TnArgs.fin == 2).  One workgroup per (tile, accumulator tile k = i*4 + j); thread tid
+// of the slab order = thread tid of the producing workgroup (wave = tid >> 6: wa = wave & 1, wb = wave >> 1), so its f32x4 is
+// rows lg*4 .. +3 of column l15 of the 16 x 16 block (i, j) of the wave's 64 x 64 quadrant.
+static __global__ __launch_bounds__(256) void tn_finalize_kernel(const f32x4* __restrict__ slabs, float* __restrict__ C, int ntiles,
+                                                                int tiles_b, int nsplits, int NA, int NB, int ldc,
+                                                                int row_perm_h) {
+  const int tile = blockIdx.x >> 4, k = blockIdx.x & 15;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int wa = wave & 1, wb = wave >> 1;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  for (int sp = 0; sp < nsplits; ++sp) sum += slabs[((long long)sp * ntiles + tile) * (16 * 256) + k * 256 + tid];
+  const int tile_b = tile % tiles_b, tile_a = tile / tiles_b;
+  const int i = k >> 2, j = k & 3;
+  const int col = tile_b * 128 + wb * 64 + j * 16 + l15;
+  if (col >= NB) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int row = tile_a * 128 + wa * 64 + i * 16 + lg * 4 + q;
+    if (row >= NA) continue;
+    if (row_perm_h > 0) {
+      const int h4 = 4 * row_perm_h;
+      const int blk = row / h4, rin = row - blk * h4;
+      row = blk * h4 + (rin & 3) * row_perm_h + (rin >> 2);
+    }
+    C[(long long)row * ldc + col] += sum[q];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

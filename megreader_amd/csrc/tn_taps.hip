@@ -294,7 +294,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void igemm_tn_taps_kern
         if (row < a.NA) atomicAdd(a.colsum + row, accs[i][q]);
       }
   }
-  if (a.grp > 1) {
+  if (a.grp > 1 || a.fin == 2) {
     // In-launch reduction over a group of splits (no spinning: correct for any residency / dispatch order).  Slabs are in
     // "register order" -- element (k, tid) of a slab is acc tile k of thread tid -- so writer and reader use the same
     // coalesced 16-byte accesses.  Publish = sc1 (write-through) slab stores, wait, barrier, then a relaxed agent-scope
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void igemm_tn_taps_kern
     // workgroup: measured no faster than the atomics it replaced).
     const int nsplits = total / ntiles;
     const int g0 = (split / a.grp) * a.grp;
-    const int gsize = min(a.grp, nsplits - g0);
+    const int gsize = a.fin == 2 ? 2 : min(a.grp, nsplits - g0);
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((char*)a.ws + TAPS_TICKETS * 4, (short)0, 0x7fffffff,
                                                        0x00020000);
     if (gsize > 1) {
@@ -317,6 +317,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void igemm_tn_taps_kern
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][t]), rs, tid * 16,
                                                    so + (i * 9 + t) * 4096, 16);
       }
+      // fin == 2: no in-launch reduction at all -- the partial tile stays in this workgroup's slab (no ticket, no wait) and
+      // taps_finalize_kernel, the next launch, sums the splits of a tile into dw
+      if (a.fin == 2) return;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       volatile __attribute__((address_space(3))) int* bc = (volatile __attribute__((address_space(3))) int*)(lds_byte_t*)(uintptr_t)0u;
@@ -463,10 +466,20 @@ int taps_set_group(int g) { const int old = g_taps_grp; if (g >= 0) g_taps_grp =
 static int g_taps_w8 = 0;
 int taps_set_w8(int on) { const int old = g_taps_w8; if (on == 0 || on == 1) g_taps_w8 = on; return old; }
 
-// 1: finalize launch instead of the group leaders' atomics (TapArgs.fin).  Opt-in: measured equal (conv2..5 wgrad 445 vs 445 us
-// per step at group 4, 436 at group 2: the second launch + its 19 MB of slab reads cost what the leaders' atomics cost)
+// How the split partials of a tile reach dw (mr_set_tn_taps_fin):
+//   0 (default): groups of splits reduce in the launch (slabs + tickets), the group leaders add into dw with f32 atomics;
+//   1: same groups, but the leaders leave the group sums in their slabs and a finalize launch adds them into dw -- measured
+//      equal to 0 (conv2..5 wgrad 445 vs 445 us per step at group 4: the second launch + 19 MB of slab reads cost what the
+//      leaders' atomics cost);
+//   2: no in-launch reduction at all -- every workgroup stores its partial tile to its own slab (no tickets, no waits) and the
+//      finalize launch sums ALL the splits of a tile.  The kernel itself gets 5 % shorter (109 -> 104 us per launch on the CRNN
+//      layers = 0.34 of peak), the step does not follow: CRNN 2.835 -> 2.81 ms, FPN-attention 10.12 -> 10.00 ms, but Res50-PPM
+//      12.90 -> 13.03 ms (16 more launches per step reading 4-8 split slabs each).  Opt-in.
+//   (A first version of mode 2 with its own copy of the slab stores pushed this 254-VGPR kernel into scratch -- 180 bytes per
+//   lane -- and slowed modes 0 / 1 from 109 to 155 us per launch; the modes share one store sequence now, resource usage is
+//   what it was.)
 static int g_taps_fin = 0;
-int taps_set_fin(int on) { const int old = g_taps_fin; if (on == 0 || on == 1) g_taps_fin = on; return old; }
+int taps_set_fin(int on) { const int old = g_taps_fin; if (on >= 0 && on <= 2) g_taps_fin = on; return old; }
 
 #ifdef MR_ABLATION
 static int g_taps_abl = 0;
@@ -521,7 +534,14 @@ int launch_tn_taps(const TapsProblem& p, int splits_override, hipStream_t stream
         (long long)tiles * cdiv(splits, want) <= TAPS_TICKETS)
       a.grp = want;
   }
-  a.fin = (a.grp > 1 && g_taps_fin) ? 1 : 0;
+  a.fin = (a.grp > 1 && g_taps_fin == 1) ? 1 : 0;
+  if (g_taps_fin == 2 && splits > 1 && !w8) {   // direct slabs + finalize launch (see the kernel's fin == 2 branch)
+    const long long need = TAPS_TICKETS * 4ll + (long long)tiles * splits * TAPS_SLAB_BYTES;
+    if (g_taps_ws && need <= g_taps_ws_bytes && need < (1ll << 31)) {
+      a.fin = 2;
+      a.grp = 1;
+    }
+  }
   const int lds = w8 ? 147456 : (4 + 4) * 64 * 128 + 4096;
   const int threads = w8 ? 512 : 256;
   static bool attr_set[2] = {false, false};
@@ -554,8 +574,8 @@ int launch_tn_taps(const TapsProblem& p, int splits_override, hipStream_t stream
   MR_CHECK_LAUNCH();
   if (a.fin) {
     hipLaunchKernelGGL(taps_finalize_kernel, dim3(tiles * 36), dim3(256), 0, stream,
-                       (const f32x4*)((const char*)a.ws + TAPS_TICKETS * 4), a.C, tiles, p.Cin / 64, splits, a.grp, a.NA,
-                       a.Cg, a.ldc);
+                       (const f32x4*)((const char*)a.ws + TAPS_TICKETS * 4), a.C, tiles, p.Cin / 64, splits,
+                       a.fin == 2 ? 1 : a.grp, a.NA, a.Cg, a.ldc);
     MR_CHECK_LAUNCH();
   }
   return MR_OK;

@@ -599,16 +599,20 @@ def test_gemm_tn_row_count_not_a_vector_multiple(dtype):
     assert _rel_err(cs[:NA], A[:, :NA].double().cpu().sum(0) + 5.0) < 2e-5
 
 
-@pytest.mark.parametrize("group", [0, 1, 2, 3, 4, 16])
+@pytest.mark.parametrize("group", [-2, 0, 1, 2, 3, 4, 16])
 @pytest.mark.parametrize("P,NA,NB,splits", [(8448, 256, 512, 4), (8448, 256, 512, 7), (4096, 40, 136, 3), (33000, 128, 128, 16)])
 def test_gemm_tn_split_group_reduction_exact(group, P, NA, NB, splits):
     """In-launch reduction of the TN GEMM kernel's split partials (TnArgs.grp: sc1 slabs + ticket, the last arriver sums; plain
     read-modify-write when one group holds all the splits, atomics otherwise).  Integer operands: every partial sum is
     exact, so C (accumulate semantics, starts at 1) and the column sums must EQUAL the float64 result for any grouping,
-    and a second launch (tickets reset by the first) must add the same amount again."""
+    and a second launch (tickets reset by the first) must add the same amount again.
+    group == -2: mr_set_tn_fin(2) -- every workgroup's partial tile goes to its slab with plain stores and a finalize launch
+    adds the sum over the splits into C (opt-in); the other values run the in-launch group reduction (fin 0, the default)."""
     from megreader_amd import _lib
     lib = _lib.load()
     _lib.ensure_tn_workspace(DEV)
+    oldf = lib.mr_set_tn_fin(2 if group == -2 else 0)
+    group = max(group, 0)
     g = torch.Generator().manual_seed(P + NA + group)
     A = torch.randint(-3, 4, (P, NA), generator=g).float()
     B = torch.randint(-3, 4, (P, NB), generator=g).float()
@@ -625,6 +629,7 @@ def test_gemm_tn_split_group_reduction_exact(group, P, NA, NB, splits):
     finally:
         lib.mr_set_tn_group(oldg)
         lib.mr_set_tn_splits(olds)
+        lib.mr_set_tn_fin(oldf)
     ref = 1 + 2 * (A.double().t() @ B.double())
     assert torch.equal(C.cpu().double(), ref), float((C.cpu().double() - ref).abs().max())
     assert torch.equal(cs.cpu().double(), 2 * A.double().sum(0))
@@ -645,8 +650,9 @@ def test_conv_wgrad_gemm_kernel_group_reduction_exact():
         ref = wref.grad.permute(0, 2, 3, 1)
         assert lib.mr_tn_taps_would_run(N, H, W, C, C, K, K, k, k, st, st, p, p, 1, 1, Ho, Wo) == 0
         xd, dyd = x.to(DEV, torch.bfloat16), dy.to(DEV, torch.bfloat16)
-        for group in (0, 1, 2):
-            old = lib.mr_set_tn_group(group)
+        for group in (-2, 0, 1, 2):      # -2: slabs + finalize launch (mr_set_tn_fin(2), opt-in); else in-launch groups
+            oldf = lib.mr_set_tn_fin(2 if group == -2 else 0)
+            old = lib.mr_set_tn_group(max(group, 0))
             try:
                 gw = torch.zeros(K, k, k, C, device=DEV)
                 gb = torch.zeros(K, device=DEV)
@@ -656,6 +662,7 @@ def test_conv_wgrad_gemm_kernel_group_reduction_exact():
                 torch.cuda.synchronize()
             finally:
                 lib.mr_set_tn_group(old)
+                lib.mr_set_tn_fin(oldf)
             assert torch.equal(gw.cpu().double(), ref), (group, float((gw.cpu().double() - ref).abs().max()))
             assert torch.equal(gb.cpu().double(), dy.double().sum((0, 1, 2)))
 

@@ -81,14 +81,16 @@ def test_taps_split_boundaries(splits):
     _run(7, 4, 33, 64, 64, 1, splits=splits)
 
 
-@pytest.mark.parametrize("fin", [1, 0])
+@pytest.mark.parametrize("fin", [2, 1, 0])
 @pytest.mark.parametrize("group", [1, 2, 3, 4, 8, 64])
 @pytest.mark.parametrize("splits", [2, 5, 8])
 def test_taps_group_reduction(group, splits, fin):
     """In-launch reduction of the split partials through slabs + tickets (TapArgs.grp): ragged last groups, groups larger
     than the split count, and back-to-back launches (the second launch of _run re-uses the tickets the first one reset)."""
     _lib.load().mr_set_tn_taps_group(group)
-    old = _lib.load().mr_set_tn_taps_fin(fin)   # 1: finalize launch adds the group sums into dw, 0: the leaders' atomics
+    # 2: every workgroup leaves its partial in its own slab, the finalize launch sums the splits (no tickets; `group` unused);
+    # 1: finalize launch adds the group sums into dw; 0: the leaders' atomics
+    old = _lib.load().mr_set_tn_taps_fin(fin)
     try:
         _run(9, 4, 33, 128, 128, 1, splits=splits)
     finally:
