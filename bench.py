@@ -128,6 +128,31 @@ def cpu_baseline(batch_size=64, budget_s=20.0):
                       (steps, batch_size, torch.__version__, threads, avail, dt)}
 
 
+def quiet_native_stdout():
+    """Ranks other than 0 print nothing of their own, but RCCL writes a version banner through C stdio into THEIR stdout, which
+    torch.distributed.run forwards to the launcher's: send file descriptor 1 of those ranks to stderr for the whole run."""
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
+
+def emit_last_line(line):
+    """Print the result as the LAST line of stdout.  Native libraries (RCCL's version banner) hold text in the C stdio buffer
+    that libc flushes at exit, i.e. after everything Python printed: flush it first, print the JSON line, then point file
+    descriptor 1 at /dev/null so that nothing flushed later can follow it."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001 - no libc handle: the dup2 below still keeps later output away
+        pass
+    sys.stdout.flush()
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+    os.close(devnull)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,6 +203,8 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rank != 0:
+            quiet_native_stdout()
         dist.init_process_group(backend="nccl", init_method="env://")
     if args.gpus != world:
         print("warning: --gpus %d but WORLD_SIZE %d (using WORLD_SIZE)" % (args.gpus, world), file=sys.stderr)
@@ -471,10 +498,8 @@ def main():
             sec.pop(k, None)
         out["secondary"] = sec
     if distributed:
-        dist.destroy_process_group()   # RCCL prints its version banner here: keep the JSON line the LAST line
-    if out is not None:
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        dist.destroy_process_group()
+    emit_last_line(json.dumps(out) if out is not None else None)
 
 
 if __name__ == "__main__":

@@ -264,3 +264,16 @@ def test_kernel_choice_host_logic():
         assert run(256, 4, 33, 512, 512, 512, 512, 3, 3, 1, 1, 1, 1, 1, 1, 4, 33) == 0
     finally:
         lib.mr_set_tn_taps(old)
+
+
+def test_bench_json_is_the_last_stdout_line_even_with_native_stdio_output():
+    """bench.py's contract is ONE JSON line on stdout; RCCL prints a version banner through C stdio, which libc flushes at
+    process exit -- after everything Python printed.  emit_last_line flushes the native buffer first and closes stdout behind
+    the JSON line: text a native library writes before or after must not follow it."""
+    code = ("import ctypes, sys; sys.path.insert(0, %r); import bench; libc = ctypes.CDLL(None); "
+            "libc.printf(b'banner (buffered in C stdio)\\n'); print('python line'); "
+            "bench.emit_last_line('{\"ok\": 1}'); libc.printf(b'late banner\\n'); print('late python line')") % REPO
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    lines = out.stdout.strip().splitlines()
+    assert lines[-1] == '{"ok": 1}' and "banner (buffered in C stdio)" in lines and "late banner" not in lines, lines
