@@ -30,11 +30,12 @@ def _engine_callback(fn):
 def plan_buckets(sizes, target):
     """Bucket plan over REVERSED registration order (~ the order backward produces gradients): lists of indices into
     `sizes`.  A bucket closes when it reaches `target` elements, or BEFORE a parameter that would push it more than 25 %
-    over (one 2.4 M-element conv weight must not drag 1.5 M elements of LSTM gradients with it); a tail bucket under 10 %
-    of the target is merged into its predecessor (not worth a collective of its own)."""
+    over (one 2.4 M-element conv weight must not drag 1.5 M elements of LSTM gradients with it) -- unless the bucket is still
+    under 10 % of the target, which is not worth a collective of its own; for the same reason a tail bucket under 10 % of the
+    target is merged into its predecessor."""
     buckets, cur, cur_n = [], [], 0
     for i in reversed(range(len(sizes))):
-        if cur and cur_n + sizes[i] > 1.25 * target:
+        if cur and cur_n >= 0.1 * target and cur_n + sizes[i] > 1.25 * target:
             buckets.append(cur)
             cur, cur_n = [], 0
         cur.append(i)

@@ -370,3 +370,27 @@ def test_graphed_path_grad_sync_two_ranks():
         assert scale == 0.5 and torch.equal(torch.from_numpy(a), a_sum) and torch.equal(torch.from_numpy(b), b_sum)
         (a, b), scale = res[rank][False]
         assert scale is None and torch.equal(torch.from_numpy(a), a_sum / 2) and torch.equal(torch.from_numpy(b), b_sum / 2)
+
+
+def test_bucket_planner_properties():
+    """plan_buckets on random parameter lists (hypothesis): the buckets partition the parameters in reverse registration order,
+    none exceeds max(1.25 x target, its largest member) by more than two under-10 % leftovers, and none of several buckets is
+    under 10 % of the target (not worth a collective of its own)."""
+    from hypothesis import given, settings, strategies as st
+    from megreader_amd.apex.parallel import plan_buckets
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.lists(st.integers(min_value=1, max_value=3_000_000), min_size=1, max_size=60), st.integers(1, 8))
+    def check(sizes, nb):
+        total = sum(sizes)
+        target = max(1, -(-total // nb))
+        plan = plan_buckets(sizes, target)
+        flat = [i for b in plan for i in b]
+        assert flat == list(reversed(range(len(sizes))))
+        elems = [sum(sizes[i] for i in b) for b in plan]
+        for b, e in zip(plan, elems):
+            biggest = max(sizes[i] for i in b)
+            # a bucket is at most 1.25 targets or its largest member, plus an under-10 % head and an under-10 % merged tail
+            assert e <= max(1.25 * target, biggest) + 0.2 * target + 1, (sizes, target, elems)
+        assert all(e >= 0.1 * target for e in elems) or len(plan) == 1, (sizes, target, elems)
+    check()
