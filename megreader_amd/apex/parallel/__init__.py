@@ -209,7 +209,34 @@ class DistributedDataParallel(nn.Module):
         return self.module(*inputs, **kwargs)
 
 
-class SyncBatchNorm(nn.SyncBatchNorm):
-    """Only reachable when the reference's config.sync_bn is switched on (backbones/resnet.py:26-30; default
-    False, config.py:14).  Falls back to torch's SyncBatchNorm over the same RCCL process group."""
-    pass
+from ...nn.modules import BatchNorm2d as _HipBatchNorm2d  # noqa: E402
+
+
+class SyncBatchNorm(_HipBatchNorm2d):
+    """apex.parallel.SyncBatchNorm as the reference constructs it when config.sync_bn is on (backbones/resnet.py:26-30;
+    default False, config.py:14): BatchNorm2d whose training-mode statistics are taken over the batches of every rank of
+    `process_group`.  Same parameters / buffers / state_dict keys as nn.BatchNorm2d; eval mode and single-process runs are
+    the plain HIP BatchNorm2d.  Kernels and the two small all-reduces: nn/functional.py SyncBatchNormFn."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None,
+                 channel_last=False, fuse_relu=False):
+        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine,
+                         track_running_stats=track_running_stats, fuse_relu=fuse_relu)
+        self.process_group = process_group
+        self.all_reduce = None       # test hook: in-place SUM over the (virtual) ranks of a 1-D f64 tensor
+
+    def forward(self, x, residual=None):
+        from ...nn import functional as F
+        multi = self.all_reduce is not None or (dist.is_available() and dist.is_initialized() and
+                                                dist.get_world_size(self.process_group) > 1)
+        if not self.training or not multi:
+            return super().forward(x, residual)
+        reduce_fn = self.all_reduce
+        if reduce_fn is None:
+            group = self.process_group
+
+            def reduce_fn(t):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        momentum = 0.1 if self.momentum is None else self.momentum
+        return F.sync_batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, momentum, self.eps,
+                                 self.fuse_relu, residual, self.num_batches_tracked, reduce_fn)

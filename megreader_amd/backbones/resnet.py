@@ -24,7 +24,12 @@ def constant_init(module, constant, bias=0):
 
 
 def bn(*args, **kwargs):
-    # reference resnet.py:26-30 switches to apex SyncBatchNorm when config.sync_bn (default False, config.py:14)
+    # reference resnet.py:26-30: apex.parallel.SyncBatchNorm when config.sync_bn (default False, config.py:14).  The
+    import sys
+    _ref_config = sys.modules.get("config")      # only if the reference's own module is already loaded (train.py imports it)
+    if _ref_config is not None and getattr(_ref_config, "sync_bn", False) is True:
+        from ..apex.parallel import SyncBatchNorm
+        return SyncBatchNorm(*args, **kwargs)
     return BatchNorm2d(*args, **kwargs)
 
 

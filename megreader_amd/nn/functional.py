@@ -503,6 +503,100 @@ def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, ep
 
 
 # --------------------------------------------------------------------------------------------------
+# Synchronised BatchNorm (reference backbones/resnet.py:26-30: apex.parallel.SyncBatchNorm when config.sync_bn; default off).
+# Statistics over the batches of ALL ranks: the local per-channel sums (mr_bn_stats) are all-reduced (2C + 1 doubles), the
+# normalisation runs on the same apply kernel as the eval path (mr_bn_fwd_eval with the global mean / variance).  Backward: the
+# local kernels (mr_bn_bwd) give dx for LOCAL statistics; the global correction is affine in x per channel,
+#     dx = dx_local + alpha_c + beta_c * x,   alpha / beta from the differences between the local and the all-reduced sums,
+# so it costs one all-reduce of 2C floats and one fused elementwise pass.  dgamma / dbeta stay local sums, like apex's (the
+# data-parallel wrapper averages parameter gradients afterwards).
+# --------------------------------------------------------------------------------------------------
+class SyncBatchNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual, num_batches_tracked,
+                all_reduce):
+        require_cuda(x, gamma, beta)
+        dtype = get_compute_dtype()
+        dt = dtype_code(dtype)
+        xi = to_internal(x, dtype)
+        N, H, W, C = xi.shape
+        P = N * H * W
+        dev = x.device
+        ri = to_internal(residual, dtype) if residual is not None else None
+        sums = torch.zeros((load().mr_bn_scratch_doubles(C),), dtype=torch.float64, device=dev)
+        call("mr_bn_stats", dt, ptr(xi), ptr(sums), P, C)
+        packed = torch.cat([sums[:16 * C].view(8, 2 * C).sum(dim=0), torch.full((1,), float(P), dtype=torch.float64,
+                                                                                 device=dev)])
+        all_reduce(packed)                                  # sum over the ranks: [sum x | sum x^2 | count]
+        total = packed[2 * C]
+        mean64 = packed[:C] / total
+        var64 = (packed[C:2 * C] / total - mean64 * mean64).clamp_(min=0.0)
+        mean_g, var_g = mean64.float(), var64.float()
+        if running_mean is not None:
+            with torch.no_grad():
+                unbiased = var64 * (total / (total - 1.0).clamp(min=1.0))
+                running_mean.mul_(1.0 - momentum).add_(mean_g, alpha=momentum)
+                running_var.mul_(1.0 - momentum).add_(unbiased.float(), alpha=momentum)
+                if num_batches_tracked is not None:
+                    num_batches_tracked.add_(1)
+        y = torch.empty_like(xi)
+        mean = torch.empty((C,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((C,), dtype=torch.float32, device=dev)
+        call("mr_bn_fwd_eval", dt, ptr(xi), ptr(y), ptr(gamma), ptr(beta), ptr(mean_g), ptr(var_g), ptr(mean), ptr(rstd),
+             ptr(ri), int(relu), P, C, float(eps))
+        ctx.save_for_backward(xi, y if relu else None, gamma, mean, rstd)
+        ctx.total = total
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        ctx.dtype = dtype
+        ctx.all_reduce = all_reduce
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xi, y, gamma, mean, rstd = ctx.saved_tensors
+        dtype = ctx.dtype
+        dt = dtype_code(dtype)
+        g = _grad_internal(gy, dtype)
+        N, H, W, C = xi.shape
+        P = N * H * W
+        dev = g.device
+        dx = torch.empty_like(xi)
+        dres = torch.empty_like(xi) if ctx.has_res else None
+        sums = torch.zeros((load().mr_bn_scratch_doubles(C),), dtype=torch.float64, device=dev)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+        call("mr_bn_bwd", dt, ptr(g), ptr(xi), ptr(y), ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(dx), ptr(dres),
+             ptr(dgamma), ptr(dbeta), int(ctx.relu) | 4, P, C)
+        # dx_local = k (g' - s1/P - xhat s2/P), k = gamma rstd, s1 = dbeta, s2 = dgamma (local sums); the global version
+        # replaces s/P by S/P_total: dx = dx_local + k (d1 + xhat d2) with d = s/P - S/P_total, affine in x per channel
+        glob = torch.cat([dbeta, dgamma]).double()
+        ctx.all_reduce(glob)
+        total = ctx.total
+        d1 = dbeta.double() / P - glob[:C] / total
+        d2 = dgamma.double() / P - glob[C:] / total
+        k = gamma.detach().double() * rstd.double()
+        slope = (k * d2 * rstd.double())
+        alpha = (k * d1 - slope * mean.double()).to(dtype)
+        dx = torch.addcmul(dx + alpha, xi, slope.to(dtype))
+        gres = dres.permute(0, 3, 1, 2) if ctx.has_res else None
+        return dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, gres, None, None
+
+
+def sync_batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, relu=False, residual=None,
+                    num_batches_tracked=None, all_reduce=None):
+    """Training-mode BatchNorm with statistics over all ranks.  `all_reduce(t)`: in-place SUM over the ranks of a 1-D f64
+    tensor (default: torch.distributed.all_reduce on the default group)."""
+    if all_reduce is None:
+        import torch.distributed as dist
+
+        def all_reduce(t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return SyncBatchNormFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, bool(relu), residual,
+                                 num_batches_tracked, all_reduce)
+
+
+# --------------------------------------------------------------------------------------------------
 # Backbone stem: Conv2d(Cin->64, 3x3, s1, p1) + ReLU + MaxPool2d(2,2) in one kernel each way.
 # reference: cnn.conv0 / relu0 / pooling0 at backbones/crnn.py:17-19,48-55
 # --------------------------------------------------------------------------------------------------

@@ -882,3 +882,66 @@ def test_adaptive_avg_pool_multi_equals_separate_pools(dtype, shape):
     xd = x0.clone().requires_grad_(True)
     (F.adaptive_avg_pool2d(xd, 2).float() * gys[1]).sum().backward()
     assert _rel_err(xc.grad, xd.grad) < tol
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_sync_batch_norm_two_virtual_ranks_equal_full_batch(relu):
+    """apex.parallel.SyncBatchNorm (reference backbones/resnet.py:26-30 under config.sync_bn) on the HIP kernels: each of two
+    virtual ranks holds half of a batch; the all-reduce hook adds the OTHER rank's contribution, computed independently in
+    float64 torch from the data (forward: sum x, sum x^2, count; backward: sum g', sum g' xhat).  Every rank's output and input
+    gradient must equal its half of plain BatchNorm on the full batch, the local dgamma / dbeta must add up to the full-batch
+    ones, and the running statistics must be the full batch's."""
+    from megreader_amd.apex.parallel import SyncBatchNorm
+    mr.set_compute_dtype(torch.float32)
+    torch.manual_seed(9)
+    C, H, W = 64, 6, 10
+    x = (torch.randn(8, C, H, W, device=DEV) * 1.5 + 0.3)
+    gy = torch.randn(8, C, H, W, device=DEV)
+    w0, b0 = (torch.rand(C, device=DEV) + 0.5), torch.randn(C, device=DEV) * 0.3
+    # full-batch reference on the plain HIP BatchNorm
+    xr = x.clone().requires_grad_(True)
+    gam, bet = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    yr = F.batch_norm(xr, gam, bet, rm, rv, True, 0.1, 1e-5, relu=relu)
+    yr.backward(gy)
+    # what each rank contributes to the two all-reduces, from the data in float64
+    xd, gd = x.double(), gy.double()
+    mean = xd.mean(dim=(0, 2, 3))
+    var = xd.var(dim=(0, 2, 3), unbiased=False)
+    xhat = (xd - mean.view(1, C, 1, 1)) / torch.sqrt(var.view(1, C, 1, 1) + 1e-5)
+    gmask = gd * (yr.detach().double() > 0) if relu else gd
+    halves = [slice(0, 3), slice(3, 8)]                       # uneven split: the count travels with the sums
+    fwd_c = [torch.cat([xd[h].sum(dim=(0, 2, 3)), (xd[h] ** 2).sum(dim=(0, 2, 3)),
+                        torch.tensor([float(xd[h].shape[0] * H * W)], dtype=torch.float64, device=DEV)]) for h in halves]
+    bwd_c = [torch.cat([gmask[h].sum(dim=(0, 2, 3)), (gmask[h] * xhat[h]).sum(dim=(0, 2, 3))]) for h in halves]
+    dg_sum, db_sum = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    for r, h in enumerate(halves):
+        other = 1 - r
+        calls = []
+
+        def fake_all_reduce(t, other=other, calls=calls):
+            calls.append(t.numel())
+            t.add_(fwd_c[other] if t.numel() == 2 * C + 1 else bwd_c[other])
+        bn = SyncBatchNorm(C, fuse_relu=relu).to(DEV).train()
+        with torch.no_grad():
+            bn.weight.copy_(w0)
+            bn.bias.copy_(b0)
+        bn.all_reduce = fake_all_reduce
+        xs = x[h].clone().requires_grad_(True)
+        ys = bn(xs)
+        ys.backward(gy[h])
+        assert calls == [2 * C + 1, 2 * C]
+        assert _rel_err(ys, yr[h]) < 2e-5, (r, _rel_err(ys, yr[h]))
+        assert _rel_err(xs.grad, xr.grad[h]) < 5e-5, (r, _rel_err(xs.grad, xr.grad[h]))
+        assert _rel_err(bn.running_mean, rm) < 1e-5 and _rel_err(bn.running_var, rv) < 1e-5
+        assert int(bn.num_batches_tracked) == 1
+        dg_sum += bn.weight.grad
+        db_sum += bn.bias.grad
+    assert _rel_err(dg_sum, gam.grad) < 2e-5 and _rel_err(db_sum, bet.grad) < 2e-5
+    # eval mode and a single process: the plain BatchNorm2d path
+    bn.all_reduce = None
+    bn.eval()
+    ye = bn(x)
+    want = (x - bn.running_mean.view(1, C, 1, 1)) / torch.sqrt(bn.running_var.view(1, C, 1, 1) + 1e-5) * w0.view(1, C, 1, 1) \
+        + b0.view(1, C, 1, 1)
+    assert _rel_err(ye, torch.relu(want) if relu else want) < 2e-5
