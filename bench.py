@@ -361,7 +361,7 @@ def main():
                     graphed = None
             if graphed is None:
                 net = model
-                sync = data_parallel_grad_sync(opt) if distributed else None
+                sync = data_parallel_grad_sync(opt, fold=True) if distributed else None
                 graphed = GraphedTrainStep(loss_fn, opt, [img, lab, ln], warmup=max(2, warmup if distributed else 2),
                                            grad_sync=sync)
                 if distributed:

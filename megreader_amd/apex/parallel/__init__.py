@@ -86,6 +86,8 @@ class DistributedDataParallel(nn.Module):
         self._fires = {}
         self._pending = []  # (bucket index, flat tensor, staged?, work handle)
         self._callback_queued = False
+        self._folded = None          # the fused optimizer that applies 1 / world (fold_average_into), else None
+        self._fold_seen_step = None
         for p in self._params:
             hook = self._make_hook()
             p.register_post_accumulate_grad_hook(hook)
@@ -101,15 +103,22 @@ class DistributedDataParallel(nn.Module):
         self._uses[id(param)] = int(uses)
 
     def fold_average_into(self, optimizer):
-        """Let a fused optimizer (megreader_amd.optim) apply the 1 / world_size of the gradient average inside its update
-        kernel: the shim then only sums (no `flat.mul_` pass over the reduced buffers).  Every parameter of this module must
-        be owned by `optimizer`."""
+        """OPT-IN: let a fused optimizer (megreader_amd.optim) apply the 1 / world_size of the gradient average inside its
+        update kernel: the shim then only sums (no `flat.mul_` pass over the reduced buffers).  Every parameter of this module
+        must be owned by `optimizer`.
+        Changed gradient semantics while folded: after backward `p.grad` holds the SUM over the ranks (world_size times the
+        average apex leaves there) -- gradient clipping / logging between backward and step must account for it; the scale
+        lives in the optimizer's device hyper block, not in its state_dict; and exactly ONE backward may precede each
+        `optimizer.step()`: a second one would all-reduce the already summed flat buffer again (W * sum(g1) + sum(g2)), so
+        the shim raises instead (gradient accumulation needs the default, unfolded mode)."""
         owned = {id(p) for group in optimizer.param_groups for p in group['params']}
         if not all(id(p) in owned for p in self._params):
             raise ValueError("fold_average_into: the optimizer does not own every parameter of the wrapped module")
         if self.gradient_average:
             optimizer.set_grad_scale(1.0 / self.world_size)
             self.gradient_average = False
+            self._folded = optimizer
+            self._fold_seen_step = None
 
     def _bucket_complete(self, bi):
         return all(self._fires.get(id(p), 0) >= self._uses.get(id(p), 1) for p in self._buckets[bi])
@@ -179,6 +188,18 @@ class DistributedDataParallel(nn.Module):
         self._n_staged += int(staged)
 
     def _finalize(self):
+        if self._folded is not None:
+            steps = getattr(self._folded, "_py_steps", 0)
+            if steps == self._fold_seen_step:
+                for _bucket, _flat, _staged, work in self._pending:
+                    work.wait()          # collectives the hooks already issued: let them land before giving up the round
+                self._reset_round()
+                self._n_launched = self._n_staged = 0
+                raise RuntimeError("apex.parallel.DistributedDataParallel: a second backward() without optimizer.step() "
+                                   "while the gradient average is folded into the optimizer (fold_average_into): the flat "
+                                   "gradient buffer already holds the all-reduced sum and would be reduced again.  Use the "
+                                   "default (unfolded) mode for gradient accumulation.")
+            self._fold_seen_step = steps
         for bi in range(len(self._buckets)):
             if not self._launched[bi]:
                 self._launch(bi)
@@ -186,13 +207,16 @@ class DistributedDataParallel(nn.Module):
         for bucket, flat, staged, work in self._pending:
             work.wait()  # RCCL: the current (main) stream waits for the collective; host does not block
             self._finish_bucket(bucket, flat, staged, scale)
+        self._reset_round()
+        # what the last backward did: all-reduces issued, and how many of them went through a staging copy
+        self.last_backward = {"all_reduces": self._n_launched, "staged": self._n_staged, "buckets": len(self._buckets)}
+        self._n_launched = self._n_staged = 0
+
+    def _reset_round(self):
         self._pending = []
         self._fires = {}
         self._launched = [False] * len(self._buckets)
         self._callback_queued = False
-        # what the last backward did: all-reduces issued, and how many of them went through a staging copy
-        self.last_backward = {"all_reduces": self._n_launched, "staged": self._n_staged, "buckets": len(self._buckets)}
-        self._n_launched = self._n_staged = 0
 
     @staticmethod
     def _finish_bucket(bucket, flat, staged, scale):
@@ -237,6 +261,5 @@ class SyncBatchNorm(_HipBatchNorm2d):
 
             def reduce_fn(t):
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        momentum = 0.1 if self.momentum is None else self.momentum
-        return F.sync_batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, momentum, self.eps,
+        return F.sync_batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps,
                                  self.fuse_relu, residual, self.num_batches_tracked, reduce_fn)

@@ -23,11 +23,20 @@ def constant_init(module, constant, bias=0):
         nn.init.constant_(module.bias, bias)
 
 
+_sync_bn_source = None     # callable -> bool, installed by megreader_amd.dropin.install(): the reference's config.sync_bn
+
+
+def set_sync_bn_source(fn):
+    """Explicit switch for reference resnet.py:26-30 (`if config.sync_bn: apex.parallel.SyncBatchNorm`).  The reference reads
+    its own top-level `config` module; here the drop-in layer registers a callable that resolves THAT module (checked
+    against the reference root) -- nothing is looked up by name in sys.modules.  None: plain BatchNorm2d."""
+    global _sync_bn_source
+    _sync_bn_source = fn
+
+
 def bn(*args, **kwargs):
-    # reference resnet.py:26-30: apex.parallel.SyncBatchNorm when config.sync_bn (default False, config.py:14).  The
-    import sys
-    _ref_config = sys.modules.get("config")      # only if the reference's own module is already loaded (train.py imports it)
-    if _ref_config is not None and getattr(_ref_config, "sync_bn", False) is True:
+    # reference resnet.py:26-30: apex.parallel.SyncBatchNorm when config.sync_bn (default False, config.py:14; truthiness)
+    if _sync_bn_source is not None and _sync_bn_source():
         from ..apex.parallel import SyncBatchNorm
         return SyncBatchNorm(*args, **kwargs)
     return BatchNorm2d(*args, **kwargs)

@@ -44,17 +44,24 @@ class CTCDecoder(nn.Module):
             raise NotImplementedError("megreader_amd decoders run on the GPU only")
         enc = self.encode(feature)                       # logical [N, inner, h, W]
         N, C, h, W = enc.shape
-        if h != 1:
-            # the reference applies the 1x1 conv to every row and then `select(2, 0)` (ctc_decoder.py:57-60): only row 0 counts
-            enc = enc[:, :, :1, :]
-        seq = F.map_to_sequence(enc)                     # [W, N, inner]
         w = self.pred_conv.weight
-        logits = F.linear(seq, w.reshape(w.shape[0], w.shape[1]), self.pred_conv.bias)     # [W, N, classes]
+
+        def row_logits(r):
+            seq = F.map_to_sequence(enc if h == 1 else enc[:, :, r:r + 1, :])               # [W, N, inner]
+            return F.linear(seq, w.reshape(w.shape[0], w.shape[1]), self.pred_conv.bias)     # [W, N, classes]
+
+        if not train and h != 1:
+            # eval: the reference returns the softmax of EVERY row, [N, classes, h, W] (ctc_decoder.py:64-66)
+            return torch.cat([F.softmax_eval_nc1t(row_logits(r)) for r in range(h)], dim=2)
+        # training: the reference applies the 1x1 conv to every row and then `select(2, 0)` (ctc_decoder.py:57-60): row 0 counts
+        logits = row_logits(0)
         if train:
             if W < 32:
                 raise RuntimeError("CTCDecoder: the reference fixes input_lengths at 32 (ctc_decoder.py:61) but the encoder "
                                    "output has only %d columns" % W)
             il = None if W == 32 else torch.full((N,), 32, dtype=torch.int64, device=feature.device)
-            loss, log_probs = F.ctc_loss_logits(logits, targets, il, lengths, blank=self.blank, zero_infinity=False)
+            # nn.CTCLoss(reduction='mean') with its default blank = 0 (ctc_decoder.py:17): `self.blank` is stored by the
+            # reference but never reaches the loss -- it only matters to the representer
+            loss, log_probs = F.ctc_loss_logits(logits, targets, il, lengths, blank=0, zero_infinity=False)
             return loss.to(torch.float32), log_probs.to(torch.float32).permute(1, 2, 0)
         return F.softmax_eval_nc1t(logits)

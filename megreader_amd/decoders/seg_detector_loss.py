@@ -29,12 +29,14 @@ class BalanceCrossEntropyLoss(nn.Module):
             negative_loss, _ = torch.topk(negative_loss.view(-1), negative_count)
             balance_loss = (positive_loss.sum() + negative_loss.sum()) / (positive_count + negative_count + self.eps)
         else:
-            pc = positive.float().sum()
-            nc = torch.minimum(negative.float().sum(), torch.floor(pc * self.negative_ratio))
+            # integer counts (exact beyond 2^24 elements, i.e. batch >= 41 at 640 x 640), the reference's
+            # `min(int(neg), int(pos * ratio))` with the product formed in double like Python's
+            pc = positive.sum(dtype=torch.int64)
+            nc = torch.minimum(negative.sum(dtype=torch.int64), torch.floor(pc.double() * self.negative_ratio).long())
             flat = negative_loss.view(-1)
             srt, _ = torch.sort(flat, descending=True)
-            take = (torch.arange(flat.numel(), device=flat.device, dtype=torch.float32) < nc).to(srt.dtype)
-            balance_loss = (positive_loss.sum() + (srt * take).sum()) / (pc + nc + self.eps)
+            take = (torch.arange(flat.numel(), device=flat.device, dtype=torch.int64) < nc).to(srt.dtype)
+            balance_loss = (positive_loss.sum() + (srt * take).sum()) / ((pc + nc).double() + self.eps).to(srt.dtype)
         if return_origin:
             return balance_loss, loss
         return balance_loss

@@ -35,30 +35,54 @@ OVERRIDES = {
 def fuse_optimizers():
     """`getattr(torch.optim, 'Adam')(parameters, **args)` (reference training/optimizer_scheduler.py:17-22) -> the fused
     flat-buffer optimizers of megreader_amd.optim when every parameter is an fp32 CUDA tensor and the options are ones they
-    implement; anything else falls through to torch's own class.  Idempotent.  Returns the names that were aliased."""
+    implement; anything else constructs torch's own optimizer.  `torch.optim.Adam` / `SGD` stay CLASSES -- subclasses of the
+    originals whose `__new__` hands eligible constructions to the fused optimizer -- so `class X(torch.optim.SGD)` and
+    `isinstance(opt, torch.optim.Adam)` in the reference or in third-party code keep working (a fused instance counts as an
+    instance of the alias).  Idempotent.  Returns the names that were aliased."""
+    import inspect
+
     import torch
     from . import optim as _optim
 
-    def _factory(orig, fused, unsupported):
-        if getattr(orig, "_mr_fused_factory", False):
+    def _alias(orig, fused, unsupported):
+        if getattr(orig, "_mr_original", None) is not None:
             return orig
+        allowed = set(inspect.signature(fused.__init__).parameters) - {"self", "params"}
 
-        def make(params, *args, **kwargs):
-            params = list(params)
-            flat = [p for g in params for p in g["params"]] if params and isinstance(params[0], dict) else params
-            ok = bool(flat) and all(p.is_cuda and p.dtype == torch.float32 for p in flat) and not args
-            ok = ok and not any(kwargs.get(k) for k in unsupported)
-            ok = ok and set(kwargs) <= set(fused.__init__.__code__.co_varnames)
-            return fused(params, **kwargs) if ok else orig(params, *args, **kwargs)
-        make._mr_fused_factory = True
-        make._mr_original = orig
-        make.__name__ = orig.__name__
-        return make
+        class _Meta(type(orig)):
+            def __instancecheck__(cls, inst):
+                return type.__instancecheck__(cls, inst) or (cls.__dict__.get("_mr_original") is orig and
+                                                              isinstance(inst, fused))
 
-    torch.optim.Adam = _factory(torch.optim.Adam, _optim.FusedAdam, ("amsgrad", "foreach", "fused", "capturable",
-                                                                     "maximize", "differentiable"))
-    torch.optim.SGD = _factory(torch.optim.SGD, _optim.FusedSGD, ("dampening", "nesterov", "foreach", "fused", "maximize",
-                                                                  "differentiable"))
+        class Alias(orig, metaclass=_Meta):
+            _mr_original = orig
+            _mr_fused = fused
+
+            def __new__(cls, params, *args, **kwargs):
+                params = list(params)      # may be a generator: consumed once, handed on through the instance
+                if cls.__dict__.get("_mr_original") is orig:       # the alias itself, not a user subclass of it
+                    flat = [p for g in params for p in g["params"]] if params and isinstance(params[0], dict) else params
+                    ok = bool(flat) and all(getattr(p, "is_cuda", False) and p.dtype == torch.float32 for p in flat)
+                    ok = ok and not args and not any(kwargs.get(k) for k in unsupported) and set(kwargs) <= allowed
+                    if ok:
+                        return fused(params, **kwargs)             # not an instance of cls: Python skips __init__
+                inst = super().__new__(cls)
+                inst.__dict__["_mr_params"] = params
+                return inst
+
+            def __init__(self, params, *args, **kwargs):
+                super().__init__(self.__dict__.pop("_mr_params", params), *args, **kwargs)
+
+        Alias.__name__ = orig.__name__
+        Alias.__qualname__ = orig.__qualname__
+        Alias.__module__ = orig.__module__
+        Alias.__doc__ = orig.__doc__
+        return Alias
+
+    torch.optim.Adam = _alias(torch.optim.Adam, _optim.FusedAdam, ("amsgrad", "foreach", "fused", "capturable",
+                                                                   "maximize", "differentiable"))
+    torch.optim.SGD = _alias(torch.optim.SGD, _optim.FusedSGD, ("dampening", "nesterov", "foreach", "fused", "maximize",
+                                                                "differentiable"))
     return ["Adam", "SGD"]
 
 
@@ -236,6 +260,21 @@ def install(reference_root=None, level="plugin", fused_optimizer=False, graph_st
         reference_root = os.path.abspath(reference_root)
         if reference_root not in sys.path:
             sys.path.insert(0, reference_root)
+    # `config.sync_bn` of the reference's OWN config.py (backbones/resnet.py:5,27 `import config` ... `if config.sync_bn:`): an
+    # explicit hook, resolved against the reference root -- some unrelated importable module named `config` does not count
+    from .backbones import resnet as _resnet
+    ref_root_for_config = reference_root
+
+    def _reference_sync_bn():
+        if not ref_root_for_config:
+            return False
+        try:
+            cfg = importlib.import_module("config")
+        except ImportError:
+            return False
+        where = os.path.dirname(os.path.abspath(getattr(cfg, "__file__", None) or ""))
+        return where == ref_root_for_config and bool(getattr(cfg, "sync_bn", False))
+    _resnet.set_sync_bn_source(_reference_sync_bn)
     installed = {}
     for pkg, (ours, names) in OVERRIDES.items():
         try:

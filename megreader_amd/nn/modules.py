@@ -53,10 +53,13 @@ class BatchNorm2d(nn.BatchNorm2d):
         super().__init__(*args, **kwargs)
         if not (self.affine and self.track_running_stats):
             raise NotImplementedError("megreader_amd.nn.BatchNorm2d requires affine=True, track_running_stats=True")
+        if self.momentum is None:
+            raise NotImplementedError("megreader_amd.nn.BatchNorm2d: momentum=None (cumulative moving average) is not "
+                                      "used by any reference model; pass a float")
         self.fuse_relu = fuse_relu
 
     def forward(self, x, residual=None):
-        momentum = 0.1 if self.momentum is None else self.momentum
+        momentum = self.momentum
         if self.training:
             # conv -> bn fusion is self-configuring: the first training forward marks the producing Conv2d, every later
             # one receives the batch statistics from that convolution's epilogue (F.conv2d(bn_stats=True)) and skips the

@@ -22,6 +22,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
     def __init__(self, params, defaults):
         super().__init__(params, defaults)
         self._flat = None  # per group: dict(p=, g=, s1=, s2=, hyper=, n=)
+        self._py_steps = 0  # host-side count of step() calls (the DDP shim's one-backward-per-step check while folded)
 
     # ------------------------------------------------------------------ flat storage
     def _materialize(self):
@@ -140,6 +141,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
                 loss = closure()
         if self._flat is None:
             self._materialize()
+        self._py_steps += 1
         for group, f in zip(self.param_groups, self._flat):
             if f is None:
                 continue

@@ -23,11 +23,15 @@ by bucket, and is what the reference's trainer uses.)
 import torch
 
 
-def data_parallel_grad_sync(optimizer, group=None, average=True, fold=True):
+def data_parallel_grad_sync(optimizer, group=None, average=True, fold=False):
     """Returns a function that averages the gradients of a fused optimizer across the ranks of `group`: one
     in-place all-reduce per flat gradient buffer (apex DDP semantics: sum, then divide by the world size).
-    fold=True (default): the 1 / world factor is applied inside the optimizer's update kernel
-    (`optimizer.set_grad_scale`), not by a separate pass over the reduced buffer."""
+    fold=True (opt-in; bench.py and the graphed step use it): the 1 / world factor is applied inside the optimizer's update
+    kernel (`optimizer.set_grad_scale`), not by a separate pass over the reduced buffer.  CHANGED GRADIENT SEMANTICS while
+    folded: after the sync `p.grad` holds the SUM over the ranks, world_size times the average -- code that reads gradients
+    between the sync and `step()` (clip_grad_norm_, gradient logging) must divide by the world size itself, and exactly one
+    backward may precede each `step()` (a second one would re-reduce the already summed buffer).  The scale is not part of
+    the optimizer's state_dict: re-apply it after loading a checkpoint."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     scale_here = average and world > 1

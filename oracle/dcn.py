@@ -101,15 +101,61 @@ class OracleModulatedDeformConv(torch.nn.Module):
                                        self.dilation)
 
 
-def perturb_offset_convs(model, seed=99):
+def perturb_offset_convs(model, seed=99, kink_safe=False):
     """The reference zero-initialises every conv2_offset (backbones/resnet.py:222-226), which would leave the
     deformable sampling trivial (offsets 0, mask 0.5).  Tests give them small seeded random values instead --
-    applied identically to the reference model, the oracle and the HIP model (parameter order = named_parameters)."""
+    applied identically to the reference model, the oracle and the HIP model (parameter order = named_parameters).
+
+    kink_safe=True: the bilinear kernel has a kink at every integer sampling coordinate -- the forward value is
+    continuous there, d/d(offset) and the set of pixels that receive gradient are not.  With feature-dependent offsets
+    spread over the real line (the default: bias ~ N(0, 0.5), weights ~ N(0, 0.02)) some of the ~1e5 coordinates of a
+    test batch always land within 1e-5 of an integer, and two arithmetically equivalent runs (another summation order of
+    the BatchNorm statistics in front) then take floor() to different sides: ONE such flip moved a gradient by 0.13 of
+    its maximum in round 3 (tools/diag_fast_paths.py, profiles/r04_diag_fast_paths_before.txt).  Tests that compare
+    GRADIENTS of two runs use this mode: offset biases k + 0.5 +- 0.05 (k in {-1, 0, 1}) and weights ~ N(0, 1e-3), so
+    every coordinate stays >= 0.2 away from an integer (the feature-dependent part has std ~0.05: BN + ReLU inputs, 9 * C
+    taps); `min_kink_distance` checks that precondition on the actual model.  Mask channels as in the default mode."""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, p in model.named_parameters():
             if 'conv2_offset' in name:
                 if name.endswith('weight'):
-                    p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+                    p.copy_(torch.randn(p.shape, generator=g) * (1e-3 if kink_safe else 0.02))
+                elif kink_safe:
+                    n_off = p.numel() * 2 // 3          # 18 offset channels, then 9 mask channels
+                    b = torch.randn(p.shape, generator=g) * 0.5
+                    k = torch.randint(-1, 2, (n_off,), generator=g).to(b.dtype)
+                    b[:n_off] = k + 0.5 + (torch.rand((n_off,), generator=g) - 0.5) * 0.1
+                    p.copy_(b)
                 else:
                     p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+
+
+def min_kink_distance(model, x, n_offset_channels=18):
+    """Smallest distance of any sampling coordinate to an integer row / column over the deformable blocks of `model` for
+    the input `x` (integer base coordinates: only the fractional part of the offsets matters)."""
+    dists, hooks = [], []
+    for m in model.modules():
+        conv = getattr(m, 'conv2_offset', None)
+        if conv is not None:
+            def hook(_m, _inp, out):
+                off = out.detach().float()[:, :n_offset_channels]
+                fr = off - off.floor()
+                dists.append(float(torch.minimum(fr, 1 - fr).min()))
+            hooks.append(conv.register_forward_hook(hook))
+    # a TRAINING-mode forward (batch statistics, like the runs under test); running statistics restored afterwards.  Call it
+    # on a copy when the model's first-forward behaviour matters (the HIP modules configure conv -> bn fusions on first use).
+    was_training = model.training
+    saved = {k: v.detach().clone() for k, v in model.named_buffers()}
+    model.train()
+    try:
+        with torch.no_grad():
+            model(x)
+    finally:
+        model.train(was_training)
+        with torch.no_grad():
+            for k, v in model.named_buffers():
+                v.copy_(saved[k])
+        for h in hooks:
+            h.remove()
+    return min(dists) if dists else float('inf')

@@ -1,0 +1,298 @@
+"""The four published configurations (BASELINE.json configs[1..4] = what bench.py times) as memoised oracle runs, shared by
+tests/test_timed_step_gpu.py, tests/test_published_configs_gpu.py and tests/test_fullsize_parity_gpu.py so that the CPU
+oracle (float32 = the reference's arithmetic, float64 = ground truth of the gradient bars, tests/_parity.py) runs ONCE per
+configuration and process.  Each case returns a dict:
+
+    ora        the CPU oracle module (float32, gradients of its training pass in .grad)
+    state0     its state_dict before the training forward (what the HIP model loads)
+    batch      the seeded synthetic batch (CPU tensors)
+    grads32    {name: gradient of the f32 oracle},  grads64 {name: gradient of the f64 oracle}
+    out32 / out64   forward outputs of the two oracle passes (per case)
+    build()    a fresh HIP model with state0 loaded, on the GPU, in training mode
+    loss_fn(model, batch_on_device) -> scalar loss the way the reference's trainer forms it (trainer.py:127 `l.mean()`)
+    optimizer(params) -> the fused optimizer of the published YAML with lr = 0 (weights stay put: gradients of later steps
+                         remain comparable with the oracle's)
+"""
+import copy
+import os
+import time
+
+import torch
+
+DEV = "cuda"
+_CACHE = {}
+
+
+def _host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 64))
+
+
+class _Threads(object):
+    """The CPU oracle's summation order (hence its last-bit results) depends on the thread count: use the host's cores for
+    the big runs and restore the setting, so that the tests that run later see the oracle they were written against."""
+
+    def __enter__(self):
+        self.old = torch.get_num_threads()
+        torch.set_num_threads(_host_threads())
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self.old)
+
+
+def _f64(ora32, forward):
+    ora64 = copy.deepcopy(ora32).double().train()
+    ora64.zero_grad()
+    forward(ora64, torch.float64).backward()
+    return {k: p.grad.detach().clone() for k, p in ora64.named_parameters() if p.grad is not None}
+
+
+def _grads(ora):
+    return {k: p.grad.detach().clone() for k, p in ora.named_parameters() if p.grad is not None}
+
+
+def _to_dev(batch):
+    return {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+
+
+def _recognition_loss(model, b):
+    loss, _ = model(b['image'], targets=b['label'], lengths=b['length'].long(), train=True)
+    return loss.mean()
+
+
+# ------------------------------------------------------------------------------------------------ configs[1]: CRNN, N = 256
+def crnn_n256():
+    if "crnn" in _CACHE:
+        return _CACHE["crnn"]
+    from megreader_amd.backbones import crnn_backbone
+    from megreader_amd.decoders import CRNNDecoder
+    from megreader_amd.optim import FusedAdam
+    from oracle.crnn import CRNNOracle, synthetic_batch
+
+    class Model(torch.nn.Module):  # reference structure/model.py:16-24
+        def __init__(self):
+            super().__init__()
+            self.backbone = crnn_backbone()
+            self.decoder = CRNNDecoder(in_channels=512, inner_channels=256, need_reduce=False)
+
+        def forward(self, data, *args, **kwargs):
+            return self.decoder(self.backbone(data), *args, **kwargs)
+
+    torch.manual_seed(4321)
+    ora = CRNNOracle()
+    state0 = {k: v.clone() for k, v in ora.state_dict().items()}
+    batch = synthetic_batch(256, 32, 128, seed=11)
+    lab, ln = batch['label'], batch['length'].long()
+
+    def fwd(m, dt):
+        loss, _ = m(batch['image'].to(dt), targets=lab, lengths=ln, train=True)
+        return loss.mean()
+
+    t0 = time.time()
+    grads64 = _f64(ora, fwd)
+    ora.train()
+    loss, logp = ora(batch['image'], targets=lab, lengths=ln, train=True)
+    loss.mean().backward()
+    state1 = {k: v.clone() for k, v in ora.state_dict().items()}   # BN running stats moved by the training forward
+    ora.eval()
+    with torch.no_grad():
+        ev = ora(batch['image'], train=False)
+    ora.train()
+    print("oracle CRNN N=256 fwd+bwd (f32 and f64) + eval: %.1f s" % (time.time() - t0))
+
+    def build():
+        m = Model()
+        m.load_state_dict(state0)
+        return m.to(DEV).train()
+
+    _CACHE["crnn"] = dict(ora=ora, state0=state0, state1=state1, batch=batch, grads32=_grads(ora), grads64=grads64,
+                          out32={"loss": float(loss), "logp": logp.detach(), "eval": ev}, build=build,
+                          loss_fn=_recognition_loss, optimizer=lambda ps: FusedAdam(ps, lr=0.0),
+                          what="CRNN fp32 32x128 N=256")
+    return _CACHE["crnn"]
+
+
+# ------------------------------------------------------------------------------------ configs[2]: Res50-PPM + 2D-CTC, N = 256
+def res50ppm_n256():
+    if "res50ppm" in _CACHE:
+        return _CACHE["res50ppm"]
+    from megreader_amd.backbones import resnet50dilated_ppm
+    from megreader_amd.decoders import CTCDecoder2D
+    from megreader_amd.optim import FusedAdam
+    from oracle.res50ppm import Res50PPM2DCTCOracle, synthetic_batch_2d
+
+    class Model(torch.nn.Module):  # structure/model.py:16-24
+        def __init__(self):
+            super().__init__()
+            self.backbone = resnet50dilated_ppm()
+            self.decoder = CTCDecoder2D(in_channels=256)
+
+        def forward(self, data, *a, **k):
+            return self.decoder(self.backbone(data), *a, **k)
+
+    torch.manual_seed(99)
+    ora = Res50PPM2DCTCOracle(dropout=0.0)
+    state0 = {k: v.clone() for k, v in ora.state_dict().items()}
+    n, height, width = 256, 32, 128          # what bench.py times (bench.py: synthetic_batch_2d(bsz, 32, 128, max_len=3))
+    batch = synthetic_batch_2d(n, height, width, seed=5, max_len=3)
+    lab, ln = batch['label'], batch['length'].long()
+    out64 = {}
+
+    def fwd(m, dt):
+        loss, pred = m(batch['image'].to(dt), targets=lab, lengths=ln, train=True)
+        if dt == torch.float64:
+            out64['pred'], out64['loss'] = pred.detach(), loss.detach()
+        return loss.mean()
+
+    with _Threads():
+        t0 = time.time()
+        grads64 = _f64(ora, fwd)
+        ora.train()
+        loss_o, pred_o = ora(batch['image'], targets=lab, lengths=ln, train=True)
+        loss_o.mean().backward()
+        print("oracle Res50-PPM-2DCTC %dx%d N=%d fwd+bwd (f32 and f64): %.1f s" % (height, width, n, time.time() - t0))
+
+    def build():
+        m = Model()
+        m.load_state_dict(state0, strict=True)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout2d):
+                mod.p = 0.0
+        return m.to(DEV).train()
+
+    _CACHE["res50ppm"] = dict(ora=ora, state0=state0, batch=batch, grads32=_grads(ora), grads64=grads64, out64=out64,
+                              out32={"loss": loss_o.detach(), "pred": pred_o.detach()}, build=build,
+                              loss_fn=_recognition_loss, optimizer=lambda ps: FusedAdam(ps, lr=0.0),
+                              what="Res50-PPM-2DCTC fp32 32x128 N=256")
+    return _CACHE["res50ppm"]
+
+
+# ------------------------------------------------------------------------------------- configs[3]: FPN50 + attention, N = 32
+def fpn_attention_n32():
+    if "fpn" in _CACHE:
+        return _CACHE["fpn"]
+    from megreader_amd.backbones import Resnet50FPN
+    from megreader_amd.decoders import AttentionDecoder
+    from megreader_amd.optim import FusedAdam
+    from oracle.crnn import synthetic_batch
+    from oracle.fpn_attention import FPNAttentionOracle
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = Resnet50FPN(resnet_pretrained=False)
+            self.decoder = AttentionDecoder(in_channels=256, gt_as_output=True)
+
+        def forward(self, data, *a, **k):
+            return self.decoder(self.backbone(data), *a, **k)
+
+    torch.manual_seed(2024)
+    ora = FPNAttentionOracle()
+    state0 = {k: v.clone() for k, v in ora.state_dict().items()}
+    n = 32
+    batch = synthetic_batch(n, 64, 256, seed=21)
+    lab, ln = batch['label'], batch['length'].long()
+    out64 = {}
+
+    def fwd(m, dt):
+        loss, att = m(batch['image'].to(dt), targets=lab, lengths=ln, train=True)
+        if dt == torch.float64:
+            out64['loss'], out64['att'] = loss.detach(), att.detach()
+        return loss.mean()
+
+    with _Threads():
+        t0 = time.time()
+        grads64 = _f64(ora, fwd)
+        ora.train()
+        loss_o, att_o = ora(batch['image'], targets=lab, lengths=ln, train=True)
+        loss_o.mean().backward()
+        print("oracle FPN50-attention 64x256 N=%d fwd+bwd (f32 and f64): %.1f s" % (n, time.time() - t0))
+
+    def build():
+        m = Model()
+        m.load_state_dict(state0, strict=True)
+        return m.to(DEV).train()
+
+    _CACHE["fpn"] = dict(ora=ora, state0=state0, batch=batch, grads32=_grads(ora), grads64=grads64, out64=out64,
+                         out32={"loss": loss_o.detach(), "att": att_o.detach()}, build=build,
+                         loss_fn=_recognition_loss, optimizer=lambda ps: FusedAdam(ps, lr=0.0),
+                         what="FPN50-attention fp32 64x256 N=32")
+    return _CACHE["fpn"]
+
+
+# --------------------------------------------------------------------------------------- configs[4]: DB detector, 640x640, N = 2
+def db_n2():
+    if "db" in _CACHE:
+        return _CACHE["db"]
+    from megreader_amd.backbones import deformable_resnet50
+    from megreader_amd.decoders import L1BalanceCELoss, SegDetector
+    from megreader_amd.optim import FusedSGD
+    from megreader_amd.synthetic import detection_batch
+    from oracle.res50ppm import _Res50Dilated
+    from oracle.seg_detector import SegDetectorOracle, l1_balance_ce_loss
+
+    class Oracle(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = _Res50Dilated(dilate=False, dcn=True)
+            self.decoder = SegDetectorOracle(in_channels=[256, 512, 1024, 2048], adaptive=True, k=50)
+
+        def forward(self, image):
+            return self.decoder(self.backbone(image))
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = deformable_resnet50(pretrained=False)
+            self.decoder = SegDetector(in_channels=[256, 512, 1024, 2048], adaptive=True, k=50)
+            self.criterion = L1BalanceCELoss()
+
+        def forward(self, image):
+            return self.decoder(self.backbone(image))
+
+    torch.manual_seed(7)
+    ora = Oracle()
+    state0 = {k: v.clone() for k, v in ora.state_dict().items()}
+    n, size = 2, 640
+    batch = detection_batch(n, size, seed=3)
+    out64 = {}
+
+    def fwd(m, dt):
+        p = m(batch['image'].to(dt))
+        if dt == torch.float64:
+            out64.update({k: v.detach() for k, v in p.items()})
+        return l1_balance_ce_loss(p, {k: v.to(dt) for k, v in batch.items()})
+
+    with _Threads():
+        t0 = time.time()
+        grads64 = _f64(ora, fwd)
+        ora.train()
+        pred_o = ora(batch['image'])
+        loss_o = l1_balance_ce_loss(pred_o, batch)
+        loss_o.backward()
+        print("oracle DB detector %dx%d N=%d fwd+bwd (f32 and f64): %.1f s" % (size, size, n, time.time() - t0))
+    loss64 = float(l1_balance_ce_loss(out64, {k: v.double() for k, v in batch.items()}))
+
+    def build():
+        m = Model()
+        m.load_state_dict(state0, strict=True)
+        return m.to(DEV).train()
+
+    def loss_fn(model, b):
+        loss, _ = model.criterion(model(b['image']), b)
+        return loss
+
+    # seg_detector_db.yaml:85-94: SGD momentum 0.9, weight decay 1e-4 -- with lr = 0 the weights stay put
+    _CACHE["db"] = dict(ora=ora, state0=state0, batch=batch, grads32=_grads(ora), grads64=grads64, out64=out64,
+                        out32={"pred": {k: v.detach() for k, v in pred_o.items()}, "loss": float(loss_o), "loss64": loss64},
+                        build=build, loss_fn=loss_fn,
+                        optimizer=lambda ps: FusedSGD(ps, lr=0.0, momentum=0.9, weight_decay=1e-4),
+                        what="DB detector fp32 640x640 N=2")
+    return _CACHE["db"]
+
+
+def to_device(batch):
+    return _to_dev(batch)

@@ -394,3 +394,54 @@ def test_bucket_planner_properties():
             assert e <= max(1.25 * target, biggest) + 0.2 * target + 1, (sizes, target, elems)
         assert all(e >= 0.1 * target for e in elems) or len(plan) == 1, (sizes, target, elems)
     check()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fold_average_into is opt-in and guarded: while the 1 / world factor lives in the optimizer's update kernel the
+# flat buffer holds the all-reduced SUM, so a second backward() without a step() would re-reduce it -- the shim raises.
+# ---------------------------------------------------------------------------------------------------------------
+class _FoldOpt(object):
+    """What fold_average_into needs of a fused optimizer: param_groups, set_grad_scale, the host step counter."""
+
+    def __init__(self, params):
+        self.param_groups = [{"params": list(params)}]
+        self.scale = None
+        self._py_steps = 0
+
+    def set_grad_scale(self, s):
+        self.scale = s
+
+    def step(self):
+        self._py_steps += 1
+
+
+def test_folded_average_allows_one_backward_per_step():
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from megreader_amd.apex.parallel import DistributedDataParallel
+        from megreader_amd.runtime import data_parallel_grad_sync
+        import inspect
+        assert inspect.signature(data_parallel_grad_sync).parameters["fold"].default is False       # opt-in
+        torch.manual_seed(0)
+        net = FlatNet()
+        ddp = DistributedDataParallel(net, message_size=64)
+        assert ddp.gradient_average                       # the default: the shim divides, p.grad is the average
+        opt = _FoldOpt(net.parameters())
+        ddp.fold_average_into(opt)
+        assert opt.scale == 1.0 and not ddp.gradient_average
+        x = torch.randn(4, 8)
+        for _ in range(3):                                # backward, step, backward, step ... is fine
+            net.zero_grad()
+            ddp(x).mean().backward()
+            opt.step()
+        ddp(x).mean().backward()
+        with pytest.raises(RuntimeError, match="second backward"):
+            ddp(x).mean().backward()                      # no step() in between
+        opt.step()
+        net.zero_grad()
+        ddp(x).mean().backward()                          # the shim recovers after the error
+        assert ddp.last_backward["all_reduces"] == ddp.last_backward["buckets"]
+    finally:
+        dist.destroy_process_group()

@@ -7,13 +7,16 @@ perturbation per block (offsets are computed from features, BatchNorm uses batch
 1e-6 after the stem becomes ~1e-2 at layer4: the whole-network comparison is therefore loose, and the strict check is
 block-wise (each HIP block on the oracle's own block input, forward and backward).
 
-The block-wise gradient check is exact only while no sample point sits on a kink of the bilinear kernel: the sampling offsets
-are themselves computed (conv2_offset) in float32 on both sides, and a point within ~1e-6 of an integer row / column takes
-floor() to different sides -- the forward value is continuous there (y still agrees to 1e-6) but d/d(offset) and the set of
-input pixels that receive gradient are not.  Seen in round 3 with the block input the oracle produces under
-torch.set_num_threads(32) (layer4.0: bn2.bias 25 % off in BOTH DCN code paths, fused and general, while the float32 and
-float64 oracles agree to 3e-6); with the default thread count of the box no point is that close.  Tests that change the
-thread count must restore it."""
+Gradient comparisons and the bilinear kink.  The sampling offsets are themselves computed (conv2_offset) in float32 on both
+sides, and a point within round-off of an integer row / column takes floor() to different sides: the forward value is
+continuous there (y still agrees to 1e-6) but d/d(offset) and the set of input pixels that receive gradient are not.  With
+the default test perturbation (offsets spread over the real line) ~1e5 coordinates per batch put the closest one ~5e-6 from
+an integer, and ONE flip moved `2.conv3.weight`'s gradient by 0.133 of its maximum in ~10 % of otherwise identical runs --
+round 3's red driver run (profiles/r04_diag_fast_paths_before.txt: same value with the statistics epilogue off, without an
+optimizer, and on every run of the general DCN kernels).  Every test here that compares GRADIENTS therefore uses
+`perturb_offset_convs(kink_safe=True)` (offsets k + 0.5 +- 0.05 + a small feature-dependent part) and asserts the
+precondition itself (`min_kink_distance >= 0.1`); the default perturbation is kept for FORWARD comparisons, which are
+continuous."""
 import os
 
 import pytest
@@ -23,7 +26,7 @@ pytestmark = pytest.mark.gpu
 
 import megreader_amd as mr  # noqa: E402
 from megreader_amd.backbones import deformable_resnet50  # noqa: E402
-from oracle.dcn import perturb_offset_convs  # noqa: E402
+from oracle.dcn import min_kink_distance, perturb_offset_convs  # noqa: E402
 from oracle.res50ppm import _Res50Dilated  # noqa: E402
 
 DEV = "cuda"
@@ -73,16 +76,17 @@ def test_seeded_init_and_whole_network(golden):
 @pytest.mark.parametrize("block", ["layer2.0", "layer2.1", "layer3.0", "layer3.3", "layer4.0", "layer4.2"])
 def test_block_parity(golden, block):
     model = _build(golden)
-    perturb_offset_convs(model)
+    perturb_offset_convs(model, kink_safe=True)
     torch.manual_seed(golden['weight_seed'])
     ora = _Res50Dilated(dilate=False, dcn=True)
-    perturb_offset_convs(ora)
+    perturb_offset_convs(ora, kink_safe=True)
     ora.train()
     captured = {}
     mod_o = dict(ora.named_modules())[block]
     mod_o.register_forward_pre_hook(lambda m, inp: captured.__setitem__('x', inp[0].detach().clone()))
     ora(golden['x'])
     x = captured['x']
+    assert min_kink_distance(mod_o, x) >= 0.1          # precondition of the gradient comparison (module docstring)
     xo = x.clone().requires_grad_(True)
     yo = mod_o(xo)
     g = torch.randn(yo.shape, generator=torch.Generator().manual_seed(3))
@@ -103,45 +107,63 @@ def test_block_parity(golden, block):
     assert not bad, bad
 
 
-def test_fast_paths_equal_plain_autograd():
-    """What the benchmarked step runs and the one-step parity tests do not: from the SECOND training forward on, every conv
-    in front of a BatchNorm supplies the batch statistics from its GEMM epilogue, and with a fused optimizer every weight
-    gradient -- incl. the 27-channel offset convolutions (Cout < stored channels) and the DCN weights -- is accumulated
-    straight into the optimizer's flat buffer.  Same layers, same input: those gradients must equal the plain autograd
-    gradients of a first forward without an optimizer (float32; differences = summation order of atomics).
-    layer2 only (four deformable bottlenecks, the first strided with a downsample branch): the whole network amplifies the
-    1e-7 noise of two summation orders to O(0.3) by itself (two identical plain runs differ that much), layer2 to 7e-6."""
+def _fast_vs_plain(kink_safe):
+    """layer2 of the deformable ResNet (four DCN bottlenecks, the first strided with a downsample branch): `plain` = one
+    first forward / backward with plain autograd; `fast` = the same layers and input on the SECOND pass under FusedSGD(lr=0)
+    (statistics from the conv epilogues, gradients into the optimizer's sinks).  Returns (relative forward difference,
+    {parameter: gradient difference / max|g|}, kink distance of the batch)."""
     import copy
     from megreader_amd.optim import FusedSGD
     mr.set_compute_dtype(torch.float32)
     torch.manual_seed(1)
     full = deformable_resnet50(pretrained=False)
-    perturb_offset_convs(full)                            # non-zero offsets: samples off the bilinear kinks
+    perturb_offset_convs(full, kink_safe=kink_safe)
     plain = full.layer2.to(DEV).train()
     fast = copy.deepcopy(plain)
     x = torch.randn(2, 256, 24, 32, device=DEV)
-
-    def loss_of(model):
-        return (model(x).float() ** 2).mean()
-
-    loss_of(plain).backward()
+    dist = min_kink_distance(copy.deepcopy(plain), x)     # on a copy: `plain` must see its FIRST forward below
+    yp = plain(x)
+    (yp.float() ** 2).mean().backward()
     ref = {k: p.grad.detach().clone() for k, p in plain.named_parameters() if p.grad is not None}
     opt = FusedSGD(fast.parameters(), lr=0.0, momentum=0.0)
     for it in range(2):                                   # 1st: learns the conv -> bn pairs; 2nd: statistics from the epilogue
         opt.zero_grad()
-        loss_of(fast).backward()
+        yf = fast(x)
+        (yf.float() ** 2).mean().backward()
     producers = [m for m in fast.modules() if getattr(m, "feeds_batch_norm", False)]
     assert len(producers) == 9, len(producers)            # conv1 / conv3 of 4 blocks + the downsample conv (conv2 is the DCN)
-    bad, worst = [], (None, 0.0)
+    fwd = float((yf.detach().float() - yp.detach().float()).abs().max() / yp.detach().float().abs().max())
+    errs = {}
     for k, p in fast.named_parameters():
         assert k in ref and p.grad is not None and p.grad.data_ptr() == p._mr_grad_sink.data_ptr(), k      # still the sink
         scale = float(ref[k].abs().max())
-        if scale < 1e-9:
-            continue
-        err = float((p.grad - ref[k]).abs().max()) / scale
-        if err > worst[1]:
-            worst = (k, err)
-        if err > 2e-4:
-            bad.append((k, err))
-    print("fast paths vs plain autograd: worst gradient difference %.2e of max|g| (%s)" % (worst[1], worst[0]))
+        if scale >= 1e-9:
+            errs[k] = float((p.grad - ref[k]).abs().max()) / scale
+    return fwd, errs, dist
+
+
+def test_fast_paths_equal_plain_autograd():
+    """What the benchmarked step runs and the one-step parity tests do not: from the SECOND training forward on, every conv
+    in front of a BatchNorm supplies the batch statistics from its GEMM epilogue, and with a fused optimizer every weight
+    gradient -- incl. the 27-channel offset convolutions (Cout < stored channels) and the DCN weights -- is accumulated
+    straight into the optimizer's flat buffer.  Same layers, same input: outputs and gradients must equal those of a first
+    forward with plain autograd and no optimizer (float32; differences = summation order of atomics).
+    Kink-safe offsets (module docstring): the comparison is then smooth, 50 of 50 repetitions on one MI355X stay below 2e-5
+    (tools/diag_fast_paths.py --kink-safe, profiles/r04_diag_fast_paths_after.txt)."""
+    fwd, errs, dist = _fast_vs_plain(kink_safe=True)
+    worst = max(errs, key=errs.get)
+    print("fast paths vs plain autograd (kink-safe offsets, kink distance %.3f): forward difference %.2e of max|y|, worst "
+          "gradient difference %.2e of max|g| (%s)" % (dist, fwd, errs[worst], worst))
+    assert dist >= 0.1, dist
+    assert fwd < 2e-5, fwd
+    bad = [(k, e) for k, e in errs.items() if e > 2e-4]
     assert not bad, bad[:8]
+
+
+def test_fast_paths_forward_with_feature_dependent_offsets():
+    """Same two runs with the default perturbation (offsets spread over the real line, some coordinates within 1e-5 of a kink):
+    the FORWARD outputs are continuous in the offsets and must still agree; gradients are not compared (module docstring)."""
+    fwd, errs, dist = _fast_vs_plain(kink_safe=False)
+    print("fast paths vs plain autograd (feature-dependent offsets, kink distance %.1e): forward difference %.2e of max|y|; "
+          "largest gradient difference %.2e (not asserted: bilinear kinks)" % (dist, fwd, max(errs.values())))
+    assert fwd < 2e-5, fwd

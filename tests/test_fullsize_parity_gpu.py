@@ -65,7 +65,6 @@ class Res50Model(torch.nn.Module):
         return self.decoder(self.backbone(data), *args, **kwargs)
 
 
-_CACHE = {}
 
 
 def _f64_grads(ora32, batch):
@@ -80,26 +79,11 @@ def _f64_grads(ora32, batch):
 
 def _crnn_oracle_run():
     """One oracle training forward/backward (f32 = the reference's arithmetic, and f64 = ground truth for gradients)
-    + eval at N=256, 32x128 (about 15 s of CPU), shared by the tests."""
-    if "crnn" in _CACHE:
-        return _CACHE["crnn"]
-    torch.manual_seed(4321)
-    ora = CRNNOracle()
-    state0 = {k: v.clone() for k, v in ora.state_dict().items()}
-    batch = synthetic_batch(256, 32, 128, seed=11)
-    t0 = time.time()
-    grads64 = _f64_grads(ora, batch)
-    ora.train()
-    loss, logp = ora(batch['image'], targets=batch['label'], lengths=batch['length'].long(), train=True)
-    loss.mean().backward()
-    grads = {k: p.grad.detach().clone() for k, p in ora.named_parameters()}
-    state1 = {k: v.clone() for k, v in ora.state_dict().items()}   # BN running stats moved by the training forward
-    ora.eval()
-    with torch.no_grad():
-        ev = ora(batch['image'], train=False)
-    print("oracle CRNN N=256 fwd+bwd (f32 and f64) + eval: %.1f s" % (time.time() - t0))
-    _CACHE["crnn"] = (state0, state1, batch, float(loss), logp.detach(), (grads, grads64), ev)
-    return _CACHE["crnn"]
+    + eval at N=256, 32x128 (about 15 s of CPU), memoised in tests/_cases.py and shared with tests/test_timed_step_gpu.py."""
+    import _cases
+    c = _cases.crnn_n256()
+    return (c["state0"], c["state1"], c["batch"], c["out32"]["loss"], c["out32"]["logp"], (c["grads32"], c["grads64"]),
+            c["out32"]["eval"])
 
 
 def _grad_report(named_params, grads_pair, what):

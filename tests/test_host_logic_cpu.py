@@ -277,3 +277,64 @@ def test_bench_json_is_the_last_stdout_line_even_with_native_stdio_output():
     assert out.returncode == 0, out.stderr[-500:]
     lines = out.stdout.strip().splitlines()
     assert lines[-1] == '{"ok": 1}' and "banner (buffered in C stdio)" in lines and "late banner" not in lines, lines
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dropin.fuse_optimizers(): torch.optim.Adam / SGD stay classes -- isinstance, subclassing and the CPU
+# fall-through keep working; the fused construction itself needs a GPU (tests/test_dropin_fast_gpu.py).
+# ---------------------------------------------------------------------------------------------------------------
+def test_fused_optimizer_alias_is_still_a_class():
+    import torch
+    from megreader_amd import dropin
+    adam0, sgd0 = torch.optim.Adam, torch.optim.SGD
+    try:
+        assert dropin.fuse_optimizers() == ["Adam", "SGD"]
+        alias = torch.optim.Adam
+        dropin.fuse_optimizers()                                   # idempotent: not wrapped twice
+        assert torch.optim.Adam is alias and alias._mr_original is adam0
+        assert isinstance(alias, type) and issubclass(alias, adam0) and alias.__name__ == "Adam"
+        w = torch.nn.Parameter(torch.randn(4, 3))
+        opt = torch.optim.Adam((p for p in [w]), lr=1e-2)          # CPU parameters (a generator, like model.parameters())
+        assert type(opt) is alias and isinstance(opt, adam0) and isinstance(opt, torch.optim.Optimizer)
+        assert opt.param_groups[0]["params"][0] is w and opt.defaults["lr"] == 1e-2
+        w.grad = torch.ones_like(w)
+        before = w.detach().clone()
+        opt.step()
+        assert not torch.equal(before, w.detach())
+
+        class Mine(torch.optim.SGD):                               # third-party style subclass of the aliased name
+            def extra(self):
+                return len(self.param_groups)
+        mine = Mine([w], lr=0.1, momentum=0.9)
+        assert isinstance(mine, sgd0) and mine.extra() == 1 and mine.defaults["momentum"] == 0.9
+        # positional hyper-parameters / unsupported options fall through to torch's own optimizer
+        assert isinstance(torch.optim.SGD([w], 0.1), sgd0)
+        assert isinstance(torch.optim.Adam([w], lr=1e-3, amsgrad=True), adam0)
+    finally:
+        torch.optim.Adam, torch.optim.SGD = adam0, sgd0
+
+
+def test_sync_bn_switch_is_an_explicit_hook():
+    """backbones/resnet.py:bn() follows the callable registered by dropin.install() (the reference's own config.sync_bn), not a
+    `config` module that merely happens to be importable."""
+    import sys
+    import types
+    from megreader_amd.backbones import resnet
+    from megreader_amd.nn import BatchNorm2d
+    old = resnet._sync_bn_source
+    fake = types.ModuleType("config")
+    fake.sync_bn = True
+    had = sys.modules.get("config")
+    sys.modules["config"] = fake
+    try:
+        resnet.set_sync_bn_source(None)
+        assert type(resnet.bn(8)) is BatchNorm2d                   # a stray module named config changes nothing
+        resnet.set_sync_bn_source(lambda: 1)                       # truthiness, like `if config.sync_bn:`
+        from megreader_amd.apex.parallel import SyncBatchNorm
+        assert type(resnet.bn(8)) is SyncBatchNorm
+    finally:
+        resnet.set_sync_bn_source(old)
+        if had is None:
+            del sys.modules["config"]
+        else:
+            sys.modules["config"] = had

@@ -8,83 +8,36 @@ every-element-of-every-gradient pattern of tests/test_fullsize_parity_gpu.py at
       configs[4]; experiments/seg_detector/seg_detector_db.yaml:53,73)
 
 against the CPU oracle on the same seeded weights and batch.  Bars: tests/_parity.py.  The measured maxima are printed
-(and listed in DESIGN.md section 5).  The oracle runs take 1-2 minutes of host time each (float64 + float32 CPU passes).
+(and listed in DESIGN.md section 5).  The oracle runs (float64 + float32 CPU passes, 15-50 s each) are memoised in
+tests/_cases.py and shared with tests/test_timed_step_gpu.py, which holds steps >= 2 and the hipGraph replay to the same bars.
 """
-import time
-
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
 import megreader_amd as mr  # noqa: E402
-from _parity import f64_grads, grad_report  # noqa: E402
+import _cases  # noqa: E402
+from _parity import REPORT, grad_report  # noqa: E402
 
 DEV = "cuda"
 
 
 @pytest.fixture(autouse=True)
 def _reset_dtype():
-    # the CPU oracle's summation order (hence its last-bit results) depends on the thread count: restore it, so that the
-    # tests that run later in the same process see the oracle they were written against
-    threads = torch.get_num_threads()
     yield
     mr.set_compute_dtype(torch.bfloat16)
-    torch.set_num_threads(threads)
-
-
-def _threads():
-    import os
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(n, 64)))
 
 
 # ------------------------------------------------------------------------------------------------ (a) Res50-PPM N = 256
 def test_res50ppm_2dctc_fp32_n256_elementwise():
-    from megreader_amd.backbones import resnet50dilated_ppm
-    from megreader_amd.decoders import CTCDecoder2D
-    from oracle.res50ppm import Res50PPM2DCTCOracle, synthetic_batch_2d
-
-    class Model(torch.nn.Module):  # structure/model.py:16-24
-        def __init__(self):
-            super().__init__()
-            self.backbone = resnet50dilated_ppm()
-            self.decoder = CTCDecoder2D(in_channels=256)
-
-        def forward(self, data, *a, **k):
-            return self.decoder(self.backbone(data), *a, **k)
-
-    _threads()
+    case = _cases.res50ppm_n256()
     mr.set_compute_dtype(torch.float32)
-    torch.manual_seed(99)
-    ora = Res50PPM2DCTCOracle(dropout=0.0)
-    model = Model()
-    model.load_state_dict(ora.state_dict(), strict=True)
-    for m in model.modules():
-        if isinstance(m, torch.nn.Dropout2d):
-            m.p = 0.0
-    model.to(DEV).train()
-    n, height, width = 256, 32, 128          # what bench.py times (bench.py: synthetic_batch_2d(bsz, 32, 128, max_len=3))
-    batch = synthetic_batch_2d(n, height, width, seed=5, max_len=3)
+    model = case["build"]()
+    batch, out64 = case["batch"], case["out64"]
     lab, ln = batch['label'], batch['length'].long()
-
-    out64 = {}
-
-    def fwd(m, dt):
-        loss, pred = m(batch['image'].to(dt), targets=lab, lengths=ln, train=True)
-        if dt == torch.float64:
-            out64['pred'], out64['loss'] = pred.detach(), loss.detach()
-        return loss.mean()
-
-    t0 = time.time()
-    grads64 = f64_grads(ora, fwd)
-    ora.train()
-    loss_o, pred_o = ora(batch['image'], targets=lab, lengths=ln, train=True)
-    loss_o.mean().backward()
-    print("oracle Res50-PPM-2DCTC %dx%d N=%d fwd+bwd (f32 and f64): %.1f s" % (height, width, n, time.time() - t0))
+    loss_o, pred_o = case["out32"]["loss"], case["out32"]["pred"]
+    grads_o, grads64 = case["grads32"], case["grads64"]
     img = batch['image'].to(DEV)
     loss, pred = model(img, targets=lab.to(DEV), lengths=ln.to(DEV), train=True)
     lerr = float(((loss.cpu() - loss_o).abs() / loss_o.abs().clamp_min(1.0)).max())
@@ -99,11 +52,11 @@ def test_res50ppm_2dctc_fp32_n256_elementwise():
     e_cpu = float((pred_o.double() - pred64).abs()[finite].max())
     print("Res50-PPM-2DCTC fp32 N=256: loss rel |d| %.2e; log-prob max|d|: HIP vs f32 oracle %.2e; vs f64 oracle: HIP %.2e, "
           "f32 oracle %.2e  (%d%% of entries finite)" % (lerr, perr, e_hip, e_cpu, int(100 * float(finite.float().mean()))))
+    REPORT["Res50-PPM-2DCTC fp32 N=256 log-probs"] = {"hip_vs_f32": perr, "hip_vs_f64": e_hip, "f32_vs_f64": e_cpu}
     assert lerr < 1e-4
     assert e_hip < max(1e-4, 2 * e_cpu), (e_hip, e_cpu)
     assert perr < 3e-4
     loss.mean().backward()
-    grads_o = {k: p.grad for k, p in ora.named_parameters() if p.grad is not None}
     named = [(k, p) for k, p in model.named_parameters() if k in grads_o]
     for k, p in model.named_parameters():
         if k not in grads_o:
@@ -113,45 +66,13 @@ def test_res50ppm_2dctc_fp32_n256_elementwise():
 
 # --------------------------------------------------------------------------------------- (b) FPN50 + attention, N = 32
 def test_fpn_attention_fp32_n32_elementwise():
-    from megreader_amd.backbones import Resnet50FPN
-    from megreader_amd.decoders import AttentionDecoder
-    from oracle.crnn import synthetic_batch
-    from oracle.fpn_attention import FPNAttentionOracle
-
-    class Model(torch.nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.backbone = Resnet50FPN(resnet_pretrained=False)
-            self.decoder = AttentionDecoder(in_channels=256, gt_as_output=True)
-
-        def forward(self, data, *a, **k):
-            return self.decoder(self.backbone(data), *a, **k)
-
-    _threads()
+    case = _cases.fpn_attention_n32()
     mr.set_compute_dtype(torch.float32)
-    torch.manual_seed(2024)
-    ora = FPNAttentionOracle()
-    model = Model()
-    model.load_state_dict(ora.state_dict(), strict=True)
-    model.to(DEV).train()
-    n = 32
-    batch = synthetic_batch(n, 64, 256, seed=21)
+    model = case["build"]()
+    ora, batch, out64 = case["ora"], case["batch"], case["out64"]
     lab, ln = batch['label'], batch['length'].long()
-
-    out64 = {}
-
-    def fwd(m, dt):
-        loss, att = m(batch['image'].to(dt), targets=lab, lengths=ln, train=True)
-        if dt == torch.float64:
-            out64['loss'], out64['att'] = loss.detach(), att.detach()
-        return loss.mean()
-
-    t0 = time.time()
-    grads64 = f64_grads(ora, fwd)
-    ora.train()
-    loss_o, att_o = ora(batch['image'], targets=lab, lengths=ln, train=True)
-    loss_o.mean().backward()
-    print("oracle FPN50-attention 64x256 N=%d fwd+bwd (f32 and f64): %.1f s" % (n, time.time() - t0))
+    loss_o, att_o = case["out32"]["loss"], case["out32"]["att"]
+    grads_o, grads64 = case["grads32"], case["grads64"]
     loss, att = model(batch['image'].to(DEV), targets=lab.to(DEV), lengths=ln.to(DEV), train=True)
     assert loss.shape == loss_o.shape and att.shape == att_o.shape
     lerr = float(((loss.cpu() - loss_o).abs() / loss_o.abs().clamp_min(1.0)).max())
@@ -166,7 +87,6 @@ def test_fpn_attention_fp32_n32_elementwise():
           (lerr, le_hip, le_cpu, aerr, ae_hip, ae_cpu))
     assert le_hip < max(1e-4, 4 * le_cpu) and ae_hip < max(1e-4, 4 * ae_cpu)
     loss.mean().backward()
-    grads_o = {k: p.grad for k, p in ora.named_parameters() if p.grad is not None}
     for k, p in model.named_parameters():
         if k not in grads_o:
             assert p.grad is None, k          # unused fc / smooth of the plain ResNet
@@ -184,6 +104,7 @@ def test_fpn_attention_fp32_n32_elementwise():
     with torch.no_grad():
         pred_o = ora(batch['image'], train=False)
         pred = model(batch['image'].to(DEV), train=False)
+    ora.train()
     same = (pred.cpu() == pred_o)
     print("FPN50-attention eval: greedy decode %d of %d positions identical" % (int(same.sum()), same.numel()))
     assert pred.dtype == torch.int32 and bool(same.all())
@@ -197,55 +118,14 @@ def test_db_detector_fp32_640_elementwise():
     gradients (and through them the conv2_offset gradients) are still full-size non-trivial tensors.  Non-zero offsets
     are covered per layer shape by tests/test_dcn_gpu.py::test_real_layer_shapes_vs_oracle and block-wise by
     tests/test_deformable_resnet_gpu.py."""
-    from megreader_amd.backbones import deformable_resnet50
-    from megreader_amd.decoders import L1BalanceCELoss, SegDetector
-    from megreader_amd.synthetic import detection_batch
-    from oracle.res50ppm import _Res50Dilated
-    from oracle.seg_detector import SegDetectorOracle, l1_balance_ce_loss
+    from megreader_amd.decoders import L1BalanceCELoss
 
-    class Oracle(torch.nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.backbone = _Res50Dilated(dilate=False, dcn=True)
-            self.decoder = SegDetectorOracle(in_channels=[256, 512, 1024, 2048], adaptive=True, k=50)
-
-        def forward(self, image):
-            return self.decoder(self.backbone(image))
-
-    class Model(torch.nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.backbone = deformable_resnet50(pretrained=False)
-            self.decoder = SegDetector(in_channels=[256, 512, 1024, 2048], adaptive=True, k=50)
-
-        def forward(self, image):
-            return self.decoder(self.backbone(image))
-
-    _threads()
+    case = _cases.db_n2()
     mr.set_compute_dtype(torch.float32)
-    torch.manual_seed(7)
-    ora = Oracle()
-    model = Model()
-    model.load_state_dict(ora.state_dict(), strict=True)
-    model.to(DEV).train()
-    n, size = 2, 640
-    batch = detection_batch(n, size, seed=3)
-
-    out64 = {}
-
-    def fwd(m, dt):
-        p = m(batch['image'].to(dt))
-        if dt == torch.float64:
-            out64.update({k: v.detach() for k, v in p.items()})
-        return l1_balance_ce_loss(p, {k: v.to(dt) for k, v in batch.items()})
-
-    t0 = time.time()
-    grads64 = f64_grads(ora, fwd)
-    ora.train()
-    pred_o = ora(batch['image'])
-    loss_o = l1_balance_ce_loss(pred_o, batch)
-    loss_o.backward()
-    print("oracle DB detector %dx%d N=%d fwd+bwd (f32 and f64): %.1f s" % (size, size, n, time.time() - t0))
+    model = case["build"]()
+    batch, out64 = case["batch"], case["out64"]
+    pred_o, loss_o, l64 = case["out32"]["pred"], case["out32"]["loss"], case["out32"]["loss64"]
+    grads_o, grads64 = case["grads32"], case["grads64"]
     dbatch = {k: v.to(DEV) for k, v in batch.items()}
     pred = model(dbatch['image'])
     loss, _ = L1BalanceCELoss()(pred, dbatch)
@@ -258,13 +138,11 @@ def test_db_detector_fp32_640_elementwise():
         print("DB fp32 640x640: %-13s max|d| HIP vs f32 oracle %.2e; vs f64 oracle: HIP %.2e, f32 oracle %.2e" %
               (k, e, e_hip, e_cpu))
         assert e_hip < max(1e-4, 4 * e_cpu), (k, e_hip, e_cpu)
-    l64 = float(l1_balance_ce_loss(out64, {k: v.double() for k, v in batch.items()}))
     lerr, lcpu = abs(float(loss) - l64), abs(float(loss_o) - l64)
     print("DB fp32 640x640: loss %.6f (f32 oracle %.6f, f64 oracle %.6f): |d| vs f64 HIP %.2e, f32 oracle %.2e" %
           (float(loss), float(loss_o), l64, lerr, lcpu))
     assert lerr < max(1e-4 * max(1.0, abs(l64)), 4 * lcpu)
     loss.backward()
-    grads_o = {k: p.grad for k, p in ora.named_parameters() if p.grad is not None}
     for k, p in model.named_parameters():
         if k not in grads_o:
             assert p.grad is None, k          # fc / smooth
