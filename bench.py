@@ -78,54 +78,112 @@ def kernel_source_hash():
 
 
 def pmc_traffic(label, workload="crnn"):
-    """HBM-side bytes per launch of `label` from the committed PMC passes (profiles/r03_pmc_traffic_<workload>.json,
-    produced by tools/profile_r03.sh + tools/pmc_to_json.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
-    this same command, FETCH_SIZE doubled for gfx950).  PMC counters cannot be read inside this process, so the file is
-    stamped with a hash of the kernel sources it was measured on: a stale file (kernels edited since) yields traffic = null
-    instead of a number that no longer describes the code."""
-    name = "r03_pmc_traffic_%s.json" % workload
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
-    try:
-        data = json.load(open(path))
-    except (OSError, ValueError):
-        return None, None
-    if data.get("_kernel_source_hash") != kernel_source_hash():
-        return None, "profiles/%s is stale (measured on kernel sources %s, current %s)" % \
-            (name, data.get("_kernel_source_hash"), kernel_source_hash())
-    if label not in data:
-        return None, None
-    return data[label]["bytes_per_launch"], "profiles/%s (rocprofv3 --pmc, %d launches)" % \
-        (name, data[label]["launches"])
+    """HBM-side bytes per launch of `label` from the committed PMC passes (profiles/rNN_pmc_traffic_<workload>.json, produced
+    by tools/profile_r04.sh + tools/pmc_to_json.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same
+    command, FETCH_SIZE doubled for gfx950).  PMC counters cannot be read inside this process, so each file is stamped with a
+    hash of the kernel sources it was measured on: the newest file whose stamp equals the current sources is used; if none
+    does (kernels edited since) traffic = null instead of a number that no longer describes the code."""
+    import glob
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    paths = sorted(glob.glob(os.path.join(prof, "r[0-9][0-9]_pmc_traffic_%s.json" % workload)), reverse=True)
+    current = kernel_source_hash()
+    stale = None
+    for path in paths:
+        try:
+            data = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        name = os.path.basename(path)
+        if data.get("_kernel_source_hash") != current:
+            stale = stale or "profiles/%s is stale (measured on kernel sources %s, current %s)" % \
+                (name, data.get("_kernel_source_hash"), current)
+            continue
+        if label not in data:
+            return None, None
+        return data[label]["bytes_per_launch"], "profiles/%s (rocprofv3 --pmc, %d launches)" % \
+            (name, data[label]["launches"])
+    return None, stale
 
 
-def cpu_baseline(batch_size=64, budget_s=20.0):
-    """Oracle CRNN train step (torch CPU kernels, fp32 weights, fp64 CTC -- what the reference executes) on the
-    host cores; a bounded sample (smaller batch, a few steps) of the same workload."""
-    from oracle.crnn import CRNNOracle, synthetic_batch, train_step
+def _host_threads():
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(avail, 32))  # more threads than this only add contention at these tensor sizes
+    return max(1, min(avail, 32)), avail  # more threads than this only add contention at these tensor sizes
+
+
+def cpu_baseline(workload="crnn", budget_s=20.0):
+    """The oracle restatement of the reference model (oracle/: torch CPU kernels, fp32 weights, the reference's own fp64 /
+    numpy CTC -- what the reference executes on a CPU) timed on this box's host cores: a BOUNDED sample of the same workload
+    (one warm-up step, then whole training steps until about half the budget is used; at least one).  CRNN runs at the
+    benchmarked batch 256; the three bigger models at a smaller batch, stated in `sample`.  kind = "port"."""
+    threads, avail = _host_threads()
     torch.set_num_threads(threads)
     torch.manual_seed(0)
-    model = CRNNOracle().train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    batch = synthetic_batch(batch_size, 32, 128, seed=0)
+    if workload == "crnn":
+        from oracle.crnn import CRNNOracle, synthetic_batch
+        model, n = CRNNOracle().train(), 256
+        batch = synthetic_batch(n, 32, 128, seed=0)
+        what = "batch 256 (32x128 crops, the benchmarked batch)"
+    elif workload == "res50ppm":
+        from oracle.res50ppm import Res50PPM2DCTCOracle, synthetic_batch_2d
+        model, n = Res50PPM2DCTCOracle().train(), 64
+        batch = synthetic_batch_2d(n, 32, 128, seed=0, max_len=3)
+        what = "batch 64 of the benchmarked 256 (32x128 crops)"
+    elif workload == "fpn_attention":
+        from oracle.crnn import synthetic_batch
+        from oracle.fpn_attention import FPNAttentionOracle
+        model, n = FPNAttentionOracle().train(), 32
+        batch = synthetic_batch(n, 64, 256, seed=0)
+        what = "batch 32 (64x256 crops, the benchmarked per-GPU batch), gt_as_output fixed"
+    else:
+        from megreader_amd.synthetic import detection_batch
+        from oracle.res50ppm import _Res50Dilated
+        from oracle.seg_detector import SegDetectorOracle, l1_balance_ce_loss
+
+        class DB(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.backbone = _Res50Dilated(dilate=False, dcn=True)
+                self.decoder = SegDetectorOracle(in_channels=[256, 512, 1024, 2048], adaptive=True, k=50)
+
+            def forward(self, image):
+                return self.decoder(self.backbone(image))
+        model, n = DB().train(), 2
+        batch = detection_batch(n, 640, seed=0)
+        what = "batch 2 (640x640 images, the benchmarked per-GPU batch); DCNv2 = the float32 torch restatement (oracle/dcn.py)"
+    if workload == "db":
+        opt = torch.optim.SGD(model.parameters(), lr=0.007, momentum=0.9, weight_decay=1e-4)
+
+        def step():
+            opt.zero_grad()
+            loss = l1_balance_ce_loss(model(batch['image']), batch)
+            loss.backward()
+            opt.step()
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        lab, ln = batch['label'], batch['length'].long()
+
+        def step():
+            opt.zero_grad()
+            loss, _ = model(batch['image'], targets=lab, lengths=ln, train=True)
+            loss.mean().backward()
+            opt.step()
     t0 = time.perf_counter()
-    train_step(model, opt, batch)  # warm-up
+    step()  # warm-up
     warm = time.perf_counter() - t0
-    max_steps = 20 if warm < 8.0 else 1
+    max_steps = 20 if warm < 0.25 * budget_s else 1
     t0 = time.perf_counter()
     steps = 0
     while steps < max_steps and (steps < 1 or time.perf_counter() - t0 < 0.5 * budget_s):
-        train_step(model, opt, batch)
+        step()
         steps += 1
     dt = time.perf_counter() - t0
-    return {"value": round(batch_size * steps / dt, 2), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": "%d CPU train steps of batch %d (32x128 crops) with the oracle restatement of the reference "
-                      "model, torch %s CPU kernels, %d threads (%d cores visible), %.1f s" %
-                      (steps, batch_size, torch.__version__, threads, avail, dt)}
+    return {"value": round(n * steps / dt, 2), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "%d CPU training step(s) at %s with the oracle restatement of the reference model, torch %s CPU kernels, "
+                      "%d threads (%d cores visible), %.1f s after one warm-up step of %.1f s" %
+                      (steps, what, torch.__version__, threads, avail, dt, warm)}
 
 
 def quiet_native_stdout():
@@ -162,7 +220,11 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the ResNet50-PPM-2D-CTC secondary measurement of the default single-GPU run")
+                    help="skip the secondary measurements (configs[2..4]) of the default single-GPU run")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --batch crops PER GPU, global batch = batch x N.  strong: the reference's rule "
+                         "(data/data_loader.py:40-48 `batch_size // world_size`): the workload's GLOBAL batch (256 crops; 16 "
+                         "images for db) is sharded over the N ranks, --batch is then the global batch")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
     ap.add_argument("--force-ddp", action="store_true",
@@ -297,14 +359,22 @@ def main():
             ddp_shim = DistributedDataParallel(model)
             ddp_shim.fold_average_into(opt)
         bsz = args.batch
+        if args.scaling == "strong":
+            # the reference shards ONE global batch: per-rank batch = global // world (data/data_loader.py:40-48)
+            glob = args.batch if args.batch != 256 else (16 if is_db else 256)
+            if glob % world:
+                raise SystemExit("--scaling strong: global batch %d is not divisible by %d ranks" % (glob, world))
+            bsz = glob // world
         if is_db:
-            bsz = args.batch if args.batch != 256 else 2           # configs[4]: 16 global = 2 per GPU on 8 GPUs
+            if args.scaling != "strong":
+                bsz = args.batch if args.batch != 256 else 2           # configs[4]: 16 global = 2 per GPU on 8 GPUs
             dbatch = {k: v.to(dev) for k, v in detection_batch(bsz, 640, seed=rank).items()}
             batch = {'image': dbatch['image'], 'label': torch.zeros(1), 'length': torch.zeros(1)}
         elif workload == "res50ppm":
             batch = synthetic_batch_2d(bsz, 32, 128, seed=rank, max_len=3)
         elif workload == "fpn_attention":
-            bsz = args.batch if args.batch != 256 else 32      # configs[3]: 256 global = 32 per GPU on 8 GPUs
+            if args.scaling != "strong":
+                bsz = args.batch if args.batch != 256 else 32      # configs[3]: 256 global = 32 per GPU on 8 GPUs
             batch = synthetic_batch(bsz, 64, 256, seed=rank)
         else:
             batch = synthetic_batch(bsz, 32, 128, seed=rank)
@@ -453,18 +523,18 @@ def main():
                                  "crops, 32 decode steps, teacher forcing fixed (gt_as_output), Adam")
                 fwd_flops = 17.25e9  # 5.01 backbone + 10.97 decoder conv encoder + 1.27 decode loop
             elif workload == "res50ppm":
-                metric_name = "training images/sec, ResNet50-PPM-2D-CTC 32x128 crops, batch %d per GPU" % args.batch
+                metric_name = "training images/sec, ResNet50-PPM-2D-CTC 32x128 crops, batch %d per GPU" % bsz
                 workload_name = ("ResNet50-dilated-PPM + 2D-CTC training step (BASELINE.json configs[2]): 32x128 crops, "
                                  "T=16 H=4 C=38, Adam")
                 fwd_flops = 6.02e9  # forward FLOPs per 32x128 image
             else:
-                metric_name = "training images/sec, CRNN-CTC 32x128 crops, batch 256 per GPU"
+                metric_name = "training images/sec, CRNN-CTC 32x128 crops, batch %d per GPU" % bsz
                 workload_name = "CRNN + 1D-CTC training step (BASELINE.json configs[1]): 32x128 crops, T=33, C=38, Adam"
                 fwd_flops = 1.80e9
             out = {
                 "metric": metric_name,
                 "value": round(images / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": steps,
-                "warmup": warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+                "warmup": warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": args.scaling,
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": workload_name, "global_batch": bsz * world,
                            "per_gpu_batch": bsz, "parallelism": "dp%d" % world,
@@ -482,8 +552,8 @@ def main():
             step_tflops = 3 * fwd_flops * bsz / (ms * 1e-3) / 1e12
             out["step_tflops_per_gpu"] = round(step_tflops, 2)
             out["host_enqueue_ms_per_step"] = round(1e3 * host_enqueue / steps, 3)
-            if world == 1 and with_cpu and workload == "crnn":
-                out["cpu_baseline"] = cpu_baseline()
+            if world == 1 and with_cpu:
+                out["cpu_baseline"] = cpu_baseline(workload, budget_s=20.0 if workload == "crnn" else 12.0)
             else:
                 out["cpu_baseline"] = None
         else:
@@ -492,11 +562,17 @@ def main():
 
     out = measure(args.workload, args.steps, args.warmup, not args.no_cpu_baseline)
     if out is not None and world == 1 and not distributed and args.workload == "crnn" and not args.no_secondary:
-        # BASELINE.json north_star target #2 (configs[2]) rides along in the default single-GPU line
-        sec = measure("res50ppm", min(args.steps, 10), min(args.warmup, 3), False)
-        for k in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "cpu_baseline"):
-            sec.pop(k, None)
-        out["secondary"] = sec
+        # the other three published configurations ride along in the default single-GPU line: BASELINE.json north_star
+        # target #2 (configs[2], also kept under the round-1..3 key `secondary`), configs[3] and configs[4]; each with its own
+        # roofline block and CPU baseline
+        out["secondaries"] = []
+        for wl in ("res50ppm", "fpn_attention", "db"):
+            sec = measure(wl, min(args.steps, 10), min(args.warmup, 3), not args.no_cpu_baseline)
+            for k in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data"):
+                sec.pop(k, None)
+            sec["workload"] = wl
+            out["secondaries"].append(sec)
+        out["secondary"] = out["secondaries"][0]
     if distributed:
         dist.destroy_process_group()
     emit_last_line(json.dumps(out) if out is not None else None)

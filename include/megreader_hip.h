@@ -29,10 +29,54 @@ extern "C" {
 
 const char* mr_last_error(void);
 int mr_abi_version(void);
-/* creates the per-device zero page (the library's only state) eagerly; call before hipGraph capture */
+/* creates the per-device zero page eagerly and applies MEGREADER_TUNING (below); call before hipGraph capture */
 int mr_init(void);
-/* 2 = direct-to-LDS NT kernel (default), 1 = register-staged NT kernel (A/B comparison); returns the old value */
-int mr_set_nt_variant(int v);
+
+/* ---- Tuning / A-B state: ONE struct -----------------------------------------------------------------------------------------
+ * Everything in the library that is process-wide and mutable, apart from the per-device zero page and the registered split-
+ * reduction workspace, is this struct.  Rounds 1-3 exported 26 separate `mr_set_*` functions over 26 unsynchronised globals;
+ * they are gone.  Every field selects between kernels that compute the SAME result (test / A-B / tuning hooks; the defaults are
+ * what bench.py measures); the timing-only ablations that compute wrong results exist only in the -DMR_ABLATION tools build
+ * (include/megreader_hip_ablation.h).
+ *   mr_tuning_get / mr_tuning_set  read / replace the whole struct (writers serialised by a mutex, values range-checked);
+ *   MEGREADER_TUNING="field=value,field=value"  is applied once by mr_init().
+ * Threading: the compute entry points may be called from any thread on any stream; each of them reads the fields it needs with
+ * single atomic loads, so a call that races with mr_tuning_set sees, per field, either the old or the new value -- never garbage.
+ * Flipping fields while a training step is in flight is still only meaningful for A/B measurements. */
+typedef struct mr_tuning {
+  int nt_variant;    /* 2 (default) = direct-to-LDS NT kernels, 1 = register-staged NT kernel */
+  int nt_deep;       /* pipeline depth of the 4-wave direct-to-LDS NT kernel: 1 (default) = launches with at most ~1.5 workgroups
+                        per CU and >= 8 k-steps (bf16) run with 4 LDS stage buffers and 3 k-steps of LDS-DMA in flight across raw
+                        barriers; 0 = always the 2-buffer loop; 2 = always the 4-buffer loop.  Same results bit for bit */
+  int nt_big;        /* 8-wave big-tile NT kernels (256x256 / 272x256 / 288x128): 0 automatic, -1 never, 1..7 forced variants */
+  int nt_p8;         /* 1 = phased-schedule 256x256 NT kernel (igemm_p8.h) for the big-tile launches, 0 (default) = plain */
+  int nt_force_bm;   /* force one 4-wave NT tile shape: bm in {128, 96, 64} with */
+  int nt_force_bn;   /* bn in {128, 64}; bm = 0 (default) = the cost model */
+  int gemm_skinny;   /* 1 (default): M <= 32 GEMMs (attention decode loop) take the latency-optimised kernel of gemm_skinny.hip */
+  int tn_big;        /* experimental wide-tile TN (weight-gradient) kernels: 1 = 256x256, 2 = 128x256, 0 / -1 = never (default) */
+  int tn_buf;        /* TN operand staging: 1 (default) = raw buffer resources (out-of-range -> zeros), 0 = flat pointers */
+  int tn_taps;       /* 1 (default): all-taps weight-gradient kernel for 3x3 / stride 1 / padding == dilation layers (tn_taps.hip)
+                        through mr_conv2d_wgrad_tab; the row table has another format for it: rebuild tables after changing this */
+  int tn_taps_group; /* split reduction of the all-taps kernel: 0 automatic, 1 atomics only, > 1 forced group size */
+  int tn_group;      /* same for the 128x128 TN GEMM kernel (uses the same workspace) */
+  int tn_fin;        /* 128x128 TN GEMM kernel: 2 = split partials -> slabs + finalize launch (measured slower), 0 (default) */
+  int tn_taps_fin;   /* all-taps kernel: 0 (default) leaders' atomics; 1 group sums added by a finalize launch; 2 no in-launch
+                        reduction, the finalize launch sums every split (1 and 2 measured within +-1 % of 0) */
+  int tn_taps_w8;    /* 1: 8-wave workgroup variant of the all-taps kernel (one per CU, half the partial tiles) */
+  int tn_model;      /* 1 (default): conv wgrad launches use the measured dense-GEMM split model */
+  int tn_splits;     /* P-split override of the TN kernels, 0 (default) = the makespan model */
+  int bn_fused;      /* 1 (default): BatchNorm finalisation folded into the apply passes (C % 64 == 0), 0 = separate launches */
+  int lstm_persist;  /* 1 (default): persistent recurrence kernels (bf16, H = 256); 0 = one launch per step; 2 = persistent
+                        without the XCD-colocating block map */
+  int lstm_fwd_bn;   /* step kernels: hidden columns per workgroup forward (0 automatic, 32, 64) */
+  int lstm_bwd_bn;   /* ... and backward (0 automatic, 16, 32 (default), 64) */
+  int dcn_fused;     /* 1 (default): fused DCNv2 kernels (dcn_fused.hip) where the shape allows; 0 = the general kernels */
+  int dcn_v1_bwd;    /* general DCN path: 1 (default) = round-1 backward kernels, 0 = the round-2 experiments */
+  int reserved[9];   /* zero */
+} mr_tuning;
+int mr_tuning_get(mr_tuning* out);
+int mr_tuning_defaults(mr_tuning* out);
+int mr_tuning_set(const mr_tuning* in);   /* MR_ERR_ARG (mr_last_error names the field) when a value is out of range */
 
 /* ---- GEMM family (replaces cuBLAS/cuDNN behind nn.Linear / nn.LSTM input projection:
  *      decoders/crnn.py:13-24; decoders/attention_decoder.py:187-231) ------------------------------------- */
@@ -41,50 +85,15 @@ int mr_gemm_nt(int dtype, const void* A, long long lda, const void* B, int ldb, 
                const float* bias, int relu, int M, int N, int K, hipStream_t stream);
 /* M <= 32 problems (the decode-loop GEMMs of the attention decoder) take a latency-optimised kernel (csrc/gemm_skinny.hip:
  * 16 output columns per workgroup, K split over the four waves, operands fetched as MFMA fragments straight from global
- * memory).  A/B switch (host only): 0 = the general tiled kernels; returns the previous setting. */
-int mr_set_gemm_skinny(int on);
-/* tuning override: force one NT tile shape (bm 128|96|64, bn 128|64); bm = 0 restores the cost model */
-int mr_force_nt_tile(int bm, int bn);
-/* big-tile (8-wave, 256x256 / 288x256) NT kernel policy: 0 automatic, -1 never, 1 / 2 force (tuning override);
- * returns the previous setting */
-int mr_set_nt_big(int mode);
-/* host only: pipeline depth of the 4-wave direct-to-LDS NT kernel.  1 (default) = launches with at most ~1.5 workgroups per CU
- * and >= 8 k-steps (bf16) run with 4 LDS stage buffers and 3 k-steps of LDS-DMA in flight across raw barriers; 0 = always the
- * 2-buffer loop; 2 = always the 4-buffer loop (tests / A-B).  Same results bit for bit.  Returns the previous setting. */
-int mr_set_nt_deep(int mode);
-/* host only: 1 = phased-schedule 256x256 NT kernel (igemm_p8.h) for the big-tile launches, 0 (default) = the v3
- * kernel (the timing-only ablation variants 2..4 exist only in the -DMR_ABLATION tools build) */
-int mr_set_nt_p8(int on);
-/* experimental wide-tile TN (weight-gradient) kernels: 1 = 256x256, 2 = 128x256, 0 / -1 = never (default; they are
- * currently slower, see gemm_conv.hip:launch_tn); returns the previous setting */
-int mr_set_tn_big(int mode);
-/* TN kernel operand staging: 1 = raw buffer resources (out-of-range -> zeros), 0 = flat pointers + zero page;
- * returns the previous setting */
-int mr_set_tn_buf(int mode);
-/* all-taps weight-gradient kernel for 3x3 / stride 1 / padding == dilation layers (csrc/tn_taps.hip): 1 = use it
- * through mr_conv2d_wgrad_tab where the geometry allows, 0 = never; returns the previous setting.  The row table passed
- * to mr_conv2d_wgrad_tab has a different format for the two kernels: rebuild it (build = 1) after changing this. */
-int mr_set_tn_taps(int mode);
+ * memory) unless mr_tuning.gemm_skinny = 0. */
 /* workspace of the all-taps kernel's in-launch split reduction: device memory zeroed once by the caller (16 KB of
  * tickets + 147456 B per workgroup of the largest launch = 2 * CUs slabs); NULL / 0 withdraws it (f32 atomics only).
  * Launches that use it must be stream-ordered with each other. */
 int mr_set_tn_taps_workspace(void* ws, long long bytes);
-int mr_set_tn_taps_group(int g);    /* tuning: 0 automatic, 1 atomics only, > 1 forced group size */
-int mr_set_tn_group(int g);         /* same for the 128x128 TN GEMM kernel (uses the same workspace) */
-int mr_set_tn_fin(int mode);        /* 128x128 TN GEMM kernel: 2 = split partials -> slabs (plain stores) + finalize launch (measured slower: opt-in); 0 (default): mr_set_tn_group */
-int mr_set_tn_taps_fin(int on);     /* 0 (default): group leaders' atomics; 1: group sums added into dw by a finalize launch; 2: no in-launch reduction, every workgroup's partial tile goes to its slab and the finalize launch sums the splits (1 and 2 measured within +-1 % of 0: opt-in) */
-int mr_set_tn_taps_w8(int on);      /* 1: 8-wave workgroup variant (one per CU, half the partial tiles) */
 /* host only: 1 when mr_conv2d_wgrad_tab (bf16, non-NULL row table) would run the all-taps kernel for this geometry
- * under the current mr_set_tn_taps setting */
+ * under the current mr_tuning.tn_taps setting */
 int mr_tn_taps_would_run(int N, int H, int W, int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw,
                          int ph, int pw, int dh, int dw, int Ho, int Wo);
-int mr_set_tn_model(int m);    /* A/B: 1 = conv wgrad uses the dense-GEMM split model too */
-int mr_set_tn_splits(int n);   /* tuning only: P-split override of the TN kernels, 0 = automatic */
-/* The process-global mr_set_* / mr_force_* switches in this header are TEST / TUNING hooks (A/B comparisons of kernels that
- * all compute the same result): they are not thread-safe and are not meant to be flipped while a training step is in flight.
- * The timing-only ABLATION switches whose kernels produce WRONG results by construction (mr_set_tn_abl, mr_set_tn_taps_abl,
- * mr_set_nt_p8(2..4)) are not part of this library: they are declared in include/megreader_hip_ablation.h and exist only in
- * the separate `make ablation` build (libmegreader_hip_abl.so, -DMR_ABLATION) that tools/ablate_*.py load. */
 /* tile (BM*1000+BN) the NT kernels pick for an M x N problem; host-only query used for profiling labels */
 int mr_nt_tile_code(int M, int N);
 /* same, including the big-tile policy (returns 256256 for the 8-wave 256x256 kernel); cg = channels of the gathered
@@ -198,8 +207,7 @@ int mr_sgd_step(float* p, const float* g, float* buf, long long n, float* hyper,
 /* doubles of reduction scratch mr_bn_fwd_train / mr_bn_bwd want for C channels (several accumulator copies: fewer
  * same-address atomics; the backward keeps 2*C f32 per-channel means behind them) */
 long long mr_bn_scratch_doubles(int C);
-/* 1 (default): training-mode BN folds its finalize kernels into the apply passes (C % 64 == 0); 0: separate launches */
-int mr_set_bn_fused(int on);
+/* training-mode BN folds its finalize kernels into the apply passes (C % 64 == 0) unless mr_tuning.bn_fused = 0 */
 int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* save_mean, float* save_rstd, double* sums, const void* residual,
                     int relu, long long P, int C, float eps, float momentum, long long* num_batches_tracked,
@@ -252,15 +260,12 @@ int mr_lstm_fwd(int dtype, const void* xproj, const void* whh, void* out, float*
                 int H, void* ws, long long ws_bytes, hipStream_t stream);
 int mr_lstm_bwd(int dtype, const void* dout, const void* whhT, const float* cbuf, void* gates, float* dc, int T,
                 int N, int H, void* ws, long long ws_bytes, hipStream_t stream);
-/* host only: workspace bytes the persistent recurrence wants (0 = not applicable: f32, H != 256, ...), and its
- * on/off switch (default on) */
+/* host only: workspace bytes the persistent recurrence wants (0 = not applicable: f32, H != 256, mr_tuning.lstm_persist = 0) */
 long long mr_lstm_ws_bytes(int dtype, int T, int N, int H);
-int mr_set_lstm_persist(int on);
 /* debug hook (host only): non-null -> the persistent backward also writes its reduced recurrent term [T,N,2H] f32 */
 int mr_lstm_debug_buffer(float* p);
-/* tuning knob (host only): column-tile width of the step kernels; 0 = LDS-staged split-K body, else the
- * direct-fragment body.  fwd_bn in {0,32,64}, bwd_bn in {0,16,32,64}; negative leaves the setting unchanged. */
-int mr_set_lstm_variant(int fwd_bn, int bwd_bn);
+/* (column-tile width of the step kernels: mr_tuning.lstm_fwd_bn / lstm_bwd_bn; 0 = LDS-staged split-K body, else the
+ * direct-fragment body) */
 
 /* ---- 1-D CTC fused with log-softmax (replaces log_softmax + nn.CTCLoss: decoders/crnn.py:48,96-98) ------- */
 int mr_ctc_fwd(int dtype, const void* logits, int ldl, const void* targets, int targets_i64,
@@ -351,8 +356,7 @@ int mr_dcn2_col2im(int dtype, const void* gcol, const float* offset, long long o
  * dw f32 [Co][kh*kw*C] and dbias f32 [Co] accumulated.  Any of the three output groups -- {doffset, dmask}, dx32, {dw, dbias} --
  * may be null: only the others are computed. */
 long long mr_dcn2_ws_bytes(int dtype, int N, int H, int W, int C, int Co, int kh, int kw, int Ho, int Wo, int backward);
-int mr_set_dcn_fused(int on);    /* A/B (host only): 0 = general kernels for every shape; returns the old value */
-int mr_set_dcn_v1_bwd(int on);   /* A/B (host only): 1 = round-1 DCN backward kernels */
+/* (mr_tuning.dcn_fused = 0: general kernels for every shape; mr_tuning.dcn_v1_bwd: backward variant of the general path) */
 int mr_dcn2_fwd(int dtype, const void* x, const void* w_n, const float* bias, const float* offset, long long off_bs,
                 const float* mask, long long msk_bs, void* y, void* col_ws, int N, int H, int W, int C, int Co, int kh,
                 int kw, int stride, int pad, int dil, int Ho, int Wo, hipStream_t stream);

@@ -13,7 +13,7 @@ extern "C" {
 int mr_set_tn_abl(int mask);
 /* ablation mask of the all-taps wgrad kernel (csrc/tn_taps.hip: ABL template parameter) */
 int mr_set_tn_taps_abl(int mask);
-/* mr_set_nt_p8(2..4): no LDS-DMA / no fragment reads / MFMA + barriers only variants of the phased 256x256 NT kernel */
+/* mr_tuning.nt_p8(2..4): no LDS-DMA / no fragment reads / MFMA + barriers only variants of the phased 256x256 NT kernel */
 #ifdef __cplusplus
 }
 #endif

@@ -105,6 +105,92 @@ SIGNATURES = {
 
 _lib = None
 
+TUNING_FIELDS = ("nt_variant", "nt_deep", "nt_big", "nt_p8", "nt_force_bm", "nt_force_bn", "gemm_skinny", "tn_big", "tn_buf",
+                 "tn_taps", "tn_taps_group", "tn_group", "tn_fin", "tn_taps_fin", "tn_taps_w8", "tn_model", "tn_splits",
+                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd")
+
+
+class Tuning(ctypes.Structure):
+    """struct mr_tuning (include/megreader_hip.h): the library's only process-wide switches."""
+    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 9)]
+
+
+def get_tuning():
+    """Current process-wide tuning state as a dict."""
+    t = Tuning()
+    if load().mr_tuning_get(ctypes.byref(t)) != 0:
+        raise RuntimeError("mr_tuning_get failed: %s" % load().mr_last_error().decode())
+    return {name: getattr(t, name) for name in TUNING_FIELDS}
+
+
+def set_tuning(**fields):
+    """Replace the named fields of the process-wide tuning state (mr_tuning_set); returns their previous values.  A/B and test
+    hook: every field selects between kernels that compute the same result (include/megreader_hip.h)."""
+    lib = load()
+    t = Tuning()
+    if lib.mr_tuning_get(ctypes.byref(t)) != 0:
+        raise RuntimeError("mr_tuning_get failed: %s" % lib.mr_last_error().decode())
+    old = {}
+    for name, value in fields.items():
+        if name not in TUNING_FIELDS:
+            raise KeyError("mr_tuning has no field %r" % name)
+        old[name] = getattr(t, name)
+        setattr(t, name, int(value))
+    if lib.mr_tuning_set(ctypes.byref(t)) != 0:
+        raise RuntimeError("mr_tuning_set failed: %s" % lib.mr_last_error().decode())
+    return old
+
+
+def _install_setter_shims(lib):
+    """Rounds 1-3 exported one `mr_set_<field>(value) -> previous value` function per switch; tests and tools still spell their
+    A/B toggles that way.  The C ABI now has ONE struct (mr_tuning_get / mr_tuning_set): these are Python callables of the old
+    names on the loaded library object, nothing more."""
+    def one(field, clamp=None):
+        def setter(value):
+            value = int(value)
+            if clamp is not None and not clamp(value):
+                return get_tuning()[field]          # the old setters ignored out-of-range values
+            return set_tuning(**{field: value})[field]
+        return setter
+    lib.mr_set_nt_variant = one("nt_variant", lambda v: v in (1, 2))
+    lib.mr_set_nt_deep = one("nt_deep", lambda v: 0 <= v <= 2)
+    lib.mr_set_nt_big = one("nt_big", lambda v: -1 <= v <= 7)
+    lib.mr_set_nt_p8 = one("nt_p8")
+    lib.mr_set_gemm_skinny = lambda v: one("gemm_skinny")(1 if v else 0)
+    lib.mr_set_tn_big = one("tn_big", lambda v: -1 <= v <= 2)
+    lib.mr_set_tn_buf = one("tn_buf", lambda v: v in (0, 1))
+    lib.mr_set_tn_taps = one("tn_taps", lambda v: v in (0, 1))
+    lib.mr_set_tn_taps_group = one("tn_taps_group", lambda v: v >= 0)
+    lib.mr_set_tn_group = one("tn_group", lambda v: v >= 0)
+    lib.mr_set_tn_fin = one("tn_fin", lambda v: v in (0, 2))
+    lib.mr_set_tn_taps_fin = one("tn_taps_fin", lambda v: 0 <= v <= 2)
+    lib.mr_set_tn_taps_w8 = one("tn_taps_w8", lambda v: v in (0, 1))
+    lib.mr_set_tn_model = lambda v: one("tn_model")(1 if v else 0)
+    lib.mr_set_tn_splits = lambda v: one("tn_splits")(max(0, int(v)))
+    lib.mr_set_bn_fused = one("bn_fused", lambda v: v in (0, 1))
+    lib.mr_set_dcn_fused = lambda v: one("dcn_fused")(1 if v else 0)
+    lib.mr_set_dcn_v1_bwd = lambda v: one("dcn_v1_bwd")(1 if v else 0)
+
+    def set_lstm_persist(on):
+        set_tuning(lstm_persist=int(on) if int(on) in (0, 1, 2) else 1)
+        return 0
+    lib.mr_set_lstm_persist = set_lstm_persist
+
+    def set_lstm_variant(fwd_bn, bwd_bn):
+        f = {}
+        if fwd_bn >= 0:
+            f["lstm_fwd_bn"] = fwd_bn
+        if bwd_bn >= 0:
+            f["lstm_bwd_bn"] = bwd_bn
+        set_tuning(**f)
+        return 0
+    lib.mr_set_lstm_variant = set_lstm_variant
+
+    def force_nt_tile(bm, bn):
+        set_tuning(nt_force_bm=bm, nt_force_bn=bn if bm else 0)
+        return 0
+    lib.mr_force_nt_tile = force_nt_tile
+
 
 def header_symbols():
     """Names of all `int mr_*(...)` entry points declared in include/megreader_hip.h."""
@@ -129,63 +215,25 @@ def load():
     lib.mr_abi_version.argtypes = []
     lib.mr_init.restype = ctypes.c_int
     lib.mr_init.argtypes = []
-    lib.mr_set_nt_variant.restype = ctypes.c_int
-    lib.mr_set_nt_variant.argtypes = [ctypes.c_int]
-    lib.mr_force_nt_tile.restype = ctypes.c_int
-    lib.mr_force_nt_tile.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mr_nt_tile_code.restype = ctypes.c_int
     lib.mr_nt_tile_code.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.mr_sizeof_prep_job.restype = ctypes.c_int
     lib.mr_sizeof_prep_job.argtypes = []
     lib.mr_nt_kernel_code.restype = ctypes.c_int
     lib.mr_nt_kernel_code.argtypes = [ctypes.c_int] * 5
-    lib.mr_set_tn_buf.restype = ctypes.c_int
-    lib.mr_set_tn_buf.argtypes = [ctypes.c_int]
     lib.mr_bn_scratch_doubles.restype = ctypes.c_longlong
     lib.mr_bn_scratch_doubles.argtypes = [ctypes.c_int]
-    lib.mr_set_dcn_v1_bwd.restype = ctypes.c_int
-    lib.mr_set_dcn_v1_bwd.argtypes = [ctypes.c_int]
-    lib.mr_set_gemm_skinny.restype = ctypes.c_int
-    lib.mr_set_gemm_skinny.argtypes = [ctypes.c_int]
-    lib.mr_set_dcn_fused.restype = ctypes.c_int
-    lib.mr_set_dcn_fused.argtypes = [ctypes.c_int]
     lib.mr_dcn2_ws_bytes.restype = ctypes.c_longlong
     lib.mr_dcn2_ws_bytes.argtypes = [ctypes.c_int] * 11
-    lib.mr_set_tn_model.restype = ctypes.c_int
-    lib.mr_set_tn_model.argtypes = [ctypes.c_int]
-    lib.mr_set_tn_splits.restype = ctypes.c_int
-    lib.mr_set_tn_splits.argtypes = [ctypes.c_int]
     if hasattr(lib, "mr_set_tn_abl"):      # only libmegreader_hip_abl.so (tools build, include/megreader_hip_ablation.h)
         lib.mr_set_tn_abl.restype = ctypes.c_int
         lib.mr_set_tn_abl.argtypes = [ctypes.c_int]
         lib.mr_set_tn_taps_abl.restype = ctypes.c_int
         lib.mr_set_tn_taps_abl.argtypes = [ctypes.c_int]
-    lib.mr_set_tn_taps.restype = ctypes.c_int
-    lib.mr_set_tn_taps.argtypes = [ctypes.c_int]
     lib.mr_set_tn_taps_workspace.restype = ctypes.c_int
     lib.mr_set_tn_taps_workspace.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
-    lib.mr_set_bn_fused.restype = ctypes.c_int
-    lib.mr_set_bn_fused.argtypes = [ctypes.c_int]
-    lib.mr_set_tn_group.restype = ctypes.c_int
-    lib.mr_set_tn_group.argtypes = [ctypes.c_int]
-    lib.mr_set_tn_taps_group.restype = ctypes.c_int
-    lib.mr_set_tn_taps_group.argtypes = [ctypes.c_int]
-    lib.mr_set_tn_taps_fin.restype = ctypes.c_int
-    lib.mr_set_tn_taps_fin.argtypes = [ctypes.c_int]
-    lib.mr_set_tn_taps_w8.restype = ctypes.c_int
-    lib.mr_set_tn_taps_w8.argtypes = [ctypes.c_int]
     lib.mr_tn_taps_would_run.restype = ctypes.c_int
     lib.mr_tn_taps_would_run.argtypes = [ctypes.c_int] * 17
-    lib.mr_set_tn_big.restype = ctypes.c_int
-    lib.mr_set_tn_big.argtypes = [ctypes.c_int]
-    lib.mr_set_nt_big.restype = ctypes.c_int
-    lib.mr_set_nt_big.argtypes = [ctypes.c_int]
-    lib.mr_set_nt_p8.restype = ctypes.c_int
-    lib.mr_set_nt_p8.argtypes = [ctypes.c_int]
-    lib.mr_set_lstm_variant.restype = ctypes.c_int
-    lib.mr_set_lstm_variant.argtypes = [ctypes.c_int, ctypes.c_int]
-    lib.mr_set_lstm_persist.restype = ctypes.c_int
-    lib.mr_set_lstm_persist.argtypes = [ctypes.c_int]
     lib.mr_lstm_debug_buffer.restype = ctypes.c_int
     lib.mr_lstm_debug_buffer.argtypes = [ctypes.c_void_p]
     lib.mr_lstm_ws_bytes.restype = ctypes.c_longlong
@@ -198,6 +246,10 @@ def load():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [_CODES[c] for c in codes]
+    for name in ("mr_tuning_get", "mr_tuning_set", "mr_tuning_defaults"):
+        getattr(lib, name).restype = ctypes.c_int
+        getattr(lib, name).argtypes = [ctypes.POINTER(Tuning)]
+    _install_setter_shims(lib)
     _lib = lib
     if torch.cuda.is_available():
         if lib.mr_init() != 0:
@@ -205,9 +257,10 @@ def load():
     return lib
 
 
-HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_set_nt_variant", "mr_force_nt_tile",
-             "mr_stem_bwd_workspace", "mr_set_lstm_variant", "mr_set_nt_big", "mr_set_nt_deep", "mr_set_lstm_persist", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_set_nt_p8", "mr_set_tn_splits", "mr_set_tn_model", "mr_set_dcn_v1_bwd", "mr_set_gemm_skinny", "mr_set_dcn_fused", "mr_dcn2_ws_bytes", "mr_bn_scratch_doubles", "mr_sizeof_img_desc",
-             "mr_nt_kernel_code", "mr_set_tn_taps", "mr_tn_taps_would_run", "mr_set_tn_taps_w8", "mr_set_tn_taps_fin", "mr_set_tn_taps_workspace", "mr_set_tn_taps_group", "mr_set_tn_group", "mr_set_tn_fin", "mr_set_bn_fused", "mr_set_tn_big", "mr_set_tn_buf", "mr_sizeof_prep_job")  # entry points that take no stream and launch nothing
+HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_tuning_get", "mr_tuning_set", "mr_tuning_defaults",
+             "mr_stem_bwd_workspace", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_dcn2_ws_bytes", "mr_bn_scratch_doubles",
+             "mr_sizeof_img_desc", "mr_nt_kernel_code", "mr_tn_taps_would_run", "mr_set_tn_taps_workspace",
+             "mr_sizeof_prep_job")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

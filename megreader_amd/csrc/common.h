@@ -98,3 +98,5 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 }  // namespace mr
+
+#include "tuning.h"   // mr_tuning: the library's only process-wide switches (MR_TUNE(field))

@@ -156,7 +156,7 @@ __global__ void dcn2_col2im_kernel(const T* __restrict__ gcol, const float* __re
   }
 }
 
-// ---- round-2 backward kernel experiments (off by default: measured slower / equal, see mr_set_dcn_v1_bwd) -----------
+// ---- round-2 backward kernel experiments (off by default: measured slower / equal, see mr_tuning.dcn_v1_bwd) -----------
 // coord v2: 8 lanes per (pixel, tap) item, each lane a 16-byte channel vector of gcol and of the four corners (the
 // first version put one WAVE on an item with 2-byte loads per lane: 295 us per layer at batch 16).  The three sums are
 // reduced over the 8 lanes with three shuffle steps.  C must be a multiple of 8 * VEC (64 for bf16).
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void dcn2_col2im_lds_kernel(const T* __restric
   }
 }
 
-static int g_dcn_v1_bwd = 1;   // 1 (default): round-1 backward kernels; 0: the round-2 experiments (mr_set_dcn_v1_bwd)
+#define g_dcn_v1_bwd MR_TUNE(dcn_v1_bwd)   // 1 (default): round-1 backward kernels; 0: the round-2 experiments (mr_tuning.dcn_v1_bwd)
 
 static inline int grid_for(long long n, int block, int max_blocks = 32768) {
   long long b = (n + block - 1) / block;
@@ -473,12 +473,6 @@ int mr_dcn2_col2im(int dtype, const void* gcol, const float* offset, long long o
 // per CU on gfx950 (the same cliff as the LDS-atomic column sums of the wide-tile TN kernel), independent of bank
 // conflicts (stride 64 vs 65 floats: same time); vectorised coordinate gradient 302 vs 295 us (both bound by the 36x
 // re-read of the input corners from L2, not by the access width).
-int mr_set_dcn_v1_bwd(int on) {
-  const int old = g_dcn_v1_bwd;
-  g_dcn_v1_bwd = on ? 1 : 0;
-  return old;
-}
-
 // bytes of the caller-owned workspace `col_ws` of mr_dcn2_fwd (backward = 0) / mr_dcn2_bwd (backward = 1) for this shape:
 // fused path: nothing forward, the CSR of the scatter pattern backward; general path: the column matrix.
 long long mr_dcn2_ws_bytes(int dtype, int N, int H, int W, int C, int Co, int kh, int kw, int Ho, int Wo, int backward) {

@@ -921,7 +921,7 @@ __global__ __launch_bounds__(256) void dcn2_wgrad_fused_kernel(DcnWgradArgs a) {
     }
 }
 
-static int g_dcn_fused = 1;   // mr_set_dcn_fused: 0 forces the general kernels of dcn.hip (A/B and tests)
+#define g_dcn_fused MR_TUNE(dcn_fused)   // mr_tuning.dcn_fused: 0 forces the general kernels of dcn.hip (A/B and tests)
 
 }  // namespace mr
 
@@ -977,7 +977,7 @@ int dcn_fused_fwd(int dtype, const void* x, const void* w_n, const float* bias, 
   a.x = x; a.w = w_n; a.bias = bias; a.offset = offset; a.mask = mask; a.y = y; a.g = g; a.Co = Co;
   a.P = g.N * g.Ho * g.Wo;
   MR_CHECK_ARG(dcn_fits_32bit(dtype, (long long)g.N * g.H * g.W * g.C, (long long)a.P * Co, (long long)Co * g.kh * g.kw * g.C),
-               "dcn (fused path): x / y / weights must each be smaller than 2 GiB (mr_set_dcn_fused(0) selects the general "
+               "dcn (fused path): x / y / weights must each be smaller than 2 GiB (mr_tuning.dcn_fused = 0 selects the general "
                "kernels)");
   const int tiles_m = cdiv(a.P, 64);
   const int bn = Co % 128 == 0 ? 128 : 64;
@@ -1099,14 +1099,3 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
 }
 
 }  // namespace mr
-
-extern "C" {
-
-// A/B switch (tests, tools/microbench_dcn.py): 0 = the general kernels of dcn.hip for every shape.  Returns the old value.
-int mr_set_dcn_fused(int on) {
-  const int old = g_dcn_fused;
-  g_dcn_fused = on ? 1 : 0;
-  return old;
-}
-
-}  // extern "C"

@@ -30,8 +30,8 @@ static const void* zero_page() {
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-static int g_nt_variant = 2;  // 2 = direct-to-LDS kernel (default), 1 = register-staged kernel (A/B debugging)
-static int g_nt_deep = 1;     // 4-stage pipeline of the 4-wave NT kernel: 1 = automatic (low-occupancy launches), 0 never, 2 always
+#define g_nt_variant MR_TUNE(nt_variant)  // 2 = direct-to-LDS kernel (default), 1 = register-staged kernel (A/B debugging)
+#define g_nt_deep MR_TUNE(nt_deep)     // 4-stage pipeline of the 4-wave NT kernel: 1 = automatic (low-occupancy launches), 0 never, 2 always
 
 // mr_conv2d_fwd_stats: the f64 column-statistics accumulators the NT launches of the current call attach to their epilogue
 // (EpiStore::stats), and whether every launch of the call could (the register-staged fallback kernel cannot)
@@ -130,17 +130,17 @@ static int num_cus() {
 
 // ---- big-tile (8-wave) NT kernel: bf16, dense or fast-gather conv operands ---------------------------------------
 // g_big_mode: 0 = automatic (nt_big_choice), -1 = never, 1 = always 256x256, 2 = always 288x256 (tuning override)
-static int g_big_mode = 0;
+#define g_big_mode MR_TUNE(nt_big)
 #ifdef MR_ABLATION
 static int g_tn_abl = 0;  // timing-only ablation mask of the TN kernel (mr_set_tn_abl)
 #endif
-static int g_tn_model = 1;   // 1 (default): the measured split model for the conv wgrad launches too; 0: the old one (A/B)
-static int g_tn_splits = 0;  // > 0: split count override of launch_tn (mr_set_tn_splits, tuning only)
-static int g_tn_buf = 1;  // TN kernel staging through buffer resources (mr_set_tn_buf); measured 4 % faster
-static int g_tn_taps = 1;  // all-taps wgrad kernel for 3x3 / stride 1 / pad == dilation layers (tn_taps.hip, mr_set_tn_taps)
-static int g_tn_group = 0;  // GEMM TN kernel split reduction: 0 automatic (slab groups when a workspace is registered), 1 atomics, > 1 forced
-static int g_tn_fin = 0;    // 2: split partials go to slabs with plain stores, a finalize launch sums them (mr_set_tn_fin); 0 (default): g_tn_group
-static int g_tn_big = 0;  // wide-tile TN kernels: 1 = 256x256, 2 = 128x256 (experimental, see launch_tn), else never
+#define g_tn_model MR_TUNE(tn_model)   // 1 (default): the measured split model for the conv wgrad launches too; 0: the old one (A/B)
+#define g_tn_splits MR_TUNE(tn_splits)  // > 0: split count override of launch_tn (mr_tuning.tn_splits, tuning only)
+#define g_tn_buf MR_TUNE(tn_buf)  // TN kernel staging through buffer resources (mr_tuning.tn_buf); measured 4 % faster
+#define g_tn_taps MR_TUNE(tn_taps)  // all-taps wgrad kernel for 3x3 / stride 1 / pad == dilation layers (tn_taps.hip, mr_tuning.tn_taps)
+#define g_tn_group MR_TUNE(tn_group)  // GEMM TN kernel split reduction: 0 automatic (slab groups when a workspace is registered), 1 atomics, > 1 forced
+#define g_tn_fin MR_TUNE(tn_fin)    // 2: split partials go to slabs with plain stores, a finalize launch sums them (mr_tuning.tn_fin); 0 (default): g_tn_group
+#define g_tn_big MR_TUNE(tn_big)  // wide-tile TN kernels: 1 = 256x256, 2 = 128x256 (experimental, see launch_tn), else never
 
 // 0 = use the 4-wave kernels, 1 = 256x256 (8 waves), 3 = 272x256 (8 waves as 1x8); 2 (288x256, spills), 4 / 5 (160x128 with 4 /
 // 8 waves) are tuning overrides only.  The big tiles run one
@@ -225,10 +225,10 @@ static int launch_nt_big(const NtArgs& a, const ConvGeom& g, void* C, long long 
 
 // Phased-schedule 256x256 kernel (igemm_p8.h); g_use_p8: 1 = use it wherever the 8-wave 256x256 kernel would run.
 // Measured equal to the v3 kernel (850-900 TF/s on conv3 / conv5, gpurun r2j) -- the schedule is not what bounds the
-// tile: its ablation ladder (mr_set_nt_p8(2..4), tools/microbench_conv.py --p8) gives 1.16-1.21 PF for the bare
+// tile: its ablation ladder (mr_tuning.nt_p8(2..4), tools/microbench_conv.py --p8) gives 1.16-1.21 PF for the bare
 // MFMA + barrier skeleton incl. prologue / epilogue, 1.03 PF with the fragment reads, 0.85-0.90 with the LDS-DMA
 // issue on top.  Default: the v3 kernel.
-static int g_use_p8 = 0;
+#define g_use_p8 MR_TUNE(nt_p8)
 template <typename T, int AMODE>
 static int launch_nt_p8(const NtArgs& a, const ConvGeom& g, void* C, long long ldc, const float* bias, int relu,
                         hipStream_t stream) {
@@ -266,7 +266,7 @@ static int launch_nt_p8(const NtArgs& a, const ConvGeom& g, void* C, long long l
     }                                                                                                             \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a2, g, epi);                                     \
   }
-#ifdef MR_ABLATION   // measurement-only ablations (mr_set_nt_p8(2..4)); wrong results: tools-only build
+#ifdef MR_ABLATION   // measurement-only ablations (mr_tuning.nt_p8(2..4)); wrong results: tools-only build
     if (g_use_p8 == 2) MR_P8_LAUNCH(1)
     else if (g_use_p8 == 3) MR_P8_LAUNCH(2)
     else if (g_use_p8 == 4) MR_P8_LAUNCH(3)
@@ -284,9 +284,10 @@ static int launch_nt_p8(const NtArgs& a, const ConvGeom& g, void* C, long long l
 // for wave quantisation: e.g. M = 33792 (264 row tiles of 128) x N = 512 gives 1056 tiles on 512 slots = 3 rounds
 // with the last one 6 % full, while BM = 96 gives 1408 tiles = 2.75 rounds.
 struct TileChoice { int bm, bn; };
-static TileChoice g_forced_tile = {0, 0};  // mr_force_nt_tile: tuning / A-B override
+// tuning / A-B override (mr_tuning.nt_force_bm / nt_force_bn): one tile shape for every NT launch, bm = 0: the cost model
+static inline TileChoice forced_tile() { return TileChoice{MR_TUNE(nt_force_bm), MR_TUNE(nt_force_bn)}; }
 static TileChoice nt_tile(int M, int N) {
-  if (g_forced_tile.bm) return g_forced_tile;
+  if (forced_tile().bm) return forced_tile();
   static const int bms[3] = {128, 96, 64};
   static const int bns[2] = {128, 64};
   // relative MFMA efficiency of a tile shape, calibrated on MI355X with tools/microbench_conv.py --tile
@@ -342,7 +343,7 @@ static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long l
                              int relu, hipStream_t stream) {
   if constexpr (sizeof(T) == 2 && (AMODE == 0 || AMODE == 2)) {
     constexpr int BK = 8 * VecOf<T>::N;
-    if (g_nt_variant == 2 && !g_forced_tile.bm && (AMODE == 0 || (g.Cg % BK) == 0) && aligned16(C) &&
+    if (g_nt_variant == 2 && !forced_tile().bm && (AMODE == 0 || (g.Cg % BK) == 0) && aligned16(C) &&
         nt_fits_buffer<T>(a, g, AMODE)) {
       const int big = nt_big_choice(a.M, a.N, a.K);
       if (big == 1) return launch_nt_p8<T, AMODE>(a, g, C, ldc, bias, relu, stream);
@@ -444,7 +445,7 @@ static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
   if (g_tn_splits > 0) splits = g_tn_splits < total_steps ? g_tn_splits : total_steps;
   if constexpr (sizeof(T) == 2) {
     // wide-tile variants (mode 1: 256x256, mode 2: 128x256; one 8-wave workgroup per CU): they cut the L2 -> LDS
-    // operand traffic of the 128x128 kernel to 0.5x / 0.75x.  EXPERIMENTAL, opt-in only (mr_set_tn_big): both are
+    // operand traffic of the 128x128 kernel to 0.5x / 0.75x.  EXPERIMENTAL, opt-in only (mr_tuning.tn_big): both are
     // bit-for-bit sane (tests/test_kernels_gpu.py) but measured 3-4x SLOWER on MI355X (conv5 wgrad 630 -> 161 /
     // 252 TFLOP/s).  Mode 1 spills ~20 VGPRs inside the k-loop and every scratch reload carries an
     // s_waitcnt vmcnt(0) that also drains the in-flight LDS-DMA prefetch; mode 2 has no spills, so the common
@@ -538,78 +539,22 @@ extern "C" {
 
 // Eagerly create per-device state (the zero page).  Call once per device before capturing a hipGraph.
 int mr_init(void) {
+  const int rc = tuning_from_env();   // MEGREADER_TUNING="field=value,..." (include/megreader_hip.h: mr_tuning), applied once
+  if (rc != MR_OK) return rc;
   if (!zero_page()) { set_error("mr_init: zero page allocation failed"); return MR_ERR_LAUNCH; }
   return MR_OK;
 }
 
-// 2 = direct-to-LDS NT kernel (default), 1 = register-staged NT kernel.  Returns the previous setting.
-int mr_set_nt_variant(int v) {
-  const int old = g_nt_variant;
-  if (v == 1 || v == 2) g_nt_variant = v;
-  return old;
-}
-
-// 1 = the phased-schedule 256x256 kernel (igemm_p8.h) serves the big-tile launches, 0 (default) = the v3 kernel,
-// 2..4 = timing-only ablations of the phased kernel (wrong results).
-// Returns the previous setting.
-int mr_set_nt_p8(int on) {
-  const int old = g_use_p8;
-#ifdef MR_ABLATION
-  g_use_p8 = (on >= 0 && on <= 4) ? on : 1;   // 2..4: ablation variants of the phased kernel (timing only)
-#else
-  g_use_p8 = on ? 1 : 0;                      // the wrong-result ablation variants exist only in the MR_ABLATION build
-#endif
-  return old;
-}
-
-// Big-tile (8-wave) NT kernel policy: 0 automatic, -1 never, 1 always 256x256, 2 always 288x256 (needs N % 256 == 0
-// callers; a tuning / A-B override).  Returns the previous setting.
-int mr_set_nt_deep(int mode) {
-  const int old = g_nt_deep;
-  if (mode >= 0 && mode <= 2) g_nt_deep = mode;
-  return old;
-}
-
-int mr_set_nt_big(int mode) {
-  const int old = g_big_mode;
-  if (mode >= -1 && mode <= 7) g_big_mode = mode;
-  return old;
-}
-
-// TN kernel operand staging: 1 = raw buffer resources (OOB -> zeros, 32-bit offsets), 0 = flat pointers + zero page.
-// Operands must be < 2 GiB in buffer mode.  Returns the previous setting.
-// timing-only: ablation mask of igemm_tn_glds_kernel (1 no LDS-DMA, 2 no fragment reads, 4 no atomic epilogue,
-// 8 no column sums; supported: 0, 1, 2, 3, 4, 8, 15).  Wrong results for mask != 0.
+// The A/B and tuning switches of the kernels in this file live in mr_tuning (tuning.hip, include/megreader_hip.h); only the
+// timing-only ablation masks of the -DMR_ABLATION tools build keep setters of their own (include/megreader_hip_ablation.h).
 #ifdef MR_ABLATION
 int mr_set_tn_abl(int mask) {
   const int old = g_tn_abl;
   g_tn_abl = mask;
   return old;
 }
+int mr_set_tn_taps_abl(int mask) { return taps_set_abl(mask); }
 #endif
-
-// A/B: 1 (default) = the conv wgrad launches use the measured split model as well (CRNN: neutral, Res50-PPM-2D-CTC:
-// wgrad 62 -> 57 us per launch, step 14.30 -> 14.01 ms), 0 = the round-1 model.  Returns the previous setting.
-int mr_set_tn_model(int m) {
-  const int old = g_tn_model;
-  g_tn_model = m ? 1 : 0;
-  return old;
-}
-
-// tuning only: force the P-split count of the TN kernels (0 = the makespan model).  Returns the previous setting.
-int mr_set_tn_splits(int n) {
-  const int old = g_tn_splits;
-  g_tn_splits = n > 0 ? n : 0;
-  return old;
-}
-
-// All-taps wgrad kernel (tn_taps.hip): 1 = use it where taps_eligible() says so, 0 = never.  The caller-owned row table
-// has a different format for the two kernels: callers must rebuild their tables (build = 1) after changing this.
-int mr_set_tn_taps(int mode) {
-  const int old = g_tn_taps;
-  if (mode == 0 || mode == 1) g_tn_taps = mode;
-  return old;
-}
 
 // Workspace of the all-taps kernel's in-launch split reduction: `bytes` of device memory (16 KB of tickets + 147456 B
 // per workgroup of the largest launch, i.e. 2 * CUs slabs), ZEROED by the caller once; NULL / 0 withdraws it (the
@@ -621,57 +566,14 @@ int mr_set_tn_taps_workspace(void* ws, long long bytes) {
   taps_set_workspace(ws, bytes);
   return MR_OK;
 }
-// tuning: group size of that reduction (0 automatic, 1 atomics only); returns the previous setting
-int mr_set_tn_taps_group(int g) { return taps_set_group(g); }
-// same for the 128x128 TN GEMM kernel (conv wgrad of the other geometries, Linear / LSTM weight gradients)
-int mr_set_tn_group(int g) { const int old = g_tn_group; if (g >= 0) g_tn_group = g; return old; }
-// 2 = the 128x128 TN GEMM kernel writes its split partials to slabs with plain stores and a finalize launch adds their sum into C
-// (the scheme that is the all-taps kernel's default, mr_set_tn_taps_fin(2)); 0 (default) = in-launch group reduction / atomics
-// (mr_set_tn_group).  Measured SLOWER here, unlike for the all-taps kernel: these launches are 25-40 us with 4-16 splits, and a
-// second launch per layer costs more than their atomics (Res50-PPM 13.26 -> 13.70 ms, FPN-attention 10.00 -> 10.47, DB 11.26 ->
-// 11.96, CRNN equal).  Returns the old value.
-int mr_set_tn_fin(int mode) { const int old = g_tn_fin; if (mode == 0 || mode == 2) g_tn_fin = mode; return old; }
-
-// 1 (opt-in, measured equal) = the all-taps kernel's group sums are added into dw by a second, tiny launch instead of the leaders' atomics
-int mr_set_tn_taps_fin(int on) { return taps_set_fin(on); }
-
-// 1 = 8-wave workgroup variant of the all-taps kernel (one per CU, half the partial tiles); returns the previous setting
-int mr_set_tn_taps_w8(int on) { return taps_set_w8(on); }
-
-// host only, timing only: ablation mask of the all-taps kernel (results are wrong for mask != 0)
-#ifdef MR_ABLATION
-int mr_set_tn_taps_abl(int mask) { return taps_set_abl(mask); }
-#endif
 
 // host only: 1 when mr_conv2d_wgrad_tab would run the all-taps kernel for this geometry (bf16, row table of
-// N*Ho*Wo*8 bytes) under the current mr_set_tn_taps setting, else 0
+// N*Ho*Wo*8 bytes) under the current mr_tuning.tn_taps setting, else 0
 int mr_tn_taps_would_run(int Nimg, int H, int W, int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw,
                          int ph, int pw, int dh, int dw, int Ho, int Wo) {
   return (g_tn_taps && g_nt_variant == 2 &&
           taps_eligible(Nimg, H, W, Cin, ldx, Cout, lddy, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo,
                         (long long)Nimg * Ho * Wo * 8)) ? 1 : 0;
-}
-
-int mr_set_tn_buf(int mode) {
-  const int old = g_tn_buf;
-  if (mode == 0 || mode == 1) g_tn_buf = mode;
-  return old;
-}
-
-// Wide-tile TN kernels: 1 = 256x256, 2 = 128x256 (experimental, currently slower -- see launch_tn), 0 / -1 = never.
-// Returns the previous setting.
-int mr_set_tn_big(int mode) {
-  const int old = g_tn_big;
-  if (mode >= -1 && mode <= 2) g_tn_big = mode;
-  return old;
-}
-
-// Force every NT launch to one tile shape (bm in {128,96,64}, bn in {128,64}); bm = 0 restores the cost model.
-int mr_force_nt_tile(int bm, int bn) {
-  if (bm == 0) { g_forced_tile.bm = g_forced_tile.bn = 0; return MR_OK; }
-  MR_CHECK_ARG((bm == 128 || bm == 96 || bm == 64) && (bn == 128 || bn == 64), "mr_force_nt_tile: bad tile %dx%d", bm, bn);
-  g_forced_tile.bm = bm; g_forced_tile.bn = bn;
-  return MR_OK;
 }
 
 // Which NT tile (BM*1000 + BN) a problem of M rows x N columns is dispatched to (profiling / bench labels).
@@ -683,7 +585,7 @@ int mr_nt_tile_code(int M, int N) {
 // Same query including the big-tile policy: cg = channel count of the gathered conv operand (0 for a dense GEMM).
 // Returns 256256 when the 8-wave 256x256 kernel would run for a bf16 problem of this shape.
 int mr_nt_kernel_code(int dtype, int M, int N, int K, int cg) {
-  if (dtype == MR_BF16 && g_nt_variant == 2 && !g_forced_tile.bm && (cg == 0 || cg % 64 == 0)) {
+  if (dtype == MR_BF16 && g_nt_variant == 2 && !forced_tile().bm && (cg == 0 || cg % 64 == 0)) {
     const int big = nt_big_choice(M, N, K);
     if (big == 1) return 256256;
     if (big == 2) return 288256;

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const T* __restrict
   }
 }
 
-static int g_skinny = 1;
+#define g_skinny MR_TUNE(gemm_skinny)
 
 // used by mr_gemm_nt (gemm_conv.hip): true when the skinny kernel took the problem
 bool gemm_nt_skinny(int dtype, const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc,
@@ -107,10 +107,4 @@ bool gemm_nt_skinny(int dtype, const void* A, long long lda, const void* B, long
 extern "C" {
 
 // A/B (host only): 0 = M <= 32 GEMMs take the general tiled kernels again.  Returns the previous setting.
-int mr_set_gemm_skinny(int on) {
-  const int old = mr::g_skinny;
-  mr::g_skinny = on ? 1 : 0;
-  return old;
-}
-
 }  // extern "C"

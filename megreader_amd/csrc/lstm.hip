@@ -120,9 +120,9 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(NtArgs a0, NtArgs a1, Ep
     igemm_nt_kdirect_body<T, LSTM_BM, BN, Epi>(a, e);
 }
 
-// tuning knobs (mr_set_lstm_variant): column-tile width of the step kernels, 0 = LDS-staged split-K body
-static int g_lstm_fwd_bn = 0;
-static int g_lstm_bwd_bn = LSTM_BN_BWD;
+// tuning knobs (mr_tuning.lstm_fwd_bn / lstm_bwd_bn): column-tile width of the step kernels, 0 = LDS-staged split-K body
+#define g_lstm_fwd_bn MR_TUNE(lstm_fwd_bn)
+#define g_lstm_bwd_bn MR_TUNE(lstm_bwd_bn)   // default LSTM_BN_BWD (tuning.hip)
 
 template <typename T>
 static int lstm_fwd_impl(const void* xproj_, const void* whh_, void* out_, float* cbuf, void* gates_, int Tn, int N,
@@ -219,8 +219,7 @@ int lstm_fwd_persist(const void* xproj, const void* whh, void* out, float* cbuf,
 int lstm_bwd_persist(const void* dout, const void* whhT, const float* cbuf, void* gates, int T, int N, void* ws,
                      long long ws_bytes, hipStream_t stream);
 void lstm_set_bwd_debug(float* p);
-int lstm_set_xcd_map(int on);
-static int g_lstm_persist = 1;
+#define g_lstm_persist (MR_TUNE(lstm_persist) != 0)   // 2 = persistent kernels without the XCD block map
 
 }  // namespace mr
 
@@ -230,15 +229,6 @@ extern "C" {
 
 // Tuning knob: column-tile width of the recurrence step kernels.  fwd_bn in {0, 32, 64}, bwd_bn in {0, 16, 32, 64};
 // 0 selects the LDS-staged split-K body, other values the direct-fragment body.  Negative = leave unchanged.
-int mr_set_lstm_variant(int fwd_bn, int bwd_bn) {
-  MR_CHECK_ARG(fwd_bn < 0 || fwd_bn == 0 || fwd_bn == 32 || fwd_bn == 64, "mr_set_lstm_variant: bad fwd_bn %d", fwd_bn);
-  MR_CHECK_ARG(bwd_bn < 0 || bwd_bn == 0 || bwd_bn == 16 || bwd_bn == 32 || bwd_bn == 64,
-               "mr_set_lstm_variant: bad bwd_bn %d", bwd_bn);
-  if (fwd_bn >= 0) g_lstm_fwd_bn = fwd_bn;
-  if (bwd_bn >= 0) g_lstm_bwd_bn = bwd_bn;
-  return MR_OK;
-}
-
 // Debug hook (host only, not part of the product path): when non-null the persistent backward kernel also writes the
 // recurrent term dh_rec [T, N, 2H] (f32) it reduced for every step.
 int mr_lstm_debug_buffer(float* p) {
@@ -248,12 +238,6 @@ int mr_lstm_debug_buffer(float* p) {
 
 // Host-only switch: 1 (default) = persistent one-launch recurrence where applicable, 0 = per-step launches,
 // 2 = persistent without the XCD-colocating block map (A/B: every hand-off then crosses XCDs through sc1 stores).
-int mr_set_lstm_persist(int on) {
-  g_lstm_persist = on != 0;
-  lstm_set_xcd_map(on != 2);
-  return MR_OK;
-}
-
 // Bytes of exchange workspace the persistent recurrence wants for this problem; 0 = it does not apply (f32 parity
 // mode, H != 256, batch too large for co-residency) and mr_lstm_fwd/bwd run one launch per step.
 long long mr_lstm_ws_bytes(int dtype, int T, int N, int H) {

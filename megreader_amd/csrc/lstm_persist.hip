@@ -461,12 +461,7 @@ static long long persist_ws_bytes(int N) {
   return (fwd > bwd ? fwd : bwd) + 256 + persist_hello_bytes(N);
 }
 
-static int g_lstm_xcd = 1;   // 0: never use the XCD-colocating block map (A/B knob, lstm_set_xcd_map)
-int lstm_set_xcd_map(int on) {
-  const int old = g_lstm_xcd;
-  g_lstm_xcd = on ? 1 : 0;
-  return old;
-}
+#define g_lstm_xcd (MR_TUNE(lstm_persist) != 2)   // lstm_persist = 2: never use the XCD-colocating block map (A/B knob)
 // the map needs whole octets of groups: 2*nbg groups, 4 slices each, 8 XCDs
 static int persist_xcd_map(int nbg) { return (g_lstm_xcd && nbg % 4 == 0) ? 1 : 0; }
 

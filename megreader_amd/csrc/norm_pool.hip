@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_fixed_kernel(const T* __restr
   ((uint4*)dx)[((long long)blockIdx.y * W + w) * cv + c] = out;
 }
 
-static int g_bn_fused = 1;   // 1: fold the finalize kernels into the apply passes (mr_set_bn_fused)
+#define g_bn_fused MR_TUNE(bn_fused)   // 1: fold the finalize kernels into the apply passes (mr_tuning.bn_fused)
 // blocks along the rows of a fused apply pass: ~8 row groups per block, at most ~16 blocks per CU in total
 static inline int bn_fused_grid_x(long long P, int rows, int slabs) {
   long long gx = (P + (long long)rows * 8 - 1) / ((long long)rows * 8);
@@ -621,14 +621,6 @@ extern "C" {
 // (zeroed here unless flags bit 2 says the caller hands it over zeroed).  Saves mean/rstd (f32[C]) for backward.
 long long mr_bn_scratch_doubles(int C) { return 2ll * C * MR_BN_COPIES + C; }   // + [2C] f32 of per-channel means (bwd)
 
-
-// 1 (default): the training-mode passes fold bn_finalize / bn_bwd_finalize into their apply kernels (C % 64 == 0);
-// 0: separate finalize launches.  Returns the previous setting.
-int mr_set_bn_fused(int on) {
-  const int old = g_bn_fused;
-  if (on == 0 || on == 1) g_bn_fused = on;
-  return old;
-}
 
 // sums (f64 [MR_BN_COPIES][2][C], zeroed by the caller) += per-channel sum / sum of squares of x [P][C]: the statistics
 // pass of mr_bn_fwd_train on its own (what mr_conv2d_fwd_stats falls back to); follow with mr_bn_fwd_train(flags bit 3).

@@ -24,9 +24,6 @@ int taps_eligible(int N, int H, int W, int Cin, int ldx, int Cout, int lddy, int
 void taps_set_workspace(void* p, long long bytes);
 void taps_get_workspace(void** p, long long* bytes);   // the current device's registered workspace (or null, 0)
 void taps_set_concurrent(bool on);   // this host thread's next launches must not touch the shared workspace
-int taps_set_group(int g);    // 0 = automatic, 1 = atomics only, > 1 = forced group size; returns the previous value
-int taps_set_fin(int on);    // 1: finalize launch instead of the group leaders' atomics; returns the previous value
-int taps_set_w8(int on);     // 1: 8-wave workgroup variant (one partial tile per CU); returns the previous value
 #ifdef MR_ABLATION
 int taps_set_abl(int mask);   // timing-only ablations (wrong results), see tn_taps.hip
 #endif

@@ -437,7 +437,7 @@ int taps_eligible(int N, int H, int W, int Cin, int ldx, int Cout, int lddy, int
 // one workspace per device (one process may drive several GPUs): indexed by the current device at set / launch time
 static void* g_taps_ws_dev[64] = {nullptr};
 static long long g_taps_ws_bytes_dev[64] = {0};
-static int g_taps_grp = 0;   // 0 = automatic, 1 = atomics only, > 1 = forced group size
+#define g_taps_grp MR_TUNE(tn_taps_group)   // 0 = automatic, 1 = atomics only, > 1 = forced group size
 static int taps_cur_dev() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
@@ -458,15 +458,13 @@ void taps_get_workspace(void** p, long long* bytes) {
   *p = (dev >= 0 && !g_tn_concurrent) ? g_taps_ws_dev[dev] : nullptr;
   *bytes = dev >= 0 ? g_taps_ws_bytes_dev[dev] : 0;
 }
-int taps_set_group(int g) { const int old = g_taps_grp; if (g >= 0) g_taps_grp = g; return old; }
 
 // 1: 8-wave workgroups (two reduction halves share one partial tile), one per CU.  Opt-in: it halves the partial-tile
 // traffic (HBM-side bytes per launch 209 -> 144 MB) and ties in the microbenchmark, but inside the training step it is
 // ~10 % slower (rocprofv3 average 122.6 vs 111.2 us per launch: one barrier-coupled 8-wave workgroup per CU)
-static int g_taps_w8 = 0;
-int taps_set_w8(int on) { const int old = g_taps_w8; if (on == 0 || on == 1) g_taps_w8 = on; return old; }
+#define g_taps_w8 MR_TUNE(tn_taps_w8)
 
-// How the split partials of a tile reach dw (mr_set_tn_taps_fin):
+// How the split partials of a tile reach dw (mr_tuning.tn_taps_fin):
 //   0 (default): groups of splits reduce in the launch (slabs + tickets), the group leaders add into dw with f32 atomics;
 //   1: same groups, but the leaders leave the group sums in their slabs and a finalize launch adds them into dw -- measured
 //      equal to 0 (conv2..5 wgrad 445 vs 445 us per step at group 4: the second launch + 19 MB of slab reads cost what the
@@ -478,8 +476,7 @@ int taps_set_w8(int on) { const int old = g_taps_w8; if (on == 0 || on == 1) g_t
 //   (A first version of mode 2 with its own copy of the slab stores pushed this 254-VGPR kernel into scratch -- 180 bytes per
 //   lane -- and slowed modes 0 / 1 from 109 to 155 us per launch; the modes share one store sequence now, resource usage is
 //   what it was.)
-static int g_taps_fin = 0;
-int taps_set_fin(int on) { const int old = g_taps_fin; if (on >= 0 && on <= 2) g_taps_fin = on; return old; }
+#define g_taps_fin MR_TUNE(tn_taps_fin)
 
 #ifdef MR_ABLATION
 static int g_taps_abl = 0;

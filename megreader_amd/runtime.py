@@ -81,7 +81,20 @@ class GraphedTrainStep(object):
         return loss
 
     def _capture(self):
-        # warm-up on a side stream (lazy initialisations, allocator pools, flat optimizer buffers) as torch requires
+        # Warm-up (lazy initialisations, allocator pools, flat optimizer buffers) and capture run on ONE dedicated side stream.
+        #
+        # HAZARD (ROCm 7.0 HIP runtime, found in round 4: tools/diag_capture.py, profiles/r04_diag_capture_crash.txt).  Autograd
+        # nodes that outlive a step -- the parameters' AccumulateGrad nodes, which torch caches weakly and therefore re-uses for
+        # as long as ANY earlier graph is alive (a caller that still holds the previous step's loss, or a reference cycle not
+        # yet collected) -- remember the stream they were created on, and the engine synchronises the producing stream with
+        # that stream when a gradient arrives.  Inside a capture such a synchronisation pulls the other stream into the
+        # capture; when it is the LEGACY DEFAULT stream, hipStreamEndCapture segfaults (hip::Stream::EndCapture walking its
+        # parallel capture streams).  Eager steps on a non-default stream are harmless (a legal fork / join), and so is a
+        # default-stream graph that is dead by now.  Therefore: collect garbage first, and callers must not keep the loss (or
+        # any other tensor with a grad_fn) of a default-stream step alive across the construction of this object.
+        import gc
+        import os
+        gc.collect()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -90,15 +103,17 @@ class GraphedTrainStep(object):
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        same = os.environ.get("MEGREADER_CAPTURE_STREAM", "same") != "own"    # "own": torch's internal capture stream (A/B)
+        kw = {"stream": s} if same else {}
         if self.grad_sync is None:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, **kw):
                 self.loss = self._eager()
             return
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, **kw):
             self.loss = self._fwd_bwd()
         self.grad_sync()
         self.graph_update = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_update):
+        with torch.cuda.graph(self.graph_update, **kw):
             self.optimizer.step()
 
     def copy_inputs(self, *tensors):

@@ -12,6 +12,8 @@ configuration and process.  Each case returns a dict:
     loss_fn(model, batch_on_device) -> scalar loss the way the reference's trainer forms it (trainer.py:127 `l.mean()`)
     optimizer(params) -> the fused optimizer of the published YAML with lr = 0 (weights stay put: gradients of later steps
                          remain comparable with the oracle's)
+`<case>_hip()` returns the same dict WITHOUT the oracle passes (ora constructed for its seeded initial state only): what a
+child process needs to rebuild the HIP side of a case whose gradients it receives through a file (tests/test_timed_step_gpu.py).
 """
 import copy
 import os
@@ -64,9 +66,7 @@ def _recognition_loss(model, b):
 
 
 # ------------------------------------------------------------------------------------------------ configs[1]: CRNN, N = 256
-def crnn_n256():
-    if "crnn" in _CACHE:
-        return _CACHE["crnn"]
+def crnn_n256_hip():
     from megreader_amd.backbones import crnn_backbone
     from megreader_amd.decoders import CRNNDecoder
     from megreader_amd.optim import FusedAdam
@@ -85,6 +85,21 @@ def crnn_n256():
     ora = CRNNOracle()
     state0 = {k: v.clone() for k, v in ora.state_dict().items()}
     batch = synthetic_batch(256, 32, 128, seed=11)
+
+    def build():
+        m = Model()
+        m.load_state_dict(state0)
+        return m.to(DEV).train()
+
+    return dict(ora=ora, state0=state0, batch=batch, build=build, loss_fn=_recognition_loss,
+                optimizer=lambda ps: FusedAdam(ps, lr=0.0), what="CRNN fp32 32x128 N=256")
+
+
+def crnn_n256():
+    if "crnn" in _CACHE:
+        return _CACHE["crnn"]
+    c = crnn_n256_hip()
+    ora, batch = c["ora"], c["batch"]
     lab, ln = batch['label'], batch['length'].long()
 
     def fwd(m, dt):
@@ -102,23 +117,14 @@ def crnn_n256():
         ev = ora(batch['image'], train=False)
     ora.train()
     print("oracle CRNN N=256 fwd+bwd (f32 and f64) + eval: %.1f s" % (time.time() - t0))
-
-    def build():
-        m = Model()
-        m.load_state_dict(state0)
-        return m.to(DEV).train()
-
-    _CACHE["crnn"] = dict(ora=ora, state0=state0, state1=state1, batch=batch, grads32=_grads(ora), grads64=grads64,
-                          out32={"loss": float(loss), "logp": logp.detach(), "eval": ev}, build=build,
-                          loss_fn=_recognition_loss, optimizer=lambda ps: FusedAdam(ps, lr=0.0),
-                          what="CRNN fp32 32x128 N=256")
-    return _CACHE["crnn"]
+    c.update(state1=state1, grads32=_grads(ora), grads64=grads64,
+             out32={"loss": float(loss), "logp": logp.detach(), "eval": ev})
+    _CACHE["crnn"] = c
+    return c
 
 
 # ------------------------------------------------------------------------------------ configs[2]: Res50-PPM + 2D-CTC, N = 256
-def res50ppm_n256():
-    if "res50ppm" in _CACHE:
-        return _CACHE["res50ppm"]
+def res50ppm_n256_hip():
     from megreader_amd.backbones import resnet50dilated_ppm
     from megreader_amd.decoders import CTCDecoder2D
     from megreader_amd.optim import FusedAdam
@@ -138,6 +144,25 @@ def res50ppm_n256():
     state0 = {k: v.clone() for k, v in ora.state_dict().items()}
     n, height, width = 256, 32, 128          # what bench.py times (bench.py: synthetic_batch_2d(bsz, 32, 128, max_len=3))
     batch = synthetic_batch_2d(n, height, width, seed=5, max_len=3)
+
+    def build():
+        m = Model()
+        m.load_state_dict(state0, strict=True)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout2d):
+                mod.p = 0.0
+        return m.to(DEV).train()
+
+    return dict(ora=ora, state0=state0, batch=batch, build=build, loss_fn=_recognition_loss,
+                optimizer=lambda ps: FusedAdam(ps, lr=0.0), what="Res50-PPM-2DCTC fp32 32x128 N=256")
+
+
+def res50ppm_n256():
+    if "res50ppm" in _CACHE:
+        return _CACHE["res50ppm"]
+    c = res50ppm_n256_hip()
+    ora, batch = c["ora"], c["batch"]
+    n, height, width = 256, 32, 128
     lab, ln = batch['label'], batch['length'].long()
     out64 = {}
 
@@ -154,26 +179,13 @@ def res50ppm_n256():
         loss_o, pred_o = ora(batch['image'], targets=lab, lengths=ln, train=True)
         loss_o.mean().backward()
         print("oracle Res50-PPM-2DCTC %dx%d N=%d fwd+bwd (f32 and f64): %.1f s" % (height, width, n, time.time() - t0))
-
-    def build():
-        m = Model()
-        m.load_state_dict(state0, strict=True)
-        for mod in m.modules():
-            if isinstance(mod, torch.nn.Dropout2d):
-                mod.p = 0.0
-        return m.to(DEV).train()
-
-    _CACHE["res50ppm"] = dict(ora=ora, state0=state0, batch=batch, grads32=_grads(ora), grads64=grads64, out64=out64,
-                              out32={"loss": loss_o.detach(), "pred": pred_o.detach()}, build=build,
-                              loss_fn=_recognition_loss, optimizer=lambda ps: FusedAdam(ps, lr=0.0),
-                              what="Res50-PPM-2DCTC fp32 32x128 N=256")
-    return _CACHE["res50ppm"]
+    c.update(grads32=_grads(ora), grads64=grads64, out64=out64, out32={"loss": loss_o.detach(), "pred": pred_o.detach()})
+    _CACHE["res50ppm"] = c
+    return c
 
 
 # ------------------------------------------------------------------------------------- configs[3]: FPN50 + attention, N = 32
-def fpn_attention_n32():
-    if "fpn" in _CACHE:
-        return _CACHE["fpn"]
+def fpn_attention_n32_hip():
     from megreader_amd.backbones import Resnet50FPN
     from megreader_amd.decoders import AttentionDecoder
     from megreader_amd.optim import FusedAdam
@@ -194,6 +206,21 @@ def fpn_attention_n32():
     state0 = {k: v.clone() for k, v in ora.state_dict().items()}
     n = 32
     batch = synthetic_batch(n, 64, 256, seed=21)
+
+    def build():
+        m = Model()
+        m.load_state_dict(state0, strict=True)
+        return m.to(DEV).train()
+
+    return dict(ora=ora, state0=state0, batch=batch, build=build, loss_fn=_recognition_loss,
+                optimizer=lambda ps: FusedAdam(ps, lr=0.0), what="FPN50-attention fp32 64x256 N=32")
+
+
+def fpn_attention_n32():
+    if "fpn" in _CACHE:
+        return _CACHE["fpn"]
+    c = fpn_attention_n32_hip()
+    ora, batch, n = c["ora"], c["batch"], 32
     lab, ln = batch['label'], batch['length'].long()
     out64 = {}
 
@@ -210,29 +237,19 @@ def fpn_attention_n32():
         loss_o, att_o = ora(batch['image'], targets=lab, lengths=ln, train=True)
         loss_o.mean().backward()
         print("oracle FPN50-attention 64x256 N=%d fwd+bwd (f32 and f64): %.1f s" % (n, time.time() - t0))
-
-    def build():
-        m = Model()
-        m.load_state_dict(state0, strict=True)
-        return m.to(DEV).train()
-
-    _CACHE["fpn"] = dict(ora=ora, state0=state0, batch=batch, grads32=_grads(ora), grads64=grads64, out64=out64,
-                         out32={"loss": loss_o.detach(), "att": att_o.detach()}, build=build,
-                         loss_fn=_recognition_loss, optimizer=lambda ps: FusedAdam(ps, lr=0.0),
-                         what="FPN50-attention fp32 64x256 N=32")
-    return _CACHE["fpn"]
+    c.update(grads32=_grads(ora), grads64=grads64, out64=out64, out32={"loss": loss_o.detach(), "att": att_o.detach()})
+    _CACHE["fpn"] = c
+    return c
 
 
 # --------------------------------------------------------------------------------------- configs[4]: DB detector, 640x640, N = 2
-def db_n2():
-    if "db" in _CACHE:
-        return _CACHE["db"]
+def db_n2_hip():
     from megreader_amd.backbones import deformable_resnet50
     from megreader_amd.decoders import L1BalanceCELoss, SegDetector
     from megreader_amd.optim import FusedSGD
     from megreader_amd.synthetic import detection_batch
     from oracle.res50ppm import _Res50Dilated
-    from oracle.seg_detector import SegDetectorOracle, l1_balance_ce_loss
+    from oracle.seg_detector import SegDetectorOracle
 
     class Oracle(torch.nn.Module):
         def __init__(self):
@@ -258,6 +275,27 @@ def db_n2():
     state0 = {k: v.clone() for k, v in ora.state_dict().items()}
     n, size = 2, 640
     batch = detection_batch(n, size, seed=3)
+
+    def build():
+        m = Model()
+        m.load_state_dict(state0, strict=True)
+        return m.to(DEV).train()
+
+    def loss_fn(model, b):
+        loss, _ = model.criterion(model(b['image']), b)
+        return loss
+
+    # seg_detector_db.yaml:85-94: SGD momentum 0.9, weight decay 1e-4 -- with lr = 0 the weights stay put
+    return dict(ora=ora, state0=state0, batch=batch, build=build, loss_fn=loss_fn,
+                optimizer=lambda ps: FusedSGD(ps, lr=0.0, momentum=0.9, weight_decay=1e-4), what="DB detector fp32 640x640 N=2")
+
+
+def db_n2():
+    if "db" in _CACHE:
+        return _CACHE["db"]
+    from oracle.seg_detector import l1_balance_ce_loss
+    c = db_n2_hip()
+    ora, batch, n, size = c["ora"], c["batch"], 2, 640
     out64 = {}
 
     def fwd(m, dt):
@@ -275,23 +313,10 @@ def db_n2():
         loss_o.backward()
         print("oracle DB detector %dx%d N=%d fwd+bwd (f32 and f64): %.1f s" % (size, size, n, time.time() - t0))
     loss64 = float(l1_balance_ce_loss(out64, {k: v.double() for k, v in batch.items()}))
-
-    def build():
-        m = Model()
-        m.load_state_dict(state0, strict=True)
-        return m.to(DEV).train()
-
-    def loss_fn(model, b):
-        loss, _ = model.criterion(model(b['image']), b)
-        return loss
-
-    # seg_detector_db.yaml:85-94: SGD momentum 0.9, weight decay 1e-4 -- with lr = 0 the weights stay put
-    _CACHE["db"] = dict(ora=ora, state0=state0, batch=batch, grads32=_grads(ora), grads64=grads64, out64=out64,
-                        out32={"pred": {k: v.detach() for k, v in pred_o.items()}, "loss": float(loss_o), "loss64": loss64},
-                        build=build, loss_fn=loss_fn,
-                        optimizer=lambda ps: FusedSGD(ps, lr=0.0, momentum=0.9, weight_decay=1e-4),
-                        what="DB detector fp32 640x640 N=2")
-    return _CACHE["db"]
+    c.update(grads32=_grads(ora), grads64=grads64, out64=out64,
+             out32={"pred": {k: v.detach() for k, v in pred_o.items()}, "loss": float(loss_o), "loss64": loss64})
+    _CACHE["db"] = c
+    return c
 
 
 def to_device(batch):

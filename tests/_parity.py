@@ -55,3 +55,47 @@ def grad_report(named_params, grads32, grads64, what, elem_floor=1e-2, l2_floor=
         print("%s: %d parameters; worst element-wise %.2e (%s; CPU f32 %.2e); worst L2 %.2e (%s; CPU f32 %.2e)" %
               (what, len(rows), we[2], we[0], we[3], wl[4], wl[0], wl[5]))
     assert not bad, (what, bad[:5])
+
+
+class ReluMasks(object):
+    """Census of ReLU decisions.  A gradient comparison between two runs of the same network is only meaningful while both
+    took the same side of every discontinuity: ONE pre-activation that rounds across zero in one run and not in the other
+    moves a whole per-pixel gradient term (4e-2 of max|g| on a 128 x 512 weight in round 4, profiles/r04_diag_fast_paths_after.txt:
+    ~10 % of otherwise identical repetitions of a 1.2 M-pre-activation layer stack, whatever fast path is on or off).  Record
+    the masks of both runs and compare them: identical masks + a gradient difference = a bug; differing masks = the
+    repetition says nothing about gradients (repeat it on another input).
+
+    hip(module):     every megreader_amd BatchNorm2d with a fused ReLU (the mask of its output; the last call wins)
+    bottleneck(blk): the oracle's _Bottleneck (bn1 / bn2 pre-activations and the block output), same keys as hip() gives"""
+
+    def __init__(self):
+        self.masks = {}
+        self.handles = []
+
+    def _put(self, key):
+        def hook(_m, _inp, out):
+            self.masks[key] = (out.detach() > 0).cpu()
+        return hook
+
+    def hip(self, module):
+        from megreader_amd.nn import BatchNorm2d
+        for name, m in module.named_modules():
+            if isinstance(m, BatchNorm2d) and m.fuse_relu:
+                self.handles.append(m.register_forward_hook(self._put(name)))
+        return self
+
+    def bottleneck(self, block):
+        self.handles.append(block.bn1.register_forward_hook(self._put("bn1")))
+        self.handles.append(block.bn2.register_forward_hook(self._put("bn2")))
+        self.handles.append(block.register_forward_hook(self._put("bn3")))     # relu(bn3(.) + residual)
+        return self
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []
+
+    def flips(self, other):
+        """Number of ReLU decisions that differ from `other` (same keys / shapes required)."""
+        assert self.masks.keys() == other.masks.keys() and self.masks, (sorted(self.masks), sorted(other.masks))
+        return sum(int((self.masks[k] != other.masks[k]).sum()) for k in self.masks)

@@ -16,7 +16,12 @@ round 3's red driver run (profiles/r04_diag_fast_paths_before.txt: same value wi
 optimizer, and on every run of the general DCN kernels).  Every test here that compares GRADIENTS therefore uses
 `perturb_offset_convs(kink_safe=True)` (offsets k + 0.5 +- 0.05 + a small feature-dependent part) and asserts the
 precondition itself (`min_kink_distance >= 0.1`); the default perturbation is kept for FORWARD comparisons, which are
-continuous."""
+continuous.
+The second discontinuity is ReLU: with the kinks out of the way, 15 % of the repetitions still differed by 4.2e-2 on
+`2.conv1.weight` (profiles/r04_diag_fast_paths_after.txt) -- ONE of 1.2 M pre-activations within 1e-7 of zero taking the other
+side under another summation order (the op-level DCN kernels are stable run to run: tools/diag_dcn_race.py,
+profiles/r04_diag_dcn_race.txt).  The gradient tests therefore record the ReLU masks of both runs (tests/_parity.py
+ReluMasks): identical masks + a gradient difference fail; a repetition with a flipped mask is repeated on another input."""
 import os
 
 import pytest
@@ -28,6 +33,7 @@ import megreader_amd as mr  # noqa: E402
 from megreader_amd.backbones import deformable_resnet50  # noqa: E402
 from oracle.dcn import min_kink_distance, perturb_offset_convs  # noqa: E402
 from oracle.res50ppm import _Res50Dilated  # noqa: E402
+from _parity import ReluMasks  # noqa: E402
 
 DEV = "cuda"
 
@@ -88,30 +94,40 @@ def test_block_parity(golden, block):
     x = captured['x']
     assert min_kink_distance(mod_o, x) >= 0.1          # precondition of the gradient comparison (module docstring)
     xo = x.clone().requires_grad_(True)
+    masks_o = ReluMasks().bottleneck(mod_o)
     yo = mod_o(xo)
+    masks_o.remove()
     g = torch.randn(yo.shape, generator=torch.Generator().manual_seed(3))
     yo.backward(g)
     mod_m = dict(model.named_modules())[block].to(DEV).train()
     xm = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    masks_m = ReluMasks().hip(mod_m)
     ym = mod_m(xm)
+    masks_m.remove()
     rel = lambda a, b: float((a.double().cpu() - b.double()).abs().max() / (b.double().abs().max() + 1e-12))  # noqa: E731
     assert rel(ym, yo) < 1e-4, rel(ym, yo)
     ym.backward(g.to(DEV).contiguous(memory_format=torch.channels_last))
     po = dict(mod_o.named_parameters())
     errs = {k: rel(p.grad, po[k].grad) for k, p in mod_m.named_parameters() if float(po[k].grad.abs().max()) >= 1e-7}
     errs["input"] = rel(xm.grad, xo.grad)
-    print("block %s: input-gradient error %.2e, worst parameter-gradient error %.2e (%s)" %
+    flips = masks_m.flips(masks_o)
+    print("block %s: input-gradient error %.2e, worst parameter-gradient error %.2e (%s); %d ReLU decisions differ" %
           (block, errs["input"], max(v for k, v in errs.items() if k != "input"),
-           max((v, k) for k, v in errs.items() if k != "input")[1]))
+           max((v, k) for k, v in errs.items() if k != "input")[1], flips))
     bad = {k: v for k, v in errs.items() if v >= (1e-3 if k == "input" else 2e-3)}
-    assert not bad, bad
+    if flips:
+        # a pre-activation within float32 round-off of zero took different sides on the CPU and the GPU: each such event moves
+        # one per-pixel gradient term (module docstring); bounded instead of exact -- an indexing bug moves O(1)
+        assert flips <= 3 and all(v < 0.15 for v in errs.values()), (flips, bad)
+    else:
+        assert not bad, bad
 
 
-def _fast_vs_plain(kink_safe):
+def _fast_vs_plain(kink_safe, input_seed=1):
     """layer2 of the deformable ResNet (four DCN bottlenecks, the first strided with a downsample branch): `plain` = one
     first forward / backward with plain autograd; `fast` = the same layers and input on the SECOND pass under FusedSGD(lr=0)
     (statistics from the conv epilogues, gradients into the optimizer's sinks).  Returns (relative forward difference,
-    {parameter: gradient difference / max|g|}, kink distance of the batch)."""
+    {parameter: gradient difference / max|g|}, kink distance of the batch, number of ReLU decisions that differ)."""
     import copy
     from megreader_amd.optim import FusedSGD
     mr.set_compute_dtype(torch.float32)
@@ -120,8 +136,9 @@ def _fast_vs_plain(kink_safe):
     perturb_offset_convs(full, kink_safe=kink_safe)
     plain = full.layer2.to(DEV).train()
     fast = copy.deepcopy(plain)
-    x = torch.randn(2, 256, 24, 32, device=DEV)
+    x = torch.randn(2, 256, 24, 32, generator=torch.Generator().manual_seed(input_seed)).to(DEV)
     dist = min_kink_distance(copy.deepcopy(plain), x)     # on a copy: `plain` must see its FIRST forward below
+    masks_p, masks_f = ReluMasks().hip(plain), ReluMasks().hip(fast)
     yp = plain(x)
     (yp.float() ** 2).mean().backward()
     ref = {k: p.grad.detach().clone() for k, p in plain.named_parameters() if p.grad is not None}
@@ -130,6 +147,8 @@ def _fast_vs_plain(kink_safe):
         opt.zero_grad()
         yf = fast(x)
         (yf.float() ** 2).mean().backward()
+    masks_p.remove()
+    masks_f.remove()
     producers = [m for m in fast.modules() if getattr(m, "feeds_batch_norm", False)]
     assert len(producers) == 9, len(producers)            # conv1 / conv3 of 4 blocks + the downsample conv (conv2 is the DCN)
     fwd = float((yf.detach().float() - yp.detach().float()).abs().max() / yp.detach().float().abs().max())
@@ -139,7 +158,7 @@ def _fast_vs_plain(kink_safe):
         scale = float(ref[k].abs().max())
         if scale >= 1e-9:
             errs[k] = float((p.grad - ref[k]).abs().max()) / scale
-    return fwd, errs, dist
+    return fwd, errs, dist, masks_f.flips(masks_p)
 
 
 def test_fast_paths_equal_plain_autograd():
@@ -148,22 +167,30 @@ def test_fast_paths_equal_plain_autograd():
     gradient -- incl. the 27-channel offset convolutions (Cout < stored channels) and the DCN weights -- is accumulated
     straight into the optimizer's flat buffer.  Same layers, same input: outputs and gradients must equal those of a first
     forward with plain autograd and no optimizer (float32; differences = summation order of atomics).
-    Kink-safe offsets (module docstring): the comparison is then smooth, 50 of 50 repetitions on one MI355X stay below 2e-5
-    (tools/diag_fast_paths.py --kink-safe, profiles/r04_diag_fast_paths_after.txt)."""
-    fwd, errs, dist = _fast_vs_plain(kink_safe=True)
-    worst = max(errs, key=errs.get)
-    print("fast paths vs plain autograd (kink-safe offsets, kink distance %.3f): forward difference %.2e of max|y|, worst "
-          "gradient difference %.2e of max|g| (%s)" % (dist, fwd, errs[worst], worst))
-    assert dist >= 0.1, dist
-    assert fwd < 2e-5, fwd
-    bad = [(k, e) for k, e in errs.items() if e > 2e-4]
-    assert not bad, bad[:8]
+    Kink-safe offsets and a ReLU census (module docstring): two repetitions whose ReLU masks agree between the two runs must
+    agree to 2e-4 on every gradient; repetitions with a flipped mask are skipped (at most four of six inputs)."""
+    clean = 0
+    for seed in range(1, 7):
+        fwd, errs, dist, flips = _fast_vs_plain(kink_safe=True, input_seed=seed)
+        worst = max(errs, key=errs.get)
+        print("fast paths vs plain autograd (input seed %d, kink distance %.3f, %d ReLU decisions differ): forward difference "
+              "%.2e of max|y|, worst gradient difference %.2e of max|g| (%s)" % (seed, dist, flips, fwd, errs[worst], worst))
+        assert dist >= 0.1, dist
+        assert fwd < 2e-5, fwd
+        if flips:
+            continue          # a pre-activation within round-off of zero: this repetition says nothing about gradients
+        bad = [(k, e) for k, e in errs.items() if e > 2e-4]
+        assert not bad, bad[:8]
+        clean += 1
+        if clean == 2:
+            break
+    assert clean == 2, "no two repetitions without a ReLU flip among six inputs"
 
 
 def test_fast_paths_forward_with_feature_dependent_offsets():
     """Same two runs with the default perturbation (offsets spread over the real line, some coordinates within 1e-5 of a kink):
     the FORWARD outputs are continuous in the offsets and must still agree; gradients are not compared (module docstring)."""
-    fwd, errs, dist = _fast_vs_plain(kink_safe=False)
+    fwd, errs, dist, _flips = _fast_vs_plain(kink_safe=False)
     print("fast paths vs plain autograd (feature-dependent offsets, kink distance %.1e): forward difference %.2e of max|y|; "
           "largest gradient difference %.2e (not asserted: bilinear kinks)" % (dist, fwd, max(errs.values())))
     assert fwd < 2e-5, fwd
