@@ -120,6 +120,12 @@ int mr_conv2d_fwd_stats(int dtype, const void* x, const void* w_krsc, const floa
 int mr_conv2d_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, int Nimg, int H, int W, int Cin,
                     int lddx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
                     int Ho, int Wo, hipStream_t stream);
+/* dx = dgrad(dy, w) + addend: the gradient of the residual branch of a ResNet block (backbones/resnet.py:152-181, `out +=
+ * residual`) is added in the epilogue of the dgrad of the block's first convolution.  addend: NHWC with dx's channel count and
+ * leading dimension, may alias dx, null = mr_conv2d_dgrad. */
+int mr_conv2d_dgrad_add(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, int Nimg, int H, int W,
+                        int Cin, int lddx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
+                        int Ho, int Wo, hipStream_t stream);
 /* dw_krsc (f32 [Cout][R][S][Cin]) and dbias (nullable, f32[Cout]) are accumulated atomically: zero them first.  Cout may be
  * smaller than lddy and need not be a multiple of the vector width when the channels Cout..lddy-1 of dy are zero padding
  * (27-channel DCN offset convolutions stored with 32): exactly Cout rows of dw / entries of dbias are written. */

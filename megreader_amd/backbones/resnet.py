@@ -86,8 +86,12 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        residual = x
-        out = self.bn1(self.conv1(x))
+        if self.downsample is None:      # identity shortcut: its gradient is added in conv1's dgrad epilogue (see Bottleneck)
+            out, residual = self.conv1.forward_fork(x)
+            out = self.bn1(out)
+        else:
+            residual = x
+            out = self.bn1(self.conv1(x))
         if not self.with_dcn:
             out = self.conv2(out)
         elif self.with_modulated_dcn:
@@ -127,8 +131,14 @@ class Bottleneck(nn.Module):
         self.dcn = dcn
 
     def forward(self, x):
-        residual = x
-        out = self.bn1(self.conv1(x))
+        if self.downsample is None:
+            # identity shortcut: x feeds conv1 AND the final add (reference resnet.py:152-181).  conv1 hands x back as a second
+            # output of its own node, so the shortcut's gradient is added in the epilogue of conv1's dgrad (nn.Conv2d.forward_fork)
+            out, residual = self.conv1.forward_fork(x)
+            out = self.bn1(out)
+        else:
+            residual = x
+            out = self.bn1(self.conv1(x))
         if not self.with_dcn:
             out = self.conv2(out)
         elif self.with_modulated_dcn:

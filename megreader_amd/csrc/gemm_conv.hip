@@ -36,6 +36,7 @@ static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // mr_conv2d_fwd_stats: the f64 column-statistics accumulators the NT launches of the current call attach to their epilogue
 // (EpiStore::stats), and whether every launch of the call could (the register-staged fallback kernel cannot)
 static thread_local double* g_epi_stats = nullptr;
+static thread_local const void* g_epi_addend = nullptr;   // second summand of the NT epilogue for THIS call (mr_conv2d_dgrad_add)
 static thread_local bool g_epi_stats_missed = false;
 
 // The direct-to-LDS NT kernels address their operands through buffer resources with 2 GiB of records.
@@ -60,7 +61,8 @@ static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long lon
   epi.relu = relu;
   epi.M = a.M;
   epi.N = a.N;
-  epi.vec_ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
+  epi.vec_ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0) && ((((uintptr_t)g_epi_addend) & 15) == 0);
+  epi.addend = (const T*)g_epi_addend;
   const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
   if constexpr (AMODE != 1) {
     if (g_nt_variant == 2 && nt_fits_buffer<T>(a, g, AMODE)) {
@@ -200,7 +202,8 @@ static int launch_nt_big(const NtArgs& a, const ConvGeom& g, void* C, long long 
   epi.relu = relu;
   epi.M = a.M;
   epi.N = a.N;
-  epi.vec_ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
+  epi.vec_ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0) && ((((uintptr_t)g_epi_addend) & 15) == 0);
+  epi.addend = (const T*)g_epi_addend;
   epi.stats = g_epi_stats;
   epi.stats_ncopy = MR_BN_COPIES;
   NtArgs a2 = a;
@@ -243,7 +246,8 @@ static int launch_nt_p8(const NtArgs& a, const ConvGeom& g, void* C, long long l
     epi.relu = relu;
     epi.M = a.M;
     epi.N = a.N;
-    epi.vec_ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
+    epi.vec_ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0) && ((((uintptr_t)g_epi_addend) & 15) == 0);
+  epi.addend = (const T*)g_epi_addend;
     epi.stats = g_epi_stats;
     epi.stats_ncopy = MR_BN_COPIES;
     NtArgs a2 = a;
@@ -707,6 +711,21 @@ int mr_conv2d_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, int
   }
   if (dtype == MR_F32) return dispatch_nt_store<float, 1>(a, g, dx, lddx, nullptr, 0, stream);
   return dispatch_nt_store<bf16_t, 1>(a, g, dx, lddx, nullptr, 0, stream);
+}
+
+// mr_conv2d_dgrad with a second summand in the epilogue: dx = dgrad(dy, w) + addend (addend: NHWC like dx, same lddx).  A
+// ResNet block's input receives its gradient from two branches (reference backbones/resnet.py:152-181: `out += residual`): the
+// residual branch's gradient rides in the epilogue of the dgrad of the block's first convolution instead of an elementwise add
+// kernel over the block input (18 per ResNet-50 step).  addend may alias dx (each element is read before it is written by the
+// same lane); null = plain mr_conv2d_dgrad.
+int mr_conv2d_dgrad_add(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, int Nimg, int H, int W,
+                        int Cin, int lddx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
+                        int Ho, int Wo, hipStream_t stream) {
+  g_epi_addend = addend;
+  const int rc = mr_conv2d_dgrad(dtype, dy, w_crsk, dx, Nimg, H, W, Cin, lddx, Cout, lddy, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo,
+                                 stream);
+  g_epi_addend = nullptr;
+  return rc;
 }
 
 // dw[k,r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*sh-ph+r*dh, wo*sw-pw+s*dw, c]   (f32, atomically accumulated)

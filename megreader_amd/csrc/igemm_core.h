@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_nt_big_kernel(NtArgs a, Co
     if (with_stats) cst.flush(epi, n0 + wn_ * WTN + lg * (4 * TN), l15);
 }
 
-// Plain epilogue: C = act(acc + bias) stored as T, row-major with leading dim ldc.
+// Plain epilogue: C = act(acc + bias [+ addend]) stored as T, row-major with leading dim ldc.
 template <typename T> struct EpiStore {
   T* C;
   long long ldc;
@@ -1032,12 +1032,22 @@ template <typename T> struct EpiStore {
   // stats[copy][1][n] += sum_m C[m][n]^2 over the values AS STORED (rounded to T); copy = workgroup % stats_ncopy
   double* stats = nullptr;
   int stats_ncopy = 1;
+  // optional second summand with C's own layout (same ldc, 16-byte aligned when vec_ok): C = act(acc + bias + addend).  The
+  // residual branch's gradient of a ResNet block rides in the epilogue of the dgrad of the block's first convolution instead of
+  // an elementwise add kernel over the block input's gradient (mr_conv2d_dgrad_add; reference backbones/resnet.py:152-181).
+  const T* addend = nullptr;
   __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
     if (m >= M || n >= N) return;
     if (bias) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (n + j < N) v[j] += bias[n + j];
+    }
+    if (addend) {
+      const T* a = addend + (long long)m * ldc + n;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n + j < N) v[j] += to_f32(a[j]);
     }
     if (relu) {
 #pragma unroll
@@ -1059,6 +1069,26 @@ template <typename T> struct EpiStore {
     constexpr int E16 = 16 / (int)sizeof(T);  // elements per 16-byte store
     if (m >= M) return;
     if (vec_ok && (ldc % E16) == 0 && (n % E16) == 0 && n + 4 * CNT <= N && (4 * CNT) % E16 == 0) {
+      uint4* dst = (uint4*)(C + (long long)m * ldc + n);
+      if (addend) {   // one 16-byte chunk at a time: at most 8 extra live registers next to the accumulators
+        const uint4* asrc = (const uint4*)(addend + (long long)m * ldc + n);
+#pragma unroll
+        for (int q = 0; q < 4 * CNT / E16; ++q) {
+          const uint4 av = asrc[q];
+          const T* ap = (const T*)&av;
+          T out[E16];
+#pragma unroll
+          for (int e = 0; e < E16; ++e) {
+            const int c = q * E16 + e;
+            float t = v[c / 4][c % 4] + to_f32(ap[e]);
+            if (bias) t += bias[n + c];
+            if (relu) t = fmaxf(t, 0.f);
+            out[e] = from_f32<T>(t);
+          }
+          dst[q] = *(const uint4*)out;
+        }
+        return;
+      }
       float x[4 * CNT];
 #pragma unroll
       for (int i = 0; i < CNT; ++i)
@@ -1072,7 +1102,6 @@ template <typename T> struct EpiStore {
       T out[4 * CNT];
 #pragma unroll
       for (int e = 0; e < 4 * CNT; ++e) out[e] = from_f32<T>(x[e]);
-      uint4* dst = (uint4*)(C + (long long)m * ldc + n);
       const uint4* src = (const uint4*)out;
 #pragma unroll
       for (int q = 0; q < 4 * CNT / E16; ++q) dst[q] = src[q];

@@ -223,6 +223,19 @@ def _zero_padded_base(gy, shape, dtype):
     return base
 
 
+def _zero_padded_rows(gy, M, Nout, Np, dtype):
+    """The tagged dense [..., Np] buffer behind the gradient `gy`, if `gy` is exactly its [..., :Nout] view; else None."""
+    base = gy._base
+    if base is None or not getattr(base, "_mr_zero_padded", False):
+        return None
+    if base.dtype != dtype or not base.is_contiguous() or base.shape[-1] != Np or base.numel() != M * Np:
+        return None
+    if gy.data_ptr() != base.data_ptr() or gy.shape[-1] != Nout or tuple(gy.shape[:-1]) != tuple(base.shape[:-1]) or \
+            tuple(gy.stride()) != tuple(base.stride()):
+        return None
+    return base.view(M, Np)
+
+
 def _conv_out(size, k, s, p, d):
     return (size + 2 * p - d * (k - 1) - 1) // s + 1
 
@@ -285,7 +298,8 @@ def _conv_operands(weight, bias, dtype, Cp, Kp, need_dx):
 # --------------------------------------------------------------------------------------------------
 class Conv2dFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation, relu, relu_grad_downstream=False, bn_sums=None):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, relu, relu_grad_downstream=False, bn_sums=None,
+                fork=False):
         require_cuda(x, weight, bias)
         dtype = get_compute_dtype()
         dt = dtype_code(dtype)
@@ -318,10 +332,15 @@ class Conv2dFn(Function):
         ctx.relu = relu and not relu_grad_downstream  # else the consumer (max-pool) applies the ReLU mask
         ctx.has_bias = bias is not None
         ctx.dtype = dtype
-        return (y if Kp == K else y[..., :K]).permute(0, 3, 1, 2)
+        out = (y if Kp == K else y[..., :K]).permute(0, 3, 1, 2)
+        if fork:
+            # second output: x itself, as an output of THIS node (conv2d_fork).  Its gradient -- the residual branch of a
+            # ResNet block -- arrives in backward together with gy and is added in the dgrad epilogue
+            return out, x.view_as(x)
+        return out
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_fork=None):
         xi, w_crsk, y = ctx.saved_tensors
         N, H, W, Cp, C, K, Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo = ctx.geom
         dtype = ctx.dtype
@@ -340,9 +359,18 @@ class Conv2dFn(Function):
         dx = dwt = db = None
         if ctx.needs_input_grad[0]:
             dxi = torch.empty((N, H, W, C), dtype=dtype, device=g.device)
-            call("mr_conv2d_dgrad", dt, ptr(g), ptr(w_crsk), ptr(dxi), N, H, W, C, C, Kp, Kp, R, S, sh, sw, ph, pw,
-                 dh, dw, Ho, Wo)
+            if g_fork is not None:     # dx = dgrad(g) + gradient of the forked alias of x, one kernel (mr_conv2d_dgrad_add)
+                ga = _grad_internal(g_fork, dtype)
+                if tuple(ga.shape) != (N, H, W, C) or not ga.is_contiguous():
+                    ga = ga.contiguous()
+                call("mr_conv2d_dgrad_add", dt, ptr(g), ptr(w_crsk), ptr(dxi), ptr(ga), N, H, W, C, C, Kp, Kp, R, S, sh, sw,
+                     ph, pw, dh, dw, Ho, Wo)
+            else:
+                call("mr_conv2d_dgrad", dt, ptr(g), ptr(w_crsk), ptr(dxi), N, H, W, C, C, Kp, Kp, R, S, sh, sw, ph, pw,
+                     dh, dw, Ho, Wo)
             dx = dxi.permute(0, 3, 1, 2)
+        elif g_fork is not None:
+            raise RuntimeError("conv2d_fork: the forked input received a gradient but the convolution input needs none")
         weight_p, bias_p = ctx.params
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         # gradient sinks (see grad_sink): the wgrad / bias kernels accumulate directly into the flat gradient buffer
@@ -380,7 +408,7 @@ class Conv2dFn(Function):
                 notify_grad_ready(bias_p)
             elif Kp != K:
                 db = db[:K]
-        return dx, dwt, db, None, None, None, None, None, None
+        return dx, dwt, db, None, None, None, None, None, None, None
 
 
 class BnStatsHandoff(object):
@@ -393,23 +421,32 @@ class BnStatsHandoff(object):
 
 
 def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), relu=False,
-           relu_grad_downstream=False, bn_stats=False):
+           relu_grad_downstream=False, bn_stats=False, fork=False):
     """relu_grad_downstream=True: the only consumer is a max_pool2d(..., relu_input=True), whose backward applies
     this layer's ReLU mask (saves one pass over the largest activation gradients).
     bn_stats=True: a training-mode BatchNorm consumes the output: its per-channel sum / sum of squares are accumulated in
     the epilogue of the convolution's GEMM and travel with the returned tensor (`_mr_bn_sums`); batch_norm() then skips its
-    statistics pass.  Ignored (plain convolution) with a fused ReLU, padded output channels or an exhausted ZeroArena."""
+    statistics pass.  Ignored (plain convolution) with a fused ReLU, padded output channels or an exhausted ZeroArena.
+    fork=True: returns (y, x'), x' = x as a second output of the same autograd node.  Use x' wherever else the block needs x
+    (the identity shortcut of a ResNet block, reference backbones/resnet.py:152-181): the gradients of both uses then meet in
+    this convolution's backward, where the shortcut's gradient is added in the dgrad epilogue (mr_conv2d_dgrad_add) instead of
+    by a separate elementwise kernel."""
     sums = None
     if bn_stats and not relu and x.is_cuda:
         K = weight.shape[0]
         if K % vec_of(get_compute_dtype()) == 0:
             sums = ZeroArena.take(x.device, load().mr_bn_scratch_doubles(K))
+    want_fork = bool(fork)
+    fork = want_fork and x.requires_grad and torch.is_grad_enabled()     # nothing to fuse when x needs no gradient
     y = Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation), bool(relu),
-                       bool(relu_grad_downstream), sums)
+                       bool(relu_grad_downstream), sums, fork)
+    x_fork = x
+    if fork:
+        y, x_fork = y
     if sums is not None:
         y._mr_bn_sums = BnStatsHandoff(sums, y.data_ptr(), get_compute_dtype(), y.shape[0] * y.shape[2] * y.shape[3],
                                        y.shape[1])
-    return y
+    return (y, x_fork) if want_fork else y
 
 
 # --------------------------------------------------------------------------------------------------
@@ -795,8 +832,10 @@ class LinearFn(Function):
         dt = dtype_code(dtype)
         g2 = gy.reshape(-1, Nout) if gy.shape[-1] == Nout else gy
         if Np != Nout:
-            gp = torch.zeros((M, Np), dtype=dtype, device=gy.device)
-            gp[:, :Nout] = g2
+            gp = _zero_padded_rows(gy, M, Nout, Np, dtype)   # producer already wrote a zero-padded [M, Np] buffer (CTC head)
+            if gp is None:
+                gp = torch.zeros((M, Np), dtype=dtype, device=gy.device)
+                gp[:, :Nout] = g2
         else:
             gp = g2 if (g2.dtype == dtype and g2.is_contiguous()) else g2.to(dtype).contiguous()
         dx = dw = db = None
@@ -1013,6 +1052,9 @@ def bilstm(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
 #   pred = log_softmax(pred, dim=2).to(float64); loss = nn.CTCLoss(zero_infinity=True)(pred, targets, [T]*b, lengths)
 # Returns (loss f64 scalar, log_probs f32 [T,N,C]).
 # --------------------------------------------------------------------------------------------------
+_FULL_LENGTHS = {}
+
+
 class CTCLossFn(Function):
     @staticmethod
     def forward(ctx, logits, targets, input_lengths, target_lengths, blank, zero_infinity):
@@ -1030,8 +1072,13 @@ class CTCLossFn(Function):
         targets = targets.contiguous()
         if targets.dtype not in (torch.int32, torch.int64):
             targets = targets.long()
-        if input_lengths is None:
-            input_lengths = torch.full((N,), T, dtype=torch.int64, device=logits.device)
+        if input_lengths is None:   # nn.CTCLoss with input_lengths = [T] * N (decoders/crnn.py:97): a cached constant, no fill launch
+            key = (N, T, logits.device)
+            input_lengths = _FULL_LENGTHS.get(key)
+            if input_lengths is None:
+                if len(_FULL_LENGTHS) > 64:
+                    _FULL_LENGTHS.clear()
+                input_lengths = _FULL_LENGTHS[key] = torch.full((N,), T, dtype=torch.int64, device=logits.device)
         input_lengths = input_lengths.to(device=logits.device, dtype=torch.int64).contiguous()
         target_lengths = target_lengths.to(device=logits.device, dtype=torch.int64).contiguous()
         dev = logits.device
@@ -1066,6 +1113,8 @@ class CTCLossFn(Function):
         call("mr_ctc_bwd", dtype_code(dtype), ptr(lp), ptr(alpha), ptr(beta), ptr(nll), ptr(targets), t64,
              ptr(input_lengths),
              ptr(target_lengths), 1, ptr(g), T, N, C, S, blank, zero_inf, ptr(grad), Cp)
+        if Cp != C:
+            mark_zero_padded(grad)    # the padded Linear in front takes the buffer as it is (LinearFn.backward)
         return grad[..., :C], None, None, None, None, None
 
 

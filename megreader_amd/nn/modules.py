@@ -12,6 +12,10 @@ from . import functional as F
 BN_EPILOGUE = __import__("os").environ.get("MEGREADER_BN_EPILOGUE", "1") != "0"
 
 
+# A/B switch (tools/): MEGREADER_FORK_RESIDUAL=0 leaves the shortcut's gradient add to autograd (an ATen add kernel per block)
+FORK_RESIDUAL = __import__("os").environ.get("MEGREADER_FORK_RESIDUAL", "1") != "0"
+
+
 def _pair(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
@@ -38,6 +42,18 @@ class Conv2d(nn.Conv2d):
                      self.relu_grad_downstream, bn_stats=self.feeds_batch_norm and self.training and BN_EPILOGUE)
         y._mr_producer = self
         return y
+
+    def forward_fork(self, x):
+        """(self(x), x') with x' = x as a second output of this convolution's autograd node: a residual block passes x' to its
+        identity shortcut, and the shortcut's gradient is then added in the epilogue of this convolution's dgrad
+        (F.conv2d(fork=True)) instead of by an elementwise kernel over the block input's gradient."""
+        if not FORK_RESIDUAL:
+            return self.forward(x), x
+        y, xr = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.fuse_relu,
+                         self.relu_grad_downstream, bn_stats=self.feeds_batch_norm and self.training and BN_EPILOGUE,
+                         fork=True)
+        y._mr_producer = self
+        return y, xr
 
 
 class FusedReLU(nn.Module):

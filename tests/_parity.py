@@ -1,12 +1,17 @@
-"""Shared helpers of the full-size parity tests (tests/test_fullsize_parity_gpu.py, tests/test_published_configs_gpu.py).
+"""Shared helpers of the full-size parity tests (tests/test_fullsize_parity_gpu.py, tests/test_published_configs_gpu.py,
+tests/test_timed_step_gpu.py).
 
 Ground truth for gradients is the CPU oracle run in FLOAT64; the bar is "HIP-f32 is as close to it as the reference's own
-f32 arithmetic (the oracle in f32)": for every parameter
-    max|g_hip - g_64| <= max(4 * max|g_cpu32 - g_64|, 1e-2 * max|g_64|)        element-wise
+f32 arithmetic (the oracle in f32)": for every parameter, with e = |g - g_64| / max|g_64| element-wise,
+    e_hip <= max(4 * max e_cpu32, 2e-3)                                       for every element, or else
+    at most max(3, min(16, 2 %)) elements of the tensor above that, none above max(4 * max e_cpu32, 1e-2)   (the CENSUS)
     ||g_hip - g_64||_2 <= max(4 * ||g_cpu32 - g_64||_2, 2e-3 * ||g_64||_2)
-(the 1e-2 floor is the size of ONE discontinuity event -- a ReLU / max-pool / top-k decision that rounds to the other side
-in one precision; an indexing or layout bug moves elements by O(max|g|)).  Every parameter's errors are recorded in
-`REPORT` and printed; the measured maxima go into DESIGN.md's parity table.
+Round 3 had a flat 1e-2 floor.  The floor is now 2e-3; what may exceed it is only a handful of ISOLATED elements, each the
+footprint of one discontinuity event -- a ReLU pre-activation, max-pool tie or top-k boundary that rounds to the other side in
+one precision moves one per-pixel gradient term (demonstrated with recorded ReLU masks in tests/test_deformable_resnet_gpu.py
+and tests/test_seg_detector_gpu.py: identical masks -> 2e-6, one flipped mask -> 1e-2 class) -- and every such element is
+counted and printed.  An indexing or layout bug moves MANY elements by O(max|g|) and fails both clauses.  Every parameter's
+errors are recorded in `REPORT` and printed; the measured maxima go into DESIGN.md's parity table.
 """
 import copy
 
@@ -23,8 +28,8 @@ def f64_grads(ora32, forward):
     return {k: p.grad.detach().clone() for k, p in ora64.named_parameters() if p.grad is not None}
 
 
-def grad_report(named_params, grads32, grads64, what, elem_floor=1e-2, l2_floor=2e-3, top=25, always=()):
-    rows, bad = [], []
+def grad_report(named_params, grads32, grads64, what, elem_floor=2e-3, l2_floor=2e-3, top=25, always=(), census_cap=1e-2):
+    rows, bad, census = [], [], []
     for k, p in named_params:
         g64 = grads64[k].double()
         assert p.grad is not None, (what, k, "no HIP gradient")
@@ -36,24 +41,34 @@ def grad_report(named_params, grads32, grads64, what, elem_floor=1e-2, l2_floor=
             assert float(g.abs().max()) < 1e-3, (k, "zero-gradient parameter has a large HIP gradient")
             continue
         g32 = grads32[k].double()
-        e_hip = float((g - g64).abs().max()) / scale
+        err = (g - g64).abs() / scale
+        e_hip = float(err.max())
         e_cpu = float((g32 - g64).abs().max()) / scale
         l_hip = float((g - g64).norm() / g64.norm())
         l_cpu = float((g32 - g64).norm() / g64.norm())
         rows.append((k, scale, e_hip, e_cpu, l_hip, l_cpu))
-        if e_hip > max(4 * e_cpu, elem_floor) or l_hip > max(4 * l_cpu, l2_floor):
-            bad.append((k, e_hip, e_cpu, l_hip, l_cpu))
+        bar = max(4 * e_cpu, elem_floor)
+        n_hi = int((err > bar).sum()) if e_hip > bar else 0
+        if n_hi:
+            census.append((k, n_hi, g.numel(), e_hip, e_cpu))
+        if (n_hi and (n_hi > max(3, min(16, g.numel() // 50)) or e_hip > max(4 * e_cpu, census_cap))) or \
+                l_hip > max(4 * l_cpu, l2_floor):
+            bad.append((k, e_hip, e_cpu, l_hip, l_cpu, n_hi))
     print("%s: element-wise gradient error / max|g_f64|   (HIP f32 | CPU f32 oracle)   rel. L2 (HIP | CPU)" % what)
     shown = rows if len(rows) <= 60 else sorted(rows, key=lambda r: -r[2])[:top]
     shown = shown + [r for r in rows if r not in shown and any(a in r[0] for a in always)]
     for k, scale, e_hip, e_cpu, l_hip, l_cpu in shown:
         print("   %-56s max|g| %.3e   %.2e | %.2e    %.2e | %.2e" % (k, scale, e_hip, e_cpu, l_hip, l_cpu))
+    for k, n_hi, numel, e_hip, e_cpu in census:
+        print("   census: %-47s %d of %d elements above max(4 x CPU-f32 error, %.0e) (largest %.2e; CPU f32 %.2e): isolated "
+              "discontinuity events" % (k, n_hi, numel, elem_floor, e_hip, e_cpu))
     if rows:
         we = max(rows, key=lambda r: r[2])
         wl = max(rows, key=lambda r: r[4])
-        REPORT[what] = {"worst_elem": (we[0], we[2], we[3]), "worst_l2": (wl[0], wl[4], wl[5]), "params": len(rows)}
-        print("%s: %d parameters; worst element-wise %.2e (%s; CPU f32 %.2e); worst L2 %.2e (%s; CPU f32 %.2e)" %
-              (what, len(rows), we[2], we[0], we[3], wl[4], wl[0], wl[5]))
+        REPORT[what] = {"worst_elem": (we[0], we[2], we[3]), "worst_l2": (wl[0], wl[4], wl[5]), "params": len(rows),
+                        "census": [(k, n, m) for k, n, m, _, _ in census]}
+        print("%s: %d parameters; worst element-wise %.2e (%s; CPU f32 %.2e); worst L2 %.2e (%s; CPU f32 %.2e); %d parameters "
+              "with census elements" % (what, len(rows), we[2], we[0], we[3], wl[4], wl[0], wl[5], len(census)))
     assert not bad, (what, bad[:5])
 
 

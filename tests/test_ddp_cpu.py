@@ -445,3 +445,66 @@ def test_folded_average_allows_one_backward_per_step():
         assert ddp.last_backward["all_reduces"] == ddp.last_backward["buckets"]
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's `-d` path (train.py -d -> structure/model.py:27-36 `parallelize`: apex.parallel.DistributedDataParallel(
+# model.cuda())) under dropin.install(), two gloo ranks: the UNMODIFIED reference function must resolve to the RCCL / gloo shim,
+# broadcast rank 0's weights and leave the gradient average in .grad.  (CPU container: `.cuda()` is the one call that cannot run
+# here and is made a no-op for the tiny torch model; the HIP modules take the same shim on the GPU, tests/test_ddp_gpu.py.)
+# ---------------------------------------------------------------------------------------------------------------
+def _dropin_d_worker(rank, world, port, ref_root, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.chdir("/tmp")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import megreader_amd.dropin as dropin
+    dropin.install(ref_root)
+    import structure.model as sm                         # the reference file, unchanged
+    assert os.path.abspath(sm.__file__).startswith(ref_root)
+    import apex
+    from megreader_amd.apex.parallel import DistributedDataParallel as Shim
+    assert apex.parallel.DistributedDataParallel is Shim
+    torch.nn.Module.cuda = lambda self, device=None: self          # no GPU in this container
+    torch.manual_seed(100 + rank)
+    net = FlatNet()
+    model = sm.parallelize(net, True, rank)              # structure/model.py:27-36 with distributed=True
+    assert isinstance(model, Shim) and model.module is net
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(8, 8, generator=g)
+    model(X[rank * 4:(rank + 1) * 4]).mean().backward()
+    q.put((rank, {k: p.grad.numpy().copy() for k, p in net.named_parameters()},
+           {k: v.numpy().copy() for k, v in net.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reference_parallelize_dash_d_resolves_to_the_shim():
+    from oracle import refimport
+    if not refimport.available():
+        pytest.skip("reference tree only exists in the build container")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dropin_d_worker, args=(r, 2, port, os.path.abspath(refimport.REF_ROOT), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, grads, state = q.get(timeout=180)
+        res[rank] = (grads, state)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(100)
+    ref = FlatNet()
+    for k, v in ref.state_dict().items():                 # rank 0's weights on both ranks
+        assert torch.equal(torch.from_numpy(res[0][1][k]), v) and torch.equal(torch.from_numpy(res[1][1][k]), v), k
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(8, 8, generator=g)
+    ref(X).mean().backward()                              # equal per-rank batches: mean of the rank means == full-batch mean
+    for k, p in ref.named_parameters():
+        g0, g1 = torch.from_numpy(res[0][0][k]), torch.from_numpy(res[1][0][k])
+        assert torch.equal(g0, g1), k
+        assert torch.allclose(g0, p.grad, atol=1e-6, rtol=1e-5), k

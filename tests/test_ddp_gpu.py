@@ -179,3 +179,77 @@ def test_graphed_train_step_with_grad_sync_single_rank_rccl():
     for a, b in zip(got, ref):
         assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), (got, ref)      # bf16, f32 atomics order differs run to run
     assert ref[-1] < ref[0] and got[-1] < got[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# apex.parallel.SyncBatchNorm over a REAL process group.  The box has one GPU: two processes share it
+# and talk through gloo (which carries CUDA tensors through the host) -- what is exercised is the module's own two collectives
+# (per-channel sums + count forward, dbeta / dgamma backward) on a real torch.distributed group with an UNEVEN batch split,
+# against plain BatchNorm2d on the concatenated batch in this process.
+# ---------------------------------------------------------------------------------------------------------------
+def _syncbn_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as d
+    d.init_process_group("gloo", rank=rank, world_size=world)
+    import megreader_amd as m
+    from megreader_amd.apex.parallel import SyncBatchNorm
+    m.set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(5)
+    x_all = torch.randn(7, 64, 5, 9, generator=g) * 2.0 + 0.5
+    gy_all = torch.randn(7, 64, 5, 9, generator=g)
+    lo, hi = (0, 3) if rank == 0 else (3, 7)                 # uneven split: the count travels with the sums
+    bn = SyncBatchNorm(64).to("cuda").train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, 64))
+        bn.bias.copy_(torch.linspace(-0.2, 0.3, 64))
+    x = x_all[lo:hi].to("cuda").requires_grad_(True)
+    y = bn(x)
+    y.float().backward(gy_all[lo:hi].to("cuda"))
+    q.put((rank, y.detach().float().cpu().numpy(), x.grad.float().cpu().numpy(), bn.weight.grad.cpu().numpy(),
+           bn.bias.grad.cpu().numpy(), bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy()))
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_sync_batch_norm_two_processes_one_gpu():
+    import numpy as np
+    import torch.multiprocessing as mp
+    from megreader_amd.nn import BatchNorm2d
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        item = q.get(timeout=300)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    mr.set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(5)
+    x_all = torch.randn(7, 64, 5, 9, generator=g) * 2.0 + 0.5
+    gy_all = torch.randn(7, 64, 5, 9, generator=g)
+    bn = BatchNorm2d(64).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, 64))
+        bn.bias.copy_(torch.linspace(-0.2, 0.3, 64))
+    x = x_all.to(DEV).requires_grad_(True)
+    y = bn(x)
+    y.float().backward(gy_all.to(DEV))
+    y_ref, dx_ref = y.detach().float().cpu().numpy(), x.grad.float().cpu().numpy()
+    y_two = np.concatenate([res[0][0], res[1][0]])
+    dx_two = np.concatenate([res[0][1], res[1][1]])
+    assert np.abs(y_two - y_ref).max() < 5e-5 * np.abs(y_ref).max()
+    assert np.abs(dx_two - dx_ref).max() < 1e-4 * np.abs(dx_ref).max()
+    # parameter gradients are LOCAL sums (apex semantics: the DDP wrapper averages them afterwards): they add up to the full batch's
+    assert np.abs(res[0][2] + res[1][2] - bn.weight.grad.cpu().numpy()).max() < 1e-4 * np.abs(bn.weight.grad.cpu().numpy()).max()
+    assert np.abs(res[0][3] + res[1][3] - bn.bias.grad.cpu().numpy()).max() < 1e-4 * np.abs(bn.bias.grad.cpu().numpy()).max()
+    for r in (0, 1):                                       # both ranks hold the GLOBAL running statistics
+        assert np.abs(res[r][4] - bn.running_mean.cpu().numpy()).max() < 1e-5
+        assert np.abs(res[r][5] - bn.running_var.cpu().numpy()).max() < 1e-4

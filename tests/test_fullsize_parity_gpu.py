@@ -9,9 +9,10 @@ Bars (BASELINE.json north_star: loss/logits within 1e-4 fp32, decode bit-exact):
         Gradients: a weight gradient of the first layers is a 1M-term f32 sum with heavy cancellation, so the CPU's own
         f32 result is only good to ~1e-3 of max|g| there; the ground truth is therefore the oracle run in FLOAT64 and the
         bar is "HIP-f32 is as close to it as the reference's own f32 arithmetic": for every parameter
-        max|g_hip - g_64| <= max(4 * max|g_cpu32 - g_64|, 1e-2 * max|g_64|)   (element-wise) and
+        max|g_hip - g_64| <= max(4 * max|g_cpu32 - g_64|, 2e-3 * max|g_64|)   (element-wise; round 4: the flat 1e-2 floor
+        became 2e-3 plus a counted census of at most max(3, min(16, 2 %)) isolated elements up to 1e-2, tests/_parity.py) and
         ||g_hip - g_64||_2 <= max(4 * ||g_cpu32 - g_64||_2, 2e-3 * ||g_64||_2).
-        The 1e-2 floor is the size of ONE discontinuity event: ReLU and max-pool are not continuous, so a single
+        The census cap is the size of ONE discontinuity event: ReLU and max-pool are not continuous, so a single
         pre-activation whose f32 value rounds across zero (or a near-tie in a pooling window) moves a whole per-pixel
         gradient term -- 0.5 % of an element of the cnn.3 / cnn.5 bias gradients at this batch; the CPU f32 oracle shows
         the same events (cnn.3 bias 5.9e-4, conv weights 1e-3..5e-3), just not always in the same tensors.  An indexing
@@ -87,30 +88,11 @@ def _crnn_oracle_run():
 
 
 def _grad_report(named_params, grads_pair, what):
-    """Element-wise gradient comparison of every parameter against the float64 oracle, next to the f32 oracle's own
-    error against it.  Prints one line per parameter; asserts the bar of the module docstring."""
+    """Element-wise gradient comparison of every parameter against the float64 oracle, next to the f32 oracle's own error against
+    it: tests/_parity.py grad_report (2e-3 floor + census of isolated discontinuity events, round 4)."""
+    from _parity import grad_report
     grads32, grads64 = grads_pair
-    rows, bad = [], []
-    for k, p in named_params:
-        g64 = grads64[k].double()
-        g = p.grad.double().cpu()
-        assert g.shape == g64.shape, k
-        scale = float(g64.abs().max())
-        if scale < 1e-7:
-            # conv biases in front of a BatchNorm: mathematically zero gradient (pure round-off on every side)
-            assert float(g.abs().max()) < 1e-3, (k, "zero-gradient parameter has a large HIP gradient")
-            continue
-        e_hip = float((g - g64).abs().max()) / scale
-        e_cpu = float((grads32[k].double() - g64).abs().max()) / scale
-        l_hip = float((g - g64).norm() / g64.norm())
-        l_cpu = float((grads32[k].double() - g64).norm() / g64.norm())
-        rows.append((k, scale, e_hip, e_cpu))
-        if e_hip > max(4 * e_cpu, 1e-2) or l_hip > max(4 * l_cpu, 2e-3):
-            bad.append((k, e_hip, e_cpu, l_hip, l_cpu))
-    print("%s: element-wise gradient error / max|g_f64|   (HIP f32 | CPU f32 oracle)" % what)
-    for k, scale, e_hip, e_cpu in rows if len(rows) <= 60 else sorted(rows, key=lambda r: -r[2])[:25]:
-        print("   %-52s max|g| %.3e   %.2e | %.2e" % (k, scale, e_hip, e_cpu))
-    assert not bad, (what, bad[:5])
+    grad_report([(k, p) for k, p in named_params if k in grads64], grads32, grads64, what)
 
 
 def test_crnn_fp32_full_batch_elementwise():

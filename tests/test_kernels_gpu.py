@@ -945,3 +945,85 @@ def test_sync_batch_norm_two_virtual_ranks_equal_full_batch(relu):
     want = (x - bn.running_mean.view(1, C, 1, 1)) / torch.sqrt(bn.running_var.view(1, C, 1, 1) + 1e-5) * w0.view(1, C, 1, 1) \
         + b0.view(1, C, 1, 1)
     assert _rel_err(ye, torch.relu(want) if relu else want) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# mr_conv2d_dgrad_add: dx = dgrad(dy, w) + addend in the NT epilogue (the shortcut gradient of a ResNet block, reference
+# backbones/resnet.py:152-181), on every NT kernel family a dgrad can be dispatched to.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,H,W,Cin,Cout,R", [
+    (256, 8, 32, 256, 64, 1),      # ResNet layer1 conv1 dgrad at the benchmarked batch: M = 65536 (big / 128x128 tiles)
+    (32, 4, 16, 1024, 256, 1),     # layer3: M = 2048, N = 1024 (small-M launch: deep-pipelined 4-wave kernel)
+    (2, 20, 20, 2048, 512, 1),     # layer4 of the detector at batch 2: M = 800, ragged last tile
+    (4, 9, 13, 64, 64, 3),         # 3x3 BasicBlock conv1, odd sizes (gathered operand, AMODE 2)
+    (3, 7, 5, 72, 40, 3),          # Cin not a multiple of the k-step: register-staged / AMODE 3 path
+])
+def test_conv_dgrad_with_addend_epilogue(dtype, N, H, W, Cin, Cout, R):
+    mr.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(N * H + Cin)
+    pad = R // 2
+    dy = torch.randn(N, H, W, Cout, generator=g).to(DEV, dtype)
+    w = (torch.randn(Cout, Cin, R, R, generator=g) / math.sqrt(Cout * R * R)).to(DEV)
+    add = torch.randn(N, H, W, Cin, generator=g).to(DEV, dtype)
+    w_crsk = w.permute(1, 2, 3, 0).contiguous().to(dtype)            # [Cin][R][S][Cout]
+    dt = dtype_code(dtype)
+    plain = torch.empty(N, H, W, Cin, device=DEV, dtype=dtype)
+    fused = torch.full((N, H, W, Cin), 3.0, device=DEV, dtype=dtype)
+    args = (N, H, W, Cin, Cin, Cout, Cout, R, R, 1, 1, pad, pad, 1, 1, H, W)
+    call("mr_conv2d_dgrad", dt, ptr(dy), ptr(w_crsk), ptr(plain), *args)
+    call("mr_conv2d_dgrad_add", dt, ptr(dy), ptr(w_crsk), ptr(fused), ptr(add), *args)
+    ref = TF.conv_transpose2d(dy.double().cpu().permute(0, 3, 1, 2), w_crsk.double().cpu().permute(3, 0, 1, 2), padding=pad)
+    ref = ref.permute(0, 2, 3, 1) + add.double().cpu()
+    assert _rel_err(fused, ref) < _tol(dtype, Cout * R * R)
+    # against the unfused pair: same accumulator, one rounding less in bf16 -- equal up to one output ulp
+    two = plain.float() + add.float()
+    assert float((fused.float() - two).abs().max()) <= (1e-5 if dtype == torch.float32 else 2 ** -7) * float(two.abs().max())
+    # in place: the addend may alias dx (each element is read before the same lane writes it)
+    alias = add.clone()
+    call("mr_conv2d_dgrad_add", dt, ptr(dy), ptr(w_crsk), ptr(alias), ptr(alias), *args)
+    assert torch.equal(alias, fused)
+    # null addend == plain dgrad, bit for bit
+    again = torch.empty_like(plain)
+    call("mr_conv2d_dgrad_add", dt, ptr(dy), ptr(w_crsk), ptr(again), 0, *args)
+    assert torch.equal(again, plain)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("block", ["bottleneck", "basic"])
+def test_residual_block_fork_equals_autograd_add(dtype, block):
+    """Identity-shortcut blocks hand x to the shortcut as a second output of conv1's autograd node (nn.Conv2d.forward_fork), so
+    the two gradients of x meet in ONE kernel.  Same block with the fork switched off (autograd's own add): same outputs,
+    same gradients."""
+    import copy
+    from megreader_amd.backbones.resnet import BasicBlock, Bottleneck
+    from megreader_amd.nn import modules as mrm
+    mr.set_compute_dtype(dtype)
+    torch.manual_seed(3)
+    blk = (Bottleneck(256, 64) if block == "bottleneck" else BasicBlock(64, 64)).to(DEV).train()
+    ref = copy.deepcopy(blk)
+    c = 256 if block == "bottleneck" else 64
+    x0 = torch.randn(4, c, 10, 14, device=DEV)
+    gy = torch.randn(4, c, 10, 14, device=DEV)
+    outs = []
+    for m, fork in ((blk, True), (ref, False)):
+        mrm.FORK_RESIDUAL = fork
+        try:
+            x = (x0 * 1.0).requires_grad_(True)
+            xin = x * 1.0                                  # non-leaf input, like inside a network
+            y = m(xin)
+            y.float().backward(gy)
+        finally:
+            mrm.FORK_RESIDUAL = True
+        outs.append((y.detach().float(), x.grad.detach().float(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+    (y1, dx1, g1), (y2, dx2, g2) = outs
+    assert torch.equal(y1, y2)                             # the forward is the same kernels either way
+    tol = 1e-5 if dtype == torch.float32 else 1.6e-2
+    assert _rel_err(dx1, dx2) < tol
+    for k in g1:
+        assert _rel_err(g1[k], g2[k]) < tol, k
+    # eval / no_grad: nothing to fuse, the module still returns the right thing
+    blk.eval()
+    with torch.no_grad():
+        ye = blk(x0)
+    assert ye.shape == y1.shape and torch.isfinite(ye.float()).all()

@@ -39,7 +39,22 @@ def test_res50ppm_2dctc_fp32_n256_elementwise():
     loss_o, pred_o = case["out32"]["loss"], case["out32"]["pred"]
     grads_o, grads64 = case["grads32"], case["grads64"]
     img = batch['image'].to(DEV)
+    st_hip = {}
+    handles = _cases.stage_hooks(model, _cases.RES50PPM_STAGES, st_hip)
     loss, pred = model(img, targets=lab.to(DEV), lengths=ln.to(DEV), train=True)
+    for h in handles:
+        h.remove()
+    # where the forward error accrues: every stage's output against the float64 oracle, HIP f32 next to
+    # the reference's own f32 arithmetic (the f32 oracle) -- max |d| / max |x_64| per stage
+    print("Res50-PPM-2DCTC fp32 N=256: forward error per stage vs the float64 oracle   (HIP f32 | CPU f32 oracle)")
+    for name in _cases.RES50PPM_STAGES:
+        if name in st_hip and name in case["stages64"]:
+            x64 = case["stages64"][name]
+            scale = float(x64.abs().max())
+            e_h = float((st_hip[name].double().cpu() - x64).abs().max()) / scale
+            e_c = float((case["stages32"][name].double() - x64).abs().max()) / scale
+            print("   %-22s %.2e | %.2e" % (name, e_h, e_c))
+            REPORT.setdefault("Res50-PPM-2DCTC fp32 N=256 stages", {})[name] = (e_h, e_c)
     lerr = float(((loss.cpu() - loss_o).abs() / loss_o.abs().clamp_min(1.0)).max())
     # log-probabilities after 53 batch-statistics BatchNorms at N = 256: the reference's own f32 arithmetic (the f32 oracle)
     # is itself ~1e-4 away from the exact (float64) value, so "within 1e-4 of the reference" is measured against the
