@@ -418,6 +418,13 @@ int mr_gru_gates_bwd(int dtype, const void* dhnew, const float* save, const void
 int mr_nll_step_fwd(int dtype, const void* logits, int ldl, const long long* target, long long tstride,
                     const float* mask, float* lp, float* loss, long long* argmax, int N, int C, int accumulate,
                     int softmax_out, hipStream_t stream);
+/* training decode loop: mr_nll_step_fwd (log-probs) that also writes the word index fed to the NEXT step,
+ * feed_idx[n] = *feed_flag ? target[n] : arg-max[n].  feed_flag points to ONE int in device memory: the teacher-forcing coin of
+ * this step (decoders/attention_decoder.py:107-110) -- a device value, so a replayed hipGraph follows the coins of the current
+ * step, not those of the step that was captured; null = arg-max feedback. */
+int mr_nll_step_feed_fwd(int dtype, const void* logits, int ldl, const long long* target, long long tstride,
+                         const float* mask, float* lp, float* loss, long long* argmax, const int* feed_flag,
+                         long long* feed_idx, int N, int C, int accumulate, hipStream_t stream);
 int mr_nll_step_bwd(int dtype, const float* gloss, const float* lp, const long long* target, long long tstride,
                     const float* mask, void* dlogits, int ldd, int N, int C, hipStream_t stream);
 /* word embedding of the attention decoder (decoders/attention_decoder.py:187-193): out[n, :D] = table[idx[n]] cast to

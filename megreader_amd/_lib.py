@@ -94,6 +94,7 @@ SIGNATURES = {
     "mr_gru_bwd2": "ippppplppplpiis",
     "mr_rows_scatter_add": "ipplpiiis",
     "mr_nll_step_fwd": "ipiplppppiiiis",
+    "mr_nll_step_feed_fwd": "ipiplpppppp" + "iiis",
     "mr_nll_step_bwd": "ippplppiiis",
     "mr_ctc_greedy_decode": "iplll" + "iiiii" + "pps",
     "mr_ctc2d_greedy_decode": "pllllplll" + "iiiiii" + "pps",

@@ -164,7 +164,8 @@ template <typename T>
 __global__ void nll_step_fwd_kernel(const T* __restrict__ logits, int ldl, const long long* __restrict__ target,
                                     long long tstride, const float* __restrict__ mask, float* __restrict__ lp,
                                     float* __restrict__ loss, long long* __restrict__ argmax, int N, int C,
-                                    int accumulate, int softmax_out) {
+                                    int accumulate, int softmax_out, const int* __restrict__ feed_flag,
+                                    long long* __restrict__ feed_idx) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -192,6 +193,9 @@ __global__ void nll_step_fwd_kernel(const T* __restrict__ logits, int ldl, const
   }
   if (lane == 0) {
     if (argmax) argmax[n] = am;
+    // word fed to the NEXT decode step: the target (teacher forcing) or this step's arg-max (attention_decoder.py:107-110),
+    // chosen by a DEVICE flag so that a captured hipGraph replays the decision of the current step, not of the captured one
+    if (feed_idx) feed_idx[n] = (feed_flag && *feed_flag != 0) ? target[(long long)n * tstride] : (long long)am;
     if (loss) {
       const long long tg = target[(long long)n * tstride];
       const float l = -(to_f32(row[tg]) - lz) * (mask ? mask[n] : 1.f);
@@ -613,7 +617,21 @@ int mr_nll_step_fwd(int dtype, const void* logits, int ldl, const long long* tar
                     int softmax_out, hipStream_t stream) {
   DISPATCH_T(dtype, hipLaunchKernelGGL((nll_step_fwd_kernel<T>), dim3(cdiv(N, 4)), dim3(256), 0, stream,
                                        (const T*)logits, ldl, target, tstride, mask, lp, loss, argmax, N, C,
-                                       accumulate, softmax_out));
+                                       accumulate, softmax_out, (const int*)nullptr, (long long*)nullptr));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+// mr_nll_step_fwd that also writes the word index the NEXT decode step is fed with: feed_idx[n] = *feed_flag ? target[n] :
+// arg-max[n] (feed_flag: one int in device memory -- the teacher-forcing coin of this step, reference
+// decoders/attention_decoder.py:107-110; null = arg-max feedback)
+int mr_nll_step_feed_fwd(int dtype, const void* logits, int ldl, const long long* target, long long tstride,
+                         const float* mask, float* lp, float* loss, long long* argmax, const int* feed_flag,
+                         long long* feed_idx, int N, int C, int accumulate, hipStream_t stream) {
+  MR_CHECK_ARG(target != nullptr && feed_idx != nullptr, "mr_nll_step_feed_fwd: target / feed_idx missing");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((nll_step_fwd_kernel<T>), dim3(cdiv(N, 4)), dim3(256), 0, stream,
+                                       (const T*)logits, ldl, target, tstride, mask, lp, loss, argmax, N, C,
+                                       accumulate, 0, feed_flag, feed_idx));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

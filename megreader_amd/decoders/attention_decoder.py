@@ -221,8 +221,9 @@ class _DecodeLoopFn(Function):
     """All `S` steps of AttentionRNNCell (reference decoders/attention_decoder.py:84-118, 146-231) forward and backward.
 
     inputs : G [C, 3H] word table (dtype), eproj [N,T,H], enc [N,T,Ep] (dtype), v [H], w_ah = attn.attn.weight[:, :H],
-             w_hh, b_hh, w_ic = rnn.weight_ih[:, H:H+E], w_out, b_out, targets_t [S,N] i64, lengths [N], flags (S bools:
-             teacher forcing per step), meta = (dtype, C, blank)
+             w_hh, b_hh, w_ic = rnn.weight_ih[:, H:H+E], w_out, b_out, targets_t [S,N] i64, lengths [N], flags (DEVICE int32
+             [S]: teacher forcing per step -- read by the step kernels, so a replayed hipGraph follows the coins of the
+             current step), meta = (dtype, C, blank)
     outputs: loss [N] f32 = sum_s NLL_s * (s <= length);  attention [N, S, T] f32"""
 
     @staticmethod
@@ -259,27 +260,24 @@ class _DecodeLoopFn(Function):
         mask_all = (torch.arange(S, device=dev).view(S, 1) <= lengths.view(1, N)).to(torch.float32).contiguous()
         ldG = G.shape[1]
         # the word fed to step s + 1 is the target of step s (teacher forcing) or its arg-max (attention_decoder.py:107-110):
-        # the GRU kernel reads it in place from targets_t / am_all; idx_all (what the backward scatters through) is filled
-        # afterwards with one copy per run of equal flags instead of one per step
-        src_rows = [idx_all[0]] + [targets_t[s] if flags[s] else am_all[s] for s in range(S - 1)]
+        # step s's log-softmax kernel writes it to idx_all[s + 1] according to the DEVICE flag of that step; the GRU kernel of
+        # step s + 1 reads it there, and the backward scatters through idx_all
+        assert flags.dtype == torch.int32 and flags.is_cuda and flags.numel() >= S
         for s in range(S):
             call("mr_gemm_nt", dt, ptr(H_all[s]), Hd, ptr(cat.w_n), Hd, ptr(HC_all[s]), HC, ptr(cat.bias_d), 0, N, HC, Hd)
             call("mr_attn_fwd2", dt, ptr(HC_all[s]), HC, ptr(eproj), ptr(vf), ptr(enc), ptr(W_att[s]), ptr(CTX_all[s]), N, T,
                  Hd, Ep)
             call("mr_gemm_nt", dt, ptr(CTX_all[s]), Ep, ptr(ic.w_n), Ep, ptr(gic), H3, 0, 0, N, H3, Ep)
-            call("mr_gru_fwd2", dt, ptr(G), ldG, ptr(src_rows[s]), ptr(gic), ptr(HC_all[s]) + Hd * es, HC, ptr(H_all[s]),
+            call("mr_gru_fwd2", dt, ptr(G), ldG, ptr(idx_all[s]), ptr(gic), ptr(HC_all[s]) + Hd * es, HC, ptr(H_all[s]),
                  ptr(H_all[s + 1]), ptr(SAVE_all[s]), N, Hd)
             call("mr_gemm_nt", dt, ptr(H_all[s + 1]), Hd, ptr(out.w_n), Hd, ptr(logits), out.np_, ptr(out.bias_d), 0, N, C,
                  Hd)
-            call("mr_nll_step_fwd", dt, ptr(logits), out.np_, ptr(targets_t[s]), 1, ptr(mask_all[s]), ptr(LP_all[s]),
-                 ptr(loss), ptr(am_all[s]), N, C, 1 if s else 0, 0)
-        s = 0
-        while s < S - 1:
-            e = s
-            while e + 1 < S - 1 and bool(flags[e + 1]) == bool(flags[s]):
-                e += 1
-            idx_all[s + 1:e + 2].copy_((targets_t if flags[s] else am_all)[s:e + 1])
-            s = e + 1
+            if s + 1 < S:
+                call("mr_nll_step_feed_fwd", dt, ptr(logits), out.np_, ptr(targets_t[s]), 1, ptr(mask_all[s]),
+                     ptr(LP_all[s]), ptr(loss), ptr(am_all[s]), ptr(flags) + 4 * s, ptr(idx_all[s + 1]), N, C, 1 if s else 0)
+            else:
+                call("mr_nll_step_fwd", dt, ptr(logits), out.np_, ptr(targets_t[s]), 1, ptr(mask_all[s]), ptr(LP_all[s]),
+                     ptr(loss), ptr(am_all[s]), N, C, 1 if s else 0, 0)
         ctx.save_for_backward(G, eproj, enc, vf, H_all, HC_all, W_att, CTX_all, SAVE_all, LP_all, idx_all, mask_all,
                               targets_t)
         ctx.lin = (cat, ic, out)
@@ -309,13 +307,17 @@ class _DecodeLoopFn(Function):
         dv = torch.zeros((Hd,), dtype=torch.float32, device=dev)
         dh_a = torch.empty((N, Hd), dtype=dtype, device=dev)     # from the next step's stacked projection
         dh_b = torch.empty((N, Hd), dtype=dtype, device=dev)     # from the next step's z * h path
-        dh_c = torch.empty((N, Hd), dtype=dtype, device=dev)     # from this step's output layer
+        # the output layer's gradient has no recurrence in it (the arg-max feedback is detached, attention_decoder.py:110): the
+        # log-softmax / NLL gradient of ALL steps is one launch over S*N rows and dh_c of all steps ONE [S*N, C] x [C, H] GEMM
+        # in front of the loop, instead of two launch-latency-sized kernels per step on the backward chain (62 launches less)
+        gl_all = gl.unsqueeze(0).expand(S, N).contiguous()
+        call("mr_nll_step_bwd", dt, ptr(gl_all), ptr(LP_all), ptr(targets_t), 1, ptr(mask_all), ptr(DL_all), out.np_, S * N,
+             C)
+        DHO_all = torch.empty((S, N, Hd), dtype=dtype, device=dev)
+        call("mr_gemm_nt", dt, ptr(DL_all), out.np_, ptr(out.w_t), out.np_, ptr(DHO_all), Hd, 0, 0, S * N, Hd, out.np_)
         for s in range(S - 1, -1, -1):
             last = s == S - 1
-            call("mr_nll_step_bwd", dt, ptr(gl), ptr(LP_all[s]), ptr(targets_t[s]), 1, ptr(mask_all[s]), ptr(DL_all[s]),
-                 out.np_, N, C)
-            call("mr_gemm_nt", dt, ptr(DL_all[s]), out.np_, ptr(out.w_t), out.np_, ptr(dh_c), Hd, 0, 0, N, Hd, out.np_)
-            call("mr_gru_bwd2", dt, 0 if last else ptr(dh_a), 0 if last else ptr(dh_b), ptr(dh_c), ptr(SAVE_all[s]),
+            call("mr_gru_bwd2", dt, 0 if last else ptr(dh_a), 0 if last else ptr(dh_b), ptr(DHO_all[s]), ptr(SAVE_all[s]),
                  ptr(HC_all[s]) + Hd * es, HC, ptr(H_all[s]), ptr(DGI_all[s]), ptr(DHC_all[s]) + Hd * es, HC, ptr(dh_b), N,
                  Hd)
             call("mr_gemm_nt", dt, ptr(DGI_all[s]), H3, ptr(ic.w_t), H3, ptr(DCTX_all[s]), Ep, 0, 0, N, Ep, H3)
@@ -407,6 +409,22 @@ class AttentionDecoder(nn.Module):
             return self.gt_as_output
         return np.random.rand() < 0.5
 
+    def _teacher_forcing_flags(self, S, dev):
+        """Device int32 [S]: 1 = the target is fed to the next step, 0 = the arg-max (attention_decoder.py:107-110).  Fixed
+        `gt_as_output`: a cached constant.  Otherwise one coin per step: drawn with np.random in the reference's order and
+        uploaded in an eager step; inside a hipGraph capture they come from torch's device generator instead (graph-safe
+        Philox state: every REPLAY draws new coins -- a host coin would be frozen into the captured step)."""
+        if self.gt_as_output is not None:
+            key = (bool(self.gt_as_output), S, dev)
+            cache = self.__dict__.setdefault("_flag_cache", {})
+            if key not in cache:
+                cache[key] = torch.full((S,), int(bool(self.gt_as_output)), dtype=torch.int32, device=dev)
+            return cache[key]
+        if torch.cuda.is_current_stream_capturing():
+            return (torch.rand((S,), device=dev) < 0.5).to(torch.int32)
+        coins = [int(bool(self._get_gt_as_output())) for _ in range(S)]
+        return torch.tensor(coins, dtype=torch.int32).to(dev)
+
     def conv_bn_relu(self, input_channels, output_channels, kernel_size=3, stride=1, padding=1):
         return nn.Sequential(Conv2d(input_channels, output_channels, kernel_size=kernel_size, stride=stride,
                                     padding=padding),
@@ -458,8 +476,8 @@ class AttentionDecoder(nn.Module):
             # the word path depends on the class index only: table G[c] = W_ih[:, :H] (word_linear(embedding[c])) + b_ih
             rows = _EmbedRowsFn.apply(torch.arange(C, device=dev), cell.embedding.weight, Cp, dtype)
             G = lin_iw(lin_word(rows))
-            # teacher-forcing coins of the S steps, drawn in the reference's order (one np.random.rand() per step, :107)
-            flags = [bool(self._get_gt_as_output()) for _ in range(S)]
+            # teacher-forcing coins of the S steps as a DEVICE tensor (see _teacher_forcing_flags)
+            flags = self._teacher_forcing_flags(S, dev)
             targets_t = targets[:, :S].t().contiguous()
             loss, att = _DecodeLoopFn.apply(G, eproj, enc, cell.attn.v, Wa[:, :Hd], cell.rnn.weight_hh, cell.rnn.bias_hh,
                                             cell.rnn.weight_ih[:, Hd:Hd + E], cell.out.weight, cell.out.bias, targets_t,

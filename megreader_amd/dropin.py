@@ -135,7 +135,7 @@ class _GraphedTrainStep(object):
                     l, _pred, metrics = results
                 else:
                     l = results
-                holder["metrics"] = metrics
+                holder["metrics"] = {k: (v.detach() if hasattr(v, "detach") else v) for k, v in metrics.items()}
                 return l.mean()
             try:
                 optimizer.push_hyper()     # no host->device copy may happen inside the capture

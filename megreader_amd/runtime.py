@@ -55,8 +55,27 @@ def broadcast_parameters(module, src=0, group=None):
             dist.broadcast(t.data, src, group=group)
 
 
+_LIVE_STEPS = []      # weak references to the GraphedTrainStep objects that are alive
+
+
 class GraphedTrainStep(object):
+    """One captured training step.  Keep ONE alive per model: with a second capture of the same model / optimizer alive at
+    the same time, replays of the newer graph read clobbered intermediates on this ROCm 7.0 runtime (the attention decoder's
+    per-step loss came back as the sum of its first k steps, k changing from replay to replay; gone as soon as the older
+    object is deleted before the new capture -- tools/diag_attn_replay.py, profiles/r04_diag_capture_crash.txt).  bench.py,
+    the drop-in trainer and the tests hold at most one at a time; a second live instance triggers a RuntimeWarning."""
+
     def __init__(self, loss_fn, optimizer, static_inputs, warmup=3, grad_sync=None):
+        import gc
+        import warnings
+        import weakref
+        gc.collect()
+        _LIVE_STEPS[:] = [r for r in _LIVE_STEPS if r() is not None]
+        if any(r().optimizer is optimizer for r in _LIVE_STEPS):
+            warnings.warn("megreader_amd.runtime.GraphedTrainStep: another captured step of the same optimizer is still alive; "
+                          "delete it before capturing a new one (replays of the newer hipGraph were observed to read "
+                          "clobbered buffers otherwise, see the class docstring)", RuntimeWarning, stacklevel=2)
+        _LIVE_STEPS.append(weakref.ref(self))
         self.loss_fn = loss_fn
         self.optimizer = optimizer
         self.inputs = list(static_inputs)
@@ -105,12 +124,18 @@ class GraphedTrainStep(object):
         self.graph = torch.cuda.CUDAGraph()
         same = os.environ.get("MEGREADER_CAPTURE_STREAM", "same") != "own"    # "own": torch's internal capture stream (A/B)
         kw = {"stream": s} if same else {}
+        # self.loss is the captured step's loss buffer WITHOUT its autograd graph: a retained graph would keep the step's
+        # AccumulateGrad nodes alive -- bound to THIS capture's stream -- and a later capture (another GraphedTrainStep on the
+        # same parameters) would be pulled onto that stream through them (see the hazard note above; measured: replays of the
+        # second graph then intermittently read clobbered buffers, tools/diag_attn_replay.py)
         if self.grad_sync is None:
             with torch.cuda.graph(self.graph, **kw):
-                self.loss = self._eager()
+                self.loss = self._eager().detach()
+            gc.collect()
             return
         with torch.cuda.graph(self.graph, **kw):
-            self.loss = self._fwd_bwd()
+            self.loss = self._fwd_bwd().detach()
+        gc.collect()
         self.grad_sync()
         self.graph_update = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_update, **kw):

@@ -92,7 +92,10 @@ class AttentionDecoderOracle(nn.Module):
         self.onehot_embedding_y.weight.data = torch.eye(height)
         self.inner, self.max_size, self.height, self.blank = inner, max_size, height, blank
 
-    def forward(self, feature, targets=None, lengths=None, train=False):
+    def forward(self, feature, targets=None, lengths=None, train=False, coins=None):
+        """coins (test infrastructure, optional list of max_size bools): the teacher-forcing decisions of the training loop,
+        reference attention_decoder.py:107-110 `if self._get_gt_as_output(): timestep_input = targets[:, timestep] else:
+        timestep_input = i.detach()`; None = gt_as_output=True (what the pinned goldens use)."""
         seq = self.encode(feature)                                    # [N,512,1,32]
         N = feature.shape[0]
         iy, ix = torch.meshgrid(torch.arange(self.height), torch.arange(self.max_size), indexing='ij')
@@ -108,7 +111,7 @@ class AttentionDecoderOracle(nn.Module):
                 out, hidden, a = self.decoder(word, hidden, dec_in, True)
                 loss = loss + F.nll_loss(out, targets[:, t], reduction='none') * (t <= lengths).float()
                 atts.append(a.unsqueeze(1))
-                word = targets[:, t]                                  # gt_as_output = True
+                word = targets[:, t] if (coins is None or coins[t]) else out.argmax(1).detach()   # :107-110
             return loss, torch.cat(atts, 1).view(N, -1, self.height, self.max_size)
         pred = torch.full((N, self.max_size), self.blank, dtype=torch.int32)
         for t in range(self.max_size):

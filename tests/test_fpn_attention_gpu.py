@@ -93,3 +93,90 @@ def test_bf16_runs_close(golden):
     rel = float(((loss.cpu() - golden['train_loss']).abs() / golden['train_loss'].abs()).max())
     print("bf16 relative loss drift:", rel)
     assert rel < 0.05
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Scheduled sampling (gt_as_output = None, what experiments/recognition/fpn50-attention-decoder.yaml trains with): one
+# teacher-forcing coin per decode step, reference decoders/attention_decoder.py:107-110.  The coins live in DEVICE memory and
+# the step kernels select target / arg-max feedback from them (a host coin would be frozen into a captured step).
+# ---------------------------------------------------------------------------------------------------------------
+def _decoder_pair():
+    from oracle.fpn_attention import AttentionDecoderOracle
+    mr.set_compute_dtype(torch.float32)
+    torch.manual_seed(11)
+    ora = AttentionDecoderOracle(256, 38).train()
+    dec = AttentionDecoder(in_channels=256)                 # gt_as_output=None: np.random coins, like the reference
+    dec.load_state_dict(ora.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(4)
+    feat = torch.randn(6, 256, 16, 64, generator=g)
+    lab = torch.randint(2, 38, (6, 32), generator=g, dtype=torch.int32)
+    ln = torch.randint(3, 11, (6,), generator=g)
+    return ora, dec.to(DEV).train(), feat, lab, ln
+
+
+def test_scheduled_sampling_coins_follow_the_reference_order():
+    """Eager step: the coins are np.random draws in the reference's order; the loop then equals the oracle run with the same
+    coin list (arg-max feedback where the coin says so), loss / attention maps / every decoder gradient."""
+    import numpy as np
+    ora, dec, feat, lab, ln = _decoder_pair()
+    np.random.seed(123)
+    coins = [bool(np.random.rand() < 0.5) for _ in range(32)]
+    assert 8 < sum(coins) < 24
+    loss_o, att_o = ora(feat, targets=lab, lengths=ln, train=True, coins=coins)
+    loss_o.mean().backward()
+    np.random.seed(123)                                      # the HIP module draws the same 32 coins
+    x = feat.to(DEV)
+    loss, att = dec(x, targets=lab.to(DEV), lengths=ln.to(DEV), train=True)
+    loss.mean().backward()
+    assert float((loss.cpu() - loss_o).abs().max()) < 2e-4 * float(loss_o.abs().max())
+    assert float((att.cpu() - att_o).abs().max()) < 1e-4
+    po = dict(ora.named_parameters())
+    gmax = max(float(p.grad.abs().max()) for p in po.values() if p.grad is not None)
+    worst_dec, worst_enc = 0.0, 0.0
+    for k, p in dec.named_parameters():
+        if po[k].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        scale = float(po[k].grad.abs().max())
+        if scale < 1e-5 * gmax:
+            continue                  # conv biases in front of a BatchNorm: mathematically zero gradient, round-off on both sides
+        e = float((p.grad.cpu() - po[k].grad).abs().max()) / scale
+        if k.startswith("encode."):
+            worst_enc = max(worst_enc, e)
+        else:
+            worst_dec = max(worst_dec, e)
+    print("scheduled sampling, %d of 32 steps teacher-forced: worst gradient difference vs the oracle %.2e of max|g| on the "
+          "decode-loop parameters, %.2e on the conv encoder (batch statistics over 6 samples)" %
+          (sum(coins), worst_dec, worst_enc))
+    assert worst_dec < 2e-3 and worst_enc < 1e-1
+    # all-False coins == pure arg-max feedback == gt_as_output=False
+    dec.gt_as_output = False
+    loss_f, _ = dec(x, targets=lab.to(DEV), lengths=ln.to(DEV), train=True)
+    loss_of, _ = ora(feat, targets=lab, lengths=ln, train=True, coins=[False] * 32)
+    assert float((loss_f.cpu() - loss_of).abs().max()) < 2e-4 * float(loss_of.abs().max())
+
+
+def test_scheduled_sampling_is_redrawn_on_every_graph_replay():
+    """Captured step (the graphed drop-in trainer): the coins come from torch's device generator inside the graph, so every
+    replay draws a new pattern.  With lr = 0 the weights never move: a frozen pattern would give the same loss on every
+    replay; redrawn coins change which words are fed back and therefore the loss."""
+    from megreader_amd.optim import FusedAdam
+    from megreader_amd.runtime import GraphedTrainStep
+    _ora, dec, feat, lab, ln = _decoder_pair()
+    x, lab_d, ln_d = feat.to(DEV), lab.to(DEV), ln.to(DEV)
+    opt = FusedAdam(dec.parameters(), lr=0.0)
+    opt.zero_grad()
+
+    def loss_fn():
+        return dec(x, targets=lab_d, lengths=ln_d, train=True)[0].mean()
+    step = GraphedTrainStep(loss_fn, opt, [], warmup=2)
+    losses = []
+    for _ in range(8):
+        losses.append(round(float(step()), 5))
+    print("losses of 8 replays with redrawn teacher-forcing coins:", losses)
+    assert len(set(losses)) >= 4, losses
+    del step                                                  # one live captured step per model (runtime.GraphedTrainStep)
+    dec.gt_as_output = True                                   # fixed teacher forcing: a new capture, identical replays
+    step2 = GraphedTrainStep(loss_fn, opt, [], warmup=1)
+    fixed = [round(float(step2()), 5) for _ in range(3)]
+    assert len(set(fixed)) == 1, fixed
