@@ -96,8 +96,11 @@ class BasicBlock(nn.Module):
             out = self.conv2(out)
         elif self.with_modulated_dcn:
             # reference: conv2(out, offset_mask[:, :18], offset_mask[:, -9:].sigmoid()) -- the same expression as one fused
-            # autograd node (assets/ops/dcn/deform_conv.py ModulatedDeformConvPackedFunction)
-            out = self.conv2.forward_packed(out, self.conv2_offset(out))
+            # autograd node (assets/ops/dcn/deform_conv.py ModulatedDeformConvPackedFunction).  `out` feeds the offset conv AND
+            # the deformable conv: the offset conv hands it on as a second output of its own node, so the deformable conv's
+            # input gradient is added in the epilogue of the offset conv's dgrad (nn.Conv2d.forward_fork) -- no ATen add
+            offset_mask, out = self.conv2_offset.forward_fork(out)
+            out = self.conv2.forward_packed(out, offset_mask)
         else:
             out = self.conv2(out, self.conv2_offset(out))
         if self.downsample is not None:
@@ -143,8 +146,11 @@ class Bottleneck(nn.Module):
             out = self.conv2(out)
         elif self.with_modulated_dcn:
             # reference: conv2(out, offset_mask[:, :18], offset_mask[:, -9:].sigmoid()) -- the same expression as one fused
-            # autograd node (assets/ops/dcn/deform_conv.py ModulatedDeformConvPackedFunction)
-            out = self.conv2.forward_packed(out, self.conv2_offset(out))
+            # autograd node (assets/ops/dcn/deform_conv.py ModulatedDeformConvPackedFunction).  `out` feeds the offset conv AND
+            # the deformable conv: the offset conv hands it on as a second output of its own node, so the deformable conv's
+            # input gradient is added in the epilogue of the offset conv's dgrad (nn.Conv2d.forward_fork) -- no ATen add
+            offset_mask, out = self.conv2_offset.forward_fork(out)
+            out = self.conv2.forward_packed(out, offset_mask)
         else:
             out = self.conv2(out, self.conv2_offset(out))
         out = self.bn2(out)

@@ -30,9 +30,12 @@ class ConvTranspose2x2(nn.ConvTranspose2d):
         xs = x.permute(0, 2, 3, 1).reshape(N * H * W, C)                       # NHWC rows (a view for HIP-layer outputs)
         wmat = self.weight.permute(2, 3, 1, 0).reshape(4 * co, C).contiguous()  # row (i, j, co)
         bias = self.bias.repeat(4) if self.bias is not None else None
-        y = F.linear(xs, wmat, bias)                                           # [N*H*W, 4*co]
-        y = y.reshape(N, H, W, 2, 2, co).permute(0, 5, 1, 3, 2, 4).reshape(N, co, 2 * H, 2 * W)
-        return y
+        y = F.linear(xs, wmat, bias)                                           # [N*H*W, 4*co], columns (i, j, co)
+        # depth-to-space straight into the HIP layers' layout (NHWC memory, logical NCHW view): rows (n, h, i, w, j), co
+        # contiguous -- ONE copy that moves 2*co-element runs.  (Round 3 produced a row-major NCHW tensor here: a transposing
+        # copy, and the BatchNorm behind it converted it back to NHWC with a second kernel -- 55 + 22 us per use at 320 x 320.)
+        y = y.reshape(N, H, W, 2, 2, co).permute(0, 1, 3, 2, 4, 5).reshape(N, 2 * H, 2 * W, co)
+        return y.permute(0, 3, 1, 2)
 
 
 class _SigmoidF32(nn.Module):
