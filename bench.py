@@ -27,8 +27,26 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense peaks, /opt/skills/gu
 HBM_PEAK_GBS = 8000.0
 
 
+CONV_CALLS = ["mr_conv2d_fwd", "mr_conv2d_fwd_stats", "mr_conv2d_dgrad", "mr_conv2d_dgrad_add", "mr_conv2d_dgrad_bnb",
+              "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab"]
+
+
+def normalize_conv_call(name, args):
+    """The dgrad variants with extra epilogue operands (round 4) and the statistics forward, mapped onto the argument layout of
+    the plain call they extend, so that FLOPs / labels are computed in one place."""
+    if name == "mr_conv2d_dgrad_add":          # (dtype, dy, w, dx, addend, N, ...)
+        return "mr_conv2d_dgrad", args[:4] + args[5:]
+    if name == "mr_conv2d_dgrad_bnb":          # (dtype, dy, w, dx, addend, bn_x, bn_y, mean, rstd, sums, produced, N, ...)
+        return "mr_conv2d_dgrad", args[:4] + args[11:]
+    if name == "mr_conv2d_fwd_stats":          # (dtype, x, w, bias, y, sums, N, H, W, Cin, ldx, Cout, R, ...): no relu / ldy
+        a = args
+        return "mr_conv2d_fwd", a[:5] + (0,) + a[6:12] + (a[11],) + a[12:]
+    return name, args
+
+
 def conv_flops(name, args, true_cin0=3):
     """algorithmic FLOPs (2*MACs, un-padded channels) of one mr_conv2d_* call from its C-ABI arguments."""
+    name, args = normalize_conv_call(name, args)
     if name == "mr_conv2d_fwd":
         N, H, W, Cin, _ldx, Cout, _ldy, R, S = args[6:15]
         Ho, Wo = args[21], args[22]
@@ -48,6 +66,8 @@ COMPOSITE = "+tail (2 launches)"   # a C-ABI call that launches the 256x256 head
 
 def kernel_label(lib, name, args, dtype_name):
     dt = 1 if dtype_name == "bf16" else 0
+    bnb = name == "mr_conv2d_dgrad_bnb"       # stays on the 4-wave tiles (the 8-wave kernels have no BatchNorm-backward epilogue)
+    name, args = normalize_conv_call(name, args)
 
     def nt(code):
         if code == 256257:   # head / tail split (gemm_conv.hip:nt_head_rows): the event bracket spans two kernels
@@ -58,6 +78,9 @@ def kernel_label(lib, name, args, dtype_name):
         return nt(lib.mr_nt_kernel_code(dt, N * args[21] * args[22], Cout, R * S * Cin, Cin))
     if name == "mr_conv2d_dgrad":
         N, H, W, Cin, _ld1, Cout, _ld2, R, S = args[4:13]
+        if bnb:
+            code = lib.mr_nt_tile_code(N * H * W, Cin)
+            return "igemm_nt_kernel<%s,%d,%d,conv+bn_bwd_sums>" % (dtype_name, code // 1000, code % 1000)
         return nt(lib.mr_nt_kernel_code(dt, N * H * W, Cin, R * S * Cout, Cout))
     # wgrad: (dtype, dy, x, dw, dbias, N, H, W, Cin, ldx, Cout, lddy, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo[, tab, build])
     if name == "mr_conv2d_wgrad_tab" and dt == 1 and args[22] and lib.mr_tn_taps_would_run(*[int(v) for v in args[5:22]]):
@@ -441,7 +464,7 @@ def main():
             run = step
         timer = None
         if not args.no_kernel_timer and not use_graph:
-            timer = _lib.KernelTimer(["mr_conv2d_fwd", "mr_conv2d_dgrad", "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab"])
+            timer = _lib.KernelTimer(CONV_CALLS)
             _lib.TIMER = timer
         barrier()
         t0 = time.perf_counter()
@@ -456,7 +479,7 @@ def main():
         if use_graph and not args.no_kernel_timer:
             # HIP events cannot bracket kernels inside a graph replay: measure the dominant kernel's launch durations
             # on the same stream with the same tensors in an eager pass right after the timed region
-            timer = _lib.KernelTimer(["mr_conv2d_fwd", "mr_conv2d_dgrad", "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab"])
+            timer = _lib.KernelTimer(CONV_CALLS)
             _lib.TIMER = timer
             timer_steps = min(steps, 10)
             for _ in range(timer_steps):

@@ -126,6 +126,16 @@ int mr_conv2d_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, int
 int mr_conv2d_dgrad_add(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, int Nimg, int H, int W,
                         int Cin, int lddx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
                         int Ho, int Wo, hipStream_t stream);
+/* mr_conv2d_dgrad_add whose epilogue also accumulates the BatchNorm-BACKWARD sums of the gradient it produces: dx is the gradient
+ * of y = act(bn(x) [+ residual]) of a training-mode BatchNorm (the conv -> bn -> relu chains of backbones/resnet.py:113-181);
+ * bn_sums (f64 [copies][2][Cin], the scratch of mr_bn_bwd, zeroed by the caller) receives sum g' and sum g' xhat per channel
+ * (g' = dx where bn_y > 0; bn_y null = no fused ReLU), and mr_bn_bwd with flags bit 3 then skips its reduction pass.  *produced
+ * (host int) = 1 when the sums were written, 0 when this geometry runs on a kernel without that epilogue (dx is complete either
+ * way; the caller then calls mr_bn_bwd without bit 3). */
+int mr_conv2d_dgrad_bnb(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* bn_x,
+                        const void* bn_y, const float* bn_mean, const float* bn_rstd, double* bn_sums, int* produced,
+                        int Nimg, int H, int W, int Cin, int lddx, int Cout, int lddy, int R, int S, int sh, int sw, int ph,
+                        int pw, int dh, int dw, int Ho, int Wo, hipStream_t stream);
 /* dw_krsc (f32 [Cout][R][S][Cin]) and dbias (nullable, f32[Cout]) are accumulated atomically: zero them first.  Cout may be
  * smaller than lddy and need not be a multiple of the vector width when the channels Cout..lddy-1 of dy are zero padding
  * (27-channel DCN offset convolutions stored with 32): exactly Cout rows of dw / entries of dbias are written. */

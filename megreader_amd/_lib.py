@@ -29,6 +29,7 @@ SIGNATURES = {
     "mr_bn_stats": "ipplis",
     "mr_conv2d_dgrad": "ippp" + "i" * 17 + "s",
     "mr_conv2d_dgrad_add": "ipppp" + "i" * 17 + "s",
+    "mr_conv2d_dgrad_bnb": "ippppppppp" + "p" + "i" * 17 + "s",
     "mr_conv2d_wgrad": "ipppp" + "i" * 17 + "s",
     "mr_conv2d_wgrad_tab": "ipppp" + "i" * 17 + "pis",
     "mr_nchw_to_nhwc": "ippiiiiis",

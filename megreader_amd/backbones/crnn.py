@@ -49,6 +49,10 @@ class CRNN(nn.Module):
         conv6 = self._make_layer(6, True)
 
         self.cnn = nn.Sequential(conv0, conv1, conv2, conv3, conv4, conv5, conv6)
+        # conv3 / conv5 are the only consumers of the BatchNorm outputs of stages 2 / 4 (no activation, no pooling in between,
+        # reference crnn.py:46-55): those BatchNorms' backward reductions ride in the dgrad epilogues (nn.Conv2d)
+        conv3[0][0].sole_consumer_of_bn = True
+        conv5[0][0].sole_consumer_of_bn = True
 
     def _make_layer(self, i, batch_normalization=False, pooled=False):
         in_channel = self.channels[i - 1]

@@ -63,6 +63,24 @@ def _make_dcn(dcn, planes, stride):
     return conv2_offset, conv2
 
 
+def _mark_bn_consumers(block):
+    """Which convolutions of a residual block are the ONLY consumer of a BatchNorm's output (nn.Conv2d.sole_consumer_of_bn:
+    that BatchNorm's backward reductions then ride in the convolution's dgrad epilogue, F.conv2d):
+      conv2 (plain)   <- bn1                      conv3 <- bn2 (Bottleneck)
+      conv2_offset    <- bn1, forked: the deformable conv takes the alias the offset conv hands back
+      conv1           <- the previous block's last BatchNorm, forked: identity shortcut through the alias.  Only blocks
+                         without a downsample branch; the block in front is then in the same nn.Sequential and feeds nothing else
+                         (a layer's LAST output also leaves the backbone, but it enters the next layer's downsample block)."""
+    if hasattr(block, "conv2_offset"):
+        block.conv2_offset.sole_consumer_when_forked = True
+    elif isinstance(block.conv2, Conv2d):
+        block.conv2.sole_consumer_of_bn = True
+    if hasattr(block, "conv3"):
+        block.conv3.sole_consumer_of_bn = True
+    if block.downsample is None:
+        block.conv1.sole_consumer_when_forked = True
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -84,6 +102,7 @@ class BasicBlock(nn.Module):
         self.bn2 = bn(planes, fuse_relu=True)   # ReLU after the residual add
         self.downsample = downsample
         self.stride = stride
+        _mark_bn_consumers(self)
 
     def forward(self, x):
         if self.downsample is None:      # identity shortcut: its gradient is added in conv1's dgrad epilogue (see Bottleneck)
@@ -132,6 +151,7 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
         self.dcn = dcn
+        _mark_bn_consumers(self)
 
     def forward(self, x):
         if self.downsample is None:

@@ -38,6 +38,10 @@ static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static thread_local double* g_epi_stats = nullptr;
 static thread_local const void* g_epi_addend = nullptr;   // second summand of the NT epilogue for THIS call (mr_conv2d_dgrad_add)
 static thread_local bool g_epi_stats_missed = false;
+// BatchNorm-backward sums requested for THIS call (mr_conv2d_dgrad_bnb): x / y / mean / rstd of the BatchNorm whose output
+// gradient the launch produces; the sums go to g_epi_stats.  Only the 4-wave direct-to-LDS conv kernels (EpiStoreB) serve it.
+struct BnbRequest { const void* x; const void* y; const float* mean; const float* rstd; };
+static thread_local BnbRequest g_epi_bnb = {nullptr, nullptr, nullptr, nullptr};
 
 // The direct-to-LDS NT kernels address their operands through buffer resources with 2 GiB of records.
 template <typename T>
@@ -50,6 +54,46 @@ static bool nt_fits_buffer(const NtArgs& a, const ConvGeom& g, int amode) {
 }
 
 static int num_cus();
+
+// The direct-to-LDS 4-wave kernel for one tile shape and epilogue type: 2-buffer loop, or the 4-buffer loop for low-occupancy
+// launches (see the comment inside).
+template <typename T, int BM, int BN, int AMODE, typename EpiT>
+static int launch_nt_glds(const NtArgs& a2, const ConvGeom& g, const EpiT& epi, int grid, int tiles, hipStream_t stream) {
+  constexpr int BK = 8 * VecOf<T>::N;
+  if constexpr (sizeof(T) == 2) {
+    // low-occupancy launches (about one workgroup per CU or fewer: the small-M layers of the batch-2 detector and the
+    // batch-32 recogniser): 4 stage buffers, 3 k-steps of LDS-DMA in flight across the barriers (igemm_nt_glds_kernel NST)
+    // Only while every workgroup of the launch is still resident at once with the larger LDS footprint (64 KB for 64x64
+    // tiles: two per CU; 96 - 128 KB above: one per CU): 264 tiles of 128x128 on 256 CUs ran 2 % SLOWER with one workgroup
+    // per CU and a second round of 8 than as 264 co-resident 2-buffer workgroups (CRNN conv6).  Measured (40 steps, same
+    // box): FPN-attention 10.75 -> 10.14 ms, DB 11.61 -> 11.21 ms, Res50-PPM 13.23 -> 13.10 ms.
+    const int nk = cdiv(a2.K, BK);
+    constexpr int NST = 4;
+    constexpr int lds = NST * (BM + BN) * 128;
+    const bool deep = g_nt_deep == 2 || (g_nt_deep == 1 && tiles <= num_cus() * ((160 * 1024) / lds) && nk >= 8);
+    if (deep && (AMODE == 0 || (g.Cg % BK) == 0)) {
+      auto kern = igemm_nt_glds_kernel<T, BM, BN, AMODE, EpiT, NST>;
+      static bool attr_set = false;  // per instantiation
+      if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+          set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", lds);
+          return MR_ERR_LAUNCH;
+        }
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a2, g, epi);
+      MR_CHECK_LAUNCH();
+      return MR_OK;
+    }
+  }
+  if (AMODE == 2 && (g.Cg % BK) != 0)
+    hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, (AMODE == 2 ? 3 : AMODE), EpiT>), dim3(grid), dim3(256), 0, stream,
+                       a2, g, epi);
+  else
+    hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, AMODE, EpiT>), dim3(grid), dim3(256), 0, stream, a2, g, epi);
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
 
 template <typename T, int BM, int BN, int AMODE>
 static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long long ldc, const float* bias,
@@ -72,41 +116,18 @@ static int launch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long lon
       if (!a2.zero) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
       epi.stats = g_epi_stats;
       epi.stats_ncopy = MR_BN_COPIES;
-      constexpr int BK = 8 * VecOf<T>::N;
-      if constexpr (sizeof(T) == 2) {
-        // low-occupancy launches (about one workgroup per CU or fewer: the small-M layers of the batch-2 detector and the
-        // batch-32 recogniser): 4 stage buffers, 3 k-steps of LDS-DMA in flight across the barriers (igemm_nt_glds_kernel NST)
-        // Only while every workgroup of the launch is still resident at once with the larger LDS footprint (64 KB for 64x64
-        // tiles: two per CU; 96 - 128 KB above: one per CU): 264 tiles of 128x128 on 256 CUs ran 2 % SLOWER with one workgroup
-        // per CU and a second round of 8 than as 264 co-resident 2-buffer workgroups (CRNN conv6).  Measured (40 steps, same
-        // box): FPN-attention 10.75 -> 10.14 ms, DB 11.61 -> 11.21 ms, Res50-PPM 13.23 -> 13.10 ms.
-        const int nk = cdiv(a.K, BK);
-        constexpr int NST = 4;
-        constexpr int lds = NST * (BM + BN) * 128;
-        const bool deep = g_nt_deep == 2 || (g_nt_deep == 1 && tiles <= num_cus() * ((160 * 1024) / lds) && nk >= 8);
-        if (deep && (AMODE == 0 || (g.Cg % BK) == 0)) {
-          auto kern = igemm_nt_glds_kernel<T, BM, BN, AMODE, EpiStore<T>, NST>;
-          static bool attr_set = false;  // per instantiation
-          if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-              set_error("hipFuncSetAttribute(max dynamic LDS = %d) failed", lds);
-              return MR_ERR_LAUNCH;
-            }
-            attr_set = true;
-          }
-          hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a2, g, epi);
-          MR_CHECK_LAUNCH();
-          return MR_OK;
+      if constexpr (AMODE == 2) {
+        if (g_epi_bnb.x != nullptr) {    // statistics epilogue in BatchNorm-backward mode: its own epilogue type
+          EpiStoreB<T> eb;
+          static_cast<EpiStore<T>&>(eb) = epi;
+          eb.bnb_x = (const T*)g_epi_bnb.x;
+          eb.bnb_y = (const T*)g_epi_bnb.y;
+          eb.bnb_mean = g_epi_bnb.mean;
+          eb.bnb_rstd = g_epi_bnb.rstd;
+          return launch_nt_glds<T, BM, BN, AMODE, EpiStoreB<T>>(a2, g, eb, grid, tiles, stream);
         }
       }
-      if (AMODE == 2 && (g.Cg % BK) != 0)
-        hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, (AMODE == 2 ? 3 : AMODE), EpiStore<T>>), dim3(grid),
-                           dim3(256), 0, stream, a2, g, epi);
-      else
-        hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, AMODE, EpiStore<T>>), dim3(grid), dim3(256), 0, stream,
-                           a2, g, epi);
-      MR_CHECK_LAUNCH();
-      return MR_OK;
+      return launch_nt_glds<T, BM, BN, AMODE, EpiStore<T>>(a2, g, epi, grid, tiles, stream);
     }
   }
   if (a.m_begin != 0) { set_error("row-range launches need the direct-to-LDS NT kernel"); return MR_ERR_ARG; }
@@ -347,8 +368,10 @@ static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long l
                              int relu, hipStream_t stream) {
   if constexpr (sizeof(T) == 2 && (AMODE == 0 || AMODE == 2)) {
     constexpr int BK = 8 * VecOf<T>::N;
+    // (a launch that also has to produce BatchNorm-backward sums, mr_conv2d_dgrad_bnb, stays on the 4-wave kernels: the
+    // 8-wave tiles have no registers to spare for that epilogue)
     if (g_nt_variant == 2 && !forced_tile().bm && (AMODE == 0 || (g.Cg % BK) == 0) && aligned16(C) &&
-        nt_fits_buffer<T>(a, g, AMODE)) {
+        nt_fits_buffer<T>(a, g, AMODE) && g_epi_bnb.x == nullptr) {
       const int big = nt_big_choice(a.M, a.N, a.K);
       if (big == 1) return launch_nt_p8<T, AMODE>(a, g, C, ldc, bias, relu, stream);
       if (big == 2) return launch_nt_big<T, 2, 4, 9, 4, AMODE>(a, g, C, ldc, bias, relu, stream);   // 288x256, 8 waves (2x4)
@@ -725,6 +748,35 @@ int mr_conv2d_dgrad_add(int dtype, const void* dy, const void* w_crsk, void* dx,
   const int rc = mr_conv2d_dgrad(dtype, dy, w_crsk, dx, Nimg, H, W, Cin, lddx, Cout, lddy, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo,
                                  stream);
   g_epi_addend = nullptr;
+  return rc;
+}
+
+// mr_conv2d_dgrad_add that ALSO leaves the BatchNorm-backward sums of the gradient it produces: dx is the gradient of the output
+// y = act(bn(x) [+ residual]) of a training-mode BatchNorm (reference nn.Sequential(conv, bn, relu) chains, backbones/resnet.py:
+// 113-181), and the BatchNorm's backward needs  sum g'  and  sum g' xhat  per channel (g' = dx where y > 0).  They are accumulated
+// in the dgrad's epilogue into bn_sums (layout and zeroing as for mr_bn_bwd's scratch: f64 [MR_BN_COPIES][2][Cin], zeroed by the
+// caller), so mr_bn_bwd(flags bit 3) skips its reduction pass over dx / x / y.  bn_x / bn_y: NHWC like dx (bn_y null = no fused
+// ReLU); bn_mean / bn_rstd: the statistics mr_bn_fwd_train saved.  *produced = 1 when the sums were written; 0 when this
+// geometry / dtype runs on a kernel without that epilogue (strided or > 32-tap dgrad, register-staged kernel): dx is complete
+// either way and the caller then lets mr_bn_bwd reduce itself.
+int mr_conv2d_dgrad_bnb(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* bn_x,
+                        const void* bn_y, const float* bn_mean, const float* bn_rstd, double* bn_sums, int* produced,
+                        int Nimg, int H, int W, int Cin, int lddx, int Cout, int lddy, int R, int S, int sh, int sw, int ph,
+                        int pw, int dh, int dw, int Ho, int Wo, hipStream_t stream) {
+  MR_CHECK_ARG(bn_x && bn_mean && bn_rstd && bn_sums && produced, "mr_conv2d_dgrad_bnb: null BatchNorm operand");
+  MR_CHECK_ARG(lddx == Cin, "mr_conv2d_dgrad_bnb: dx must be dense (lddx == Cin), like the BatchNorm's tensors");
+  MR_CHECK_ARG(aligned16(bn_x) && (bn_y == nullptr || aligned16(bn_y)), "mr_conv2d_dgrad_bnb: bn_x / bn_y must be 16-byte aligned");
+  g_epi_addend = addend;
+  g_epi_stats = bn_sums;
+  g_epi_stats_missed = false;
+  g_epi_bnb = BnbRequest{bn_x, bn_y, bn_mean, bn_rstd};
+  const int rc = mr_conv2d_dgrad(dtype, dy, w_crsk, dx, Nimg, H, W, Cin, lddx, Cout, lddy, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo,
+                                 stream);
+  *produced = g_epi_stats_missed ? 0 : 1;
+  g_epi_addend = nullptr;
+  g_epi_stats = nullptr;
+  g_epi_stats_missed = false;
+  g_epi_bnb = BnbRequest{nullptr, nullptr, nullptr, nullptr};
   return rc;
 }
 

@@ -103,16 +103,44 @@ template <typename T, int CNT> struct EpiColStats {
   }
   template <typename Epi> __device__ __forceinline__ void add(const Epi& epi, int m, int n, const f32x4* v) {
     if (m >= epi.M) return;
+    if constexpr (Epi::kBnb) {
+      // BACKWARD mode (EpiStoreB, mr_conv2d_dgrad_bnb): the stored matrix is the gradient dy of a training-mode BatchNorm's output.
+      // s += g', q += g' * x with g' = the value the store writes (addend included), zeroed where the BatchNorm's fused ReLU
+      // was off (y <= 0); flush() turns the raw sum into  sum g' * xhat = rstd * (q - mean * s)  -- mean / rstd stay out of
+      // the loop, the cancellation happens once per partial sum in f64.
+      const long long row = (long long)m * epi.ldc + n;
 #pragma unroll
-    for (int i = 0; i < CNT; ++i)
+      for (int i = 0; i < CNT; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float t = v[i][j];
-        if (epi.bias && n + 4 * i + j < epi.N) t += epi.bias[n + 4 * i + j];
-        t = to_f32(from_f32<T>(t));   // the value the store writes
-        s[4 * i + j] += t;
-        q[4 * i + j] += t * t;
-      }
+        for (int j = 0; j < 4; ++j) {
+          const int c = 4 * i + j;
+          if (n + c < epi.N) {
+            float t = v[i][j];
+            if (epi.addend) t += to_f32(epi.addend[row + c]);
+            t = to_f32(from_f32<T>(t));   // the value the store writes
+            if (epi.bnb_y && !(to_f32(epi.bnb_y[row + c]) > 0.f)) t = 0.f;
+            s[c] += t;
+            q[c] += t * to_f32(epi.bnb_x[row + c]);
+          }
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CNT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = v[i][j];
+          if (epi.bias && n + 4 * i + j < epi.N) t += epi.bias[n + 4 * i + j];
+          t = to_f32(from_f32<T>(t));   // the value the store writes
+          s[4 * i + j] += t;
+          q[4 * i + j] += t * t;
+        }
+    }
+  }
+  // backward mode: q_raw = sum g' x  ->  sum g' xhat = rstd (q_raw - mean s), in f64 per partial sum (linear, so the partial
+  // sums of all workgroups still add up to the total)
+  template <typename Epi> __device__ __forceinline__ double q_out(const Epi& epi, int c, float sv, float qv) const {
+    if constexpr (Epi::kBnb) return ((double)qv - (double)epi.bnb_mean[c] * (double)sv) * (double)epi.bnb_rstd[c];
+    else return (double)qv;
   }
   template <typename Epi> __device__ __forceinline__ void flush(const Epi& epi, int n, int l15) {
     // all-reduce over the 16 lanes of a DPP row (= the row group): four rotate-and-add steps, one v_add_f32_dpp each
@@ -133,21 +161,27 @@ template <typename T, int CNT> struct EpiColStats {
       }
       if (n + l15 < epi.N) {
         atomicAdd(dst + n + l15, (double)sv);
-        atomicAdd(dst + epi.N + n + l15, (double)qv);
+        atomicAdd(dst + epi.N + n + l15, q_out(epi, n + l15, sv, qv));
       }
     } else if constexpr (CNT == 2) {
       const int c = l15 & 7;
-      float v = l15 < 8 ? s[0] : q[0];
+      float sv = s[0], qv = q[0];
 #pragma unroll
-      for (int e = 1; e < 8; ++e) v = c == e ? (l15 < 8 ? s[e] : q[e]) : v;
-      if (n + c < epi.N) atomicAdd(dst + (l15 < 8 ? 0 : epi.N) + n + c, (double)v);
+      for (int e = 1; e < 8; ++e) {
+        sv = c == e ? s[e] : sv;
+        qv = c == e ? q[e] : qv;
+      }
+      if (n + c < epi.N) {
+        if (l15 < 8) atomicAdd(dst + n + c, (double)sv);
+        else atomicAdd(dst + epi.N + n + c, q_out(epi, n + c, sv, qv));
+      }
     } else {
       if (l15 != 0) return;
 #pragma unroll
       for (int e = 0; e < 4 * CNT; ++e)
         if (n + e < epi.N) {
           atomicAdd(dst + n + e, (double)s[e]);
-          atomicAdd(dst + epi.N + n + e, (double)q[e]);
+          atomicAdd(dst + epi.N + n + e, q_out(epi, n + e, s[e], q[e]));
         }
     }
   }
@@ -1036,6 +1070,7 @@ template <typename T> struct EpiStore {
   // residual branch's gradient of a ResNet block rides in the epilogue of the dgrad of the block's first convolution instead of
   // an elementwise add kernel over the block input's gradient (mr_conv2d_dgrad_add; reference backbones/resnet.py:152-181).
   const T* addend = nullptr;
+  static constexpr bool kBnb = false;   // see EpiStoreB
   __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
     if (m >= M || n >= N) return;
     if (bias) {
@@ -1111,8 +1146,22 @@ template <typename T> struct EpiStore {
     }
   }
 };
+// EpiStore whose statistics epilogue runs in BatchNorm-BACKWARD mode (mr_conv2d_dgrad_bnb): the stored matrix is the gradient
+// dy of a training-mode BatchNorm's output y = act(bn(x) [+ residual]), C's own layout.  `stats` receives
+//   stats[copy][0][n] += sum_m g'[m][n],   stats[copy][1][n] += sum_m g'[m][n] * xhat[m][n]
+// (g' = dy where y > 0 if bnb_y is given, else dy; xhat = (x - mean) rstd) -- the accumulator layout of mr_bn_bwd, which then
+// skips its reduction pass over dy / x / y.  A separate TYPE, instantiated for the 4-wave direct-to-LDS kernels only: as a
+// runtime branch of EpiStore it pushed the 272x256 kernel (249 VGPRs) into 560 bytes of scratch per lane.
+template <typename T> struct EpiStoreB : EpiStore<T> {
+  const T* bnb_x = nullptr;
+  const T* bnb_y = nullptr;
+  const float* bnb_mean = nullptr;
+  const float* bnb_rstd = nullptr;
+  static constexpr bool kBnb = true;
+};
 #ifndef MR_NO_EPI_STATS   // (A/B build of tools/: the NT kernels compiled without the statistics epilogue)
 template <typename T> struct EpiHasStats<EpiStore<T>> { static constexpr bool value = true; };
+template <typename T> struct EpiHasStats<EpiStoreB<T>> { static constexpr bool value = true; };
 #endif
 
 // ---------------------------------------------------------------------------------------------

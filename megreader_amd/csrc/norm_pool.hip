@@ -702,17 +702,22 @@ int mr_bn_fwd_eval(int dtype, const void* x, void* y, const float* gamma, const 
 }
 
 // Backward of training-mode BN (+ optional fused ReLU / residual).  y is only read when the relu bit is set.
-// flags: bit 0 = fused ReLU, bit 1 = accumulate (+=) into dgamma / dbeta instead of overwriting them.
+// flags: bit 0 = fused ReLU, bit 1 = accumulate (+=) into dgamma / dbeta instead of overwriting them, bit 2 = `sums` arrives
+// zeroed, bit 3 = `sums` already holds the two reductions (the dgrad that produced dy accumulated them in its epilogue,
+// mr_conv2d_dgrad_bnb): the reduction pass over dy / x / y is skipped.
 int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
               const float* save_rstd, double* sums, void* dx, void* dres, float* dgamma, float* dbeta, int flags,
               long long P, int C, hipStream_t stream) {
   const int relu = flags & 1, accumulate = (flags >> 1) & 1, presum_zero = (flags >> 2) & 1;
+  const int have_stats = (flags >> 3) & 1;   // `sums` already holds sum g' / sum g' xhat (mr_conv2d_dgrad_bnb's epilogue)
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(C % vec == 0, "mr_bn_bwd: C (%d) must be a multiple of %d", C, vec);
   MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_bwd: bad P");
-  if (!presum_zero) (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * MR_BN_COPIES, stream);
+  if (!presum_zero && !have_stats) (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * MR_BN_COPIES, stream);
   int rpb, ncopy = 1;
-  if (C / vec <= 256 && 256 % (C / vec) == 0) {
+  if (have_stats) {
+    ncopy = MR_BN_COPIES;
+  } else if (C / vec <= 256 && 256 % (C / vec) == 0) {
     const int splits = split_rows_vec((int)P, C / vec, rpb);
     ncopy = MR_BN_COPIES;
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_vec_kernel<T, 1>), dim3(splits), dim3(256), 0, stream,

@@ -398,11 +398,14 @@ class AttentionDecoder(nn.Module):
 
     def _init_encoder(self, in_channels, stride=(2, 1), padding=(0, 1)):
         c = self.inner_channels
-        return nn.Sequential(
+        enc = nn.Sequential(
             self.conv_bn_relu(in_channels, c), self.conv_bn_relu(c, c), MaxPool2d((2, 2), (2, 2), (0, 0)),
             self.conv_bn_relu(c, c), self.conv_bn_relu(c, c), MaxPool2d(stride, stride, (0, 0)),
             self.conv_bn_relu(c, c), self.conv_bn_relu(c, c), MaxPool2d(stride, stride, (0, 0)),
             self.conv_bn_relu(c, c, kernel_size=(2, 3), stride=stride, padding=padding))
+        for i in (1, 4, 7):     # the second convolution of each pair is the only consumer of the first one's BatchNorm
+            enc[i][0].sole_consumer_of_bn = True
+        return enc
 
     def _get_gt_as_output(self):
         if self.gt_as_output is not None:

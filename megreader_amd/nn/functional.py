@@ -299,8 +299,9 @@ def _conv_operands(weight, bias, dtype, Cp, Kp, need_dx):
 class Conv2dFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, relu, relu_grad_downstream=False, bn_sums=None,
-                fork=False):
+                fork=False, bnb_link=None):
         require_cuda(x, weight, bias)
+        ctx.bnb_link = bnb_link
         dtype = get_compute_dtype()
         dt = dtype_code(dtype)
         v = vec_of(dtype)
@@ -359,10 +360,29 @@ class Conv2dFn(Function):
         dx = dwt = db = None
         if ctx.needs_input_grad[0]:
             dxi = torch.empty((N, H, W, C), dtype=dtype, device=g.device)
+            ga = None
             if g_fork is not None:     # dx = dgrad(g) + gradient of the forked alias of x, one kernel (mr_conv2d_dgrad_add)
                 ga = _grad_internal(g_fork, dtype)
                 if tuple(ga.shape) != (N, H, W, C) or not ga.is_contiguous():
                     ga = ga.contiguous()
+            link = ctx.bnb_link
+            fused_bnb = False
+            if link is not None and link.xi is not None and link.dtype == dtype and tuple(link.xi.shape) == (N, H, W, C) and \
+                    BNB_EPILOGUE:
+                # x is the output of a training-mode BatchNorm and this convolution its only consumer: dxi IS that
+                # BatchNorm's incoming gradient, and its two per-channel reductions ride in this dgrad's epilogue
+                sums = ZeroArena.take(g.device, load().mr_bn_scratch_doubles(C))
+                if sums is not None:
+                    produced = ctypes.c_int(0)
+                    call("mr_conv2d_dgrad_bnb", dt, ptr(g), ptr(w_crsk), ptr(dxi), ptr(ga), ptr(link.xi), ptr(link.y),
+                         ptr(link.mean), ptr(link.rstd), ptr(sums), ctypes.byref(produced), N, H, W, C, C, Kp, Kp, R, S, sh,
+                         sw, ph, pw, dh, dw, Ho, Wo)
+                    fused_bnb = True
+                    if produced.value:
+                        link.sums, link.grad_ptr = sums, dxi.data_ptr()
+            if fused_bnb:
+                pass
+            elif ga is not None:
                 call("mr_conv2d_dgrad_add", dt, ptr(g), ptr(w_crsk), ptr(dxi), ptr(ga), N, H, W, C, C, Kp, Kp, R, S, sh, sw,
                      ph, pw, dh, dw, Ho, Wo)
             else:
@@ -408,7 +428,26 @@ class Conv2dFn(Function):
                 notify_grad_ready(bias_p)
             elif Kp != K:
                 db = db[:K]
-        return dx, dwt, db, None, None, None, None, None, None, None
+        return dx, dwt, db, None, None, None, None, None, None, None, None
+
+
+# BatchNorm-backward sums in the dgrad epilogue of the consuming convolution: OFF by default.  Measured in the step (round 4,
+# gpurun r4r, same box, 40 graph replays each, on / off): CRNN 2.922 / 2.838 ms, Res50-PPM 13.955 / 12.698, FPN-attention
+# 10.192 / 9.865, DB 11.449 / 10.929 -- the epilogue's element-wise reads of x and y in the MFMA accumulator layout plus its
+# per-column f64 atomics, on the 4-wave tiles only, cost more than the g re-read the reduction pass saves (DESIGN.md section 4,
+# "Round 4").  MEGREADER_BNB_EPILOGUE=1 turns it on; tests/test_kernels_gpu.py keeps its parity covered.
+BNB_EPILOGUE = os.environ.get("MEGREADER_BNB_EPILOGUE", "0") == "1"
+
+
+class BnBwdLink(object):
+    """Backward hand-over between a training-mode BatchNorm and the ONE convolution that consumes its output: the tensors the
+    BatchNorm's backward reductions need (filled by BatchNormFn.forward), and -- once that convolution's backward has run --
+    the f64 scratch in which its dgrad epilogue accumulated them (mr_conv2d_dgrad_bnb) plus the address of the gradient they
+    describe.  BatchNormFn.backward uses the sums only if it is handed exactly that gradient tensor."""
+    __slots__ = ("xi", "y", "mean", "rstd", "dtype", "sums", "grad_ptr")
+
+    def __init__(self):
+        self.xi = self.y = self.mean = self.rstd = self.dtype = self.sums = self.grad_ptr = None
 
 
 class BnStatsHandoff(object):
@@ -421,7 +460,7 @@ class BnStatsHandoff(object):
 
 
 def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), relu=False,
-           relu_grad_downstream=False, bn_stats=False, fork=False):
+           relu_grad_downstream=False, bn_stats=False, fork=False, sole_consumer_of_bn=False):
     """relu_grad_downstream=True: the only consumer is a max_pool2d(..., relu_input=True), whose backward applies
     this layer's ReLU mask (saves one pass over the largest activation gradients).
     bn_stats=True: a training-mode BatchNorm consumes the output: its per-channel sum / sum of squares are accumulated in
@@ -430,7 +469,11 @@ def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
     fork=True: returns (y, x'), x' = x as a second output of the same autograd node.  Use x' wherever else the block needs x
     (the identity shortcut of a ResNet block, reference backbones/resnet.py:152-181): the gradients of both uses then meet in
     this convolution's backward, where the shortcut's gradient is added in the dgrad epilogue (mr_conv2d_dgrad_add) instead of
-    by a separate elementwise kernel."""
+    by a separate elementwise kernel.
+    sole_consumer_of_bn=True: the CALLER guarantees that x, if it is the output of a training-mode batch_norm(), is consumed by
+    nothing else (the conv -> bn -> relu -> conv chains of a ResNet block).  The input gradient this convolution computes is then
+    that BatchNorm's complete incoming gradient, and the BatchNorm's two backward reductions are accumulated in this dgrad's
+    epilogue (mr_conv2d_dgrad_bnb) -- its backward skips the reduction pass over dy / x / y."""
     sums = None
     if bn_stats and not relu and x.is_cuda:
         K = weight.shape[0]
@@ -438,8 +481,9 @@ def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
             sums = ZeroArena.take(x.device, load().mr_bn_scratch_doubles(K))
     want_fork = bool(fork)
     fork = want_fork and x.requires_grad and torch.is_grad_enabled()     # nothing to fuse when x needs no gradient
+    link = getattr(x, "_mr_bnb_link", None) if (sole_consumer_of_bn and x.requires_grad and torch.is_grad_enabled()) else None
     y = Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation), bool(relu),
-                       bool(relu_grad_downstream), sums, fork)
+                       bool(relu_grad_downstream), sums, fork, link)
     x_fork = x
     if fork:
         y, x_fork = y
@@ -455,7 +499,7 @@ def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
 class BatchNormFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, residual,
-                num_batches_tracked=None, pre=None):
+                num_batches_tracked=None, pre=None, link=None):
         require_cuda(x, gamma, beta)
         dtype = get_compute_dtype()
         dt = dtype_code(dtype)
@@ -492,6 +536,10 @@ class BatchNormFn(Function):
         ctx.has_res = residual is not None
         ctx.dtype = dtype
         ctx.training_mode = training
+        ctx.bnb_link = None
+        if link is not None and training:
+            link.xi, link.y, link.mean, link.rstd, link.dtype = xi, (y if relu else None), mean, rstd, dtype
+            ctx.bnb_link = link
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -507,10 +555,17 @@ class BatchNormFn(Function):
         dx = torch.empty_like(xi)
         dres = torch.empty_like(xi) if ctx.has_res else None
         nsum = load().mr_bn_scratch_doubles(C)
-        sums = ZeroArena.take(g.device, nsum)
-        prezeroed = sums is not None
-        if not prezeroed:
-            sums = torch.empty((nsum,), dtype=torch.float64, device=g.device)
+        link = ctx.bnb_link
+        have = link is not None and link.sums is not None and link.grad_ptr == g.data_ptr()
+        if have:      # the consuming convolution's dgrad epilogue already accumulated sum g' / sum g' xhat (BnBwdLink)
+            sums, prezeroed = link.sums, True
+        else:
+            sums = ZeroArena.take(g.device, nsum)
+            prezeroed = sums is not None
+            if not prezeroed:
+                sums = torch.empty((nsum,), dtype=torch.float64, device=g.device)
+        if link is not None:
+            link.xi = link.y = link.mean = link.rstd = link.sums = None      # one use; drop the tensor references
         gamma_p, beta_p = ctx.params
         g_sink, b_sink = grad_sink(gamma_p, (C,)), grad_sink(beta_p, (C,))
         sunk = g_sink is not None and b_sink is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
@@ -520,13 +575,14 @@ class BatchNormFn(Function):
             dgamma = torch.empty((C,), dtype=torch.float32, device=g.device)
             dbeta = torch.empty((C,), dtype=torch.float32, device=g.device)
         call("mr_bn_bwd", dt, ptr(g), ptr(xi), ptr(y), ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(dx),
-             ptr(dres), ptr(dgamma), ptr(dbeta), int(ctx.relu) | (2 if sunk else 0) | (4 if prezeroed else 0), P, C)
+             ptr(dres), ptr(dgamma), ptr(dbeta),
+             int(ctx.relu) | (2 if sunk else 0) | (4 if prezeroed else 0) | (8 if have else 0), P, C)
         gres = dres.permute(0, 3, 1, 2) if ctx.has_res else None
         if sunk:
             notify_grad_ready(gamma_p)
             notify_grad_ready(beta_p)
             dgamma = dbeta = None
-        return dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None, gres, None, None
+        return dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None, gres, None, None, None
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu=False, residual=None,
@@ -535,8 +591,12 @@ def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, ep
     if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not training):
         num_batches_tracked = None
     pre = getattr(x, "_mr_bn_sums", None) if training else None
-    return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, bool(training), momentum, eps, bool(relu),
-                             residual, num_batches_tracked, pre)
+    link = BnBwdLink() if (training and BNB_EPILOGUE and torch.is_grad_enabled() and x.requires_grad) else None
+    out = BatchNormFn.apply(x, gamma, beta, running_mean, running_var, bool(training), momentum, eps, bool(relu),
+                            residual, num_batches_tracked, pre, link)
+    if link is not None and link.xi is not None:
+        out._mr_bnb_link = link        # read by conv2d(sole_consumer_of_bn=True) of the layer that consumes `out`
+    return out
 
 
 # --------------------------------------------------------------------------------------------------

@@ -36,10 +36,17 @@ class Conv2d(nn.Conv2d):
     # set by the BatchNorm2d that consumed this layer's output in training mode (see BatchNorm2d.forward): from the next
     # forward on, the batch statistics come out of this convolution's GEMM epilogue
     feeds_batch_norm = False
+    # set by the module that builds the graph (ResNet blocks, the CRNN backbone) when this convolution is the ONLY consumer of a
+    # BatchNorm's output: the BatchNorm's backward reductions then ride in this convolution's dgrad epilogue (F.conv2d)
+    sole_consumer_of_bn = False
+    # the same guarantee for forward_fork(): x is consumed by this convolution and -- through the forked alias it hands back --
+    # by nothing that autograd does not route through this node (identity shortcut, deformable conv)
+    sole_consumer_when_forked = False
 
     def forward(self, x):
         y = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.fuse_relu,
-                     self.relu_grad_downstream, bn_stats=self.feeds_batch_norm and self.training and BN_EPILOGUE)
+                     self.relu_grad_downstream, bn_stats=self.feeds_batch_norm and self.training and BN_EPILOGUE,
+                     sole_consumer_of_bn=self.sole_consumer_of_bn)
         y._mr_producer = self
         return y
 
@@ -47,11 +54,14 @@ class Conv2d(nn.Conv2d):
         """(self(x), x') with x' = x as a second output of this convolution's autograd node: a residual block passes x' to its
         identity shortcut, and the shortcut's gradient is then added in the epilogue of this convolution's dgrad
         (F.conv2d(fork=True)) instead of by an elementwise kernel over the block input's gradient."""
-        if not FORK_RESIDUAL:
-            return self.forward(x), x
+        if not FORK_RESIDUAL:     # x then has a second consumer outside this node: no BatchNorm-backward sums here
+            y = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.fuse_relu,
+                         self.relu_grad_downstream, bn_stats=self.feeds_batch_norm and self.training and BN_EPILOGUE)
+            y._mr_producer = self
+            return y, x
         y, xr = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.fuse_relu,
                          self.relu_grad_downstream, bn_stats=self.feeds_batch_norm and self.training and BN_EPILOGUE,
-                         fork=True)
+                         fork=True, sole_consumer_of_bn=self.sole_consumer_when_forked)
         y._mr_producer = self
         return y, xr
 

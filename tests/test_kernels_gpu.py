@@ -1027,3 +1027,58 @@ def test_residual_block_fork_equals_autograd_add(dtype, block):
     with torch.no_grad():
         ye = blk(x0)
     assert ye.shape == y1.shape and torch.isfinite(ye.float()).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BatchNorm-backward sums in the epilogue of the consuming convolution's dgrad (mr_conv2d_dgrad_bnb, F.BnBwdLink; VERDICT r3
+# item 4, reference conv -> bn -> relu -> conv chains of backbones/resnet.py:113-181): same gradients as BatchNorm's own
+# reduction pass, with and without a fused ReLU / residual / forked shortcut, and on the geometries that must fall back.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    # (N, C_bn, H, W, Cout2, k2, stride2, relu, residual)
+    (8, 64, 12, 20, 128, 3, 1, True, False),      # bn1 -> conv2 (3x3)
+    (4, 256, 9, 7, 64, 1, 1, True, True),         # bn3 + residual + relu -> next block's 1x1 conv
+    (16, 128, 8, 32, 512, 1, 1, False, False),    # no activation (CRNN: conv -> bn -> conv)
+    (4, 64, 10, 10, 64, 3, 2, True, False),       # strided consumer: no epilogue for it, falls back to BatchNorm's own pass
+])
+def test_bn_backward_sums_in_dgrad_epilogue(dtype, case):
+    from megreader_amd import nn as mnn
+    N, C, H, W, Co, k, st, relu, with_res = case
+    mr.set_compute_dtype(dtype)
+    torch.manual_seed(C + H)
+    conv0 = mnn.Conv2d(32, C, 3, padding=1, bias=False).to(DEV)
+    bn = mnn.BatchNorm2d(C, fuse_relu=relu).to(DEV).train()
+    conv = mnn.Conv2d(C, Co, k, stride=st, padding=k // 2, bias=False).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.3, 0.3)
+    x0 = torch.randn(N, 32, H, W, device=DEV)
+    res0 = torch.randn(N, C, H, W, device=DEV) if with_res else None
+    Ho, Wo = (H + 2 * (k // 2) - k) // st + 1, (W + 2 * (k // 2) - k) // st + 1
+    gy = torch.randn(N, Co, Ho, Wo, device=DEV)
+    outs = []
+    default = F.BNB_EPILOGUE
+    for fused in (True, False):
+        F.BNB_EPILOGUE = fused
+        conv.sole_consumer_of_bn = True
+        try:
+            for p in list(conv0.parameters()) + list(bn.parameters()) + list(conv.parameters()):
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            res = res0.clone().requires_grad_(True) if with_res else None
+            h = conv0(x)
+            hb = bn(h, residual=res) if with_res else bn(h)
+            assert (getattr(hb, "_mr_bnb_link", None) is not None) == fused
+            y = conv(hb)
+            y.float().backward(gy)
+        finally:
+            F.BNB_EPILOGUE = default
+        outs.append((y.detach().float(), x.grad.float(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                     conv0.weight.grad.clone(), res.grad.float() if with_res else None))
+    tol = 2e-5 if dtype == torch.float32 else 1.6e-2
+    # the forward is the same code either way; the batch statistics come from f64 atomics whose order is not fixed
+    assert _rel_err(outs[0][0], outs[1][0]) < 1e-6, _rel_err(outs[0][0], outs[1][0])
+    for a, b, name in zip(outs[0][1:], outs[1][1:], ("dx", "dgamma", "dbeta", "dw0", "dres")):
+        if a is not None:
+            assert _rel_err(a, b) < tol, (name, _rel_err(a, b))
