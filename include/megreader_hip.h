@@ -72,7 +72,12 @@ typedef struct mr_tuning {
   int lstm_bwd_bn;   /* ... and backward (0 automatic, 16, 32 (default), 64) */
   int dcn_fused;     /* 1 (default): fused DCNv2 kernels (dcn_fused.hip) where the shape allows; 0 = the general kernels */
   int dcn_v1_bwd;    /* general DCN path: 1 (default) = round-1 backward kernels, 0 = the round-2 experiments */
-  int reserved[9];   /* zero */
+  int bn_onepass;    /* 1 (default): BatchNorm backward of tensors that fit the registers of one resident grid runs as ONE launch
+                        (reductions, a barrier among the workgroups of a 64-channel slab, dx from registers); 0 = always the
+                        reduction launch + the apply launch */
+  int skinny_depth;  /* k-chunks in flight per wave of the M <= 32 GEMM: 0 (default) = 4, or 8 when K needs more than one round
+                        trip at 4 (K > 512 in bf16); 4 / 8 forced */
+  int reserved[7];   /* zero */
 } mr_tuning;
 int mr_tuning_get(mr_tuning* out);
 int mr_tuning_defaults(mr_tuning* out);
@@ -463,6 +468,27 @@ int mr_gru_bwd2(int dtype, const void* dh_a, const void* dh_b, const void* dh_c,
                 hipStream_t stream);
 int mr_rows_scatter_add(int dtype, const long long* idx, const void* rows, long long ldr, float* dtable, int R, int V,
                         int D, hipStream_t stream);
+
+/* ---- Round-4 decode-step fusions (csrc/gemm_skinny.hip): the element-wise GRU kernels in the epilogue of the M <= 32 GEMM next
+ *      to them, the output layer + log-softmax + NLL + arg-max feedback as one kernel.  Same reference lines as above
+ *      (attention_decoder.py:92-115,195-231); forward chain per step 6 -> 4 launches, backward 4 -> 3. ---------------------- */
+/* mr_gemm_nt(ctx, w_ic) + mr_gru_fwd2 in one launch: gi_c = ctx [M, K] * w_ic [3H, K]^T stays in f32 and feeds the GRU cell of
+ * the workgroup's 16 hidden units.  G: word table rows gathered by idx (null: row m), leading dimension ldG >= 3H; gh: the
+ * hidden projection with its bias, leading dimension ldgh; h / hnew [M, H]; save f32 [M, 3H] (r, z, n).  M <= 32. */
+int mr_gemm_gru_fwd(int dtype, const void* ctx, long long ldc, const void* w_ic, long long ldw, const void* G, long long ldG,
+                    const long long* idx, const void* gh, long long ldgh, const void* h, void* hnew, float* save, int M, int H,
+                    int K, hipStream_t stream);
+/* mr_gemm_nt(dhc, w_t) + mr_gru_bwd2 in one launch: dh_a = dhc [M, K] * w_t [H, K]^T is never stored; dh_b / dh_c nullable;
+ * dh_prev may alias dh_b.  Outputs as mr_gru_bwd2. */
+int mr_gemm_gru_bwd(int dtype, const void* dhc, long long lda, const void* w_t, long long ldw, const void* dh_b,
+                    const void* dh_c, const float* save, const void* gh, long long ldgh, const void* h, void* dgi, void* dgh,
+                    long long lddgh, void* dh_prev, int M, int H, int K, hipStream_t stream);
+/* mr_gemm_nt(h, W, bias) + mr_nll_step_feed_fwd in one launch (one workgroup per sample; the logits stay in f32 and are not
+ * stored): lp f32 [N, C] = log_softmax, loss[n] (+)= -lp[n, target] * mask[n], argmax, feed_idx[n] = *feed_flag ? target[n] :
+ * argmax[n] (feed_flag / feed_idx / loss / argmax / mask / bias nullable).  C <= 256. */
+int mr_out_nll_fwd(int dtype, const void* h, long long ldh, const void* W, long long ldw, const float* bias,
+                   const long long* target, long long tstride, const float* mask, float* lp, float* loss, long long* argmax,
+                   const int* feed_flag, long long* feed_idx, int N, int C, int K, int accumulate, hipStream_t stream);
 
 /* eval head: softmax over classes of logits [T,N,C] -> f32 [N,C,1,T] (decoders/crnn.py:101-104) */
 int mr_softmax_nc1t(int dtype, const void* logits, int ldl, float* out, int T, int N, int C, hipStream_t stream);

@@ -94,6 +94,9 @@ SIGNATURES = {
     "mr_gru_fwd2": "iplppplpppiis",
     "mr_gru_bwd2": "ippppplppplpiis",
     "mr_rows_scatter_add": "ipplpiiis",
+    "mr_gemm_gru_fwd": "iplplplpplpppiiis",
+    "mr_gemm_gru_bwd": "iplplpppplppplpiiis",
+    "mr_out_nll_fwd": "iplplpplpppppp" + "iiiis",
     "mr_nll_step_fwd": "ipiplppppiiiis",
     "mr_nll_step_feed_fwd": "ipiplpppppp" + "iiis",
     "mr_nll_step_bwd": "ippplppiiis",
@@ -110,12 +113,12 @@ _lib = None
 
 TUNING_FIELDS = ("nt_variant", "nt_deep", "nt_big", "nt_p8", "nt_force_bm", "nt_force_bn", "gemm_skinny", "tn_big", "tn_buf",
                  "tn_taps", "tn_taps_group", "tn_group", "tn_fin", "tn_taps_fin", "tn_taps_w8", "tn_model", "tn_splits",
-                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd")
+                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth")
 
 
 class Tuning(ctypes.Structure):
     """struct mr_tuning (include/megreader_hip.h): the library's only process-wide switches."""
-    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 9)]
+    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 7)]
 
 
 def get_tuning():

@@ -398,6 +398,171 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(
   }
 }
 
+// ------------------------------------------------------------------ BN backward in ONE pass (round 4)
+// The two-kernel backward reads dy and x (and y under a fused ReLU) twice: once for the two per-channel reductions, once to
+// form dx.  For the tensors of the small-batch workloads (FPN-attention at 32 crops, the DB detector at 2 images: 59-62
+// BatchNorm layers of 9 + 11 us each, launch latency included) the whole tensor fits in the registers of ONE resident grid:
+// a workgroup owns a [ROWS * R rows] x [64 channels] patch, loads it once (R x 2 uint4 per thread, ReLU mask applied in
+// place), reduces it, adds its partial sums to the f64 accumulators (the same scratch and copies as the two-kernel path),
+// passes a barrier among the workgroups of its 64-channel slab, reads the totals back and writes dx (and the masked dy for
+// the residual branch) from the registers.  One launch and one read of every operand instead of two.
+//
+// Inter-workgroup protocol (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility"): the data
+// channel is 8-byte agent-scope atomics on both sides (f64 atomicAdd / relaxed agent loads: neither is served by a
+// non-coherent cache), the arrival counter is a relaxed agent atomic issued behind s_waitcnt vmcnt(0) + __syncthreads -- the
+// form the split reduction of the TN kernels uses (igemm_core.h, TnArgs.grp).  The barrier needs every workgroup of the launch
+// resident at once: the host only takes this path when the grid is within the occupancy the runtime reports (bn_onepass_cap).
+// The wait is bounded by a wall-clock limit (2 s: a concurrent collective kernel may hold CUs for a while); on timeout the
+// workgroup POISONS its outputs with NaN instead of hanging or silently using partial sums.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void bn_bwd_onepass_kernel(
+    const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, double* __restrict__ sums, int ncopy,
+    unsigned* __restrict__ counters, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+    T* __restrict__ dx, T* __restrict__ dres, int relu, int P, int C) {
+  constexpr int VEC = VecOf<T>::N, LANES = 64 / VEC, ROWS = 256 / LANES;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  __shared__ float red[2][ROWS][64];
+  __shared__ float s_sb[64], s_sg[64];
+  __shared__ int s_dead;
+  const int tid = threadIdx.x;
+  const int cbase = blockIdx.y * 64;
+  const int v = tid % LANES, r0 = tid / LANES;
+  const int cv = C / VEC;
+  // Buffer resources sized to the tensor (the host checks P * C * sizeof(T) < 2^31): one 32-bit byte offset per access, and
+  // rows beyond P read as zeros / drop their stores without a branch.  The whole offset travels in the VGPR operand: the
+  // SGPR offset of a buffer instruction is excluded from the bounds check.
+  const int bytes = (int)((long long)P * C * (long long)sizeof(T));
+  const __amdgpu_buffer_rsrc_t r_g = __builtin_amdgcn_make_buffer_rsrc((void*)dy, (short)0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, (short)0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc((void*)(relu ? y : x), (short)0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_dx = __builtin_amdgcn_make_buffer_rsrc((void*)dx, (short)0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_dr = __builtin_amdgcn_make_buffer_rsrc((void*)(dres ? dres : dx), (short)0, bytes, 0x00020000);
+  const int voff = (r0 * cv + blockIdx.y * LANES + v) * 16;          // this lane inside a batch of ROWS rows
+  const int row_bytes = cv * 16;
+  const int sbase = blockIdx.x * (ROWS * R) * row_bytes;              // first row of this workgroup
+  float mu[VEC], rs[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    mu[j] = mean[cbase + v * VEC + j];
+    rs[j] = rstd[cbase + v * VEC + j];
+  }
+  u32x4 gq[R], xq[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    gq[k] = __builtin_amdgcn_raw_buffer_load_b128(r_g, voff + sbase + k * ROWS * row_bytes, 0, 0);
+    xq[k] = __builtin_amdgcn_raw_buffer_load_b128(r_x, voff + sbase + k * ROWS * row_bytes, 0, 0);
+  }
+  float s[VEC], q[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = q[j] = 0.f;
+  // y is only needed for the ReLU mask: it passes through registers in batches of RB rows instead of staying cached
+  constexpr int RB = R < 4 ? R : 4;
+#pragma unroll
+  for (int kb = 0; kb < R; kb += RB) {
+    u32x4 yq[RB];
+    if (relu) {
+#pragma unroll
+      for (int u = 0; u < RB; ++u)
+        yq[u] = __builtin_amdgcn_raw_buffer_load_b128(r_y, voff + sbase + (kb + u) * ROWS * row_bytes, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int k = kb + u;
+      T* pg = (T*)&gq[k];
+      const T* pa = (const T*)&xq[k];
+      const T* po = (const T*)&yq[u];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float gd = to_f32(pg[j]);
+        if (relu && !(to_f32(po[j]) > 0.f)) {
+          gd = 0.f;
+          pg[j] = from_f32<T>(0.f);
+        }
+        s[j] += gd;
+        q[j] += gd * (to_f32(pa[j]) - mu[j]) * rs[j];     // rows beyond P read as zeros: gd == 0
+      }
+      __builtin_amdgcn_sched_barrier(0);   // one row's unpacked values live at a time (the scheduler interleaved all rows: 159 VGPRs)
+    }
+  }
+  // the patch stays PACKED across the barrier: without this the compiler keeps the f32 conversions of phase 1 alive for phase 2
+  // (128 more VGPRs for 8 bf16 rows)
+#pragma unroll
+  for (int k = 0; k < R; ++k) asm volatile("" : "+v"(gq[k]), "+v"(xq[k]));
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    red[0][r0][v * VEC + j] = s[j];
+    red[1][r0][v * VEC + j] = q[j];
+  }
+  if (tid == 0) s_dead = 0;
+  __syncthreads();
+  double* mine = sums + (size_t)(blockIdx.x % ncopy) * 2 * C;
+  if (tid < 128) {
+    const int c = tid & 63, which = tid >> 6;
+    double d = 0;
+#pragma unroll 8
+    for (int r = 0; r < ROWS; ++r) d += (double)red[which][r][c];
+    atomicAdd(mine + which * C + cbase + c, d);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned* ctr = counters + blockIdx.y * 128;     // one 512-byte segment per slab: arrivals of different slabs do not share a line
+  if (tid == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned want = gridDim.x;
+    const long long t0 = wall_clock64();
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 255u) == 0 && wall_clock64() - t0 > 200000000ll) {   // 100 MHz constant clock: 2 s
+        s_dead = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  const bool dead = s_dead != 0;
+  if (tid < 64) {
+    const int c = cbase + tid;
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < ncopy; ++k) {
+      s1 += __hip_atomic_load(sums + (size_t)k * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s2 += __hip_atomic_load(sums + (size_t)k * 2 * C + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (dead) s1 = s2 = (double)__builtin_nanf("");
+    const float invP = 1.f / (float)P;
+    s_sb[tid] = (float)s1 * invP;
+    s_sg[tid] = (float)s2 * invP;
+    if (blockIdx.x == 0) {
+      dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+      dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+    }
+  }
+  __syncthreads();
+  float sb[VEC], sg[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sb[j] = s_sb[v * VEC + j];
+    sg[j] = s_sg[v * VEC + j];
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const T* pg = (const T*)&gq[k];
+    const T* pa = (const T*)&xq[k];
+    u32x4 out;
+    T* pout = (T*)&out;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float xh = (to_f32(pa[j]) - mu[j]) * rs[j];
+      const float kj = gamma[cbase + v * VEC + j] * rs[j];
+      pout[j] = from_f32<T>(kj * (to_f32(pg[j]) - sb[j] - xh * sg[j]));
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(out, r_dx, voff + sbase + k * ROWS * row_bytes, 0, 0);
+    if (dres) __builtin_amdgcn_raw_buffer_store_b128(gq[k], r_dr, voff + sbase + k * ROWS * row_bytes, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // eval-mode BN: y = (x - running_mean) / sqrt(running_var + eps) * gamma + beta
 __global__ void bn_eval_coeff_kernel(const float* __restrict__ rm, const float* __restrict__ rv, float eps,
                                      float* __restrict__ mean, float* __restrict__ rstd, int C) {
@@ -579,6 +744,27 @@ static inline int bn_fused_grid_x(long long P, int rows, int slabs) {
   return (int)gx;
 }
 
+#define g_bn_onepass MR_TUNE(bn_onepass)
+// Workgroups of bn_bwd_onepass_kernel that are resident at once on the current device: CUs x (reported occupancy of the
+// hungrier instantiation, at most 4: 49 SGPRs, so the API's VGPR-limited answer is the admission limit of
+// MI355X_MICROARCH.md "Residency and cooperative launch") minus a margin of a quarter workgroup per CU.  0 = not available.
+static int bn_onepass_cap() {
+  static int cap = -1;
+  if (cap >= 0) return cap;
+  int dev = 0, cus = 0, occ_b = 0, occ_f = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, bn_bwd_onepass_kernel<bf16_t, 8>, 256, 0) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, bn_bwd_onepass_kernel<float, 8>, 256, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return cap = 0;
+  }
+  int occ = occ_b < occ_f ? occ_b : occ_f;
+  if (occ > 4) occ = 4;
+  cap = occ >= 1 ? cus * occ - cus / 4 : 0;
+  return cap;
+}
+
 static inline int grid_for(long long n, int block, int max_blocks = 16384) {
   long long b = (n + block - 1) / block;
   if (b > max_blocks) b = max_blocks;
@@ -713,6 +899,33 @@ int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const flo
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(C % vec == 0, "mr_bn_bwd: C (%d) must be a multiple of %d", C, vec);
   MR_CHECK_ARG(P > 0 && P < (1ll << 31), "mr_bn_bwd: bad P");
+  // one-pass path: the whole tensor in the registers of one resident grid (bn_bwd_onepass_kernel)
+  if (!have_stats && g_bn_onepass && C % 64 == 0) {
+    const int rows = 256 / (64 / vec);
+    const int slabs = C / 64;
+    const int cap = bn_onepass_cap();
+    const long long g8 = (P + rows * 8 - 1) / (rows * 8), g2 = (P + rows * 2 - 1) / (rows * 2);
+    const int rr = (g8 * slabs >= 256 || g2 * slabs > cap) ? 8 : 2;   // fewer rows per workgroup while that fills more CUs
+    const long long gx = rr == 8 ? g8 : g2;
+    if (cap > 0 && gx * slabs <= cap && P * C * (dtype == MR_F32 ? 4 : 2) < (1ll << 31)) {
+      // arrival counters: one per slab, 512 bytes apart, behind the accumulator copies (the C doubles of the unfused path's
+      // f32 [2C] area: unused here)
+      unsigned* counters = (unsigned*)(sums + (size_t)2 * C * MR_BN_COPIES);
+      if (!presum_zero) (void)hipMemsetAsync(sums, 0, sizeof(double) * (2 * C * MR_BN_COPIES + C), stream);
+      const dim3 grid((unsigned)gx, slabs);
+      if (rr == 8) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_onepass_kernel<T, 8>), grid, dim3(256), 0, stream, (const T*)dy,
+                                             (const T*)x, (const T*)y, save_mean, save_rstd, gamma, sums, MR_BN_COPIES,
+                                             counters, dgamma, dbeta, accumulate, (T*)dx, (T*)dres, relu, (int)P, C));
+      } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_onepass_kernel<T, 2>), grid, dim3(256), 0, stream, (const T*)dy,
+                                             (const T*)x, (const T*)y, save_mean, save_rstd, gamma, sums, MR_BN_COPIES,
+                                             counters, dgamma, dbeta, accumulate, (T*)dx, (T*)dres, relu, (int)P, C));
+      }
+      MR_CHECK_LAUNCH();
+      return MR_OK;
+    }
+  }
   if (!presum_zero && !have_stats) (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * MR_BN_COPIES, stream);
   int rpb, ncopy = 1;
   if (have_stats) {

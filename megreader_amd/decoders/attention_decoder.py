@@ -23,6 +23,8 @@ accumulate in f32 buffers across the steps and are handed to autograd by the ste
 Glue that is pure data movement on tiny tensors (one-hot position embeddings, cat/pad of the encoder sequence) uses
 torch ops.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -32,6 +34,11 @@ from .. import get_compute_dtype
 from .._lib import call, dtype_code, ptr, vec_of
 from ..charsets import DefaultCharset
 from ..nn import Conv2d, BatchNorm2d, MaxPool2d, FusedReLU
+
+
+# round 4: GRU kernels in the epilogue of the neighbouring skinny GEMM, output layer + NLL as one kernel (csrc/gemm_skinny.hip);
+# MEGREADER_DECODE_FUSED=0 keeps the round-3 chain (A/B)
+FUSED_STEP = os.environ.get("MEGREADER_DECODE_FUSED", "1") != "0"
 
 
 def _ceil_to(x, m):
@@ -263,10 +270,20 @@ class _DecodeLoopFn(Function):
         # step s's log-softmax kernel writes it to idx_all[s + 1] according to the DEVICE flag of that step; the GRU kernel of
         # step s + 1 reads it there, and the backward scatters through idx_all
         assert flags.dtype == torch.int32 and flags.is_cuda and flags.numel() >= S
+        fused = FUSED_STEP and N <= 32 and C <= 256
         for s in range(S):
             call("mr_gemm_nt", dt, ptr(H_all[s]), Hd, ptr(cat.w_n), Hd, ptr(HC_all[s]), HC, ptr(cat.bias_d), 0, N, HC, Hd)
             call("mr_attn_fwd2", dt, ptr(HC_all[s]), HC, ptr(eproj), ptr(vf), ptr(enc), ptr(W_att[s]), ptr(CTX_all[s]), N, T,
                  Hd, Ep)
+            if fused:
+                # round 4: [GEMM(context) + GRU gates] and [output layer + log-softmax + NLL + feedback word]: 4 launches a step
+                call("mr_gemm_gru_fwd", dt, ptr(CTX_all[s]), Ep, ptr(ic.w_n), Ep, ptr(G), ldG, ptr(idx_all[s]),
+                     ptr(HC_all[s]) + Hd * es, HC, ptr(H_all[s]), ptr(H_all[s + 1]), ptr(SAVE_all[s]), N, Hd, Ep)
+                last = s + 1 == S
+                call("mr_out_nll_fwd", dt, ptr(H_all[s + 1]), Hd, ptr(out.w_n), Hd, ptr(out.bias_d), ptr(targets_t[s]), 1,
+                     ptr(mask_all[s]), ptr(LP_all[s]), ptr(loss), ptr(am_all[s]), 0 if last else ptr(flags) + 4 * s,
+                     0 if last else ptr(idx_all[s + 1]), N, C, Hd, 1 if s else 0)
+                continue
             call("mr_gemm_nt", dt, ptr(CTX_all[s]), Ep, ptr(ic.w_n), Ep, ptr(gic), H3, 0, 0, N, H3, Ep)
             call("mr_gru_fwd2", dt, ptr(G), ldG, ptr(idx_all[s]), ptr(gic), ptr(HC_all[s]) + Hd * es, HC, ptr(H_all[s]),
                  ptr(H_all[s + 1]), ptr(SAVE_all[s]), N, Hd)
@@ -315,16 +332,24 @@ class _DecodeLoopFn(Function):
              C)
         DHO_all = torch.empty((S, N, Hd), dtype=dtype, device=dev)
         call("mr_gemm_nt", dt, ptr(DL_all), out.np_, ptr(out.w_t), out.np_, ptr(DHO_all), Hd, 0, 0, S * N, Hd, out.np_)
+        fused = FUSED_STEP and N <= 32
         for s in range(S - 1, -1, -1):
             last = s == S - 1
-            call("mr_gru_bwd2", dt, 0 if last else ptr(dh_a), 0 if last else ptr(dh_b), ptr(DHO_all[s]), ptr(SAVE_all[s]),
-                 ptr(HC_all[s]) + Hd * es, HC, ptr(H_all[s]), ptr(DGI_all[s]), ptr(DHC_all[s]) + Hd * es, HC, ptr(dh_b), N,
-                 Hd)
+            if fused and not last:
+                # round 4: the GEMM that sends the next step's stacked-projection gradient back to h' carries this step's
+                # GRU backward in its epilogue (dh_a is never stored): 3 launches a step
+                call("mr_gemm_gru_bwd", dt, ptr(DHC_all[s + 1]), HC, ptr(cat.w_t), HC, ptr(dh_b), ptr(DHO_all[s]),
+                     ptr(SAVE_all[s]), ptr(HC_all[s]) + Hd * es, HC, ptr(H_all[s]), ptr(DGI_all[s]),
+                     ptr(DHC_all[s]) + Hd * es, HC, ptr(dh_b), N, Hd, HC)
+            else:
+                call("mr_gru_bwd2", dt, 0 if last else ptr(dh_a), 0 if last else ptr(dh_b), ptr(DHO_all[s]),
+                     ptr(SAVE_all[s]), ptr(HC_all[s]) + Hd * es, HC, ptr(H_all[s]), ptr(DGI_all[s]),
+                     ptr(DHC_all[s]) + Hd * es, HC, ptr(dh_b), N, Hd)
             call("mr_gemm_nt", dt, ptr(DGI_all[s]), H3, ptr(ic.w_t), H3, ptr(DCTX_all[s]), Ep, 0, 0, N, Ep, H3)
             call("mr_attn_bwd2", dt, ptr(DCTX_all[s]), (ptr(ga) + s * T * 4) if ga is not None else 0, S * T,
                  ptr(HC_all[s]), HC, ptr(eproj), ptr(vf), ptr(enc), ptr(W_att[s]), ptr(DHC_all[s]), HC, ptr(deproj),
                  ptr(dv), N, T, Hd, Ep)
-            if s > 0:
+            if s > 0 and not fused:
                 call("mr_gemm_nt", dt, ptr(DHC_all[s]), HC, ptr(cat.w_t), HC, ptr(dh_a), Hd, 0, 0, N, Hd, HC)
         P = S * N
         dWcat = torch.zeros((HC, Hd), dtype=torch.float32, device=dev)

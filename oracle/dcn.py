@@ -9,8 +9,13 @@ Follows assets/ops/dcn/src/deform_conv_cuda_kernel.cu:
 and the host GEMM of assets/ops/dcn/src/deform_conv_cuda.cpp:534-563.  The backward of the op is autograd through
 this forward: SURVEY.md Appendix A.4 verified that the reference's explicit backward kernels (:634-766) equal it.
 
-PARITY STATUS: the reference has no CPU implementation / tests of this op ("parity unpinned" by the reference);
-anchors (tests/test_oracle_dcn.py): zero offsets and unit mask == F.conv2d; integer offsets == shifted conv taps;
+PARITY STATUS: pinned (round 4).  The reference has no CPU implementation and no tests of this op, but its OWN extension
+(assets/ops/dcn/src/deform_conv_cuda.cpp + deform_conv_cuda_kernel.cu) compiles for gfx950 from the sources where they lie
+(oracle/build_ref_ext.sh -> oracle/_ref/) and runs on the MI355X: oracle/gen_golden_dcn.py recorded its outputs for seven DCNv2
+and three DCN v1 cases (flat stride-1 offset map under a stride-2 layer, the non-contiguous 27-channel slice, dilation, offsets
+far outside the image, integer / half-integer offsets) in tests/golden/dcn_reference_ext.npz, and
+tests/test_oracle_dcn_pinned_cpu.py holds this restatement to them (2e-5 forward, 1e-4 gradients: the reference is float32).
+Older anchors (tests/test_oracle_dcn.py): zero offsets and unit mask == F.conv2d; integer offsets == shifted conv taps;
 gradcheck of the restatement.
 """
 import torch

@@ -11,10 +11,14 @@ Follows assets/ops/dcn/src/deform_pool_cuda_kernel.cu line by line in meaning:
               gradient from the corner values (:248-255)
 and the host wrappers deform_pool_cuda.cpp:30-77 (num_classes = channels_trans / 2, channels_each_class).
 
-PARITY STATUS: "parity unpinned" -- the reference has no CPU implementation and no tests of this op, and the CUDA source
-cannot be built here.  Anchors (tests/test_oracle_deform_pool.py): no_trans with group_size = 1 on an aligned RoI equals
-average pooling of the bin's samples computed independently; the analytic offset gradient equals central finite
-differences of the forward; the data gradient is the exact adjoint of the (linear in data) forward.
+PARITY STATUS: pinned (round 4) against the reference's own `deform_pool_cuda` module, compiled for gfx950 from
+assets/ops/dcn/src/deform_pool_cuda.cpp + deform_pool_cuda_kernel.cu where they lie (oracle/build_ref_ext.sh) and run on the
+MI355X by oracle/gen_golden_dcn.py: six cases in tests/golden/dcn_reference_ext.npz (with / without offsets, several classes,
+group sizes, 70 output channels, a single 1 x 1 bin), checked by tests/test_oracle_dcn_pinned_cpu.py -- sample counts exactly,
+outputs to 2e-6, gradients to 1e-5 (the reference is float32 with float atomics).  Older anchors
+(tests/test_oracle_deform_pool.py): no_trans with group_size = 1 on an aligned RoI equals average pooling of the bin's samples
+computed independently; the analytic offset gradient equals central finite differences of the forward; the data gradient is
+the exact adjoint of the (linear in data) forward.
 """
 import math
 

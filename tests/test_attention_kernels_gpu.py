@@ -314,3 +314,115 @@ def test_gru2_table_gather_strided_vs_f64(dtype, N, H, V):
     dtab = torch.full((V, 3 * H), 1.0, dtype=torch.float32, device=DEV)
     call("mr_rows_scatter_add", dt, ptr(idd), ptr(dgi), 3 * H, ptr(dtab), N, V, 3 * H)
     assert _rel(dtab - 1.0, t64.grad) < _tol(dtype, 1e-5, 2e-2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round-4 decode-step fusions (csrc/gemm_skinny.hip): [GEMM(context) + GRU gates], [GEMM + GRU backward], [out + NLL] against
+# f64 torch restatements of the same reference lines (attention_decoder.py:92-115,195-231: nn.GRUCell over
+# cat([word, context]) split into the table gather + the context GEMM, nn.Linear out, log_softmax, NLLLoss, topk(1)).
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,H,K,V", [(32, 512, 552, 38), (7, 96, 40, 5), (17, 48, 72, 3)])
+def test_gemm_gru_fwd_bwd_fused_vs_f64(dtype, N, H, K, V):
+    g = torch.Generator().manual_seed(N + H + K)
+    vec = 4 if dtype == torch.float32 else 8
+    assert K % vec == 0
+    table = torch.randn(V, 3 * H, generator=g).to(dtype)
+    idx = torch.randint(0, V, (N,), generator=g)
+    ctx = torch.randn(N, K, generator=g).to(dtype)
+    w_ic = (torch.randn(3 * H, K, generator=g) * K ** -0.5).to(dtype)
+    hc = torch.randn(N, 4 * H, generator=g).to(dtype)                    # gh = hc[:, H:]
+    h = torch.randn(N, H, generator=g).to(dtype)
+
+    t64, c64, w64 = table.double(), ctx.double().requires_grad_(True), w_ic.double().requires_grad_(True)
+    hc64, h64 = hc.double().requires_grad_(True), h.double().requires_grad_(True)
+    gi = t64[idx] + c64 @ w64.t()
+    gi.retain_grad()
+    gh = hc64[:, H:]
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    nn_ = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    hn64 = (1 - z) * nn_ + z * h64
+
+    dt = dtype_code(dtype)
+    es = 2 if dtype == torch.bfloat16 else 4
+    td, idd, cd, wd, hcd, hd = (t.to(DEV) for t in (table, idx, ctx, w_ic, hc, h))
+    hnew = torch.empty_like(hd)
+    save = torch.empty((N, 3 * H), dtype=torch.float32, device=DEV)
+    call("mr_gemm_gru_fwd", dt, ptr(cd), K, ptr(wd), K, ptr(td), 3 * H, ptr(idd), ptr(hcd) + H * es, 4 * H, ptr(hd), ptr(hnew),
+         ptr(save), N, H, K)
+    assert _rel(hnew, hn64) < _tol(dtype, 1e-5, 1e-2)
+    assert _rel(save[:, :H], r) < _tol(dtype, 1e-5, 1e-2) and _rel(save[:, 2 * H:], nn_) < _tol(dtype, 1e-5, 2e-2)
+    # ... equals the unfused pair up to the bf16 rounding of the intermediate gi_c it no longer stores
+    gic = torch.empty((N, 3 * H), dtype=dtype, device=DEV)
+    call("mr_gemm_nt", dt, ptr(cd), K, ptr(wd), K, ptr(gic), 3 * H, 0, 0, N, 3 * H, K)
+    hnew2, save2 = torch.empty_like(hd), torch.empty_like(save)
+    call("mr_gru_fwd2", dt, ptr(td), 3 * H, ptr(idd), ptr(gic), ptr(hcd) + H * es, 4 * H, ptr(hd), ptr(hnew2), ptr(save2), N, H)
+    assert _rel(hnew, hnew2) < _tol(dtype, 2e-6, 1e-2)
+
+    # backward: dh_a = dhc_next @ w_t^T (w_t = [H, Kb] image of a [Kb, H] weight), then the GRU backward of THIS step
+    Kb = 4 * H
+    dhc_next = (torch.randn(N, Kb, generator=g) * 0.3).to(dtype)
+    w_t = (torch.randn(H, Kb, generator=g) * Kb ** -0.5).to(dtype)
+    dh_b, dh_c = torch.randn(N, H, generator=g).to(dtype), torch.randn(N, H, generator=g).to(dtype)
+    gout = dhc_next.double() @ w_t.double().t() + dh_b.double() + dh_c.double()
+    (hn64 * gout).sum().backward()
+    dn, wt, bb, bc = (t.to(DEV) for t in (dhc_next, w_t, dh_b, dh_c))
+    save64 = torch.cat([r, z, nn_], 1).float().to(DEV)                   # exact gates: isolates the backward
+    dgi = torch.empty((N, 3 * H), dtype=dtype, device=DEV)
+    dhc = torch.full((N, 4 * H), 5.0, dtype=dtype, device=DEV)
+    dhp = bb.clone()                                                     # dh_prev aliases dh_b, as in the decode loop
+    call("mr_gemm_gru_bwd", dt, ptr(dn), Kb, ptr(wt), Kb, ptr(dhp), ptr(bc), ptr(save64), ptr(hcd) + H * es, 4 * H, ptr(hd),
+         ptr(dgi), ptr(dhc) + H * es, 4 * H, ptr(dhp), N, H, Kb)
+    tol = _tol(dtype, 2e-5, 2e-2)
+    assert _rel(dgi, gi.grad) < tol
+    assert _rel(dhc[:, H:], hc64.grad[:, H:]) < tol and bool((dhc[:, :H] == 5.0).all())
+    assert _rel(dhp, h64.grad) < tol
+    # nullable dh_b / dh_c
+    call("mr_gemm_gru_bwd", dt, ptr(dn), Kb, ptr(wt), Kb, 0, 0, ptr(save64), ptr(hcd) + H * es, 4 * H, ptr(hd), ptr(dgi),
+         ptr(dhc) + H * es, 4 * H, ptr(dhp), N, H, Kb)
+    for t in (c64, w64, hc64, h64):
+        t.grad = None
+    gi2 = t64[idx] + c64 @ w64.t()
+    gh = hc64[:, H:]
+    r2 = torch.sigmoid(gi2[:, :H] + gh[:, :H]); z2 = torch.sigmoid(gi2[:, H:2 * H] + gh[:, H:2 * H])
+    n2 = torch.tanh(gi2[:, 2 * H:] + r2 * gh[:, 2 * H:])
+    (((1 - z2) * n2 + z2 * h64) * (dhc_next.double() @ w_t.double().t())).sum().backward()
+    assert _rel(dhp, h64.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,K", [(32, 38, 512), (5, 7, 64), (3, 200, 96)])
+@pytest.mark.parametrize("feed", [0, 1, None])
+def test_out_nll_fused_vs_f64(dtype, N, C, K, feed):
+    g = torch.Generator().manual_seed(N + C + K)
+    h = torch.randn(N, K, generator=g).to(dtype)
+    W = (torch.randn(C, K, generator=g) * K ** -0.5 * 3).to(dtype)
+    b = torch.randn(C, generator=g)
+    target = torch.randint(0, C, (N,), generator=g)
+    mask = (torch.rand(N, generator=g) > 0.3).float()
+    logits = h.double() @ W.double().t() + b.double()
+    lp64 = torch.log_softmax(logits, 1)
+    loss64 = -lp64[torch.arange(N), target] * mask.double()
+    am64 = logits.argmax(1)
+    top2 = logits.topk(2, 1).values
+    clear = (top2[:, 0] - top2[:, 1]) > _tol(dtype, 1e-4, 5e-2)          # rows whose arg-max survives the compute dtype
+
+    dt = dtype_code(dtype)
+    hd, Wd, bd, td, md = h.to(DEV), W.to(DEV), b.to(DEV), target.to(DEV), mask.to(DEV)
+    lp = torch.empty((N, C), dtype=torch.float32, device=DEV)
+    loss = torch.full((N,), 2.0, dtype=torch.float32, device=DEV)
+    am = torch.empty((N,), dtype=torch.int64, device=DEV)
+    flag = torch.tensor([feed or 0], dtype=torch.int32, device=DEV)
+    fidx = torch.full((N,), -1, dtype=torch.int64, device=DEV)
+    call("mr_out_nll_fwd", dt, ptr(hd), K, ptr(Wd), K, ptr(bd), ptr(td), 1, ptr(md), ptr(lp), ptr(loss), ptr(am),
+         0 if feed is None else ptr(flag), 0 if feed is None else ptr(fidx), N, C, K, 1)
+    assert _rel(lp, lp64) < _tol(dtype, 2e-6, 2e-6) * 10                 # f32 accumulation of already rounded operands
+    assert _rel(loss - 2.0, loss64) < 1e-5                               # accumulate = 1
+    assert bool((am.cpu()[clear] == am64[clear]).all())
+    if feed is None:
+        assert bool((fidx == -1).all())
+    elif feed:
+        assert bool((fidx.cpu() == target).all())
+    else:
+        assert bool((fidx == am).all())

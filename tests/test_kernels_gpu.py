@@ -683,8 +683,10 @@ def test_batchnorm_fused_finalize_bit_identical(dtype, N, C, H, W, relu, res):
     gy = torch.randn(N, C, H, W, generator=g).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
     w0, b0 = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
     outs = []
+    from megreader_amd._lib import set_tuning
     for mode in (1, 0):
         old = lib.mr_set_bn_fused(mode)
+        old1 = set_tuning(bn_onepass=0)      # the one-pass backward has its own test below (other summation order)
         try:
             xd = x0.clone().requires_grad_(True)
             rd = r0.clone().requires_grad_(True) if res else None
@@ -697,9 +699,109 @@ def test_batchnorm_fused_finalize_bit_identical(dtype, N, C, H, W, relu, res):
             outs.append([y.detach(), rm, rv, nbt, xd.grad, gamma.grad, beta.grad] + ([rd.grad] if res else []))
         finally:
             lib.mr_set_bn_fused(old)
+            set_tuning(**old1)
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert int(outs[0][3]) == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# One-pass BatchNorm backward (bn_bwd_onepass_kernel, mr_tuning.bn_onepass): reductions, a barrier among the workgroups of a
+# 64-channel slab and dx from registers in ONE launch, against the reduction launch + apply launch on the same inputs (the
+# partial sums are grouped differently, so equality is to rounding, not bit for bit) and against f64 torch.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,C,H,W,relu,res", [
+    (4, 64, 6, 9, True, False),          # 216 rows: one ragged workgroup (2-row variant)
+    (16, 256, 4, 33, True, True),        # 2112 rows x 4 slabs, fused ReLU + residual gradient
+    (3, 512, 5, 7, False, False),        # 105 rows: less than one batch of rows
+    (2, 2048, 2, 3, False, True),        # 12 rows x 32 slabs
+    (32, 256, 16, 64, True, True),       # 32768 x 256 = 8.4 M elements: the 8-row variant, 512 workgroups (FPN layer1 at N = 32)
+    (2, 64, 320, 320, True, False),      # 204800 x 64 (DB stem): 800 workgroups of one slab (above the resident grid in bf16:
+                                         #   falls back to the two launches there, runs in one pass in f32 if it fits)
+    (7, 128, 37, 41, True, True),        # ragged everywhere
+])
+def test_batchnorm_backward_one_pass(dtype, N, C, H, W, relu, res):
+    from megreader_amd._lib import set_tuning
+    mr.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(N + C + H)
+    x0 = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+    r0 = torch.randn(N, C, H, W, generator=g).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last) if res else None
+    gy = torch.randn(N, C, H, W, generator=g).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+    w0, b0 = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    outs = []
+    for mode in (1, 0, 1):
+        old = set_tuning(bn_onepass=mode)
+        try:
+            xd = x0.clone().requires_grad_(True)
+            rd = r0.clone().requires_grad_(True) if res else None
+            gamma, beta = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            y = F.batch_norm(xd, gamma, beta, rm, rv, True, 0.1, 1e-5, relu=relu, residual=rd)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            outs.append([xd.grad.float(), gamma.grad, beta.grad] + ([rd.grad.float()] if res else []))
+            y_hip = y.detach()
+        finally:
+            set_tuning(**old)
+    for o in outs:
+        assert all(bool(torch.isfinite(t).all()) for t in o)      # a barrier that timed out poisons its outputs
+    tol_dx = 2e-6 if dtype == torch.float32 else 8e-3              # bf16: one rounding of a dx element may flip
+    for a, b, name in zip(outs[0], outs[1], ("dx", "dgamma", "dbeta", "dres")):
+        bar = tol_dx if name == "dx" else (0.0 if name == "dres" else 2e-6)
+        assert _rel_err(a, b) <= bar, (name, _rel_err(a, b))
+    for a, b in zip(outs[0], outs[2]):                            # and the same launch again (f64 atomics: order is not fixed)
+        assert _rel_err(a, b) <= tol_dx
+    # against f64 torch (the statistics of the stored, compute-dtype x)
+    bn = torch.nn.BatchNorm2d(C).double().to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(w0.double())
+        bn.bias.copy_(b0.double())
+    xr = x0.double().requires_grad_(True)
+    rr = r0.double().requires_grad_(True) if res else None
+    yr = bn(xr)
+    if res:
+        yr = yr + rr
+    if relu:     # the kernels' mask is `stored y > 0`: the same mask here (an f64 y within rounding of zero would flip elements)
+        yr = yr * (y_hip > 0).double()
+    yr.backward(gy.double())
+    assert _rel_err(outs[0][0], xr.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert _rel_err(outs[0][1], bn.weight.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert _rel_err(outs[0][2], bn.bias.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+def test_batchnorm_backward_one_pass_repeated_under_load():
+    """200 back-to-back one-pass launches on fresh scratch while a second stream streams through HBM: every launch must pass its
+    barrier (no NaN poison) and reproduce the first result to rounding -- with and without the pre-zeroed arena (after the
+    arena is exhausted the launcher zeroes sums + arrival counters itself)."""
+    from megreader_amd._lib import set_tuning, get_tuning
+    assert get_tuning()["bn_onepass"] == 1
+    mr.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(11)
+    N, C, H, W = 32, 512, 8, 32
+    x0 = torch.randn(N, C, H, W, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(N, C, H, W, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV).requires_grad_(True)
+    beta = torch.randn(C, generator=g).to(DEV).requires_grad_(True)
+    big = torch.empty(1 << 28, dtype=torch.uint8, device=DEV)
+    side = torch.cuda.Stream()
+    first = None
+    for it in range(200):
+        if it % 4 == 0:
+            with torch.cuda.stream(side):
+                big.add_(1)
+        xd = x0.clone().requires_grad_(True)
+        gamma.grad = beta.grad = None
+        y = F.batch_norm(xd, gamma, beta, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), True, 0.1, 1e-5, relu=True)
+        y.backward(gy)
+        out = (xd.grad.float(), gamma.grad.clone(), beta.grad.clone())
+        assert all(bool(torch.isfinite(t).all()) for t in out), it
+        if first is None:
+            first = out
+        else:
+            assert _rel_err(out[0], first[0]) <= 8e-3 and _rel_err(out[1], first[1]) <= 2e-6 and \
+                _rel_err(out[2], first[2]) <= 2e-6, it
+    torch.cuda.synchronize()
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--v1", type=int, default=1, help="general path: 1 = round-1 backward kernels, 0 = round-2 experiments")
     ap.add_argument("--layers", default="", help="comma-separated substrings of layer names to run (default: all)")
     ap.add_argument("--fused", type=int, default=1, help="1 (default): fused kernels (csrc/dcn_fused.hip), 0: general path")
+    ap.add_argument("--reference", action="store_true",
+                    help="also time the REFERENCE's own extension (oracle/_ref, built by oracle/build_ref_ext.sh from "
+                         "assets/ops/dcn/src) on the same layers: NCHW float32, the call sequence of its Function file")
     a = ap.parse_args()
     dtype, dt, es = torch.bfloat16, 1, 2
     mr.set_compute_dtype(dtype)
@@ -48,7 +51,13 @@ def main():
     load().mr_set_dcn_fused(a.fused)
     from megreader_amd._lib import dcn_workspace
     N = a.batch
-    tot = {"fwd": 0.0, "bwd": 0.0}
+    tot = {"fwd": 0.0, "bwd": 0.0, "ref_fwd": 0.0, "ref_bwd": 0.0}
+    ref_ext = None
+    if a.reference:
+        from oracle.gen_golden_dcn import load_reference_extension     # tools/ may use the checker; the product path never does
+        ref_ext, _ = load_reference_extension()
+        if ref_ext is None:
+            raise SystemExit("--reference: oracle/_ref holds no reference extension (bash oracle/build_ref_ext.sh)")
     print("DCNv2 3x3, batch %d, bf16 activations / f32 offsets+mask, offsets ~ N(0, %.1f px), backward kernels %s; "
           "rooflines %.0f TB/s, %.0f TFLOP/s" % (N, a.offscale, "fused (round 3)" if a.fused else ("round 1" if a.v1 else "round 2"), HBM_TBS, MFMA_TFS))
     for name, count, C, H, s in LAYERS:
@@ -95,7 +104,34 @@ def main():
                  2 * flops / tb / 1e6 / MFMA_TFS, alg_b / 1e6, alg_b / tb / 1e6, alg_b / tb / 1e6 / HBM_TBS), flush=True)
         tot["fwd"] += count * tf
         tot["bwd"] += count * tb
+        if ref_ext is not None:
+            # the reference as it runs in its own model: NCHW float32 tensors, ModulatedDeformConvFunction's calls
+            # (functions/deform_conv.py:110-165: caller-allocated output, zeroed gradients every backward)
+            xr = x.float().permute(0, 3, 1, 2).contiguous()
+            wr = w_n.float().view(Co, k, k, C).permute(0, 3, 1, 2).contiguous()
+            gyr = gy.float().permute(0, 3, 1, 2).contiguous()
+            fake, bufs = xr.new_empty(1), [xr.new_empty(0), xr.new_empty(0)]
+            out = xr.new_empty((N, Co, Ho, Wo))
+
+            def rfwd():
+                ref_ext.modulated_deform_conv_cuda_forward(xr, wr, fake, bufs[0], off, msk, out, bufs[1], k, k, s, s, pad, pad, 1, 1,
+                                                           1, 1, False)
+
+            def rbwd():
+                gi, go, gm = torch.zeros_like(xr), torch.zeros_like(off), torch.zeros_like(msk)
+                gwr, gb = torch.zeros_like(wr), torch.zeros_like(fake)
+                ref_ext.modulated_deform_conv_cuda_backward(xr, wr, fake, bufs[0], off, msk, bufs[1], gi, gwr, gb, go, gm, gyr, k, k,
+                                                            s, s, pad, pad, 1, 1, 1, 1, False)
+
+            rf, rb = timeit(rfwd, a.iters), timeit(rbwd, a.iters)
+            tot["ref_fwd"] += count * rf
+            tot["ref_bwd"] += count * rb
+            print("%-11s    reference extension (f32 NCHW, im2col + GEMM per sample) | fwd %7.1f us (%.1fx)             "
+                  "                                          | bwd %7.1f us (%.1fx)" % ("", rf, rf / tf, rb, rb / tb), flush=True)
     print("all 13 layers: fwd %.1f us, bwd %.1f us per step of batch %d" % (tot["fwd"], tot["bwd"], N))
+    if ref_ext is not None:
+        print("reference extension, same 13 layers on this GPU: fwd %.1f us, bwd %.1f us (%.1fx / %.1fx the HIP kernels)"
+              % (tot["ref_fwd"], tot["ref_bwd"], tot["ref_fwd"] / tot["fwd"], tot["ref_bwd"] / tot["bwd"]))
 
 
 if __name__ == "__main__":
