@@ -17,6 +17,11 @@ exp(lp) - oracle.grad == occupancy to 1e-6 (float64) wherever the oracle's gradi
 exactly 0 wherever the reference occupancy is 0 (tests/test_oracle_ctc2d.py::test_gradient_pinned_to_reference_...).
 What the python class cannot pin (it has no such term): the additive exp(lp) on extended-target classes and the
 "-inf -> 0" rule are the CUDA collect kernel's (ctc2d_cuda_kernel.cu:498-515), restated from the source.
+Round 4: ALSO pinned to the CUDA extension itself -- ops/ctc_2d/csrc/** compiles for gfx950 from the sources where they lie
+(oracle/build_ref_ext.sh -> oracle/_ref/ctc_2d_csrc) and runs on the MI355X; oracle/gen_golden_ctc2d_ext.py recorded nll, the
+saved log_alpha [N, T, H, 2S+1] and the returned gradient of five cases in tests/golden/ctc2d_reference_ext.npz, and
+tests/test_oracle_ctc2d_ext_pinned_cpu.py holds this restatement to them (including the exact zero pattern of the gradient,
+i.e. the collect kernel's additive term and its "-inf -> 0" rule, which the python class could not pin).
 Further anchors: H = 1 == torch.nn.functional.ctc_loss; sum over (h, s) of exp(alpha+beta-lp+nll) == 1 for every t;
 finite differences of nll.
 """
