@@ -98,12 +98,13 @@ class AttentionDecoderOracle(nn.Module):
         timestep_input = i.detach()`; None = gt_as_output=True (what the pinned goldens use)."""
         seq = self.encode(feature)                                    # [N,512,1,32]
         N = feature.shape[0]
-        iy, ix = torch.meshgrid(torch.arange(self.height), torch.arange(self.max_size), indexing='ij')
+        dev = feature.device      # (device-agnostic so that tools/bench_reference_stack_gpu.py can time these modules on the GPU)
+        iy, ix = torch.meshgrid(torch.arange(self.height, device=dev), torch.arange(self.max_size, device=dev), indexing='ij')
         ex = self.onehot_embedding_x(ix).permute(2, 0, 1).unsqueeze(0).expand(N, -1, -1, -1)
         ey = self.onehot_embedding_y(iy).permute(2, 0, 1).unsqueeze(0).expand(N, -1, -1, -1)
         dec_in = torch.cat([seq, ey, ex], 1).reshape(N, -1, self.height * self.max_size).permute(2, 0, 1)  # [T,N,545]
-        hidden = torch.zeros(N, self.inner, dtype=feature.dtype)
-        word = torch.full((N,), self.blank, dtype=torch.long)
+        hidden = torch.zeros(N, self.inner, dtype=feature.dtype, device=dev)
+        word = torch.full((N,), self.blank, dtype=torch.long, device=dev)
         if self.training:
             targets = targets.long()
             loss, atts = 0, []
@@ -113,7 +114,7 @@ class AttentionDecoderOracle(nn.Module):
                 atts.append(a.unsqueeze(1))
                 word = targets[:, t] if (coins is None or coins[t]) else out.argmax(1).detach()   # :107-110
             return loss, torch.cat(atts, 1).view(N, -1, self.height, self.max_size)
-        pred = torch.full((N, self.max_size), self.blank, dtype=torch.int32)
+        pred = torch.full((N, self.max_size), self.blank, dtype=torch.int32, device=dev)
         for t in range(self.max_size):
             out, hidden, a = self.decoder(word, hidden, dec_in, False)
             word = out.argmax(1)
