@@ -88,6 +88,36 @@ def kernel_label(lib, name, args, dtype_name):
     return "igemm_tn_kernel<%s,conv>" % dtype_name
 
 
+def write_shape_table(path, lib, results, dtype_name, steps):
+    """Per-(entry point, geometry) statistics of the event-bracketed convolution launches of `steps` eager steps (--shape-table):
+    the table the tile / split heuristics are read against.  Columns: launches per step, average microseconds, algorithmic
+    TFLOP/s, entry, kernel label, M x N x K of the implicit GEMM, geometry."""
+    rows = {}
+    for name, cargs, t_ms in results:
+        n0, a0 = normalize_conv_call(name, cargs)
+        if n0 == "mr_conv2d_fwd":
+            N, H, W, Cin, _l, Cout, _l2, R, S, sh, sw = a0[6:17]
+            Ho, Wo = a0[21], a0[22]
+            M, Nn, K = N * Ho * Wo, Cout, R * S * Cin
+        elif n0 == "mr_conv2d_dgrad":
+            N, H, W, Cin, _l, Cout, _l2, R, S, sh, sw = a0[4:15]
+            Ho, Wo = a0[19], a0[20]
+            M, Nn, K = N * H * W, Cin, R * S * Cout
+        else:
+            N, H, W, Cin, _l, Cout, _l2, R, S, sh, sw = a0[5:16]
+            Ho, Wo = a0[20], a0[21]
+            M, Nn, K = Cout, R * S * Cin, N * Ho * Wo
+        key = (name, kernel_label(lib, name, cargs, dtype_name), M, Nn, K, "%dx%d s%d %dx%d->%dx%d" % (R, S, sh, H, W, Ho, Wo))
+        r = rows.setdefault(key, [0, 0.0, conv_flops(name, cargs)[0]])
+        r[0] += 1
+        r[1] += t_ms
+    with open(path, "w") as f:
+        f.write("per_step  avg_us  tflops  entry  kernel  M N K  geometry\n")
+        for key, (n, t_ms, fl) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+            f.write("%5.1f %8.2f %7.1f  %-22s %-44s %7d %6d %7d  %s\n" %
+                    (n / steps, 1e3 * t_ms / n, fl / (t_ms / n * 1e-3) / 1e12, key[0], key[1], key[2], key[3], key[4], key[5]))
+
+
 def kernel_source_hash():
     """sha256 over megreader_amd/csrc/*.hip, *.h (same function as tools/pmc_to_json.py, which stamps it into the PMC file)."""
     import hashlib
@@ -250,6 +280,7 @@ def main():
                          "images for db) is sharded over the N ranks, --batch is then the global batch")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
+    ap.add_argument("--shape-table", default="", help="write per-geometry statistics of the convolution launches to this file")
     ap.add_argument("--force-ddp", action="store_true",
                     help="take the multi-GPU code path even with WORLD_SIZE=1 (single-GPU test of that path)")
     ap.add_argument("--ddp-mode", default="auto", choices=["auto", "capture", "graph2"],
@@ -512,6 +543,8 @@ def main():
                     a[0] += fl
                     a[1] += t_ms
                     a[2] += 1
+                if args.shape_table:
+                    write_shape_table(args.shape_table, lib, timer.results(), args.dtype, timer_steps)
                 for label, (fl, t_ms, n) in agg.items():
                     kernels[label] = {"launches_per_step": n / timer_steps, "avg_us": round(1e3 * t_ms / n, 2),
                                       "tflops": round(fl / (t_ms * 1e-3) / 1e12, 1),

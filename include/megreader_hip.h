@@ -77,7 +77,12 @@ typedef struct mr_tuning {
                         reduction launch + the apply launch */
   int skinny_depth;  /* k-chunks in flight per wave of the M <= 32 GEMM: 0 (default) = 4, or 8 when K needs more than one round
                         trip at 4 (K > 512 in bf16); 4 / 8 forced */
-  int reserved[7];   /* zero */
+  int nt_big_min_k;  /* smallest K for which the automatic choice considers the 8-wave big-tile NT kernels (default 512) */
+  int tn_taps_min_p; /* layers with fewer output pixels (N * H * W) than this (default 10000) keep the 128x128 TN GEMM kernel
+                        instead of the all-taps kernel (round-4 in-step A/B: FPN-attention 9.68 -> 9.56 ms, CRNN at 32 crops per
+                        GPU 1.47 -> 1.41, the P >= 16384 layers of Res50-PPM keep the all-taps kernel); rebuild row tables after
+                        changing it (as for tn_taps) */
+  int reserved[5];   /* zero */
 } mr_tuning;
 int mr_tuning_get(mr_tuning* out);
 int mr_tuning_defaults(mr_tuning* out);

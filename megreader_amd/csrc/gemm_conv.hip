@@ -175,7 +175,7 @@ static int g_tn_abl = 0;  // timing-only ablation mask of the TN kernel (mr_set_
 static int nt_big_choice(int M, int N, int K) {
   if (g_big_mode < 0) return 0;
   if (g_big_mode > 0) return g_big_mode;
-  if (N % 256 != 0 || K < 512) return 0;
+  if (N % 256 != 0 || K < MR_TUNE(nt_big_min_k)) return 0;
   const int cus = num_cus();
   const long long tiles = (long long)cdiv(M, 256) * (N / 256);
   const long long rounds = (tiles + cus - 1) / cus;
@@ -203,7 +203,7 @@ static int nt_big_choice(int M, int N, int K) {
 
 // Rows of the head of a head / tail launch (see dispatch_nt_store), 0 = do not split.
 static long long nt_head_rows(int M, int N, int K) {
-  if (g_big_mode != 0 || N % 256 != 0 || K < 512) return 0;
+  if (g_big_mode != 0 || N % 256 != 0 || K < MR_TUNE(nt_big_min_k)) return 0;
   const int cus = num_cus();
   const int tiles_n = N / 256;
   if (cus % tiles_n != 0) return 0;

@@ -25,6 +25,7 @@
 // 36 MFMAs) per wave.  Wave w owns Cin columns 16w..16w+15 of the block for all 4 Cout row tiles and all 9 taps
 // (36 accumulator tiles = 144 registers).
 #include "tn_taps.h"
+#include "tuning.h"
 #include "igemm_core.h"
 
 namespace mr {
@@ -423,6 +424,7 @@ int taps_eligible(int N, int H, int W, int Cin, int ldx, int Cout, int lddy, int
                   int pw, int dh, int dw, int Ho, int Wo, long long tab_bytes) {
   if (R != 3 || S != 3 || sh != 1 || sw != 1 || dh != dw || ph != dh || pw != dw || Ho != H || Wo != W) return 0;
   if (dh < 1 || dh >= H || dh >= W) return 0;
+  if ((long long)N * H * W < MR_TUNE(tn_taps_min_p)) return 0;   // few output pixels: the plain TN GEMM kernel wins (round 4 A/B)
   if (Cin % 64 != 0 || ldx % 8 != 0 || lddy % 8 != 0 || Cout % 8 != 0) return 0;
   const long long stream = (long long)N * ((H * (W + dh) + 7) / 8 * 8);
   if (stream + 64 >= (1ll << 31) / 4) return 0;

@@ -260,6 +260,10 @@ def test_kernel_choice_host_logic():
         assert run(64, 8, 24, 64, 64, 64, 64, 3, 3, 1, 1, 2, 2, 2, 2, 8, 24) == 1           # dilation 2 == padding 2
         assert run(64, 8, 32, 64, 64, 64, 64, 3, 3, 1, 1, 2, 2, 2, 2, 8, 32) == 0           # ... but 2*(32+2)+2 > 64 rows of halo
         assert run(64, 8, 32, 64, 64, 64, 64, 3, 3, 1, 1, 1, 1, 2, 2, 6, 30) == 0           # padding != dilation
+        assert run(32, 4, 16, 256, 256, 256, 256, 3, 3, 1, 1, 1, 1, 1, 1, 4, 16) == 0       # 2048 output pixels < tn_taps_min_p
+        oldp = _lib.set_tuning(tn_taps_min_p=0)
+        assert run(32, 4, 16, 256, 256, 256, 256, 3, 3, 1, 1, 1, 1, 1, 1, 4, 16) == 1
+        _lib.set_tuning(**oldp)
         lib.mr_set_tn_taps(0)
         assert run(256, 4, 33, 512, 512, 512, 512, 3, 3, 1, 1, 1, 1, 1, 1, 4, 33) == 0
     finally:

@@ -23,10 +23,12 @@ DEV = "cuda"
 def _taps_on(request):
     """Every test runs with the 4-wave (two workgroups per CU) and the 8-wave (one per CU) variant of the kernel."""
     old = F.set_tn_taps(1)
+    oldp = _lib.set_tuning(tn_taps_min_p=0)      # the small test shapes must reach the all-taps kernel (default: P >= 10000 only)
     oldw = _lib.load().mr_set_tn_taps_w8(request.param)
     F.ensure_tn_taps_workspace(DEV)
     yield
     F.set_tn_taps(old)
+    _lib.set_tuning(**oldp)
     _lib.load().mr_set_tn_taps_w8(oldw)
     _lib.load().mr_set_tn_splits(0)
     _lib.load().mr_set_tn_taps_group(0)
