@@ -344,6 +344,11 @@ int mr_nearest_up_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, 
                       hipStream_t stream);
 int mr_copy_channels(int dtype, const void* src, int lds, int soff, void* dst, int ldd, int doff, long long P, int C,
                      hipStream_t stream);
+/* dx [N, H, W, C] <- the gradient of the sub-sampling x[:, ::sh, ::sw, :]: dxs [N, Ho, Wo, C] at the sampled positions, zeros
+ * elsewhere (one pass over dx).  With mr_conv2d_dgrad on the sub-sampled grid this is the data gradient of a strided 1x1
+ * convolution without padding (the downsample branch of a ResNet stage, backbones/resnet.py:204-213). */
+int mr_scatter_strided(int dtype, const void* dxs, void* dx, int N, int H, int W, int C, int sh, int sw, int Ho, int Wo,
+                       hipStream_t stream);
 int mr_scale_channels(int dtype, const void* x, const float* scale, void* y, int N, long long HW, int C,
                       hipStream_t stream);
 /* lp[w,h,n,c] = log(max(softmax_h(mask)[n,h,w] * softmax_c(cls)[n,h,w,c], tiny)); also returns both softmaxes (f32) */

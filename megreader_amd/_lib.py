@@ -94,6 +94,7 @@ SIGNATURES = {
     "mr_gru_fwd2": "iplppplpppiis",
     "mr_gru_bwd2": "ippppplppplpiis",
     "mr_rows_scatter_add": "ipplpiiis",
+    "mr_scatter_strided": "ippiiiiiiiis",
     "mr_gemm_gru_fwd": "iplplplpplpppiiis",
     "mr_gemm_gru_bwd": "iplplpppplppplpiiis",
     "mr_out_nll_fwd": "iplplpplpppppp" + "iiiis",

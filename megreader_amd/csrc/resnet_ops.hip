@@ -263,6 +263,32 @@ __global__ void copy_channels_kernel(const T* __restrict__ src, int lds, int sof
   }
 }
 
+// ---------------------------------------------------------------- gradient of a spatial sub-sampling x[:, ::sh, ::sw, :]
+// dx[n, h, w, :] = (h % sh == 0 && w % sw == 0 && h / sh < Ho && w / sw < Wo) ? dxs[n, h / sh, w / sw, :] : 0 -- one pass over
+// dx.  The data gradient of a strided 1x1 convolution (the downsample branch of a ResNet stage, backbones/resnet.py:204-213) is
+// the dense dgrad on the sub-sampled grid followed by this: the implicit-GEMM dgrad spent its MFMAs on the 3/4 of the output
+// rows that are zero (2048 x 1024 x 2048 at stride 2: 52 us = 41 TFLOP/s).
+template <typename T>
+__global__ void scatter_strided_kernel(const T* __restrict__ dxs, T* __restrict__ dx, int N, int H, int W, int C, int sh,
+                                       int sw, int Ho, int Wo) {
+  constexpr int VEC = VecOf<T>::N;
+  const int cv = C / VEC;
+  const long long total = (long long)N * H * W * cv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv);
+    long long p = i / cv;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const long long n = p / H;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (h % sh == 0 && w % sw == 0 && h / sh < Ho && w / sw < Wo)
+      v = ((const uint4*)dxs)[((n * Ho + h / sh) * Wo + w / sw) * cv + c];
+    ((uint4*)dx)[i] = v;
+  }
+}
+
 // ---------------------------------------------------------------- y[n,p,c] = x[n,p,c] * scale[n,c]  (Dropout2d)
 template <typename T>
 __global__ void scale_channels_kernel(const T* __restrict__ x, const float* __restrict__ scale, T* __restrict__ y,
@@ -520,6 +546,19 @@ int mr_copy_channels(int dtype, const void* src, int lds, int soff, void* dst, i
   MR_CHECK_ARG(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "mr_copy_channels: 16-byte alignment");
   DISPATCH_T(dtype, hipLaunchKernelGGL((copy_channels_kernel<T>), dim3(grid_for(P * (C / vec), 256)), dim3(256), 0,
                                        stream, (const T*)src, lds, soff, (T*)dst, ldd, doff, P, C));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_scatter_strided(int dtype, const void* dxs, void* dx, int N, int H, int W, int C, int sh, int sw, int Ho, int Wo,
+                       hipStream_t stream) {
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  MR_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0 && sh >= 1 && sw >= 1 && Ho >= 1 && Wo >= 1 &&
+                   (Ho - 1) * sh < H && (Wo - 1) * sw < W,
+               "mr_scatter_strided: bad shape N=%d H=%d W=%d C=%d stride %dx%d Ho=%d Wo=%d", N, H, W, C, sh, sw, Ho, Wo);
+  MR_CHECK_ARG(((uintptr_t)dxs & 15) == 0 && ((uintptr_t)dx & 15) == 0, "mr_scatter_strided: 16-byte alignment");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((scatter_strided_kernel<T>), dim3(grid_for((long long)N * H * W * (C / vec), 256)),
+                                       dim3(256), 0, stream, (const T*)dxs, (T*)dx, N, H, W, C, sh, sw, Ho, Wo));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

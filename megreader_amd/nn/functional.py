@@ -385,6 +385,13 @@ class Conv2dFn(Function):
             elif ga is not None:
                 call("mr_conv2d_dgrad_add", dt, ptr(g), ptr(w_crsk), ptr(dxi), ptr(ga), N, H, W, C, C, Kp, Kp, R, S, sh, sw,
                      ph, pw, dh, dw, Ho, Wo)
+            elif POINTWISE_STRIDED_DGRAD and R == 1 and S == 1 and (sh > 1 or sw > 1) and ph == 0 and pw == 0:
+                # strided 1x1 convolution (ResNet downsample branch): the dense dgrad on the sub-sampled grid, then one pass
+                # that places it at the sampled positions of dx and zeroes the rest (mr_scatter_strided)
+                dxs = torch.empty((N, Ho, Wo, C), dtype=dtype, device=g.device)
+                call("mr_conv2d_dgrad", dt, ptr(g), ptr(w_crsk), ptr(dxs), N, Ho, Wo, C, C, Kp, Kp, 1, 1, 1, 1, 0, 0, 1, 1, Ho,
+                     Wo)
+                call("mr_scatter_strided", dt, ptr(dxs), ptr(dxi), N, H, W, C, sh, sw, Ho, Wo)
             else:
                 call("mr_conv2d_dgrad", dt, ptr(g), ptr(w_crsk), ptr(dxi), N, H, W, C, C, Kp, Kp, R, S, sh, sw, ph, pw,
                      dh, dw, Ho, Wo)
@@ -430,6 +437,10 @@ class Conv2dFn(Function):
                 db = db[:K]
         return dx, dwt, db, None, None, None, None, None, None, None, None
 
+
+# data gradient of a strided 1x1 convolution as dense dgrad + scatter (round 4); MEGREADER_POINTWISE_STRIDED_DGRAD=0: the
+# implicit-GEMM dgrad over every output pixel (A/B)
+POINTWISE_STRIDED_DGRAD = os.environ.get("MEGREADER_POINTWISE_STRIDED_DGRAD", "1") != "0"
 
 # BatchNorm-backward sums in the dgrad epilogue of the consuming convolution: OFF by default.  Measured in the step (round 4,
 # gpurun r4r, same box, 40 graph replays each, on / off): CRNN 2.922 / 2.838 ms, Res50-PPM 13.955 / 12.698, FPN-attention

@@ -1184,3 +1184,43 @@ def test_bn_backward_sums_in_dgrad_epilogue(dtype, case):
     for a, b, name in zip(outs[0][1:], outs[1][1:], ("dx", "dgamma", "dbeta", "dw0", "dres")):
         if a is not None:
             assert _rel_err(a, b) < tol, (name, _rel_err(a, b))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Data gradient of a strided 1x1 convolution (ResNet downsample branch, backbones/resnet.py:204-213) as the dense dgrad on the
+# sub-sampled grid + mr_scatter_strided: equal to the implicit-GEMM dgrad over every output pixel (same products, same order
+# per pixel) and to torch; odd sizes, anisotropic strides, the sampled grid not reaching the last row / column.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,C,K,H,W,stride", [(4, 64, 128, 8, 32, (2, 2)), (3, 128, 64, 7, 9, (2, 2)), (2, 256, 512, 5, 16, (2, 1)),
+                                             (2, 64, 64, 6, 10, (3, 2)), (32, 1024, 2048, 4, 16, (2, 2))])
+def test_strided_pointwise_dgrad_is_dense_dgrad_plus_scatter(dtype, N, C, K, H, W, stride):
+    from megreader_amd import nn as mnn
+    mr.set_compute_dtype(dtype)
+    torch.manual_seed(C + H)
+    conv = mnn.Conv2d(C, K, 1, stride=stride, bias=False).to(DEV)
+    x0 = torch.randn(N, C, H, W, device=DEV)
+    Ho, Wo = (H - 1) // stride[0] + 1, (W - 1) // stride[1] + 1
+    gy = torch.randn(N, K, Ho, Wo, device=DEV)
+    outs = []
+    default = F.POINTWISE_STRIDED_DGRAD
+    for fast in (True, False):
+        F.POINTWISE_STRIDED_DGRAD = fast
+        try:
+            x = x0.clone().requires_grad_(True)
+            conv.weight.grad = None
+            y = conv(x)
+            y.float().backward(gy)
+            outs.append((x.grad.float(), conv.weight.grad.clone()))
+        finally:
+            F.POINTWISE_STRIDED_DGRAD = default
+    assert _rel_err(outs[0][0], outs[1][0]) < (1e-6 if dtype == torch.float32 else 4e-3)
+    assert _rel_err(outs[0][1], outs[1][1]) < 1e-5          # the weight gradient is untouched (f32 atomics: order not fixed)
+    xr = x0.to(dtype).double().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, conv.weight.detach().to(dtype).double(), None, stride)
+    yr.backward(gy.to(dtype).double())
+    assert _rel_err(outs[0][0], xr.grad) < (1e-5 if dtype == torch.float32 else 1.6e-2)
+    # zeros exactly where no output pixel samples the input
+    mask = torch.zeros(H, W, dtype=torch.bool, device=DEV)
+    mask[::stride[0], ::stride[1]] = True
+    assert bool((outs[0][0][:, :, ~mask] == 0).all())
