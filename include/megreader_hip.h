@@ -230,8 +230,10 @@ int mr_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
 int mr_sgd_step(float* p, const float* g, float* buf, long long n, float* hyper, hipStream_t stream);
 
 /* ---- BatchNorm2d / MaxPool2d (backbones/crnn.py:17-31,49-52; backbones/resnet.py:26-30,199) ------------- */
-/* doubles of reduction scratch mr_bn_fwd_train / mr_bn_bwd want for C channels (several accumulator copies: fewer
- * same-address atomics; the backward keeps 2*C f32 per-channel means behind them) */
+/* doubles of reduction scratch mr_bn_fwd_train / mr_bn_bwd want for C channels: 8 accumulator copies of [2][C] (fewer
+ * same-address atomics) followed by C doubles the backward uses -- the unfused path for 2*C f32 per-channel means, the one-pass
+ * path (mr_tuning.bn_onepass) for one arrival counter per 64-channel slab, 512 bytes apart.  "Zeroed" below means the WHOLE
+ * scratch. */
 long long mr_bn_scratch_doubles(int C);
 /* training-mode BN folds its finalize kernels into the apply passes (C % 64 == 0) unless mr_tuning.bn_fused = 0 */
 int mr_bn_fwd_train(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* running_mean,
@@ -248,7 +250,12 @@ int mr_bn_fwd_eval(int dtype, const void* x, void* y, const float* gamma, const 
                    const void* residual, int relu, long long P, int C, float eps, hipStream_t stream);
 int mr_bn_bwd(int dtype, const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
               const float* save_rstd, double* sums, void* dx, void* dres, float* dgamma, float* dbeta, int flags,
-              long long P, int C, hipStream_t stream); /* flags: bit0 fused ReLU, bit1 accumulate into dgamma/dbeta, bit2 `sums` is already zero */
+              long long P, int C, hipStream_t stream); /* flags: bit0 fused ReLU, bit1 accumulate into dgamma/dbeta, bit2 `sums`
+                                          is already zero (all mr_bn_scratch_doubles(C) of it), bit3 `sums` already holds the two
+                                          reductions (mr_conv2d_dgrad_bnb).  Tensors that fit one resident grid (C % 64 == 0,
+                                          P * C * sizeof(T) < 2 GiB) take ONE launch with a barrier among the workgroups of a
+                                          64-channel slab (bounded wait; a workgroup that times out poisons its outputs with NaN);
+                                          the others the reduction launch + the apply launch. */
 int mr_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int kh,
                    int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, hipStream_t stream);
 /* relu_y (nullable): the pool's OUTPUT [N,Ho,Wo,C] when its input is the output of a ReLU -- fuses that ReLU's backward
