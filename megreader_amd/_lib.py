@@ -261,6 +261,12 @@ def load():
     if torch.cuda.is_available():
         if lib.mr_init() != 0:
             raise RuntimeError("mr_init failed: %s" % lib.mr_last_error().decode())
+    elif lib.mr_init() != 0:
+        # no GPU (build container, host-only queries such as mr_nt_kernel_code): mr_init still applies MEGREADER_TUNING before
+        # it touches the device, so a malformed variable is reported here too; the device part failing is expected
+        err = lib.mr_last_error().decode()
+        if "MEGREADER_TUNING" in err:
+            raise RuntimeError("mr_init failed: %s" % err)
     return lib
 
 
