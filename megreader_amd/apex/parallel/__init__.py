@@ -60,6 +60,8 @@ class DistributedDataParallel(nn.Module):
         self.module = module
         self.group = process_group
         self.world_size = dist.get_world_size(process_group)
+        from ...runtime import no_resident_grid_kernels_beside_collectives
+        no_resident_grid_kernels_beside_collectives(self.world_size)
         self.gradient_average = gradient_average
         self.delay_allreduce = delay_allreduce
         self._params = [p for p in module.parameters() if p.requires_grad]

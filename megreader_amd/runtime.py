@@ -23,6 +23,18 @@ by bucket, and is what the reference's trainer uses.)
 import torch
 
 
+def no_resident_grid_kernels_beside_collectives(world_size):
+    """With more than one rank a collective kernel (RCCL, on its side stream) can hold CUs while the backward pass runs.  The
+    one-pass BatchNorm backward (mr_tuning.bn_onepass) passes a barrier that needs its whole grid resident at once: beside a
+    collective it would not deadlock (the collective finishes without it) but its resident workgroups would spin until the
+    collective frees the CUs.  Data-parallel runs therefore keep the two-launch backward, which is what every multi-rank code
+    path was validated with; single-GPU runs keep the one-pass kernel.  Called by the DDP shim and data_parallel_grad_sync."""
+    if world_size > 1:
+        from . import _lib
+        if _lib.get_tuning()["bn_onepass"]:
+            _lib.set_tuning(bn_onepass=0)
+
+
 def data_parallel_grad_sync(optimizer, group=None, average=True, fold=False):
     """Returns a function that averages the gradients of a fused optimizer across the ranks of `group`: one
     in-place all-reduce per flat gradient buffer (apex DDP semantics: sum, then divide by the world size).
@@ -34,6 +46,7 @@ def data_parallel_grad_sync(optimizer, group=None, average=True, fold=False):
     the optimizer's state_dict: re-apply it after loading a checkpoint."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    no_resident_grid_kernels_beside_collectives(world)
     scale_here = average and world > 1
     if scale_here and fold and hasattr(optimizer, "set_grad_scale"):
         optimizer.set_grad_scale(1.0 / world)

@@ -42,7 +42,11 @@ def _worker(rank, world, port, delay, q):
     from megreader_amd.apex.parallel import DistributedDataParallel
     torch.manual_seed(100 + rank)          # different init per rank: the shim must broadcast rank 0's weights
     net = Net()
+    from megreader_amd import _lib
+    assert _lib.get_tuning()["bn_onepass"] == 1
     ddp = DistributedDataParallel(net, message_size=64, delay_allreduce=delay)  # tiny buckets -> several buckets
+    # more than one rank: no resident-grid barrier kernels beside the collectives (runtime.no_resident_grid_kernels_beside_...)
+    assert _lib.get_tuning()["bn_onepass"] == 0
     g = torch.Generator().manual_seed(7)
     X = torch.randn(8, 8, generator=g)
     IMG = torch.randn(8, 2, 5, 5, generator=g)
