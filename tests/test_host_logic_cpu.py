@@ -342,3 +342,42 @@ def test_sync_bn_switch_is_an_explicit_hook():
             del sys.modules["config"]
         else:
             sys.modules["config"] = had
+
+
+def test_bench_shape_table_and_conv_call_normalisation(tmp_path):
+    """bench.py --shape-table: the dgrad variants with extra epilogue operands and the statistics forward map onto the plain
+    calls' argument layout (FLOPs and geometry from ONE place), and the table lists M x N x K of the implicit GEMM per
+    entry point (forward: pixels x Cout x taps*Cin; dgrad: input pixels x Cin x taps*Cout; wgrad: Cout x taps*Cin x pixels)."""
+    import bench
+    from megreader_amd import _lib
+    lib = _lib.load()
+    geom = (4, 8, 16, 64, 64, 128, 128, 3, 3, 1, 1, 1, 1, 1, 1, 8, 16)      # N H W Cin ldx Cout ldy R S sh sw ph pw dh dw Ho Wo
+    fwd = (1, 0, 0, 0, 0, 0) + geom
+    stats = (1, 0, 0, 0, 0, 0) + geom[:6] + geom[7:]                          # no relu / ldy, a sums pointer instead
+    dgrad = (1, 0, 0, 0) + geom
+    dgrad_add = (1, 0, 0, 0, 0) + geom
+    dgrad_bnb = (1, 0, 0, 0) + (0,) * 7 + geom
+    wgrad = (1, 0, 0, 0, 0) + geom
+    flops = 2.0 * 4 * 8 * 16 * 128 * 9 * 64
+    assert bench.conv_flops("mr_conv2d_fwd", fwd)[0] == flops
+    assert bench.conv_flops("mr_conv2d_fwd_stats", stats)[0] == flops
+    for name, args in (("mr_conv2d_dgrad", dgrad), ("mr_conv2d_dgrad_add", dgrad_add), ("mr_conv2d_dgrad_bnb", dgrad_bnb)):
+        assert bench.conv_flops(name, args)[0] == flops, name
+        assert bench.normalize_conv_call(name, args) == ("mr_conv2d_dgrad", dgrad)
+    assert bench.conv_flops("mr_conv2d_wgrad", wgrad)[0] == flops
+    path = str(tmp_path / "shapes.txt")
+    recs = [("mr_conv2d_fwd", fwd, 0.02), ("mr_conv2d_fwd", fwd, 0.04), ("mr_conv2d_dgrad_add", dgrad_add, 0.05),
+            ("mr_conv2d_wgrad", wgrad, 0.01)]
+    bench.write_shape_table(path, lib, recs, "bf16", steps=2)
+    rows = open(path).read().splitlines()
+    assert rows[0].startswith("per_step") and len(rows) == 4
+    body = "\\n".join(rows[1:])
+    assert " 512    128     576 " in body.replace("  ", " ").replace("  ", " ") or "512" in body      # forward: M N K
+    by_entry = {r.split()[3]: r.split() for r in rows[1:]}
+    assert by_entry["mr_conv2d_fwd"][0] == "1.0" and abs(float(by_entry["mr_conv2d_fwd"][1]) - 30.0) < 1e-6
+    m, n, k = (int(v) for v in by_entry["mr_conv2d_fwd"][5:8])
+    assert (m, n, k) == (4 * 8 * 16, 128, 9 * 64)
+    m, n, k = (int(v) for v in by_entry["mr_conv2d_dgrad_add"][5:8])
+    assert (m, n, k) == (4 * 8 * 16, 64, 9 * 128)
+    m, n, k = (int(v) for v in by_entry["mr_conv2d_wgrad"][5:8])
+    assert (m, n, k) == (128, 9 * 64, 4 * 8 * 16)
