@@ -332,6 +332,7 @@ def main():
         from megreader_amd.backbones import crnn_backbone
         from megreader_amd.decoders import CRNNDecoder
         from megreader_amd.optim import FusedAdam
+        from megreader_amd.runtime import scalar_mean
         from megreader_amd.synthetic import recognition_batch as synthetic_batch  # BASELINE.md §3 value distributions
 
         lib = _lib.load()
@@ -442,7 +443,7 @@ def main():
                 loss, _ = net(dbatch)
             else:
                 loss, _ = net(img, targets=lab, lengths=ln, train=True)
-            loss = loss.mean()
+            loss = scalar_mean(loss)     # trainer.py:124 `l.mean()`; a 0-dim loss is its own mean (no launch)
             loss.backward()
             opt.step()
             return loss
@@ -463,9 +464,9 @@ def main():
             def loss_fn(i, l, n):
                 if is_db:
                     loss, _ = net(dbatch)
-                    return loss.mean()
+                    return scalar_mean(loss)
                 loss, _ = net(i, targets=l, lengths=n, train=True)
-                return loss.mean()
+                return scalar_mean(loss)
 
             ddp_launch = None
             if distributed and args.ddp_mode in ("auto", "capture"):

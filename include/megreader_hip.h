@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 1
+#define MR_ABI_VERSION 2   /* 2 (round 5): mr_ctc_fwd gained log_probs_f64; mr_tuning.tn_defer; mr_tn_defer / mr_tn_flush;
+                              the 26 mr_set_* setters of version 1 are gone (mr_tuning) */
 #define MR_DTYPE_F32 0
 #define MR_DTYPE_BF16 1
 
@@ -82,7 +83,13 @@ typedef struct mr_tuning {
                         instead of the all-taps kernel (round-4 in-step A/B: FPN-attention 9.68 -> 9.56 ms, CRNN at 32 crops per
                         GPU 1.47 -> 1.41, the P >= 16384 layers of Res50-PPM keep the all-taps kernel); rebuild row tables after
                         changing it (as for tn_taps) */
-  int reserved[5];   /* zero */
+  int tn_defer;      /* 1 (default): mr_tn_defer(1) records the weight-gradient launches of the 128x128 TN GEMM kernel and
+                        mr_tn_flush launches them several problems per launch (round 5); 0: mr_tn_defer is ignored, every
+                        launch is immediate (A/B) */
+  int pool_fixed;    /* 1 (default): max-pool forward with the window geometry as template constants (one packed store for the
+                        arg-max codes) and the pooled-element-organised backward of the 2x2 / stride 2 pool (round 5); 0: the
+                        round-4 kernels (bit-identical results; A/B) */
+  int reserved[3];   /* zero */
 } mr_tuning;
 int mr_tuning_get(mr_tuning* out);
 int mr_tuning_defaults(mr_tuning* out);
@@ -114,6 +121,20 @@ int mr_nt_kernel_code(int dtype, int M, int N, int K, int cg);
  * fused into the same pass over A). */
 int mr_gemm_tn(int dtype, const void* A, long long lda, const void* B, long long ldb, float* C, int ldc, int P,
                int NA, int NB, int row_perm_h, float* colsum, hipStream_t stream);
+
+/* Deferred, grouped weight-gradient launches (round 5).  The weight gradients of small layers -- the 1x1 / strided layers of a
+ * ResNet at batch 32 (backbones/resnet.py:113-181), the LSTM / Linear layers of the CRNN head (decoders/crnn.py:8-24) -- are GEMMs
+ * of 16..64 output tiles: alone, each has to cut its pixel loop into 8..32 splits to fill the chip.  Nothing later in the backward
+ * pass reads them, so they can wait and run side by side.  mr_tn_defer(1): on the calling host thread, bf16 launches that would
+ * take the 128x128 TN GEMM kernel (mr_gemm_tn; mr_conv2d_wgrad_tab off the all-taps kernel) are RECORDED (operand pointers and
+ * geometry) instead of launched; mr_tn_defer(0) stops recording.  mr_tn_flush launches everything recorded, up to 12 problems per
+ * launch, each with 1 / n-th of the splits.  The caller keeps every operand alive and unmodified until the flush, flushes on the
+ * stream the operands were produced on, and must not read an output (or zero it) before the flush.  mr_tn_defer returns the
+ * previous setting, mr_tn_pending the number of recorded problems (both host only).  mr_tuning.tn_defer = 0 makes mr_tn_defer a
+ * no-op (A/B). */
+int mr_tn_defer(int on);
+int mr_tn_pending(void);
+int mr_tn_flush(hipStream_t stream);
 
 /* ---- Convolution (replaces cuDNN conv fwd/dgrad/wgrad behind nn.Conv2d: backbones/crnn.py:44-55,
  *      backbones/resnet.py:39-256, backbones/ppm.py:11-44, decoders/ctc_decoder2d.py:16-27) --------------- */
@@ -304,8 +325,11 @@ int mr_lstm_debug_buffer(float* p);
 int mr_ctc_fwd(int dtype, const void* logits, int ldl, const void* targets, int targets_i64,
                const void* input_lengths, const void* target_lengths, int lengths_i64, int T, int N, int C, int S,
                int blank, int zero_infinity, float* log_probs, double* alpha, double* beta, double* nll,
-               double* loss, hipStream_t stream);
-/* alpha, beta: f64 [N][T][2S+1].  beta may be null in mr_ctc_fwd when no gradient is wanted (the beta recursion runs
+               double* loss, double* log_probs_f64, hipStream_t stream);
+/* log_probs_f64 (nullable, f64 [T][N][C]): the same log-probabilities widened to float64 -- what the reference returns as
+ * `pred` (decoders/crnn.py:96 `log_softmax(pred, dim=2).to(torch.float64)`), written by the same kernel.
+ * mr_ctc_bwd writes the padding columns C .. ldg-1 of grad_logits as zeros.
+ * alpha, beta: f64 [N][T][2S+1].  beta may be null in mr_ctc_fwd when no gradient is wanted (the beta recursion runs
  * concurrently with alpha on other wavefronts of the same workgroup, so storing it costs no extra latency and makes
  * the gradient kernel independent per (t, n) row). */
 int mr_ctc_bwd(int dtype, const float* log_probs, const double* alpha, const double* beta, const double* nll,

@@ -16,6 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "megreader_hip.h")
 
 MR_F32 = 0
 MR_BF16 = 1
+ABI_VERSION = 2     # include/megreader_hip.h: MR_ABI_VERSION
 
 _P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_double
 _CODES = {"p": _P, "i": _I, "l": _L, "f": _F, "d": _D, "s": _P}
@@ -58,7 +59,7 @@ SIGNATURES = {
     "mr_maxpool_bwd": "ipppp" + "i" * 12 + "s",
     "mr_lstm_fwd": "ipppppiiipls",
     "mr_lstm_bwd": "ipppppiiipls",
-    "mr_ctc_fwd": "ipipippiiiiiiippppps",
+    "mr_ctc_fwd": "ipipippiiiiiiipppppps",
     "mr_ctc_bwd": "ipppppippipiiiiiipis",
     "mr_softmax_nc1t": "ipipiiis",
     "mr_adaptive_avgpool_fwd": "ippiiiiiis",
@@ -108,18 +109,19 @@ SIGNATURES = {
     "mr_encode_labels": "ppiippiipps",
     "mr_ctc2d_fwd": "ippppiiiiiipps",
     "mr_ctc2d_bwd": "ippppppppp" + "iiiiiis",
+    "mr_tn_flush": "s",
 }
 
 _lib = None
 
 TUNING_FIELDS = ("nt_variant", "nt_deep", "nt_big", "nt_p8", "nt_force_bm", "nt_force_bn", "gemm_skinny", "tn_big", "tn_buf",
                  "tn_taps", "tn_taps_group", "tn_group", "tn_fin", "tn_taps_fin", "tn_taps_w8", "tn_model", "tn_splits",
-                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth", "nt_big_min_k", "tn_taps_min_p")
+                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth", "nt_big_min_k", "tn_taps_min_p", "tn_defer", "pool_fixed")
 
 
 class Tuning(ctypes.Structure):
     """struct mr_tuning (include/megreader_hip.h): the library's only process-wide switches."""
-    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 5)]
+    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 3)]
 
 
 def get_tuning():
@@ -220,6 +222,9 @@ def load():
     lib.mr_last_error.argtypes = []
     lib.mr_abi_version.restype = ctypes.c_int
     lib.mr_abi_version.argtypes = []
+    if lib.mr_abi_version() != ABI_VERSION:
+        raise RuntimeError("%s implements C ABI version %d, this binding expects %d -- rebuild it (`make -C megreader_amd/csrc`)"
+                           % (LIB_PATH, lib.mr_abi_version(), ABI_VERSION))
     lib.mr_init.restype = ctypes.c_int
     lib.mr_init.argtypes = []
     lib.mr_nt_tile_code.restype = ctypes.c_int
@@ -247,6 +252,10 @@ def load():
     lib.mr_lstm_ws_bytes.argtypes = [ctypes.c_int] * 4
     lib.mr_sizeof_img_desc.restype = ctypes.c_int
     lib.mr_sizeof_img_desc.argtypes = []
+    lib.mr_tn_defer.restype = ctypes.c_int
+    lib.mr_tn_defer.argtypes = [ctypes.c_int]
+    lib.mr_tn_pending.restype = ctypes.c_int
+    lib.mr_tn_pending.argtypes = []
     lib.mr_stem_bwd_workspace.restype = ctypes.c_longlong
     lib.mr_stem_bwd_workspace.argtypes = [ctypes.c_int]
     for name, codes in SIGNATURES.items():
@@ -273,7 +282,7 @@ def load():
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_tuning_get", "mr_tuning_set", "mr_tuning_defaults",
              "mr_stem_bwd_workspace", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_dcn2_ws_bytes", "mr_bn_scratch_doubles",
              "mr_sizeof_img_desc", "mr_nt_kernel_code", "mr_tn_taps_would_run", "mr_set_tn_taps_workspace",
-             "mr_sizeof_prep_job")  # entry points that take no stream and launch nothing
+             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

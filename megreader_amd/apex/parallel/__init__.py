@@ -190,6 +190,10 @@ class DistributedDataParallel(nn.Module):
         self._n_staged += int(staged)
 
     def _finalize(self):
+        # weight gradients still waiting for a grouped launch (nn.functional._TnDefer): launch them and let their parameters
+        # report ready BEFORE the incomplete buckets are closed below -- whichever end-of-backward callback runs first
+        from ...nn.functional import flush_deferred_wgrads
+        flush_deferred_wgrads()
         if self._folded is not None:
             steps = getattr(self._folded, "_py_steps", 0)
             if steps == self._fold_seen_step:

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const T* __restrict__ logi
                                                       int tg64, const void* in_len, const void* tg_len, int len64,
                                                       int Tn, int N, int C, int S, int blank,
                                                       float* __restrict__ lp_out, double* __restrict__ alpha_out,
-                                                      double* __restrict__ beta_out, double* __restrict__ nll_out) {
+                                                      double* __restrict__ beta_out, double* __restrict__ nll_out,
+                                                      double* __restrict__ lp64_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int SPmax = 2 * S + 1;
   double* al0 = (double*)smem_raw;  // [SPmax]
@@ -68,6 +69,12 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const T* __restrict__ logi
     const float lz = mx + logf(se);
     float* orow = lp_out + ((long long)t * N + b) * C;
     for (int c = lane; c < C; c += 64) orow[c] = to_f32(row[c]) - lz;
+    // the reference hands `log_softmax(pred).to(float64)` back to its caller (decoders/crnn.py:96): written here, exactly the
+    // f32 values widened, instead of by a conversion pass over lp
+    if (lp64_out) {
+      double* orow64 = lp64_out + ((long long)t * N + b) * C;
+      for (int c = lane; c < C; c += 64) orow64[c] = (double)(to_f32(row[c]) - lz);
+    }
   }
   for (int s = tid; s < SPmax; s += 256) lab[s] = (s < SP) ? ext_label(targets, tg64, (long long)b * S, s, blank) : blank;
   __syncthreads();
@@ -207,6 +214,10 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
   // rows at or beyond the input length get zero gradient
   if (valid && !active)
     for (int c = lane; c < C; c += 64) grad[((long long)t * N + b) * ldg + c] = from_f32<T>(0.f);
+  // padding columns C .. ldg-1 of every row (a 38-class head stored with 40 columns): written as zeros here, so the caller
+  // needs no fill pass and the padded Linear in front can take the buffer as it is
+  if (valid)
+    for (int c = C + lane; c < ldg; c += 64) grad[((long long)t * N + b) * ldg + c] = from_f32<T>(0.f);
   const float* lrow = lp + ((long long)(valid ? t : 0) * N + b) * C;
   if (active) {
     const double* arow = alpha + ((long long)b * Tn + t) * SPmax;
@@ -261,7 +272,7 @@ extern "C" {
 int mr_ctc_fwd(int dtype, const void* logits, int ldl, const void* targets, int targets_i64, const void* input_lengths,
                const void* target_lengths, int lengths_i64, int T, int N, int C, int S, int blank,
                int zero_infinity, float* log_probs, double* alpha, double* beta, double* nll, double* loss,
-               hipStream_t stream) {
+               double* log_probs_f64, hipStream_t stream) {
   MR_CHECK_ARG(T > 0 && N > 0 && C > 0 && S >= 0, "mr_ctc_fwd: bad shape T=%d N=%d C=%d S=%d", T, N, C, S);
   MR_CHECK_ARG(blank >= 0 && blank < C, "mr_ctc_fwd: blank %d out of range", blank);
   const size_t smem = (size_t)(2 * S + 1) * (4 * sizeof(double) + sizeof(int)) + 16;
@@ -269,11 +280,11 @@ int mr_ctc_fwd(int dtype, const void* logits, int ldl, const void* targets, int 
   if (dtype == MR_F32)
     hipLaunchKernelGGL((ctc_fwd_kernel<float>), dim3(N), dim3(256), smem, stream, (const float*)logits, ldl, targets,
                        targets_i64, input_lengths, target_lengths, lengths_i64, T, N, C, S, blank, log_probs, alpha,
-                       beta, nll);
+                       beta, nll, log_probs_f64);
   else if (dtype == MR_BF16)
     hipLaunchKernelGGL((ctc_fwd_kernel<bf16_t>), dim3(N), dim3(256), smem, stream, (const bf16_t*)logits, ldl,
                        targets, targets_i64, input_lengths, target_lengths, lengths_i64, T, N, C, S, blank,
-                       log_probs, alpha, beta, nll);
+                       log_probs, alpha, beta, nll, log_probs_f64);
   else { mr::set_error("mr_ctc_fwd: bad dtype %d", dtype); return MR_ERR_DTYPE; }
   if (loss)
     hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(256), 0, stream, (const double*)nll, target_lengths,

@@ -7,7 +7,9 @@
 #include "tn_taps.h"
 #include "../../include/megreader_hip.h"
 
+#include <algorithm>
 #include <mutex>
+#include <vector>
 
 namespace mr {
 
@@ -448,8 +450,106 @@ static int launch_tn_big(TnArgs a, const ConvGeom& g, int total_steps, hipStream
   return MR_OK;
 }
 
+// ---- deferred / grouped weight-gradient launches (mr_tn_defer, mr_tn_flush; igemm_tn_glds_grouped_kernel) ----------------
+// While deferral is on for the calling host thread, bf16 launches of the 128x128 TN GEMM kernel (dense: BMODE 0, conv with a row
+// table: BMODE 2) are RECORDED instead of launched; mr_tn_flush launches everything recorded so far, up to TN_GROUP_MAX problems
+// per launch.  The split of every problem is chosen for the GROUP: one p-step count L per workgroup for all problems, so that
+// the workgroups of the launch finish together and the chip is filled by problems, not by splits.
+#define g_tn_defer MR_TUNE(tn_defer)   // 1 (default): mr_tn_defer(1) records; 0: it is ignored (every launch immediate)
+struct TnRecord { TnArgs a; ConvGeom g; };
+struct TnDeferState {
+  bool on = false;
+  std::vector<TnRecord> q[2];   // [0]: BMODE 0, [1]: BMODE 2
+};
+static thread_local TnDeferState g_tn_defer_state;
+
+template <int BMODE>
+static int launch_tn_group(const TnRecord* recs, int n, hipStream_t stream) {
+  const void* z = zero_page();
+  if (!z) { set_error("zero page allocation failed"); return MR_ERR_LAUNCH; }
+  const int cus = num_cus();
+  int tiles[TN_GROUP_MAX], steps[TN_GROUP_MAX], max_steps = 1;
+  for (int i = 0; i < n; ++i) {
+    tiles[i] = cdiv(recs[i].a.NA, 128) * cdiv(recs[i].a.NB, 128);
+    steps[i] = cdiv(recs[i].a.P, 64);
+    if (steps[i] > max_steps) max_steps = steps[i];
+  }
+  // L = p-steps per workgroup: makespan model of launch_tn (launch + prologue + atomic epilogue ~ 20 p-steps; two
+  // workgroups per CU run their p-steps ~1.3x slower than one)
+  int bestL = max_steps;
+  double best = 1e300;
+  for (int L = 1; L <= max_steps; ++L) {
+    long long blocks = 0;
+    for (int i = 0; i < n; ++i) blocks += (long long)cdiv(tiles[i] * cdiv(steps[i], L), 8) * 8;
+    const long long rounds = (blocks + 2 * cus - 1) / (2 * cus);
+    const double cost = (double)rounds * (L + 20.0) * (blocks > cus ? 1.3 : 1.0);
+    if (cost < best) { best = cost; bestL = L; }
+  }
+  TnGroup grp;
+  int end = 0;
+  for (int i = 0; i < n; ++i) {
+    TnArgs a = recs[i].a;
+    int splits = cdiv(steps[i], bestL);
+    a.p_chunk = cdiv(cdiv(a.P, splits), 64) * 64;
+    splits = cdiv(a.P, a.p_chunk);
+    a.grp = 1; a.ws = nullptr; a.fin = 0;     // split partials of a grouped launch: f32 atomics (few splits per problem)
+    grp.a[i] = a;
+    grp.g[i] = recs[i].g;
+    grp.nblk[i] = tiles[i] * splits;
+    end += cdiv(grp.nblk[i], 8) * 8;
+    grp.blk_end[i] = end;
+  }
+  for (int i = n; i < TN_GROUP_MAX; ++i) { grp.a[i] = grp.a[0]; grp.g[i] = grp.g[0]; grp.nblk[i] = 0; grp.blk_end[i] = end; }
+  grp.n = n;
+  hipLaunchKernelGGL((igemm_tn_glds_grouped_kernel<BMODE>), dim3(end), dim3(256), 0, stream, grp, z);
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+template <typename T, int BMODE>
+static int launch_tn_now(TnArgs a, const ConvGeom& g, hipStream_t stream);
+
+static int tn_flush(hipStream_t stream) {
+  TnDeferState& st = g_tn_defer_state;
+  const bool was_on = st.on;
+  st.on = false;      // single problems below go through launch_tn_now
+  int rc = MR_OK;
+  for (int m = 0; m < 2 && rc == MR_OK; ++m) {
+    std::vector<TnRecord>& q = st.q[m];
+    size_t i = 0;
+    while (i < q.size() && rc == MR_OK) {
+      const int n = (int)std::min<size_t>(TN_GROUP_MAX, q.size() - i);
+      if (n == 1)
+        rc = m == 0 ? launch_tn_now<bf16_t, 0>(q[i].a, q[i].g, stream) : launch_tn_now<bf16_t, 2>(q[i].a, q[i].g, stream);
+      else
+        rc = m == 0 ? launch_tn_group<0>(&q[i], n, stream) : launch_tn_group<2>(&q[i], n, stream);
+      i += n;
+    }
+    q.clear();
+  }
+  st.on = was_on;
+  return rc;
+}
+
 template <typename T, int BMODE>
 static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
+  if constexpr (sizeof(T) == 2 && BMODE != 1) {
+    TnDeferState& st = g_tn_defer_state;
+    if (st.on && g_tn_defer && g_nt_variant == 2 && g_tn_buf && g_tn_big <= 0 && g_tn_fin != 2 && g_tn_splits == 0) {
+      const long long bytesA = (long long)a.P * a.lda * 2;
+      const long long bytesB = BMODE == 0 ? (long long)a.P * a.ldb * 2
+                                          : ((long long)a.P / ((long long)g.Hm * g.Wm) + 1) * g.Hg * g.Wg * g.ldg * 2;
+      if (bytesA < (1ll << 31) && bytesB < (1ll << 31)) {
+        st.q[BMODE == 0 ? 0 : 1].push_back(TnRecord{a, g});
+        return MR_OK;
+      }
+    }
+  }
+  return launch_tn_now<T, BMODE>(a, g, stream);
+}
+
+template <typename T, int BMODE>
+static int launch_tn_now(TnArgs a, const ConvGeom& g, hipStream_t stream) {
   constexpr int BP = TnCfg<T>::BP;
   const int tiles = cdiv(a.NA, 128) * cdiv(a.NB, 128);
   // split count: workgroups run 2 per CU and are latency-bound, so time ~ rounds(blocks / 2*CUs) * (p-steps per
@@ -644,6 +744,19 @@ int mr_gemm_nt(int dtype, const void* A, long long lda, const void* B, int ldb, 
   if (dtype == MR_F32) return dispatch_nt_store<float, 0>(a, g, C, ldc, bias, relu, stream);
   return dispatch_nt_store<bf16_t, 0>(a, g, C, ldc, bias, relu, stream);
 }
+
+// Deferred weight-gradient launches.  mr_tn_defer(1): from now on, on the calling host thread, the bf16 weight-gradient GEMMs that
+// would run on the 128x128 TN kernel (mr_gemm_tn; mr_conv2d_wgrad_tab off the all-taps kernel) are recorded instead of launched;
+// mr_tn_defer(0) stops recording (what is recorded stays).  mr_tn_flush(stream) launches everything recorded, several problems
+// per launch.  The CALLER keeps every operand alive and unmodified until the flush and must not read an output before it.
+// Returns the previous setting.  Host only.
+int mr_tn_defer(int on) {
+  const int old = g_tn_defer_state.on ? 1 : 0;
+  g_tn_defer_state.on = on != 0;
+  return old;
+}
+int mr_tn_pending(void) { return (int)(g_tn_defer_state.q[0].size() + g_tn_defer_state.q[1].size()); }
+int mr_tn_flush(hipStream_t stream) { return tn_flush(stream); }
 
 int mr_gemm_tn(int dtype, const void* A, long long lda, const void* B, long long ldb, float* C, int ldc, int P,
                int NA, int NB, int row_perm_h, float* colsum, hipStream_t stream) {

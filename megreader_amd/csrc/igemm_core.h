@@ -1457,11 +1457,14 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
 // BUF: stage through raw buffer resources (glds16_buf) instead of flat pointers + zero page
 // ABL (timing only, wrong results): bit 0 = no LDS-DMA in the loop, bit 1 = no fragment reads in the loop,
 // bit 2 = no atomic epilogue, bit 3 = no column sums.
-template <int BMODE, bool BUF = false, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeom g, const void* zero) {
+// The kernel body: workgroup `bid` of `total` (= tiles * splits) of ONE problem.  igemm_tn_glds_kernel runs it with
+// (blockIdx.x, gridDim.x); igemm_tn_glds_grouped_kernel runs SEVERAL problems in one launch (TnGroup), each on its own
+// contiguous range of workgroups that starts at a multiple of 8 -- so (bid & 7) is still the XCD of the workgroup.
+template <int BMODE, bool BUF, int ABL>
+__device__ __forceinline__ void tn_glds_body(const TnArgs& a, const ConvGeom& g, const void* zero, const int bid,
+                                             const int total, unsigned char* smem) {
   typedef bf16_t T;
   constexpr int BP = 64, ROW_BYTES = 256, TILE_BYTES = BP * ROW_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // [stage][A|B]
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1472,9 +1475,8 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
   // it, i.e. whole P-chunks: the workgroups that share an L2 stream through the same rows of dy / x, which are
   // then fetched from HBM about once instead of once per XCD (FETCH_SIZE per launch was ~5x the algorithmic bytes
   // with tiles dealt round-robin over the XCDs).
-  const int total = gridDim.x;
-  const int xq = total >> 3, xr = total & 7, xcd = blockIdx.x & 7;
-  const int vb = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
+  const int xq = total >> 3, xr = total & 7, xcd = bid & 7;
+  const int vb = xcd * xq + (xcd < xr ? xcd : xr) + (bid >> 3);
   const int ntiles = tiles_a * tiles_b;
   const int split = vb / ntiles, tile = vb - split * ntiles;
   const int tile_b = tile % tiles_b, tile_a = tile / tiles_b;
@@ -1788,6 +1790,39 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeo
         else atomicAdd(dst, acc[i][j][q]);
       }
     }
+}
+
+template <int BMODE, bool BUF = false, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void igemm_tn_glds_kernel(TnArgs a, ConvGeom g, const void* zero) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 64 * 256];  // [stage][A|B]
+  tn_glds_body<BMODE, BUF, ABL>(a, g, zero, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+
+// Grouped launch: up to TN_GROUP_MAX independent weight-gradient problems of one BMODE in ONE launch (mr_tn_defer /
+// mr_tn_flush, gemm_conv.hip).  Why: the weight gradients of the small layers (ResNet 1x1 / strided layers at batch 32, the
+// LSTM / Linear layers of the CRNN) are launches of 16..64 output tiles whose P loop had to be cut into 8..32 splits to fill
+// the chip -- a 2..8-step main loop between an address prologue and a 64 KB atomic epilogue per workgroup.  Several such
+// problems side by side fill the chip with 1/8 of the splits each: longer loops, 1/8 of the atomics.  Problem i owns the
+// workgroups [blk_end[i-1], blk_end[i]) (each range padded to a multiple of 8: blockIdx & 7 stays the XCD inside a range; the
+// pad workgroups leave at once); the struct travels by value in the kernarg segment, indexed with a uniform index.
+constexpr int TN_GROUP_MAX = 12;
+struct TnGroup {
+  TnArgs a[TN_GROUP_MAX];
+  ConvGeom g[TN_GROUP_MAX];
+  int blk_end[TN_GROUP_MAX];   // exclusive end of problem i's workgroup range (multiple of 8)
+  int nblk[TN_GROUP_MAX];      // tiles * splits of problem i (<= the range's length)
+  int n;
+};
+template <int BMODE>
+__global__ __launch_bounds__(256, 2) void igemm_tn_glds_grouped_kernel(TnGroup grp, const void* zero) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 64 * 256];
+  const int b = (int)blockIdx.x;
+  int i = 0;
+  while (i + 1 < grp.n && b >= grp.blk_end[i]) ++i;   // uniform: scalar loads from the kernarg segment
+  const int b0 = i > 0 ? grp.blk_end[i - 1] : 0;
+  const int bid = b - b0;
+  if (bid >= grp.nblk[i]) return;
+  tn_glds_body<BMODE, true, 0>(grp.a[i], grp.g[i], zero, bid, grp.nblk[i], smem);
 }
 
 // C += sum over the splits of a tile's slabs (TnArgs.fin == 2).  One workgroup per (tile, accumulator tile k = i*4 + j); thread tid

@@ -734,6 +734,96 @@ __global__ __launch_bounds__(256) void maxpool_bwd_fixed_kernel(const T* __restr
   ((uint4*)dx)[((long long)blockIdx.y * W + w) * cv + c] = out;
 }
 
+// Forward with the window geometry as template constants (the pools the models use: 2x2 stride (2,2) and (2,1), 3x3 stride 2):
+// one (n, ho) output row per blockIdx.y, no runtime divisions per window tap, the KH*KW loads of a thread issued back to back,
+// the arg-max codes of a channel vector stored as ONE 4- / 8-byte word (the generic kernel stores them byte by byte).  Same
+// comparison rule, so values and codes are bit-identical to maxpool_fwd_kernel.
+template <typename T, int KH, int KW, int SH, int SW>
+__global__ __launch_bounds__(256) void maxpool_fwd_fixed_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                                 unsigned char* __restrict__ idx, int H, int W, int cv,
+                                                                 int ph, int pw, int Ho, int Wo) {
+  constexpr int VEC = VecOf<T>::N;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= Wo * cv) return;
+  const int wo = t / cv, c = t - wo * cv;
+  const int n = blockIdx.y / Ho, ho = blockIdx.y - n * Ho;
+  uint4 v[KH * KW];
+  bool ok[KH * KW];
+#pragma unroll
+  for (int i = 0; i < KH; ++i)
+#pragma unroll
+    for (int jx = 0; jx < KW; ++jx) {
+      const int h = ho * SH - ph + i, w = wo * SW - pw + jx;
+      ok[i * KW + jx] = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+      v[i * KW + jx] = ok[i * KW + jx] ? ((const uint4*)x)[(((long long)n * H + h) * W + w) * cv + c] : make_uint4(0, 0, 0, 0);
+    }
+  float best[VEC];
+  unsigned char bi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) best[j] = -INFINITY;
+  bool first = true;
+#pragma unroll
+  for (int k = 0; k < KH * KW; ++k) {
+    if (!ok[k]) continue;
+    const T* pv = (const T*)&v[k];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float f = to_f32(pv[j]);
+      if (first || f > best[j] || f != f) { best[j] = f; bi[j] = (unsigned char)k; }
+    }
+    first = false;
+  }
+  uint4 o;
+  T* po = (T*)&o;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) po[j] = from_f32<T>(best[j]);
+  const long long q = (((long long)n * Ho + ho) * Wo + wo) * cv + c;
+  ((uint4*)y)[q] = o;
+  if (VEC == 8) *(uint2*)(idx + q * VEC) = *(const uint2*)bi;
+  else *(unsigned*)(idx + q * VEC) = *(const unsigned*)bi;
+}
+
+// Backward of the 2x2 / stride 2 / no padding pool on even H and W (CRNN conv1, ResNet-free): every input pixel belongs to
+// exactly one window, so the pass is organised by POOLED element -- a thread loads dy, the codes and the ReLU mask source of
+// one pooled channel vector once and writes the four input vectors of its window (the value at the arg-max position, zeros at
+// the other three); nothing is summed, so no conversion either.  Same result as maxpool_bwd_fixed_kernel<T, 2, 2, 2, 2>.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_2x2s2_kernel(const T* __restrict__ dy,
+                                                                 const unsigned char* __restrict__ idx,
+                                                                 const T* __restrict__ relu_y, T* __restrict__ dx, int H,
+                                                                 int W, int cv, int Ho, int Wo) {
+  constexpr int VEC = VecOf<T>::N;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= Wo * cv) return;
+  const int wo = t / cv, c = t - wo * cv;
+  const int n = blockIdx.y / Ho, ho = blockIdx.y - n * Ho;
+  const long long o = (((long long)n * Ho + ho) * Wo + wo) * cv + c;
+  const uint4 g = ((const uint4*)dy)[o];
+  unsigned char code[8];
+  if (VEC == 8) *(uint2*)code = *(const uint2*)(idx + o * VEC);
+  else *(unsigned*)code = *(const unsigned*)(idx + o * VEC);
+  const T* pg = (const T*)&g;
+  T gm[VEC];
+  if (relu_y) {
+    const uint4 yv = ((const uint4*)relu_y)[o];
+    const T* py = (const T*)&yv;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) gm[j] = to_f32(py[j]) > 0.f ? pg[j] : from_f32<T>(0.f);
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) gm[j] = pg[j];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint4 out;
+    T* po = (T*)&out;
+    // (the gather kernel computes 0.f + g and rounds back: the same bits, except that it turns -0 into +0 -- kept)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) po[j] = code[j] == k ? from_f32<T>(0.f + to_f32(gm[j])) : from_f32<T>(0.f);
+    ((uint4*)dx)[(((long long)n * H + 2 * ho + (k >> 1)) * W + 2 * wo + (k & 1)) * cv + c] = out;
+  }
+}
+
 #define g_bn_fused MR_TUNE(bn_fused)   // 1: fold the finalize kernels into the apply passes (mr_tuning.bn_fused)
 // blocks along the rows of a fused apply pass: ~8 row groups per block, at most ~16 blocks per CU in total
 static inline int bn_fused_grid_x(long long P, int rows, int slabs) {
@@ -969,6 +1059,19 @@ int mr_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* idx, int N,
   MR_CHECK_ARG(Ho == (H + 2 * ph - kh) / sh + 1 && Wo == (W + 2 * pw - kw) / sw + 1,
                "mr_maxpool_fwd: output size inconsistent");
   const long long total = (long long)N * Ho * Wo * (C / vec);
+  if ((long long)N * Ho <= 65535 && MR_TUNE(pool_fixed)) {   // one (n, ho) row per blockIdx.y
+    const int cv = C / vec;
+    const dim3 grid(cdiv(Wo * cv, 256), N * Ho);
+#define MR_POOL_FIXED(KH_, KW_, SH_, SW_)                                                                            \
+  if (kh == KH_ && kw == KW_ && sh == SH_ && sw == SW_) {                                                            \
+    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_fwd_fixed_kernel<T, KH_, KW_, SH_, SW_>), grid, dim3(256), 0,       \
+                                         stream, (const T*)x, (T*)y, idx, H, W, cv, ph, pw, Ho, Wo));                \
+    MR_CHECK_LAUNCH();                                                                                               \
+    return MR_OK;                                                                                                    \
+  }
+    MR_POOL_FIXED(2, 2, 2, 2) MR_POOL_FIXED(2, 2, 2, 1) MR_POOL_FIXED(3, 3, 2, 2)
+#undef MR_POOL_FIXED
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
                                        (const T*)x, (T*)y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, Ho, Wo));
   MR_CHECK_LAUNCH();
@@ -982,6 +1085,13 @@ int mr_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, const vo
   MR_CHECK_ARG(C % vec == 0, "mr_maxpool_bwd: C (%d) must be a multiple of %d", C, vec);
   const long long total = (long long)N * H * W * (C / vec);
   const int cv = C / vec;
+  if (kh == 2 && kw == 2 && sh == 2 && sw == 2 && ph == 0 && pw == 0 && H == 2 * Ho && W == 2 * Wo &&
+      (long long)N * Ho <= 65535 && MR_TUNE(pool_fixed)) {   // organised by pooled element (maxpool_bwd_2x2s2_kernel)
+    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_2x2s2_kernel<T>), dim3(cdiv(Wo * cv, 256), N * Ho), dim3(256), 0, stream,
+                                         (const T*)dy, idx, (const T*)relu_y, (T*)dx, H, W, cv, Ho, Wo));
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+  }
   if ((long long)N * H <= 65535) {   // one (n, h) row per blockIdx.y
     const dim3 grid(cdiv(W * cv, 256), N * H);
 #define MR_POOL_FIXED(KH_, KW_, SH_, SW_)                                                                            \

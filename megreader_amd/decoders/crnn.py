@@ -82,7 +82,7 @@ class CRNNDecoder(nn.Module):
             # reference: log_softmax(dim=2).to(float64) -> self.ctc_loss(pred, targets, [T]*N, lengths)
             loss, log_probs = F.ctc_loss_logits(pred, targets, None, lengths, blank=0,
                                                 zero_infinity=not self.per_sample_loss,
-                                                per_sample=self.per_sample_loss)
-            return loss, log_probs.to(torch.float64)
+                                                per_sample=self.per_sample_loss, log_probs_f64=True)
+            return loss, log_probs
         else:
             return F.softmax_eval_nc1t(pred)

@@ -112,7 +112,7 @@ class _GraphedTrainStep(object):
     def __call__(self, trainer, model, optimizer, batch, epoch, step, **kwargs):
         import torch
         from . import optim as _optim
-        from .runtime import GraphedTrainStep
+        from .runtime import GraphedTrainStep, scalar_mean
         self.calls += 1
         usable = (not self.disabled and isinstance(optimizer, _optim._FlatOptimizer) and isinstance(batch, dict)
                   and torch.cuda.is_available() and model.training)
@@ -136,7 +136,7 @@ class _GraphedTrainStep(object):
                 else:
                     l = results
                 holder["metrics"] = {k: (v.detach() if hasattr(v, "detach") else v) for k, v in metrics.items()}
-                return l.mean()
+                return scalar_mean(l)
             try:
                 optimizer.push_hyper()     # no host->device copy may happen inside the capture
                 graphed = GraphedTrainStep(loss_fn, optimizer, [], warmup=0)

@@ -172,6 +172,71 @@ def accumulate_multi(pairs):
         call("mr_accumulate_multi", n, dst, src, cnt)
 
 
+class _TnDefer(object):
+    """Deferred, grouped weight-gradient launches (include/megreader_hip.h: mr_tn_defer / mr_tn_flush).  Nothing later in a
+    backward pass reads a weight gradient that goes to a gradient sink, so the small weight-gradient GEMMs (ResNet 1x1 / strided
+    layers, LSTM / Linear layers) are recorded while backward runs and launched several problems per launch: at the latest from
+    an autograd-engine callback at the end of the backward pass, earlier whenever MAX problems are waiting.  The operands of the
+    recorded problems are kept alive here until the flush; parameters are reported to data-parallel wrappers
+    (notify_grad_ready) only after the launch that completes their gradient.
+    MEGREADER_TN_DEFER=0 (or mr_tuning.tn_defer = 0): every launch immediate (A/B)."""
+    enabled = os.environ.get("MEGREADER_TN_DEFER", "1") != "0"
+    MAX = 12
+    keep = []
+    notify = []
+    queued = False
+    mark = 0
+
+    @staticmethod
+    def begin():
+        """Start recording for the calls that follow (until end()); False when deferral is not possible here (switched off,
+        or not inside a backward pass -- the end-of-backward flush could not be registered)."""
+        if not _TnDefer.enabled:
+            return False
+        if not _TnDefer.queued:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_TnDefer.flush)
+            except RuntimeError:
+                return False
+            _TnDefer.queued = True
+        lib = load()
+        _TnDefer.mark = lib.mr_tn_pending()
+        lib.mr_tn_defer(1)
+        return True
+
+    @staticmethod
+    def end(tensors, params):
+        """Stop recording.  True when the calls since begin() were recorded (the caller must then NOT report its parameters
+        ready: the flush does); False when the library launched them at once (f32, all-taps kernel, mr_tuning.tn_defer = 0)."""
+        lib = load()
+        lib.mr_tn_defer(0)
+        n = lib.mr_tn_pending()
+        if n == _TnDefer.mark:
+            return False
+        _TnDefer.keep.extend(t for t in tensors if t is not None)
+        _TnDefer.notify.extend(params)
+        if n >= _TnDefer.MAX:
+            _TnDefer.flush(final=False)
+        return True
+
+    @staticmethod
+    def flush(final=True):
+        if load().mr_tn_pending():
+            call("mr_tn_flush")
+        ready, _TnDefer.notify = _TnDefer.notify, []
+        del _TnDefer.keep[:]
+        if final:
+            _TnDefer.queued = False
+        for p in ready:
+            notify_grad_ready(p)
+
+
+def flush_deferred_wgrads():
+    """Launch every recorded weight-gradient problem now (data-parallel wrappers call this before they finalise a backward
+    pass; harmless when nothing is recorded)."""
+    _TnDefer.flush(final=False)
+
+
 def to_internal(x, dtype):
     """logical [N,C,H,W] (any layout) -> NHWC-contiguous [N,H,W,Cp] tensor of `dtype` (view when possible)."""
     N, C, H, W = x.shape
@@ -418,8 +483,12 @@ class Conv2dFn(Function):
                 # (Kw % 8: the all-taps kernel needs whole channel vectors and its table has another format than the GEMM
                 # kernel's -- two layers of one geometry that differ in that must not share a table)
                 tab, build = _wgrad_rowtab(g.device, (N, H, W, Cp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo), Kw % 8 == 0)
+            # sunk gradients have no reader inside the backward pass: the launch may wait and share a grouped launch (_TnDefer)
+            defer = w_sink is not None and (not want_db or b_sink is not None) and _TnDefer.begin()
             call("mr_conv2d_wgrad_tab", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, Kw,
                  Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo, ptr(tab), build)
+            if defer and _TnDefer.end((g, xi, tab), [weight_p] + ([bias_p] if want_db else [])):
+                return dx, None, None, None, None, None, None, None, None, None, None
             if w_sink is not None:
                 dwt = None
                 notify_grad_ready(weight_p)
@@ -883,9 +952,9 @@ class LinearFn(Function):
             return (w_n_, w_t_), [prep.matrix_job(ptr(weight), K, ptr(w_n_), K, ptr(w_t_), Np, Nout, K, 0)]
 
         w_n, w_t = prep.prepared((weight,), ("linear", Np), build, dtype)
+        # (Np != Nout: the padding columns of y stay unwritten -- the only tensor handed out is the [:, :Nout] view, and the
+        # kernels that take the padded buffer itself (the CTC head: logits with ldl = Np) read Nout columns)
         y = torch.empty((M, Np), dtype=dtype, device=x.device)
-        if Np != Nout:
-            y[:, Nout:].zero_()
         call("mr_gemm_nt", dt, ptr(x2), K, ptr(w_n), K, ptr(y), Np, ptr(bias), 0, M, Nout, K)
         ctx.save_for_backward(x2, w_t)
         ctx.params = (weight, bias)
@@ -936,6 +1005,14 @@ class LinearFn(Function):
                 with torch.cuda.stream(_Side.fork()):
                     call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, NA, K, 0, ptr(gb))
                 _Side.pending.extend((gp, x2))
+            elif (w_sink is not None and (gb is None or b_sink is not None) and not _Fan.enabled and
+                  dtype == torch.bfloat16 and _TnDefer.begin()):
+                # sunk gradients: recorded for a grouped launch (_TnDefer); the flush reports the parameters ready
+                call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, NA, K, 0, ptr(gb))
+                if _TnDefer.end((gp, x2), [weight_p] + ([bias_p] if want_db else [])):
+                    if dx_fn is not None:
+                        dx_fn()
+                    return dx, None, None
             else:   # input-gradient and weight-gradient GEMMs are independent: side by side (_Fan)
                 _Fan.run([dx_fn, lambda: call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, NA, K, 0,
                                               ptr(gb))])
@@ -1066,6 +1143,29 @@ class BiLSTMFn(Function):
             dx = torch.empty((T, N, I), dtype=dtype, device=dev)
             dx_fn = lambda: call("mr_gemm_nt", dt, ptr(dgates), 8 * H, ptr(wcat_t), 8 * H, ptr(dx), I, 0, 0, T * N, I,
                                  8 * H)
+        if (use_sinks and not overlap and not _Fan.enabled and dtype == torch.bfloat16 and T > 1 and _TnDefer.begin()):
+            # Grouped launch (_TnDefer): the four weight-gradient GEMMs of the layer -- W_ih and W_hh of both directions, each
+            # straight into its sink -- plus whatever the Linear layers behind this one recorded run as ONE launch; only the
+            # bias sums (column sums of dgates, shared by b_ih and b_hh) pass through a scratch.
+            if dx_fn is not None:
+                dx_fn()
+            arena = ZeroArena.take(dev, 4 * H)
+            gb = (arena.view(torch.float32)[:8 * H] if arena is not None else
+                  torch.zeros((8 * H,), dtype=torch.float32, device=dev)).view(2, 4 * H)
+            P = (T - 1) * N
+            for d in range(2):
+                call("mr_gemm_tn", dt, ptr(dgates) + d * 4 * H * es, 8 * H, ptr(x), I, ptr(sinks[4 * d]), I, T * N, 4 * H, I, H,
+                     ptr(gb[d]))
+            # forward direction: dgates[t] (t >= 1) with h[t-1]; reverse direction: dgates[t] (t <= T-2) with h[t+1]
+            call("mr_gemm_tn", dt, ptr(dgates) + N * 8 * H * es, 8 * H, ptr(out), 2 * H, ptr(sinks[1]), H, P, 4 * H, H, H, 0)
+            call("mr_gemm_tn", dt, ptr(dgates) + 4 * H * es, 8 * H, ptr(out) + (N * 2 * H + H) * es, 2 * H, ptr(sinks[5]), H, P,
+                 4 * H, H, H, 0)
+            if _TnDefer.end((dgates, x, out, gb), []):
+                _TnDefer.flush(final=False)      # the bias sums are read right below
+            accumulate_multi([(sinks[2], gb[0]), (sinks[3], gb[0]), (sinks[6], gb[1]), (sinks[7], gb[1])])
+            for p in ctx.params:
+                notify_grad_ready(p)
+            return (dx,) + (None,) * 8
         if overlap and dx_fn is not None:
             dx_fn()
         with torch.cuda.stream(side) if overlap else contextlib.nullcontext():
@@ -1128,7 +1228,7 @@ _FULL_LENGTHS = {}
 
 class CTCLossFn(Function):
     @staticmethod
-    def forward(ctx, logits, targets, input_lengths, target_lengths, blank, zero_infinity):
+    def forward(ctx, logits, targets, input_lengths, target_lengths, blank, zero_infinity, want_f64=False):
         require_cuda(logits, targets, target_lengths)
         T, N, C = logits.shape
         dtype = logits.dtype
@@ -1154,6 +1254,8 @@ class CTCLossFn(Function):
         target_lengths = target_lengths.to(device=logits.device, dtype=torch.int64).contiguous()
         dev = logits.device
         lp = torch.empty((T, N, C), dtype=torch.float32, device=dev)
+        # the float64 copy the reference returns as `pred` (decoders/crnn.py:96): written by the same kernel
+        lp64 = torch.empty((T, N, C), dtype=torch.float64, device=dev) if want_f64 else None
         alpha = torch.empty((N, T, 2 * S + 1), dtype=torch.float64, device=dev)
         # beta is produced by the same kernel (concurrently with alpha) when a gradient may be asked for
         beta = torch.empty((N, T, 2 * S + 1), dtype=torch.float64, device=dev) if ctx.needs_input_grad[0] else None
@@ -1162,14 +1264,15 @@ class CTCLossFn(Function):
         t64 = int(targets.dtype == torch.int64)
         call("mr_ctc_fwd", dtype_code(dtype), ptr(logits), ldl, ptr(targets), t64, ptr(input_lengths),
              ptr(target_lengths), 1, T, N, C, S, int(blank), int(zero_infinity), ptr(lp), ptr(alpha), ptr(beta),
-             ptr(nll), ptr(loss))
+             ptr(nll), ptr(loss), ptr(lp64))
         ctx.save_for_backward(lp, alpha, beta, nll, targets, input_lengths, target_lengths)
         ctx.dims = (T, N, C, S, int(blank), int(zero_infinity), t64)
         ctx.dtype = dtype
-        ctx.mark_non_differentiable(lp)
+        out_lp = lp64 if want_f64 else lp
+        ctx.mark_non_differentiable(out_lp)
         if int(zero_infinity) & 2:   # per-sample losses nll_b / L_b (reference decoders/ctc_loss.py:118-122)
-            return nll / target_lengths.to(torch.float64), lp
-        return loss, lp
+            return nll / target_lengths.to(torch.float64), out_lp
+        return loss, out_lp
 
     @staticmethod
     def backward(ctx, gloss, _glp):
@@ -1179,22 +1282,24 @@ class CTCLossFn(Function):
         v = vec_of(dtype)
         Cp = _ceil_to(C, v)
         g = gloss.to(torch.float64).contiguous()
-        grad = torch.zeros((T, N, Cp), dtype=dtype, device=lp.device) if Cp != C else \
-            torch.empty((T, N, Cp), dtype=dtype, device=lp.device)
+        grad = torch.empty((T, N, Cp), dtype=dtype, device=lp.device)    # the kernel writes the padding columns as zeros
         call("mr_ctc_bwd", dtype_code(dtype), ptr(lp), ptr(alpha), ptr(beta), ptr(nll), ptr(targets), t64,
              ptr(input_lengths),
              ptr(target_lengths), 1, ptr(g), T, N, C, S, blank, zero_inf, ptr(grad), Cp)
         if Cp != C:
             mark_zero_padded(grad)    # the padded Linear in front takes the buffer as it is (LinearFn.backward)
-        return grad[..., :C], None, None, None, None, None
+        return grad[..., :C], None, None, None, None, None, None
 
 
-def ctc_loss_logits(logits, targets, input_lengths, target_lengths, blank=0, zero_infinity=True, per_sample=False):
+def ctc_loss_logits(logits, targets, input_lengths, target_lengths, blank=0, zero_infinity=True, per_sample=False,
+                    log_probs_f64=False):
     """CTC loss of log_softmax(logits) (fused); returns (loss, log_probs).  Default: nn.CTCLoss(reduction='mean')
     semantics (f64 scalar).  per_sample=True: the [N] vector nll_b / L_b of the reference's own python CTCLoss
-    (decoders/ctc_loss.py:118-122, reduction='mean' there means "divide by the target length", no batch mean)."""
+    (decoders/ctc_loss.py:118-122, reduction='mean' there means "divide by the target length", no batch mean).
+    log_probs_f64=True: the returned log-probabilities are float64 (the f32 values widened by the kernel itself -- the
+    reference's `log_softmax(pred, dim=2).to(torch.float64)`) instead of float32."""
     flags = int(bool(zero_infinity)) | (2 if per_sample else 0)
-    return CTCLossFn.apply(logits, targets, input_lengths, target_lengths, blank, flags)
+    return CTCLossFn.apply(logits, targets, input_lengths, target_lengths, blank, flags, bool(log_probs_f64))
 
 
 def softmax_eval_nc1t(logits):

@@ -68,6 +68,13 @@ def broadcast_parameters(module, src=0, group=None):
             dist.broadcast(t.data, src, group=group)
 
 
+def scalar_mean(loss):
+    """`loss.mean()` of the reference's train step (trainer.py:124) without the two launches it costs when the loss already is
+    a 0-dim tensor (nn.CTCLoss(reduction='mean') and the detector's criterion return scalars): the mean of one element is the
+    element, forward and backward."""
+    return loss if loss.dim() == 0 else loss.mean()
+
+
 _LIVE_STEPS = []      # weak references to the GraphedTrainStep objects that are alive
 
 
@@ -96,13 +103,18 @@ class GraphedTrainStep(object):
         self.graph = None
         self.graph_update = None
         self.loss = None
+        self._one = None
         self._warmup = warmup
         self._capture()
 
     def _fwd_bwd(self):
         self.optimizer.zero_grad()
         loss = self.loss_fn(*self.inputs)
-        loss.backward()
+        # the root gradient (ones) is a constant: created once during warm-up instead of by a fill launch in every step
+        one = self._one
+        if one is None or one.shape != loss.shape or one.dtype != loss.dtype or one.device != loss.device:
+            one = self._one = torch.ones_like(loss, requires_grad=False)
+        loss.backward(one)
         return loss
 
     def _eager(self):

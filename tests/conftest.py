@@ -20,7 +20,7 @@ def pytest_configure(config):
 # RoI pooling); whole-network tests whose tolerances lean on chaotic amplification run last.
 _ORDER = [
     "test_timed_step_gpu", "test_published_configs_gpu", "test_fullsize_parity_gpu", "test_kernels_gpu",
-    "test_tn_taps_gpu", "test_stem_gpu", "test_crnn_gpu", "test_ctc2d_gpu", "test_res50ppm_gpu", "test_fpn_attention_gpu",
+    "test_tn_taps_gpu", "test_tn_grouped_gpu", "test_stem_gpu", "test_crnn_gpu", "test_ctc2d_gpu", "test_res50ppm_gpu", "test_fpn_attention_gpu",
     "test_attention_kernels_gpu", "test_dcn_gpu", "test_dcn_reference_gpu", "test_ctc2d_reference_gpu", "test_seg_detector_gpu", "test_dropin_fast_gpu", "test_ddp_gpu",
     "test_ctc_decoder_gpu", "test_decode_gpu", "test_pipeline_gpu", "test_db_post_gpu", "test_deform_pool_gpu",
     "test_deformable_resnet_gpu",

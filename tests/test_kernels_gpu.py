@@ -214,6 +214,35 @@ def test_maxpool(dtype, k, s, p, relu_input):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k,s,p,shape", [((2, 2), (2, 2), (0, 0), (5, 128, 16, 64)), ((2, 2), (2, 2), (0, 0), (3, 64, 10, 14)),
+                                         ((2, 2), (2, 2), (0, 0), (2, 64, 9, 13)),      # odd sizes: uncovered last row / column
+                                         ((2, 2), (2, 1), (0, 1), (4, 256, 8, 32)), ((3, 3), (2, 2), (1, 1), (2, 64, 17, 31))])
+def test_maxpool_round5_kernels_are_bit_identical(dtype, k, s, p, shape):
+    """mr_tuning.pool_fixed: the fixed-geometry forward (packed code store) and the pooled-element-organised 2x2 / stride 2
+    backward give the same bits -- values, arg-max codes (through the gradient) and ReLU masking -- as the round-4 kernels."""
+    from megreader_amd import _lib
+    mr.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(5)
+    x = torch.relu(torch.randn(*shape, generator=g)).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+    out = {}
+    for mode in (0, 1):
+        old = _lib.set_tuning(pool_fixed=mode)
+        try:
+            res = []
+            for relu_input in (False, True):
+                xd = x.clone().requires_grad_(True)
+                y = F.max_pool2d(xd, k, s, p, relu_input=relu_input)
+                gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(9)).to(dtype).to(DEV)
+                y.backward(gy.contiguous(memory_format=torch.channels_last))
+                res += [y.detach().float().cpu(), xd.grad.float().cpu()]
+            out[mode] = res
+        finally:
+            _lib.set_tuning(**old)
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_linear(dtype):
     mr.set_compute_dtype(dtype)
     g = torch.Generator().manual_seed(3)
