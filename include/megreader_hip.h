@@ -89,7 +89,11 @@ typedef struct mr_tuning {
   int pool_fixed;    /* 1 (default): max-pool forward with the window geometry as template constants (one packed store for the
                         arg-max codes) and the pooled-element-organised backward of the 2x2 / stride 2 pool (round 5); 0: the
                         round-4 kernels (bit-identical results; A/B) */
-  int reserved[3];   /* zero */
+  int ctc_linear;    /* 1 (default): 1-D CTC recursions in the scaled linear domain (float64 products with exact power-of-two
+                        rescaling, emission table in LDS) when the table fits; 0: the log-domain kernels (float64 log-sum-exp
+                        per state and step).  alpha / beta buffers change meaning with it: the same value must be in force for
+                        mr_ctc_fwd and the mr_ctc_bwd that consumes its buffers */
+  int reserved[2];   /* zero */
 } mr_tuning;
 int mr_tuning_get(mr_tuning* out);
 int mr_tuning_defaults(mr_tuning* out);
@@ -329,7 +333,9 @@ int mr_ctc_fwd(int dtype, const void* logits, int ldl, const void* targets, int 
 /* log_probs_f64 (nullable, f64 [T][N][C]): the same log-probabilities widened to float64 -- what the reference returns as
  * `pred` (decoders/crnn.py:96 `log_softmax(pred, dim=2).to(torch.float64)`), written by the same kernel.
  * mr_ctc_bwd writes the padding columns C .. ldg-1 of grad_logits as zeros.
- * alpha, beta: f64 [N][T][2S+1].  beta may be null in mr_ctc_fwd when no gradient is wanted (the beta recursion runs
+ * alpha, beta: f64 [N][T][2S+1] -- scratch that travels from mr_ctc_fwd to mr_ctc_bwd: the log-domain forward / backward
+ * variables (mr_tuning.ctc_linear = 0, or an emission table beyond 64 KB of LDS) or, by default, their scaled linear-domain
+ * counterparts (alpha rescaled per step by exact powers of two; beta without the emission of its own step).  beta may be null in mr_ctc_fwd when no gradient is wanted (the beta recursion runs
  * concurrently with alpha on other wavefronts of the same workgroup, so storing it costs no extra latency and makes
  * the gradient kernel independent per (t, n) row). */
 int mr_ctc_bwd(int dtype, const float* log_probs, const double* alpha, const double* beta, const double* nll,

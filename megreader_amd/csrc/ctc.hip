@@ -142,6 +142,233 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const T* __restrict__ logi
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 5: the same recursions in the SCALED LINEAR domain (mr_tuning.ctc_linear, default).  The log-domain kernel above spends
+// its 33-step dependency chain on float64 log-sum-exps (3 exp + 1 log per state and step: ~1.5 us per step, 50 us per launch at
+// T = 33 -- independent of the batch size, i.e. 4 % of the 32-crops-per-GPU step).  Here a step is two adds and a multiply:
+//   alpha_t[s] = (alpha_{t-1}[s] + alpha_{t-1}[s-1] + [skip] alpha_{t-1}[s-2]) * p_t(l'_s) * 2^-e,   p = exp(lp) in float64,
+// e = exponent of max_s alpha_{t-1}[s] (an exact power-of-two rescale, so no rounding is added; the exponents are summed as
+// integers and enter nll once, as E ln 2).  All T x (2L+1) emission probabilities are computed up front, in parallel, into an LDS
+// table.  The backward variable is stored WITHOUT the emission of its own step (B'_t = the bracket above, for beta): the
+// occupancy of state s at time t is then alpha_t[s] B'_t[s] / sum_s' alpha_t[s'] B'_t[s'] -- no division by p, no nll, no exp
+// in the gradient kernel.  float64 throughout: nll and the gradient agree with the log-domain kernel to ~1e-13.
+// Range: within one time step, states more than ~1e-308 below the largest one flush to zero (the log domain keeps them).  That
+// needs log-probability gaps of ~700 between competing paths at one step -- logits hundreds apart; such a row gets occupancy 0.
+// Buffers: alpha_out[n][t][s] = scaled alpha, beta_out[n][t][s] = scaled B' (same [N][T][2S+1] doubles as the log-domain pair).
+__device__ __forceinline__ double pow2_neg(int e) {   // 2^-e, -1022 <= -e <= 1023
+  return __longlong_as_double((long long)(1023 - e) << 52);
+}
+__device__ __forceinline__ int hi_word(double v) { return (int)(__double_as_longlong(v) >> 32); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_fwd_lin_kernel(const T* __restrict__ logits, int ldl, const void* targets,
+                                                          int tg64, const void* in_len, const void* tg_len, int len64,
+                                                          int Tn, int N, int C, int S, int blank,
+                                                          float* __restrict__ lp_out, double* __restrict__ alpha_out,
+                                                          double* __restrict__ beta_out, double* __restrict__ nll_out,
+                                                          double* __restrict__ lp64_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int SPmax = 2 * S + 1;
+  double* ptab = (double*)smem_raw;          // [Tn][SPmax] emission probabilities of the extended target
+  double* al0 = ptab + (size_t)Tn * SPmax;   // [SPmax] x 4: alpha / beta double buffers
+  double* al1 = al0 + SPmax;
+  double* be0 = al1 + SPmax;
+  double* be1 = be0 + SPmax;
+  int* lab = (int*)(be1 + SPmax);            // [SPmax]
+  int* wmax = lab + SPmax;                   // [2 parities][2 halves][2 waves]: hi words of the per-wave maxima
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Tb = min((int)load_idx(in_len, b, len64), Tn);
+  int L = (int)load_idx(tg_len, b, len64);
+  if (L > S) L = S;
+  const int SP = 2 * L + 1;
+
+  // 1) log-softmax rows t = wave, wave+4, ... in f32 (identical to ctc_fwd_kernel)
+  for (int t = wave; t < Tn; t += 4) {
+    const T* row = logits + ((long long)t * N + b) * ldl;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, to_f32(row[c]));
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int c = lane; c < C; c += 64) se += expf(to_f32(row[c]) - mx);
+    se = wave_sum(se);
+    const float lz = mx + logf(se);
+    float* orow = lp_out + ((long long)t * N + b) * C;
+    for (int c = lane; c < C; c += 64) orow[c] = to_f32(row[c]) - lz;
+    if (lp64_out) {
+      double* orow64 = lp64_out + ((long long)t * N + b) * C;
+      for (int c = lane; c < C; c += 64) orow64[c] = (double)(to_f32(row[c]) - lz);
+    }
+  }
+  for (int s = tid; s < SPmax; s += 256) lab[s] = (s < SP) ? ext_label(targets, tg64, (long long)b * S, s, blank) : blank;
+  if (tid < 8) wmax[tid] = 0;
+  __syncthreads();
+  // 1b) emission table: p[t][s] = exp(lp[t][l'_s]) in float64, all (t, s) in parallel
+  for (int idx = tid; idx < Tn * SP; idx += 256) {
+    const int t = idx / SP, s = idx - t * SP;
+    ptab[(size_t)t * SPmax + s] = exp((double)lp_out[((long long)t * N + b) * C + lab[s]]);
+  }
+  __syncthreads();
+
+  // 2) alpha (threads 0..127) and beta (threads 128..255), one time step per barrier
+  const bool beta_half = tid >= 128;
+  const int half = beta_half ? 1 : 0, hw = wave & 1;
+  const int htid = tid & 127;
+  double* prev = beta_half ? be0 : al0;
+  double* cur = beta_half ? be1 : al1;
+  double* aout = alpha_out + (long long)b * Tn * SPmax;
+  double* bout = beta_out ? beta_out + (long long)b * Tn * SPmax : nullptr;
+  int e_prev = 0;          // rescale exponent taken from the previous step's maximum
+  long long Esum = 0;      // alpha half: sum of the exponents applied so far
+  long long E_last = 0;    // ... as of step Tb - 1
+  for (int i = 0; i < Tn; ++i) {
+    int mhi = 0;
+    const double sc = pow2_neg(e_prev);
+    if (!beta_half) {
+      const int t = i;
+      const double* prow = ptab + (size_t)t * SPmax;
+      for (int s = htid; s < SPmax; s += 128) {
+        double a = 0.0;
+        if (t == 0) {
+          if (Tb > 0) {
+            if (s == 0) a = prow[0];
+            else if (s == 1 && L > 0) a = prow[1];
+          }
+        } else if (t < Tb && s < SP) {
+          double v = prev[s];
+          if (s > 0) v += prev[s - 1];
+          if (s > 1 && lab[s] != lab[s - 2]) v += prev[s - 2];
+          a = v * prow[s] * sc;
+        }
+        cur[s] = a;
+        aout[(long long)t * SPmax + s] = a;
+        mhi = max(mhi, hi_word(a));
+      }
+      if (t > 0 && t < Tb) Esum += e_prev;
+      if (t == Tb - 1) E_last = Esum;
+    } else if (bout && i < Tb) {
+      const int t = Tb - 1 - i;
+      const double* prow = ptab + (size_t)t * SPmax;
+      for (int s = htid; s < SPmax; s += 128) {
+        double bv = 0.0, bp = 0.0;
+        if (s < SP) {
+          if (i == 0) {
+            if (s == SP - 1 || s == SP - 2) { bp = 1.0; bv = prow[s]; }
+          } else {
+            double v = prev[s];
+            if (s + 1 < SP) v += prev[s + 1];
+            if (s + 2 < SP && lab[s] != lab[s + 2]) v += prev[s + 2];
+            bp = v * sc;
+            bv = bp * prow[s];
+          }
+        }
+        cur[s] = bv;
+        bout[(long long)t * SPmax + s] = bp;
+        mhi = max(mhi, hi_word(bv));
+      }
+    }
+    // exponent of this step's maximum (non-negative doubles order like their high words) -> next step's rescale
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mhi = max(mhi, __shfl_xor(mhi, o, 64));
+    if (lane == 0) wmax[(i & 1) * 4 + half * 2 + hw] = mhi;
+    __syncthreads();
+    const int m2 = max(wmax[(i & 1) * 4 + half * 2], wmax[(i & 1) * 4 + half * 2 + 1]);
+    const int be = (m2 >> 20) & 0x7ff;
+    e_prev = be == 0 ? 0 : be - 1023;
+    double* tmp = prev; prev = cur; cur = tmp;
+  }
+  if (tid == 0) {
+    double nll = INFINITY;
+    if (Tb > 0) {
+      const double* last = aout + (long long)(Tb - 1) * SPmax;
+      const double tot = last[SP - 1] + (SP > 1 ? last[SP - 2] : 0.0);
+      if (tot > 0.0) nll = -(log(tot) + (double)E_last * 0.6931471805599453094);
+    }
+    nll_out[b] = nll;
+  }
+}
+
+// gradient from the scaled pair: occupancy[t, c] = sum_{s: l'_s = c} alpha_t[s] B'_t[s] / sum_s alpha_t[s] B'_t[s]
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_grad_lin_kernel(const float* __restrict__ lp, const double* __restrict__ alpha,
+                                                           const double* __restrict__ beta,
+                                                           const double* __restrict__ nll_in, const void* targets,
+                                                           int tg64, const void* in_len, const void* tg_len, int len64,
+                                                           const double* __restrict__ grad_out, int Tn, int N, int C,
+                                                           int S, int blank, int zero_infinity, T* __restrict__ grad,
+                                                           int ldg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int SPmax = 2 * S + 1;
+  double* ab_all = (double*)smem_raw;                       // [4][SPmax] alpha * B'
+  int* lab = (int*)(ab_all + 4 * SPmax);                    // [SPmax]
+  int* owner = lab + SPmax;                                 // [SPmax] 1 if first state carrying its label
+  float* row_all = (float*)(owner + SPmax + (SPmax & 1));   // [4][C]
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = blockIdx.y * 4 + wave;
+  const int Tb = min((int)load_idx(in_len, b, len64), Tn);
+  int L = (int)load_idx(tg_len, b, len64);
+  if (L > S) L = S;
+  const int SP = 2 * L + 1;
+  const double nll = nll_in[b];
+  const bool per_sample = (zero_infinity & 2) != 0;
+  const bool dead = ((zero_infinity & 1) && nll == INFINITY) || Tb <= 0;
+  const double k = dead ? 0.0 : (per_sample ? grad_out[b] : grad_out[0] / (double)N) / (double)(L < 1 ? 1 : L);
+  const bool valid = t < Tn;
+  const bool active = valid && t < Tb;
+  double* ab = ab_all + wave * SPmax;
+  float* rowbuf = row_all + wave * C;
+
+  for (int s = tid; s < SPmax; s += 256) lab[s] = (s < SP) ? ext_label(targets, tg64, (long long)b * S, s, blank) : blank;
+  __syncthreads();
+  for (int s = tid; s < SPmax; s += 256) {
+    int own = 0;
+    if (s < SP) {
+      own = 1;
+      const int l = lab[s];
+      for (int s2 = (s & 1); s2 < s; s2 += 2)
+        if (lab[s2] == l) { own = 0; break; }
+    }
+    owner[s] = own;
+  }
+  if (valid && !active)
+    for (int c = lane; c < C; c += 64) grad[((long long)t * N + b) * ldg + c] = from_f32<T>(0.f);
+  if (valid)
+    for (int c = C + lane; c < ldg; c += 64) grad[((long long)t * N + b) * ldg + c] = from_f32<T>(0.f);
+  const float* lrow = lp + ((long long)(valid ? t : 0) * N + b) * C;
+  double total = 0.0;
+  if (active) {
+    const double* arow = alpha + ((long long)b * Tn + t) * SPmax;
+    const double* brow = beta + ((long long)b * Tn + t) * SPmax;
+    for (int s = lane; s < SPmax; s += 64) {
+      const double r = (s < SP) ? arow[s] * brow[s] : 0.0;
+      ab[s] = r;
+      total += r;
+    }
+    for (int c = lane; c < C; c += 64) rowbuf[c] = (float)exp((double)lrow[c]);
+  }
+  total = wave_sum(total);
+  __syncthreads();
+  if (active && !dead && total > 0.0) {
+    const double inv = 1.0 / total;
+    for (int s = lane; s < SP; s += 64) {
+      if (!owner[s]) continue;
+      const int l = lab[s];
+      double g = ab[s];
+      for (int s2 = s + 2; s2 < SP; s2 += 2)
+        if (lab[s2] == l) g += ab[s2];
+      if (g != 0.0) rowbuf[l] -= (float)(g * inv);
+    }
+  }
+  __syncthreads();
+  if (active) {
+    T* grow = grad + ((long long)t * N + b) * ldg;
+    for (int c = lane; c < C; c += 64) grow[c] = from_f32<T>((float)((double)rowbuf[c] * k));
+  }
+}
+
 // loss = mean_b( zero_inf(nll_b) / max(L_b,1) )   (reduction='mean', zero_infinity=True)
 __global__ void ctc_reduce_kernel(const double* __restrict__ nll, const void* tg_len, int len64, int N, int S,
                                   int zero_infinity, double* __restrict__ loss) {
@@ -263,6 +490,15 @@ __global__ void softmax_nc1t_kernel(const T* __restrict__ logits, int ldl, float
   for (int c = lane; c < C; c += 64) out[((long long)n * C + c) * Tn + t] = expf(to_f32(src[c]) - mx) * inv;
 }
 
+// LDS of ctc_fwd_lin_kernel: emission table [T][2S+1] + four state vectors (f64), labels and the 8 reduction slots (int)
+static size_t ctc_lin_smem(int T, int S) {
+  const size_t sp = (size_t)(2 * S + 1);
+  return ((size_t)T * sp + 4 * sp) * sizeof(double) + (sp + 8) * sizeof(int) + 16;
+}
+// The scaled linear-domain kernels serve a problem when its emission table fits in LDS (CRNN: T = 33, S = 25..32: 17-22 KB);
+// longer sequences keep the log-domain kernels.  mr_ctc_fwd and mr_ctc_bwd must see the same mr_tuning.ctc_linear.
+static bool ctc_use_linear(int T, int S) { return MR_TUNE(ctc_linear) != 0 && ctc_lin_smem(T, S) <= 64 * 1024; }
+
 }  // namespace mr
 
 using namespace mr;
@@ -277,6 +513,23 @@ int mr_ctc_fwd(int dtype, const void* logits, int ldl, const void* targets, int 
   MR_CHECK_ARG(blank >= 0 && blank < C, "mr_ctc_fwd: blank %d out of range", blank);
   const size_t smem = (size_t)(2 * S + 1) * (4 * sizeof(double) + sizeof(int)) + 16;
   MR_CHECK_ARG(smem <= 64 * 1024, "mr_ctc_fwd: target too long for LDS (S=%d)", S);
+  if (ctc_use_linear(T, S)) {   // scaled linear-domain recursion (mr_tuning.ctc_linear); mr_ctc_bwd makes the same choice
+    const size_t smem_lin = ctc_lin_smem(T, S);
+    if (dtype == MR_F32)
+      hipLaunchKernelGGL((ctc_fwd_lin_kernel<float>), dim3(N), dim3(256), smem_lin, stream, (const float*)logits, ldl, targets,
+                         targets_i64, input_lengths, target_lengths, lengths_i64, T, N, C, S, blank, log_probs, alpha, beta, nll,
+                         log_probs_f64);
+    else if (dtype == MR_BF16)
+      hipLaunchKernelGGL((ctc_fwd_lin_kernel<bf16_t>), dim3(N), dim3(256), smem_lin, stream, (const bf16_t*)logits, ldl,
+                         targets, targets_i64, input_lengths, target_lengths, lengths_i64, T, N, C, S, blank, log_probs, alpha,
+                         beta, nll, log_probs_f64);
+    else { mr::set_error("mr_ctc_fwd: bad dtype %d", dtype); return MR_ERR_DTYPE; }
+    if (loss)
+      hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(256), 0, stream, (const double*)nll, target_lengths,
+                         lengths_i64, N, S, zero_infinity, loss);
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+  }
   if (dtype == MR_F32)
     hipLaunchKernelGGL((ctc_fwd_kernel<float>), dim3(N), dim3(256), smem, stream, (const float*)logits, ldl, targets,
                        targets_i64, input_lengths, target_lengths, lengths_i64, T, N, C, S, blank, log_probs, alpha,
@@ -304,6 +557,19 @@ int mr_ctc_bwd(int dtype, const float* log_probs, const double* alpha, const dou
   const size_t smem = (size_t)SP * (4 * sizeof(double) + 2 * sizeof(int)) + 8 + (size_t)4 * C * sizeof(float) + 16;
   MR_CHECK_ARG(smem <= 64 * 1024, "mr_ctc_bwd: alphabet/target too large for LDS (C=%d S=%d)", C, S);
   const dim3 grid(N, cdiv(T, 4));
+  if (ctc_use_linear(T, S)) {   // alpha / beta hold the scaled linear-domain pair (see mr_ctc_fwd)
+    if (dtype == MR_F32)
+      hipLaunchKernelGGL((ctc_grad_lin_kernel<float>), grid, dim3(256), smem, stream, log_probs, alpha, beta, nll, targets,
+                         targets_i64, input_lengths, target_lengths, lengths_i64, grad_out, T, N, C, S, blank,
+                         zero_infinity, (float*)grad_logits, ldg);
+    else if (dtype == MR_BF16)
+      hipLaunchKernelGGL((ctc_grad_lin_kernel<bf16_t>), grid, dim3(256), smem, stream, log_probs, alpha, beta, nll, targets,
+                         targets_i64, input_lengths, target_lengths, lengths_i64, grad_out, T, N, C, S, blank,
+                         zero_infinity, (bf16_t*)grad_logits, ldg);
+    else { mr::set_error("mr_ctc_bwd: bad dtype %d", dtype); return MR_ERR_DTYPE; }
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+  }
   if (dtype == MR_F32)
     hipLaunchKernelGGL((ctc_grad_kernel<float>), grid, dim3(256), smem, stream, log_probs, alpha, beta, nll, targets,
                        targets_i64, input_lengths, target_lengths, lengths_i64, grad_out, T, N, C, S, blank,

@@ -1008,10 +1008,10 @@ class LinearFn(Function):
             elif (w_sink is not None and (gb is None or b_sink is not None) and not _Fan.enabled and
                   dtype == torch.bfloat16 and _TnDefer.begin()):
                 # sunk gradients: recorded for a grouped launch (_TnDefer); the flush reports the parameters ready
+                if dx_fn is not None:
+                    dx_fn()
                 call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, NA, K, 0, ptr(gb))
                 if _TnDefer.end((gp, x2), [weight_p] + ([bias_p] if want_db else [])):
-                    if dx_fn is not None:
-                        dx_fn()
                     return dx, None, None
             else:   # input-gradient and weight-gradient GEMMs are independent: side by side (_Fan)
                 _Fan.run([dx_fn, lambda: call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, NA, K, 0,
@@ -1270,6 +1270,7 @@ class CTCLossFn(Function):
         ctx.dtype = dtype
         out_lp = lp64 if want_f64 else lp
         ctx.mark_non_differentiable(out_lp)
+        ctx.set_materialize_grads(False)     # no zero-filled [T, N, C] gradient for the log-probabilities nobody differentiates
         if int(zero_infinity) & 2:   # per-sample losses nll_b / L_b (reference decoders/ctc_loss.py:118-122)
             return nll / target_lengths.to(torch.float64), out_lp
         return loss, out_lp
@@ -1281,6 +1282,8 @@ class CTCLossFn(Function):
         dtype = ctx.dtype
         v = vec_of(dtype)
         Cp = _ceil_to(C, v)
+        if gloss is None:
+            return None, None, None, None, None, None, None
         g = gloss.to(torch.float64).contiguous()
         grad = torch.empty((T, N, Cp), dtype=dtype, device=lp.device)    # the kernel writes the padding columns as zeros
         call("mr_ctc_bwd", dtype_code(dtype), ptr(lp), ptr(alpha), ptr(beta), ptr(nll), ptr(targets), t64,

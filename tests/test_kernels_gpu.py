@@ -388,6 +388,43 @@ def test_ctc_matches_torch_and_oracle(dtype):
     assert float((torch.from_numpy(o['grad_logits']).float() - xd.grad.float().cpu()).abs().max()) < gtol
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("scale", [1.0, 8.0])
+def test_ctc_scaled_linear_domain_equals_log_domain(dtype, scale):
+    """mr_tuning.ctc_linear: the scaled linear-domain recursions (round 5) against the float64 log-sum-exp kernels they
+    replace -- ragged input lengths, an empty target, repeated labels, an infeasible target (zero_infinity), peaked logits."""
+    from megreader_amd import _lib
+    g = torch.Generator().manual_seed(29)
+    T, N, C, S = 33, 9, 38, 25
+    logits = (torch.randn(T, N, C, generator=g) * scale).to(dtype)
+    lengths = torch.tensor([3, 1, 6, 0, 10, 5, 25, 12, 2])
+    in_len = torch.tensor([33, 20, 33, 5, 12, 33, 33, 30, 1])
+    targets = torch.zeros(N, S, dtype=torch.int64)
+    for i, L in enumerate(lengths.tolist()):
+        targets[i, :L] = torch.randint(1, C, (L,), generator=g)
+    targets[2, 1] = targets[2, 0]
+    targets[4, :10] = 5                        # 10 repeats in 12 frames: infeasible
+    out = {}
+    for mode in (0, 1):
+        old = _lib.set_tuning(ctc_linear=mode)
+        try:
+            xd = logits.to(DEV).requires_grad_(True)
+            loss, logp = F.ctc_loss_logits(xd, targets.to(DEV), in_len.to(DEV), lengths.to(DEV))
+            loss.backward()
+            per, _ = F.ctc_loss_logits(xd.detach(), targets.to(DEV), in_len.to(DEV), lengths.to(DEV), per_sample=True,
+                                       zero_infinity=False)
+            out[mode] = (float(loss), xd.grad.float().cpu().clone(), logp.cpu().clone(), per.cpu().clone())
+        finally:
+            _lib.set_tuning(**old)
+    assert abs(out[0][0] - out[1][0]) <= 1e-11 * max(1.0, abs(out[0][0]))
+    assert torch.equal(out[0][2], out[1][2])
+    assert torch.equal(torch.isinf(out[0][3]), torch.isinf(out[1][3]))
+    fin = ~torch.isinf(out[0][3])
+    assert float((out[0][3][fin] - out[1][3][fin]).abs().max()) < 1e-10
+    # gradients pass through one float32 / bfloat16 rounding: identical up to that rounding
+    assert float((out[0][1] - out[1][1]).abs().max()) <= (1e-9 if dtype == torch.float32 else 1e-4)
+
+
 def test_ctc_full_size_properties():
     """BASELINE size (T=33, N=256, C=38): occupancy rows of the gradient sum to zero, loss finite and positive."""
     g = torch.Generator().manual_seed(1)
