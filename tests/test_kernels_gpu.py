@@ -422,7 +422,7 @@ def test_ctc_scaled_linear_domain_equals_log_domain(dtype, scale):
     fin = ~torch.isinf(out[0][3])
     assert float((out[0][3][fin] - out[1][3][fin]).abs().max()) < 1e-10
     # gradients pass through one float32 / bfloat16 rounding: identical up to that rounding
-    assert float((out[0][1] - out[1][1]).abs().max()) <= (1e-9 if dtype == torch.float32 else 1e-4)
+    assert float((out[0][1] - out[1][1]).abs().max()) <= (3e-8 if dtype == torch.float32 else 1e-4)
 
 
 def test_ctc_full_size_properties():
