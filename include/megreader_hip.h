@@ -49,7 +49,7 @@ typedef struct mr_tuning {
   int nt_deep;       /* pipeline depth of the 4-wave direct-to-LDS NT kernel: 1 (default) = launches with at most ~1.5 workgroups
                         per CU and >= 8 k-steps (bf16) run with 4 LDS stage buffers and 3 k-steps of LDS-DMA in flight across raw
                         barriers; 0 = always the 2-buffer loop; 2 = always the 4-buffer loop.  Same results bit for bit */
-  int nt_big;        /* 8-wave big-tile NT kernels (256x256 / 272x256 / 288x128): 0 automatic, -1 never, 1..7 forced variants */
+  int nt_big;        /* 8-wave big-tile NT kernels (256x256 / 272x256 / 288x128): 0 automatic, -1 never, 1..13 forced variants */
   int nt_p8;         /* 1 = phased-schedule 256x256 NT kernel (igemm_p8.h) for the big-tile launches, 0 (default) = plain */
   int nt_force_bm;   /* force one 4-wave NT tile shape: bm in {128, 96, 64} with */
   int nt_force_bn;   /* bn in {128, 64}; bm = 0 (default) = the cost model */
@@ -93,7 +93,9 @@ typedef struct mr_tuning {
                         rescaling, emission table in LDS) when the table fits; 0: the log-domain kernels (float64 log-sum-exp
                         per state and step).  alpha / beta buffers change meaning with it: the same value must be in force for
                         mr_ctc_fwd and the mr_ctc_bwd that consumes its buffers */
-  int reserved[2];   /* zero */
+  int nt_wide8;      /* 8-wave workgroups (two per CU) on the 128x128 / 128x64 NT tile shapes instead of 4-wave ones: 0 never,
+                        1 launches of at least 4 x CUs tiles (many rounds of short tiles), 2 more than one round, 3 always */
+  int reserved[1];   /* zero */
 } mr_tuning;
 int mr_tuning_get(mr_tuning* out);
 int mr_tuning_defaults(mr_tuning* out);
@@ -125,6 +127,10 @@ int mr_nt_kernel_code(int dtype, int M, int N, int K, int cg);
  * fused into the same pass over A). */
 int mr_gemm_tn(int dtype, const void* A, long long lda, const void* B, long long ldb, float* C, int ldc, int P,
                int NA, int NB, int row_perm_h, float* colsum, hipStream_t stream);
+/* the same with a second destination for the column sums (colsum2, nullable; ignored when colsum is null): b_ih and b_hh of an
+ * LSTM direction (decoders/crnn.py:13 nn.LSTM keeps both) receive the same gradient from one launch */
+int mr_gemm_tn2(int dtype, const void* A, long long lda, const void* B, long long ldb, float* C, int ldc, int P,
+                int NA, int NB, int row_perm_h, float* colsum, float* colsum2, hipStream_t stream);
 
 /* Deferred, grouped weight-gradient launches (round 5).  The weight gradients of small layers -- the 1x1 / strided layers of a
  * ResNet at batch 32 (backbones/resnet.py:113-181), the LSTM / Linear layers of the CRNN head (decoders/crnn.py:8-24) -- are GEMMs

@@ -25,6 +25,7 @@ _CODES = {"p": _P, "i": _I, "l": _L, "f": _F, "d": _D, "s": _P}
 SIGNATURES = {
     "mr_gemm_nt": "iplpiplpiiiis",
     "mr_gemm_tn": "iplplpiiiiips",
+    "mr_gemm_tn2": "iplplpiiiiipps",
     "mr_conv2d_fwd": "ipppp" + "i" * 18 + "s",
     "mr_conv2d_fwd_stats": "ippppp" + "i" * 16 + "s",
     "mr_bn_stats": "ipplis",
@@ -116,12 +117,12 @@ _lib = None
 
 TUNING_FIELDS = ("nt_variant", "nt_deep", "nt_big", "nt_p8", "nt_force_bm", "nt_force_bn", "gemm_skinny", "tn_big", "tn_buf",
                  "tn_taps", "tn_taps_group", "tn_group", "tn_fin", "tn_taps_fin", "tn_taps_w8", "tn_model", "tn_splits",
-                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth", "nt_big_min_k", "tn_taps_min_p", "tn_defer", "pool_fixed", "ctc_linear")
+                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth", "nt_big_min_k", "tn_taps_min_p", "tn_defer", "pool_fixed", "ctc_linear", "nt_wide8")
 
 
 class Tuning(ctypes.Structure):
     """struct mr_tuning (include/megreader_hip.h): the library's only process-wide switches."""
-    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 2)]
+    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 1)]
 
 
 def get_tuning():
@@ -163,7 +164,7 @@ def _install_setter_shims(lib):
         return setter
     lib.mr_set_nt_variant = one("nt_variant", lambda v: v in (1, 2))
     lib.mr_set_nt_deep = one("nt_deep", lambda v: 0 <= v <= 2)
-    lib.mr_set_nt_big = one("nt_big", lambda v: -1 <= v <= 7)
+    lib.mr_set_nt_big = one("nt_big", lambda v: -1 <= v <= 13)
     lib.mr_set_nt_p8 = one("nt_p8")
     lib.mr_set_gemm_skinny = lambda v: one("gemm_skinny")(1 if v else 0)
     lib.mr_set_tn_big = one("tn_big", lambda v: -1 <= v <= 2)
@@ -321,7 +322,7 @@ class KernelTimer(object):
 TIMER = None  # set to a KernelTimer to enable
 
 _TN_WS = {}
-_TN_WS_CALLS = frozenset(("mr_gemm_tn", "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab"))
+_TN_WS_CALLS = frozenset(("mr_gemm_tn", "mr_gemm_tn2", "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab"))
 
 
 def ensure_tn_workspace(device=None):

@@ -382,6 +382,12 @@ static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long l
       if (big == 5) return launch_nt_big<T, 2, 4, 5, 2, AMODE>(a, g, C, ldc, bias, relu, stream);   // 160x128, 8 waves (2x4)
       if (big == 6) return launch_nt_big<T, 2, 4, 8, 2, AMODE>(a, g, C, ldc, bias, relu, stream);   // 256x128, 8 waves (2x4)
       if (big == 7) return launch_nt_big<T, 2, 4, 9, 2, AMODE>(a, g, C, ldc, bias, relu, stream);   // 288x128, 8 waves (2x4)
+      if (big == 8) return launch_nt_big<T, 2, 4, 4, 2, AMODE>(a, g, C, ldc, bias, relu, stream);   // 128x128, 8 waves (2x4)
+      if (big == 9) return launch_nt_big<T, 2, 4, 6, 2, AMODE>(a, g, C, ldc, bias, relu, stream);   // 192x128, 8 waves (2x4)
+      if (big == 10) return launch_nt_big<T, 4, 2, 2, 2, AMODE>(a, g, C, ldc, bias, relu, stream);  // 128x64, 8 waves (4x2)
+      if (big == 11) return launch_nt_big<T, 4, 2, 3, 2, AMODE>(a, g, C, ldc, bias, relu, stream);  // 192x64, 8 waves (4x2)
+      if (big == 12) return launch_nt_big<T, 4, 2, 4, 2, AMODE>(a, g, C, ldc, bias, relu, stream);  // 256x64, 8 waves (4x2)
+      if (big == 13) return launch_nt_big<T, 2, 4, 3, 2, AMODE>(a, g, C, ldc, bias, relu, stream);  // 96x128, 8 waves (2x4)
       // Head / tail: rows are independent, so a problem whose 256x256 tile count is a few tiles over whole rounds of
       // the CUs (33792 x 512: 264 tiles on 256 CUs) is cut into a head that is EXACTLY whole rounds of big tiles and
       // a tail of the remaining rows for the 4-wave kernel.  No cross-workgroup reduction, two launches.
@@ -401,6 +407,21 @@ static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long l
         MR_NT_TAIL(128, 128) MR_NT_TAIL(128, 64) MR_NT_TAIL(96, 128) MR_NT_TAIL(96, 64) MR_NT_TAIL(64, 128)
         MR_NT_TAIL(64, 64)
 #undef MR_NT_TAIL
+      }
+      // 8-wave workgroups on the 4-wave tile shapes (mr_tuning.nt_wide8): a 128x128 (2x4 waves of 64x32) or 128x64 (4x2 waves
+      // of 32x32) tile with TWO 8-wave workgroups per CU instead of two 4-wave ones -- twice the waves to hide the prologue /
+      // first-operand latency / epilogue of launches that are many rounds of short-K tiles (CRNN conv1: 2048 tiles, K = 576:
+      // forward 98.7 -> 80.1 us, dgrad 77.8 -> 72.0 us in tools/microbench_conv.py; profiles/r05_conv_tile_sweep.txt).
+      // Not for launches the 4-buffer loop serves (at most one round of workgroups).
+      const int w8 = MR_TUNE(nt_wide8);
+      if (w8 > 0 && a.m_begin == 0) {
+        const TileChoice tw = nt_tile(a.M, a.N);
+        const long long tiles = (long long)cdiv(a.M, tw.bm) * cdiv(a.N, tw.bn);
+        const long long min_tiles = w8 == 1 ? 4ll * num_cus() : (w8 == 2 ? (long long)num_cus() + 1 : 0);
+        if (tiles >= min_tiles) {
+          if (tw.bm == 128 && tw.bn == 128) return launch_nt_big<T, 2, 4, 4, 2, AMODE>(a, g, C, ldc, bias, relu, stream);
+          if (tw.bm == 128 && tw.bn == 64) return launch_nt_big<T, 4, 2, 2, 2, AMODE>(a, g, C, ldc, bias, relu, stream);
+        }
       }
     }
   }
@@ -760,6 +781,13 @@ int mr_tn_flush(hipStream_t stream) { return tn_flush(stream); }
 
 int mr_gemm_tn(int dtype, const void* A, long long lda, const void* B, long long ldb, float* C, int ldc, int P,
                int NA, int NB, int row_perm_h, float* colsum, hipStream_t stream) {
+  return mr_gemm_tn2(dtype, A, lda, B, ldb, C, ldc, P, NA, NB, row_perm_h, colsum, nullptr, stream);
+}
+
+// mr_gemm_tn with a second destination for the column sums (both receive += sum_p A[p, :]): the two bias vectors of an LSTM
+// direction (b_ih, b_hh: nn.LSTM keeps two, their gradients are equal) take them straight from the weight-gradient launch.
+int mr_gemm_tn2(int dtype, const void* A, long long lda, const void* B, long long ldb, float* C, int ldc, int P,
+                int NA, int NB, int row_perm_h, float* colsum, float* colsum2, hipStream_t stream) {
   MR_CHECK_ARG(dtype == MR_F32 || dtype == MR_BF16, "mr_gemm_tn: bad dtype %d", dtype);
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(P > 0 && NA > 0 && NB > 0, "mr_gemm_tn: bad shape P=%d NA=%d NB=%d", P, NA, NB);
@@ -773,6 +801,7 @@ int mr_gemm_tn(int dtype, const void* A, long long lda, const void* B, long long
   TnArgs a;
   a.A = A; a.B = B; a.C = C; a.P = P; a.NA = NA; a.NB = NB; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.p_chunk = 0; a.row_perm_h = row_perm_h; a.colsum = colsum; a.rowtab = nullptr; a.grp = 1; a.ws = nullptr;
+  a.colsum2 = colsum ? colsum2 : nullptr;
   ConvGeom g = {};
   if (dtype == MR_F32) return launch_tn<float, 0>(a, g, stream);
   return launch_tn<bf16_t, 0>(a, g, stream);

@@ -1181,6 +1181,7 @@ struct TnArgs {
   int p_chunk;  // rows of P per split (multiple of the p-step)
   int row_perm_h;
   float* colsum;  // optional [NA]: += sum_p A[p, na] (bias gradient), accumulated by the tile_b == 0 blocks
+  float* colsum2 = nullptr;  // optional second destination of the same column sums (an LSTM layer's b_ih and b_hh share theirs)
   const int2* rowtab;  // BMODE 2: per output pixel {element offset of its window's top-left input pixel, tap mask}
   // igemm_tn_glds_kernel only -- in-launch reduction of the split partials (see tn_taps.hip, TapArgs.grp): groups of
   // `grp` consecutive splits publish their 64 KB accumulator slabs (sc1) and take a ticket; the last arriver sums the
@@ -1424,6 +1425,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TnArgs a, ConvGeom g) {
         row = blk * h4 + (rin & 3) * a.row_perm_h + (rin >> 2);
       }
       atomicAdd(a.colsum + row, (float)sum);
+      if (a.colsum2) atomicAdd(a.colsum2 + row, (float)sum);
     }
   }
 
@@ -1710,6 +1712,7 @@ __device__ __forceinline__ void tn_glds_body(const TnArgs& a, const ConvGeom& g,
         row = blk * h4 + (rin & 3) * a.row_perm_h + (rin >> 2);
       }
       atomicAdd(a.colsum + row, red[tid]);
+      if (a.colsum2) atomicAdd(a.colsum2 + row, red[tid]);
     }
   }
 
@@ -2097,6 +2100,7 @@ __global__ __launch_bounds__(512) void igemm_tn_big_kernel(TnArgs a, ConvGeom g,
         row = blk * h4 + (rin & 3) * a.row_perm_h + (rin >> 2);
       }
       atomicAdd(a.colsum + row, red[tid]);
+      if (a.colsum2) atomicAdd(a.colsum2 + row, red[tid]);
     }
   }
 

@@ -1145,26 +1145,25 @@ class BiLSTMFn(Function):
                                  8 * H)
         if (use_sinks and not overlap and not _Fan.enabled and dtype == torch.bfloat16 and T > 1 and _TnDefer.begin()):
             # Grouped launch (_TnDefer): the four weight-gradient GEMMs of the layer -- W_ih and W_hh of both directions, each
-            # straight into its sink -- plus whatever the Linear layers behind this one recorded run as ONE launch; only the
-            # bias sums (column sums of dgates, shared by b_ih and b_hh) pass through a scratch.
+            # straight into its sink, the bias sums (column sums of dgates, shared by b_ih and b_hh) into both bias sinks --
+            # plus whatever the Linear layers behind this one recorded run as ONE launch.
             if dx_fn is not None:
                 dx_fn()
-            arena = ZeroArena.take(dev, 4 * H)
-            gb = (arena.view(torch.float32)[:8 * H] if arena is not None else
-                  torch.zeros((8 * H,), dtype=torch.float32, device=dev)).view(2, 4 * H)
             P = (T - 1) * N
-            for d in range(2):
-                call("mr_gemm_tn", dt, ptr(dgates) + d * 4 * H * es, 8 * H, ptr(x), I, ptr(sinks[4 * d]), I, T * N, 4 * H, I, H,
-                     ptr(gb[d]))
+            for d in range(2):    # bias gradient = column sums of dgates, added to b_ih AND b_hh by the same launch
+                call("mr_gemm_tn2", dt, ptr(dgates) + d * 4 * H * es, 8 * H, ptr(x), I, ptr(sinks[4 * d]), I, T * N, 4 * H, I, H,
+                     ptr(sinks[4 * d + 2]), ptr(sinks[4 * d + 3]))
             # forward direction: dgates[t] (t >= 1) with h[t-1]; reverse direction: dgates[t] (t <= T-2) with h[t+1]
             call("mr_gemm_tn", dt, ptr(dgates) + N * 8 * H * es, 8 * H, ptr(out), 2 * H, ptr(sinks[1]), H, P, 4 * H, H, H, 0)
             call("mr_gemm_tn", dt, ptr(dgates) + 4 * H * es, 8 * H, ptr(out) + (N * 2 * H + H) * es, 2 * H, ptr(sinks[5]), H, P,
                  4 * H, H, H, 0)
-            if _TnDefer.end((dgates, x, out, gb), []):
-                _TnDefer.flush(final=False)      # the bias sums are read right below
-            accumulate_multi([(sinks[2], gb[0]), (sinks[3], gb[0]), (sinks[6], gb[1]), (sinks[7], gb[1])])
-            for p in ctx.params:
-                notify_grad_ready(p)
+            if _TnDefer.end((dgates, x, out), list(ctx.params)):
+                # one launch for the layer (and the Linear layers recorded behind it); a data-parallel wrapper wants the
+                # gradients as they complete, and the next layer's recurrence is a latency chain that leaves the CUs idle anyway
+                _TnDefer.flush(final=False)
+            else:
+                for p in ctx.params:
+                    notify_grad_ready(p)
             return (dx,) + (None,) * 8
         if overlap and dx_fn is not None:
             dx_fn()

@@ -105,6 +105,24 @@ def test_grouped_dense_equals_float64(count):
         _check_dense(pr, times=2)
 
 
+@pytest.mark.parametrize("defer", [0, 1])
+def test_gemm_tn2_adds_the_column_sums_to_both_destinations(defer):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(77)
+    probs = [_dense_problem(g, 33 * 8, 1024, 512, lda=2048, perm_h=256, colsum=True) for _ in range(3)]
+    second = [torch.full((1024,), 5.0, device=DEV) for _ in probs]
+    lib.mr_tn_defer(defer)
+    for pr, c2 in zip(probs, second):
+        call("mr_gemm_tn2", BF, ptr(pr["A"]), pr["lda"], ptr(pr["B"]), pr["ldb"], ptr(pr["C"]), pr["NB"], pr["P"], pr["NA"],
+             pr["NB"], pr["perm_h"], ptr(pr["cs"]), ptr(c2))
+    lib.mr_tn_defer(0)
+    call("mr_tn_flush")
+    torch.cuda.synchronize()
+    for pr, c2 in zip(probs, second):
+        _check_dense(pr)
+        assert torch.equal(c2.cpu().double(), 5.0 + pr["cs_ref"])
+
+
 def test_defer_is_ignored_when_switched_off_or_f32():
     lib = _lib.load()
     g = torch.Generator().manual_seed(5)
