@@ -93,8 +93,8 @@ typedef struct mr_tuning {
                         rescaling, emission table in LDS) when the table fits; 0: the log-domain kernels (float64 log-sum-exp
                         per state and step).  alpha / beta buffers change meaning with it: the same value must be in force for
                         mr_ctc_fwd and the mr_ctc_bwd that consumes its buffers */
-  int nt_wide8;      /* 8-wave workgroups (two per CU) on the 128x128 / 128x64 NT tile shapes instead of 4-wave ones: 0 never,
-                        1 launches of at least 4 x CUs tiles (many rounds of short tiles), 2 more than one round, 3 always */
+  int nt_wide8;      /* 8-wave workgroups (two per CU) instead of the 4-wave ones on the NT tile shapes named by this bit mask:
+                        1 = 128x128, 2 = 128x64, 4 = 96x128, 8 = 64x128, 16 = 96x64, 32 = 64x64; 0 = never (round 4) */
   int reserved[1];   /* zero */
 } mr_tuning;
 int mr_tuning_get(mr_tuning* out);

@@ -408,20 +408,20 @@ static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long l
         MR_NT_TAIL(64, 64)
 #undef MR_NT_TAIL
       }
-      // 8-wave workgroups on the 4-wave tile shapes (mr_tuning.nt_wide8): a 128x128 (2x4 waves of 64x32) or 128x64 (4x2 waves
-      // of 32x32) tile with TWO 8-wave workgroups per CU instead of two 4-wave ones -- twice the waves to hide the prologue /
-      // first-operand latency / epilogue of launches that are many rounds of short-K tiles (CRNN conv1: 2048 tiles, K = 576:
-      // forward 98.7 -> 80.1 us, dgrad 77.8 -> 72.0 us in tools/microbench_conv.py; profiles/r05_conv_tile_sweep.txt).
-      // Not for launches the 4-buffer loop serves (at most one round of workgroups).
+      // 8-wave workgroups on the 4-wave tile shapes (mr_tuning.nt_wide8, a bit mask over the shapes): e.g. a 128x128 tile as
+      // 2x4 waves of 64x32, two 8-wave workgroups per CU instead of two 4-wave ones -- twice the waves to hide the prologue,
+      // the first-operand latency and the epilogue of short-K tiles.  Measured (round 5): CRNN conv1 forward 98.7 -> 80.1 us,
+      // dgrad 77.8 -> 72.0 us (tools/microbench_conv.py, profiles/r05_conv_tile_sweep.txt); in the steps, 128x128 + 128x64
+      // (mask 3) alone: CRNN 2.658 -> 2.615 ms, Res50-PPM 12.21 -> 11.68, FPN-attention 8.73 -> 8.55, DB 9.85 -> 9.53
+      // (profiles/r05_ab_nt_wide8.txt) -- also for the one-round launches the 4-buffer loop used to serve.
       const int w8 = MR_TUNE(nt_wide8);
       if (w8 > 0 && a.m_begin == 0) {
         const TileChoice tw = nt_tile(a.M, a.N);
-        const long long tiles = (long long)cdiv(a.M, tw.bm) * cdiv(a.N, tw.bn);
-        const long long min_tiles = w8 == 1 ? 4ll * num_cus() : (w8 == 2 ? (long long)num_cus() + 1 : 0);
-        if (tiles >= min_tiles) {
-          if (tw.bm == 128 && tw.bn == 128) return launch_nt_big<T, 2, 4, 4, 2, AMODE>(a, g, C, ldc, bias, relu, stream);
-          if (tw.bm == 128 && tw.bn == 64) return launch_nt_big<T, 4, 2, 2, 2, AMODE>(a, g, C, ldc, bias, relu, stream);
-        }
+#define MR_NT_W8(BIT_, BM_, BN_, WM_, WN_, TM_, TN_) \
+  if ((w8 & (BIT_)) && tw.bm == BM_ && tw.bn == BN_) return launch_nt_big<T, WM_, WN_, TM_, TN_, AMODE>(a, g, C, ldc, bias, relu, stream);
+        MR_NT_W8(1, 128, 128, 2, 4, 4, 2) MR_NT_W8(2, 128, 64, 4, 2, 2, 2) MR_NT_W8(4, 96, 128, 2, 4, 3, 2)
+        MR_NT_W8(8, 64, 128, 2, 4, 2, 2) MR_NT_W8(16, 96, 64, 2, 4, 3, 1) MR_NT_W8(32, 64, 64, 2, 4, 2, 1)
+#undef MR_NT_W8
       }
     }
   }
