@@ -253,10 +253,14 @@ int mr_sizeof_prep_job(void);
 #define MR_MAX_SEGMENTS 8
 int mr_accumulate_multi(int count, float* const* dst, const float* const* src, const long long* n,
                         hipStream_t stream);
+/* zero fill of count <= MR_MAX_SEGMENTS buffers (16-byte aligned, sizes multiples of 16 bytes) in one launch: zero_grad() of the
+ * fused optimizers clears the flat gradient buffers and the pre-zeroed scratch arena together */
+int mr_zero_multi(int count, void* const* dst, const long long* bytes, hipStream_t stream);
 
 /* ---- optimizers (replaces torch.optim.Adam / SGD at training/optimizer_scheduler.py:17-22) -------------- */
-/* hyper: device f32[8] = {lr, beta1 (SGD: momentum), beta2, eps, weight_decay, step, -, -}; step is
- * incremented on device so the call is hipGraph-replay safe */
+/* hyper: device f32[8] = {lr, beta1 (SGD: momentum), beta2, eps, weight_decay, completed steps, gradient scale (0 = 1),
+ * arrival counter (u32, zero between launches)}.  The update kernel itself runs step hyper[5] + 1 and advances hyper[5] when its
+ * last workgroup has read it: hipGraph-replay safe, no separate launch.  (hyper[7] was unused in ABI version 1: zero it.) */
 int mr_adam_step(float* p, const float* g, float* m, float* v, long long n, float* hyper, hipStream_t stream);
 int mr_sgd_step(float* p, const float* g, float* buf, long long n, float* hyper, hipStream_t stream);
 

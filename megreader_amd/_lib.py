@@ -46,6 +46,7 @@ SIGNATURES = {
     "mr_prep_bias": "pppiis",
     "mr_prep_batch": "ipils",
     "mr_accumulate_multi": "ippps",
+    "mr_zero_multi": "ipps",
     "mr_adaptive_avgpool_multi_fwd": "ippppiiiiis",
     "mr_adaptive_avgpool_multi_bwd": "ipppipiiiis",
     "mr_adam_step": "pppplps",

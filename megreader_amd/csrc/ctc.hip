@@ -159,6 +159,18 @@ __device__ __forceinline__ double pow2_neg(int e) {   // 2^-e, -1022 <= -e <= 10
   return __longlong_as_double((long long)(1023 - e) << 52);
 }
 __device__ __forceinline__ int hi_word(double v) { return (int)(__double_as_longlong(v) >> 32); }
+// maximum over the wavefront of a non-negative int: four DPP row rotations (every lane of a 16-lane row then holds the row's
+// maximum) + one scalar read per row -- ~30 cycles instead of six dependent ds_bpermute round trips on the per-step chain
+__device__ __forceinline__ int wave_max_nonneg(int v) {
+#define MR_ROW_ROR_I(V, N) __builtin_amdgcn_update_dpp(0, V, 0x120 + (N), 0xf, 0xf, false)
+  v = max(v, MR_ROW_ROR_I(v, 8));
+  v = max(v, MR_ROW_ROR_I(v, 4));
+  v = max(v, MR_ROW_ROR_I(v, 2));
+  v = max(v, MR_ROW_ROR_I(v, 1));
+#undef MR_ROW_ROR_I
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void ctc_fwd_lin_kernel(const T* __restrict__ logits, int ldl, const void* targets,
@@ -184,21 +196,58 @@ __global__ __launch_bounds__(256) void ctc_fwd_lin_kernel(const T* __restrict__ 
   if (L > S) L = S;
   const int SP = 2 * L + 1;
 
-  // 1) log-softmax rows t = wave, wave+4, ... in f32 (identical to ctc_fwd_kernel)
-  for (int t = wave; t < Tn; t += 4) {
-    const T* row = logits + ((long long)t * N + b) * ldl;
-    float mx = -INFINITY;
-    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, to_f32(row[c]));
-    mx = wave_max(mx);
-    float se = 0.f;
-    for (int c = lane; c < C; c += 64) se += expf(to_f32(row[c]) - mx);
-    se = wave_sum(se);
-    const float lz = mx + logf(se);
-    float* orow = lp_out + ((long long)t * N + b) * C;
-    for (int c = lane; c < C; c += 64) orow[c] = to_f32(row[c]) - lz;
-    if (lp64_out) {
-      double* orow64 = lp64_out + ((long long)t * N + b) * C;
-      for (int c = lane; c < C; c += 64) orow64[c] = (double)(to_f32(row[c]) - lz);
+  // 1) log-softmax in f32.  Small alphabets (C <= 64: the 38-class CRNN head): 8 lanes per row, 32 rows of the sample at once --
+  // the row-per-wavefront loop of ctc_fwd_kernel walks 8 rows one after the other with two 6-step butterflies each; wider
+  // alphabets keep it.  Same operations per element in both forms except the order of the sum of exponentials.
+  if (C <= 64) {
+    const int l8 = tid & 7;
+    for (int t = tid >> 3; t < Tn; t += 32) {
+      const T* row = logits + ((long long)t * N + b) * ldl;
+      float xv[8];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = l8 + 8 * q;
+        xv[q] = c < C ? to_f32(row[c]) : -INFINITY;
+        mx = fmaxf(mx, xv[q]);
+      }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      float se = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (l8 + 8 * q < C) se += expf(xv[q] - mx);
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+      const float lz = mx + logf(se);
+      float* orow = lp_out + ((long long)t * N + b) * C;
+      double* orow64 = lp64_out ? lp64_out + ((long long)t * N + b) * C : nullptr;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = l8 + 8 * q;
+        if (c < C) {
+          const float v = xv[q] - lz;
+          orow[c] = v;
+          if (orow64) orow64[c] = (double)v;
+        }
+      }
+    }
+  } else {
+    for (int t = wave; t < Tn; t += 4) {
+      const T* row = logits + ((long long)t * N + b) * ldl;
+      float mx = -INFINITY;
+      for (int c = lane; c < C; c += 64) mx = fmaxf(mx, to_f32(row[c]));
+      mx = wave_max(mx);
+      float se = 0.f;
+      for (int c = lane; c < C; c += 64) se += expf(to_f32(row[c]) - mx);
+      se = wave_sum(se);
+      const float lz = mx + logf(se);
+      float* orow = lp_out + ((long long)t * N + b) * C;
+      for (int c = lane; c < C; c += 64) orow[c] = to_f32(row[c]) - lz;
+      if (lp64_out) {
+        double* orow64 = lp64_out + ((long long)t * N + b) * C;
+        for (int c = lane; c < C; c += 64) orow64[c] = (double)(to_f32(row[c]) - lz);
+      }
     }
   }
   for (int s = tid; s < SPmax; s += 256) lab[s] = (s < SP) ? ext_label(targets, tg64, (long long)b * S, s, blank) : blank;
@@ -269,8 +318,7 @@ __global__ __launch_bounds__(256) void ctc_fwd_lin_kernel(const T* __restrict__ 
       }
     }
     // exponent of this step's maximum (non-negative doubles order like their high words) -> next step's rescale
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mhi = max(mhi, __shfl_xor(mhi, o, 64));
+    mhi = wave_max_nonneg(mhi);
     if (lane == 0) wmax[(i & 1) * 4 + half * 2 + hw] = mhi;
     __syncthreads();
     const int m2 = max(wmax[(i & 1) * 4 + half * 2], wmax[(i & 1) * 4 + half * 2 + 1]);

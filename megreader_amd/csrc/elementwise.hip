@@ -350,15 +350,52 @@ __global__ void accumulate_multi_kernel(AccumSegs segs) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) d[i] += a[i];
 }
 
+struct ZeroSegs {
+  void* dst[MR_MAX_SEGMENTS];
+  long long n16[MR_MAX_SEGMENTS];   // 16-byte vectors
+};
+// zero fill of several 16-byte-aligned buffers in ONE launch (zero_grad: the flat gradient buffers + the scratch arena)
+__global__ void zero_multi_kernel(ZeroSegs segs) {
+  const int s = blockIdx.y;
+  uint4* __restrict__ d = (uint4*)segs.dst[s];
+  const long long n = segs.n16[s];
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) d[i] = make_uint4(0, 0, 0, 0);
+}
+
 // ---------------------------------------------------------------- fused Adam over one flat buffer
 // hyper (device, f32[8]): lr, beta1, beta2, eps, weight_decay, step (as float), unused, unused
 // Semantics = torch.optim.Adam (no amsgrad, L2 weight decay added to the gradient).
+// Called by every workgroup of an update kernel AFTER it has read hyper[5]: the last arriver publishes the new step count.
+// The hyper block is read by the first 8 threads into LDS; __syncthreads() completes those loads (it drains vmcnt) before any
+// thread -- in particular thread 0, which arrives -- goes on, so no thread of the grid can see the advanced counter.
+__device__ __forceinline__ void opt_load_hyper(float* hyper, float* sh) {
+  if (threadIdx.x < 8) sh[threadIdx.x] = __hip_atomic_load(hyper + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+}
+__device__ __forceinline__ void opt_step_arrive(float* hyper, float done) {
+  if (threadIdx.x == 0) {
+    unsigned* cnt = (unsigned*)(hyper + 7);
+    const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == gridDim.x - 1) {      // everybody has read hyper[5] (the read precedes the arrival in program order)
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(hyper + 5, done + 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long long n, const float* __restrict__ hyper) {
-  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], step = hyper[5];
+                            float* __restrict__ v, long long n, float* hyper) {
+  // hyper[5] = number of COMPLETED steps: this launch is step hyper[5] + 1.  Every workgroup reads it first, then arrives at the
+  // counter in hyper[7]; the last one to arrive advances hyper[5] for the next launch and clears the counter (a separate
+  // one-thread "tick" launch in front of every update was 5 us of launch floor per step).
+  __shared__ float sh[8];
+  opt_load_hyper(hyper, sh);
+  const float lr = sh[0], b1 = sh[1], b2 = sh[2], eps = sh[3], wd = sh[4], step = sh[5] + 1.f;
+  opt_step_arrive(hyper, sh[5]);
   // hyper[6]: scale applied to the raw gradient (data parallel: 1 / world size folded into the update instead of a
   // separate pass over the flat gradient buffer after the all-reduce); 0 = unset = 1
-  const float gs = hyper[6] != 0.f ? hyper[6] : 1.f;
+  const float gs = sh[6] != 0.f ? sh[6] : 1.f;
   const float bc1 = 1.f - powf(b1, step);
   const float bc2 = 1.f - powf(b2, step);
   const float step_size = lr / bc1;
@@ -390,13 +427,15 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
-__global__ void adam_tick_kernel(float* hyper) { hyper[5] += 1.f; }
 
 // SGD with momentum (torch.optim.SGD semantics: buf = mu*buf + g(+wd*p); p -= lr*buf; first step buf = g)
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long long n,
-                           const float* __restrict__ hyper) {
-  const float lr = hyper[0], mu = hyper[1], wd = hyper[4], step = hyper[5];
-  const float gs = hyper[6] != 0.f ? hyper[6] : 1.f;   // gradient scale (1 / world size), see adam_kernel
+                           float* hyper) {
+  __shared__ float sh[8];
+  opt_load_hyper(hyper, sh);
+  const float lr = sh[0], mu = sh[1], wd = sh[4], step = sh[5] + 1.f;   // see adam_kernel
+  opt_step_arrive(hyper, sh[5]);
+  const float gs = sh[6] != 0.f ? sh[6] : 1.f;   // gradient scale (1 / world size), see adam_kernel
   const bool first = step <= 1.f;
   const long long nv = n / 4;      // the flat buffers are 256-byte aligned and padded to 64 elements (optim.py)
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
@@ -575,21 +614,36 @@ int mr_accumulate_multi(int count, float* const* dst, const float* const* src, c
   return MR_OK;
 }
 
+int mr_zero_multi(int count, void* const* dst, const long long* bytes, hipStream_t stream) {
+  if (count <= 0) return MR_OK;
+  MR_CHECK_ARG(count <= MR_MAX_SEGMENTS, "mr_zero_multi: at most %d segments per call", MR_MAX_SEGMENTS);
+  ZeroSegs segs;
+  long long nmax = 0;
+  for (int i = 0; i < count; ++i) {
+    MR_CHECK_ARG(dst[i] != nullptr && bytes[i] >= 0 && (((uintptr_t)dst[i]) & 15) == 0 && (bytes[i] & 15) == 0,
+                 "mr_zero_multi: segment %d must be 16-byte aligned with a size that is a multiple of 16", i);
+    segs.dst[i] = dst[i];
+    segs.n16[i] = bytes[i] / 16;
+    if (segs.n16[i] > nmax) nmax = segs.n16[i];
+  }
+  for (int i = count; i < MR_MAX_SEGMENTS; ++i) { segs.dst[i] = nullptr; segs.n16[i] = 0; }
+  if (nmax == 0) return MR_OK;
+  hipLaunchKernelGGL(zero_multi_kernel, dim3(grid_for(nmax, 256, 2048), count), dim3(256), 0, stream, segs);
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
 int mr_adam_step(float* p, const float* g, float* m, float* v, long long n, float* hyper, hipStream_t stream) {
   MR_CHECK_ARG(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)m & 15) == 0 &&
                    ((uintptr_t)v & 15) == 0,
                "mr_adam_step: buffers must be 16-byte aligned");
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, hyper);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, p, g, m, v, n,
-                     (const float*)hyper);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, p, g, m, v, n, hyper);
   MR_CHECK_LAUNCH();
   return MR_OK;
 }
 
 int mr_sgd_step(float* p, const float* g, float* buf, long long n, float* hyper, hipStream_t stream) {
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, hyper);
-  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, p, g, buf, n,
-                     (const float*)hyper);
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, p, g, buf, n, hyper);
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

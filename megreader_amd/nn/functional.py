@@ -94,6 +94,25 @@ class ZeroArena(object):
             a.buf[:a.offset].zero_()
             a.offset = 0
 
+    @staticmethod
+    def rewind(device):
+        """(data pointer, bytes) of the used prefix -- which the CALLER zeroes (zero_tensors: one launch together with the flat
+        gradient buffers) -- and rewind; None when nothing was handed out."""
+        a = ZeroArena.arenas.get(device)
+        if a is None or not a.offset:
+            return None
+        used = a.offset
+        a.offset = 0
+        return a.buf.data_ptr(), used * 8
+
+
+def zero_segments(segments):
+    """Zero fill of (data pointer, bytes) pairs, 8 per launch (mr_zero_multi); 16-byte aligned, sizes multiples of 16."""
+    for i in range(0, len(segments), 8):
+        chunk = segments[i:i + 8]
+        n = len(chunk)
+        call("mr_zero_multi", n, (ctypes.c_void_p * n)(*[p for p, _ in chunk]), (ctypes.c_longlong * n)(*[b for _, b in chunk]))
+
 
 class _Side(object):
     """Side HIP stream for weight-gradient GEMMs that nothing later in the backward pass depends on.  The LSTM

@@ -13,7 +13,7 @@ import torch
 
 from ._lib import call, ptr
 from .nn import prep
-from .nn.functional import ZeroArena
+from .nn.functional import ZeroArena, zero_segments
 
 _ALIGN = 64  # elements; keeps every parameter slice 256-byte aligned
 
@@ -77,13 +77,22 @@ class _FlatOptimizer(torch.optim.Optimizer):
         device step counter) and the parameters' home are NEVER dropped once created."""
         if self._flat is None:
             self._materialize()
+        segments, devices = [], []
         for f in self._flat:
             if f is not None:
-                f['g'].zero_()
-                ZeroArena.reset(f['g'].device)  # pre-zeroed reduction scratch of the BatchNorm layers
+                segments.append((f['g'].data_ptr(), f['g'].numel() * 4))      # (padded to 64 elements: whole 16-byte vectors)
+                if f['g'].device not in devices:
+                    devices.append(f['g'].device)
                 if set_to_none:
                     for p in f['params']:
                         p.grad = None     # grad_sink() is inactive while .grad is None; _sync_views re-attaches
+        for dev in devices:     # pre-zeroed scratch arena (BatchNorm reductions, LSTM exchange rings): cleared by the same launch
+            used = ZeroArena.rewind(dev)
+            if used is not None:
+                segments.append(used)
+        if segments:
+            with torch.cuda.device(devices[0]):
+                zero_segments(segments)
 
     def _sync_views(self, f):
         for p, off in zip(f['params'], f['offs']):
