@@ -243,7 +243,8 @@ typedef struct mr_prep_job {
   int pad, ld_b, perm_h;
   int block_start, reserved;
 } mr_prep_job;
-int mr_prep_batch(int dtype, const mr_prep_job* jobs_device, int njobs, long long total_blocks, hipStream_t stream);
+int mr_prep_batch(int dtype, const mr_prep_job* jobs_device, int njobs, long long total_blocks, float* tick,
+                  hipStream_t stream);   /* tick (nullable): an optimizer's hyper block whose step counter this launch advances */
 /* sizeof(mr_prep_job) as compiled into the library (host only): bindings verify their struct mirror against it */
 int mr_sizeof_prep_job(void);
 
@@ -258,9 +259,10 @@ int mr_accumulate_multi(int count, float* const* dst, const float* const* src, c
 int mr_zero_multi(int count, void* const* dst, const long long* bytes, hipStream_t stream);
 
 /* ---- optimizers (replaces torch.optim.Adam / SGD at training/optimizer_scheduler.py:17-22) -------------- */
-/* hyper: device f32[8] = {lr, beta1 (SGD: momentum), beta2, eps, weight_decay, completed steps, gradient scale (0 = 1),
- * arrival counter (u32, zero between launches)}.  The update kernel itself runs step hyper[5] + 1 and advances hyper[5] when its
- * last workgroup has read it: hipGraph-replay safe, no separate launch.  (hyper[7] was unused in ABI version 1: zero it.) */
+/* hyper: device f32[8] = {lr, beta1 (SGD: momentum), beta2, eps, weight_decay, completed steps, gradient scale (0 = 1), -}.
+ * The update kernels run step hyper[5] + 1 and only READ the counter; the launch behind them advances it: mr_prep_batch(tick =
+ * hyper) -- the regeneration of the weight images that follows every update anyway -- or mr_opt_tick.  hipGraph-replay safe. */
+int mr_opt_tick(float* hyper, hipStream_t stream);
 int mr_adam_step(float* p, const float* g, float* m, float* v, long long n, float* hyper, hipStream_t stream);
 int mr_sgd_step(float* p, const float* g, float* buf, long long n, float* hyper, hipStream_t stream);
 

@@ -44,7 +44,8 @@ SIGNATURES = {
     "mr_prep_conv_weight": "ipllllppiiiiiis",
     "mr_prep_matrix": "ipipipiiiis",
     "mr_prep_bias": "pppiis",
-    "mr_prep_batch": "ipils",
+    "mr_prep_batch": "ipilps",
+    "mr_opt_tick": "ps",
     "mr_accumulate_multi": "ippps",
     "mr_zero_multi": "ipps",
     "mr_adaptive_avgpool_multi_fwd": "ippppiiiiis",

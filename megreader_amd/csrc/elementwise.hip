@@ -223,8 +223,9 @@ __global__ void prep_bias_kernel(const float* __restrict__ a, const float* __res
 // written row-wise to the normal image and -- through LDS -- column-wise to the transposed image, so that both
 // images are written in full 128-byte runs (the transposed one used to be 2-byte scatter writes).
 template <typename T>
-__global__ __launch_bounds__(256) void prep_batch_kernel(const mr_prep_job* __restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(256) void prep_batch_kernel(const mr_prep_job* __restrict__ jobs, int njobs, float* tick) {
   __shared__ int starts[1024];
+  if (tick && blockIdx.x == 0 && threadIdx.x == 0) tick[5] += 1.f;   // the optimizer's step counter (mr_adam_step)
   __shared__ T tile[64][66];
   for (int t = threadIdx.x; t < njobs; t += blockDim.x) starts[t] = jobs[t].block_start;
   __syncthreads();
@@ -366,36 +367,16 @@ __global__ void zero_multi_kernel(ZeroSegs segs) {
 // ---------------------------------------------------------------- fused Adam over one flat buffer
 // hyper (device, f32[8]): lr, beta1, beta2, eps, weight_decay, step (as float), unused, unused
 // Semantics = torch.optim.Adam (no amsgrad, L2 weight decay added to the gradient).
-// Called by every workgroup of an update kernel AFTER it has read hyper[5]: the last arriver publishes the new step count.
-// The hyper block is read by the first 8 threads into LDS; __syncthreads() completes those loads (it drains vmcnt) before any
-// thread -- in particular thread 0, which arrives -- goes on, so no thread of the grid can see the advanced counter.
-__device__ __forceinline__ void opt_load_hyper(float* hyper, float* sh) {
-  if (threadIdx.x < 8) sh[threadIdx.x] = __hip_atomic_load(hyper + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-}
-__device__ __forceinline__ void opt_step_arrive(float* hyper, float done) {
-  if (threadIdx.x == 0) {
-    unsigned* cnt = (unsigned*)(hyper + 7);
-    const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ticket == gridDim.x - 1) {      // everybody has read hyper[5] (the read precedes the arrival in program order)
-      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(hyper + 5, done + 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long long n, float* hyper) {
-  // hyper[5] = number of COMPLETED steps: this launch is step hyper[5] + 1.  Every workgroup reads it first, then arrives at the
-  // counter in hyper[7]; the last one to arrive advances hyper[5] for the next launch and clears the counter (a separate
-  // one-thread "tick" launch in front of every update was 5 us of launch floor per step).
-  __shared__ float sh[8];
-  opt_load_hyper(hyper, sh);
-  const float lr = sh[0], b1 = sh[1], b2 = sh[2], eps = sh[3], wd = sh[4], step = sh[5] + 1.f;
-  opt_step_arrive(hyper, sh[5]);
+                            float* __restrict__ v, long long n, const float* __restrict__ hyper) {
+  // hyper[5] = number of COMPLETED steps: this launch is step hyper[5] + 1 and only READS the counter.  The launch that
+  // follows it in the stream advances it -- mr_prep_batch(tick = hyper), or mr_opt_tick when there is nothing to prepare (a
+  // one-thread "tick" launch in front of every update was 5 us of launch floor per step; an arrival counter inside this kernel
+  // serialised 4096 returning atomics on one address: 38 -> 157 us, measured).
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], step = hyper[5] + 1.f;
   // hyper[6]: scale applied to the raw gradient (data parallel: 1 / world size folded into the update instead of a
   // separate pass over the flat gradient buffer after the all-reduce); 0 = unset = 1
-  const float gs = sh[6] != 0.f ? sh[6] : 1.f;
+  const float gs = hyper[6] != 0.f ? hyper[6] : 1.f;
   const float bc1 = 1.f - powf(b1, step);
   const float bc2 = 1.f - powf(b2, step);
   const float step_size = lr / bc1;
@@ -430,12 +411,9 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 // SGD with momentum (torch.optim.SGD semantics: buf = mu*buf + g(+wd*p); p -= lr*buf; first step buf = g)
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long long n,
-                           float* hyper) {
-  __shared__ float sh[8];
-  opt_load_hyper(hyper, sh);
-  const float lr = sh[0], mu = sh[1], wd = sh[4], step = sh[5] + 1.f;   // see adam_kernel
-  opt_step_arrive(hyper, sh[5]);
-  const float gs = sh[6] != 0.f ? sh[6] : 1.f;   // gradient scale (1 / world size), see adam_kernel
+                           const float* __restrict__ hyper) {
+  const float lr = hyper[0], mu = hyper[1], wd = hyper[4], step = hyper[5] + 1.f;   // see adam_kernel
+  const float gs = hyper[6] != 0.f ? hyper[6] : 1.f;   // gradient scale (1 / world size), see adam_kernel
   const bool first = step <= 1.f;
   const long long nv = n / 4;      // the flat buffers are 256-byte aligned and padded to 64 elements (optim.py)
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
@@ -585,12 +563,22 @@ int mr_prep_bias(const float* a, const float* b, float* dst, int R, int perm_h, 
 // sizeof(mr_prep_job) as compiled into the library (host-side bindings check their struct mirror against it)
 int mr_sizeof_prep_job(void) { return (int)sizeof(mr_prep_job); }
 
-int mr_prep_batch(int dtype, const mr_prep_job* jobs_device, int njobs, long long total_blocks, hipStream_t stream) {
-  if (njobs <= 0) return MR_OK;
+__global__ void opt_tick_kernel(float* hyper) { hyper[5] += 1.f; }
+
+int mr_opt_tick(float* hyper, hipStream_t stream) {
+  MR_CHECK_ARG(hyper != nullptr, "mr_opt_tick: null");
+  hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(1), 0, stream, hyper);
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_prep_batch(int dtype, const mr_prep_job* jobs_device, int njobs, long long total_blocks, float* tick,
+                  hipStream_t stream) {
+  if (njobs <= 0) return tick ? mr_opt_tick(tick, stream) : MR_OK;
   MR_CHECK_ARG(jobs_device != nullptr && njobs <= 1024, "mr_prep_batch: bad job table (at most 1024 jobs)");
   MR_CHECK_ARG(total_blocks > 0 && total_blocks < (1ll << 31), "mr_prep_batch: bad total_blocks");
   DISPATCH_T(dtype, hipLaunchKernelGGL((prep_batch_kernel<T>), dim3((unsigned)total_blocks), dim3(256), 0, stream,
-                                       jobs_device, njobs));
+                                       jobs_device, njobs, tick));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }
@@ -637,13 +625,13 @@ int mr_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
   MR_CHECK_ARG(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)m & 15) == 0 &&
                    ((uintptr_t)v & 15) == 0,
                "mr_adam_step: buffers must be 16-byte aligned");
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, p, g, m, v, n, hyper);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, p, g, m, v, n, (const float*)hyper);
   MR_CHECK_LAUNCH();
   return MR_OK;
 }
 
 int mr_sgd_step(float* p, const float* g, float* buf, long long n, float* hyper, hipStream_t stream) {
-  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, p, g, buf, n, hyper);
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, p, g, buf, n, (const float*)hyper);
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

@@ -149,14 +149,20 @@ class _Plan(object):
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self.tables.append((dtype_code(dtype), host.to(device), len(jobs), nblocks))
 
-    def launch(self):
+    def launch(self, tick=None):
+        """tick: the optimizer's device hyper block -- the first launch also advances its step counter (mr_prep_batch)."""
         for dt, table, njobs, nblocks in self.tables:
-            call("mr_prep_batch", dt, ptr(table), njobs, nblocks)
+            call("mr_prep_batch", dt, ptr(table), njobs, nblocks, ptr(tick))
+            tick = None
+        if tick is not None:
+            call("mr_opt_tick", ptr(tick))
 
 
-def refresh(params, holder):
+def refresh(params, holder, tick=None):
     """Regenerate every recorded image whose sources are in `params` (called by the fused optimizers right after the
-    parameter update).  `holder` (the optimizer's per-group dict) keeps the device job table between calls."""
+    parameter update).  `holder` (the optimizer's per-group dict) keeps the device job table between calls.
+    tick: the optimizer's device hyper block; its step counter is advanced by the regeneration launch (or by a one-thread
+    launch when there is nothing to regenerate) -- the update kernel itself only reads it."""
     entries = []
     for p in params:
         cache = p.__dict__.get("_mr_prep")
@@ -166,11 +172,13 @@ def refresh(params, holder):
             entries.extend(cache.values())
     if not entries:
         holder.pop('prep_plan', None)
+        if tick is not None:
+            call("mr_opt_tick", ptr(tick))
         return
     plan = holder.get('prep_plan')
     if plan is None or plan.signature != tuple(id(e) for e in entries):
         plan = holder['prep_plan'] = _Plan(entries, params[0].device)
-    plan.launch()
+    plan.launch(tick)
     for e in entries:
         e.stamp = _stamp(e.params)
 

@@ -159,7 +159,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
             self._launch(f)
             # the update went through raw pointers (no autograd version bump): regenerate the compute-dtype
             # operand images of these parameters in one launch
-            prep.refresh(f['params'], f)
+            prep.refresh(f['params'], f, tick=f['hyper'])     # ... and advance the device step counter
         return loss
 
 
