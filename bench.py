@@ -166,7 +166,7 @@ def _host_threads():
     return max(1, min(avail, 32)), avail  # more threads than this only add contention at these tensor sizes
 
 
-def cpu_baseline(workload="crnn", budget_s=20.0):
+def cpu_baseline(workload="crnn", budget_s=20.0, crop=None):
     """The oracle restatement of the reference model (oracle/: torch CPU kernels, fp32 weights, the reference's own fp64 /
     numpy CTC -- what the reference executes on a CPU) timed on this box's host cores: a BOUNDED sample of the same workload
     (one warm-up step, then whole training steps until about half the budget is used; at least one).  CRNN runs at the
@@ -181,9 +181,10 @@ def cpu_baseline(workload="crnn", budget_s=20.0):
         what = "batch 256 (32x128 crops, the benchmarked batch)"
     elif workload == "res50ppm":
         from oracle.res50ppm import Res50PPM2DCTCOracle, synthetic_batch_2d
-        model, n = Res50PPM2DCTCOracle().train(), 64
-        batch = synthetic_batch_2d(n, 32, 128, seed=0, max_len=3)
-        what = "batch 64 of the benchmarked 256 (32x128 crops)"
+        ch, cw = crop or (32, 128)
+        model, n = Res50PPM2DCTCOracle().train(), (64 if ch * cw <= 32 * 128 else 16)
+        batch = synthetic_batch_2d(n, ch, cw, seed=0, max_len=3)
+        what = "batch %d of the benchmarked 256 (%dx%d crops)" % (n, ch, cw)
     elif workload == "fpn_attention":
         from oracle.crnn import synthetic_batch
         from oracle.fpn_attention import FPNAttentionOracle
@@ -279,6 +280,12 @@ def main():
                          "(data/data_loader.py:40-48 `batch_size // world_size`): the workload's GLOBAL batch (256 crops; 16 "
                          "images for db) is sharded over the N ranks, --batch is then the global batch")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--crop", default="", metavar="HxW",
+                    help="res50ppm only: crop size (default 32x128 = BASELINE.json configs[2] as benchmarked since round 1; 64x256 = "
+                         "the YAML-native size of experiments/recognition/community-base.yaml:33-35, BASELINE.md C3)")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="N > 1, weak scaling: do not append the strong-scaling measurement (the workload's GLOBAL batch sharded "
+                         "over the ranks, data/data_loader.py:40-48) as a `strong` block to the JSON line")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
     ap.add_argument("--shape-table", default="", help="write per-geometry statistics of the convolution launches to this file")
     ap.add_argument("--force-ddp", action="store_true",
@@ -325,8 +332,11 @@ def main():
     if args.gpus != world:
         print("warning: --gpus %d but WORLD_SIZE %d (using WORLD_SIZE)" % (args.gpus, world), file=sys.stderr)
 
-    def measure(workload, steps, warmup, with_cpu):
+    def measure(workload, steps, warmup, with_cpu, scaling=None, crop=None):
         """One workload: build, warm up, time `steps` steps; returns the result dict on rank 0 (None elsewhere)."""
+        scaling = scaling or args.scaling
+        if crop is None and args.crop and workload == "res50ppm":
+            crop = tuple(int(v) for v in args.crop.lower().split("x"))
         import megreader_amd as mr
         from megreader_amd import _lib
         from megreader_amd.backbones import crnn_backbone
@@ -414,21 +424,22 @@ def main():
             ddp_shim = DistributedDataParallel(model)
             ddp_shim.fold_average_into(opt)
         bsz = args.batch
-        if args.scaling == "strong":
+        if scaling == "strong":
             # the reference shards ONE global batch: per-rank batch = global // world (data/data_loader.py:40-48)
             glob = args.batch if args.batch != 256 else (16 if is_db else 256)
             if glob % world:
                 raise SystemExit("--scaling strong: global batch %d is not divisible by %d ranks" % (glob, world))
             bsz = glob // world
         if is_db:
-            if args.scaling != "strong":
+            if scaling != "strong":
                 bsz = args.batch if args.batch != 256 else 2           # configs[4]: 16 global = 2 per GPU on 8 GPUs
             dbatch = {k: v.to(dev) for k, v in detection_batch(bsz, 640, seed=rank).items()}
             batch = {'image': dbatch['image'], 'label': torch.zeros(1), 'length': torch.zeros(1)}
         elif workload == "res50ppm":
-            batch = synthetic_batch_2d(bsz, 32, 128, seed=rank, max_len=3)
+            ch, cw = crop or (32, 128)
+            batch = synthetic_batch_2d(bsz, ch, cw, seed=rank, max_len=3)
         elif workload == "fpn_attention":
-            if args.scaling != "strong":
+            if scaling != "strong":
                 bsz = args.batch if args.batch != 256 else 32      # configs[3]: 256 global = 32 per GPU on 8 GPUs
             batch = synthetic_batch(bsz, 64, 256, seed=rank)
         else:
@@ -486,6 +497,9 @@ def main():
                     graphed = None
             if graphed is None:
                 net = model
+                if distributed:
+                    ddp_shim.suspended = True      # its parameter hooks stay registered: the eager all-reduce below replaces them
+                    ddp_shim.unfold_average()
                 sync = data_parallel_grad_sync(opt, fold=True) if distributed else None
                 graphed = GraphedTrainStep(loss_fn, opt, [img, lab, ln], warmup=max(2, warmup if distributed else 2),
                                            grad_sync=sync)
@@ -558,7 +572,7 @@ def main():
                     fl, t_ms, n = agg[dom]
                     ach = fl / (t_ms * 1e-3) / 1e12
                     peak = MFMA_PEAK_TFLOPS[args.dtype]
-                    traffic, traffic_src = pmc_traffic(dom, workload)
+                    traffic, traffic_src = pmc_traffic(dom, workload if crop is None else "%s_%dx%d" % (workload, crop[0], crop[1]))
                     roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                                 "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
@@ -580,10 +594,11 @@ def main():
                                  "crops, 32 decode steps, teacher forcing fixed (gt_as_output), Adam")
                 fwd_flops = 17.25e9  # 5.01 backbone + 10.97 decoder conv encoder + 1.27 decode loop
             elif workload == "res50ppm":
-                metric_name = "training images/sec, ResNet50-PPM-2D-CTC 32x128 crops, batch %d per GPU" % bsz
-                workload_name = ("ResNet50-dilated-PPM + 2D-CTC training step (BASELINE.json configs[2]): 32x128 crops, "
-                                 "T=16 H=4 C=38, Adam")
-                fwd_flops = 6.02e9  # forward FLOPs per 32x128 image
+                ch, cw = crop or (32, 128)
+                metric_name = "training images/sec, ResNet50-PPM-2D-CTC %dx%d crops, batch %d per GPU" % (ch, cw, bsz)
+                workload_name = ("ResNet50-dilated-PPM + 2D-CTC training step (BASELINE.json configs[2]): %dx%d crops, "
+                                 "T=%d H=%d C=38, Adam" % (ch, cw, cw // 8, ch // 8))
+                fwd_flops = 6.02e9 * (ch * cw) / (32.0 * 128.0)  # 6.02 GFLOP forward per 32x128 image
             else:
                 metric_name = "training images/sec, CRNN-CTC 32x128 crops, batch %d per GPU" % bsz
                 workload_name = "CRNN + 1D-CTC training step (BASELINE.json configs[1]): 32x128 crops, T=33, C=38, Adam"
@@ -591,7 +606,7 @@ def main():
             out = {
                 "metric": metric_name,
                 "value": round(images / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": steps,
-                "warmup": warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": args.scaling,
+                "warmup": warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": scaling,
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": workload_name, "global_batch": bsz * world,
                            "per_gpu_batch": bsz, "parallelism": "dp%d" % world,
@@ -610,7 +625,7 @@ def main():
             out["step_tflops_per_gpu"] = round(step_tflops, 2)
             out["host_enqueue_ms_per_step"] = round(1e3 * host_enqueue / steps, 3)
             if world == 1 and with_cpu:
-                out["cpu_baseline"] = cpu_baseline(workload, budget_s=20.0 if workload == "crnn" else 12.0)
+                out["cpu_baseline"] = cpu_baseline(workload, budget_s=20.0 if workload == "crnn" else 12.0, crop=crop)
             else:
                 out["cpu_baseline"] = None
         else:
@@ -623,13 +638,28 @@ def main():
         # target #2 (configs[2], also kept under the round-1..3 key `secondary`), configs[3] and configs[4]; each with its own
         # roofline block and CPU baseline
         out["secondaries"] = []
-        for wl in ("res50ppm", "fpn_attention", "db"):
-            sec = measure(wl, min(args.steps, 10), min(args.warmup, 3), not args.no_cpu_baseline)
+        for wl, crop in (("res50ppm", None), ("fpn_attention", None), ("db", None), ("res50ppm", (64, 256))):
+            sec = measure(wl, min(args.steps, 10), min(args.warmup, 3), not args.no_cpu_baseline, crop=crop)
             for k in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data"):
                 sec.pop(k, None)
-            sec["workload"] = wl
+            sec["workload"] = wl if crop is None else "%s_%dx%d" % (wl, crop[0], crop[1])
             out["secondaries"].append(sec)
         out["secondary"] = out["secondaries"][0]
+    if world > 1 and args.scaling == "weak" and not args.no_strong:
+        # N > 1: the same line also carries the STRONG-scaling measurement -- the workload's global batch (256 crops) sharded
+        # over the ranks as the reference's loader does (data/data_loader.py:40-48) -- whichever --scaling the driver passed
+        # (VERDICT r4 item 9).  A second model / optimizer / captured step in the same process; a failure is reported, not fatal.
+        try:
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            strong = measure(args.workload, args.steps, args.warmup, False, scaling="strong")
+            if out is not None:
+                out["strong"] = {k: strong[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config",
+                                                         "final_loss", "host_enqueue_ms_per_step") if k in strong}
+        except Exception as e:  # noqa: BLE001
+            if out is not None:
+                out["strong"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if distributed:
         torch.cuda.synchronize()
         dist.barrier()     # every rank is past its timed region and its part of the result

@@ -89,6 +89,9 @@ class DistributedDataParallel(nn.Module):
         self._pending = []  # (bucket index, flat tensor, staged?, work handle)
         self._callback_queued = False
         self._folded = None          # the fused optimizer that applies 1 / world (fold_average_into), else None
+        # True: the hooks do nothing -- the gradient exchange is done elsewhere (the two-graph captured step reduces the flat
+        # gradient buffers between its graphs with an eager collective, megreader_amd.dropin / bench.py --ddp-mode graph2)
+        self.suspended = False
         self._fold_seen_step = None
         for p in self._params:
             hook = self._make_hook()
@@ -103,6 +106,14 @@ class DistributedDataParallel(nn.Module):
         """Declare that `param` is used `uses` times per forward (its gradient is complete only after that many
         accumulations): its bucket is then reduced from the end-of-backward callback instead of the first hook."""
         self._uses[id(param)] = int(uses)
+
+    def unfold_average(self):
+        """Undo fold_average_into: the shim scales the reduced buffers itself again."""
+        if self._folded is not None:
+            if self.gradient_average:
+                self._folded.set_grad_scale(1.0)
+            self._folded = None
+            self._fold_seen_step = None
 
     def fold_average_into(self, optimizer):
         """OPT-IN: let a fused optimizer (megreader_amd.optim) apply the 1 / world_size of the gradient average inside its
@@ -128,6 +139,8 @@ class DistributedDataParallel(nn.Module):
     # ------------------------------------------------------------------ hooks
     def _make_hook(self):
         def hook(param):
+            if self.suspended:       # somebody else exchanges the gradients (two-graph step: runtime.GraphedTrainStep(grad_sync=))
+                return
             if not self._callback_queued:
                 _engine_callback(self._finalize)
                 self._callback_queued = True
@@ -195,13 +208,14 @@ class DistributedDataParallel(nn.Module):
         from ...nn.functional import flush_deferred_wgrads
         flush_deferred_wgrads()
         if self._folded is not None:
-            steps = getattr(self._folded, "_py_steps", 0)
+            # (zero_grad() and step() both advance the epoch: a skipped step -- zero_grad, then a new backward -- is legal)
+            steps = getattr(self._folded, "_grad_epoch", 0)
             if steps == self._fold_seen_step:
                 for _bucket, _flat, _staged, work in self._pending:
                     work.wait()          # collectives the hooks already issued: let them land before giving up the round
                 self._reset_round()
                 self._n_launched = self._n_staged = 0
-                raise RuntimeError("apex.parallel.DistributedDataParallel: a second backward() without optimizer.step() "
+                raise RuntimeError("apex.parallel.DistributedDataParallel: a second backward() without optimizer.step() / zero_grad() "
                                    "while the gradient average is folded into the optimizer (fold_average_into): the flat "
                                    "gradient buffer already holds the all-reduced sum and would be reduced again.  Use the "
                                    "default (unfolded) mode for gradient accumulation.")

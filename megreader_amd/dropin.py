@@ -58,7 +58,9 @@ def fuse_optimizers():
             _mr_original = orig
             _mr_fused = fused
 
-            def __new__(cls, params, *args, **kwargs):
+            def __new__(cls, params=None, *args, **kwargs):
+                if params is None:         # copy.deepcopy / pickle rebuild instances through cls.__new__(cls)
+                    return super().__new__(cls)
                 params = list(params)      # may be a generator: consumed once, handed on through the instance
                 if cls.__dict__.get("_mr_original") is orig:       # the alias itself, not a user subclass of it
                     flat = [p for g in params for p in g["params"]] if params and isinstance(params[0], dict) else params
@@ -103,6 +105,7 @@ class _GraphedTrainStep(object):
         self.calls = 0
         self.state = None     # (signature, static batch, graphed step, holder)
         self.disabled = False
+        self.mode = None      # "single" | "capture" | "graph2" once captured (_capture)
 
     @staticmethod
     def _signature(batch):
@@ -139,7 +142,7 @@ class _GraphedTrainStep(object):
                 return scalar_mean(l)
             try:
                 optimizer.push_hyper()     # no host->device copy may happen inside the capture
-                graphed = GraphedTrainStep(loss_fn, optimizer, [], warmup=0)
+                graphed = self._capture(model, optimizer, loss_fn)
             except Exception as e:  # noqa: BLE001 - a model that cannot be captured keeps training eagerly
                 torch.cuda.synchronize()
                 self.disabled = True
@@ -152,6 +155,52 @@ class _GraphedTrainStep(object):
         loss = graphed()
         self._log(trainer, loss, holder.get("metrics", {}), epoch, step)
         return loss.detach().clone()     # the graph's loss tensor is overwritten by the next replay
+
+    def _capture(self, model, optimizer, loss_fn):
+        """Single process: one graph.  Data parallel (`train.py -d`: structure/model.py:27-36 wraps the model in the apex shim):
+        'capture' -- the shim's bucketed all-reduces on its side stream are captured INSIDE the step graph (what bench.py
+        measures at N > 1; needs a collective backend that can be captured: RCCL), the 1 / world factor folded into the update
+        kernel; or 'graph2' -- [zero_grad, forward, backward] and [update] as two graphs with ONE eager in-place all-reduce of
+        the flat gradient buffers between them, the shim's hooks suspended (any backend).  MEGREADER_DDP_GRAPH =
+        auto (default: capture on nccl, falling back to graph2) | capture | graph2 | off (eager distributed step)."""
+        import torch
+        import torch.distributed as dist
+        from .apex.parallel import DistributedDataParallel as Shim
+        from .runtime import GraphedTrainStep, data_parallel_grad_sync
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        shim = model if isinstance(model, Shim) else None
+        if world <= 1 or shim is None:
+            if world > 1:
+                raise RuntimeError("distributed run without the apex.parallel shim around the model: no gradient exchange to capture")
+            self.mode = "single"
+            return GraphedTrainStep(loss_fn, optimizer, [], warmup=0)
+        want = os.environ.get("MEGREADER_DDP_GRAPH", "auto")
+        if want == "off":
+            raise RuntimeError("MEGREADER_DDP_GRAPH=off")
+        backend = dist.get_backend(shim.group)
+        if want == "capture" or (want == "auto" and backend == "nccl"):
+            try:
+                shim.fold_average_into(optimizer)
+                graphed = GraphedTrainStep(loss_fn, optimizer, [], warmup=0)
+                self.mode = "capture"
+                return graphed
+            except Exception as e:  # noqa: BLE001
+                shim.unfold_average()
+                if want == "capture":
+                    raise
+                torch.cuda.synchronize()
+                print("megreader_amd.dropin: in-graph collective capture failed (%s: %s); two graphs + eager all-reduce" %
+                      (type(e).__name__, e), file=sys.stderr)
+        shim.suspended = True
+        try:
+            sync = data_parallel_grad_sync(optimizer, group=shim.group, average=shim.gradient_average, fold=True)
+            graphed = GraphedTrainStep(loss_fn, optimizer, [], warmup=0, grad_sync=sync)
+        except Exception:
+            shim.suspended = False
+            optimizer.set_grad_scale(1.0)
+            raise
+        self.mode = "graph2"
+        return graphed
 
     def _upload(self, batch, static):
         """Host batch -> the graph's static tensors without stalling the host: H2D into one of two staging sets on a copy
@@ -218,7 +267,8 @@ def accelerate_trainer(trainer_cls, eager_steps=3):
 def install(reference_root=None, level="plugin", fused_optimizer=False, graph_step=False):
     """fused_optimizer=True: torch.optim.Adam / SGD resolve to the fused flat-buffer optimizers (fuse_optimizers()).
     graph_step=True: the reference's `trainer.Trainer.train_step` replays one captured hipGraph per step
-    (accelerate_trainer(); needs fused_optimizer and the reference tree on the path; distributed runs keep the eager step).
+    (accelerate_trainer(); needs fused_optimizer and the reference tree on the path; under `-d` the gradient exchange of the
+    apex shim is captured inside the graph, or runs eagerly between two graphs: _GraphedTrainStep._capture).
     Together they give the unchanged `train.py` the step bench.py measures.
 
     level="plugin" (default): the reference's `ops` package is replaced by megreader_amd.ops (our CTCLoss2DFunction).
@@ -268,12 +318,21 @@ def install(reference_root=None, level="plugin", fused_optimizer=False, graph_st
     def _reference_sync_bn():
         if not ref_root_for_config:
             return False
-        try:
-            cfg = importlib.import_module("config")
-        except ImportError:
-            return False
-        where = os.path.dirname(os.path.abspath(getattr(cfg, "__file__", None) or ""))
-        return where == ref_root_for_config and bool(getattr(cfg, "sync_bn", False))
+        # the reference's OWN config.py, by path: an unrelated importable module called `config` is neither executed nor read
+        cfg = sys.modules.get("config")
+        where = os.path.dirname(os.path.abspath(getattr(cfg, "__file__", None) or "")) if cfg is not None else None
+        if where != ref_root_for_config:
+            path = os.path.join(ref_root_for_config, "config.py")
+            if not os.path.isfile(path):
+                return False
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("_megreader_reference_config", path)
+            cfg = importlib.util.module_from_spec(spec)
+            try:
+                spec.loader.exec_module(cfg)
+            except Exception:  # noqa: BLE001
+                return False
+        return bool(getattr(cfg, "sync_bn", False))
     _resnet.set_sync_bn_source(_reference_sync_bn)
     installed = {}
     for pkg, (ours, names) in OVERRIDES.items():

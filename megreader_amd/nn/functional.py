@@ -538,6 +538,24 @@ POINTWISE_STRIDED_DGRAD = os.environ.get("MEGREADER_POINTWISE_STRIDED_DGRAD", "1
 BNB_EPILOGUE = os.environ.get("MEGREADER_BNB_EPILOGUE", "0") == "1"
 
 
+_DIST_GUARD = {"done": False}
+
+
+def _no_resident_grids_beside_collectives():
+    """The one-pass BatchNorm backward needs its whole grid resident at once (slab barrier).  Beside a collective kernel of
+    ANOTHER stream -- any data-parallel run, whoever issues the collectives: the apex shim, torch's own DistributedDataParallel,
+    SyncBatchNorm with user code -- workgroups could wait for CUs a collective holds, for as long as a slow peer takes.  Once
+    torch.distributed is initialised with more than one rank the two-launch backward is used (not only when the
+    shim is constructed).  Checked at every BatchNorm backward until a process group exists; one attribute lookup afterwards."""
+    if _DIST_GUARD["done"]:
+        return
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        from ..runtime import no_resident_grid_kernels_beside_collectives
+        no_resident_grid_kernels_beside_collectives(dist.get_world_size())
+        _DIST_GUARD["done"] = True
+
+
 class BnBwdLink(object):
     """Backward hand-over between a training-mode BatchNorm and the ONE convolution that consumes its output: the tensors the
     BatchNorm's backward reductions need (filled by BatchNormFn.forward), and -- once that convolution's backward has run --
@@ -645,6 +663,7 @@ class BatchNormFn(Function):
     def backward(ctx, gy):
         if not ctx.training_mode:
             raise NotImplementedError("backward through eval-mode BatchNorm is not on the training hot path")
+        _no_resident_grids_beside_collectives()
         xi, y, gamma, mean, rstd = ctx.saved_tensors
         dtype = ctx.dtype
         dt = dtype_code(dtype)

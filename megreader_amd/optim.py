@@ -22,7 +22,10 @@ class _FlatOptimizer(torch.optim.Optimizer):
     def __init__(self, params, defaults):
         super().__init__(params, defaults)
         self._flat = None  # per group: dict(p=, g=, s1=, s2=, hyper=, n=)
-        self._py_steps = 0  # host-side count of step() calls (the DDP shim's one-backward-per-step check while folded)
+        self._py_steps = 0  # host-side count of step() calls
+        # advanced by zero_grad() AND step(): "the flat gradient buffer was cleared / consumed since then" (the DDP shim's
+        # one-backward-per-round check while the gradient average is folded into the update kernel)
+        self._grad_epoch = 0
 
     # ------------------------------------------------------------------ flat storage
     def _materialize(self):
@@ -77,6 +80,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         device step counter) and the parameters' home are NEVER dropped once created."""
         if self._flat is None:
             self._materialize()
+        self._grad_epoch += 1
         segments, devices = [], []
         for f in self._flat:
             if f is not None:
@@ -151,6 +155,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         if self._flat is None:
             self._materialize()
         self._py_steps += 1
+        self._grad_epoch += 1
         for group, f in zip(self.param_groups, self._flat):
             if f is None:
                 continue

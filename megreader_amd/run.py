@@ -2,9 +2,10 @@
 
     cd <MegReader checkout> && python -m megreader_amd.run train.py experiments/recognition/crnn.yaml --batch_size 256
 
-The optimizer named by the YAML (torch.optim.Adam / SGD) resolves to the fused flat-buffer optimizers and, for single-process
-runs, `Trainer.train_step` replays one captured hipGraph per step (MEGREADER_FAST=0 switches both off: the reference's own
-eager step on the HIP modules).
+The optimizer named by the YAML (torch.optim.Adam / SGD) resolves to the fused flat-buffer optimizers and `Trainer.train_step`
+replays one captured hipGraph per step -- with `-d` the gradient all-reduce of the apex shim is captured inside it
+(MEGREADER_DDP_GRAPH=auto|capture|graph2|off) -- MEGREADER_FAST=0 switches both off: the reference's own eager step on the HIP
+modules.
 """
 import os
 import runpy
@@ -18,8 +19,7 @@ def main():
     root = os.path.dirname(os.path.abspath(script))
     from . import dropin
     fast = os.environ.get("MEGREADER_FAST", "1") != "0"
-    distributed = "-d" in sys.argv or "--distributed" in sys.argv or int(os.environ.get("WORLD_SIZE", "1")) > 1
-    dropin.install(root, fused_optimizer=fast, graph_step=fast and not distributed)
+    dropin.install(root, fused_optimizer=fast, graph_step=fast)     # distributed (-d) too: dropin._GraphedTrainStep._capture
     sys.argv = sys.argv[1:]
     runpy.run_path(script, run_name="__main__")
 

@@ -410,13 +410,18 @@ class _FoldOpt(object):
     def __init__(self, params):
         self.param_groups = [{"params": list(params)}]
         self.scale = None
-        self._py_steps = 0
+        self._grad_epoch = 0
 
     def set_grad_scale(self, s):
         self.scale = s
 
+    def zero_grad(self):          # the fused optimizers advance the epoch in zero_grad() and in step()
+        self._grad_epoch += 1
+        for p in self.param_groups[0]["params"]:
+            p.grad = None
+
     def step(self):
-        self._py_steps += 1
+        self._grad_epoch += 1
 
 
 def test_folded_average_allows_one_backward_per_step():
@@ -447,6 +452,9 @@ def test_folded_average_allows_one_backward_per_step():
         net.zero_grad()
         ddp(x).mean().backward()                          # the shim recovers after the error
         assert ddp.last_backward["all_reduces"] == ddp.last_backward["buckets"]
+        opt.zero_grad()                                   # a SKIPPED step (overflow / NaN loss): zero_grad, then a new backward
+        ddp(x).mean().backward()                          # ... is legal: the flat buffer was cleared
+        opt.step()
     finally:
         dist.destroy_process_group()
 

@@ -259,6 +259,85 @@ def test_sync_batch_norm_two_processes_one_gpu():
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# The graphed DATA-PARALLEL drop-in step: `python -m megreader_amd.run train.py ... -d` wraps the model in the
+# apex shim (structure/model.py:27-36) and `Trainer.train_step` is replaced by dropin._GraphedTrainStep.  Two processes share the
+# box's one GPU over gloo, which cannot be captured into a hipGraph: the step runs in 'graph2' mode ([zero_grad, forward,
+# backward] graph, ONE eager all-reduce of the flat gradient buffer, [update] graph; the shim's hooks suspended).  Checked
+# against the eager shim (bucketed all-reduces from the hooks) on the same batches: same parameters after the same steps, on both
+# ranks.
+# ---------------------------------------------------------------------------------------------------------------
+def _dropin_ddp_worker(rank, world, port, q):
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    sys.path.insert(0, os.path.join(repo, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MEGREADER_DDP_GRAPH"] = "auto"
+    import torch.distributed as d
+    d.init_process_group("gloo", rank=rank, world_size=world)
+    import megreader_amd as m
+    from megreader_amd import dropin
+    from megreader_amd.apex.parallel import DistributedDataParallel
+    from megreader_amd.synthetic import recognition_batch
+    from test_dropin_fast_gpu import MiniTrainer, SequenceRecognitionModel
+    m.set_compute_dtype(torch.float32)
+    dropin.fuse_optimizers()
+    dev = torch.device("cuda")
+    batches = [recognition_batch(4, 32, 64, seed=10 * s + rank) for s in range(7)]     # every rank its own shard
+
+    def run(accelerated):
+        torch.manual_seed(0)
+        model = SequenceRecognitionModel(dev).train()
+        net = DistributedDataParallel(model)                 # structure/model.py:34
+        opt = getattr(torch.optim, 'Adam')(net.parameters(), lr=1e-3)
+
+        class T(MiniTrainer):
+            pass
+        wrapper = dropin.accelerate_trainer(T, eager_steps=2) if accelerated else None
+        tr = T()
+        losses = [float(tr.train_step(net, opt, b, epoch=0, step=i)) for i, b in enumerate(batches)]
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().reshape(-1).float() for p in model.parameters()]).cpu()
+        return losses, flat, (wrapper.mode if wrapper is not None else None), (wrapper.calls if wrapper is not None else 0)
+
+    l0, p0, _, _ = run(False)
+    l1, p1, mode, calls = run(True)
+    q.put((rank, l0, l1, p0.numpy(), p1.numpy(), mode, calls))
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_graphed_dropin_step_two_processes_one_gpu_graph2():
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dropin_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        item = q.get(timeout=600)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        l0, l1, p0, p1, mode, calls = res[r]
+        assert mode == "graph2" and calls == 7            # gloo cannot be captured: two graphs + an eager all-reduce
+        assert np.all(np.isfinite(l1))
+        # same trajectory as the eager shim (float32 compute; summation order of the atomics is the only difference)
+        assert np.abs(np.array(l0) - np.array(l1)).max() < 2e-4 * max(1.0, np.abs(l0).max())
+        # (Adam normalises the update: an element whose gradient is round-off noise may move by +-lr per step in either run)
+        assert np.abs(p0 - p1).max() <= 2.5 * 1e-3 * 7 and np.abs(p0 - p1).mean() < 2e-5
+    # the ranks hold the same model after every exchange
+    assert np.abs(res[0][3] - res[1][3]).max() < 1e-6 * np.abs(res[0][3]).max()
+    assert np.abs(res[0][2] - res[1][2]).max() < 1e-6 * np.abs(res[0][2]).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # The RCCL tests proper: each body above in its own process (module docstring).
 # ---------------------------------------------------------------------------------------------------------------
 _BODIES = {
