@@ -94,7 +94,70 @@ def _timed_step(case, always=(), replay_bar=1e-3):
           % (what, worst_l2[1], worst_l2[0], worst_el[1], worst_el[0]))
     REPORT[what + " | replay vs eager"] = {"worst_l2": worst_l2, "worst_elem": worst_el}
     assert worst_l2[1] <= replay_bar, (worst_l2, worst_el)
+    del graphed, eager
+    _bf16_drift(case, named, losses[1])
     return producers
+
+
+# bf16 bars per configuration: (relative L2 error, cosine) of a parameter's gradient against the float64 oracle, for parameters
+# whose name starts with one of the prefixes, first match wins; "" = everything else.  bf16 is the BENCHMARKED dtype; the
+# reference has no bf16 path, so this is drift of another precision (not parity): the bars are ~1.5 x what the replayed step
+# measured on the MI355X (profiles/r05_bf16_drift_timed_step.txt) and exist to catch a kernel that drifts further.
+BF16_BARS = {}
+
+
+def _bf16_drift(case, named32, loss32):
+    """the step that is TIMED runs in bf16.  Same weights, same batch, fused optimizer (lr = 0), two eager
+    steps and a hipGraph replay in bf16; every parameter's gradient out of the REPLAY against the float64 oracle."""
+    import gc
+    gc.collect()
+    mr.set_compute_dtype(torch.bfloat16)
+    what = case["what"].replace("fp32", "bf16")
+    model = case["build"]()
+    batch = _cases.to_device(case["batch"])
+    grads64 = case["grads64"]
+    named = [(k, p) for k, p in model.named_parameters() if k in grads64]
+    opt = case["optimizer"](model.parameters())
+    loss_fn = case["loss_fn"]
+    for _ in range(2):
+        opt.zero_grad()
+        loss = loss_fn(model, batch)
+        loss.backward()
+        opt.step()
+        l16 = float(loss)
+        del loss
+    graphed = GraphedTrainStep(lambda: loss_fn(model, batch), opt, [], warmup=1)
+    for _ in range(2):
+        gl = graphed()
+    torch.cuda.synchronize()
+    print("%s: loss eager %.6f, replay %.6f (fp32 %.6f)" % (what, l16, float(gl), loss32))
+    assert abs(float(gl) - l16) <= 2e-3 * max(1.0, abs(l16)), (float(gl), l16)
+    assert abs(l16 - loss32) <= 5e-2 * max(1.0, abs(loss32)), (l16, loss32)
+    bars = BF16_BARS.get(case["what"])
+    rows, bad = [], []
+    for k, p in named:
+        go, g = grads64[k].double().flatten(), p.grad.double().cpu().flatten()
+        if float(go.abs().max()) < 1e-7:
+            continue
+        l2 = float((g - go).norm() / go.norm())
+        cos = float(torch.dot(g, go) / (g.norm() * go.norm() + 1e-300))
+        rows.append((k, float(go.norm()), l2, cos))
+        if bars is not None:
+            for prefix, (l2_bar, cos_bar) in bars:
+                if k.startswith(prefix):
+                    if not (l2 <= l2_bar and cos >= cos_bar):
+                        bad.append((k, l2, cos, l2_bar, cos_bar))
+                    break
+    print("%s: per-parameter gradient of the hipGraph replay vs the f64 oracle (relative L2 error, cosine), %d parameters" %
+          (what, len(rows)))
+    for k, gn, l2, cos in rows:
+        print("   %-60s |g| %.3e   l2 %.4f  cos %.5f" % (k, gn, l2, cos))
+    worst = sorted(rows, key=lambda r: -r[2])[:5]
+    print("BF16-DRIFT %s: worst l2 %s | lowest cosine %s" %
+          (what, ", ".join("%s %.3f" % (r[0], r[2]) for r in worst),
+           ", ".join("%s %.4f" % (r[0], r[3]) for r in sorted(rows, key=lambda r: r[3])[:5])))
+    REPORT[what + " | bf16 replay drift"] = {"worst_l2": worst[0][:3] if worst else None}
+    assert not bad, bad[:10]
 
 
 def _isolated(name, always=(), replay_bar=1e-3):
@@ -111,6 +174,10 @@ def _isolated(name, always=(), replay_bar=1e-3):
                              capture_output=True, text=True, timeout=900)
     text = out.stdout + out.stderr
     print("\n".join(ln for ln in out.stdout.splitlines() if not ln.startswith("   ")))
+    dump = os.environ.get("MEGREADER_TIMED_STEP_DUMP")
+    if dump:      # the per-parameter tables (lines starting with three blanks) for profiles/
+        with open(dump, "a") as f:
+            f.write(out.stdout)
     assert out.returncode == 0, "child exited with %d\n%s" % (out.returncode, text[-3000:])
     res = [ln for ln in out.stdout.splitlines() if ln.startswith("TIMED-STEP-OK ")]
     assert res, text[-2000:]
