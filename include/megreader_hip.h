@@ -444,6 +444,15 @@ int mr_dcn2_bwd(int dtype, const void* dy, const void* x, const void* w_t, const
                 const float* mask, long long msk_bs, void* col_ws, float* dx32, float* doffset, float* dmask, float* dw,
                 float* dbias, int N, int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int Ho,
                 int Wo, hipStream_t stream);
+/* host only: 1 when mr_dcn2_bwd2 can write the input gradient in `dtype` directly (dx_t) for this shape */
+int mr_dcn2_dx_direct(int dtype, int N, int H, int W, int C, int Co, int kh, int kw);
+/* mr_dcn2_bwd with: dx_t (nullable, INSTEAD of dx32) = the input gradient in `dtype`, overwritten (no zero fill, no conversion
+ * pass; only where mr_dcn2_dx_direct says 1); flags bit 0 = col_ws was zeroed once and has been used by this function only
+ * since (its counters clean themselves): the memset node in front of the CSR build is dropped. */
+int mr_dcn2_bwd2(int dtype, const void* dy, const void* x, const void* w_t, const float* offset, long long off_bs,
+                 const float* mask, long long msk_bs, void* col_ws, float* dx32, void* dx_t, int flags, float* doffset,
+                 float* dmask, float* dw, float* dbias, int N, int H, int W, int C, int Co, int kh, int kw, int stride, int pad,
+                 int dil, int Ho, int Wo, hipStream_t stream);
 /* Packed offset/mask operand of the deformable ResNet blocks (reference backbones/resnet.py:125-142: offset_mask =
  * conv2_offset(x); conv2(x, offset_mask[:, :18], offset_mask[:, -9:].sigmoid())).  raw = the offset conv's output, NHWC
  * [N][HW][ld] in `dtype` (channels n_offset + n_mask <= ld).  mr_dcn_unpack writes the flat f32 NCHW offset [N][n_offset][HW]

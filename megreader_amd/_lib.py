@@ -80,6 +80,7 @@ SIGNATURES = {
     "mr_dcn2_col2im": "ipplplp" + "i" * 11 + "s",
     "mr_dcn2_fwd": "ippp" + "plpl" + "pp" + "i" * 12 + "s",
     "mr_dcn2_bwd": "ippp" + "plpl" + "pppppp" + "i" * 12 + "s",
+    "mr_dcn2_bwd2": "ippp" + "plpl" + "pppi" + "pppp" + "i" * 12 + "s",
     "mr_dcn_unpack": "ipippiiiis",
     "mr_dcn_pack_grad": "ippppiiiiis",
     "mr_db_components": "pfpppiiii" + "s",
@@ -240,6 +241,8 @@ def load():
     lib.mr_bn_scratch_doubles.argtypes = [ctypes.c_int]
     lib.mr_dcn2_ws_bytes.restype = ctypes.c_longlong
     lib.mr_dcn2_ws_bytes.argtypes = [ctypes.c_int] * 11
+    lib.mr_dcn2_dx_direct.restype = ctypes.c_int
+    lib.mr_dcn2_dx_direct.argtypes = [ctypes.c_int] * 8
     if hasattr(lib, "mr_set_tn_abl"):      # only libmegreader_hip_abl.so (tools build, include/megreader_hip_ablation.h)
         lib.mr_set_tn_abl.restype = ctypes.c_int
         lib.mr_set_tn_abl.argtypes = [ctypes.c_int]
@@ -285,7 +288,7 @@ def load():
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_tuning_get", "mr_tuning_set", "mr_tuning_defaults",
              "mr_stem_bwd_workspace", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_dcn2_ws_bytes", "mr_bn_scratch_doubles",
              "mr_sizeof_img_desc", "mr_nt_kernel_code", "mr_tn_taps_would_run", "mr_set_tn_taps_workspace",
-             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending")  # entry points that take no stream and launch nothing
+             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending", "mr_dcn2_dx_direct")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

@@ -20,9 +20,10 @@ long long dcn_fused_ws_bytes(int N, int H, int W, int Ho, int Wo, int taps);
 int dcn_fused_fwd(int dtype, const void* x, const void* w_n, const float* bias, const float* offset, const float* mask,
                   void* y, void* ws, const DcnGeom& g, int Co, hipStream_t stream);
 long long dcn_fused_fwd_ws_bytes(int N, int Ho, int Wo, int Co, int taps);
+bool dcn_fused_dx_direct(int N, int H, int W, int C, int taps);
 int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, const float* offset, const float* mask,
-                  void* ws, float* dx32, float* doffset, float* dmask, float* dw, float* dbias, const DcnGeom& g, int Co,
-                  hipStream_t stream);
+                  void* ws, float* dx32, void* dx_t, int flags, float* doffset, float* dmask, float* dw, float* dbias,
+                  const DcnGeom& g, int Co, hipStream_t stream);
 
 // col[p, tap*C + c] = valid ? mask * bilinear(x[n,:,:,c], p_tap) : 0     thread = (p, tap, 16-byte channel vector)
 template <typename T>
@@ -510,12 +511,30 @@ int mr_dcn2_bwd(int dtype, const void* dy, const void* x, const void* w_t, const
                 const float* mask, long long msk_bs, void* col_ws, float* dx32, float* doffset, float* dmask, float* dw,
                 float* dbias, int N, int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int Ho,
                 int Wo, hipStream_t stream) {
+  return mr_dcn2_bwd2(dtype, dy, x, w_t, offset, off_bs, mask, msk_bs, col_ws, dx32, nullptr, 0, doffset, dmask, dw, dbias, N, H,
+                      W, C, Co, kh, kw, stride, pad, dil, Ho, Wo, stream);
+}
+
+// host only: 1 when mr_dcn2_bwd2 can write the input gradient directly in the compute dtype (dx_t) for this shape
+int mr_dcn2_dx_direct(int dtype, int N, int H, int W, int C, int Co, int kh, int kw) {
+  return (dcn_fused_ok(dtype, H, W, C, Co, kh, kw) && dcn_fused_dx_direct(N, H, W, C, kh * kw)) ? 1 : 0;
+}
+
+// mr_dcn2_bwd with two launch-saving options of the fused path (round 5; the 13 DCN layers of the batch-2 detector are ~10
+// launch-floor-sized launches each): dx_t (nullable, instead of dx32) = the input gradient in `dtype`, OVERWRITTEN -- no zero
+// fill in front, no conversion pass behind (only where mr_dcn2_dx_direct says 1); flags bit 0 = the workspace is one that was
+// zeroed ONCE and has since been used by this function only (its counters return to zero by themselves): no memset node.
+int mr_dcn2_bwd2(int dtype, const void* dy, const void* x, const void* w_t, const float* offset, long long off_bs,
+                 const float* mask, long long msk_bs, void* col_ws, float* dx32, void* dx_t, int flags, float* doffset,
+                 float* dmask, float* dw, float* dbias, int N, int H, int W, int C, int Co, int kh, int kw, int stride, int pad,
+                 int dil, int Ho, int Wo, hipStream_t stream) {
   if (dcn_fused_ok(dtype, H, W, C, Co, kh, kw)) {
     DcnGeom g;
     int rcg = make_geom(g, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo, off_bs, msk_bs);
     if (rcg) return rcg;
-    return dcn_fused_bwd(dtype, dy, x, w_t, offset, mask, col_ws, dx32, doffset, dmask, dw, dbias, g, Co, stream);
+    return dcn_fused_bwd(dtype, dy, x, w_t, offset, mask, col_ws, dx32, dx_t, flags, doffset, dmask, dw, dbias, g, Co, stream);
   }
+  MR_CHECK_ARG(dx_t == nullptr, "mr_dcn2_bwd2: dx_t needs the fused path (mr_dcn2_dx_direct)");
   MR_CHECK_ARG(col_ws != nullptr, "mr_dcn2_bwd: workspace missing (mr_dcn2_ws_bytes)");
   const int K = kh * kw * C, P = N * Ho * Wo;
   int rc = MR_OK;

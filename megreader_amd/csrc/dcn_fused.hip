@@ -86,6 +86,7 @@ struct DcnFusedArgs {
   float* doffset;
   float* dmask;
   float* dx;
+  void* dx_t;            // dx in the compute dtype, OVERWRITTEN (no zero fill, no conversion pass); only with tsplit == 1
   const int* start;      // CSR row starts, [Q*taps + 1]
   const int2* entries;   // CSR entries {output pixel p, bits of the bilinear * mask weight}
   float* y32;            // fwd with tap splits: f32 [P][Co] accumulator (zeroed), converted by dcn_finish_kernel
@@ -573,6 +574,10 @@ __global__ __launch_bounds__(256) void dcn2_dx_fused_kernel(DcnFusedArgs a) {
       const int q = m0 + wm_ * Nt::WTM + j * 16 + l15;
       const int n = n0 + wn_ * Nt::WTN + i * 16 + lg * 4;
       if (q >= a.Q) continue;
+      if (a.dx_t) {                      // the complete sum of this element: written once, in the compute dtype
+        store4((T*)a.dx_t + (long long)q * g.C + n, acc[i][j]);
+        continue;
+      }
       float* dst = a.dx + (long long)q * g.C + n;
       if (a.tsplit > 1) {                // several workgroups (tap groups) add into the same elements
 #pragma unroll
@@ -668,9 +673,23 @@ __global__ __launch_bounds__(256) void scan_blocks_kernel(int* __restrict__ bsum
   }
 }
 
-__global__ __launch_bounds__(256) void scan_write_kernel(const int* __restrict__ in, const int* __restrict__ bofs,
+// bsum = the RAW block totals of scan_sums_kernel: every block adds up the totals in front of it itself (a few hundred ints:
+// cheaper than the one-block launch that used to scan them -- 5 us of launch floor per DCN layer at batch 2)
+__global__ __launch_bounds__(256) void scan_write_kernel(const int* __restrict__ in, const int* __restrict__ bsum,
                                                          int* __restrict__ out, int n) {
   __shared__ int sh[4];
+  __shared__ int sh_off;
+  {
+    int part = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += bsum[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) sh_off = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+  }
+  const int block_off = sh_off;
   const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
   int v[SCAN_ITEMS], s = 0;
 #pragma unroll
@@ -679,7 +698,7 @@ __global__ __launch_bounds__(256) void scan_write_kernel(const int* __restrict__
     s += v[j];
   }
   int total;
-  int run = bofs[blockIdx.x] + block_excl_scan(s, sh, total);
+  int run = block_off + block_excl_scan(s, sh, total);
 #pragma unroll
   for (int j = 0; j < SCAN_ITEMS; ++j) {
     const int idx = base + j;
@@ -1020,9 +1039,17 @@ long long dcn_fused_ws_bytes(int N, int H, int W, int Ho, int Wo, int taps) {
   return (long long)dcn_ws_layout(nullptr, (long long)N * H * W, (long long)N * Ho * Wo, taps).bytes;
 }
 
+// 1 when the fused input-gradient kernel runs un-split for this shape, i.e. can write dx directly in the compute dtype
+bool dcn_fused_dx_direct(int N, int H, int W, int C, int taps) {
+  const long long tiles_q = cdivll((long long)N * H * W, 64);
+  return dcn_tap_split(tiles_q * (C / (C % 128 == 0 ? 128 : 64)), taps) == 1;
+}
+
+// dx_t (nullable, instead of dx32): dx in the compute dtype, overwritten.  flags bit 0: the counter region of `ws` is already
+// zero (a workspace that only this function has used since it was zeroed: the fill pass returns every counter to zero).
 int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, const float* offset, const float* mask,
-                  void* ws, float* dx32, float* doffset, float* dmask, float* dw, float* dbias, const DcnGeom& g, int Co,
-                  hipStream_t stream) {
+                  void* ws, float* dx32, void* dx_t, int flags, float* doffset, float* dmask, float* dw, float* dbias,
+                  const DcnGeom& g, int Co, hipStream_t stream) {
   const int taps = g.kh * g.kw;
   const long long Q = (long long)g.N * g.H * g.W, P = (long long)g.N * g.Ho * g.Wo;
   MR_CHECK_ARG(Q * taps < (1ll << 31) - SCAN_BLOCK && P * taps * 4 < (1ll << 31) && Q * g.C < (1ll << 31),
@@ -1030,6 +1057,10 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
   DcnFusedArgs a = {};
   a.x = x; a.w = w_t; a.dy = dy; a.offset = offset; a.mask = mask; a.doffset = doffset; a.dmask = dmask; a.dx = dx32;
   a.g = g; a.Co = Co; a.P = (int)P; a.Q = (int)Q; a.tsplit = 1;
+  a.dx_t = nullptr;
+  MR_CHECK_ARG(!(dx32 && dx_t), "dcn backward: dx32 and dx_t are alternatives");
+  MR_CHECK_ARG(!dx_t || dcn_fused_dx_direct(g.N, g.H, g.W, g.C, taps),
+               "dcn backward: this shape splits the input gradient over tap groups (ask mr_dcn2_dx_direct first)");
   const int tiles_p = cdiv((int)P, 64);
   // The three parts below are independent of each other (each reads dy / x / w / offset / mask and writes its own outputs):
   // a caller may ask for any subset by passing null for the outputs of the others, e.g. to run them on parallel streams.
@@ -1045,10 +1076,10 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
     MR_CHECK_LAUNCH();
   }
   // ---- input gradient: CSR of the scatter pattern, then the gather-GEMM
-  if (dx32) {
+  if (dx32 || dx_t) {
     MR_CHECK_ARG(ws != nullptr, "dcn backward: workspace missing (mr_dcn2_ws_bytes)");
     DcnWs w = dcn_ws_layout(ws, Q, P, taps);
-    if (hipMemsetAsync(w.count, 0, (size_t)w.nkeys * 4, stream) != hipSuccess) {
+    if (!(flags & 1) && hipMemsetAsync(w.count, 0, (size_t)w.nkeys * 4, stream) != hipSuccess) {
       mr::set_error("dcn backward: hipMemsetAsync failed");
       return MR_ERR_LAUNCH;
     }
@@ -1056,7 +1087,6 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
     hipLaunchKernelGGL((dcn_csr_kernel<false>), dim3(items), dim3(256), 0, stream, offset, mask, w.count,
                        (const int*)nullptr, (int2*)nullptr, g, (int)P);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(w.nblocks), dim3(256), 0, stream, (const int*)w.count, w.bsum, w.nkeys);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, stream, w.bsum, w.nblocks);
     hipLaunchKernelGGL(scan_write_kernel, dim3(w.nblocks), dim3(256), 0, stream, (const int*)w.count, (const int*)w.bsum,
                        w.start, w.nkeys);
     hipLaunchKernelGGL((dcn_csr_kernel<true>), dim3(items), dim3(256), 0, stream, offset, mask, w.count,
@@ -1064,6 +1094,7 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
     MR_CHECK_LAUNCH();
     a.start = w.start;
     a.entries = w.entries;
+    a.dx_t = dx_t;
     const int tiles_q = cdiv((int)Q, 64);
     a.tsplit = dcn_tap_split((long long)tiles_q * (g.C / (g.C % 128 == 0 ? 128 : 64)), taps);
     if (g.C % 128 == 0) {
