@@ -391,6 +391,13 @@ int mr_nearest_up_fwd(int dtype, const void* x, const void* add, void* y, int N,
                       int coff, hipStream_t stream);
 int mr_nearest_up_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int s, int lddy, int coff,
                       hipStream_t stream);
+/* nn.ConvTranspose2d(cin, cout, 2, 2) of the DB heads (decoders/seg_detector.py:66-79) = a GEMM y2[p, co*4 + i*2 + j] = sum_ci
+ * x[p, ci] W[ci, co, i, j] (mr_gemm_nt on the weight's own [Cin][Cout*4] matrix) + this depth-to-space pass with the bias:
+ * y[n, 2h+i, 2w+j, co] = y2[p, (co, i, j)] + bias[co].  y2 [N*H*W][ld2 >= 4*C], y NHWC [N, 2H, 2W, C], bias f32 nullable. */
+int mr_deconv2x2_d2s(int dtype, const void* y2, int ld2, const float* bias, void* y, int N, int H, int W, int C,
+                     hipStream_t stream);
+/* the inverse gather for backward: dy2[p, (co, i, j)] = dy[n, 2h+i, 2w+j, co], columns 4*C .. ld2-1 zero */
+int mr_deconv2x2_s2d(int dtype, const void* dy, void* dy2, int ld2, int N, int H, int W, int C, hipStream_t stream);
 int mr_copy_channels(int dtype, const void* src, int lds, int soff, void* dst, int ldd, int doff, long long P, int C,
                      hipStream_t stream);
 /* dx [N, H, W, C] <- the gradient of the sub-sampling x[:, ::sh, ::sw, :]: dxs [N, Ho, Wo, C] at the sampled positions, zeros
@@ -444,6 +451,8 @@ int mr_dcn2_bwd(int dtype, const void* dy, const void* x, const void* w_t, const
                 const float* mask, long long msk_bs, void* col_ws, float* dx32, float* doffset, float* dmask, float* dw,
                 float* dbias, int N, int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int Ho,
                 int Wo, hipStream_t stream);
+/* host only: 1 when the fused kernels serve this shape (C and Co multiples of 64, at most 9 taps, mr_tuning.dcn_fused) */
+int mr_dcn2_fused(int dtype, int H, int W, int C, int Co, int kh, int kw);
 /* host only: 1 when mr_dcn2_bwd2 can write the input gradient in `dtype` directly (dx_t) for this shape */
 int mr_dcn2_dx_direct(int dtype, int N, int H, int W, int C, int Co, int kh, int kw);
 /* mr_dcn2_bwd with: dx_t (nullable, INSTEAD of dx32) = the input gradient in `dtype`, overwritten (no zero fill, no conversion

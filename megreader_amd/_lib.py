@@ -72,6 +72,8 @@ SIGNATURES = {
     "mr_nearest_up_fwd": "ippp" + "i" * 7 + "s",
     "mr_nearest_up_bwd": "ipp" + "i" * 7 + "s",
     "mr_copy_channels": "ipiipiilis",
+    "mr_deconv2x2_d2s": "ipippiiiis",
+    "mr_deconv2x2_s2d": "ippiiiiis",
     "mr_scale_channels": "ipppilis",
     "mr_ctc2d_head_fwd": "ipipipppiiiifs",
     "mr_ctc2d_head_bwd": "ippppipiiiiifs",
@@ -243,6 +245,8 @@ def load():
     lib.mr_dcn2_ws_bytes.argtypes = [ctypes.c_int] * 11
     lib.mr_dcn2_dx_direct.restype = ctypes.c_int
     lib.mr_dcn2_dx_direct.argtypes = [ctypes.c_int] * 8
+    lib.mr_dcn2_fused.restype = ctypes.c_int
+    lib.mr_dcn2_fused.argtypes = [ctypes.c_int] * 7
     if hasattr(lib, "mr_set_tn_abl"):      # only libmegreader_hip_abl.so (tools build, include/megreader_hip_ablation.h)
         lib.mr_set_tn_abl.restype = ctypes.c_int
         lib.mr_set_tn_abl.argtypes = [ctypes.c_int]
@@ -288,7 +292,7 @@ def load():
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_tuning_get", "mr_tuning_set", "mr_tuning_defaults",
              "mr_stem_bwd_workspace", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_dcn2_ws_bytes", "mr_bn_scratch_doubles",
              "mr_sizeof_img_desc", "mr_nt_kernel_code", "mr_tn_taps_would_run", "mr_set_tn_taps_workspace",
-             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending", "mr_dcn2_dx_direct")  # entry points that take no stream and launch nothing
+             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending", "mr_dcn2_dx_direct", "mr_dcn2_fused")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):
@@ -382,6 +386,26 @@ def dcn_workspace(dtype, N, H, W, C, Co, kh, kw, Ho, Wo, backward, device):
     if n <= 0:
         return None
     return torch.empty((n,), dtype=torch.uint8, device=device)
+
+
+_DCN_WS = {}
+
+
+def dcn_backward_workspace(dtype, N, H, W, C, Co, kh, kw, Ho, Wo, device):
+    """(workspace, flags) for mr_dcn2_bwd2.  Fused path: ONE persistent buffer per geometry, zeroed when it is created -- the CSR
+    build returns its counters to zero by itself, so later calls pass flags bit 0 and no memset node runs in front of them (13
+    DCN layers per detector step; layers of one geometry share the buffer, stream-ordered).  General path: a fresh buffer, 0."""
+    if not load().mr_dcn2_fused(dtype_code(dtype), H, W, C, Co, kh, kw):
+        return dcn_workspace(dtype, N, H, W, C, Co, kh, kw, Ho, Wo, True, device), 0
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), dtype, N, H, W, C, Co, kh, kw, Ho, Wo)
+    ws = _DCN_WS.get(key)
+    if ws is None:
+        n = load().mr_dcn2_ws_bytes(dtype_code(dtype), N, H, W, C, Co, kh, kw, Ho, Wo, 1)
+        if len(_DCN_WS) > 64:
+            _DCN_WS.clear()
+        ws = _DCN_WS[key] = torch.zeros((max(int(n), 16),), dtype=torch.uint8, device=dev)
+    return ws, 1
 
 
 def require_cuda(*tensors):

@@ -20,9 +20,9 @@ from torch.autograd import Function
 from torch.nn.modules.utils import _pair
 
 from .... import get_compute_dtype
-from ...._lib import call, dcn_workspace, dtype_code, ptr, vec_of
+from ...._lib import call, dcn_backward_workspace, dcn_workspace, dtype_code, load, ptr, vec_of
 from ....nn import prep
-from ....nn.functional import (_grad_internal, grad_sink, mark_zero_padded, notify_grad_ready, to_internal)
+from ....nn.functional import (ZeroArena, _grad_internal, grad_sink, mark_zero_padded, notify_grad_ready, to_internal)
 
 
 def _dcn_forward(ctx, input, off, msk, weight, bias, stride, padding, dilation, groups, deformable_groups):
@@ -71,7 +71,7 @@ def _dcn_forward(ctx, input, off, msk, weight, bias, stride, padding, dilation, 
     return y
 
 
-def _dcn_backward(ctx, grad_output, want_dx, want_dw, want_db):
+def _dcn_backward(ctx, grad_output, want_dx, want_dw, want_db, scratch_ok=False):
     """Shared backward: (grad_input NCHW view | None, grad_offset f32 NCHW, grad_mask f32 NCHW, grad_weight | None,
     grad_bias | None).  Parameter gradients go straight into the fused optimizers' gradient sinks when those exist
     (nn/functional.py grad_sink: no temporary, no `grad += tmp` launch) -- the returned gradient is then None."""
@@ -82,32 +82,45 @@ def _dcn_backward(ctx, grad_output, want_dx, want_dw, want_db):
     dev = xi.device
     K = kh * kw * C
     g = _grad_internal(grad_output, dtype)
-    col = dcn_workspace(dtype, N, H, W, C, Co, kh, kw, Ho, Wo, True, dev)   # CSR of the scatter / column matrix
+    col, ws_flags = dcn_backward_workspace(dtype, N, H, W, C, Co, kh, kw, Ho, Wo, dev)   # CSR of the scatter / column matrix
     weight, bias = ctx.params
     w_sink = grad_sink(weight, (Co, kh, kw, C)) if want_dw else None
     b_sink = grad_sink(bias, (Co,)) if want_db else None
+    # the input gradient straight in the compute dtype where the fused kernel runs un-split (every layer of the detector at
+    # batch 2): no zero fill in front of it, no conversion pass behind it
+    direct = bool(want_dx and load().mr_dcn2_dx_direct(dt, N, H, W, C, Co, kh, kw))
     # every accumulated output of mr_dcn2_bwd must arrive zeroed: ONE zero-fill for all of them (separate torch.zeros
-    # were 52 fill launches per DB step)
-    sizes = [off.numel(), msk.numel(), N * H * W * C if want_dx else 0, Co * K if (want_dw and w_sink is None) else 0,
-             Co if (want_db and b_sink is None) else 0]
+    # were 52 fill launches per DB step) -- or none: scratch_ok (the packed node consumes the offset / mask gradients before
+    # it returns) takes them from the pre-zeroed arena that zero_grad() clears with the gradient buffers
+    sizes = [off.numel(), msk.numel(), N * H * W * C if (want_dx and not direct) else 0,
+             Co * K if (want_dw and w_sink is None) else 0, Co if (want_db and b_sink is None) else 0]
     offs = [0]
     for n_ in sizes:
         offs.append(offs[-1] + (n_ + 63) // 64 * 64)
-    zbuf = torch.zeros((offs[-1],), dtype=torch.float32, device=dev)
+    zbuf = None
+    if scratch_ok and not any(sizes[2:]):
+        arena = ZeroArena.take(dev, (offs[-1] + 1) // 2)
+        if arena is not None:
+            zbuf = arena.view(torch.float32)[:offs[-1]]
+    if zbuf is None:
+        zbuf = torch.zeros((offs[-1],), dtype=torch.float32, device=dev)
     grad_offset = zbuf[offs[0]:offs[0] + sizes[0]].view(off.shape)
     grad_mask = zbuf[offs[1]:offs[1] + sizes[1]].view(msk.shape)
-    dx32 = zbuf[offs[2]:offs[2] + sizes[2]].view(N, H, W, C) if want_dx else None
+    dx32 = zbuf[offs[2]:offs[2] + sizes[2]].view(N, H, W, C) if (want_dx and not direct) else None
+    dxi = torch.empty((N, H, W, C), dtype=dtype, device=dev) if direct else None
     gw = gb = None
     if want_dw:
         gw = w_sink if w_sink is not None else zbuf[offs[3]:offs[3] + sizes[3]].view(Co, kh, kw, C)
     if want_db:
         gb = b_sink if b_sink is not None else zbuf[offs[4]:offs[4] + sizes[4]]
-    call("mr_dcn2_bwd", dt, ptr(g), ptr(xi), ptr(w_t), ptr(off), off_bs, ptr(msk), msk_bs, ptr(col), ptr(dx32),
-         ptr(grad_offset), ptr(grad_mask), ptr(gw), ptr(gb), N, H, W, C, Co, kh, kw, stride, padding, dilation, Ho,
+    call("mr_dcn2_bwd2", dt, ptr(g), ptr(xi), ptr(w_t), ptr(off), off_bs, ptr(msk), msk_bs, ptr(col), ptr(dx32), ptr(dxi),
+         ws_flags, ptr(grad_offset), ptr(grad_mask), ptr(gw), ptr(gb), N, H, W, C, Co, kh, kw, stride, padding, dilation, Ho,
          Wo)
     grad_input = None
     if want_dx:
-        if dtype == torch.float32:
+        if direct:
+            pass
+        elif dtype == torch.float32:
             dxi = dx32
         else:
             dxi = torch.empty((N, H, W, C), dtype=dtype, device=dev)
@@ -195,7 +208,7 @@ class ModulatedDeformConvPackedFunction(Function):
             raise NotImplementedError
         grad_input, grad_offset, grad_mask, grad_weight, grad_bias = _dcn_backward(
             ctx, grad_output, ctx.needs_input_grad[0], ctx.needs_input_grad[2],
-            ctx.with_bias and ctx.needs_input_grad[3])
+            ctx.with_bias and ctx.needs_input_grad[3], scratch_ok=True)
         g_raw = None
         if ctx.needs_input_grad[1]:
             msk = ctx.saved_tensors[2]

@@ -515,6 +515,9 @@ int mr_dcn2_bwd(int dtype, const void* dy, const void* x, const void* w_t, const
                       W, C, Co, kh, kw, stride, pad, dil, Ho, Wo, stream);
 }
 
+// host only: 1 when the fused kernels (dcn_fused.hip) serve this shape under the current mr_tuning.dcn_fused
+int mr_dcn2_fused(int dtype, int H, int W, int C, int Co, int kh, int kw) { return dcn_fused_ok(dtype, H, W, C, Co, kh, kw) ? 1 : 0; }
+
 // host only: 1 when mr_dcn2_bwd2 can write the input gradient directly in the compute dtype (dx_t) for this shape
 int mr_dcn2_dx_direct(int dtype, int N, int H, int W, int C, int Co, int kh, int kw) {
   return (dcn_fused_ok(dtype, H, W, C, Co, kh, kw) && dcn_fused_dx_direct(N, H, W, C, kh * kw)) ? 1 : 0;

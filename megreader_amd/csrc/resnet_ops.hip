@@ -413,6 +413,55 @@ __global__ void nearest_up_fwd_kernel(const T* __restrict__ x, const T* __restri
   }
 }
 
+// ---- ConvTranspose2d(k = 2, s = 2) as a GEMM + depth-to-space (decoders/seg_detector.py:66-79: the DB heads' two deconvolutions).
+// The GEMM leaves y2[p, co*4 + i*2 + j] (columns in the WEIGHT's own order [Cin][Cout][2][2], so the weight gradient of the
+// transposed GEMM lands in the parameter's layout); this pass writes y[n, 2h+i, 2w+j, co] = y2[p, co, i, j] + bias[co].  A thread
+// owns one pixel p and a run of VEC output channels: 4*VEC contiguous source elements, four VEC-wide stores.
+template <typename T>
+__global__ void deconv2x2_d2s_kernel(const T* __restrict__ y2, int ld2, const float* __restrict__ bias, T* __restrict__ y, int N,
+                                     int H, int W, int C) {
+  constexpr int VEC = VecOf<T>::N;
+  const int cg = (C + VEC - 1) / VEC;
+  const long long total = (long long)N * H * W * cg;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(t % cg);
+    const long long p = t / cg;
+    const int w = (int)(p % W);
+    const long long r = p / W;
+    const int h = (int)(r % H), n = (int)(r / H);
+    const int c0 = g * VEC, nc = min(VEC, C - c0);
+    const T* src = y2 + p * ld2 + (long long)c0 * 4;
+    for (int k = 0; k < 4; ++k) {
+      T* dst = y + ((((long long)n * 2 * H + 2 * h + (k >> 1)) * 2 * W) + 2 * w + (k & 1)) * C + c0;
+      for (int j = 0; j < nc; ++j) dst[j] = from_f32<T>(to_f32(src[j * 4 + k]) + (bias ? bias[c0 + j] : 0.f));
+    }
+  }
+}
+
+// the inverse gather for the backward pass: dy2[p, co*4 + i*2 + j] = dy[n, 2h+i, 2w+j, co]; columns 4C .. ld2-1 (padding of the
+// GEMM operand to whole vectors) are written as zeros
+template <typename T>
+__global__ void deconv2x2_s2d_kernel(const T* __restrict__ dy, T* __restrict__ dy2, int ld2, int N, int H, int W, int C) {
+  constexpr int VEC = VecOf<T>::N;
+  const int cg = (C + VEC - 1) / VEC;
+  const long long total = (long long)N * H * W * cg;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(t % cg);
+    const long long p = t / cg;
+    const int w = (int)(p % W);
+    const long long r = p / W;
+    const int h = (int)(r % H), n = (int)(r / H);
+    const int c0 = g * VEC, nc = min(VEC, C - c0);
+    T* dst = dy2 + p * ld2 + (long long)c0 * 4;
+    for (int k = 0; k < 4; ++k) {
+      const T* src = dy + ((((long long)n * 2 * H + 2 * h + (k >> 1)) * 2 * W) + 2 * w + (k & 1)) * C + c0;
+      for (int j = 0; j < nc; ++j) dst[j * 4 + k] = src[j];
+    }
+    if (g == cg - 1)
+      for (int c = 4 * C; c < ld2; ++c) dy2[p * ld2 + c] = from_f32<T>(0.f);
+  }
+}
+
 // dx[n, h, w, c] = sum over the s x s block of dy[n, h*s + i, w*s + j, coff + c]   (gather form, no atomics)
 template <typename T>
 __global__ void nearest_up_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C, int s,
@@ -600,6 +649,27 @@ int mr_nearest_up_fwd(int dtype, const void* x, const void* add, void* y, int N,
   const long long total = (long long)N * H * s * W * s * (C / vec);
   DISPATCH_T(dtype, hipLaunchKernelGGL((nearest_up_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
                                        (const T*)x, (const T*)add, (T*)y, N, H, W, C, s, ldy, coff));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_deconv2x2_d2s(int dtype, const void* y2, int ld2, const float* bias, void* y, int N, int H, int W, int C,
+                     hipStream_t stream) {
+  MR_CHECK_ARG(y2 && y && N > 0 && H > 0 && W > 0 && C > 0 && ld2 >= 4 * C, "mr_deconv2x2_d2s: bad arguments");
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  const long long total = (long long)N * H * W * ((C + vec - 1) / vec);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((deconv2x2_d2s_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
+                                       (const T*)y2, ld2, bias, (T*)y, N, H, W, C));
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+int mr_deconv2x2_s2d(int dtype, const void* dy, void* dy2, int ld2, int N, int H, int W, int C, hipStream_t stream) {
+  MR_CHECK_ARG(dy && dy2 && N > 0 && H > 0 && W > 0 && C > 0 && ld2 >= 4 * C, "mr_deconv2x2_s2d: bad arguments");
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  const long long total = (long long)N * H * W * ((C + vec - 1) / vec);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((deconv2x2_s2d_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
+                                       (const T*)dy, (T*)dy2, ld2, N, H, W, C));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

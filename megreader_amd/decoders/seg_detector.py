@@ -4,8 +4,8 @@ and shapes (in5..in2, out5..out2, binarize.{0,1,3,4,6}, thresh.{0,1,3,4,6}) and 
 (kaiming_normal_ on every conv / deconv weight, BatchNorm weight 1 / bias 1e-4), so checkpoints interchange.
 
 The 1x1 / 3x3 convolutions and BatchNorms run on the MFMA / HIP kernels; nn.Upsample(nearest) (+ the top-down add) is
-mr_nearest_up_fwd / _bwd; ConvTranspose2d(k=2, s=2) is a GEMM (one output pixel quad = a [Cin] x [Cin, 4*Cout] product,
-megreader_amd.nn.functional.linear) followed by a depth-to-space view.  The final sigmoid (always float32, `_SigmoidF32`) and the differentiable
+mr_nearest_up_fwd / _bwd; ConvTranspose2d(k=2, s=2) is a GEMM (one output pixel quad = a [Cin] x [Cin, 4*Cout] product)
+followed by a depth-to-space pass (megreader_amd.nn.functional.conv_transpose2x2).  The final sigmoid (always float32, `_SigmoidF32`) and the differentiable
 binarisation 1 / (1 + exp(-k (x - y))) are elementwise torch ops on 1-channel maps.
 `smooth=True` / `serial=True` are not used by any reference YAML and raise NotImplementedError."""
 from collections import OrderedDict
@@ -25,17 +25,9 @@ class ConvTranspose2x2(nn.ConvTranspose2d):
         super().__init__(in_channels, out_channels, 2, 2)
 
     def forward(self, x):
-        N, C, H, W = x.shape
-        co = self.out_channels
-        xs = x.permute(0, 2, 3, 1).reshape(N * H * W, C)                       # NHWC rows (a view for HIP-layer outputs)
-        wmat = self.weight.permute(2, 3, 1, 0).reshape(4 * co, C).contiguous()  # row (i, j, co)
-        bias = self.bias.repeat(4) if self.bias is not None else None
-        y = F.linear(xs, wmat, bias)                                           # [N*H*W, 4*co], columns (i, j, co)
-        # depth-to-space straight into the HIP layers' layout (NHWC memory, logical NCHW view): rows (n, h, i, w, j), co
-        # contiguous -- ONE copy that moves 2*co-element runs.  (Round 3 produced a row-major NCHW tensor here: a transposing
-        # copy, and the BatchNorm behind it converted it back to NHWC with a second kernel -- 55 + 22 us per use at 320 x 320.)
-        y = y.reshape(N, H, W, 2, 2, co).permute(0, 1, 3, 2, 4, 5).reshape(N, 2 * H, 2 * W, co)
-        return y.permute(0, 3, 1, 2)
+        if self.weight.is_cuda:
+            return F.conv_transpose2x2(x, self.weight, self.bias)     # GEMM + depth-to-space, one autograd node (nn/functional.py)
+        raise NotImplementedError("megreader_amd ops run only on an AMD GPU (HIP); there is no CPU fallback")
 
 
 class _SigmoidF32(nn.Module):

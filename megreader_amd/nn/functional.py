@@ -67,7 +67,7 @@ class ZeroArena(object):
     are handed out once per zeroing by a bump pointer; `reset()` -- called by the fused optimizers' `zero_grad()` --
     re-zeroes the used prefix with ONE fill and rewinds.  When the arena is exhausted (nobody calls reset: eval
     loops, foreign optimizers) `take` returns None and the caller falls back to its own memset."""
-    SIZE = 1 << 23  # doubles (64 MB: ResNet-50 takes ~34 doubles per BN channel per step, ~1 M; the four persistent-LSTM
+    SIZE = 1 << 24  # doubles (128 MB: the offset / mask gradients of the 13 DCN layers of a detector step take ~32 MB; ResNet-50 takes ~34 doubles per BN channel per step, ~1 M; the four persistent-LSTM
                     # exchange rings of a CRNN step 3.2 M)
     arenas = {}
 
@@ -1073,6 +1073,110 @@ class LinearFn(Function):
 
 def linear(x, weight, bias=None):
     return LinearFn.apply(x, weight, bias)
+
+
+# --------------------------------------------------------------------------------------------------
+# nn.ConvTranspose2d(cin, cout, 2, 2) of the DB heads (reference decoders/seg_detector.py:66-79).  Kernel = stride: every output
+# pixel receives exactly one input pixel, so the layer is a GEMM on the weight's own [Cin][Cout*4] matrix plus a depth-to-space
+# pass (mr_deconv2x2_d2s, which also adds the bias).  One autograd node: prepared weight images (no per-step permute / repeat /
+# contiguous launches), the weight gradient accumulated straight into the fused optimizer's sink -- the transposed GEMM's
+# [Cin][Cout*4] result IS the parameter's layout -- and deferred into the grouped weight-gradient launch.
+# --------------------------------------------------------------------------------------------------
+class ConvTranspose2x2Fn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        require_cuda(x, weight, bias)
+        dtype = get_compute_dtype()
+        dt = dtype_code(dtype)
+        v = vec_of(dtype)
+        xi = to_internal(x, dtype)                        # [N, H, W, Cin]
+        N, H, W, Cin = xi.shape
+        if tuple(weight.shape[2:]) != (2, 2) or weight.shape[0] != Cin or not weight.is_contiguous():
+            raise RuntimeError("conv_transpose2x2: weight must be a dense [Cin, Cout, 2, 2] tensor matching the input")
+        Cout = weight.shape[1]
+        K4 = 4 * Cout
+        ld2 = _ceil_to(K4, v)
+        P = N * H * W
+        dev = x.device
+
+        def build(old):
+            if old is None:
+                # w_n: the weight as [Cin][ld2] (zero padding columns), B operand of dx = dy2 . W^T; w_t: [4*Cout][Cin], B of fwd
+                w_n_ = (torch.zeros if ld2 != K4 else torch.empty)((Cin, ld2), dtype=dtype, device=dev)
+                w_t_ = torch.empty((K4, Cin), dtype=dtype, device=dev)
+            else:
+                w_n_, w_t_ = old
+            return (w_n_, w_t_), [prep.matrix_job(ptr(weight), K4, ptr(w_n_), ld2, ptr(w_t_), Cin, Cin, K4, 0)]
+
+        w_n, w_t = prep.prepared((weight,), ("deconv2x2", ld2), build, dtype)
+        x2 = xi.reshape(P, Cin)
+        y2 = torch.empty((P, ld2), dtype=dtype, device=dev)
+        call("mr_gemm_nt", dt, ptr(x2), Cin, ptr(w_t), Cin, ptr(y2), ld2, 0, 0, P, K4, Cin)
+        y = torch.empty((N, 2 * H, 2 * W, Cout), dtype=dtype, device=dev)
+        call("mr_deconv2x2_d2s", dt, ptr(y2), ld2, ptr(bias), ptr(y), N, H, W, Cout)
+        ctx.save_for_backward(x2, w_n)
+        ctx.params = (weight, bias)
+        ctx.geom = (N, H, W, Cin, Cout, ld2)
+        ctx.dtype = dtype
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w_n = ctx.saved_tensors
+        N, H, W, Cin, Cout, ld2 = ctx.geom
+        dtype = ctx.dtype
+        dt = dtype_code(dtype)
+        P, K4 = N * H * W, 4 * Cout
+        dev = gy.device
+        if Cout % vec_of(dtype) == 0:
+            g = _grad_internal(gy, dtype)                 # [N, 2H, 2W, Cout]
+            if not g.is_contiguous():
+                g = g.contiguous()
+        else:   # the 1-channel maps of the heads' last layer: dense NHWC (to_internal would pad the channels to a vector)
+            g = gy.permute(0, 2, 3, 1).contiguous().to(dtype)
+        dy2 = torch.empty((P, ld2), dtype=dtype, device=dev)
+        call("mr_deconv2x2_s2d", dt, ptr(g), ptr(dy2), ld2, N, H, W, Cout)
+        weight_p, bias_p = ctx.params
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dxi = torch.empty((N, H, W, Cin), dtype=dtype, device=dev)
+            call("mr_gemm_nt", dt, ptr(dy2), ld2, ptr(w_n), ld2, ptr(dxi), Cin, 0, 0, P, Cin, ld2)
+            dx = dxi.permute(0, 3, 1, 2)
+        want_db = bias_p is not None and ctx.needs_input_grad[2]
+        if want_db:
+            b_sink = grad_sink(bias_p, (Cout,))
+            gb = b_sink if b_sink is not None else torch.zeros((Cout,), dtype=torch.float32, device=dev)
+            call("mr_colsum", dt, ptr(g), ptr(gb), N * 4 * H * W, Cout, Cout, 0)
+            if b_sink is not None:
+                notify_grad_ready(bias_p)
+            else:
+                db = gb
+        if ctx.needs_input_grad[1]:
+            w_sink = grad_sink(weight_p)      # dense in the parameter's own (row-major) layout
+            if ld2 != K4:     # Cout = 1: the GEMM needs whole vectors of columns -- a padded scratch, folded into the gradient
+                tmp = torch.zeros((Cin, ld2), dtype=torch.float32, device=dev)
+                call("mr_gemm_tn", dt, ptr(x2), Cin, ptr(dy2), ld2, ptr(tmp), ld2, P, Cin, ld2, 0, 0)
+                if w_sink is not None:
+                    w_sink.view(Cin, K4).add_(tmp[:, :K4])
+                    notify_grad_ready(weight_p)
+                else:
+                    dw = tmp[:, :K4].reshape(Cin, Cout, 2, 2)
+            else:
+                gw = w_sink if w_sink is not None else torch.zeros((Cin, K4), dtype=torch.float32, device=dev)
+                defer = w_sink is not None and dtype == torch.bfloat16 and _TnDefer.begin()
+                # dW[ci, (co, i, j)] += sum_p x[p, ci] dy2[p, (co, i, j)]: the parameter's own memory order
+                call("mr_gemm_tn", dt, ptr(x2), Cin, ptr(dy2), ld2, ptr(gw), K4, P, Cin, K4, 0, 0)
+                if defer and _TnDefer.end((x2, dy2), [weight_p]):
+                    pass
+                elif w_sink is not None:
+                    notify_grad_ready(weight_p)
+                else:
+                    dw = gw.view(Cin, Cout, 2, 2)
+        return dx, dw, db
+
+
+def conv_transpose2x2(x, weight, bias=None):
+    return ConvTranspose2x2Fn.apply(x, weight, bias)
 
 
 # --------------------------------------------------------------------------------------------------

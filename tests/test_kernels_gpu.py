@@ -243,6 +243,47 @@ def test_maxpool_round5_kernels_are_bit_identical(dtype, k, s, p, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cout,sinks", [(64, False), (64, True), (1, False), (1, True), (24, False)])
+def test_conv_transpose2x2(dtype, cout, sinks):
+    """nn.ConvTranspose2d(cin, cout, 2, 2) of the DB heads (reference decoders/seg_detector.py:66-79) as GEMM + depth-to-space in
+    ONE autograd node, against torch's conv_transpose2d in float64; with the fused optimizer's gradient sinks the weight / bias
+    gradients land in the flat buffer (deferred, grouped weight-gradient launch included)."""
+    from megreader_amd.decoders.seg_detector import ConvTranspose2x2
+    from megreader_amd.optim import FusedSGD
+    mr.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(17 + cout)
+    N, cin, H, W = 2, 64, 5, 7
+    x = torch.randn(N, cin, H, W, generator=g).to(dtype)
+    mod = ConvTranspose2x2(cin, cout)
+    w = mod.weight.detach().clone()
+    b = mod.bias.detach().clone()
+    xr = x.double().requires_grad_(True)
+    wr = w.to(dtype).double().requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    yr = TF.conv_transpose2d(xr, wr, br, stride=2)
+    gy = torch.randn(yr.shape, generator=g).to(dtype)
+    yr.backward(gy.double())
+    mod = mod.to(DEV)
+    opt = FusedSGD(mod.parameters(), lr=0.0) if sinks else None
+    if opt is not None:
+        opt.zero_grad()
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = mod(xd)
+    assert tuple(y.shape) == tuple(yr.shape)
+    tol = 2e-5 if dtype == torch.float32 else 1.6e-2
+    assert _rel_err(y, yr) < tol
+    gyd = gy.to(DEV)
+    y.backward(gyd.contiguous(memory_format=torch.channels_last) if cout % 8 == 0 else gyd)
+    torch.cuda.synchronize()
+    gtol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert _rel_err(xd.grad, xr.grad) < gtol
+    assert _rel_err(mod.weight.grad, wr.grad) < gtol
+    assert _rel_err(mod.bias.grad, br.grad) < gtol
+    if sinks:
+        assert mod.weight.grad.data_ptr() == mod.weight._mr_grad_sink.data_ptr()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_linear(dtype):
     mr.set_compute_dtype(dtype)
     g = torch.Generator().manual_seed(3)
