@@ -431,6 +431,24 @@ __global__ void deconv2x2_d2s_kernel(const T* __restrict__ y2, int ld2, const fl
     const int h = (int)(r % H), n = (int)(r / H);
     const int c0 = g * VEC, nc = min(VEC, C - c0);
     const T* src = y2 + p * ld2 + (long long)c0 * 4;
+    if (nc == VEC && (C % VEC) == 0 && (ld2 % VEC) == 0) {   // whole vectors: 4 x 16-byte loads, 4 x 16-byte stores
+      uint4 in[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) in[q] = ((const uint4*)src)[q];
+      const T* pin = (const T*)in;
+      float bv[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) bv[j] = bias ? bias[c0 + j] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint4 o;
+        T* po = (T*)&o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) po[j] = from_f32<T>(to_f32(pin[j * 4 + k]) + bv[j]);
+        *(uint4*)(y + ((((long long)n * 2 * H + 2 * h + (k >> 1)) * 2 * W) + 2 * w + (k & 1)) * C + c0) = o;
+      }
+      continue;
+    }
     for (int k = 0; k < 4; ++k) {
       T* dst = y + ((((long long)n * 2 * H + 2 * h + (k >> 1)) * 2 * W) + 2 * w + (k & 1)) * C + c0;
       for (int j = 0; j < nc; ++j) dst[j] = from_f32<T>(to_f32(src[j * 4 + k]) + (bias ? bias[c0 + j] : 0.f));
@@ -453,9 +471,24 @@ __global__ void deconv2x2_s2d_kernel(const T* __restrict__ dy, T* __restrict__ d
     const int h = (int)(r % H), n = (int)(r / H);
     const int c0 = g * VEC, nc = min(VEC, C - c0);
     T* dst = dy2 + p * ld2 + (long long)c0 * 4;
-    for (int k = 0; k < 4; ++k) {
-      const T* src = dy + ((((long long)n * 2 * H + 2 * h + (k >> 1)) * 2 * W) + 2 * w + (k & 1)) * C + c0;
-      for (int j = 0; j < nc; ++j) dst[j * 4 + k] = src[j];
+    if (nc == VEC && (C % VEC) == 0 && (ld2 % VEC) == 0) {
+      uint4 in[4], out[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        in[k] = *(const uint4*)(dy + ((((long long)n * 2 * H + 2 * h + (k >> 1)) * 2 * W) + 2 * w + (k & 1)) * C + c0);
+      const T* pin = (const T*)in;
+      T* pout = (T*)out;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pout[j * 4 + k] = pin[k * VEC + j];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ((uint4*)dst)[q] = out[q];
+    } else {
+      for (int k = 0; k < 4; ++k) {
+        const T* src = dy + ((((long long)n * 2 * H + 2 * h + (k >> 1)) * 2 * W) + 2 * w + (k & 1)) * C + c0;
+        for (int j = 0; j < nc; ++j) dst[j * 4 + k] = src[j];
+      }
     }
     if (g == cg - 1)
       for (int c = 4 * C; c < ld2; ++c) dy2[p * ld2 + c] = from_f32<T>(0.f);
