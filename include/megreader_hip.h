@@ -192,6 +192,28 @@ int mr_conv2d_wgrad_tab(int dtype, const void* dy, const void* x, float* dw_krsc
                         int Cin, int ldx, int Cout, int lddy, int R, int S, int sh, int sw, int ph, int pw, int dh,
                         int dw, int Ho, int Wo, void* rowtab, int build, hipStream_t stream);
 
+/* ---- DB detector loss (replaces the ~100 torch launches of decoders/seg_detector_loss.py:157-185 L1BalanceCELoss =
+ *      balance_cross_entropy_loss.py:29-56 + l1_loss.py:5-11 + dice_loss.py:28-42) ---------------------------------------------
+ * binary / thresh / thresh_binary / gt: f32 [N, H*W] (the [N,1,H,W] maps); mask / thresh_map / thresh_mask: f32 [N, H*W].  The
+ * reference multiplies gt [N,1,H,W] with mask [N,H,W]: broadcasting makes positive / negative [N,N,H,W] tensors (gt of sample a,
+ * mask and loss of sample b); that is restated as is.  negloss: f32 scratch [N*N*H*W]; ws: mr_db_loss_ws_bytes() bytes ZEROED by
+ * the caller; out: f32 [16] = {loss, bce, l1, dice, state read by mr_db_loss_bwd ...}.  The sum of the nc largest negative losses
+ * is an exact radix selection; elements tied at the threshold share the remaining count equally in the gradient. */
+long long mr_db_loss_ws_bytes(void);
+/* tail of the two DB heads (decoders/seg_detector.py:77-79,142-147): binary = sigmoid(xb), thresh = sigmoid(xt) -- float32 outputs
+ * whatever `dtype` the logits have -- and thresh_binary = 1 / (1 + exp(-k (binary - thresh))); n elements each */
+int mr_db_head_tail_fwd(int dtype, const void* xb, const void* xt, float* binary, float* thresh, float* tbinary, long long n,
+                        float k, hipStream_t stream);
+int mr_db_head_tail_bwd(int dtype, const float* binary, const float* thresh, const float* tbinary, const float* gb,
+                        const float* gt, const float* gtb, void* dxb, void* dxt, long long n, float k, hipStream_t stream);
+int mr_db_loss_fwd(const float* binary, const float* thresh, const float* tbinary, const float* gt, const float* mask,
+                   const float* tmap, const float* tmask, float* negloss, void* ws, float* out, int N, long long HW,
+                   float negative_ratio, float eps, float l1_scale, float bce_scale, hipStream_t stream);
+int mr_db_loss_bwd(const float* binary, const float* thresh, const float* tbinary, const float* gt, const float* mask,
+                   const float* tmap, const float* tmask, const float* out, const float* gloss, float* g_binary,
+                   float* g_thresh, float* g_tbinary, int N, long long HW, float l1_scale, float bce_scale,
+                   hipStream_t stream);
+
 /* ---- layout / elementwise helpers ---------------------------------------------------------------------- */
 int mr_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int Cpad,
                     hipStream_t stream);

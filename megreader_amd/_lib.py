@@ -116,6 +116,10 @@ SIGNATURES = {
     "mr_ctc2d_fwd": "ippppiiiiiipps",
     "mr_ctc2d_bwd": "ippppppppp" + "iiiiiis",
     "mr_tn_flush": "s",
+    "mr_db_loss_fwd": "pppppppppp" + "ilffffs",
+    "mr_db_head_tail_fwd": "ippppplfs",
+    "mr_db_head_tail_bwd": "i" + "pppppppp" + "lfs",
+    "mr_db_loss_bwd": "pppppppppppp" + "ilffs",
 }
 
 _lib = None
@@ -245,6 +249,8 @@ def load():
     lib.mr_dcn2_ws_bytes.argtypes = [ctypes.c_int] * 11
     lib.mr_dcn2_dx_direct.restype = ctypes.c_int
     lib.mr_dcn2_dx_direct.argtypes = [ctypes.c_int] * 8
+    lib.mr_db_loss_ws_bytes.restype = ctypes.c_longlong
+    lib.mr_db_loss_ws_bytes.argtypes = []
     lib.mr_dcn2_fused.restype = ctypes.c_int
     lib.mr_dcn2_fused.argtypes = [ctypes.c_int] * 7
     if hasattr(lib, "mr_set_tn_abl"):      # only libmegreader_hip_abl.so (tools build, include/megreader_hip_ablation.h)
@@ -292,7 +298,7 @@ def load():
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_tuning_get", "mr_tuning_set", "mr_tuning_defaults",
              "mr_stem_bwd_workspace", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_dcn2_ws_bytes", "mr_bn_scratch_doubles",
              "mr_sizeof_img_desc", "mr_nt_kernel_code", "mr_tn_taps_would_run", "mr_set_tn_taps_workspace",
-             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending", "mr_dcn2_dx_direct", "mr_dcn2_fused")  # entry points that take no stream and launch nothing
+             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending", "mr_dcn2_dx_direct", "mr_dcn2_fused", "mr_db_loss_ws_bytes")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

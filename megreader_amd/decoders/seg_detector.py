@@ -17,6 +17,9 @@ from ..nn import BatchNorm2d, Conv2d, FusedReLU
 from ..nn import functional as F
 
 
+FUSED_TAIL = __import__("os").environ.get("MEGREADER_DB_TAIL_FUSED", "1") != "0"     # A/B: 0 = the torch expression
+
+
 class ConvTranspose2x2(nn.ConvTranspose2d):
     """nn.ConvTranspose2d(cin, cout, 2, 2) (weight [cin, cout, 2, 2], bias [cout]) computed as a GEMM:
     out[n, co, 2h+i, 2w+j] = sum_ci x[n, ci, h, w] * W[ci, co, i, j] + b[co]."""
@@ -107,6 +110,12 @@ class SegDetector(nn.Module):
         p3 = self.out3(out3)
         p2 = self.out2(out2)
         fuse = F.cat_channels([p5, p4, p3, p2])
+        if (self.adaptive and FUSED_TAIL and fuse.is_cuda and isinstance(self.binarize[-1], _SigmoidF32) and
+                isinstance(self.thresh[-1], _SigmoidF32)):
+            # the two heads up to their last deconvolution, then sigmoid / sigmoid / step function as ONE launch each way
+            xb, xt = self.binarize[:-1](fuse), self.thresh[:-1](fuse)
+            binary, thresh, thresh_binary = F.db_head_tail(xb, xt, self.k)
+            return OrderedDict(binary=binary, thresh=thresh, thresh_binary=thresh_binary)
         binary = self.binarize(fuse).float()
         result = OrderedDict(binary=binary)
         if self.adaptive:

@@ -65,6 +65,62 @@ class DiceLoss(nn.Module):
         return 1 - 2.0 * intersection / union
 
 
+class _DBLossFn(torch.autograd.Function):
+    """The whole L1BalanceCELoss on the device in 7 launches forward / 1 backward (csrc/db_loss.hip) instead of ~100 torch
+    launches: returns f32 [4] = (loss, bce, l1, dice); only element 0 carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, binary, thresh, tbinary, gt, mask, tmap, tmask, ratio, eps, l1_scale, bce_scale):
+        from .._lib import call, load, ptr
+        from ..nn.functional import ZeroArena
+        N = binary.shape[0]
+        HW = binary.numel() // N
+        dev = binary.device
+        maps = [t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
+                for t in (binary, thresh, tbinary, gt, mask, tmap, tmask)]
+        nbytes = load().mr_db_loss_ws_bytes()
+        arena = ZeroArena.take(dev, (nbytes + 7) // 8)
+        ws = arena if arena is not None else torch.zeros(((nbytes + 7) // 8,), dtype=torch.float64, device=dev)
+        negloss = torch.empty((N * N * HW,), dtype=torch.float32, device=dev)
+        out = torch.empty((16,), dtype=torch.float32, device=dev)
+        call("mr_db_loss_fwd", *[ptr(t) for t in maps], ptr(negloss), ptr(ws), ptr(out), N, HW, float(ratio), float(eps),
+             float(l1_scale), float(bce_scale))
+        ctx.save_for_backward(out, *maps)
+        ctx.scales = (float(l1_scale), float(bce_scale))
+        ctx.shapes = (binary.shape, thresh.shape, tbinary.shape)
+        return out[:4]
+
+    @staticmethod
+    def backward(ctx, g):
+        from .._lib import call, ptr
+        out, binary, thresh, tbinary, gt, mask, tmap, tmask = ctx.saved_tensors
+        N = binary.shape[0]
+        HW = binary.numel() // N
+        gl = g[0:1].contiguous().float()          # metrics (elements 1..3) are for logging only
+        gb, gth, gtb = torch.empty_like(binary), torch.empty_like(thresh), torch.empty_like(tbinary)
+        call("mr_db_loss_bwd", ptr(binary), ptr(thresh), ptr(tbinary), ptr(gt), ptr(mask), ptr(tmap), ptr(tmask), ptr(out),
+             ptr(gl), ptr(gb), ptr(gth), ptr(gtb), N, HW, ctx.scales[0], ctx.scales[1])
+        s0, s1, s2 = ctx.shapes
+        return (gb.view(s0), gth.view(s1), gtb.view(s2)) + (None,) * 8
+
+
+def _fused_ok(pred, batch):
+    try:
+        b, t, tb = pred['binary'], pred['thresh'], pred['thresh_binary']
+        gt, mask, tmap, tmask = batch['gt'], batch['mask'], batch['thresh_map'], batch['thresh_mask']
+    except KeyError:
+        return False
+    if not all(isinstance(x, torch.Tensor) and x.is_cuda for x in (b, t, tb, gt, mask, tmap, tmask)):
+        return False
+    N = b.shape[0]
+    return (b.dim() == 4 and b.shape[1] == 1 and t.shape == b.shape and tb.shape == b.shape and gt.shape == b.shape and
+            mask.dim() == 3 and mask.shape[0] == N and mask.shape[1:] == b.shape[2:] and tmap.shape == mask.shape and
+            tmask.shape == mask.shape)
+
+
+FUSED_DB_LOSS = __import__("os").environ.get("MEGREADER_DB_LOSS_FUSED", "1") != "0"     # A/B: 0 = the torch restatement
+
+
 class L1BalanceCELoss(nn.Module):
     """Balanced cross entropy on `binary`, masked L1 on `thresh`, Dice on `thresh_binary`."""
 
@@ -77,6 +133,12 @@ class L1BalanceCELoss(nn.Module):
         self.bce_scale = bce_scale
 
     def forward(self, pred, batch):
+        if FUSED_DB_LOSS and _fused_ok(pred, batch):
+            r = _DBLossFn.apply(pred['binary'], pred['thresh'], pred['thresh_binary'], batch['gt'], batch['mask'],
+                                batch['thresh_map'], batch['thresh_mask'], self.bce_loss.negative_ratio, self.bce_loss.eps,
+                                self.l1_scale, self.bce_scale)
+            m = r.detach()
+            return r[0], dict(bce_loss=m[1], thresh_loss=m[3], l1_loss=m[2])
         bce_loss = self.bce_loss(pred['binary'], batch['gt'], batch['mask'])
         metrics = dict(bce_loss=bce_loss)
         l1_loss, l1_metric = self.l1_loss(pred['thresh'], batch['thresh_map'], batch['thresh_mask'])

@@ -1175,6 +1175,47 @@ class ConvTranspose2x2Fn(Function):
         return dx, dw, db
 
 
+class DBHeadTailFn(Function):
+    """(binary, thresh, thresh_binary) of the DB heads from the two 1-channel logit maps (reference decoders/seg_detector.py:77-79
+    nn.Sigmoid at the end of `binarize` / `thresh`, :142-147 step_function): float32 outputs whatever the compute dtype, one
+    launch each way (the torch expression is two casts, two sigmoids and five elementwise ops forward, ~14 launches backward)."""
+
+    @staticmethod
+    def forward(ctx, xb, xt, k):
+        require_cuda(xb, xt)
+        if xb.dtype != xt.dtype or xb.dtype not in _ESIZE or xb.shape != xt.shape:
+            raise RuntimeError("db_head_tail: the two logit maps must share shape and dtype (float32 / bfloat16)")
+        # logical [N,1,H,W]; with one channel every dense layout is the same memory order
+        xbc = xb if xb.is_contiguous() or xb.permute(0, 2, 3, 1).is_contiguous() else xb.contiguous()
+        xtc = xt if xt.is_contiguous() or xt.permute(0, 2, 3, 1).is_contiguous() else xt.contiguous()
+        n = xb.numel()
+        shape = tuple(xb.shape)
+        binary = torch.empty(shape, dtype=torch.float32, device=xb.device)
+        thresh = torch.empty(shape, dtype=torch.float32, device=xb.device)
+        tbinary = torch.empty(shape, dtype=torch.float32, device=xb.device)
+        call("mr_db_head_tail_fwd", dtype_code(xb.dtype), ptr(xbc), ptr(xtc), ptr(binary), ptr(thresh), ptr(tbinary), n, float(k))
+        ctx.save_for_backward(binary, thresh, tbinary)
+        ctx.meta = (xb.dtype, shape, float(k))
+        ctx.set_materialize_grads(False)
+        return binary, thresh, tbinary
+
+    @staticmethod
+    def backward(ctx, gb, gt, gtb):
+        binary, thresh, tbinary = ctx.saved_tensors
+        dtype, shape, k = ctx.meta
+        gs = [None if g is None else (g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous())
+              for g in (gb, gt, gtb)]
+        dxb = torch.empty(shape, dtype=dtype, device=binary.device)
+        dxt = torch.empty(shape, dtype=dtype, device=binary.device)
+        call("mr_db_head_tail_bwd", dtype_code(dtype), ptr(binary), ptr(thresh), ptr(tbinary), ptr(gs[0]), ptr(gs[1]), ptr(gs[2]),
+             ptr(dxb), ptr(dxt), binary.numel(), k)
+        return dxb, dxt, None
+
+
+def db_head_tail(xb, xt, k):
+    return DBHeadTailFn.apply(xb, xt, k)
+
+
 def conv_transpose2x2(x, weight, bias=None):
     return ConvTranspose2x2Fn.apply(x, weight, bias)
 

@@ -147,3 +147,75 @@ def test_db_detector_training_step_bf16():
         losses.append(float(loss))
     assert all(l == l and abs(l) < 1e3 for l in losses), losses
     assert set(metrics) == {'bce_loss', 'thresh_loss', 'l1_loss'}
+
+
+@pytest.mark.parametrize("n,quantized", [(2, False), (2, True), (3, False), (1, True)])
+def test_fused_db_loss_equals_the_torch_restatement(n, quantized):
+    """csrc/db_loss.hip (radix-selected sum of the nc largest negative losses, every reduction, one backward launch) against the
+    torch restatement of reference decoders/seg_detector_loss.py:157-185 -- including the [N,N,H,W] broadcast of gt * mask.
+    quantized: predictions on a 1/64 grid, so thousands of negative losses are EQUAL at the selection threshold: the loss must
+    still agree exactly; the gradient gives the tied elements equal shares (the restatement's sort picks some of them), so it
+    is compared where no tie is involved and through its sum."""
+    from megreader_amd.decoders import seg_detector_loss as sdl
+    g = torch.Generator().manual_seed(11 + n)
+    H = W = 96
+    batch = {k: v.to(DEV) for k, v in detection_batch(n, H, seed=3, boxes=2).items()}
+
+    def maps():
+        out = {}
+        for k in ("binary", "thresh", "thresh_binary"):
+            p = torch.rand(n, 1, H, W, generator=g) * 0.98 + 0.01
+            if quantized:
+                p = (p * 64).round().clamp(1, 63) / 64
+            out[k] = p.to(DEV).requires_grad_(True)
+        return out
+    pred = maps()
+    res = {}
+    for fused in (False, True):
+        old = sdl.FUSED_DB_LOSS
+        sdl.FUSED_DB_LOSS = fused
+        try:
+            for v in pred.values():
+                v.grad = None
+            loss, metrics = L1BalanceCELoss()(pred, batch)
+            loss.backward()
+            res[fused] = (float(loss), {k: float(v) for k, v in metrics.items()}, {k: v.grad.clone() for k, v in pred.items()})
+        finally:
+            sdl.FUSED_DB_LOSS = old
+    l0, m0, g0 = res[False]
+    l1, m1, g1 = res[True]
+    assert abs(l0 - l1) < 2e-6 * max(1.0, abs(l0)), (l0, l1)
+    for k in m0:
+        assert abs(m0[k] - m1[k]) < 2e-6 * max(1.0, abs(m0[k])), (k, m0[k], m1[k])
+    for k in ("thresh", "thresh_binary"):
+        assert _rel(g1[k], g0[k]) < 1e-5, k
+    if not quantized:
+        assert _rel(g1["binary"], g0["binary"]) < 1e-5
+    else:
+        d = (g1["binary"] - g0["binary"]).abs()
+        scale = float(g0["binary"].abs().max())
+        assert float((d > 1e-5 * scale).float().mean()) < 0.2          # only tied elements may differ ...
+        assert abs(float(g1["binary"].sum()) - float(g0["binary"].sum())) < 2e-3 * float(g0["binary"].abs().sum())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_db_head_tail_equals_the_torch_expression(dtype):
+    """sigmoid / sigmoid / step function of the DB heads (decoders/seg_detector.py:77-79,142-147) as one launch each way."""
+    from megreader_amd.nn import functional as F
+    g = torch.Generator().manual_seed(2)
+    xb = (torch.randn(2, 1, 40, 56, generator=g) * 3).to(dtype).to(DEV).requires_grad_(True)
+    xt = (torch.randn(2, 1, 40, 56, generator=g) * 3).to(dtype).to(DEV).requires_grad_(True)
+    w = [torch.randn(2, 1, 40, 56, generator=g).to(DEV) for _ in range(3)]
+    k = 50.0
+    b, t, tb = F.db_head_tail(xb, xt, k)
+    (b * w[0] + t * w[1] + tb * w[2]).sum().backward()
+    got = (b.detach(), t.detach(), tb.detach(), xb.grad.clone(), xt.grad.clone())
+    xb2 = xb.detach().clone().requires_grad_(True)
+    xt2 = xt.detach().clone().requires_grad_(True)
+    b2, t2 = torch.sigmoid(xb2.double()), torch.sigmoid(xt2.double())
+    tb2 = torch.reciprocal(1 + torch.exp(-k * (b2 - t2)))
+    (b2 * w[0] + t2 * w[1] + tb2 * w[2]).sum().backward()
+    want = (b2.detach(), t2.detach(), tb2.detach(), xb2.grad, xt2.grad)
+    tol = 2e-6 if dtype == torch.float32 else 1e-2
+    for i, (a, r) in enumerate(zip(got, want)):
+        assert _rel(a, r) < (5e-6 if i < 3 else tol), i
