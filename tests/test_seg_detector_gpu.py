@@ -158,8 +158,10 @@ def test_fused_db_loss_equals_the_torch_restatement(n, quantized):
     is compared where no tie is involved and through its sum."""
     from megreader_amd.decoders import seg_detector_loss as sdl
     g = torch.Generator().manual_seed(11 + n)
-    H = W = 96
+    H = W = 256
     batch = {k: v.to(DEV) for k, v in detection_batch(n, H, seed=3, boxes=2).items()}
+    batch['mask'][:, :24, :] = 0.0          # ignored pixels
+    batch['mask'][0, :, 200:] = 0.0
 
     def maps():
         out = {}
