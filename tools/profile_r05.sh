@@ -1,0 +1,38 @@
+#!/bin/bash
+# Round-5 measurement (GPU box).  Outputs: gpurun_out/r05p/ (copy what should be judged into profiles/).
+#   rocprofv3 kernel traces of the four workloads at the benchmarked batch + the CRNN at 32 crops per GPU: per-kernel statistics
+#   (tools/rocpd_stats.py) and the launch sequence of one replayed step (tools/rocpd_sequence.py)
+#   FETCH_SIZE / WRITE_SIZE PMC passes of the two north-star workloads (separate passes) -> pmc_traffic_<workload>.json
+# usage: bash tools/profile_r05.sh [quick]      (quick: no PMC passes)
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r05p; mkdir -p $O
+trace() {   # name, marker, bench args...
+  local name=$1; local marker=$2; shift; shift
+  timeout 300 rocprofv3 --kernel-trace -d $O/trace_$name -- python bench.py "$@" --no-cpu-baseline --no-secondary --no-kernel-timer --steps 10 --warmup 3 > $O/trace_$name.log 2>&1
+  local db=$(find $O/trace_$name -name "*.db" | head -1)
+  if [ -n "$db" ]; then
+    python tools/rocpd_stats.py "$db" > $O/${name}_kernel_stats.csv 2>&1
+    python tools/rocpd_sequence.py "$db" --marker $marker > $O/${name}_step_sequence.txt 2>&1
+    head -1 $O/${name}_step_sequence.txt
+  fi
+  grep -o '"ms_per_step": [0-9.]*' $O/trace_$name.log | head -1
+  rm -rf $O/trace_$name
+}
+trace crnn adam_kernel --workload crnn
+trace crnn_b32 adam_kernel --workload crnn --batch 32
+trace res50ppm adam_kernel --workload res50ppm
+trace fpn_attention adam_kernel --workload fpn_attention
+trace db sgd_kernel --workload db
+if [ "$1" != "quick" ]; then
+for w in crnn res50ppm; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 400 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${w}_$c -- python bench.py --workload $w --no-secondary --no-cpu-baseline --no-graph --no-kernel-timer --steps 3 --warmup 2 > $O/pmc_${w}_$c.log 2>&1
+    f=$(find $O/pmc_${w}_$c -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then python tools/pmc_summary.py "$f" > $O/pmc_${w}_$c.txt 2>&1; fi
+    rm -rf $O/pmc_${w}_$c
+  done
+  python tools/pmc_to_json.py $O/pmc_${w}_FETCH_SIZE.txt $O/pmc_${w}_WRITE_SIZE.txt $O/pmc_traffic_${w}.json > /dev/null 2>&1
+  ls -la $O/pmc_traffic_${w}.json
+done
+fi
+echo done
