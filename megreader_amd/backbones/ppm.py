@@ -28,12 +28,9 @@ class PPMDeepsup(nn.Module):
 
     def forward(self, conv_out, segSize=None):
         conv5 = conv_out[-1]
-        input_size = conv5.size()
-        ppm_out = [conv5]
         # reference: pool_scale(conv5) per branch = AdaptiveAvgPool2d(scale) -> conv -> bn -> relu.  The four pools read the
         # same map: one launch (F.adaptive_avg_pool2d_multi), then the rest of each branch
         pooled = F.adaptive_avg_pool2d_multi(conv5, [branch[0].output_size for branch in self.ppm])
-        for branch, p in zip(self.ppm, pooled):
-            ppm_out.append(F.interpolate_bilinear(branch[1:](p), (input_size[2], input_size[3])))
-        ppm_out = F.cat_channels(ppm_out)
+        # torch.cat([conv5] + [interpolate(branch, conv5 size, bilinear)], 1): branches resized into their slices of the buffer
+        ppm_out = F.cat_bilinear(conv5, [branch[1:](p) for branch, p in zip(self.ppm, pooled)])
         return self.conv_last(ppm_out)

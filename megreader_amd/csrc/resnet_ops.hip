@@ -8,6 +8,7 @@
 #include "../../include/megreader_hip.h"
 
 #define MR_POOL_MULTI_MAX 8   /* scales per mr_adaptive_avgpool_multi_* call */
+#define MR_POOL_MULTI_BINS 256 /* sum of oh*ow over the scales */
 
 namespace mr {
 
@@ -98,14 +99,32 @@ struct PoolMultiArgs {
   void* y[MR_POOL_MULTI_MAX];       // forward outputs / backward incoming gradients, [N][oh][ow][C]
 };
 
+// Bin tables are built once per workgroup in LDS: computing bin_start / bin_end (integer divisions) per bin per thread made
+// both kernels VALU-bound (113 + 139 us on the [256,4,16,2048] map, r05 trace) instead of one pass over the map.
+__device__ __forceinline__ int pool_multi_find(const PoolMultiArgs& a, int b, int& local) {
+  int s = 0;
+  while (s < a.nsc - 1 && b >= a.oh[s] * a.ow[s]) { b -= a.oh[s] * a.ow[s]; ++s; }
+  local = b;
+  return s;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void adaptive_avgpool_multi_fwd_kernel(const T* __restrict__ x, PoolMultiArgs a, int N,
-                                                                         int H, int W, int C) {
+                                                                         int H, int W, int C, int nbins) {
   constexpr int VEC = VecOf<T>::N;
   constexpr int CPB = 128 / (int)sizeof(T);          // channels per workgroup: one 128-byte line per pixel
-  extern __shared__ uint4 pool_tile[];               // [H*W][8] vectors
-  const int n = blockIdx.x, c0 = blockIdx.y * CPB;
+  extern __shared__ uint4 pool_tile[];               // [H*W][8] vectors, then ushort4 bins[nbins] = (h0, h1, w0, w1)
+  const int n = blockIdx.y, c0 = blockIdx.x * CPB;
   const int HW = H * W;
+  ushort4* bins = (ushort4*)(pool_tile + HW * 8);
+  for (int b = threadIdx.x; b < nbins; b += 256) {
+    int l;
+    const int s = pool_multi_find(a, b, l);
+    const int OH = a.oh[s], OW = a.ow[s];
+    const int oh = l / OW, ow = l - oh * OW;
+    bins[b] = make_ushort4((unsigned short)bin_start(oh, H, OH), (unsigned short)bin_end(oh, H, OH),
+                           (unsigned short)bin_start(ow, W, OW), (unsigned short)bin_end(ow, W, OW));
+  }
   for (int i = threadIdx.x; i < HW * 8; i += 256) {
     const int pix = i >> 3, v = i & 7;
     uint4 val = make_uint4(0, 0, 0, 0);
@@ -116,60 +135,95 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_multi_fwd_kernel(const T
   const T* tile = (const T*)pool_tile;
   const int c = threadIdx.x % CPB, sub = threadIdx.x / CPB, nsub = 256 / CPB;
   if (c0 + c >= C) return;
+  int base = 0;
   for (int s = 0; s < a.nsc; ++s) {
-    const int OH = a.oh[s], OW = a.ow[s];
+    const int nb = a.oh[s] * a.ow[s];
     T* __restrict__ y = (T*)a.y[s];
-    for (int b = sub; b < OH * OW; b += nsub) {
-      const int oh = b / OW, ow = b - oh * OW;
-      const int h0 = bin_start(oh, H, OH), h1 = bin_end(oh, H, OH);
-      const int w0 = bin_start(ow, W, OW), w1 = bin_end(ow, W, OW);
+    for (int b = sub; b < nb; b += nsub) {
+      const ushort4 e = bins[base + b];
       float acc = 0.f;
-      for (int h = h0; h < h1; ++h)
-        for (int w = w0; w < w1; ++w) acc += to_f32(tile[(h * W + w) * CPB + c]);
-      y[(((long long)n * OH + oh) * OW + ow) * C + c0 + c] = from_f32<T>(acc / (float)((h1 - h0) * (w1 - w0)));
+      for (int h = e.x; h < e.y; ++h)
+        for (int w = e.z; w < e.w; ++w) acc += to_f32(tile[(h * W + w) * CPB + c]);
+      y[((long long)n * nb + b) * C + c0 + c] = from_f32<T>(acc / (float)((e.y - e.x) * (e.w - e.z)));
     }
+    base += nb;
   }
 }
 
+// One workgroup = one image x one 128-byte channel slice: the slice of every bin's gradient is staged in LDS (nbins x 128 B)
+// next to the row -> bins and column -> bins ranges; each thread then sums the bins covering its pixel in the order
+// (scale, oh, ow) of the element-wise kernel above and writes one 16-byte vector.
 template <typename T>
-__global__ void adaptive_avgpool_multi_bwd_kernel(PoolMultiArgs a, T* __restrict__ dx, int N, int H, int W, int C) {
+__global__ __launch_bounds__(256) void adaptive_avgpool_multi_bwd_kernel(PoolMultiArgs a, T* __restrict__ dx, int N, int H,
+                                                                         int W, int C, int nbins) {
   constexpr int VEC = VecOf<T>::N;
-  const int cv = C / VEC;
-  const long long total = (long long)N * H * W * cv;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cv);
-    long long q = i / cv;
-    const int w = (int)(q % W);
-    q /= W;
-    const int h = (int)(q % H);
-    const int n = (int)(q / H);
+  constexpr int CPB = 128 / (int)sizeof(T);
+  extern __shared__ uint4 pool_tile[];               // [nbins][8] vectors | float inv[nbins] | ushort2 rows[nsc*H] | cols[nsc*W]
+  const int n = blockIdx.y, c0 = blockIdx.x * CPB;
+  const int HW = H * W;
+  float* inv = (float*)(pool_tile + nbins * 8);
+  ushort2* rows = (ushort2*)(inv + nbins);
+  ushort2* cols = rows + a.nsc * H;
+  for (int b = threadIdx.x; b < nbins; b += 256) {
+    int l;
+    const int s = pool_multi_find(a, b, l);
+    const int OH = a.oh[s], OW = a.ow[s];
+    const int oh = l / OW, ow = l - oh * OW;
+    inv[b] = 1.f / (float)((bin_end(oh, H, OH) - bin_start(oh, H, OH)) * (bin_end(ow, W, OW) - bin_start(ow, W, OW)));
+  }
+  for (int i = threadIdx.x; i < a.nsc * (H + W); i += 256) {
+    // row h lies in bin oh  <=>  floor(h*OH/H) <= oh <= ceil((h+1)*OH/H) - 1   (see adaptive_avgpool_bwd_kernel)
+    if (i < a.nsc * H) {
+      const int s = i / H, h = i - s * H, OH = a.oh[s];
+      rows[i] = make_ushort2((unsigned short)(h * OH / H), (unsigned short)min(OH - 1, ((h + 1) * OH + H - 1) / H - 1));
+    } else {
+      const int j = i - a.nsc * H;
+      const int s = j / W, w = j - s * W, OW = a.ow[s];
+      cols[j] = make_ushort2((unsigned short)(w * OW / W), (unsigned short)min(OW - 1, ((w + 1) * OW + W - 1) / W - 1));
+    }
+  }
+  {
+    int base = 0;
+    for (int s = 0; s < a.nsc; ++s) {
+      const int nb = a.oh[s] * a.ow[s];
+      const T* __restrict__ dy = (const T*)a.y[s];
+      for (int i = threadIdx.x; i < nb * 8; i += 256) {
+        const int b = i >> 3, v = i & 7;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (c0 + v * VEC < C) val = *(const uint4*)(dy + ((long long)n * nb + b) * C + c0 + v * VEC);
+        pool_tile[(base + b) * 8 + v] = val;
+      }
+      base += nb;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HW * 8; i += 256) {
+    const int pix = i >> 3, v = i & 7;
+    if (c0 + v * VEC >= C) continue;
+    const int h = pix / W, w = pix - h * W;
     float sum[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) sum[j] = 0.f;
+    int base = 0;
     for (int s = 0; s < a.nsc; ++s) {
-      const int OH = a.oh[s], OW = a.ow[s];
-      const uint4* __restrict__ dy = (const uint4*)a.y[s];
-      // row h lies in bin oh  <=>  floor(h*OH/H) <= oh <= ceil((h+1)*OH/H) - 1   (see adaptive_avgpool_bwd_kernel)
-      const int oh_lo = h * OH / H, oh_hi = min(OH - 1, ((h + 1) * OH + H - 1) / H - 1);
-      const int ow_lo = w * OW / W, ow_hi = min(OW - 1, ((w + 1) * OW + W - 1) / W - 1);
-      for (int oh = oh_lo; oh <= oh_hi; ++oh) {
-        const int h0 = bin_start(oh, H, OH), h1 = bin_end(oh, H, OH);
-        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-          const int w0 = bin_start(ow, W, OW), w1 = bin_end(ow, W, OW);
-          const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
-          const uint4 g = dy[(((long long)n * OH + oh) * OW + ow) * cv + c];
+      const int OW = a.ow[s];
+      const ushort2 rr = rows[s * H + h], cc = cols[s * W + w];
+      for (int oh = rr.x; oh <= rr.y; ++oh)
+        for (int ow = cc.x; ow <= cc.y; ++ow) {
+          const int b = base + oh * OW + ow;
+          const float iv = inv[b];
+          const uint4 g = pool_tile[b * 8 + v];
           const T* pg = (const T*)&g;
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) sum[j] += to_f32(pg[j]) * inv;
+          for (int j = 0; j < VEC; ++j) sum[j] += to_f32(pg[j]) * iv;
         }
-      }
+      base += a.oh[s] * OW;
     }
     uint4 o;
     T* po = (T*)&o;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) po[j] = from_f32<T>(sum[j]);
-    ((uint4*)dx)[i] = o;
+    *(uint4*)(dx + ((long long)n * HW + pix) * C + c0 + v * VEC) = o;
   }
 }
 
@@ -245,6 +299,102 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx
       }
     }
     dx[i] = from_f32<T>(s);
+  }
+}
+
+// 16-byte-vector forms (C, ldy, coff multiples of one vector): same arithmetic per element as the scalar kernels above.
+template <typename T>
+__global__ void bilinear_fwd_vec_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int OH,
+                                        int OW, int ldy, int coff, int accumulate) {
+  constexpr int VEC = VecOf<T>::N;
+  const int cv = C / VEC;
+  const long long total = (long long)N * OH * OW * cv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    long long q = i / cv;
+    const int ow = (int)(q % OW);
+    q /= OW;
+    const int oh = (int)(q % OH);
+    const int n = (int)(q / OH);
+    int h0, h1, w0, w1;
+    float lh, lw;
+    bilin_src(oh, H, OH, h0, h1, lh);
+    bilin_src(ow, W, OW, w0, w1, lw);
+    const T* xb = x + (long long)n * H * W * C + c;
+    const uint4 v00 = *(const uint4*)(xb + ((long long)h0 * W + w0) * C), v01 = *(const uint4*)(xb + ((long long)h0 * W + w1) * C);
+    const uint4 v10 = *(const uint4*)(xb + ((long long)h1 * W + w0) * C), v11 = *(const uint4*)(xb + ((long long)h1 * W + w1) * C);
+    const T *p00 = (const T*)&v00, *p01 = (const T*)&v01, *p10 = (const T*)&v10, *p11 = (const T*)&v11;
+    T* dst = y + (((long long)n * OH + oh) * OW + ow) * ldy + coff + c;
+    uint4 o = make_uint4(0, 0, 0, 0);
+    if (accumulate) o = *(const uint4*)dst;
+    T* po = (T*)&o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float v = (1.f - lh) * ((1.f - lw) * to_f32(p00[j]) + lw * to_f32(p01[j])) +
+                      lh * ((1.f - lw) * to_f32(p10[j]) + lw * to_f32(p11[j]));
+      po[j] = from_f32<T>(accumulate ? to_f32(po[j]) + v : v);
+    }
+    *(uint4*)dst = o;
+  }
+}
+
+// Output pixels touching input index i form a contiguous range (the source coordinate is monotone in o): a conservative
+// float estimate of it, widened by one either side; the exact index test of the scalar kernel is kept inside.
+__device__ __forceinline__ void bilin_touch_range(int i, int in, int out, int& lo, int& hi) {
+  const float inv = (float)out / (float)in;
+  lo = max(0, (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1);
+  hi = min(out - 1, (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1);
+}
+
+template <typename T>
+__global__ void bilinear_bwd_vec_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C, int OH,
+                                        int OW, int lddy, int coff) {
+  constexpr int VEC = VecOf<T>::N;
+  const int cv = C / VEC;
+  const long long total = (long long)N * H * W * cv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    long long q = i / cv;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H);
+    const int n = (int)(q / H);
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+    int oh_lo, oh_hi, ow_lo, ow_hi;
+    bilin_touch_range(h, H, OH, oh_lo, oh_hi);
+    bilin_touch_range(w, W, OW, ow_lo, ow_hi);
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      int h0, h1;
+      float lh;
+      bilin_src(oh, H, OH, h0, h1, lh);
+      float wh = 0.f;
+      if (h0 == h) wh += 1.f - lh;
+      if (h1 == h) wh += lh;
+      if (wh == 0.f) continue;
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        int w0, w1;
+        float lw;
+        bilin_src(ow, W, OW, w0, w1, lw);
+        float ww = 0.f;
+        if (w0 == w) ww += 1.f - lw;
+        if (w1 == w) ww += lw;
+        if (ww == 0.f) continue;
+        const uint4 g = *(const uint4*)(dy + (((long long)n * OH + oh) * OW + ow) * lddy + coff + c);
+        const T* pg = (const T*)&g;
+        const float wt = wh * ww;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s[j] += wt * to_f32(pg[j]);
+      }
+    }
+    uint4 o;
+    T* po = (T*)&o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) po[j] = from_f32<T>(s[j]);
+    *(uint4*)(dx + ((((long long)n * H + h) * W + w) * C + c)) = o;
   }
 }
 
@@ -568,17 +718,21 @@ int mr_adaptive_avgpool_multi_fwd(int dtype, const void* x, void* const* ys, con
   const int vec = dtype == MR_F32 ? 4 : 8;
   MR_CHECK_ARG(nscales > 0 && nscales <= MR_POOL_MULTI_MAX && N > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0,
                "mr_adaptive_avgpool_multi_fwd: bad arguments");
-  MR_CHECK_ARG((long long)H * W * 128 <= 65536, "mr_adaptive_avgpool_multi_fwd: H*W (%d) too large for the LDS tile", H * W);
+  MR_CHECK_ARG((long long)H * W * 128 <= 61440 && H < 65536 && W < 65536,
+               "mr_adaptive_avgpool_multi_fwd: H*W (%d) too large for the LDS tile", H * W);
   PoolMultiArgs a;
   a.nsc = nscales;
   for (int i = 0; i < nscales; ++i) {
     MR_CHECK_ARG(ys[i] != nullptr && oh[i] > 0 && ow[i] > 0, "mr_adaptive_avgpool_multi_fwd: bad scale %d", i);
     a.oh[i] = oh[i]; a.ow[i] = ow[i]; a.y[i] = ys[i];
   }
+  int nbins = 0;
+  for (int i = 0; i < nscales; ++i) nbins += oh[i] * ow[i];
+  MR_CHECK_ARG(nbins <= MR_POOL_MULTI_BINS, "mr_adaptive_avgpool_multi_fwd: %d bins > %d", nbins, MR_POOL_MULTI_BINS);
   const int cpb = dtype == MR_F32 ? 32 : 64;
-  const int lds = H * W * 128;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((adaptive_avgpool_multi_fwd_kernel<T>), dim3(N, cdiv(C, cpb)), dim3(256), lds, stream,
-                                       (const T*)x, a, N, H, W, C));
+  const int lds = H * W * 128 + nbins * 8;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((adaptive_avgpool_multi_fwd_kernel<T>), dim3(cdiv(C, cpb), N), dim3(256), lds, stream,
+                                       (const T*)x, a, N, H, W, C, nbins));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }
@@ -593,9 +747,14 @@ int mr_adaptive_avgpool_multi_bwd(int dtype, void* const* dys, const int* oh, co
     MR_CHECK_ARG(dys[i] != nullptr && oh[i] > 0 && ow[i] > 0, "mr_adaptive_avgpool_multi_bwd: bad scale %d", i);
     a.oh[i] = oh[i]; a.ow[i] = ow[i]; a.y[i] = dys[i];
   }
-  const long long total = (long long)N * H * W * (C / vec);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((adaptive_avgpool_multi_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
-                                       a, (T*)dx, N, H, W, C));
+  int nbins = 0;
+  for (int i = 0; i < nscales; ++i) nbins += oh[i] * ow[i];
+  MR_CHECK_ARG(nbins <= MR_POOL_MULTI_BINS, "mr_adaptive_avgpool_multi_bwd: %d bins > %d", nbins, MR_POOL_MULTI_BINS);
+  const int cpb = dtype == MR_F32 ? 32 : 64;
+  const int lds = nbins * (128 + 4) + nscales * (H + W) * 4;
+  MR_CHECK_ARG(lds <= 65536, "mr_adaptive_avgpool_multi_bwd: tables (%d B) too large for LDS", lds);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((adaptive_avgpool_multi_bwd_kernel<T>), dim3(cdiv(C, cpb), N), dim3(256), lds, stream,
+                                       a, (T*)dx, N, H, W, C, nbins));
   MR_CHECK_LAUNCH();
   return MR_OK;
 }
@@ -603,6 +762,13 @@ int mr_adaptive_avgpool_multi_bwd(int dtype, void* const* dys, const int* oh, co
 int mr_bilinear_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, int OH, int OW, int ldy, int coff,
                     int accumulate, hipStream_t stream) {
   MR_CHECK_ARG(ldy >= coff + C, "mr_bilinear_fwd: channel slice out of range");
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  if (C % vec == 0 && ldy % vec == 0 && coff % vec == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_vec_kernel<T>), dim3(grid_for((long long)N * OH * OW * (C / vec), 256)),
+                                         dim3(256), 0, stream, (const T*)x, (T*)y, N, H, W, C, OH, OW, ldy, coff, accumulate));
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+  }
   const long long total = (long long)N * OH * OW * C;
   DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
                                        (const T*)x, (T*)y, N, H, W, C, OH, OW, ldy, coff, accumulate));
@@ -613,6 +779,13 @@ int mr_bilinear_fwd(int dtype, const void* x, void* y, int N, int H, int W, int 
 int mr_bilinear_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int OH, int OW, int lddy,
                     int coff, hipStream_t stream) {
   MR_CHECK_ARG(lddy >= coff + C, "mr_bilinear_bwd: channel slice out of range");
+  const int vec = dtype == MR_F32 ? 4 : 8;
+  if (C % vec == 0 && lddy % vec == 0 && coff % vec == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_vec_kernel<T>), dim3(grid_for((long long)N * H * W * (C / vec), 256)),
+                                         dim3(256), 0, stream, (const T*)dy, (T*)dx, N, H, W, C, OH, OW, lddy, coff));
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+  }
   const long long total = (long long)N * H * W * C;
   DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, stream,
                                        (const T*)dy, (T*)dx, N, H, W, C, OH, OW, lddy, coff));

@@ -1573,7 +1573,8 @@ def adaptive_avg_pool2d_multi(x, output_sizes):
     """[adaptive_avg_pool2d(x, s) for s in output_sizes] in one launch each way (<= 8 scales, H * W <= 512 pixels);
     falls back to the separate pools otherwise."""
     sizes = [(s_, s_) if isinstance(s_, int) else tuple(s_) for s_ in output_sizes]
-    if not (1 <= len(sizes) <= 8) or x.shape[2] * x.shape[3] * 128 > 65536 or x.shape[1] % vec_of(get_compute_dtype()):
+    if not (1 <= len(sizes) <= 8) or x.shape[2] * x.shape[3] * 128 > 32768 or x.shape[1] % vec_of(get_compute_dtype()) \
+            or sum(a * b for a, b in sizes) > 256 or max(x.shape[2], x.shape[3]) > 128:
         return tuple(adaptive_avg_pool2d(x, s_) for s_ in sizes)
     return AdaptiveAvgPoolMultiFn.apply(x, tuple(sizes))
 
@@ -1604,6 +1605,57 @@ class BilinearFn(Function):
 def interpolate_bilinear(x, size):
     """F.interpolate(x, size, mode='bilinear', align_corners=False)."""
     return BilinearFn.apply(x, tuple(size))
+
+
+class BilinearCatFn(Function):
+    """torch.cat([base] + [F.interpolate(b, base.shape[2:], mode='bilinear') for b in branches], 1) -- the pyramid pooling
+    head's concatenation (reference backbones/ppm.py:36-42): every resized branch is written straight into its channel slice
+    of the concatenation buffer, and backward reads the slices in place (no per-branch copy either way)."""
+
+    @staticmethod
+    def forward(ctx, base, *branches):
+        require_cuda(base)
+        dtype = get_compute_dtype()
+        dt = dtype_code(dtype)
+        bi = to_internal(base, dtype)
+        parts = [to_internal(b, dtype) for b in branches]
+        N, OH, OW, C0 = bi.shape
+        Ct = C0 + sum(p.shape[3] for p in parts)
+        y = torch.empty((N, OH, OW, Ct), dtype=dtype, device=bi.device)
+        call("mr_copy_channels", dt, ptr(bi), C0, 0, ptr(y), Ct, 0, N * OH * OW, C0)
+        off = C0
+        geoms = []
+        for p in parts:
+            _, H, W, C = p.shape
+            call("mr_bilinear_fwd", dt, ptr(p), ptr(y), N, H, W, C, OH, OW, Ct, off, 0)
+            geoms.append((H, W, C, off))
+            off += C
+        ctx.geom = (N, OH, OW, C0, Ct, tuple(geoms))
+        ctx.dtype = dtype
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, OH, OW, C0, Ct, geoms = ctx.geom
+        g = _grad_internal(gy, ctx.dtype)
+        dt = dtype_code(ctx.dtype)
+        d0 = torch.empty((N, OH, OW, C0), dtype=ctx.dtype, device=g.device)
+        call("mr_copy_channels", dt, ptr(g), Ct, 0, ptr(d0), C0, 0, N * OH * OW, C0)
+        outs = [d0.permute(0, 3, 1, 2)]
+        for H, W, C, off in geoms:
+            d = torch.empty((N, H, W, C), dtype=ctx.dtype, device=g.device)
+            call("mr_bilinear_bwd", dt, ptr(g), ptr(d), N, H, W, C, OH, OW, Ct, off)
+            outs.append(d.permute(0, 3, 1, 2))
+        return tuple(outs)
+
+
+def cat_bilinear(base, branches):
+    """cat([base] + [interpolate_bilinear(b, base.shape[2:]) for b in branches], 1); channel counts must be multiples of one
+    16-byte vector (falls back to the separate ops otherwise)."""
+    v = vec_of(get_compute_dtype())
+    if base.shape[1] % v or any(b.shape[1] % v for b in branches):
+        return cat_channels([base] + [interpolate_bilinear(b, base.shape[2:]) for b in branches])
+    return BilinearCatFn.apply(base, *branches)
 
 
 class UpsampleAddFn(Function):

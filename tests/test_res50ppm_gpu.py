@@ -90,6 +90,34 @@ def test_small_ops_vs_torch(dtype):
     assert torch.equal(c.float().cpu(), torch.cat([a, b], 1).float())
     c.backward(c.detach())
     assert torch.equal(ad.grad.float().cpu(), a.float()) and torch.equal(bd.grad.float().cpu(), b.float())
+    # F.cat_bilinear (the PPM's cat([conv5] + resized branches), branches written straight into the buffer) == separate ops,
+    # bit for bit both ways; also a down-scaling resize and an FPN-sized 2x up-scaling through the bounded gather
+    base = torch.randn(2, 32, 4, 16, generator=g).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+    brs = [torch.randn(2, 16, s_, s_, generator=g).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+           for s_ in (1, 2, 3, 6)]
+    outs = []
+    for fused in (False, True):
+        xs = [t.clone().requires_grad_(True) for t in [base] + brs]
+        if fused:
+            y = F.cat_bilinear(xs[0], xs[1:])
+        else:
+            y = F.cat_channels([xs[0]] + [F.interpolate_bilinear(b_, (4, 16)) for b_ in xs[1:]])
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(dtype).to(DEV)
+        y.backward(gy.contiguous(memory_format=torch.channels_last))
+        outs.append([y] + [t.grad for t in xs])
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    for (h, w), (oh, ow), ch in (((8, 32), (16, 64), 64), ((9, 7), (4, 3), 8), ((5, 6), (5, 6), 8), ((3, 5), (17, 11), 24)):
+        x = torch.randn(2, ch, h, w, generator=g).to(dtype)
+        xr = x.double().requires_grad_(True)
+        yr = TF.interpolate(xr, (oh, ow), mode='bilinear', align_corners=False)
+        gy = torch.randn(yr.shape, generator=g).to(dtype)
+        yr.backward(gy.double())
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = F.interpolate_bilinear(xd, (oh, ow))
+        y.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
+        tol = 1e-5 if dtype == torch.float32 else 1.2e-2
+        assert _rel(y, yr) < tol and _rel(xd.grad, xr.grad) < tol
 
 
 def test_ctc2d_head_vs_torch():
