@@ -525,13 +525,22 @@ def main():
         if use_graph and not args.no_kernel_timer:
             # HIP events cannot bracket kernels inside a graph replay: measure the dominant kernel's launch durations
             # on the same stream with the same tensors in an eager pass right after the timed region
+            # (deferred weight-gradient problems are launched grouped, from mr_tn_flush: an event bracket around the recording
+            # call would time nothing, so this pass launches every problem on its own -- the grouped launches of the timed
+            # region are in the rocprofv3 summaries under profiles/)
+            from megreader_amd.nn import functional as _F
+            defer_was = _F._TnDefer.enabled
+            _F._TnDefer.enabled = False
             timer = _lib.KernelTimer(CONV_CALLS)
             _lib.TIMER = timer
             timer_steps = min(steps, 10)
-            for _ in range(timer_steps):
-                step()
-            torch.cuda.synchronize()
-            _lib.TIMER = None
+            try:
+                for _ in range(timer_steps):
+                    step()
+                torch.cuda.synchronize()
+            finally:
+                _lib.TIMER = None
+                _F._TnDefer.enabled = defer_was
         else:
             timer_steps = steps
         if distributed:

@@ -145,6 +145,11 @@ int mr_gemm_tn2(int dtype, const void* A, long long lda, const void* B, long lon
 int mr_tn_defer(int on);
 int mr_tn_pending(void);
 int mr_tn_flush(hipStream_t stream);
+/* mr_tn_flush on a stream that runs CONCURRENTLY with the stream of the other weight-gradient launches (the reference leaves this
+ * to cuDNN's wgrad behind nn.Conv2d / nn.LSTM backward on PyTorch's single stream, backbones/crnn.py:44-55, decoders/crnn.py:13):
+ * nothing it launches touches the per-device split-reduction workspace (mr_set_tn_taps_workspace).  The caller orders the
+ * stream after the producers of the recorded operands and joins it before anything reads the gradients. */
+int mr_tn_flush_beside(hipStream_t stream);
 
 /* ---- Convolution (replaces cuDNN conv fwd/dgrad/wgrad behind nn.Conv2d: backbones/crnn.py:44-55,
  *      backbones/resnet.py:39-256, backbones/ppm.py:11-44, decoders/ctc_decoder2d.py:16-27) --------------- */

@@ -116,6 +116,7 @@ SIGNATURES = {
     "mr_ctc2d_fwd": "ippppiiiiiipps",
     "mr_ctc2d_bwd": "ippppppppp" + "iiiiiis",
     "mr_tn_flush": "s",
+    "mr_tn_flush_beside": "s",
     "mr_db_loss_fwd": "pppppppppp" + "ilffffs",
     "mr_db_head_tail_fwd": "ippppplfs",
     "mr_db_head_tail_bwd": "i" + "pppppppp" + "lfs",

@@ -480,6 +480,7 @@ static int launch_tn_big(TnArgs a, const ConvGeom& g, int total_steps, hipStream
 struct TnRecord { TnArgs a; ConvGeom g; };
 struct TnDeferState {
   bool on = false;
+  bool beside = false;          // mr_tn_flush_beside in progress: launches must not touch the shared split-reduction workspace
   std::vector<TnRecord> q[2];   // [0]: BMODE 0, [1]: BMODE 2
 };
 static thread_local TnDeferState g_tn_defer_state;
@@ -530,10 +531,11 @@ static int launch_tn_group(const TnRecord* recs, int n, hipStream_t stream) {
 template <typename T, int BMODE>
 static int launch_tn_now(TnArgs a, const ConvGeom& g, hipStream_t stream);
 
-static int tn_flush(hipStream_t stream) {
+static int tn_flush(hipStream_t stream, bool beside = false) {
   TnDeferState& st = g_tn_defer_state;
   const bool was_on = st.on;
   st.on = false;      // single problems below go through launch_tn_now
+  st.beside = beside;
   int rc = MR_OK;
   for (int m = 0; m < 2 && rc == MR_OK; ++m) {
     std::vector<TnRecord>& q = st.q[m];
@@ -549,6 +551,7 @@ static int tn_flush(hipStream_t stream) {
     q.clear();
   }
   st.on = was_on;
+  st.beside = false;
   return rc;
 }
 
@@ -618,7 +621,8 @@ static int launch_tn_now(TnArgs a, const ConvGeom& g, hipStream_t stream) {
       // Measured (tools/gpu_r2_tn.sh): the publish + ticket round costs ~8 us of latency, the atomics it removes scale with
       // the split count -- conv1 wgrad (5 tiles x ~100 splits) 92.6 -> 80.1 us, but conv6 wgrad (16 splits... of 64 tiles)
       // 44.2 -> 46.8 and the LSTM / Linear weight gradients (4 splits) +-2 us: automatic = only from 16 splits up.
-      if (g_tn_fin == 2 && splits > 1) {   // direct slabs + finalize launch (TnArgs.fin)
+      const bool beside = g_tn_defer_state.beside;   // concurrent with launches of another stream: plain atomics only
+      if (g_tn_fin == 2 && splits > 1 && !beside) {   // direct slabs + finalize launch (TnArgs.fin)
         void* ws = nullptr;
         long long ws_bytes = 0;
         taps_get_workspace(&ws, &ws_bytes);
@@ -629,7 +633,7 @@ static int launch_tn_now(TnArgs a, const ConvGeom& g, hipStream_t stream) {
           a.ws = ws;
         }
       }
-      if (a.fin != 2 && g_tn_group != 1 && splits > 1 && (g_tn_group > 1 || splits >= 16)) {
+      if (a.fin != 2 && g_tn_group != 1 && !beside && splits > 1 && (g_tn_group > 1 || splits >= 16)) {
         void* ws = nullptr;
         long long ws_bytes = 0;
         taps_get_workspace(&ws, &ws_bytes);
@@ -778,6 +782,10 @@ int mr_tn_defer(int on) {
 }
 int mr_tn_pending(void) { return (int)(g_tn_defer_state.q[0].size() + g_tn_defer_state.q[1].size()); }
 int mr_tn_flush(hipStream_t stream) { return tn_flush(stream); }
+// The same on a stream that runs BESIDE the stream of the other weight-gradient launches: single leftover problems reduce their
+// split partials with plain f32 atomics (the ticket / slab workspace of the in-launch reduction is shared per device and
+// must only be used by launches that are stream-ordered with each other).
+int mr_tn_flush_beside(hipStream_t stream) { return tn_flush(stream, true); }
 
 int mr_gemm_tn(int dtype, const void* A, long long lda, const void* B, long long ldb, float* C, int ldc, int P,
                int NA, int NB, int row_perm_h, float* colsum, hipStream_t stream) {

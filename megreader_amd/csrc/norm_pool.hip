@@ -824,6 +824,53 @@ __global__ __launch_bounds__(256) void maxpool_bwd_2x2s2_kernel(const T* __restr
   }
 }
 
+// Backward of the 2x2 / stride (2, 1) / padding (0, pw) pool on even H (CRNN pools 3 and 4, reference backbones/crnn.py:52-55):
+// the two input rows of a window row share their windows, so one thread serves the input pixels (2*ho, w) and (2*ho + 1, w):
+// the (at most) two windows wo = w + pw - {0, 1} are loaded once -- dy, codes, ReLU mask source -- instead of once per row.
+// Accumulation order per output as in maxpool_bwd_fixed_kernel<T, 2, 2, 2, 1> (jx = 0, then 1): the same bits.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_2x2s21_kernel(const T* __restrict__ dy,
+                                                                  const unsigned char* __restrict__ idx,
+                                                                  const T* __restrict__ relu_y, T* __restrict__ dx, int H,
+                                                                  int W, int cv, int pw, int Ho, int Wo) {
+  constexpr int VEC = VecOf<T>::N;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= W * cv) return;
+  const int w = t / cv, c = t - w * cv;
+  const int n = blockIdx.y / Ho, ho = blockIdx.y - n * Ho;
+  float acc[2][VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = 0.f;
+#pragma unroll
+  for (int jx = 0; jx < 2; ++jx) {
+    const int wo = w + pw - jx;
+    if (wo < 0 || wo >= Wo) continue;
+    const long long o = (((long long)n * Ho + ho) * Wo + wo) * cv + c;
+    const uint4 g = ((const uint4*)dy)[o];
+    const T* pg = (const T*)&g;
+    unsigned char code[8];
+    if (VEC == 8) *(uint2*)code = *(const uint2*)(idx + o * VEC);
+    else *(unsigned*)code = *(const unsigned*)(idx + o * VEC);
+    uint4 yv = make_uint4(0, 0, 0, 0);
+    if (relu_y) yv = ((const uint4*)relu_y)[o];
+    const T* py = (const T*)&yv;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const bool live = !relu_y || to_f32(py[j]) > 0.f;
+      if (live && code[j] == jx) acc[0][j] += to_f32(pg[j]);
+      if (live && code[j] == 2 + jx) acc[1][j] += to_f32(pg[j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    uint4 out;
+    T* po = (T*)&out;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) po[j] = from_f32<T>(acc[i][j]);
+    ((uint4*)dx)[(((long long)n * H + 2 * ho + i) * W + w) * cv + c] = out;
+  }
+}
+
 #define g_bn_fused MR_TUNE(bn_fused)   // 1: fold the finalize kernels into the apply passes (mr_tuning.bn_fused)
 // blocks along the rows of a fused apply pass: ~8 row groups per block, at most ~16 blocks per CU in total
 static inline int bn_fused_grid_x(long long P, int rows, int slabs) {
@@ -1089,6 +1136,13 @@ int mr_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, const vo
       (long long)N * Ho <= 65535 && MR_TUNE(pool_fixed)) {   // organised by pooled element (maxpool_bwd_2x2s2_kernel)
     DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_2x2s2_kernel<T>), dim3(cdiv(Wo * cv, 256), N * Ho), dim3(256), 0, stream,
                                          (const T*)dy, idx, (const T*)relu_y, (T*)dx, H, W, cv, Ho, Wo));
+    MR_CHECK_LAUNCH();
+    return MR_OK;
+  }
+  if (kh == 2 && kw == 2 && sh == 2 && sw == 1 && ph == 0 && (pw == 0 || pw == 1) && H == 2 * Ho && Wo == W + 2 * pw - 1 &&
+      (long long)N * Ho <= 65535 && MR_TUNE(pool_fixed)) {   // both input rows of a window row per thread
+    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_2x2s21_kernel<T>), dim3(cdiv(W * cv, 256), N * Ho), dim3(256), 0, stream,
+                                         (const T*)dy, idx, (const T*)relu_y, (T*)dx, H, W, cv, pw, Ho, Wo));
     MR_CHECK_LAUNCH();
     return MR_OK;
   }

@@ -201,6 +201,17 @@ class _TnDefer(object):
     MEGREADER_TN_DEFER=0 (or mr_tuning.tn_defer = 0): every launch immediate (A/B)."""
     enabled = os.environ.get("MEGREADER_TN_DEFER", "1") != "0"
     MAX = 12
+    # MEGREADER_TN_SIDE: where a flush in the MIDDLE of a backward pass is launched.  0: on the backward stream.  1: the group a
+    # BiLSTM layer closes (its four weight gradients + the Linear layers recorded behind it) goes to the side stream (_Side),
+    # beside the next layer's recurrence -- a latency chain on half of the CUs.  2: also the convolution problems, SIDE_MAX at a
+    # time, beside the input-gradient chain (pays when that chain's launches leave CUs idle: small per-GPU batches).
+    # Never for parameters a data-parallel wrapper watches (it wants the gradients as they complete, on the backward stream).
+    # MEASURED SLOWER in every replayed step (profiles/r05_ab_tn_side_stream.txt: CRNN 2.542 -> 2.565 / 2.560 ms, 32 crops 1.154 ->
+    # 1.173 / 1.210, Res50-PPM 11.21 -> 11.69, FPN-attention 8.25 -> 9.37, DB 9.05 -> 9.83 for modes 1 / 2): a grouped launch
+    # holds 198 VGPRs per lane, so the recurrence's workgroups cannot share a SIMD with it and wait for its CUs anyway, and
+    # beside the convolution chain the two streams evict each other's L2 lines.  Default 0; kept as an A/B switch.
+    side = int(os.environ.get("MEGREADER_TN_SIDE", "0"))
+    SIDE_MAX = int(os.environ.get("MEGREADER_TN_SIDE_MAX", "3"))
     keep = []
     notify = []
     queued = False
@@ -235,12 +246,26 @@ class _TnDefer(object):
         _TnDefer.keep.extend(t for t in tensors if t is not None)
         _TnDefer.notify.extend(params)
         if n >= _TnDefer.MAX:
-            _TnDefer.flush(final=False)
+            _TnDefer.flush(final=False, side=_TnDefer.side >= 2)
+        elif _TnDefer.side >= 2 and n >= _TnDefer.SIDE_MAX:
+            _TnDefer.flush(final=False, side=True, only_side=True)
         return True
 
     @staticmethod
-    def flush(final=True):
+    def flush(final=True, side=False, only_side=False):
+        """side: the caller is in the middle of a backward pass and nothing before its end reads these gradients -- launch on
+        the side stream if MEGREADER_TN_SIDE allows (only_side: or not at all yet)."""
         if load().mr_tn_pending():
+            watched = any(getattr(p, "_mr_grad_ready_hooks", None) for p in _TnDefer.notify)
+            if side and not final and _TnDefer.side >= 1 and not watched:
+                with torch.cuda.stream(_Side.fork()):
+                    call("mr_tn_flush_beside")
+                _Side.pending.extend(_TnDefer.keep)      # operands stay alive until the join at the end of the backward pass
+                del _TnDefer.keep[:]
+                del _TnDefer.notify[:]                   # nobody watches these parameters
+                return
+            if only_side:
+                return
             call("mr_tn_flush")
         ready, _TnDefer.notify = _TnDefer.notify, []
         del _TnDefer.keep[:]
@@ -252,8 +277,10 @@ class _TnDefer(object):
 
 def flush_deferred_wgrads():
     """Launch every recorded weight-gradient problem now (data-parallel wrappers call this before they finalise a backward
-    pass; harmless when nothing is recorded)."""
+    pass; harmless when nothing is recorded) and make the current stream wait for the ones already launched on the side stream."""
     _TnDefer.flush(final=False)
+    if _Side.queued:
+        _Side.join()
 
 
 def to_internal(x, dtype):
@@ -1343,7 +1370,8 @@ class BiLSTMFn(Function):
             if _TnDefer.end((dgates, x, out), list(ctx.params)):
                 # one launch for the layer (and the Linear layers recorded behind it); a data-parallel wrapper wants the
                 # gradients as they complete, and the next layer's recurrence is a latency chain that leaves the CUs idle anyway
-                _TnDefer.flush(final=False)
+                # (MEGREADER_TN_SIDE >= 1: beside that chain, on the side stream)
+                _TnDefer.flush(final=False, side=True)
             else:
                 for p in ctx.params:
                     notify_grad_ready(p)

@@ -216,7 +216,8 @@ def test_maxpool(dtype, k, s, p, relu_input):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("k,s,p,shape", [((2, 2), (2, 2), (0, 0), (5, 128, 16, 64)), ((2, 2), (2, 2), (0, 0), (3, 64, 10, 14)),
                                          ((2, 2), (2, 2), (0, 0), (2, 64, 9, 13)),      # odd sizes: uncovered last row / column
-                                         ((2, 2), (2, 1), (0, 1), (4, 256, 8, 32)), ((3, 3), (2, 2), (1, 1), (2, 64, 17, 31))])
+                                         ((2, 2), (2, 1), (0, 1), (4, 256, 8, 32)), ((2, 2), (2, 1), (0, 1), (3, 64, 4, 33)),
+                                         ((2, 2), (2, 1), (0, 0), (2, 64, 6, 9)), ((3, 3), (2, 2), (1, 1), (2, 64, 17, 31))])
 def test_maxpool_round5_kernels_are_bit_identical(dtype, k, s, p, shape):
     """mr_tuning.pool_fixed: the fixed-geometry forward (packed code store) and the pooled-element-organised 2x2 / stride 2
     backward give the same bits -- values, arg-max codes (through the gradient) and ReLU masking -- as the round-4 kernels."""
