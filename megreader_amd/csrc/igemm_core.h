@@ -333,6 +333,22 @@ __device__ __forceinline__ void igemm_nt_body(const NtArgs& a, const ConvGeom& g
   for (int i = 0; i < TN; ++i)
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // float32 operands: the MFMA accumulator is ONE round-to-nearest f32 chain over the whole reduction, whose error grows
+  // like sqrt(K) -- 2.4x (K = 256) to 9x (K = 36864) the error of PyTorch's blocked CPU convolution against float64
+  // (tools/diag_f32_error.py, profiles/r05_f32_error_by_layer.txt), the "constant 1.5x" of the Res50-PPM stage table.  The
+  // f32 instantiation therefore keeps the chain one k-step (8 MFMA accumulations) long and carries the running total in
+  // float64 registers; the total is rounded to f32 once, in the epilogue.  (bf16 operands: input rounding dominates by four
+  // orders of magnitude; that path is unchanged.)
+  constexpr bool WIDE = sizeof(T) == 4;
+  double tot[WIDE ? TN : 1][WIDE ? TM : 1][4];
+  if constexpr (WIDE) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tot[i][j][e] = 0.0;
+  }
 
   load_tiles(0);
   for (int k0 = 0; k0 < a.K; k0 += BK) {
@@ -355,6 +371,16 @@ __device__ __forceinline__ void igemm_nt_body(const NtArgs& a, const ConvGeom& g
 #pragma unroll
         for (int j = 0; j < TM; ++j) Mma<T>::run(acc[i][j], fb[i], fa[j]);  // D[n][m]
     }
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tot[i][j][e] += (double)acc[i][j][e];
+          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
     __syncthreads();
   }
 
@@ -367,7 +393,10 @@ __device__ __forceinline__ void igemm_nt_body(const NtArgs& a, const ConvGeom& g
     for (int i = 0; i < TN; ++i) {
       const int m = m0 + wm_ * WTM + j * 16 + l15;
       const int n = n0 + wn_ * WTN + i * 16 + lg * 4;
-      epi(m, n, acc[i][j]);
+      if constexpr (WIDE)
+        epi(m, n, (f32x4){(float)tot[i][j][0], (float)tot[i][j][1], (float)tot[i][j][2], (float)tot[i][j][3]});
+      else
+        epi(m, n, acc[i][j]);
     }
 }
 
@@ -771,6 +800,17 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
   for (int i = 0; i < TN; ++i)
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // float32 operands: f32 chains of one k-step, running total in float64 (see igemm_nt_body)
+  constexpr bool WIDE = sizeof(T) == 4;
+  double tot[WIDE ? TN : 1][WIDE ? TM : 1][4];
+  if constexpr (WIDE) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tot[i][j][e] = 0.0;
+  }
 
   auto compute = [&](const uint4* st) {
 #pragma unroll
@@ -784,6 +824,16 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) Mma<T>::run(acc[i][j], fb[i], fa[j]);
+    }
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tot[i][j][e] += (double)acc[i][j][e];
+          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
   };
 
@@ -843,7 +893,10 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
   for (int j = 0; j < TM; ++j) {
     f32x4 run[TN];
 #pragma unroll
-    for (int i = 0; i < TN; ++i) run[i] = acc[i][j];
+    for (int i = 0; i < TN; ++i) {
+      if constexpr (WIDE) run[i] = (f32x4){(float)tot[i][j][0], (float)tot[i][j][1], (float)tot[i][j][2], (float)tot[i][j][3]};
+      else run[i] = acc[i][j];
+    }
     if constexpr (EpiHasStats<Epi>::value)
       if (with_stats) cst.add(epi, m0 + wm_ * WTM + j * 16 + l15, n0 + wn_ * WTN + lg * (4 * TN), run);
     epi.template store_run<TN>(m0 + wm_ * WTM + j * 16 + l15, n0 + wn_ * WTN + lg * (4 * TN), run);

@@ -69,8 +69,11 @@ def test_res50ppm_2dctc_fp32_n256_elementwise():
           "f32 oracle %.2e  (%d%% of entries finite)" % (lerr, perr, e_hip, e_cpu, int(100 * float(finite.float().mean()))))
     REPORT["Res50-PPM-2DCTC fp32 N=256 log-probs"] = {"hip_vs_f32": perr, "hip_vs_f64": e_hip, "f32_vs_f64": e_cpu}
     assert lerr < 1e-4
-    assert e_hip < max(1e-4, 2 * e_cpu), (e_hip, e_cpu)
-    assert perr < 3e-4
+    # round 5: the f32 convolution kernels carry their running total in float64 (csrc/igemm_core.h, tools/diag_f32_error.py), and
+    # north_star's 1e-4 is met literally -- 5.2e-5 from the exact value (the reference's own f32 arithmetic: 8.1e-5), 9.1e-5 from
+    # the f32 reference, nearly all of which is the reference's distance from the exact value (round 4: 1.26e-4 / 1.57e-4)
+    assert e_hip < 1e-4, (e_hip, e_cpu)
+    assert perr < 1.2e-4, (perr, e_cpu)
     loss.mean().backward()
     named = [(k, p) for k, p in model.named_parameters() if k in grads_o]
     for k, p in model.named_parameters():
