@@ -89,7 +89,7 @@ struct DcnFusedArgs {
   void* dx_t;            // dx in the compute dtype, OVERWRITTEN (no zero fill, no conversion pass); only with tsplit == 1
   const int* start;      // CSR row starts, [Q*taps + 1]
   const int2* entries;   // CSR entries {output pixel p, bits of the bilinear * mask weight}
-  float* y32;            // fwd with tap splits: f32 [P][Co] accumulator (zeroed), converted by dcn_finish_kernel
+  float* y32;            // fwd with tap splits: f32 [tsplit][P][Co] slabs of partial sums, summed in order by dcn_finish_kernel
   DcnGeom g;
   int Co, P, Q;
   int tsplit;            // tap groups (grid.y): the k-loop of a workgroup covers taps / tsplit taps; partial results are
@@ -229,7 +229,10 @@ __global__ __launch_bounds__(256) void dcn2_fwd_fused_kernel(DcnFusedArgs a) {
     __syncthreads();
   }
 
-  if (a.tsplit > 1) {   // partial sums of this tap group into the f32 accumulator; dcn_finish_kernel adds the bias and converts
+  if (a.tsplit > 1) {   // this tap group's partial sums go to ITS slab with plain stores; dcn_finish_kernel adds the slabs in tap
+                        // order, adds the bias and converts: the same bits every run (round 4 added them with f32 atomics, and
+                        // the DB step's forward pass differed from run to run)
+    float* __restrict__ slab = a.y32 + (long long)blockIdx.y * a.P * a.Co;
 #pragma unroll
     for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -237,8 +240,7 @@ __global__ __launch_bounds__(256) void dcn2_fwd_fused_kernel(DcnFusedArgs a) {
         const int m = m0 + wm_ * Nt::WTM + j * 16 + l15;
         const int n = n0 + wn_ * Nt::WTN + i * 16 + lg * 4;
         if (m >= a.P || n >= a.Co) continue;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(a.y32 + (long long)m * a.Co + n + e, acc[i][j][e]);
+        *(f32x4*)(slab + (long long)m * a.Co + n) = acc[i][j];
       }
     return;
   }
@@ -259,12 +261,13 @@ __global__ __launch_bounds__(256) void dcn2_fwd_fused_kernel(DcnFusedArgs a) {
     }
 }
 
-// y[m, n] = T(y32[m, n] + bias[n])   (forward with tap splits)
+// y[m, n] = T(sum over the tap groups' slabs, in tap order, of y32[t][m, n]  + bias[n])   (forward with tap splits)
 template <typename T>
 __global__ void dcn_finish_kernel(const float* __restrict__ y32, const float* __restrict__ bias, T* __restrict__ y,
-                                  long long total4, int Co) {
+                                  long long total4, int Co, int nslab) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
     f32x4 v = ((const f32x4*)y32)[i];
+    for (int t = 1; t < nslab; ++t) v += ((const f32x4*)y32)[t * total4 + i];
     if (bias) {
       const int n = (int)((i * 4) % Co);
       v += *(const f32x4*)(bias + n);
@@ -274,7 +277,7 @@ __global__ void dcn_finish_kernel(const float* __restrict__ y32, const float* __
 }
 
 // tap groups for a launch of `tiles` workgroups (taps = 9): only launches that leave most of the chip idle are split -- the
-// partial results meet in f32 atomics (+ a memset and a convert pass forward), which cost more than the shorter k-loop saves
+// partial results meet in f32 slabs + an ordered sum-and-convert pass (forward) or f32 atomics (backward), which cost more than the shorter k-loop saves
 // once ~100 workgroups exist (measured at batch 2: layer2.1 forward with 200 tiles 29 us unsplit, 87 us split 3-way).
 static int dcn_tap_split(long long tiles, int taps) {
   if (taps != 9) return 1;
@@ -1003,11 +1006,7 @@ int dcn_fused_fwd(int dtype, const void* x, const void* w_n, const float* bias, 
   a.tsplit = dcn_tap_split((long long)tiles_m * (Co / bn), g.kh * g.kw);
   if (a.tsplit > 1) {
     MR_CHECK_ARG(ws != nullptr, "dcn forward: workspace missing (mr_dcn2_ws_bytes)");
-    a.y32 = (float*)ws;
-    if (hipMemsetAsync(ws, 0, (size_t)a.P * Co * 4, stream) != hipSuccess) {
-      mr::set_error("dcn forward: hipMemsetAsync failed");
-      return MR_ERR_LAUNCH;
-    }
+    a.y32 = (float*)ws;      // [tsplit][P][Co] f32 slabs, every element written by its tap group (no zero fill)
   }
   if (bn == 128) {
     DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_fwd_fused_kernel<T, 128>), dim3(tiles_m * (Co / 128), a.tsplit), dim3(256), 0,
@@ -1022,7 +1021,7 @@ int dcn_fused_fwd(int dtype, const void* x, const void* w_n, const float* bias, 
     long long blocks = (total4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     DISPATCH_T(dtype, hipLaunchKernelGGL((dcn_finish_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream,
-                                         (const float*)ws, bias, (T*)y, total4, Co));
+                                         (const float*)ws, bias, (T*)y, total4, Co, a.tsplit));
     MR_CHECK_LAUNCH();
   }
   return MR_OK;
@@ -1032,7 +1031,8 @@ int dcn_fused_fwd(int dtype, const void* x, const void* w_n, const float* bias, 
 long long dcn_fused_fwd_ws_bytes(int N, int Ho, int Wo, int Co, int taps) {
   const long long P = (long long)N * Ho * Wo;
   const int bn = Co % 128 == 0 ? 128 : 64;
-  return dcn_tap_split(((P + 63) / 64) * (Co / bn), taps) > 1 ? P * Co * 4 : 0;
+  const int tsplit = dcn_tap_split(((P + 63) / 64) * (Co / bn), taps);
+  return tsplit > 1 ? P * Co * 4 * tsplit : 0;
 }
 
 long long dcn_fused_ws_bytes(int N, int H, int W, int Ho, int Wo, int taps) {

@@ -227,10 +227,11 @@ def test_fpn_attention_timed_step():
 
 
 def test_db_detector_timed_step():
-    # whole deformable network at default initialisation: the small layers' tap-split forward adds its partial sums with f32
-    # atomics, so eager and replay differ by round-off in the FORWARD pass, which this network amplifies (module docstring of
-    # tests/test_deformable_resnet_gpu.py); the f64-anchored bars above are the parity statement, this one is loose
-    _isolated("db_n2", always=("conv2_offset.weight", "layer4.2.conv2."), replay_bar=5e-2)
+    # whole deformable network at default initialisation.  Round 4: the small layers' tap-split forward added its partial sums
+    # with f32 atomics, eager and replay differed by round-off in the FORWARD pass, which this network amplifies (module docstring
+    # of tests/test_deformable_resnet_gpu.py), and this bar was 5e-2.  Round 5: per-tap-group slabs summed in tap order
+    # (csrc/dcn_fused.hip: dcn_finish_kernel) -- the forward pass is the same bits every run, the default bar applies again
+    _isolated("db_n2", always=("conv2_offset.weight", "layer4.2.conv2."))
 
 
 if __name__ == "__main__":
