@@ -872,10 +872,17 @@ __global__ __launch_bounds__(256) void maxpool_bwd_2x2s21_kernel(const T* __rest
 }
 
 #define g_bn_fused MR_TUNE(bn_fused)   // 1: fold the finalize kernels into the apply passes (mr_tuning.bn_fused)
-// blocks along the rows of a fused apply pass: ~8 row groups per block, at most ~16 blocks per CU in total
+// blocks along the rows of a fused apply pass: ~4 row groups per block (8 until round 5), at most ~16 blocks per CU in total
 static inline int bn_fused_grid_x(long long P, int rows, int slabs) {
-  long long gx = (P + (long long)rows * 8 - 1) / ((long long)rows * 8);
-  const long long cap = 4096 / slabs > 1 ? 4096 / slabs : 1;
+  static int groups = 0, capw = 0;   // experiment hooks (tools/): MEGREADER_BN_GROUPS row groups per block, MEGREADER_BN_CAP blocks
+  if (!groups) {
+    const char* e = getenv("MEGREADER_BN_GROUPS");
+    groups = e && atoi(e) > 0 ? atoi(e) : 4;    // Res50-PPM step: 11.14 / 11.11 / 11.18 / 11.30 / 11.62 ms at 2 / 4 / 8 / 16 / 32
+    const char* c = getenv("MEGREADER_BN_CAP");
+    capw = c && atoi(c) > 0 ? atoi(c) : 4096;
+  }
+  long long gx = (P + (long long)rows * groups - 1) / ((long long)rows * groups);
+  const long long cap = capw / slabs > 1 ? capw / slabs : 1;
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   return (int)gx;
