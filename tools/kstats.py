@@ -4,7 +4,7 @@ import csv
 import subprocess
 import sys
 
-rows = list(csv.DictReader(open(sys.argv[1])))
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if r['kernel'].strip('"') != 'TOTAL']
 steps = int(sys.argv[2])
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 names = [r['kernel'].strip('"').replace('.kd', '') for r in rows]
