@@ -38,14 +38,12 @@ def label(name):
     m = re.search(r"igemm_nt_glds_kernelIDF16bLi(\d+)ELi(\d+)ELi[23]E", name)
     if m:
         return "igemm_nt_kernel<bf16,%s,%s,conv>" % (m.group(1), m.group(2))
-    if "igemm_nt_big_kernelIDF16bLi2ELi4ELi8ELi4ELi2E" in name:
-        return "igemm_nt_kernel<bf16,256,256,conv>"
+    m = re.search(r"igemm_nt_big_kernelIDF16bLi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi[23]E", name)
+    if m:   # 8-wave kernels: WM x WN waves of TM x TN MFMA tiles -> a (WM*TM*16) x (WN*TN*16) tile (bench.py labels launches by tile)
+        wm, wn, tm, tn = (int(x) for x in m.groups())
+        return "igemm_nt_kernel<bf16,%d,%d,conv>" % (wm * tm * 16, wn * tn * 16)
     if re.search(r"igemm_tn_glds_kernel<[12]", name) or re.search(r"igemm_tn_glds_kernelILi[12]E", name):
         return "igemm_tn_kernel<bf16,conv>"
-    if "igemm_nt_big_kernelIDF16bLi1ELi8ELi17ELi2ELi2E" in name:
-        return "igemm_nt_kernel<bf16,272,256,conv>"
-    if "igemm_nt_big_kernelIDF16bLi2ELi4ELi9ELi2ELi2E" in name:
-        return "igemm_nt_kernel<bf16,288,128,conv>"
     if "igemm_tn_taps_kernel" in name:
         return "igemm_tn_taps_kernel<bf16,3x3>"
     return None
