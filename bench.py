@@ -319,7 +319,11 @@ def main():
     for kv in args.set:
         from megreader_amd import _lib as _l
         name, val = kv.split("=")
-        getattr(_l.load(), "mr_set_" + name)(int(val))
+        _lib_ = _l.load()
+        if name in _l.TUNING_FIELDS and not hasattr(_lib_, "mr_set_" + name):
+            _l.set_tuning(**{name: int(val)})       # a plain mr_tuning field
+        else:
+            getattr(_lib_, "mr_set_" + name)(int(val))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or args.force_ddp

@@ -95,6 +95,11 @@ typedef struct mr_tuning {
                         mr_ctc_fwd and the mr_ctc_bwd that consumes its buffers */
   int nt_wide8;      /* 8-wave workgroups (two per CU) instead of the 4-wave ones on the NT tile shapes named by this bit mask:
                         1 = 128x128, 2 = 128x64, 4 = 96x128, 8 = 64x128, 16 = 96x64, 32 = 64x64; 0 = never (round 4) */
+  int nt_ksplit;     /* split reduction of the 4-wave NT kernels for launches of a few tiles with a long k-loop (round 5:
+                        at most a quarter of the CUs busy, >= 16 k-steps): 1 (default) = as many splits as fill the chip once
+                        with >= 4 k-steps each (<= 8), n > 1 = at most n, 0 = never.  Partial tiles meet in f32 slabs of the
+                        split-reduction workspace (mr_set_tn_taps_workspace) and are added in split order: the same bits every
+                        run; without a registered workspace the launch is unsplit */
   int reserved[1];   /* zero */
 } mr_tuning;
 int mr_tuning_get(mr_tuning* out);

@@ -127,7 +127,7 @@ _lib = None
 
 TUNING_FIELDS = ("nt_variant", "nt_deep", "nt_big", "nt_p8", "nt_force_bm", "nt_force_bn", "gemm_skinny", "tn_big", "tn_buf",
                  "tn_taps", "tn_taps_group", "tn_group", "tn_fin", "tn_taps_fin", "tn_taps_w8", "tn_model", "tn_splits",
-                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth", "nt_big_min_k", "tn_taps_min_p", "tn_defer", "pool_fixed", "ctc_linear", "nt_wide8")
+                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth", "nt_big_min_k", "tn_taps_min_p", "tn_defer", "pool_fixed", "ctc_linear", "nt_wide8", "nt_ksplit")
 
 
 class Tuning(ctypes.Structure):
@@ -338,7 +338,10 @@ class KernelTimer(object):
 TIMER = None  # set to a KernelTimer to enable
 
 _TN_WS = {}
-_TN_WS_CALLS = frozenset(("mr_gemm_tn", "mr_gemm_tn2", "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab"))
+_TN_WS_CALLS = frozenset(("mr_gemm_tn", "mr_gemm_tn2", "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab",
+                          # (the split reduction of the NT kernels, mr_tuning.nt_ksplit, uses the same workspace)
+                          "mr_conv2d_fwd", "mr_conv2d_fwd_stats", "mr_conv2d_dgrad", "mr_conv2d_dgrad_add", "mr_conv2d_dgrad_bnb",
+                          "mr_gemm_nt"))
 
 
 def ensure_tn_workspace(device=None):

@@ -60,8 +60,34 @@ static int num_cus();
 // The direct-to-LDS 4-wave kernel for one tile shape and epilogue type: 2-buffer loop, or the 4-buffer loop for low-occupancy
 // launches (see the comment inside).
 template <typename T, int BM, int BN, int AMODE, typename EpiT>
-static int launch_nt_glds(const NtArgs& a2, const ConvGeom& g, const EpiT& epi, int grid, int tiles, hipStream_t stream) {
+static int launch_nt_glds(const NtArgs& a_in, const ConvGeom& g, const EpiT& epi, int grid, int tiles, hipStream_t stream) {
   constexpr int BK = 8 * VecOf<T>::N;
+  NtArgs a2 = a_in;
+  unsigned gy = 1;
+  if constexpr (sizeof(T) == 2) {
+    // Split reduction for launches of a few tiles with a long k-loop (NtArgs.ksplit): at most a quarter of the CUs busy and
+    // >= 16 k-steps -> as many splits as keep >= 4 k-steps each, the chip filled once, <= 8.  Needs the per-device
+    // split-reduction workspace (mr_set_tn_taps_workspace; launches that use it are stream-ordered with each other).
+    const int mode = MR_TUNE(nt_ksplit);     // 0: never, 1: automatic, n > 1: at most n splits
+    const int nk_all = cdiv(a2.K, BK);
+    const int cus = num_cus();
+    if (mode > 0 && a2.m_begin == 0 && tiles * 4 <= cus && nk_all >= 16 && (AMODE == 0 || (g.Cg % BK) == 0) &&
+        tiles <= NT_SPLIT_TICKETS) {
+      int S = cus / tiles;
+      if (S > nk_all / 4) S = nk_all / 4;
+      if (S > 8) S = 8;
+      if (mode > 1 && S > mode) S = mode;
+      void* ws = nullptr;
+      long long ws_bytes = 0;
+      taps_get_workspace(&ws, &ws_bytes);
+      const long long need = NT_SPLIT_TICKETS * 4ll + (long long)tiles * S * BM * BN * 4;
+      if (S > 1 && ws && need <= ws_bytes && need < (1ll << 31)) {
+        a2.ksplit = S;
+        a2.ws = ws;
+        gy = (unsigned)S;
+      }
+    }
+  }
   if constexpr (sizeof(T) == 2) {
     // low-occupancy launches (about one workgroup per CU or fewer: the small-M layers of the batch-2 detector and the
     // batch-32 recogniser): 4 stage buffers, 3 k-steps of LDS-DMA in flight across the barriers (igemm_nt_glds_kernel NST)
@@ -83,7 +109,7 @@ static int launch_nt_glds(const NtArgs& a2, const ConvGeom& g, const EpiT& epi, 
         }
         attr_set = true;
       }
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a2, g, epi);
+      hipLaunchKernelGGL(kern, dim3(grid, gy), dim3(256), lds, stream, a2, g, epi);
       MR_CHECK_LAUNCH();
       return MR_OK;
     }
@@ -92,7 +118,7 @@ static int launch_nt_glds(const NtArgs& a2, const ConvGeom& g, const EpiT& epi, 
     hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, (AMODE == 2 ? 3 : AMODE), EpiT>), dim3(grid), dim3(256), 0, stream,
                        a2, g, epi);
   else
-    hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, AMODE, EpiT>), dim3(grid), dim3(256), 0, stream, a2, g, epi);
+    hipLaunchKernelGGL((igemm_nt_glds_kernel<T, BM, BN, AMODE, EpiT>), dim3(grid, gy), dim3(256), 0, stream, a2, g, epi);
   MR_CHECK_LAUNCH();
   return MR_OK;
 }

@@ -77,7 +77,15 @@ struct NtArgs {
   const void* zero;  // >= 16 bytes of zeros in global memory (source of padded / out-of-range vectors)
   int m_begin = 0;   // first row this launch computes (rows [m_begin, M)): lets the host cut a problem into a head that
                      // fills the CUs in whole rounds of big tiles and a small tail (glds / big kernels only)
+  // Split reduction (igemm_nt_glds_kernel, bf16): gridDim.y = ksplit workgroups share one output tile, each runs 1/ksplit of
+  // the k-steps, writes its f32 partial tile to a slab of `ws` and takes a ticket; the last arriver adds the slabs IN SPLIT
+  // ORDER (same bits whoever is last) and runs the epilogue.  For launches of a few tiles with a long reduction (the 512-row
+  // layers of a batch-32 / batch-2 step: 64 tiles x 72 dependent k-steps on a quarter of the CUs).
+  // ws = [NT_SPLIT_TICKETS ints, zero between launches][slabs of BM*BN*4 bytes, index tile*ksplit + split].
+  int ksplit = 1;
+  void* ws = nullptr;
 };
+constexpr int NT_SPLIT_TICKETS = 4096;
 
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *(const uint4*)p; }
 
@@ -837,19 +845,33 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
     }
   };
 
-  const int nk = (a.K + BK - 1) / BK;
+  // this workgroup's share of the reduction: k-steps [split * per, split * per + nk) of nk_all (NtArgs.ksplit; 1: all of them)
+  const int nk_all = (a.K + BK - 1) / BK;
+  int nk = nk_all, kb = 0;
+  if (a.ksplit > 1) {
+    const int per = (nk_all + a.ksplit - 1) / a.ksplit;
+    const int first = (int)blockIdx.y * per;
+    kb = first * BK;
+    nk = min(per, nk_all - first);     // may be <= 0 for the last splits: they contribute a zero slab
+    if (AMODE == 2) {
+      s_tap = kb / g.Cg;
+      s_c0 = kb - s_tap * g.Cg;
+      s_r = s_tap / g.S;
+      s_s = s_tap - s_r * g.S;
+    }
+  }
   if constexpr (NST == 2) {
     uint4* st0 = smem;
     uint4* st1 = smem + TILE_VECS;
-    if (nk > 0) stage(st0, 0);
+    if (nk > 0) stage(st0, kb);
     // two k-steps per iteration so that the stage base is a compile-time constant in every LDS access
     int t = 0;
     for (; t + 1 < nk; t += 2) {
       __syncthreads();  // k-step t landed (vmcnt drained before the barrier); stage 1 is free
-      stage(st1, (t + 1) * BK);
+      stage(st1, kb + (t + 1) * BK);
       compute(st0);
       __syncthreads();
-      if (t + 2 < nk) stage(st0, (t + 2) * BK);
+      if (t + 2 < nk) stage(st0, kb + (t + 2) * BK);
       compute(st1);
     }
     if (t < nk) {
@@ -865,7 +887,7 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
     static_assert((NST - 2) * LPS <= 63, "vmcnt is a 6-bit counter");
 #pragma unroll
     for (int u = 0; u < NST - 1; ++u)
-      if (u < nk) stage(smem + u * TILE_VECS, u * BK);
+      if (u < nk) stage(smem + u * TILE_VECS, kb + u * BK);
     for (int t0 = 0; t0 < nk; t0 += NST) {
 #pragma unroll
       for (int u = 0; u < NST; ++u) {
@@ -875,9 +897,47 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(NtArgs a, ConvGeom g
           if (younger >= 2 && NST >= 4) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
           else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
           else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-          if (t + NST - 1 < nk) stage(smem + ((u + NST - 1) % NST) * TILE_VECS, (t + NST - 1) * BK);
+          if (t + NST - 1 < nk) stage(smem + ((u + NST - 1) % NST) * TILE_VECS, kb + (t + NST - 1) * BK);
           compute(smem + u * TILE_VECS);
         }
+      }
+    }
+  }
+
+  if constexpr (!WIDE) {
+    if (a.ksplit > 1) {
+      // partial tile -> own slab (register order: element (k, tid) = accumulator tile k of thread tid), ticket, and the last
+      // arriver of the tile sums all slabs in split order (the protocol of the TN kernels' group reduction: sc1 stores, the
+      // ticket behind s_waitcnt vmcnt(0) + barrier, sc1 loads)
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
+      const int tile_lin = tile_m * tiles_n + tile_n;
+      const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((char*)a.ws + NT_SPLIT_TICKETS * 4, (short)0, 0x7fffffff, 0x00020000);
+      constexpr int SLAB = BM * BN * 4;
+      const int so = (tile_lin * a.ksplit + (int)blockIdx.y) * SLAB;
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, acc[i][j]), rs, tid * 16, so + (i * TM + j) * 4096, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();       // (also: every wave is done with the stage buffers)
+      volatile int* bc = (volatile int*)smem;
+      int* tk = (int*)a.ws + (tile_lin % NT_SPLIT_TICKETS);
+      if (tid == 0) *bc = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (*bc != a.ksplit - 1) return;
+      if (tid == 0) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int sp = 0; sp < a.ksplit; ++sp) {
+        const int sj = (tile_lin * a.ksplit + sp) * SLAB;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, sj + (i * TM + j) * 4096, 16));
       }
     }
   }

@@ -52,6 +52,63 @@ def test_gemm_nt(dtype, M, N, K):
         assert float((C[:, N:].float() - 7.0).abs().max()) == 0.0  # pad columns untouched
 
 
+@pytest.mark.parametrize("case", [("gemm", 512, 512, 4608), ("gemm", 300, 200, 2048), ("gemm", 64, 1024, 1056),
+                                  ("conv", 2, 16, 16, 512, 256, 3), ("conv", 3, 7, 9, 256, 192, 3), ("conv", 2, 20, 20, 1024, 256, 1)])
+def test_nt_split_reduction_is_exact_and_repeatable(case):
+    """mr_tuning.nt_ksplit (round 5): launches of a few tiles with a long k-loop are cut along the reduction; the partial
+    tiles meet in f32 slabs and are added in split order.  With integer-valued operands every product and partial sum is exact,
+    so split and unsplit launches must agree BIT FOR BIT (output, fused bias + ReLU, BatchNorm statistics of the epilogue); with
+    random operands two split launches must agree bit for bit with each other (fixed summation order) and with the unsplit one
+    to bf16 rounding."""
+    from megreader_amd import _lib
+    _lib.ensure_tn_workspace(DEV)
+    mr.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(len(case) + case[1] + case[3])
+
+    def run(ints):
+        if case[0] == "gemm":
+            _, M, N, K = case
+            A = (torch.randint(-3, 4, (M, K), generator=g).float() if ints else torch.randn(M, K, generator=g)).to(DEV, torch.bfloat16)
+            B = (torch.randint(-2, 3, (N, K), generator=g).float() if ints else torch.randn(N, K, generator=g)).to(DEV, torch.bfloat16)
+            bias = torch.randint(-4, 5, (N,), generator=g).float().to(DEV)
+            ldc = (N + 7) // 8 * 8
+
+            def launch():
+                C = torch.zeros((M, ldc), device=DEV, dtype=torch.bfloat16)
+                call("mr_gemm_nt", dtype_code(torch.bfloat16), ptr(A), K, ptr(B), K, ptr(C), ldc, ptr(bias), 1, M, N, K)
+                return (C,)
+        else:
+            _, N_, H, W, Cin, Cout, R = case
+            x = (torch.randint(-3, 4, (N_, Cin, H, W), generator=g).float() if ints else torch.randn(N_, Cin, H, W, generator=g))
+            w = (torch.randint(-2, 3, (Cout, Cin, R, R), generator=g).float() if ints else
+                 torch.randn(Cout, Cin, R, R, generator=g) / (Cin * R * R) ** 0.5)
+            xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+            wd = w.to(DEV)
+
+            def launch():
+                y = F.conv2d(xd, wd, None, (1, 1), (R // 2, R // 2), bn_stats=True)
+                pre = getattr(y, "_mr_bn_sums", None)     # the BatchNorm statistics of the epilogue (arena slice: clone now)
+                return (y,) + ((pre.sums.clone(),) if pre is not None else ())
+        outs = {}
+        for mode in (0, 1, 1, 4):
+            old = _lib.set_tuning(nt_ksplit=mode)
+            try:
+                outs.setdefault(mode, []).append([t.detach().clone() for t in launch()])
+            finally:
+                _lib.set_tuning(**old)
+        return outs
+
+    exact = run(True)
+    for mode in (1, 4):
+        for a, b in zip(exact[0][0], exact[mode][0]):
+            assert torch.equal(a, b), (case, mode)
+    rnd = run(False)
+    for a, b in zip(rnd[1][0], rnd[1][1]):
+        assert torch.equal(a, b), case                    # repeatable
+    for a, b in zip(rnd[0][0], rnd[1][0]):
+        assert _rel_err(a.float(), b.float()) < 1.6e-2, case
+
+
 @pytest.mark.parametrize("M,N,K,code", [(70000, 256, 576, 256257), (66000, 256, 576, 272256), (33792, 512, 640, 272256),
                                         (65536 + 256, 256, 512, 272256)])
 def test_gemm_nt_head_tail_split(M, N, K, code):
