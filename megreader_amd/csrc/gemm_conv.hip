@@ -59,6 +59,21 @@ static int num_cus();
 
 // The direct-to-LDS 4-wave kernel for one tile shape and epilogue type: 2-buffer loop, or the 4-buffer loop for low-occupancy
 // launches (see the comment inside).
+static int num_cus();
+// Splits of the reduction for a 4-wave NT launch of `tiles` output tiles and nk_all k-steps (NtArgs.ksplit): only launches that
+// keep at most a quarter of the CUs busy on a chain of >= 16 k-steps; as many splits as fill the chip once with >= 4 k-steps
+// each, at most 8 (mr_tuning.nt_ksplit: 0 never, 1 automatic, n: at most n).  1 = do not split.
+static int nt_split_count(int tiles, int nk_all) {
+  const int mode = MR_TUNE(nt_ksplit);
+  const int cus = num_cus();
+  if (mode <= 0 || tiles * 4 > cus || nk_all < 16 || tiles > NT_SPLIT_TICKETS) return 1;
+  int S = cus / tiles;
+  if (S > nk_all / 4) S = nk_all / 4;
+  if (S > 8) S = 8;
+  if (mode > 1 && S > mode) S = mode;
+  return S > 1 ? S : 1;
+}
+
 template <typename T, int BM, int BN, int AMODE, typename EpiT>
 static int launch_nt_glds(const NtArgs& a_in, const ConvGeom& g, const EpiT& epi, int grid, int tiles, hipStream_t stream) {
   constexpr int BK = 8 * VecOf<T>::N;
@@ -68,20 +83,14 @@ static int launch_nt_glds(const NtArgs& a_in, const ConvGeom& g, const EpiT& epi
     // Split reduction for launches of a few tiles with a long k-loop (NtArgs.ksplit): at most a quarter of the CUs busy and
     // >= 16 k-steps -> as many splits as keep >= 4 k-steps each, the chip filled once, <= 8.  Needs the per-device
     // split-reduction workspace (mr_set_tn_taps_workspace; launches that use it are stream-ordered with each other).
-    const int mode = MR_TUNE(nt_ksplit);     // 0: never, 1: automatic, n > 1: at most n splits
     const int nk_all = cdiv(a2.K, BK);
-    const int cus = num_cus();
-    if (mode > 0 && a2.m_begin == 0 && tiles * 4 <= cus && nk_all >= 16 && (AMODE == 0 || (g.Cg % BK) == 0) &&
-        tiles <= NT_SPLIT_TICKETS) {
-      int S = cus / tiles;
-      if (S > nk_all / 4) S = nk_all / 4;
-      if (S > 8) S = 8;
-      if (mode > 1 && S > mode) S = mode;
+    const int S = (a2.m_begin == 0 && (AMODE == 0 || (g.Cg % BK) == 0)) ? nt_split_count(tiles, nk_all) : 1;
+    if (S > 1) {
       void* ws = nullptr;
       long long ws_bytes = 0;
       taps_get_workspace(&ws, &ws_bytes);
       const long long need = NT_SPLIT_TICKETS * 4ll + (long long)tiles * S * BM * BN * 4;
-      if (S > 1 && ws && need <= ws_bytes && need < (1ll << 31)) {
+      if (ws && need <= ws_bytes && need < (1ll << 31)) {
         a2.ksplit = S;
         a2.ws = ws;
         gy = (unsigned)S;
@@ -441,6 +450,8 @@ static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long l
       // (mask 3) alone: CRNN 2.658 -> 2.615 ms, Res50-PPM 12.21 -> 11.68, FPN-attention 8.73 -> 8.55, DB 9.85 -> 9.53
       // (profiles/r05_ab_nt_wide8.txt) -- also for the one-round launches the 4-buffer loop used to serve.
       const int w8 = MR_TUNE(nt_wide8);
+      // (few-tile launches of these shapes stay on the 8-wave kernels: sending them to the 4-wave kernel's split reduction
+      // instead, mr_tuning.nt_ksplit, measured equal or slower -- DB 8.86 vs 8.93 ms, CRNN at 32 crops 1.139 vs 1.148)
       if (w8 > 0 && a.m_begin == 0) {
         const TileChoice tw = nt_tile(a.M, a.N);
 #define MR_NT_W8(BIT_, BM_, BN_, WM_, WN_, TM_, TN_) \
