@@ -367,6 +367,7 @@ def ensure_tn_workspace(device=None):
         if os.environ.get("MEGREADER_FAN", "0") == "1" or os.environ.get("MEGREADER_OVERLAP", "0") == "1":
             lib.mr_set_tn_group(1)
             lib.mr_set_tn_taps_group(1)
+            set_tuning(nt_ksplit=0)      # GEMMs of one layer on several streams: nobody may use the shared slabs / tickets
     return ws
 
 

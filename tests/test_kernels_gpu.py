@@ -584,13 +584,18 @@ def test_big_tile_nt_kernel_bit_identical_to_4wave_kernel(mode):
     g = torch.Generator().manual_seed(5 + mode)
 
     def both(fn):
+        from megreader_amd import _lib as _l
         old = lib.mr_set_nt_big(-1)
+        # (same summation order on both sides: the 4-wave kernel's split reduction, mr_tuning.nt_ksplit, would cut the k-loop of
+        # these few-tile problems)
+        old_split = _l.set_tuning(nt_ksplit=0)
         try:
             ref = fn()
             lib.mr_set_nt_big(mode)
             out = fn()
         finally:
             lib.mr_set_nt_big(old)
+            _l.set_tuning(**old_split)
         return ref, out
 
     # dense: M ragged against 256 and 288, N = 512 (two column tiles), K not a multiple of 64
