@@ -99,7 +99,9 @@ typedef struct mr_tuning {
                         at most a quarter of the CUs busy, >= 16 k-steps): 1 (default) = as many splits as fill the chip once
                         with >= 4 k-steps each (<= 8), n > 1 = at most n, 0 = never.  Partial tiles meet in f32 slabs of the
                         split-reduction workspace (mr_set_tn_taps_workspace) and are added in split order: the same bits every
-                        run; without a registered workspace the launch is unsplit */
+                        run; without a registered workspace the launch is unsplit.  Like the weight-gradient launches that use
+                        that workspace, split launches must be stream-ordered with every other user of it: a process that
+                        drives the library from two streams at once (training beside inference) sets this field to 0 */
   int reserved[1];   /* zero */
 } mr_tuning;
 int mr_tuning_get(mr_tuning* out);
