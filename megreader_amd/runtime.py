@@ -78,23 +78,27 @@ def scalar_mean(loss):
 _LIVE_STEPS = []      # weak references to the GraphedTrainStep objects that are alive
 
 
+_CAPTURE_STREAMS = {}     # device index -> the stream every GraphedTrainStep of this process warms up and captures on
+
+
 class GraphedTrainStep(object):
-    """One captured training step.  Keep ONE alive per model: with a second capture of the same model / optimizer alive at
-    the same time, replays of the newer graph read clobbered intermediates on this ROCm 7.0 runtime (the attention decoder's
-    per-step loss came back as the sum of its first k steps, k changing from replay to replay; gone as soon as the older
-    object is deleted before the new capture -- tools/diag_attn_replay.py, profiles/r04_diag_capture_crash.txt).  bench.py,
-    the drop-in trainer and the tests hold at most one at a time; a second live instance triggers a RuntimeWarning."""
+    """One captured training step.
+
+    Several captures of one model / optimizer may be alive at once since round 5.  Rounds 3-4 saw replays of the NEWER graph
+    race while an older capture was alive (the attention decoder's loss came back as the sum of its first k steps; with more
+    replays an HSA memory-aperture violation).  Root cause: torch caches the parameters' AccumulateGrad nodes for as long as any
+    earlier autograd graph lives, each bound to the stream it was created on; every instance used to capture on a stream of its
+    own, so the second capture found nodes bound to the FIRST capture's stream and the engine synchronised the two streams
+    inside the capture.  All instances now warm up and capture on one stream per device (_CAPTURE_STREAMS, see _capture);
+    tools/diag_attn_replay.py, profiles/r05_diag_two_live_captures.txt, tests/test_fpn_attention_gpu.py::
+    test_two_live_captured_steps_replay_consistently.  (The process-global scratch -- zero arena, split-reduction workspace --
+    is shared by all captures by design: replays on one stream are ordered.)"""
 
     def __init__(self, loss_fn, optimizer, static_inputs, warmup=3, grad_sync=None):
         import gc
-        import warnings
         import weakref
         gc.collect()
         _LIVE_STEPS[:] = [r for r in _LIVE_STEPS if r() is not None]
-        if any(r().optimizer is optimizer for r in _LIVE_STEPS):
-            warnings.warn("megreader_amd.runtime.GraphedTrainStep: another captured step of the same optimizer is still alive; "
-                          "delete it before capturing a new one (replays of the newer hipGraph were observed to read "
-                          "clobbered buffers otherwise, see the class docstring)", RuntimeWarning, stacklevel=2)
         _LIVE_STEPS.append(weakref.ref(self))
         self.loss_fn = loss_fn
         self.optimizer = optimizer
@@ -139,7 +143,17 @@ class GraphedTrainStep(object):
         import gc
         import os
         gc.collect()
-        s = torch.cuda.Stream()
+        # ONE capture stream per device for every GraphedTrainStep of the process (round 5).  The AccumulateGrad nodes of the
+        # parameters are cached by torch for as long as any earlier autograd graph lives and stay bound to the stream they
+        # were created on; with a fresh stream per instance, a second capture while the first is alive found nodes bound to the
+        # FIRST capture's stream, the engine synchronised the two streams inside the capture ("The AccumulateGrad node's
+        # stream does not match ..."), and replays of the second graph raced: partial decode-step sums in round 4, an
+        # HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION after some tens of replays in round 5 (tools/diag_attn_replay.py,
+        # profiles/r05_diag_two_live_captures.txt).  With a shared stream the cached nodes already sit on the capture stream.
+        dev = torch.cuda.current_device()
+        s = _CAPTURE_STREAMS.get(dev)
+        if s is None:
+            s = _CAPTURE_STREAMS[dev] = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(self._warmup):

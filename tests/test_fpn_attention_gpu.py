@@ -180,3 +180,41 @@ def test_scheduled_sampling_is_redrawn_on_every_graph_replay():
     step2 = GraphedTrainStep(loss_fn, opt, [], warmup=1)
     fixed = [round(float(step2()), 5) for _ in range(3)]
     assert len(set(fixed)) == 1, fixed
+
+
+def test_two_live_captured_steps_replay_consistently():
+    """VERDICT r4 parity item 4.  Two GraphedTrainStep captures of ONE model alive at the same time -- the older one still
+    holding its loss WITH its autograd graph, which keeps the parameters' AccumulateGrad nodes (and the stream they are bound
+    to) alive.  With a capture stream per instance the newer graph's replays raced (partial decode-step sums in round 4, a memory
+    aperture violation after some tens of replays in round 5: profiles/r05_diag_two_live_captures.txt); all instances now
+    capture on one stream per device (runtime._CAPTURE_STREAMS).  lr = 0 and fixed teacher forcing: every replay of the second
+    graph must give the same loss, equal to an eager step's, and interleaved replays of the first graph must not disturb it."""
+    import warnings
+    from megreader_amd.optim import FusedAdam
+    from megreader_amd.runtime import GraphedTrainStep
+    _ora, dec, feat, lab, ln = _decoder_pair()
+    x, lab_d, ln_d = feat.to(DEV), lab.to(DEV), ln.to(DEV)
+    opt = FusedAdam(dec.parameters(), lr=0.0)
+    opt.zero_grad()
+    hold = {}
+
+    def loss_fn():
+        loss = dec(x, targets=lab_d, lengths=ln_d, train=True)[0]
+        hold["loss"] = loss                                    # keeps the step's autograd graph alive, like a careless caller
+        return loss.mean()
+    step1 = GraphedTrainStep(loss_fn, opt, [], warmup=2)      # random coins
+    first = [float(step1()) for _ in range(3)]
+    dec.gt_as_output = True
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                         # torch's "AccumulateGrad node's stream does not match" included
+        step2 = GraphedTrainStep(loss_fn, opt, [], warmup=1)
+    losses = []
+    for i in range(120):
+        losses.append(round(float(step2()), 5))
+        if i % 40 == 39:
+            float(step1())                                     # the older graph is still usable and does not disturb the newer
+    assert len(set(losses)) == 1, sorted(set(losses))
+    opt.zero_grad()
+    eager = float(loss_fn())
+    assert abs(eager - losses[0]) <= 2e-5 * max(1.0, abs(eager)), (eager, losses[0])
+    assert all(v == v for v in first)

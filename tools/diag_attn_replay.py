@@ -44,6 +44,10 @@ def run(first_graph, warmup, fixed, variant=''):
         os.environ["MEGREADER_CAPTURE_STREAM"] = "own"
     dec.gt_as_output = fixed
     s2 = GraphedTrainStep(loss_fn, opt, [], warmup=warmup)
+    many = [round(float(s2()), 4) for _ in range(int(os.environ.get("DIAG_REPLAYS", "0")))]
+    if many:
+        torch.cuda.synchronize()
+        print("  graph 2, %d replays: distinct losses %s" % (len(many), sorted(set(many))))
     for r in range(3):
         l = float(s2())
         torch.cuda.synchronize()
@@ -52,7 +56,27 @@ def run(first_graph, warmup, fixed, variant=''):
                [v.tolist()[:6] for v in dec.__dict__.get("_flag_cache", {}).values()]))
 
 
-for cfg in ((True, 1, True, "del1"), (True, 1, True, "own"), (True, 1, True, "fixed1"), (True, 1, True, "")):
-    print("first_graph=%s warmup=%d gt_as_output=%s variant=%s" % cfg)
-    run(*cfg)
-    os.environ.pop("MEGREADER_CAPTURE_STREAM", None)
+def no_singletons():
+    """VERDICT r4 parity item 4: rule the process-global scratch out -- no zero arena (every kernel zeroes its own scratch), no
+    split-reduction workspace (plain atomics, unsplit NT launches), per-step output kernels."""
+    from megreader_amd import _lib
+    from megreader_amd.nn import functional as F
+    from megreader_amd.decoders import attention_decoder as ad
+    F.ZeroArena.take = staticmethod(lambda device, n: None)
+    _lib.load()
+    _lib.set_tuning(nt_ksplit=0, tn_group=1, tn_taps_group=1, bn_onepass=0)
+    F._TnDefer.enabled = False
+    ad.BATCHED_OUT = False
+
+
+if __name__ == "__main__":
+    variants = sys.argv[1:] or ["del1", "own", "fixed1", ""]
+    if "nosingletons" in variants:
+        no_singletons()
+        variants = [v for v in variants if v != "nosingletons"] or [""]
+        print("process-global scratch switched off (arena, split-reduction workspace, resident-grid BatchNorm, deferred wgrads)")
+    for v in variants:
+        cfg = (True, 1, True, v)
+        print("first_graph=%s warmup=%d gt_as_output=%s variant=%s" % cfg)
+        run(*cfg)
+        os.environ.pop("MEGREADER_CAPTURE_STREAM", None)
