@@ -381,3 +381,27 @@ def test_bench_shape_table_and_conv_call_normalisation(tmp_path):
     assert (m, n, k) == (4 * 8 * 16, 64, 9 * 128)
     m, n, k = (int(v) for v in by_entry["mr_conv2d_wgrad"][5:8])
     assert (m, n, k) == (128, 9 * 64, 4 * 8 * 16)
+
+
+def test_pmc_label_mapping_covers_the_kernel_families():
+    """tools/pmc_to_json.py keys the PMC traffic by bench.py's kernel labels; the 8-wave kernels are labelled by their tile
+    (WM x WN waves of TM x TN MFMA tiles), so that e.g. the 128x128 launches of a ResNet step -- which run on the 8-wave
+    variant since round 5 -- find their traffic under the label bench.py gives them."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "pmc_to_json", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pmc_to_json.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lab = mod.label
+    assert lab("_ZN2mr19igemm_nt_big_kernelIDF16bLi2ELi4ELi4ELi2ELi2ENS_8EpiStoreIDF16bEEEEvNS_6NtArgsE") == "igemm_nt_kernel<bf16,128,128,conv>"
+    assert lab("_ZN2mr19igemm_nt_big_kernelIDF16bLi4ELi2ELi2ELi2ELi2ENS_8EpiStoreIDF16bEEEEv") == "igemm_nt_kernel<bf16,128,64,conv>"
+    assert lab("_ZN2mr19igemm_nt_big_kernelIDF16bLi1ELi8ELi17ELi2ELi2ENS_8EpiStoreIDF16bEEEEv") == "igemm_nt_kernel<bf16,272,256,conv>"
+    assert lab("_ZN2mr19igemm_nt_big_kernelIDF16bLi2ELi4ELi9ELi2ELi2ENS_8EpiStoreIDF16bEEEEv") == "igemm_nt_kernel<bf16,288,128,conv>"
+    assert lab("_ZN2mr19igemm_nt_big_kernelIDF16bLi2ELi4ELi8ELi4ELi2ENS_8EpiStoreIDF16bEEEEv") == "igemm_nt_kernel<bf16,256,256,conv>"
+    assert lab("_ZN2mr19igemm_nt_big_kernelIDF16bLi2ELi4ELi3ELi2ELi0ENS_8EpiStoreIDF16bEEEEv") is None      # dense GEMM: not a conv label
+    assert lab("_ZN2mr20igemm_nt_glds_kernelIDF16bLi64ELi128ELi2ENS_8EpiStoreIDF16bEELi4EEEv") == "igemm_nt_kernel<bf16,64,128,conv>"
+    assert lab("_ZN2mr20igemm_tn_taps_kernelILi2ELi1ELi0ELb0EEEvNS_7TapArgsE") == "igemm_tn_taps_kernel<bf16,3x3>"
+    assert lab("_ZN2mr20igemm_tn_glds_kernelILi2ELb1ELi0EEEvNS_6TnArgsE") == "igemm_tn_kernel<bf16,conv>"
+    # the stamp bench.py compares: both sides hash the same files
+    assert len(mod.kernel_source_hash()) == 16
