@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 2   /* 2 (round 5): mr_ctc_fwd gained log_probs_f64; mr_tuning.tn_defer; mr_tn_defer / mr_tn_flush;
+#define MR_ABI_VERSION 3   /* 3 (round 6): mr_tuning grew (nt_m32, nt_m32_opt, reserved[6]).  2 (round 5): mr_ctc_fwd gained log_probs_f64; mr_tuning.tn_defer; mr_tn_defer / mr_tn_flush;
                               the 26 mr_set_* setters of version 1 are gone (mr_tuning) */
 #define MR_DTYPE_F32 0
 #define MR_DTYPE_BF16 1
@@ -102,7 +102,15 @@ typedef struct mr_tuning {
                         run; without a registered workspace the launch is unsplit.  Like the weight-gradient launches that use
                         that workspace, split launches must be stream-ordered with every other user of it: a process that
                         drives the library from two streams at once (training beside inference) sets this field to 0 */
-  int reserved[1];   /* zero */
+  int nt_m32;        /* round 6: ping-pong NT kernel on v_mfma_f32_32x32x16_bf16 (nt32.hip: 8 waves as two groups one phase apart,
+                        one always in its MFMA-only compute phase; output tile through LDS).  0 (default) = never: measured EQUAL
+                        to the round-5 kernels on every CRNN layer (profiles/r06_nt32_*: the steady-state k-tile is 15 % shorter,
+                        the fixed cost per launch 6 us longer; both kernels sit on the same launch + epilogue cost and the
+                        chip's power-limited MFMA rate); 1 = wherever the automatic choice takes a 256-column big tile
+                        (256x256 -> 256x256, 272x256 -> 288x256 as 1x8 waves); 2..5 = shape 256x256 / 288x256 / 256x128 / 128x256
+                        for every eligible bf16 launch (sweeps) */
+  int nt_m32_opt;    /* schedule variant of that kernel, 10 * PH + OPT (tools build -DMR_NT32_SWEEP only); 0 = the default */
+  int reserved[6];   /* zero */
 } mr_tuning;
 int mr_tuning_get(mr_tuning* out);
 int mr_tuning_defaults(mr_tuning* out);
@@ -151,6 +159,10 @@ int mr_gemm_tn2(int dtype, const void* A, long long lda, const void* B, long lon
  * no-op (A/B). */
 int mr_tn_defer(int on);
 int mr_tn_pending(void);
+/* The queue is per DEVICE and process-wide (records pushed by one host thread are flushed by whichever thread calls mr_tn_flush
+ * with that device current); mr_tn_discard drops the current device's records without launching them and switches recording off
+ * for the calling thread -- for a caller whose backward pass raised and is about to release the recorded operands (round 6). */
+int mr_tn_discard(void);
 int mr_tn_flush(hipStream_t stream);
 /* mr_tn_flush on a stream that runs CONCURRENTLY with the stream of the other weight-gradient launches (the reference leaves this
  * to cuDNN's wgrad behind nn.Conv2d / nn.LSTM backward on PyTorch's single stream, backbones/crnn.py:44-55, decoders/crnn.py:13):

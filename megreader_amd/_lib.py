@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "megreader_hip.h")
 
 MR_F32 = 0
 MR_BF16 = 1
-ABI_VERSION = 2     # include/megreader_hip.h: MR_ABI_VERSION
+ABI_VERSION = 3     # include/megreader_hip.h: MR_ABI_VERSION
 
 _P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_double
 _CODES = {"p": _P, "i": _I, "l": _L, "f": _F, "d": _D, "s": _P}
@@ -127,12 +127,12 @@ _lib = None
 
 TUNING_FIELDS = ("nt_variant", "nt_deep", "nt_big", "nt_p8", "nt_force_bm", "nt_force_bn", "gemm_skinny", "tn_big", "tn_buf",
                  "tn_taps", "tn_taps_group", "tn_group", "tn_fin", "tn_taps_fin", "tn_taps_w8", "tn_model", "tn_splits",
-                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth", "nt_big_min_k", "tn_taps_min_p", "tn_defer", "pool_fixed", "ctc_linear", "nt_wide8", "nt_ksplit")
+                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth", "nt_big_min_k", "tn_taps_min_p", "tn_defer", "pool_fixed", "ctc_linear", "nt_wide8", "nt_ksplit", "nt_m32", "nt_m32_opt")
 
 
 class Tuning(ctypes.Structure):
     """struct mr_tuning (include/megreader_hip.h): the library's only process-wide switches."""
-    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 1)]
+    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 6)]
 
 
 def get_tuning():
@@ -273,6 +273,8 @@ def load():
     lib.mr_tn_defer.argtypes = [ctypes.c_int]
     lib.mr_tn_pending.restype = ctypes.c_int
     lib.mr_tn_pending.argtypes = []
+    lib.mr_tn_discard.restype = ctypes.c_int
+    lib.mr_tn_discard.argtypes = []
     lib.mr_stem_bwd_workspace.restype = ctypes.c_longlong
     lib.mr_stem_bwd_workspace.argtypes = [ctypes.c_int]
     for name, codes in SIGNATURES.items():
@@ -299,7 +301,7 @@ def load():
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_tuning_get", "mr_tuning_set", "mr_tuning_defaults",
              "mr_stem_bwd_workspace", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_dcn2_ws_bytes", "mr_bn_scratch_doubles",
              "mr_sizeof_img_desc", "mr_nt_kernel_code", "mr_tn_taps_would_run", "mr_set_tn_taps_workspace",
-             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending", "mr_dcn2_dx_direct", "mr_dcn2_fused", "mr_db_loss_ws_bytes")  # entry points that take no stream and launch nothing
+             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending", "mr_tn_discard", "mr_dcn2_dx_direct", "mr_dcn2_fused", "mr_db_loss_ws_bytes")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

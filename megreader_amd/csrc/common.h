@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#define MR_MAX_DEVICES 16   /* per-device host-side tables (one node: 8 GPUs) */
 #define MR_BN_COPIES 8   /* accumulator copies of the BatchNorm forward statistics (norm_pool.hip bn_reduce_vec_kernel,
                             the NT kernels' statistics epilogue): f64 [MR_BN_COPIES][2][C] */
 

@@ -5,6 +5,7 @@
 #include "igemm_core.h"
 #include "igemm_p8.h"
 #include "tn_taps.h"
+#include "nt32.h"
 #include "../../include/megreader_hip.h"
 
 #include <algorithm>
@@ -410,6 +411,25 @@ static int dispatch_nt_store(const NtArgs& a, const ConvGeom& g, void* C, long l
     if (g_nt_variant == 2 && !forced_tile().bm && (AMODE == 0 || (g.Cg % BK) == 0) && aligned16(C) &&
         nt_fits_buffer<T>(a, g, AMODE) && g_epi_bnb.x == nullptr) {
       const int big = nt_big_choice(a.M, a.N, a.K);
+      // Ping-pong 32x32x16 kernel (nt32.hip, round 6; mr_tuning.nt_m32): 1 = wherever the automatic choice takes a 256-column
+      // big tile (256x256 -> 256x256, 272x256 -> 288x256), >= 2 = shape (nt_m32 - 1) for every eligible launch (sweeps)
+      if (const int m32 = MR_TUNE(nt_m32); m32 != 0 && a.m_begin == 0 && a.ksplit <= 1) {
+        const int shape = m32 >= 2 ? m32 - 1 : big == 1 ? 1 : big == 3 ? 2 : 0;
+        if (shape) {
+          EpiStore<bf16_t> epi;
+          epi.C = (bf16_t*)C;
+          epi.ldc = ldc;
+          epi.bias = bias;
+          epi.relu = relu;
+          epi.M = a.M;
+          epi.N = a.N;
+          epi.vec_ok = ((ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0) && ((((uintptr_t)g_epi_addend) & 15) == 0);
+          epi.addend = (const bf16_t*)g_epi_addend;
+          epi.stats = g_epi_stats;
+          epi.stats_ncopy = MR_BN_COPIES;
+          return launch_nt32(shape, MR_TUNE(nt_m32_opt), AMODE, a, g, epi, stream);
+        }
+      }
       if (big == 1) return launch_nt_p8<T, AMODE>(a, g, C, ldc, bias, relu, stream);
       if (big == 2) return launch_nt_big<T, 2, 4, 9, 4, AMODE>(a, g, C, ldc, bias, relu, stream);   // 288x256, 8 waves (2x4)
       if (big == 3) return launch_nt_big<T, 1, 8, 17, 2, AMODE>(a, g, C, ldc, bias, relu, stream);  // 272x256, 8 waves (1x8)
@@ -515,12 +535,23 @@ static int launch_tn_big(TnArgs a, const ConvGeom& g, int total_steps, hipStream
 // the workgroups of the launch finish together and the chip is filled by problems, not by splits.
 #define g_tn_defer MR_TUNE(tn_defer)   // 1 (default): mr_tn_defer(1) records; 0: it is ignored (every launch immediate)
 struct TnRecord { TnArgs a; ConvGeom g; };
+// Recording is switched per host THREAD (the bracket mr_tn_defer(1) ... mr_tn_defer(0) is one autograd node's), the QUEUE is per
+// DEVICE and process-wide behind a mutex: records are pushed on an autograd device worker thread, while the
+// end-of-backward callback that flushes them runs on whichever thread completes the graph task -- with a thread-local queue
+// that thread saw nothing pending, skipped the launch and still released the operands.
 struct TnDeferState {
   bool on = false;
   bool beside = false;          // mr_tn_flush_beside in progress: launches must not touch the shared split-reduction workspace
-  std::vector<TnRecord> q[2];   // [0]: BMODE 0, [1]: BMODE 2
 };
 static thread_local TnDeferState g_tn_defer_state;
+struct TnQueue { std::vector<TnRecord> q[2]; };   // [0]: BMODE 0, [1]: BMODE 2
+static std::mutex g_tn_queue_mutex;
+static TnQueue g_tn_queue[MR_MAX_DEVICES];
+static TnQueue& tn_queue_of_current_device() {     // (call with g_tn_queue_mutex held)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return g_tn_queue[(unsigned)dev % MR_MAX_DEVICES];
+}
 
 template <int BMODE>
 static int launch_tn_group(const TnRecord* recs, int n, hipStream_t stream) {
@@ -574,8 +605,15 @@ static int tn_flush(hipStream_t stream, bool beside = false) {
   st.on = false;      // single problems below go through launch_tn_now
   st.beside = beside;
   int rc = MR_OK;
+  TnQueue mine;       // the device's records, taken out under the lock: launches run without it
+  {
+    std::lock_guard<std::mutex> lock(g_tn_queue_mutex);
+    TnQueue& dq = tn_queue_of_current_device();
+    mine.q[0].swap(dq.q[0]);
+    mine.q[1].swap(dq.q[1]);
+  }
   for (int m = 0; m < 2 && rc == MR_OK; ++m) {
-    std::vector<TnRecord>& q = st.q[m];
+    std::vector<TnRecord>& q = mine.q[m];
     size_t i = 0;
     while (i < q.size() && rc == MR_OK) {
       const int n = (int)std::min<size_t>(TN_GROUP_MAX, q.size() - i);
@@ -601,7 +639,8 @@ static int launch_tn(TnArgs a, const ConvGeom& g, hipStream_t stream) {
       const long long bytesB = BMODE == 0 ? (long long)a.P * a.ldb * 2
                                           : ((long long)a.P / ((long long)g.Hm * g.Wm) + 1) * g.Hg * g.Wg * g.ldg * 2;
       if (bytesA < (1ll << 31) && bytesB < (1ll << 31)) {
-        st.q[BMODE == 0 ? 0 : 1].push_back(TnRecord{a, g});
+        std::lock_guard<std::mutex> lock(g_tn_queue_mutex);
+        tn_queue_of_current_device().q[BMODE == 0 ? 0 : 1].push_back(TnRecord{a, g});
         return MR_OK;
       }
     }
@@ -817,7 +856,22 @@ int mr_tn_defer(int on) {
   g_tn_defer_state.on = on != 0;
   return old;
 }
-int mr_tn_pending(void) { return (int)(g_tn_defer_state.q[0].size() + g_tn_defer_state.q[1].size()); }
+int mr_tn_pending(void) {
+  std::lock_guard<std::mutex> lock(g_tn_queue_mutex);
+  const TnQueue& dq = tn_queue_of_current_device();
+  return (int)(dq.q[0].size() + dq.q[1].size());
+}
+// Drops the current device's recorded problems WITHOUT launching them (a backward pass that raised: its records point at operands
+// the caller is about to release) and switches recording off for the calling thread; returns how many were dropped.  Host only.
+int mr_tn_discard(void) {
+  g_tn_defer_state.on = false;
+  std::lock_guard<std::mutex> lock(g_tn_queue_mutex);
+  TnQueue& dq = tn_queue_of_current_device();
+  const int n = (int)(dq.q[0].size() + dq.q[1].size());
+  dq.q[0].clear();
+  dq.q[1].clear();
+  return n;
+}
 int mr_tn_flush(hipStream_t stream) { return tn_flush(stream); }
 // The same on a stream that runs BESIDE the stream of the other weight-gradient launches: single leftover problems reduce their
 // split partials with plain f32 atomics (the ticket / slab workspace of the in-launch reduction is shared per device and

@@ -1,0 +1,3 @@
+// ping-pong 32x32x16 NT kernel, tile shape 3 (see nt32_impl.h)
+#define MR_NT32_SHAPE 3
+#include "nt32_impl.h"

@@ -215,7 +215,28 @@ class _TnDefer(object):
     keep = []
     notify = []
     queued = False
+    task = -1      # graph task (one backward() call) the end-of-backward callback is registered with
     mark = 0
+
+    @staticmethod
+    def _task_id():
+        fn = getattr(torch._C, "_current_graph_task_id", None)
+        return fn() if fn is not None else -1
+
+    @staticmethod
+    def abort():
+        """Forget everything recorded and not yet launched: the backward pass that recorded it raised -- the autograd
+        engine skips its final callbacks then, so `queued` would stay set, the records would point at operands about to be
+        released and a later step would add stale problems into its gradients.  Called from the recording sites when a call
+        between begin() and end() raises, from begin() when it finds the state of ANOTHER graph task, and from the optimizers'
+        zero_grad() / the capture fallbacks of the graphed step."""
+        lib = load()
+        lib.mr_tn_defer(0)
+        lib.mr_tn_discard()
+        del _TnDefer.keep[:]
+        del _TnDefer.notify[:]
+        _TnDefer.queued = False
+        _TnDefer.task = -1
 
     @staticmethod
     def begin():
@@ -223,16 +244,31 @@ class _TnDefer(object):
         or not inside a backward pass -- the end-of-backward flush could not be registered)."""
         if not _TnDefer.enabled:
             return False
+        tid = _TnDefer._task_id()
+        if _TnDefer.queued and tid != _TnDefer.task:
+            _TnDefer.abort()          # left over from a backward pass that never reached its callback
         if not _TnDefer.queued:
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(_TnDefer.flush)
             except RuntimeError:
                 return False
             _TnDefer.queued = True
+            _TnDefer.task = tid
         lib = load()
         _TnDefer.mark = lib.mr_tn_pending()
         lib.mr_tn_defer(1)
         return True
+
+    @staticmethod
+    def record(launch, tensors, params):
+        """begin() was True: run `launch` (the library calls to record) and end(); a raise in between drops the recording state
+        instead of leaving mr_tn_defer(1) on for whatever this thread launches next."""
+        try:
+            launch()
+        except BaseException:
+            _TnDefer.abort()
+            raise
+        return _TnDefer.end(tensors, params)
 
     @staticmethod
     def end(tensors, params):
@@ -271,8 +307,14 @@ class _TnDefer(object):
         del _TnDefer.keep[:]
         if final:
             _TnDefer.queued = False
+            _TnDefer.task = -1
         for p in ready:
             notify_grad_ready(p)
+
+
+def discard_deferred_wgrads():
+    """Drop every recorded, not yet launched weight-gradient problem (a backward pass that raised; a failed capture)."""
+    _TnDefer.abort()
 
 
 def flush_deferred_wgrads():
@@ -531,10 +573,15 @@ class Conv2dFn(Function):
                 tab, build = _wgrad_rowtab(g.device, (N, H, W, Cp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo), Kw % 8 == 0)
             # sunk gradients have no reader inside the backward pass: the launch may wait and share a grouped launch (_TnDefer)
             defer = w_sink is not None and (not want_db or b_sink is not None) and _TnDefer.begin()
-            call("mr_conv2d_wgrad_tab", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, Kw,
-                 Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo, ptr(tab), build)
-            if defer and _TnDefer.end((g, xi, tab), [weight_p] + ([bias_p] if want_db else [])):
-                return dx, None, None, None, None, None, None, None, None, None, None
+
+            def wgrad_launch():
+                call("mr_conv2d_wgrad_tab", dt, ptr(g), ptr(xi), ptr(gw), ptr(db) if want_db else 0, N, H, W, Cp, Cp, Kw,
+                     Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo, ptr(tab), build)
+            if defer:
+                if _TnDefer.record(wgrad_launch, (g, xi, tab), [weight_p] + ([bias_p] if want_db else [])):
+                    return dx, None, None, None, None, None, None, None, None, None, None
+            else:
+                wgrad_launch()
             if w_sink is not None:
                 dwt = None
                 notify_grad_ready(weight_p)
@@ -1073,10 +1120,11 @@ class LinearFn(Function):
             elif (w_sink is not None and (gb is None or b_sink is not None) and not _Fan.enabled and
                   dtype == torch.bfloat16 and _TnDefer.begin()):
                 # sunk gradients: recorded for a grouped launch (_TnDefer); the flush reports the parameters ready
-                if dx_fn is not None:
-                    dx_fn()
-                call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, NA, K, 0, ptr(gb))
-                if _TnDefer.end((gp, x2), [weight_p] + ([bias_p] if want_db else [])):
+                def lin_launch():
+                    if dx_fn is not None:
+                        dx_fn()
+                    call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, NA, K, 0, ptr(gb))
+                if _TnDefer.record(lin_launch, (gp, x2), [weight_p] + ([bias_p] if want_db else [])):
                     return dx, None, None
             else:   # input-gradient and weight-gradient GEMMs are independent: side by side (_Fan)
                 _Fan.run([dx_fn, lambda: call("mr_gemm_tn", dt, ptr(gp), Np, ptr(x2), K, ptr(gw), K, M, NA, K, 0,
@@ -1191,9 +1239,13 @@ class ConvTranspose2x2Fn(Function):
             else:
                 gw = w_sink if w_sink is not None else torch.zeros((Cin, K4), dtype=torch.float32, device=dev)
                 defer = w_sink is not None and dtype == torch.bfloat16 and _TnDefer.begin()
+
                 # dW[ci, (co, i, j)] += sum_p x[p, ci] dy2[p, (co, i, j)]: the parameter's own memory order
-                call("mr_gemm_tn", dt, ptr(x2), Cin, ptr(dy2), ld2, ptr(gw), K4, P, Cin, K4, 0, 0)
-                if defer and _TnDefer.end((x2, dy2), [weight_p]):
+                def deconv_launch():
+                    call("mr_gemm_tn", dt, ptr(x2), Cin, ptr(dy2), ld2, ptr(gw), K4, P, Cin, K4, 0, 0)
+                if not defer:
+                    deconv_launch()
+                if defer and _TnDefer.record(deconv_launch, (x2, dy2), [weight_p]):
                     pass
                 elif w_sink is not None:
                     notify_grad_ready(weight_p)
@@ -1357,17 +1409,18 @@ class BiLSTMFn(Function):
             # Grouped launch (_TnDefer): the four weight-gradient GEMMs of the layer -- W_ih and W_hh of both directions, each
             # straight into its sink, the bias sums (column sums of dgates, shared by b_ih and b_hh) into both bias sinks --
             # plus whatever the Linear layers behind this one recorded run as ONE launch.
-            if dx_fn is not None:
-                dx_fn()
-            P = (T - 1) * N
-            for d in range(2):    # bias gradient = column sums of dgates, added to b_ih AND b_hh by the same launch
-                call("mr_gemm_tn2", dt, ptr(dgates) + d * 4 * H * es, 8 * H, ptr(x), I, ptr(sinks[4 * d]), I, T * N, 4 * H, I, H,
-                     ptr(sinks[4 * d + 2]), ptr(sinks[4 * d + 3]))
-            # forward direction: dgates[t] (t >= 1) with h[t-1]; reverse direction: dgates[t] (t <= T-2) with h[t+1]
-            call("mr_gemm_tn", dt, ptr(dgates) + N * 8 * H * es, 8 * H, ptr(out), 2 * H, ptr(sinks[1]), H, P, 4 * H, H, H, 0)
-            call("mr_gemm_tn", dt, ptr(dgates) + 4 * H * es, 8 * H, ptr(out) + (N * 2 * H + H) * es, 2 * H, ptr(sinks[5]), H, P,
-                 4 * H, H, H, 0)
-            if _TnDefer.end((dgates, x, out), list(ctx.params)):
+            def lstm_launch():
+                if dx_fn is not None:
+                    dx_fn()
+                P = (T - 1) * N
+                for d in range(2):    # bias gradient = column sums of dgates, added to b_ih AND b_hh by the same launch
+                    call("mr_gemm_tn2", dt, ptr(dgates) + d * 4 * H * es, 8 * H, ptr(x), I, ptr(sinks[4 * d]), I, T * N, 4 * H, I,
+                         H, ptr(sinks[4 * d + 2]), ptr(sinks[4 * d + 3]))
+                # forward direction: dgates[t] (t >= 1) with h[t-1]; reverse direction: dgates[t] (t <= T-2) with h[t+1]
+                call("mr_gemm_tn", dt, ptr(dgates) + N * 8 * H * es, 8 * H, ptr(out), 2 * H, ptr(sinks[1]), H, P, 4 * H, H, H, 0)
+                call("mr_gemm_tn", dt, ptr(dgates) + 4 * H * es, 8 * H, ptr(out) + (N * 2 * H + H) * es, 2 * H, ptr(sinks[5]), H,
+                     P, 4 * H, H, H, 0)
+            if _TnDefer.record(lstm_launch, (dgates, x, out), list(ctx.params)):
                 # one launch for the layer (and the Linear layers recorded behind it); a data-parallel wrapper wants the
                 # gradients as they complete, and the next layer's recurrence is a latency chain that leaves the CUs idle anyway
                 # (MEGREADER_TN_SIDE >= 1: beside that chain, on the side stream)

@@ -16,7 +16,7 @@ def test_library_exports_every_header_symbol():
     assert len(syms) >= 25
     for s in syms:
         assert hasattr(lib, s), "libmegreader_hip.so does not export %s" % s
-    assert lib.mr_abi_version() == 2 == _lib.ABI_VERSION
+    assert lib.mr_abi_version() == 3 == _lib.ABI_VERSION
 
 
 def test_signature_table_matches_header():

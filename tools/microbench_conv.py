@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--p8", type=int, default=0, help="phased-schedule 256x256 kernel for the big-tile launches (0/1)")
     ap.add_argument("--tnmodel", type=int, default=0, help="1: dense-GEMM split model for conv wgrad too")
     ap.add_argument("--tnsplits", type=int, default=0, help="force the TN P-split count (0 = model)")
+    ap.add_argument("--tune", default="", help="mr_tuning fields, e.g. nt_m32=2,nt_m32_opt=20")
     a = ap.parse_args()
     from megreader_amd import _lib
     _lib.load().mr_set_tn_model(a.tnmodel)
@@ -51,6 +52,8 @@ def main():
     if a.tile:
         bm, bn = [int(v) for v in a.tile.split("x")]
         assert _lib.load().mr_force_nt_tile(bm, bn) == 0
+    if a.tune:
+        _lib.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(","))})
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dt = dtype_code(dtype)
     dev = "cuda"
