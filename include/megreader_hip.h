@@ -110,7 +110,11 @@ typedef struct mr_tuning {
                         (256x256 -> 256x256, 272x256 -> 288x256 as 1x8 waves); 2..5 = shape 256x256 / 288x256 / 256x128 / 128x256
                         for every eligible bf16 launch (sweeps) */
   int nt_m32_opt;    /* schedule variant of that kernel, 10 * PH + OPT (tools build -DMR_NT32_SWEEP only); 0 = the default */
-  int reserved[6];   /* zero */
+  int dcn_gcol;      /* round 6: 1 (default) = bf16 DCNv2 backward through ONE materialised gcol = dy * W (tuned NT GEMM, bf16 output)
+                        read by a coordinate-gradient pass and a CSR gather pass for the input gradient (dcn_fused.hip, C in
+                        {64, 128, 256, 512}); 0 = the round-3 fused kernels (gcol in accumulators, gather-GEMM).  Changes the size
+                        mr_dcn2_ws_bytes reports: workspaces must be sized under the value in force at the call */
+  int reserved[5];   /* zero */
 } mr_tuning;
 int mr_tuning_get(mr_tuning* out);
 int mr_tuning_defaults(mr_tuning* out);

@@ -127,12 +127,12 @@ _lib = None
 
 TUNING_FIELDS = ("nt_variant", "nt_deep", "nt_big", "nt_p8", "nt_force_bm", "nt_force_bn", "gemm_skinny", "tn_big", "tn_buf",
                  "tn_taps", "tn_taps_group", "tn_group", "tn_fin", "tn_taps_fin", "tn_taps_w8", "tn_model", "tn_splits",
-                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth", "nt_big_min_k", "tn_taps_min_p", "tn_defer", "pool_fixed", "ctc_linear", "nt_wide8", "nt_ksplit", "nt_m32", "nt_m32_opt")
+                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth", "nt_big_min_k", "tn_taps_min_p", "tn_defer", "pool_fixed", "ctc_linear", "nt_wide8", "nt_ksplit", "nt_m32", "nt_m32_opt", "dcn_gcol")
 
 
 class Tuning(ctypes.Structure):
     """struct mr_tuning (include/megreader_hip.h): the library's only process-wide switches."""
-    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 6)]
+    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 5)]
 
 
 def get_tuning():
@@ -415,8 +415,7 @@ def dcn_backward_workspace(dtype, N, H, W, C, Co, kh, kw, Ho, Wo, device):
     ws = _DCN_WS.get(key)
     if ws is None:
         n = load().mr_dcn2_ws_bytes(dtype_code(dtype), N, H, W, C, Co, kh, kw, Ho, Wo, 1)
-        if len(_DCN_WS) > 64:
-            _DCN_WS.clear()
+        # (never evicted: captured hipGraphs hold raw pointers into these buffers -- ADVICE r5; one entry per layer geometry)
         ws = _DCN_WS[key] = torch.zeros((max(int(n), 16),), dtype=torch.uint8, device=dev)
     return ws, 1
 

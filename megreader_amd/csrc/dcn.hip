@@ -16,11 +16,11 @@ namespace mr {
 
 // fused kernels (dcn_fused.hip): no column matrix, no floating-point atomics on the input gradient
 bool dcn_fused_ok(int dtype, int H, int W, int C, int Co, int kh, int kw);
-long long dcn_fused_ws_bytes(int N, int H, int W, int Ho, int Wo, int taps);
+long long dcn_fused_ws_bytes(int dtype, int N, int H, int W, int C, int Ho, int Wo, int taps);
 int dcn_fused_fwd(int dtype, const void* x, const void* w_n, const float* bias, const float* offset, const float* mask,
                   void* y, void* ws, const DcnGeom& g, int Co, hipStream_t stream);
 long long dcn_fused_fwd_ws_bytes(int N, int Ho, int Wo, int Co, int taps);
-bool dcn_fused_dx_direct(int N, int H, int W, int C, int taps);
+bool dcn_fused_dx_direct(int dtype, int N, int H, int W, int C, int taps);
 int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, const float* offset, const float* mask,
                   void* ws, float* dx32, void* dx_t, int flags, float* doffset, float* dmask, float* dw, float* dbias,
                   const DcnGeom& g, int Co, hipStream_t stream);
@@ -478,7 +478,7 @@ int mr_dcn2_col2im(int dtype, const void* gcol, const float* offset, long long o
 // fused path: nothing forward, the CSR of the scatter pattern backward; general path: the column matrix.
 long long mr_dcn2_ws_bytes(int dtype, int N, int H, int W, int C, int Co, int kh, int kw, int Ho, int Wo, int backward) {
   if (dcn_fused_ok(dtype, H, W, C, Co, kh, kw))
-    return backward ? dcn_fused_ws_bytes(N, H, W, Ho, Wo, kh * kw) : dcn_fused_fwd_ws_bytes(N, Ho, Wo, Co, kh * kw);
+    return backward ? dcn_fused_ws_bytes(dtype, N, H, W, C, Ho, Wo, kh * kw) : dcn_fused_fwd_ws_bytes(N, Ho, Wo, Co, kh * kw);
   return (long long)N * Ho * Wo * kh * kw * C * (dtype == MR_F32 ? 4 : 2);
 }
 
@@ -520,7 +520,7 @@ int mr_dcn2_fused(int dtype, int H, int W, int C, int Co, int kh, int kw) { retu
 
 // host only: 1 when mr_dcn2_bwd2 can write the input gradient directly in the compute dtype (dx_t) for this shape
 int mr_dcn2_dx_direct(int dtype, int N, int H, int W, int C, int Co, int kh, int kw) {
-  return (dcn_fused_ok(dtype, H, W, C, Co, kh, kw) && dcn_fused_dx_direct(N, H, W, C, kh * kw)) ? 1 : 0;
+  return (dcn_fused_ok(dtype, H, W, C, Co, kh, kw) && dcn_fused_dx_direct(dtype, N, H, W, C, kh * kw)) ? 1 : 0;
 }
 
 // mr_dcn2_bwd with two launch-saving options of the fused path (round 5; the 13 DCN layers of the batch-2 detector are ~10

@@ -21,6 +21,7 @@
 // take the general kernels of dcn.hip.  MFMA tile code (LDS image, fragment reads) follows igemm_nt_body / igemm_tn_kernel.
 #include "dcn_geom.h"
 #include "igemm_core.h"
+#include "tuning.h"
 #include "../../include/megreader_hip.h"
 
 namespace mr {
@@ -593,6 +594,109 @@ __global__ __launch_bounds__(256) void dcn2_dx_fused_kernel(DcnFusedArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16: materialised gcol
+// Round 6.  The fused kernels above keep gcol = dy * W in accumulators and pay for it twice: the coord kernel
+// runs the whole GEMM again per column tile just to dot it with four corner vectors, and the gather-GEMM of the input gradient is
+// a chain of dependent (entries -> dy rows) round trips per 64-deep k-step (0.02-0.04 of the MFMA peak, 0.1-0.3 TB/s).  For bf16
+// the cheaper order is the reference's own (deform_conv_cuda.cpp:611-675): ONE dense GEMM gcol[P, taps*C] = dy[P, Co] * W
+// (mr_gemm_nt: the tuned NT kernels, bf16 output = 2 bytes per element of traffic), then two bandwidth-bound passes over it:
+//   dcn2_coord_gcol_kernel : per (pixel, tap) the C/8 lanes of a group dot gcol's slice with the four corner vectors of x,
+//                            reduce over the group with shuffles and WRITE the three gradients (one writer: no atomics);
+//   dcn2_dx_gcol_kernel    : per input pixel the C/8 lanes walk the CSR lists of the nine taps and gather
+//                            sum_e w_e * gcol[p_e, tap, :] in f32 -- the reference's col2im inverted (no atomics, same bits every run).
+// float32 keeps the fused kernels (their f32 accumulators are what the 2e-4 parity bars against the reference extension need).
+template <int L>   // lanes per item = C / 8
+__global__ __launch_bounds__(256) void dcn2_coord_gcol_kernel(DcnFusedArgs a, const bf16_t* __restrict__ gcol) {
+  const DcnGeom& g = a.g;
+  const int taps = g.kh * g.kw, C = L * 8;
+  const long long item = (long long)blockIdx.x * (256 / L) + threadIdx.x / L;
+  const int sub = threadIdx.x % L;
+  const long long items = (long long)a.P * taps;
+  const bool live = item < items;
+  const long long it = live ? item : 0;
+  const int p = (int)(it / taps), tap = (int)(it - (long long)p * taps);
+  const int wo = p % g.Wo, r = p / g.Wo;
+  const int ho = r % g.Ho, n = r / g.Ho;
+  const DcnDesc d = dcn_desc(g, a.offset, a.mask, n, tap, ho, wo);
+  const bf16_t* __restrict__ X = (const bf16_t*)a.x;
+  float S[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live && d.hl != -2) {
+    const uint4 gv = *(const uint4*)(gcol + it * C + sub * 8);
+    const bf16_t* gp = (const bf16_t*)&gv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int h = d.hl + (k >> 1), w = d.wl + (k & 1);
+      if (dcn_inside(g, h, w)) {
+        const uint4 xv = *(const uint4*)(X + ((long long)(n * g.H + h) * g.W + w) * C + sub * 8);
+        const bf16_t* xp = (const bf16_t*)&xv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) S[k] += to_f32(gp[e]) * to_f32(xp[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < L; o <<= 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) S[k] += __shfl_xor(S[k], o, 64);
+  if (sub == 0 && live && d.hl != -2) {
+    const float lh = d.lh, lw = d.lw;
+    const float dm = (1.f - lh) * (1.f - lw) * S[0] + (1.f - lh) * lw * S[1] + lh * (1.f - lw) * S[2] + lh * lw * S[3];
+    const float dh = d.m * (-(1.f - lw) * S[0] - lw * S[1] + (1.f - lw) * S[2] + lw * S[3]);
+    const float dw = d.m * (-(1.f - lh) * S[0] + (1.f - lh) * S[1] - lh * S[2] + lh * S[3]);
+    const long long hw = (long long)g.Ho * g.Wo, o = (long long)ho * g.Wo + wo;
+    a.doffset[n * g.off_bs + (2 * tap) * hw + o] += dh;       // accumulate semantics; this group is the element's only writer
+    a.doffset[n * g.off_bs + (2 * tap + 1) * hw + o] += dw;
+    a.dmask[n * g.msk_bs + tap * hw + o] += dm;
+  }
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void dcn2_dx_gcol_kernel(DcnFusedArgs a, const bf16_t* __restrict__ gcol) {
+  const DcnGeom& g = a.g;
+  const int taps = g.kh * g.kw, C = L * 8;
+  const int q = blockIdx.x * (256 / L) + threadIdx.x / L;
+  const int sub = threadIdx.x % L;
+  if (q >= a.Q) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const long long row = (long long)taps * C;
+  for (int tap = 0; tap < taps; ++tap) {
+    const int lo = a.start[(long long)tap * a.Q + q], hi = a.start[(long long)tap * a.Q + q + 1];
+    const bf16_t* __restrict__ gt = gcol + (long long)tap * C + sub * 8;
+    int e = lo;
+    for (; e + 1 < hi; e += 2) {      // two independent (entry -> row) chains in flight
+      const int2 e0 = a.entries[e], e1 = a.entries[e + 1];
+      const uint4 v0 = *(const uint4*)(gt + (long long)e0.x * row);
+      const uint4 v1 = *(const uint4*)(gt + (long long)e1.x * row);
+      const float w0 = __int_as_float(e0.y), w1 = __int_as_float(e1.y);
+      const bf16_t* p0 = (const bf16_t*)&v0;
+      const bf16_t* p1 = (const bf16_t*)&v1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += w0 * to_f32(p0[j]) + w1 * to_f32(p1[j]);
+    }
+    if (e < hi) {
+      const int2 e0 = a.entries[e];
+      const uint4 v0 = *(const uint4*)(gt + (long long)e0.x * row);
+      const float w0 = __int_as_float(e0.y);
+      const bf16_t* p0 = (const bf16_t*)&v0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += w0 * to_f32(p0[j]);
+    }
+  }
+  if (a.dx_t) {
+    *(uint4*)((bf16_t*)a.dx_t + (long long)q * C + sub * 8) = pack_vec<bf16_t>(acc);
+  } else {
+    float* dst = a.dx + (long long)q * C + sub * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j] += acc[j];
+  }
+}
+
+#define g_dcn_gcol MR_TUNE(dcn_gcol)
+// the materialised-gcol backward serves: bf16, C a power of two in 64 .. 512 (C / 8 lanes per item fit one wave)
+bool dcn_use_gcol(int dtype, int C) {
+  return dtype == MR_BF16 && g_dcn_gcol && (C == 64 || C == 128 || C == 256 || C == 512);
+}
+
 // ------------------------------------------------------------------------------------------------ CSR of the scatter
 // key = tap * Q + q (q = input pixel index over the whole batch; tap-major, so that the neighbouring pixels a wave handles
 // hit neighbouring counters -- pixel-major keys measured 28 G atomics/s, one cache line per atomic); an entry = (output
@@ -970,10 +1074,11 @@ struct DcnWs {
   int* start;
   int* bsum;
   int2* entries;
+  void* gcol;        // bf16 [P][taps * C] (materialised-gcol path), else null
   size_t bytes;
   int nkeys, nblocks;
 };
-static DcnWs dcn_ws_layout(void* base, long long Q, long long P, int taps) {
+static DcnWs dcn_ws_layout(void* base, long long Q, long long P, int taps, long long gcol_bytes = 0) {
   DcnWs w;
   const long long nkeys = Q * taps;
   w.nkeys = (int)nkeys;
@@ -984,6 +1089,12 @@ static DcnWs dcn_ws_layout(void* base, long long Q, long long P, int taps) {
   w.start = (int*)(b + o); o += align16((size_t)(nkeys + 1) * 4);
   w.bsum = (int*)(b + o); o += align16((size_t)w.nblocks * 4);
   w.entries = (int2*)(b + o); o += align16((size_t)P * taps * 4 * 8);
+  w.gcol = nullptr;
+  if (gcol_bytes > 0) {
+    o = (o + 255) & ~(size_t)255;
+    w.gcol = b + o;
+    o += align16((size_t)gcol_bytes);
+  }
   w.bytes = o;
   return w;
 }
@@ -1035,12 +1146,15 @@ long long dcn_fused_fwd_ws_bytes(int N, int Ho, int Wo, int Co, int taps) {
   return tsplit > 1 ? P * Co * 4 * tsplit : 0;
 }
 
-long long dcn_fused_ws_bytes(int N, int H, int W, int Ho, int Wo, int taps) {
-  return (long long)dcn_ws_layout(nullptr, (long long)N * H * W, (long long)N * Ho * Wo, taps).bytes;
+static long long dcn_gcol_bytes(int dtype, int C, long long P, int taps) { return dcn_use_gcol(dtype, C) ? P * taps * C * 2 : 0; }
+long long dcn_fused_ws_bytes(int dtype, int N, int H, int W, int C, int Ho, int Wo, int taps) {
+  const long long P = (long long)N * Ho * Wo;
+  return (long long)dcn_ws_layout(nullptr, (long long)N * H * W, P, taps, dcn_gcol_bytes(dtype, C, P, taps)).bytes;
 }
 
 // 1 when the fused input-gradient kernel runs un-split for this shape, i.e. can write dx directly in the compute dtype
-bool dcn_fused_dx_direct(int N, int H, int W, int C, int taps) {
+bool dcn_fused_dx_direct(int dtype, int N, int H, int W, int C, int taps) {
+  if (dcn_use_gcol(dtype, C)) return true;     // the gather pass owns every element of dx
   const long long tiles_q = cdivll((long long)N * H * W, 64);
   return dcn_tap_split(tiles_q * (C / (C % 128 == 0 ? 128 : 64)), taps) == 1;
 }
@@ -1059,13 +1173,36 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
   a.g = g; a.Co = Co; a.P = (int)P; a.Q = (int)Q; a.tsplit = 1;
   a.dx_t = nullptr;
   MR_CHECK_ARG(!(dx32 && dx_t), "dcn backward: dx32 and dx_t are alternatives");
-  MR_CHECK_ARG(!dx_t || dcn_fused_dx_direct(g.N, g.H, g.W, g.C, taps),
+  MR_CHECK_ARG(!dx_t || dcn_fused_dx_direct(dtype, g.N, g.H, g.W, g.C, taps),
                "dcn backward: this shape splits the input gradient over tap groups (ask mr_dcn2_dx_direct first)");
   const int tiles_p = cdiv((int)P, 64);
+  // ---- bf16: gcol = dy * W once (tuned NT GEMM), both consumers read it (see "materialised gcol" above)
+  const bool use_gcol = dcn_use_gcol(dtype, g.C) && ((doffset && dmask) || dx32 || dx_t);
+  const bf16_t* gcol = nullptr;
+  if (use_gcol) {
+    MR_CHECK_ARG(ws != nullptr, "dcn backward: workspace missing (mr_dcn2_ws_bytes)");
+    MR_CHECK_ARG(P * taps * g.C < (1ll << 31), "dcn backward: gcol too large for 32-bit element offsets");
+    DcnWs w = dcn_ws_layout(ws, Q, P, taps, dcn_gcol_bytes(dtype, g.C, P, taps));
+    gcol = (const bf16_t*)w.gcol;
+    const int rc = mr_gemm_nt(MR_BF16, dy, Co, w_t, Co, w.gcol, taps * g.C, nullptr, 0, (int)P, taps * g.C, Co, stream);
+    if (rc) return rc;
+  }
+#define MR_DCN_GCOL_LAUNCH(KERN, ITEMS)                                                                                   \
+  {                                                                                                                      \
+    const int L_ = g.C / 8;                                                                                              \
+    const unsigned nb_ = (unsigned)cdivll((long long)(ITEMS), 256 / L_);                                                 \
+    if (L_ == 8) hipLaunchKernelGGL((KERN<8>), dim3(nb_), dim3(256), 0, stream, a, gcol);                                \
+    else if (L_ == 16) hipLaunchKernelGGL((KERN<16>), dim3(nb_), dim3(256), 0, stream, a, gcol);                         \
+    else if (L_ == 32) hipLaunchKernelGGL((KERN<32>), dim3(nb_), dim3(256), 0, stream, a, gcol);                         \
+    else hipLaunchKernelGGL((KERN<64>), dim3(nb_), dim3(256), 0, stream, a, gcol);                                       \
+    MR_CHECK_LAUNCH();                                                                                                   \
+  }
   // The three parts below are independent of each other (each reads dy / x / w / offset / mask and writes its own outputs):
   // a caller may ask for any subset by passing null for the outputs of the others, e.g. to run them on parallel streams.
   // ---- offset / mask gradients (gcol tiles stay in registers)
-  if (doffset && dmask) {
+  if (doffset && dmask && use_gcol) {
+    MR_DCN_GCOL_LAUNCH(dcn2_coord_gcol_kernel, P * taps)
+  } else if (doffset && dmask) {
     if (g.C % 128 == 0) {
       DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_coord_fused_kernel<T, 128>), dim3(tiles_p * (taps * g.C / 128)), dim3(256), 0,
                                            stream, a));
@@ -1078,7 +1215,7 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
   // ---- input gradient: CSR of the scatter pattern, then the gather-GEMM
   if (dx32 || dx_t) {
     MR_CHECK_ARG(ws != nullptr, "dcn backward: workspace missing (mr_dcn2_ws_bytes)");
-    DcnWs w = dcn_ws_layout(ws, Q, P, taps);
+    DcnWs w = dcn_ws_layout(ws, Q, P, taps, dcn_gcol_bytes(dtype, g.C, P, taps));
     if (!(flags & 1) && hipMemsetAsync(w.count, 0, (size_t)w.nkeys * 4, stream) != hipSuccess) {
       mr::set_error("dcn backward: hipMemsetAsync failed");
       return MR_ERR_LAUNCH;
@@ -1095,6 +1232,9 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
     a.start = w.start;
     a.entries = w.entries;
     a.dx_t = dx_t;
+    if (use_gcol) {
+      MR_DCN_GCOL_LAUNCH(dcn2_dx_gcol_kernel, Q)
+    } else {
     const int tiles_q = cdiv((int)Q, 64);
     a.tsplit = dcn_tap_split((long long)tiles_q * (g.C / (g.C % 128 == 0 ? 128 : 64)), taps);
     if (g.C % 128 == 0) {
@@ -1106,7 +1246,9 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
     }
     a.tsplit = 1;
     MR_CHECK_LAUNCH();
+    }
   }
+#undef MR_DCN_GCOL_LAUNCH
   // ---- weight / bias gradients
   if (dw) {
     DcnWgradArgs wa = {};

@@ -395,9 +395,14 @@ __global__ __launch_bounds__(512) void igemm_nt32_kernel(NtArgs a, ConvGeom g, E
     }
     __syncthreads();
     bf16_t* __restrict__ Cp = epi.C;
+    // every workgroup starts at another row of its tile: the 256 workgroups finish their k-loops together, and tiles that all
+    // start at row 0 put their first lines 128 KiB apart -- on the same few memory channels at every instant
+    const int rot = (OPT & 16) ? 0 : (int)((blockIdx.x * 8u) % (unsigned)BM);
 #pragma unroll 4
     for (int idx = tid; idx < BM * CH; idx += 512) {
-      const int r = idx / CH, c = idx % CH;
+      int r = idx / CH + rot;
+      if (r >= BM) r -= BM;
+      const int c = idx % CH;
       const int m = m0 + r, n = n0 + c * 8;
       if (m < epi.M && n < epi.N) *(uint4*)(Cp + (long long)m * epi.ldc + n) = smem[r * CH + (c ^ (r & (CH - 1)))];
     }

@@ -59,6 +59,7 @@ static int launch_variant(int variant, const NtArgs& a, const ConvGeom& g, const
     case 20: return launch_one<AMODE, 2, 0>(a, g, epi, stream);
     case 21: return launch_one<AMODE, 2, 1>(a, g, epi, stream);
     case 28: return launch_one<AMODE, 2, 8>(a, g, epi, stream);
+    case 26: return launch_one<AMODE, 2, 16>(a, g, epi, stream);
     case 48: return launch_one<AMODE, 4, 8>(a, g, epi, stream);
     case 40: return launch_one<AMODE, 4, 0>(a, g, epi, stream);
 #endif
