@@ -30,6 +30,13 @@ extern "C" {
 
 const char* mr_last_error(void);
 int mr_abi_version(void);
+/* Measurement only (bench.py's roofline pass): while mr_phase_timer(1) is in force, entry points made of several launches (the
+ * DCNv2 forward / backward) bracket their parts with HIP events on the launch stream; mr_phase_read(id, &ms, &work) waits for them
+ * and returns the number of records of phase id with their total milliseconds and total algorithmic work (bytes for the
+ * bandwidth-bound passes, flops for the GEMMs).  ids: 0 dcn forward, 1 gcol GEMM, 2 coordinate pass, 3 CSR build (4 launches),
+ * 4 input-gradient gather, 5 im2col, 6 weight-gradient GEMM.  Not capturable.  Host only. */
+int mr_phase_timer(int on);
+int mr_phase_read(int id, double* total_ms, double* total_work);
 /* creates the per-device zero page eagerly and applies MEGREADER_TUNING (below); call before hipGraph capture */
 int mr_init(void);
 

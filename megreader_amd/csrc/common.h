@@ -51,6 +51,19 @@ void set_error(const char* fmt, ...);
     }                                                                  \
   } while (0)
 
+// Phase timer (measurement only; include/megreader_hip.h: mr_phase_timer): entry points that consist of several launches bracket
+// their parts with HIP events on the launch stream while it is on, so that bench.py can name the dominant KERNEL of a workload whose
+// C-ABI calls are composites (mr_dcn2_bwd2: GEMM + coordinate pass + CSR build + gather + im2col + GEMM).  Off: one relaxed load.
+enum { MR_PH_DCN_FWD = 0, MR_PH_DCN_GCOL_GEMM, MR_PH_DCN_COORD, MR_PH_DCN_CSR, MR_PH_DCN_DX, MR_PH_DCN_IM2COL, MR_PH_DCN_WGRAD,
+       MR_PH_COUNT };
+bool phase_timer_on();
+void phase_mark(int id, bool end, double work, hipStream_t stream);   // work: algorithmic bytes (or flops) of the phase
+struct PhaseScope {
+  int id; hipStream_t s; bool on;
+  PhaseScope(int id_, double work, hipStream_t s_) : id(id_), s(s_), on(phase_timer_on()) { if (on) phase_mark(id, false, work, s); }
+  ~PhaseScope() { if (on) phase_mark(id, true, 0.0, s); }
+};
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }
 

@@ -1114,6 +1114,7 @@ int dcn_fused_fwd(int dtype, const void* x, const void* w_n, const float* bias, 
                "kernels)");
   const int tiles_m = cdiv(a.P, 64);
   const int bn = Co % 128 == 0 ? 128 : 64;
+  PhaseScope ph_fwd(MR_PH_DCN_FWD, 2.0 * a.P * Co * g.kh * g.kw * g.C, stream);
   a.tsplit = dcn_tap_split((long long)tiles_m * (Co / bn), g.kh * g.kw);
   if (a.tsplit > 1) {
     MR_CHECK_ARG(ws != nullptr, "dcn forward: workspace missing (mr_dcn2_ws_bytes)");
@@ -1184,6 +1185,7 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
     MR_CHECK_ARG(P * taps * g.C < (1ll << 31), "dcn backward: gcol too large for 32-bit element offsets");
     DcnWs w = dcn_ws_layout(ws, Q, P, taps, dcn_gcol_bytes(dtype, g.C, P, taps));
     gcol = (const bf16_t*)w.gcol;
+    PhaseScope ph(MR_PH_DCN_GCOL_GEMM, 2.0 * P * Co * taps * g.C, stream);
     const int rc = mr_gemm_nt(MR_BF16, dy, Co, w_t, Co, w.gcol, taps * g.C, nullptr, 0, (int)P, taps * g.C, Co, stream);
     if (rc) return rc;
   }
@@ -1200,9 +1202,14 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
   // The three parts below are independent of each other (each reads dy / x / w / offset / mask and writes its own outputs):
   // a caller may ask for any subset by passing null for the outputs of the others, e.g. to run them on parallel streams.
   // ---- offset / mask gradients (gcol tiles stay in registers)
+  const double es = dtype == MR_F32 ? 4.0 : 2.0;
+  const double gemm_flops = 2.0 * P * Co * taps * g.C;
   if (doffset && dmask && use_gcol) {
+    // algorithmic bytes: gcol + x once, offsets / mask read, their three gradients read-modify-written
+    PhaseScope ph(MR_PH_DCN_COORD, 2.0 * P * taps * g.C + es * Q * g.C + 9.0 * 4 * 3 * P * taps, stream);
     MR_DCN_GCOL_LAUNCH(dcn2_coord_gcol_kernel, P * taps)
   } else if (doffset && dmask) {
+    PhaseScope ph(MR_PH_DCN_COORD, gemm_flops, stream);
     if (g.C % 128 == 0) {
       DISPATCH_T(dtype, hipLaunchKernelGGL((dcn2_coord_fused_kernel<T, 128>), dim3(tiles_p * (taps * g.C / 128)), dim3(256), 0,
                                            stream, a));
@@ -1221,6 +1228,9 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
       return MR_ERR_LAUNCH;
     }
     const unsigned items = (unsigned)cdivll(P * taps, 256);
+    {
+    // bytes: offsets + mask twice, counters (atomics) twice, the scan over Q * taps keys, the entries
+    PhaseScope ph(MR_PH_DCN_CSR, 2.0 * 12 * P * taps + 5.0 * 4 * Q * taps + 8.0 * 4 * P * taps, stream);
     hipLaunchKernelGGL((dcn_csr_kernel<false>), dim3(items), dim3(256), 0, stream, offset, mask, w.count,
                        (const int*)nullptr, (int2*)nullptr, g, (int)P);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(w.nblocks), dim3(256), 0, stream, (const int*)w.count, w.bsum, w.nkeys);
@@ -1228,13 +1238,17 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
                        w.start, w.nkeys);
     hipLaunchKernelGGL((dcn_csr_kernel<true>), dim3(items), dim3(256), 0, stream, offset, mask, w.count,
                        (const int*)w.start, w.entries, g, (int)P);
+    }
     MR_CHECK_LAUNCH();
     a.start = w.start;
     a.entries = w.entries;
     a.dx_t = dx_t;
     if (use_gcol) {
+      // bytes: every gcol element once, the CSR (entries + row starts), dx written once
+      PhaseScope ph(MR_PH_DCN_DX, 2.0 * P * taps * g.C + 8.0 * 4 * P * taps + 4.0 * Q * taps + (dx_t ? es : 8.0) * Q * g.C, stream);
       MR_DCN_GCOL_LAUNCH(dcn2_dx_gcol_kernel, Q)
     } else {
+    PhaseScope ph(MR_PH_DCN_DX, gemm_flops, stream);
     const int tiles_q = cdiv((int)Q, 64);
     a.tsplit = dcn_tap_split((long long)tiles_q * (g.C / (g.C % 128 == 0 ? 128 : 64)), taps);
     if (g.C % 128 == 0) {
@@ -1250,7 +1264,23 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
   }
 #undef MR_DCN_GCOL_LAUNCH
   // ---- weight / bias gradients
-  if (dw) {
+  if (dw && dcn_use_gcol(dtype, g.C) && ws != nullptr) {
+    // bf16: the sampled column matrix col[P, taps*C] is written ONCE into the buffer gcol just left (the reference re-uses
+    // `columns` the same way, deform_conv_cuda.cpp:641-658) and dW = dy^T * col runs on the tuned TN GEMM kernel -- the fused
+    // kernel below samples every B tile again per 128-row output tile and reduces its pixel splits with f32 atomics
+    // (237 us per layer at batch 16 against ~110 us for the two launches here).
+    DcnWs w = dcn_ws_layout(ws, Q, P, taps, dcn_gcol_bytes(dtype, g.C, P, taps));
+    int rc;
+    {
+      PhaseScope ph(MR_PH_DCN_IM2COL, es * Q * g.C + 2.0 * P * taps * g.C + 12.0 * P * taps, stream);
+      rc = mr_dcn2_im2col(dtype, x, offset, g.off_bs, mask, g.msk_bs, w.gcol, g.N, g.H, g.W, g.C, g.kh, g.kw, g.stride, g.pad,
+                          g.dil, g.Ho, g.Wo, stream);
+    }
+    if (rc) return rc;
+    PhaseScope ph(MR_PH_DCN_WGRAD, gemm_flops, stream);
+    return mr_gemm_tn(dtype, dy, Co, w.gcol, taps * g.C, dw, taps * g.C, (int)P, Co, taps * g.C, 0, dbias, stream);
+  } else if (dw) {
+    PhaseScope ph(MR_PH_DCN_WGRAD, gemm_flops, stream);
     DcnWgradArgs wa = {};
     wa.dy = dy; wa.x = x; wa.offset = offset; wa.mask = mask; wa.dw = dw; wa.dbias = dbias; wa.g = g; wa.Co = Co;
     wa.P = (int)P;

@@ -1,6 +1,8 @@
 // HBM-bound helper kernels: layout conversion, ReLU backward, column sums, weight preparation
 // (fp32 master -> compute-dtype operand images), fused Adam.  All 16-byte vectorised where the
 // tensors are large (activations); weight-sized tensors use simple grid-stride loops.
+#include <mutex>
+#include <vector>
 #include "common.h"
 #include "../../include/megreader_hip.h"
 #include <stdarg.h>
@@ -438,6 +440,26 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     }
 }
 
+// ---- phase timer (common.h)
+static int g_phase_on = 0;
+struct PhaseRec { int id; double work; hipEvent_t e0, e1; };
+static std::vector<PhaseRec> g_phase_recs;
+static std::mutex g_phase_mutex;
+bool phase_timer_on() { return __atomic_load_n(&g_phase_on, __ATOMIC_RELAXED) != 0; }
+void phase_mark(int id, bool end, double work, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_phase_mutex);
+  if (!end) {
+    PhaseRec r;
+    r.id = id; r.work = work; r.e0 = nullptr; r.e1 = nullptr;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    (void)hipEventRecord(r.e0, stream);
+    g_phase_recs.push_back(r);
+  } else {
+    for (size_t i = g_phase_recs.size(); i-- > 0;)
+      if (g_phase_recs[i].id == id) { (void)hipEventRecord(g_phase_recs[i].e1, stream); break; }
+  }
+}
+
 }  // namespace mr
 
 using namespace mr;
@@ -450,6 +472,35 @@ using namespace mr;
 extern "C" {
 
 const char* mr_last_error(void) { return mr::g_err; }
+
+// Phase timer: mr_phase_timer(1) starts recording (and drops earlier records), mr_phase_timer(0) stops.  mr_phase_read(id, ...)
+// synchronises with the recorded events and returns the number of records of phase `id`, their total milliseconds and total
+// `work`.  Not capturable: for eager measurement passes only.  Host only.
+int mr_phase_timer(int on) {
+  std::lock_guard<std::mutex> lock(mr::g_phase_mutex);
+  const int old = mr::g_phase_on;
+  if (on) {
+    for (auto& r : mr::g_phase_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    mr::g_phase_recs.clear();
+  }
+  __atomic_store_n(&mr::g_phase_on, on ? 1 : 0, __ATOMIC_RELAXED);
+  return old;
+}
+int mr_phase_read(int id, double* total_ms, double* total_work) {
+  std::lock_guard<std::mutex> lock(mr::g_phase_mutex);
+  int n = 0;
+  double ms = 0.0, work = 0.0;
+  for (auto& r : mr::g_phase_recs)
+    if (r.id == id) {
+      float t = 0.f;
+      if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+        ms += t; work += r.work; ++n;
+      }
+    }
+  if (total_ms) *total_ms = ms;
+  if (total_work) *total_work = work;
+  return n;
+}
 int mr_abi_version(void) { return MR_ABI_VERSION; }
 
 int mr_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int Cpad,
