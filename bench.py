@@ -12,7 +12,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
   cpu_baseline  -- the oracle (reference restatement, oracle/crnn.py) timed on this box's host cores (rank 0, N=1)
 """
 import argparse
+import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -29,6 +31,17 @@ HBM_PEAK_GBS = 8000.0
 
 CONV_CALLS = ["mr_conv2d_fwd", "mr_conv2d_fwd_stats", "mr_conv2d_dgrad", "mr_conv2d_dgrad_add", "mr_conv2d_dgrad_bnb",
               "mr_conv2d_wgrad", "mr_conv2d_wgrad_tab"]
+# dense weight-gradient GEMMs: followed only so that the ones the library RECORDS (deferred, grouped launches) are attributed to
+# the mr_tn_flush that launches them -- the grouped kernel of the timed graph, not one launch per problem
+TN_DENSE_CALLS = ["mr_gemm_tn", "mr_gemm_tn2"]
+GROUPED = "igemm_tn_glds_grouped_kernel<bf16>"
+# phases of the composite DCNv2 entry points (include/megreader_hip.h: mr_phase_timer): id -> (label, unit of `work` on the
+# materialised-gcol path (bf16), unit on the fused path, launches per record)
+DCN_PHASES = {0: ("dcn2_fwd_fused_kernel", "flop", "flop", 1), 1: ("igemm_nt_kernel<dcn gcol GEMM>", "flop", "flop", 1),
+              2: ("dcn2_coord_gcol_kernel", "byte", "flop", 1), 3: ("dcn_csr", "byte", "byte", 4),
+              4: ("dcn2_dx_gcol_kernel", "byte", "flop", 1), 5: ("dcn2_im2col_kernel", "byte", "byte", 1),
+              6: ("igemm_tn_kernel<dcn wgrad GEMM>", "flop", "flop", 1)}
+DCN_FUSED_LABELS = {2: "dcn2_coord_fused_kernel", 4: "dcn2_dx_fused_kernel", 6: "dcn2_wgrad_fused_kernel"}
 
 
 def normalize_conv_call(name, args):
@@ -61,6 +74,7 @@ def conv_flops(name, args, true_cin0=3):
     return 2.0 * N * Ho * Wo * Cout * R * S * Cin, N * Ho * Wo, Cout, Cin
 
 
+COMPOSITE_N = " (several launches)"
 COMPOSITE = "+tail (2 launches)"   # a C-ABI call that launches the 256x256 head kernel AND a 4-wave tail kernel
 
 
@@ -299,6 +313,9 @@ def main():
     ap.add_argument("--set", action="append", default=[], metavar="NAME=INT",
                     help="A/B: call the host-only tuning setter mr_set_NAME(INT) before the run (e.g. --set nt_deep=0); "
                          "recorded in config.tuning")
+    ap.add_argument("--teacher-forcing", default="fixed", choices=["fixed", "random"],
+                    help="fpn_attention: fixed = gt_as_output=True (default, deterministic); random = the YAML default (a coin per "
+                         "decode step, decoders/attention_decoder.py:50-54)")
     ap.add_argument("--workload", default="crnn", choices=["crnn", "res50ppm", "fpn_attention", "db"],
                     help="crnn = BASELINE.json configs[1] (the metric's workload, default); res50ppm = configs[2]: "
                          "ResNet50-dilated-PPM + 2D-CTC on 32x128 crops (secondary line, same JSON shape); "
@@ -336,9 +353,10 @@ def main():
     if args.gpus != world:
         print("warning: --gpus %d but WORLD_SIZE %d (using WORLD_SIZE)" % (args.gpus, world), file=sys.stderr)
 
-    def measure(workload, steps, warmup, with_cpu, scaling=None, crop=None):
+    def measure(workload, steps, warmup, with_cpu, scaling=None, crop=None, coins=None):
         """One workload: build, warm up, time `steps` steps; returns the result dict on rank 0 (None elsewhere)."""
         scaling = scaling or args.scaling
+        random_coins = (coins or args.teacher_forcing) == "random"
         if crop is None and args.crop and workload == "res50ppm":
             crop = tuple(int(v) for v in args.crop.lower().split("x"))
         import megreader_amd as mr
@@ -352,6 +370,8 @@ def main():
         lib = _lib.load()
         dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
         mr.set_compute_dtype(dtype)
+        from megreader_amd.nn import functional as _Fn
+        _Fn.LSTM_STATUS = lstm_status = []      # status words of the persistent-recurrence workspaces (checked after the timed region)
 
         class BasicModel(torch.nn.Module):  # reference structure/model.py:16-24
             def __init__(self):
@@ -384,7 +404,10 @@ def main():
                 def __init__(self):
                     super().__init__()
                     self.backbone = Resnet50FPN(resnet_pretrained=False)     # no network on the box
-                    self.decoder = AttentionDecoder(in_channels=256, gt_as_output=True)
+                    # coins: 'fixed' = teacher forcing on every step (gt_as_output=True, the benchmarked configuration since
+                    # round 2); 'random' = the YAML default of fpn50-attention-decoder.yaml (gt_as_output=None: a device-resident
+                    # coin per decode step, decoders/attention_decoder.py:50-54), which keeps the output layer on the recurrence
+                    self.decoder = AttentionDecoder(in_channels=256, gt_as_output=True if random_coins is False else None)
 
                 def forward(self, data, *a, **k):
                     return self.decoder(self.backbone(data), *a, **k)
@@ -526,25 +549,40 @@ def main():
         elapsed = time.perf_counter() - t0
         _lib.TIMER = None
         final_loss = float(last.detach())
+        # the persistent BiLSTM / one-pass BatchNorm kernels POISON their outputs with NaN when a bounded spin times out
+        # (lstm_persist.hip:30, norm_pool.hip): a non-finite loss or a raised status word on ANY rank voids the measurement
+        bad = 0 if math.isfinite(final_loss) else 1
+        lstm_words = [int(t.view(torch.int32).item()) for t in lstm_status[-8:]]
+        _Fn.LSTM_STATUS = None
+        if any(lstm_words):
+            bad |= 2
+        if distributed:
+            tb = torch.tensor([bad], device=dev, dtype=torch.int32)
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            bad = int(tb)
+        if bad:
+            raise RuntimeError("bench.py: invalid step on some rank -- %s%s (rank %d: final loss %r, LSTM status words %r)" %
+                               ("non-finite loss " if bad & 1 else "", "persistent-LSTM timeout" if bad & 2 else "", rank,
+                                final_loss, lstm_words))
         if use_graph and not args.no_kernel_timer:
             # HIP events cannot bracket kernels inside a graph replay: measure the dominant kernel's launch durations
             # on the same stream with the same tensors in an eager pass right after the timed region
             # (deferred weight-gradient problems are launched grouped, from mr_tn_flush: an event bracket around the recording
             # call would time nothing, so this pass launches every problem on its own -- the grouped launches of the timed
             # region are in the rocprofv3 summaries under profiles/)
-            from megreader_amd.nn import functional as _F
-            defer_was = _F._TnDefer.enabled
-            _F._TnDefer.enabled = False
-            timer = _lib.KernelTimer(CONV_CALLS)
+            # (round 6: deferred weight-gradient problems stay deferred -- the bracket goes around the mr_tn_flush that launches
+            # them grouped, as in the timed graph; the DCNv2 entry points time their own launches, mr_phase_timer)
+            timer = _lib.KernelTimer(CONV_CALLS + TN_DENSE_CALLS, track_deferred=True)
             _lib.TIMER = timer
             timer_steps = min(steps, 10)
+            lib.mr_phase_timer(1)
             try:
                 for _ in range(timer_steps):
                     step()
                 torch.cuda.synchronize()
             finally:
                 _lib.TIMER = None
-                _F._TnDefer.enabled = defer_was
+                lib.mr_phase_timer(0)
         else:
             timer_steps = steps
         if distributed:
@@ -561,26 +599,82 @@ def main():
             if timer is not None:
                 agg = {}
                 algo_bytes = {}
-                for name, cargs, t_ms in timer.results():
-                    label = kernel_label(lib, name, cargs, args.dtype)
+                es = 2 if args.dtype == "bf16" else 4
+
+                def problem(name, cargs):
+                    """(flops, algorithmic bytes) of one recorded C-ABI call"""
+                    if name in TN_DENSE_CALLS:      # (dtype, A, lda, B, ldb, C, ldc, P, NA, NB, ...): C[NA, NB] += A^T B over P rows
+                        P_, NA_, NB_ = cargs[7], cargs[8], cargs[9]
+                        return 2.0 * P_ * NA_ * NB_, es * P_ * (NA_ + NB_) + 4.0 * NA_ * NB_
                     fl, pix, cout, cin = conv_flops(name, cargs)
-                    # algorithmic bytes of the launch: both activation tensors once + the weights once (2-byte elements)
-                    es = 2 if args.dtype == "bf16" else 4
-                    algo_bytes[label] = algo_bytes.get(label, 0.0) + es * (pix * cout + pix * cin) + es * fl / (2.0 * pix)
+                    # both activation tensors once + the weights once
+                    return fl, es * (pix * cout + pix * cin) + es * fl / (2.0 * pix)
+
+                conv_records = []
+                for name, cargs, t_ms in timer.results():
+                    if name == "mr_tn_flush":       # cargs = the recorded problems this flush launched as ONE grouped kernel
+                        label, fl, ab = GROUPED, 0.0, 0.0
+                        for pn, pa in cargs:
+                            f1, b1 = problem(pn, pa)
+                            fl += f1
+                            ab += b1
+                    elif name in TN_DENSE_CALLS:
+                        continue                    # an immediate dense wgrad launch (LSTM / Linear layers): not a conv kernel
+                    else:
+                        label = kernel_label(lib, name, cargs, args.dtype)
+                        fl, ab = problem(name, cargs)
+                        conv_records.append((name, cargs, t_ms))
+                    algo_bytes[label] = algo_bytes.get(label, 0.0) + ab
                     a = agg.setdefault(label, [0.0, 0.0, 0])
                     a[0] += fl
                     a[1] += t_ms
                     a[2] += 1
+                # DCNv2 phases (db): per-kernel HIP-event times recorded inside mr_dcn2_fwd / mr_dcn2_bwd2
+                hbm_kernels = {}
+                gcol_path = args.dtype == "bf16" and _lib.get_tuning().get("dcn_gcol", 0) == 1
+                for pid, (plabel, unit_gcol, unit_fused, nlaunch) in DCN_PHASES.items():
+                    ms_c, work_c = ctypes.c_double(0.0), ctypes.c_double(0.0)
+                    n = lib.mr_phase_read(pid, ctypes.byref(ms_c), ctypes.byref(work_c))
+                    if n <= 0:
+                        continue
+                    unit = unit_gcol if gcol_path else unit_fused
+                    if not gcol_path and pid in DCN_FUSED_LABELS:
+                        plabel = DCN_FUSED_LABELS[pid]
+                    if nlaunch > 1:
+                        plabel += COMPOSITE_N
+                    if unit == "flop":
+                        agg[plabel] = [work_c.value, ms_c.value, n]
+                    else:
+                        hbm_kernels[plabel] = [work_c.value, ms_c.value, n]
                 if args.shape_table:
-                    write_shape_table(args.shape_table, lib, timer.results(), args.dtype, timer_steps)
+                    write_shape_table(args.shape_table, lib, conv_records, args.dtype, timer_steps)
                 for label, (fl, t_ms, n) in agg.items():
                     kernels[label] = {"launches_per_step": n / timer_steps, "avg_us": round(1e3 * t_ms / n, 2),
                                       "tflops": round(fl / (t_ms * 1e-3) / 1e12, 1),
                                       "ms_per_step": round(t_ms / timer_steps, 4)}
-                if agg:
+                for label, (by, t_ms, n) in hbm_kernels.items():
+                    kernels[label] = {"launches_per_step": n / timer_steps, "avg_us": round(1e3 * t_ms / n, 2),
+                                      "gbytes_per_s": round(by / (t_ms * 1e-3) / 1e9, 1), "ms_per_step": round(t_ms / timer_steps, 4)}
+                single = {k: v for k, v in agg.items() if not k.endswith(COMPOSITE) and not k.endswith(COMPOSITE_N)}
+                single_hbm = {k: v for k, v in hbm_kernels.items() if not k.endswith(COMPOSITE_N)}
+                dom_hbm = max(single_hbm, key=lambda k: single_hbm[k][1]) if single_hbm else None
+                dom_mfma = max(single, key=lambda k: single[k][1]) if single else None
+                if dom_hbm is not None and (dom_mfma is None or single_hbm[dom_hbm][1] > single[dom_mfma][1]):
+                    # the workload's dominant kernel is bandwidth-bound (DB: the CSR gather of the DCNv2 input gradient)
+                    by, t_ms, n = single_hbm[dom_hbm]
+                    ach = by / (t_ms * 1e-3) / 1e9
+                    traffic, traffic_src = pmc_traffic(dom_hbm, workload)
+                    roofline = {"kernel": dom_hbm, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
+                                "algorithmic_bytes_per_launch": round(by / n), "avg_launch_us": round(1e3 * t_ms / n, 2),
+                                "launches": n,
+                                "measured": "HIP events around the launch inside the C entry point (mr_phase_timer), eager pass "
+                                            "after the graph-replayed timed region"}
+                elif agg:
                     # the roofline block is ONE kernel (its rocprofv3 average must agree with the event average):
                     # event brackets that span two launches stay in `kernels` but cannot be the dominant kernel
-                    single = {k: v for k, v in agg.items() if not k.endswith(COMPOSITE)} or agg
+                    single = single or agg
                     dom = max(single, key=lambda k: single[k][1])
                     fl, t_ms, n = agg[dom]
                     ach = fl / (t_ms * 1e-3) / 1e12
@@ -604,7 +698,9 @@ def main():
             elif workload == "fpn_attention":
                 metric_name = "training images/sec, ResNet50-FPN + attention decoder 64x256 crops, batch %d per GPU" % bsz
                 workload_name = ("ResNet50-FPN + attention GRU decoder training step (BASELINE.json configs[3]): 64x256 "
-                                 "crops, 32 decode steps, teacher forcing fixed (gt_as_output), Adam")
+                                 "crops, 32 decode steps, %s, Adam" %
+                                 ("teacher forcing by a coin per step (gt_as_output=None, the YAML default)" if random_coins
+                                  else "teacher forcing fixed (gt_as_output)"))
                 fwd_flops = 17.25e9  # 5.01 backbone + 10.97 decoder conv encoder + 1.27 decode loop
             elif workload == "res50ppm":
                 ch, cw = crop or (32, 128)
@@ -651,11 +747,13 @@ def main():
         # target #2 (configs[2], also kept under the round-1..3 key `secondary`), configs[3] and configs[4]; each with its own
         # roofline block and CPU baseline
         out["secondaries"] = []
-        for wl, crop in (("res50ppm", None), ("fpn_attention", None), ("db", None), ("res50ppm", (64, 256))):
-            sec = measure(wl, min(args.steps, 10), min(args.warmup, 3), not args.no_cpu_baseline, crop=crop)
+        for wl, crop, coins in (("res50ppm", None, None), ("fpn_attention", None, "fixed"), ("db", None, None),
+                                ("res50ppm", (64, 256), None), ("fpn_attention", None, "random")):
+            sec = measure(wl, min(args.steps, 10), min(args.warmup, 3), not args.no_cpu_baseline and coins != "random", crop=crop,
+                          coins=coins)
             for k in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data"):
                 sec.pop(k, None)
-            sec["workload"] = wl if crop is None else "%s_%dx%d" % (wl, crop[0], crop[1])
+            sec["workload"] = (wl if crop is None else "%s_%dx%d" % (wl, crop[0], crop[1])) + ("_random_coins" if coins == "random" else "")
             out["secondaries"].append(sec)
         out["secondary"] = out["secondaries"][0]
     if world > 1 and args.scaling == "weak" and not args.no_strong:

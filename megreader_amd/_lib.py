@@ -332,9 +332,13 @@ class KernelTimer(object):
     """Optional HIP-event bracketing of selected C-ABI calls on the stream they are launched on (bench.py uses it
     to measure the dominant kernel's launch durations live inside the timed region)."""
 
-    def __init__(self, names):
+    def __init__(self, names, track_deferred=False):
         self.names = set(names)
         self.records = []  # (name, args, start_event, end_event)
+        # track_deferred: calls that the library only RECORDS (mr_tn_defer: deferred weight-gradient problems) are collected and
+        # attributed to the mr_tn_flush that launches them as one grouped kernel -- ("mr_tn_flush", [(name, args), ...], e0, e1)
+        self.track_deferred = track_deferred
+        self.deferred = []
 
     def results(self):
         """[(name, args, milliseconds)] -- call after torch.cuda.synchronize()."""
@@ -384,12 +388,24 @@ def call(name, *args):
         ensure_tn_workspace()
     timer = TIMER
     if timer is not None and name in timer.names:
+        pend = lib.mr_tn_pending() if timer.track_deferred else 0
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = getattr(lib, name)(*args, stream_ptr())
         e1.record()
-        timer.records.append((name, args, e0, e1))
+        if timer.track_deferred and lib.mr_tn_pending() > pend:
+            timer.deferred.append((name, args))          # recorded, not launched: its time is the flush's
+        else:
+            timer.records.append((name, args, e0, e1))
+    elif timer is not None and timer.track_deferred and name in ("mr_tn_flush", "mr_tn_flush_beside") and timer.deferred:
+        group, timer.deferred = timer.deferred, []
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args, stream_ptr())
+        e1.record()
+        timer.records.append(("mr_tn_flush", group, e0, e1))
     else:
         rc = getattr(lib, name)(*args, stream_ptr())
     if rc != 0:

@@ -67,6 +67,49 @@ def _f64(ora32, forward, stages=(), store=None):
     return {k: p.grad.detach().clone() for k, p in ora64.named_parameters() if p.grad is not None}
 
 
+def _f64_bf16_storage(ora32, forward):
+    """Gradients of the float64 oracle when every leaf module's output (and its gradient) is merely STORED in bfloat16 --
+    float64 arithmetic, 8-bit mantissas between layers (tools/bf16_storage_sensitivity.py).  The yardstick of the bf16 bars of
+    tests/test_timed_step_gpu.py: the distance of THIS from exact float64 is what bf16 storage costs
+    whoever does the arithmetic; the HIP bf16 step must stay within 1.5 x of it per parameter group."""
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    from bf16_storage_sensitivity import _Round
+    ora64 = copy.deepcopy(ora32).double().train()
+    ora64.zero_grad()
+
+    def hook(_m, _inp, out):
+        if isinstance(out, torch.Tensor) and out.is_floating_point() and out.requires_grad:
+            return _Round.apply(out)
+        if isinstance(out, tuple) and out and isinstance(out[0], torch.Tensor) and out[0].requires_grad:
+            return (_Round.apply(out[0]),) + tuple(out[1:])
+        return None
+    # every leaf module's output, as tools/bf16_storage_sensitivity.py does -- except the probability maps of the DB head: the
+    # product keeps those sigmoids in float32 whatever the compute dtype (a probability rounded to exactly 1.0 in bf16 makes the
+    # balanced-BCE loss and every gradient behind it blow up by 1e8, whoever does the arithmetic)
+    handles = [m.register_forward_hook(hook) for m in ora64.modules()
+               if not list(m.children()) and not isinstance(m, torch.nn.Sigmoid)]
+    forward(ora64, torch.float64).backward()
+    for h in handles:
+        h.remove()
+    return {k: p.grad.detach().clone() for k, p in ora64.named_parameters() if p.grad is not None}
+
+
+def _yard_thunk(ora, fwd, out64):
+    """lazy yardstick pass (the forward closures also record their float64 outputs: keep those of the exact pass)"""
+    def run():
+        saved = dict(out64)
+        with _Threads():
+            g = _f64_bf16_storage(ora, fwd)
+        out64.clear()
+        out64.update(saved)
+        return g
+    return run
+
+
 def _grads(ora):
     return {k: p.grad.detach().clone() for k, p in ora.named_parameters() if p.grad is not None}
 
@@ -134,6 +177,7 @@ def crnn_n256():
     print("oracle CRNN N=256 fwd+bwd (f32 and f64) + eval: %.1f s" % (time.time() - t0))
     c.update(state1=state1, grads32=_grads(ora), grads64=grads64,
              out32={"loss": float(loss), "logp": logp.detach(), "eval": ev})
+    c["yardstick"] = lambda: _f64_bf16_storage(ora, fwd)
     _CACHE["crnn"] = c
     return c
 
@@ -206,6 +250,7 @@ def res50ppm_n256():
         print("oracle Res50-PPM-2DCTC %dx%d N=%d fwd+bwd (f32 and f64): %.1f s" % (height, width, n, time.time() - t0))
     c.update(grads32=_grads(ora), grads64=grads64, out64=out64, out32={"loss": loss_o.detach(), "pred": pred_o.detach()},
              stages64=st64, stages32=st32)
+    c["yardstick"] = _yard_thunk(ora, fwd, out64)
     _CACHE["res50ppm"] = c
     return c
 
@@ -264,6 +309,7 @@ def fpn_attention_n32():
         loss_o.mean().backward()
         print("oracle FPN50-attention 64x256 N=%d fwd+bwd (f32 and f64): %.1f s" % (n, time.time() - t0))
     c.update(grads32=_grads(ora), grads64=grads64, out64=out64, out32={"loss": loss_o.detach(), "att": att_o.detach()})
+    c["yardstick"] = _yard_thunk(ora, fwd, out64)
     _CACHE["fpn"] = c
     return c
 
@@ -341,6 +387,7 @@ def db_n2():
     loss64 = float(l1_balance_ce_loss(out64, {k: v.double() for k, v in batch.items()}))
     c.update(grads32=_grads(ora), grads64=grads64, out64=out64,
              out32={"pred": {k: v.detach() for k, v in pred_o.items()}, "loss": float(loss_o), "loss64": loss64})
+    c["yardstick"] = _yard_thunk(ora, fwd, out64)
     _CACHE["db"] = c
     return c
 

@@ -23,6 +23,7 @@ profiles/r04_diag_capture_crash.txt).  That is fixed, but a crash of this kind m
 """
 import os
 import subprocess
+import time
 import sys
 
 import pytest
@@ -126,6 +127,14 @@ BF16_BARS = {
 }
 
 
+def _group_of(name):
+    """parameter group of the yardstick rule: backbone stage / block family / head layer"""
+    parts = name.split(".")
+    if parts[0] == "backbone" and len(parts) > 2:
+        return ".".join(parts[:3]) if parts[1] in ("0", "1", "bottom_up", "cnn") or parts[1].startswith("layer") else ".".join(parts[:2])
+    return ".".join(parts[:2])
+
+
 def _bf16_drift(case, named32, loss32):
     """the step that is TIMED runs in bf16.  Same weights, same batch, fused optimizer (lr = 0), two eager
     steps and a hipGraph replay in bf16; every parameter's gradient out of the REPLAY against the float64 oracle."""
@@ -154,7 +163,8 @@ def _bf16_drift(case, named32, loss32):
     assert abs(float(gl) - l16) <= 2e-3 * max(1.0, abs(l16)), (float(gl), l16)
     assert abs(l16 - loss32) <= 5e-2 * max(1.0, abs(loss32)), (l16, loss32)
     bars = BF16_BARS.get(case["what"])
-    rows, bad = [], []
+    yard = case.get("grads64s")
+    rows, bad, groups = [], [], {}
     for k, p in named:
         go, g = grads64[k].double().flatten(), p.grad.double().cpu().flatten()
         if float(go.abs().max()) < 1e-7:
@@ -162,12 +172,35 @@ def _bf16_drift(case, named32, loss32):
         l2 = float((g - go).norm() / go.norm())
         cos = float(torch.dot(g, go) / (g.norm() * go.norm() + 1e-300))
         rows.append((k, float(go.norm()), l2, cos))
+        if yard is not None and k in yard:
+            gs = yard[k].double().flatten()
+            grp = groups.setdefault(_group_of(k), {"hip": [], "yard": [], "nh": [], "ny": []})
+            grp["hip"].append(l2)
+            grp["yard"].append(float((gs - go).norm() / go.norm()))
+            grp["nh"].append(float(g.norm() / go.norm()))
+            grp["ny"].append(float(gs.norm() / go.norm()))
         if bars is not None:
             for prefix, (l2_bar, cos_bar) in bars:
                 if k.startswith(prefix):
+                    if cos_bar <= 0.0:
+                        break            # a bar that cannot fail: this parameter is held by the yardstick rule below
                     if not (l2 <= l2_bar and cos >= cos_bar):
                         bad.append((k, l2, cos, l2_bar, cos_bar))
                     break
+    # The discriminating bar for the deep backbones (VERDICT r5 weak item 1 / task 6e): per parameter group, the HIP bf16 step may
+    # be at most 1.5 x as far from exact float64 as the float64 ORACLE ITSELF is once its activations are stored in bf16, and its
+    # gradient norms must match that oracle's within 1.5 x -- a kernel that loses a term, doubles one or drifts beyond what bf16
+    # storage costs anybody fails; the chaos of 53 batch-statistics BatchNorms at random initialisation (which both share) does not.
+    med = lambda v: sorted(v)[len(v) // 2]
+    for gname, grp in sorted(groups.items()):
+        h, y = med(grp["hip"]), med(grp["yard"])
+        nh, ny = med(grp["nh"]), med(grp["ny"])
+        print("   group %-34s %3d parameters: l2 vs f64 -- HIP bf16 %.4f, f64 oracle with bf16 storage %.4f (ratio %.2f); "
+              "norm ratio %.3f vs %.3f" % (gname, len(grp["hip"]), h, y, h / max(y, 1e-12), nh, ny))
+        if not (h <= 1.5 * y + 0.02):
+            bad.append(("group " + gname, h, y, "l2 <= 1.5 x yardstick + 0.02"))
+        if not (ny / 1.5 <= nh <= ny * 1.5):
+            bad.append(("group " + gname, nh, ny, "gradient norm within 1.5 x of the yardstick's"))
     print("%s: per-parameter gradient of the hipGraph replay vs the f64 oracle (relative L2 error, cosine), %d parameters" %
           (what, len(rows)))
     for k, gn, l2, cos in rows:
@@ -186,8 +219,12 @@ def _isolated(name, always=(), replay_bar=1e-3):
     case = getattr(_cases, name)()
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "case.pt")
-        torch.save({"name": name, "grads32": case["grads32"], "grads64": case["grads64"], "always": tuple(always),
-                    "replay_bar": replay_bar}, path)
+        t0 = time.time()
+        yard = case["yardstick"]()          # float64 oracle with bf16 storage: the yardstick of the bf16 bars (memoised below)
+        case["yardstick"] = lambda y=yard: y
+        print("oracle %s with bf16 storage (yardstick): %.1f s" % (name, time.time() - t0))
+        torch.save({"name": name, "grads32": case["grads32"], "grads64": case["grads64"], "grads64s": yard,
+                    "always": tuple(always), "replay_bar": replay_bar}, path)
         repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=os.pathsep.join([repo, os.path.join(repo, "tests"), os.environ.get("PYTHONPATH", "")]))
         out = subprocess.run([sys.executable, "-u", os.path.abspath(__file__), "--child", path], cwd=repo, env=env,
@@ -210,6 +247,7 @@ def _child(path):
     name = blob["name"]
     case = dict(getattr(_cases, name + "_hip")())
     case["grads32"], case["grads64"] = blob["grads32"], blob["grads64"]
+    case["grads64s"] = blob.get("grads64s")
     producers = _timed_step(case, always=blob["always"], replay_bar=blob["replay_bar"])
     print("TIMED-STEP-OK %d" % producers)
 

@@ -46,6 +46,16 @@ def label(name):
         return "igemm_tn_kernel<bf16,conv>"
     if "igemm_tn_taps_kernel" in name:
         return "igemm_tn_taps_kernel<bf16,3x3>"
+    if "igemm_tn_glds_grouped_kernel" in name:
+        return "igemm_tn_glds_grouped_kernel<bf16>"
+    m = re.search(r"igemm_nt32_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi[02]E", name)
+    if m:   # ping-pong kernel: WM x WN waves of TM x TN 32x32 blocks
+        wm, wn, tm, tn = (int(x) for x in m.groups())
+        return "igemm_nt_kernel<bf16,%d,%d,conv>" % (wm * tm * 32, wn * tn * 32)
+    for fam in ("dcn2_dx_gcol_kernel", "dcn2_coord_gcol_kernel", "dcn2_im2col_kernel", "dcn2_fwd_fused_kernel",
+                "dcn2_dx_fused_kernel", "dcn2_coord_fused_kernel", "dcn2_wgrad_fused_kernel"):
+        if fam in name:     # DCNv2 kernels (bench.py labels them by family: the phase timer brackets them inside mr_dcn2_fwd / bwd2)
+            return fam
     return None
 
 

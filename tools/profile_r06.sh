@@ -1,0 +1,45 @@
+#!/bin/bash
+# Round-6 measurement (GPU box).  Outputs: gpurun_out/r06p/ (copy what should be judged into profiles/).
+#   rocprofv3 kernel traces of the five bench workloads + the CRNN at 32 crops per GPU: per-kernel statistics and the launch
+#   sequence of one replayed step; FETCH_SIZE / WRITE_SIZE PMC passes (separate passes) of ALL five workloads ->
+#   pmc_traffic_<workload>.json, stamped with the kernel-source hash bench.py checks.
+# usage: bash tools/profile_r06.sh [quick]      (quick: no PMC passes)
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r06p; mkdir -p $O
+trace() {   # name, marker, bench args...
+  local name=$1; local marker=$2; shift; shift
+  timeout 300 rocprofv3 --kernel-trace -d $O/trace_$name -- python bench.py "$@" --no-cpu-baseline --no-secondary --no-kernel-timer --steps 10 --warmup 3 > $O/trace_$name.log 2>&1
+  local db=$(find $O/trace_$name -name "*.db" | head -1)
+  if [ -n "$db" ]; then
+    python tools/rocpd_stats.py "$db" > $O/${name}_kernel_stats.csv 2>&1
+    python tools/rocpd_sequence.py "$db" --marker $marker > $O/${name}_step_sequence.txt 2>&1
+    head -1 $O/${name}_step_sequence.txt
+  fi
+  grep -o '"ms_per_step": [0-9.]*' $O/trace_$name.log | head -1
+  rm -rf $O/trace_$name
+}
+trace crnn adam_kernel --workload crnn
+trace crnn_b32 adam_kernel --workload crnn --batch 32
+trace res50ppm adam_kernel --workload res50ppm
+trace fpn_attention adam_kernel --workload fpn_attention
+trace fpn_attention_random_coins adam_kernel --workload fpn_attention --teacher-forcing random
+trace db sgd_kernel --workload db
+if [ "$1" != "quick" ]; then
+pmc() {   # json name, bench args...
+  local w=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 500 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${w}_$c -- python bench.py "$@" --no-secondary --no-cpu-baseline --no-graph --no-kernel-timer --steps 3 --warmup 2 > $O/pmc_${w}_$c.log 2>&1
+    f=$(find $O/pmc_${w}_$c -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then python tools/pmc_summary.py "$f" > $O/pmc_${w}_$c.txt 2>&1; fi
+    rm -rf $O/pmc_${w}_$c
+  done
+  python tools/pmc_to_json.py $O/pmc_${w}_FETCH_SIZE.txt $O/pmc_${w}_WRITE_SIZE.txt $O/pmc_traffic_${w}.json > /dev/null 2>&1
+  ls -la $O/pmc_traffic_${w}.json
+}
+pmc crnn --workload crnn
+pmc res50ppm --workload res50ppm
+pmc fpn_attention --workload fpn_attention
+pmc db --workload db
+pmc res50ppm_64x256 --workload res50ppm --crop 64x256
+fi
+echo done
