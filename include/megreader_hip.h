@@ -186,6 +186,16 @@ int mr_tn_flush_beside(hipStream_t stream);
 int mr_conv2d_fwd(int dtype, const void* x, const void* w_krsc, const float* bias, void* y, int relu, int Nimg,
                   int H, int W, int Cin, int ldx, int Cout, int ldy, int R, int S, int sh, int sw, int ph, int pw,
                   int dh, int dw, int Ho, int Wo, hipStream_t stream);
+/* conv + bias (+ ReLU) + max-pool as ONE launch (round 6): y_pool [Nimg, PHo, PWo, Cout] and the arg-max codes of mr_maxpool_fwd,
+ * bit-identical to mr_conv2d_fwd followed by mr_maxpool_fwd; the full-resolution activation never reaches HBM.  bf16, stride-1
+ * convolutions whose 8-wave tiles can be cut on window-row / image boundaries -- mr_conv2d_fwd_pool_ok (host only) says which;
+ * replaces cuDNN conv + ReLU + MaxPool2d of backbones/crnn.py:14-33 (conv1: 2x2 / 2; conv3, conv5: 2x2, stride (2,1), pad (0,1)). */
+int mr_conv2d_fwd_pool_ok(int dtype, int Nimg, int H, int W, int Cin, int ldx, int Cout, int R, int S, int sh, int sw, int ph, int pw,
+                          int dh, int dw, int Ho, int Wo, int pkh, int pkw, int psh, int psw, int pph, int ppw);
+int mr_conv2d_fwd_pool(int dtype, const void* x, const void* w_krsc, const float* bias, void* y_pool, unsigned char* idx, int relu,
+                       int Nimg, int H, int W, int Cin, int ldx, int Cout, int R, int S, int sh, int sw, int ph, int pw, int dh,
+                       int dw, int Ho, int Wo, int pkh, int pkw, int psh, int psw, int pph, int ppw, int PHo, int PWo,
+                       hipStream_t stream);
 /* mr_conv2d_fwd (no ReLU, ldy == Cout) that also leaves the BatchNorm batch statistics of y in bn_sums (layout and zeroing as
  * for mr_bn_stats) -- accumulated in the GEMM epilogue, so the BatchNorm that follows (reference nn.Sequential(conv, bn) at
  * backbones/resnet.py:39-56,113-181, crnn.py:48-52) skips its reduction pass over y: mr_bn_fwd_train(flags bit 3). */

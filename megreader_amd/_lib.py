@@ -27,6 +27,7 @@ SIGNATURES = {
     "mr_gemm_tn": "iplplpiiiiips",
     "mr_gemm_tn2": "iplplpiiiiipps",
     "mr_conv2d_fwd": "ipppp" + "i" * 18 + "s",
+    "mr_conv2d_fwd_pool": "ippppp" + "i" * 25 + "s",
     "mr_conv2d_fwd_stats": "ippppp" + "i" * 16 + "s",
     "mr_bn_stats": "ipplis",
     "mr_conv2d_dgrad": "ippp" + "i" * 17 + "s",
@@ -275,6 +276,8 @@ def load():
     lib.mr_tn_pending.argtypes = []
     lib.mr_tn_discard.restype = ctypes.c_int
     lib.mr_tn_discard.argtypes = []
+    lib.mr_conv2d_fwd_pool_ok.restype = ctypes.c_int
+    lib.mr_conv2d_fwd_pool_ok.argtypes = [ctypes.c_int] * 23
     lib.mr_phase_timer.restype = ctypes.c_int
     lib.mr_phase_timer.argtypes = [ctypes.c_int]
     lib.mr_phase_read.restype = ctypes.c_int
@@ -305,7 +308,7 @@ def load():
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_tuning_get", "mr_tuning_set", "mr_tuning_defaults",
              "mr_stem_bwd_workspace", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_dcn2_ws_bytes", "mr_bn_scratch_doubles",
              "mr_sizeof_img_desc", "mr_nt_kernel_code", "mr_tn_taps_would_run", "mr_set_tn_taps_workspace",
-             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending", "mr_tn_discard", "mr_phase_timer", "mr_phase_read", "mr_dcn2_dx_direct", "mr_dcn2_fused", "mr_db_loss_ws_bytes")  # entry points that take no stream and launch nothing
+             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending", "mr_tn_discard", "mr_phase_timer", "mr_phase_read", "mr_conv2d_fwd_pool_ok", "mr_dcn2_dx_direct", "mr_dcn2_fused", "mr_db_loss_ws_bytes")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

@@ -24,6 +24,21 @@ class _Stem(nn.Sequential):
         return super().forward(input)
 
 
+class _ConvReluPool(nn.Sequential):
+    """conv + ReLU + max-pool (reference crnn.py:20-22, 26-28, 32-34).  Same children / state_dict keys as the plain Sequential;
+    in bf16, where the convolution's tiles can be cut on pooling-window boundaries, the three ops are ONE forward launch whose
+    epilogue pools the tile out of LDS (megreader_amd/csrc/igemm_core.h: EpiPool) -- the full-resolution activation (67 MB for
+    conv1 at N = 256) is neither written nor re-read; backward is the pool's and the convolution's, unchanged."""
+
+    def forward(self, input):
+        conv, pool = self[0][0], self[1]
+        if F.conv_relu_pool_eligible(input, conv.weight, conv.stride, conv.padding, conv.dilation, _pair(pool.kernel_size),
+                                     _pair(pool.stride), _pair(pool.padding)):
+            return F.conv_relu_pool(input, conv.weight, conv.bias, conv.padding, _pair(pool.kernel_size), _pair(pool.stride),
+                                    _pair(pool.padding))
+        return super().forward(input)
+
+
 def _pair(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
@@ -41,11 +56,11 @@ class CRNN(nn.Module):
 
         # conv+ReLU stages feed a max-pool: the pool's backward also applies the ReLU mask (one pass saved)
         conv0 = _Stem(self._make_layer(0, pooled=True), MaxPool2d((2, 2), relu_input=True))
-        conv1 = nn.Sequential(self._make_layer(1, pooled=True), MaxPool2d((2, 2), relu_input=True))
+        conv1 = _ConvReluPool(self._make_layer(1, pooled=True), MaxPool2d((2, 2), relu_input=True))
         conv2 = self._make_layer(2, True)
-        conv3 = nn.Sequential(self._make_layer(3, pooled=True), MaxPool2d((2, 2), (2, 1), (0, 1), relu_input=True))
+        conv3 = _ConvReluPool(self._make_layer(3, pooled=True), MaxPool2d((2, 2), (2, 1), (0, 1), relu_input=True))
         conv4 = self._make_layer(4, True)
-        conv5 = nn.Sequential(self._make_layer(5, pooled=True), MaxPool2d((2, 2), (2, 1), (0, 1), relu_input=True))
+        conv5 = _ConvReluPool(self._make_layer(5, pooled=True), MaxPool2d((2, 2), (2, 1), (0, 1), relu_input=True))
         conv6 = self._make_layer(6, True)
 
         self.cnn = nn.Sequential(conv0, conv1, conv2, conv3, conv4, conv5, conv6)

@@ -763,6 +763,56 @@ bool gemm_nt_skinny(int dtype, const void* A, long long lda, const void* B, long
                     const float* bias, int relu, int M, int N, int K, hipStream_t stream);
 }
 
+// ---- conv + bias + ReLU + max-pool in one launch (EpiPool, igemm_core.h; round 6, VERDICT r5 task 8) -----------------------
+// Which 8-wave tile serves the fused launch: the one the plain forward would take, if its rows can be cut on window-row / image
+// boundaries.  Returns 0 (not eligible), 1 = 256x256, 3 = 272x256 (1x8 waves), 8 = 128x128 (two 8-wave workgroups per CU) and the
+// rows of M a tile covers in *tile_rows.
+static int conv_pool_plan(int M, int N, int K, int Cin, int Ho, int Wo, int kh, int sh, int ph, int* tile_rows) {
+  if (kh != sh || ph != 0 || Ho % kh != 0 || (Cin % 64) != 0 || g_nt_variant != 2) return 0;
+  const int img = Ho * Wo, wrow = kh * Wo;
+  auto fit = [&](int bm) {      // largest multiple of a window row that fills at most bm rows and tiles the images exactly
+    int t = (bm / wrow) * wrow;
+    if (t <= 0) return 0;
+    if (t >= img) t = (t / img) * img;
+    else while (t > 0 && img % t != 0) t -= wrow;
+    return t;
+  };
+  const int big = nt_big_choice(M, N, K);
+  if (big == 1 || big == 3) {
+    const int bm = big == 1 ? 256 : 272;
+    const int t = fit(bm);
+    if (t > 0 && N % 256 == 0 && t * 16 >= bm * 15) { *tile_rows = t; return big; }   // (at most 1/16 of a tile's rows idle)
+  }
+  const TileChoice tw = nt_tile(M, N);
+  if (tw.bm == 128 && tw.bn == 128 && (MR_TUNE(nt_wide8) & 1) && N % 128 == 0) {
+    const int t = fit(128);
+    if (t == 128) { *tile_rows = t; return 8; }
+  }
+  return 0;
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_nt_pool(const NtArgs& a, const ConvGeom& g, const EpiPool<bf16_t>& epi, hipStream_t stream) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr size_t lds_stage = 2 * (size_t)(BM + BN) * 128, lds_tile = (size_t)BM * BN * 2;
+  constexpr size_t lds = lds_stage > lds_tile ? lds_stage : lds_tile;
+  auto kern = igemm_nt_big_kernel<bf16_t, WM, WN, TM, TN, 2, EpiPool<bf16_t>>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
+      return MR_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int tiles_m = cdiv(a.M, a.tile_rows), tiles_n = cdiv(a.N, BN);
+  const int grid = cdiv(tiles_m, 8) * 8 * tiles_n;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, stream, a, g, epi);
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+
+
 extern "C" {
 
 // Eagerly create per-device state (the zero page).  Call once per device before capturing a hipGraph.
@@ -935,6 +985,43 @@ int mr_conv2d_fwd(int dtype, const void* x, const void* w_krsc, const float* bia
   }
   if (dtype == MR_F32) return dispatch_nt_store<float, 1>(a, g, y, ldy, bias, relu, stream);
   return dispatch_nt_store<bf16_t, 1>(a, g, y, ldy, bias, relu, stream);
+}
+
+// host only: 1 when mr_conv2d_fwd_pool serves this geometry (else run mr_conv2d_fwd + mr_maxpool_fwd)
+int mr_conv2d_fwd_pool_ok(int dtype, int Nimg, int H, int W, int Cin, int ldx, int Cout, int R, int S, int sh, int sw, int ph, int pw,
+                          int dh, int dw, int Ho, int Wo, int pkh, int pkw, int psh, int psw, int pph, int ppw) {
+  (void)H; (void)W; (void)ppw; (void)pkw; (void)psw;
+  if (dtype != MR_BF16 || R * S > 32 || Cin != ldx || Cout % 8 != 0 || sh != 1 || sw != 1 || dh != 1 || dw != 1 || ph < 0 || pw < 0)
+    return 0;
+  int tr = 0;
+  return conv_pool_plan(Nimg * Ho * Wo, Cout, R * S * Cin, Cin, Ho, Wo, pkh, psh, pph, &tr) ? 1 : 0;
+}
+
+// y_pool [Nimg, PHo, PWo, Cout] (bf16) = maxpool_{pkh x pkw, stride (psh, psw), pad (pph, ppw)}(relu?(conv(x) + bias)), idx = the
+// arg-max codes mr_maxpool_fwd would store for it (one byte per element).  Replaces the pair mr_conv2d_fwd + mr_maxpool_fwd for
+// the geometries mr_conv2d_fwd_pool_ok accepts: the full-resolution activation is neither written nor re-read.
+int mr_conv2d_fwd_pool(int dtype, const void* x, const void* w_krsc, const float* bias, void* y_pool, unsigned char* idx, int relu,
+                       int Nimg, int H, int W, int Cin, int ldx, int Cout, int R, int S, int sh, int sw, int ph, int pw, int dh,
+                       int dw, int Ho, int Wo, int pkh, int pkw, int psh, int psw, int pph, int ppw, int PHo, int PWo,
+                       hipStream_t stream) {
+  MR_CHECK_ARG(mr_conv2d_fwd_pool_ok(dtype, Nimg, H, W, Cin, ldx, Cout, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo, pkh, pkw, psh, psw, pph,
+                                     ppw),
+               "mr_conv2d_fwd_pool: geometry not served (ask mr_conv2d_fwd_pool_ok)");
+  MR_CHECK_ARG(PHo == Ho / pkh && PWo == (Wo + 2 * ppw - pkw) / psw + 1 && pkh * pkw <= 255,
+               "mr_conv2d_fwd_pool: pooled size %dx%d inconsistent", PHo, PWo);
+  MR_CHECK_ARG(aligned16(x) && aligned16(w_krsc) && aligned16(y_pool) && ((uintptr_t)idx & 7) == 0, "mr_conv2d_fwd_pool: alignment");
+  NtArgs a;
+  a.A = x; a.B = w_krsc; a.M = Nimg * Ho * Wo; a.N = Cout; a.K = R * S * Cin; a.lda = 0; a.ldb = R * S * Cin; a.zero = zero_page();
+  ConvGeom g;
+  fill_geom(g, 1, H, W, Cin, ldx, Ho, Wo, R, S, sh, sw, ph, pw, dh, dw);
+  MR_CHECK_ARG(nt_fits_buffer<bf16_t>(a, g, 2), "mr_conv2d_fwd_pool: operands must be smaller than 2 GiB");
+  const int plan = conv_pool_plan(a.M, a.N, a.K, Cin, Ho, Wo, pkh, psh, pph, &a.tile_rows);
+  EpiPool<bf16_t> epi;
+  epi.C = (bf16_t*)y_pool; epi.idx = idx; epi.ldc = Cout; epi.bias = bias; epi.relu = relu; epi.M = a.M; epi.N = Cout;
+  epi.Nimg = Nimg; epi.Ho = Ho; epi.Wo = Wo; epi.kh = pkh; epi.kw = pkw; epi.sw = psw; epi.pw = ppw; epi.PHo = PHo; epi.PWo = PWo;
+  if (plan == 1) return launch_nt_pool<2, 4, 8, 4>(a, g, epi, stream);
+  if (plan == 3) return launch_nt_pool<1, 8, 17, 2>(a, g, epi, stream);
+  return launch_nt_pool<2, 4, 4, 2>(a, g, epi, stream);
 }
 
 // mr_conv2d_fwd + the BatchNorm batch statistics of its output: bn_sums (f64 [MR_BN_COPIES][2][Cout], zeroed by the caller;

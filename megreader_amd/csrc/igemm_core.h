@@ -84,6 +84,10 @@ struct NtArgs {
   // ws = [NT_SPLIT_TICKETS ints, zero between launches][slabs of BM*BN*4 bytes, index tile*ksplit + split].
   int ksplit = 1;
   void* ws = nullptr;
+  // Rows of the M index space one tile COVERS (igemm_nt_big_kernel only; 0 = the tile height BM): a tile of BM rows computes
+  // rows [m_begin + t * tile_rows, + tile_rows) and leaves its last BM - tile_rows rows empty.  Lets tiles start on image
+  // boundaries whatever the tile height (the pooled epilogue, EpiPool: 2 images of 4 x 33 = 264 rows in a 272-row tile).
+  int tile_rows = 0;
 };
 constexpr int NT_SPLIT_TICKETS = 4096;
 
@@ -94,6 +98,7 @@ __device__ __forceinline__ uint4 ldg16(const void* p) { return *(const uint4*)p;
 // lanes of a row group (same lg) are combined with four butterfly steps, lane l15 == 0 adds the result to the f64
 // accumulators.  2 * 4*CNT f64 atomics per (wave, lg): 512 per 128x128 tile against 16384 elements.
 template <typename Epi> struct EpiHasStats { static constexpr bool value = false; };  // specialised for EpiStore below
+template <typename Epi> struct EpiIsPool { static constexpr bool value = false; };   // specialised for EpiPool below
 __device__ __forceinline__ float row16_sum(float v) {   // total over the lane's 16-lane DPP row, in every lane of it
 #define MR_ROW_ROR(V, N) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), 0x120 + (N), 0xf, 0xf, false))
   v += MR_ROW_ROR(v, 8);
@@ -995,12 +1000,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_nt_big_kernel(NtArgs a, Co
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M - a.m_begin + BM - 1) / BM;
+  const int trows = a.tile_rows > 0 ? a.tile_rows : BM;     // rows of M a tile covers (<= BM)
+  const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M - a.m_begin + trows - 1) / trows;
   // XCD-aware map: hardware block b -> xcd = b & 7, slot = b >> 3
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int tile_m = (slot / tiles_n) * 8 + xcd, tile_n = slot % tiles_n;
   if (tile_m >= tiles_m) return;
-  const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
+  const int m0 = a.m_begin + tile_m * trows, n0 = tile_n * BN;
   const int lrow = lane >> 3, lpc = lane & 7;
 
   const T* __restrict__ A = (const T*)a.A;
@@ -1020,7 +1026,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_nt_big_kernel(NtArgs a, Co
     const int m = m0 + gi * 8 + lrow;
     a_mask[i] = 0;
     a_off[i] = 0;
-    if (gi < AG) {
+    if (gi < AG && gi * 8 + lrow < trows) {
       if (AMODE == 0) {
         a_off[i] = (int)((long long)m * a.lda + kc_of(gi));
         a_mask[i] = m < a.M ? 1u : 0u;
@@ -1147,6 +1153,95 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_nt_big_kernel(NtArgs a, Co
     compute(st0);
   }
 
+  if constexpr (EpiIsPool<Epi>::value) {
+    // conv + bias + ReLU + MAX-POOL in one launch (EpiPool below): the tile goes to LDS as T [BM][BN] (16-byte chunk c of row r
+    // at chunk c ^ (r & (CH-1)): conflict-free both ways), then every thread pools whole channel vectors out of it with the
+    // comparison rule of maxpool_fwd_kernel (first maximum in window order, NaN wins) -- same values, same arg-max codes.
+    static_assert(sizeof(T) == 2, "pooled epilogue: bf16 only");
+    constexpr int CH = BN / 8;
+    static_assert((CH & (CH - 1)) == 0 && (4 * TN) % 8 == 0, "pooled epilogue: tile width / lane run in whole 16-byte chunks");
+    __syncthreads();                       // every wave is done reading the stage buffers (no LDS-DMA is in flight here)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int r = wm_ * WTM + j * 16 + l15;
+#pragma unroll
+      for (int q = 0; q < TN / 2; ++q) {   // one 16-byte chunk = the 8 channels of accumulator tiles 2q, 2q+1
+        const int n = n0 + wn_ * WTN + lg * (4 * TN) + q * 8;
+        T o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = acc[2 * q + e / 4][j][e % 4];
+          if (epi.bias && n + e < epi.N) t += epi.bias[n + e];
+          if (epi.relu) t = fmaxf(t, 0.f);
+          o[e] = from_f32<T>(t);
+        }
+        const int c = (wn_ * WTN + lg * (4 * TN)) / 8 + q;
+        smem[r * CH + (c ^ (r & (CH - 1)))] = *(const uint4*)o;
+      }
+    }
+    __syncthreads();
+    // pooled elements of this tile: thread -> channel chunk c = tid % CH (fixed) and pooled pixels tid / CH, + 64 NW / CH, ...
+    // in (pooled row, pooled column) order; the indices advance incrementally (no division in the loop)
+    const int img_rows = trows / epi.Wo;                 // conv image-rows the tile covers (a multiple of kh)
+    const int prows = img_rows / epi.kh;
+    const int row0 = m0 / epi.Wo;                        // global conv image-row of the tile's first row (m0 % Wo == 0)
+    constexpr int PSTEP = 64 * NW / CH;                  // pooled pixels per sweep of the workgroup
+    const int c = tid % CH;
+    int pix = tid / CH;
+    int pr = pix / epi.PWo, pwi = pix - pr * epi.PWo;
+    int nimg = (row0 + pr * epi.kh) / epi.Ho, h = (row0 + pr * epi.kh) - nimg * epi.Ho;
+    const bool col_ok = n0 + c * 8 < epi.N;
+    auto pool_one = [&](auto kh_tag, auto kw_tag) {
+      constexpr int KH = decltype(kh_tag)::value, KW = decltype(kw_tag)::value;   // 0 = runtime window
+      const int kh = KH ? KH : epi.kh, kw = KW ? KW : epi.kw;
+      for (; pr < prows; ) {
+        if (nimg < epi.Nimg && col_ok) {
+          float best[8];
+          unsigned char bi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+          bool first = true;
+#pragma unroll
+          for (int i = 0; i < (KH ? KH : 1); ++i)
+            for (int i2 = 0; i2 < (KH ? 1 : kh); ++i2) {
+              const int ii = KH ? i : i2;
+#pragma unroll
+              for (int jx = 0; jx < (KW ? KW : 1); ++jx)
+                for (int j2 = 0; j2 < (KW ? 1 : kw); ++j2) {
+                  const int jj = KW ? jx : j2;
+                  const int w = pwi * epi.sw - epi.pw + jj;
+                  if ((unsigned)w >= (unsigned)epi.Wo) continue;
+                  const int r = (pr * kh + ii) * epi.Wo + w;
+                  const uint4 v = smem[r * CH + (c ^ (r & (CH - 1)))];
+                  const T* pv = (const T*)&v;
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) {
+                    const float f = to_f32(pv[e]);
+                    if (first || f > best[e] || f != f) { best[e] = f; bi[e] = (unsigned char)(ii * kw + jj); }
+                  }
+                  first = false;
+                }
+            }
+          T o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(best[e]);
+          const long long q = (((long long)nimg * epi.PHo + h / kh) * epi.PWo + pwi) * epi.ldc + n0 + c * 8;
+          *(uint4*)(epi.C + q) = *(const uint4*)o;
+          *(uint2*)(epi.idx + q) = *(const uint2*)bi;
+        }
+        pwi += PSTEP;
+        while (pwi >= epi.PWo) {
+          pwi -= epi.PWo;
+          ++pr;
+          h += kh;
+          if (h >= epi.Ho) { h -= epi.Ho; ++nimg; }
+        }
+      }
+    };
+    if (epi.kh == 2 && epi.kw == 2) pool_one(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+    else pool_one(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    return;
+  } else {
   // row block outer, column block inner: the TN stores of one output row land back to back, so its 128-byte line is
   // completed in L2 before it can be evicted half-written (the 256x256 kernel wrote 2.5x its output bytes to HBM
   // with the loops the other way round)
@@ -1165,7 +1260,24 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_nt_big_kernel(NtArgs a, Co
   }
   if constexpr (EpiHasStats<Epi>::value)
     if (with_stats) cst.flush(epi, n0 + wn_ * WTN + lg * (4 * TN), l15);
+  }
 }
+
+// Pooled epilogue of igemm_nt_big_kernel: y_pool = maxpool(relu(conv + bias)) and the arg-max codes of mr_maxpool_fwd, written
+// directly -- the full-resolution activation never reaches HBM (round 6; reference backbones/crnn.py:14-33: Conv2d -> ReLU ->
+// MaxPool2d).  Geometry contract (checked by the host, conv_pool_plan in gemm_conv.hip): non-overlapping window rows without
+// vertical padding (kh == stride_h, pad_h == 0, Ho % kh == 0), NtArgs.tile_rows a multiple of kh * Wo that divides or is a
+// multiple of Ho * Wo; any horizontal window (kw, sw, pw).  C / idx: [Nimg, PHo, PWo, ldc] in T / one byte per element.
+template <typename T> struct EpiPool {
+  T* C;
+  unsigned char* idx;
+  long long ldc;
+  const float* bias;
+  int relu;
+  int M, N;
+  int Nimg, Ho, Wo, kh, kw, sw, pw, PHo, PWo;
+};
+template <typename T> struct EpiIsPool<EpiPool<T>> { static constexpr bool value = true; };
 
 // Plain epilogue: C = act(acc + bias [+ addend]) stored as T, row-major with leading dim ldc.
 template <typename T> struct EpiStore {

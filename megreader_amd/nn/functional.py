@@ -960,6 +960,84 @@ def stem_conv_relu_pool(x, weight, bias):
 # --------------------------------------------------------------------------------------------------
 # MaxPool2d.  reference: nn.MaxPool2d at backbones/crnn.py:17-31
 # --------------------------------------------------------------------------------------------------
+class ConvReluPoolFn(Function):
+    """conv + bias + ReLU + max-pool as ONE forward launch (mr_conv2d_fwd_pool; reference backbones/crnn.py:14-33: Conv2d -> ReLU ->
+    MaxPool2d): the pooled activation and the arg-max codes come straight out of the GEMM's epilogue, the full-resolution
+    activation is never written.  Backward = the two nodes it replaces, unchanged: mr_maxpool_bwd (which also applies the ReLU
+    mask, read at pooled resolution) expands the gradient, then Conv2dFn's backward runs on it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, padding, pool_kernel, pool_stride, pool_padding):
+        require_cuda(x, weight, bias)
+        dtype = get_compute_dtype()
+        dt = dtype_code(dtype)
+        xi = to_internal(x, dtype)
+        N, H, W, Cp = xi.shape
+        K, C, R, S = weight.shape
+        ph, pw = padding
+        Ho, Wo = _conv_out(H, R, 1, ph, 1), _conv_out(W, S, 1, pw, 1)
+        kh, kw = pool_kernel
+        psh, psw = pool_stride
+        pph, ppw = pool_padding
+        PHo, PWo = (Ho + 2 * pph - kh) // psh + 1, (Wo + 2 * ppw - kw) // psw + 1
+        need_dx = ctx.needs_input_grad[0]
+        w_krsc, w_crsk, bias_k = _conv_operands(weight, bias, dtype, Cp, K, need_dx)
+        y = torch.empty((N, PHo, PWo, K), dtype=dtype, device=x.device)
+        idx = torch.empty((N, PHo, PWo, K), dtype=torch.uint8, device=x.device)
+        call("mr_conv2d_fwd_pool", dt, ptr(xi), ptr(w_krsc), ptr(bias_k), ptr(y), ptr(idx), 1, N, H, W, Cp, Cp, K, R, S, 1, 1, ph, pw,
+             1, 1, Ho, Wo, kh, kw, psh, psw, pph, ppw, PHo, PWo)
+        ctx.save_for_backward(xi, w_crsk, idx, y)
+        ctx.params = (weight, bias)
+        ctx.geom = (N, H, W, Cp, C, K, K, R, S, 1, 1, ph, pw, 1, 1, Ho, Wo)
+        ctx.pool = (kh, kw, psh, psw, pph, ppw, PHo, PWo)
+        ctx.has_bias = bias is not None
+        ctx.dtype = dtype
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xi, w_crsk, idx, y = ctx.saved_tensors
+        N, H, W, Cp, C, K, Kp, R, S, sh, sw, ph, pw, dh, dw, Ho, Wo = ctx.geom
+        kh, kw, psh, psw, pph, ppw, PHo, PWo = ctx.pool
+        dtype = ctx.dtype
+        g = _grad_internal(gy, dtype)
+        dz = torch.empty((N, Ho, Wo, K), dtype=dtype, device=g.device)
+        call("mr_maxpool_bwd", dtype_code(dtype), ptr(g), ptr(idx), ptr(y), ptr(dz), N, Ho, Wo, K, kh, kw, psh, psw, pph, ppw,
+             PHo, PWo)
+
+        class _ConvCtx(object):      # what Conv2dFn.backward reads from its ctx (relu already applied by the pool's backward)
+            pass
+        c = _ConvCtx()
+        c.saved_tensors = (xi, w_crsk, None)
+        c.geom, c.dtype, c.params, c.has_bias = ctx.geom, dtype, ctx.params, ctx.has_bias
+        c.relu, c.bnb_link = False, None
+        c.needs_input_grad = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]) + (False,) * 8
+        grads = Conv2dFn.backward(c, dz.permute(0, 3, 1, 2))
+        return grads[0], grads[1], grads[2], None, None, None, None
+
+
+def conv_relu_pool_eligible(x, weight, stride, padding, dilation, pool_kernel, pool_stride, pool_padding):
+    """True when conv + ReLU + max-pool of this geometry runs as one forward launch (bf16, stride-1 convolution whose 8-wave
+    tiles can be cut on pooling-window / image boundaries; see mr_conv2d_fwd_pool_ok)."""
+    if not x.is_cuda or get_compute_dtype() != torch.bfloat16 or tuple(stride) != (1, 1) or tuple(dilation) != (1, 1):
+        return False
+    if os.environ.get("MEGREADER_CONV_POOL", "1") == "0":
+        return False
+    N, C, H, W = x.shape
+    K, Cw, R, S = weight.shape
+    if C != Cw or C % 8 != 0 or K % 8 != 0:
+        return False
+    ph, pw = padding
+    Ho, Wo = _conv_out(H, R, 1, ph, 1), _conv_out(W, S, 1, pw, 1)
+    return bool(load().mr_conv2d_fwd_pool_ok(dtype_code(torch.bfloat16), N, H, W, C, C, K, R, S, 1, 1, ph, pw, 1, 1, Ho, Wo,
+                                             pool_kernel[0], pool_kernel[1], pool_stride[0], pool_stride[1],
+                                             pool_padding[0], pool_padding[1]))
+
+
+def conv_relu_pool(x, weight, bias, padding, pool_kernel, pool_stride, pool_padding):
+    return ConvReluPoolFn.apply(x, weight, bias, tuple(padding), tuple(pool_kernel), tuple(pool_stride), tuple(pool_padding))
+
+
 class MaxPoolFn(Function):
     @staticmethod
     def forward(ctx, x, kernel, stride, padding, relu_input=False):
