@@ -121,7 +121,10 @@ typedef struct mr_tuning {
                         read by a coordinate-gradient pass and a CSR gather pass for the input gradient (dcn_fused.hip, C in
                         {64, 128, 256, 512}); 0 = the round-3 fused kernels (gcol in accumulators, gather-GEMM).  Changes the size
                         mr_dcn2_ws_bytes reports: workspaces must be sized under the value in force at the call */
-  int reserved[5];   /* zero */
+  int dcn_col_fwd;   /* round 6: 1 (default) = on the dcn_gcol shapes the bf16 forward also goes through the column matrix (one sampling
+                        pass into the caller's col_ws + the tuned NT GEMM) and leaves it there for the backward's weight gradient
+                        (mr_dcn2_col_saved / mr_dcn2_bwd3); 0 = the fused forward kernel, the backward samples again */
+  int reserved[4];   /* zero */
 } mr_tuning;
 int mr_tuning_get(mr_tuning* out);
 int mr_tuning_defaults(mr_tuning* out);
@@ -529,6 +532,14 @@ int mr_dcn2_bwd2(int dtype, const void* dy, const void* x, const void* w_t, cons
                  const float* mask, long long msk_bs, void* col_ws, float* dx32, void* dx_t, int flags, float* doffset,
                  float* dmask, float* dw, float* dbias, int N, int H, int W, int C, int Co, int kh, int kw, int stride, int pad,
                  int dil, int Ho, int Wo, hipStream_t stream);
+/* round 6: mr_dcn2_col_saved (host only) = 1 when mr_dcn2_fwd leaves the sampled column matrix [N*Ho*Wo, kh*kw*C] in its col_ws
+ * (bf16, mr_tuning.dcn_col_fwd); mr_dcn2_bwd3 = mr_dcn2_bwd2 + col_saved (nullable): that buffer, kept alive by the caller --
+ * the weight gradient reads it instead of sampling x again. */
+int mr_dcn2_col_saved(int dtype, int H, int W, int C, int Co, int kh, int kw);
+int mr_dcn2_bwd3(int dtype, const void* dy, const void* x, const void* w_t, const float* offset, long long off_bs,
+                 const float* mask, long long msk_bs, void* col_ws, float* dx32, void* dx_t, int flags, float* doffset,
+                 float* dmask, float* dw, float* dbias, const void* col_saved, int N, int H, int W, int C, int Co, int kh, int kw,
+                 int stride, int pad, int dil, int Ho, int Wo, hipStream_t stream);
 /* Packed offset/mask operand of the deformable ResNet blocks (reference backbones/resnet.py:125-142: offset_mask =
  * conv2_offset(x); conv2(x, offset_mask[:, :18], offset_mask[:, -9:].sigmoid())).  raw = the offset conv's output, NHWC
  * [N][HW][ld] in `dtype` (channels n_offset + n_mask <= ld).  mr_dcn_unpack writes the flat f32 NCHW offset [N][n_offset][HW]

@@ -84,6 +84,7 @@ SIGNATURES = {
     "mr_dcn2_fwd": "ippp" + "plpl" + "pp" + "i" * 12 + "s",
     "mr_dcn2_bwd": "ippp" + "plpl" + "pppppp" + "i" * 12 + "s",
     "mr_dcn2_bwd2": "ippp" + "plpl" + "pppi" + "pppp" + "i" * 12 + "s",
+    "mr_dcn2_bwd3": "ippp" + "plpl" + "pppi" + "pppp" + "p" + "i" * 12 + "s",
     "mr_dcn_unpack": "ipippiiiis",
     "mr_dcn_pack_grad": "ippppiiiiis",
     "mr_db_components": "pfpppiiii" + "s",
@@ -128,12 +129,12 @@ _lib = None
 
 TUNING_FIELDS = ("nt_variant", "nt_deep", "nt_big", "nt_p8", "nt_force_bm", "nt_force_bn", "gemm_skinny", "tn_big", "tn_buf",
                  "tn_taps", "tn_taps_group", "tn_group", "tn_fin", "tn_taps_fin", "tn_taps_w8", "tn_model", "tn_splits",
-                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth", "nt_big_min_k", "tn_taps_min_p", "tn_defer", "pool_fixed", "ctc_linear", "nt_wide8", "nt_ksplit", "nt_m32", "nt_m32_opt", "dcn_gcol")
+                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth", "nt_big_min_k", "tn_taps_min_p", "tn_defer", "pool_fixed", "ctc_linear", "nt_wide8", "nt_ksplit", "nt_m32", "nt_m32_opt", "dcn_gcol", "dcn_col_fwd")
 
 
 class Tuning(ctypes.Structure):
     """struct mr_tuning (include/megreader_hip.h): the library's only process-wide switches."""
-    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 5)]
+    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 4)]
 
 
 def get_tuning():
@@ -276,6 +277,8 @@ def load():
     lib.mr_tn_pending.argtypes = []
     lib.mr_tn_discard.restype = ctypes.c_int
     lib.mr_tn_discard.argtypes = []
+    lib.mr_dcn2_col_saved.restype = ctypes.c_int
+    lib.mr_dcn2_col_saved.argtypes = [ctypes.c_int] * 7
     lib.mr_conv2d_fwd_pool_ok.restype = ctypes.c_int
     lib.mr_conv2d_fwd_pool_ok.argtypes = [ctypes.c_int] * 23
     lib.mr_phase_timer.restype = ctypes.c_int
@@ -308,7 +311,7 @@ def load():
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_tuning_get", "mr_tuning_set", "mr_tuning_defaults",
              "mr_stem_bwd_workspace", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_dcn2_ws_bytes", "mr_bn_scratch_doubles",
              "mr_sizeof_img_desc", "mr_nt_kernel_code", "mr_tn_taps_would_run", "mr_set_tn_taps_workspace",
-             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending", "mr_tn_discard", "mr_phase_timer", "mr_phase_read", "mr_conv2d_fwd_pool_ok", "mr_dcn2_dx_direct", "mr_dcn2_fused", "mr_db_loss_ws_bytes")  # entry points that take no stream and launch nothing
+             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending", "mr_tn_discard", "mr_phase_timer", "mr_phase_read", "mr_conv2d_fwd_pool_ok", "mr_dcn2_col_saved", "mr_dcn2_dx_direct", "mr_dcn2_fused", "mr_db_loss_ws_bytes")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

@@ -64,7 +64,9 @@ def _dcn_forward(ctx, input, off, msk, weight, bias, stride, padding, dilation, 
     y = torch.empty((N, Ho, Wo, Co), dtype=dtype, device=xi.device)
     call("mr_dcn2_fwd", dt, ptr(xi), ptr(w_n), ptr(bias), ptr(off), off_bs, ptr(msk), msk_bs, ptr(y), ptr(col), N, H,
          W, C, Co, kh, kw, stride, padding, dilation, Ho, Wo)
-    ctx.save_for_backward(xi, off, msk, w_t)
+    # bf16 materialised path (round 6): the forward's column matrix stays alive for the backward's weight gradient
+    keep_col = col is not None and bool(load().mr_dcn2_col_saved(dt, H, W, C, Co, kh, kw))
+    ctx.save_for_backward(xi, off, msk, w_t, col if keep_col else None)
     ctx.geom = (N, H, W, C, Co, kh, kw, stride, padding, dilation, Ho, Wo, off_bs, msk_bs)
     ctx.params = (weight, bias)
     ctx.dtype = dtype
@@ -75,7 +77,7 @@ def _dcn_backward(ctx, grad_output, want_dx, want_dw, want_db, scratch_ok=False)
     """Shared backward: (grad_input NCHW view | None, grad_offset f32 NCHW, grad_mask f32 NCHW, grad_weight | None,
     grad_bias | None).  Parameter gradients go straight into the fused optimizers' gradient sinks when those exist
     (nn/functional.py grad_sink: no temporary, no `grad += tmp` launch) -- the returned gradient is then None."""
-    xi, off, msk, w_t = ctx.saved_tensors
+    xi, off, msk, w_t, col_saved = ctx.saved_tensors
     N, H, W, C, Co, kh, kw, stride, padding, dilation, Ho, Wo, off_bs, msk_bs = ctx.geom
     dtype = ctx.dtype
     dt = dtype_code(dtype)
@@ -113,9 +115,9 @@ def _dcn_backward(ctx, grad_output, want_dx, want_dw, want_db, scratch_ok=False)
         gw = w_sink if w_sink is not None else zbuf[offs[3]:offs[3] + sizes[3]].view(Co, kh, kw, C)
     if want_db:
         gb = b_sink if b_sink is not None else zbuf[offs[4]:offs[4] + sizes[4]]
-    call("mr_dcn2_bwd2", dt, ptr(g), ptr(xi), ptr(w_t), ptr(off), off_bs, ptr(msk), msk_bs, ptr(col), ptr(dx32), ptr(dxi),
-         ws_flags, ptr(grad_offset), ptr(grad_mask), ptr(gw), ptr(gb), N, H, W, C, Co, kh, kw, stride, padding, dilation, Ho,
-         Wo)
+    call("mr_dcn2_bwd3", dt, ptr(g), ptr(xi), ptr(w_t), ptr(off), off_bs, ptr(msk), msk_bs, ptr(col), ptr(dx32), ptr(dxi),
+         ws_flags, ptr(grad_offset), ptr(grad_mask), ptr(gw), ptr(gb), ptr(col_saved), N, H, W, C, Co, kh, kw, stride, padding,
+         dilation, Ho, Wo)
     grad_input = None
     if want_dx:
         if direct:

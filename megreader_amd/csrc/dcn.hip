@@ -19,11 +19,12 @@ bool dcn_fused_ok(int dtype, int H, int W, int C, int Co, int kh, int kw);
 long long dcn_fused_ws_bytes(int dtype, int N, int H, int W, int C, int Ho, int Wo, int taps);
 int dcn_fused_fwd(int dtype, const void* x, const void* w_n, const float* bias, const float* offset, const float* mask,
                   void* y, void* ws, const DcnGeom& g, int Co, hipStream_t stream);
-long long dcn_fused_fwd_ws_bytes(int N, int Ho, int Wo, int Co, int taps);
+long long dcn_fused_fwd_ws_bytes(int dtype, int C, int N, int Ho, int Wo, int Co, int taps);
+bool dcn_use_col_fwd(int dtype, int C);
 bool dcn_fused_dx_direct(int dtype, int N, int H, int W, int C, int taps);
 int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, const float* offset, const float* mask,
                   void* ws, float* dx32, void* dx_t, int flags, float* doffset, float* dmask, float* dw, float* dbias,
-                  const DcnGeom& g, int Co, hipStream_t stream);
+                  const DcnGeom& g, int Co, const void* col_saved, hipStream_t stream);
 
 // col[p, tap*C + c] = valid ? mask * bilinear(x[n,:,:,c], p_tap) : 0     thread = (p, tap, 16-byte channel vector)
 template <typename T>
@@ -478,7 +479,7 @@ int mr_dcn2_col2im(int dtype, const void* gcol, const float* offset, long long o
 // fused path: nothing forward, the CSR of the scatter pattern backward; general path: the column matrix.
 long long mr_dcn2_ws_bytes(int dtype, int N, int H, int W, int C, int Co, int kh, int kw, int Ho, int Wo, int backward) {
   if (dcn_fused_ok(dtype, H, W, C, Co, kh, kw))
-    return backward ? dcn_fused_ws_bytes(dtype, N, H, W, C, Ho, Wo, kh * kw) : dcn_fused_fwd_ws_bytes(N, Ho, Wo, Co, kh * kw);
+    return backward ? dcn_fused_ws_bytes(dtype, N, H, W, C, Ho, Wo, kh * kw) : dcn_fused_fwd_ws_bytes(dtype, C, N, Ho, Wo, Co, kh * kw);
   return (long long)N * Ho * Wo * kh * kw * C * (dtype == MR_F32 ? 4 : 2);
 }
 
@@ -531,11 +532,28 @@ int mr_dcn2_bwd2(int dtype, const void* dy, const void* x, const void* w_t, cons
                  const float* mask, long long msk_bs, void* col_ws, float* dx32, void* dx_t, int flags, float* doffset,
                  float* dmask, float* dw, float* dbias, int N, int H, int W, int C, int Co, int kh, int kw, int stride, int pad,
                  int dil, int Ho, int Wo, hipStream_t stream) {
+  return mr_dcn2_bwd3(dtype, dy, x, w_t, offset, off_bs, mask, msk_bs, col_ws, dx32, dx_t, flags, doffset, dmask, dw, dbias, nullptr,
+                      N, H, W, C, Co, kh, kw, stride, pad, dil, Ho, Wo, stream);
+}
+
+// host only: 1 when mr_dcn2_fwd leaves the sampled column matrix [N*Ho*Wo, kh*kw*C] of this layer in its col_ws (bf16 shapes of the
+// materialised path under mr_tuning.dcn_col_fwd): a caller that keeps that buffer alive hands it to mr_dcn2_bwd3 as col_saved
+int mr_dcn2_col_saved(int dtype, int H, int W, int C, int Co, int kh, int kw) {
+  return (dcn_fused_ok(dtype, H, W, C, Co, kh, kw) && dcn_use_col_fwd(dtype, C)) ? 1 : 0;
+}
+
+// mr_dcn2_bwd2 + col_saved (nullable): the column matrix the forward wrote (mr_dcn2_col_saved) -- the weight gradient then runs
+// straight off it instead of sampling x again (round 6).  Ignored by the general path and by float32.
+int mr_dcn2_bwd3(int dtype, const void* dy, const void* x, const void* w_t, const float* offset, long long off_bs,
+                 const float* mask, long long msk_bs, void* col_ws, float* dx32, void* dx_t, int flags, float* doffset,
+                 float* dmask, float* dw, float* dbias, const void* col_saved, int N, int H, int W, int C, int Co, int kh, int kw,
+                 int stride, int pad, int dil, int Ho, int Wo, hipStream_t stream) {
   if (dcn_fused_ok(dtype, H, W, C, Co, kh, kw)) {
     DcnGeom g;
     int rcg = make_geom(g, N, H, W, C, kh, kw, stride, pad, dil, Ho, Wo, off_bs, msk_bs);
     if (rcg) return rcg;
-    return dcn_fused_bwd(dtype, dy, x, w_t, offset, mask, col_ws, dx32, dx_t, flags, doffset, dmask, dw, dbias, g, Co, stream);
+    return dcn_fused_bwd(dtype, dy, x, w_t, offset, mask, col_ws, dx32, dx_t, flags, doffset, dmask, dw, dbias, g, Co,
+                         dcn_use_col_fwd(dtype, C) ? col_saved : nullptr, stream);
   }
   MR_CHECK_ARG(dx_t == nullptr, "mr_dcn2_bwd2: dx_t needs the fused path (mr_dcn2_dx_direct)");
   MR_CHECK_ARG(col_ws != nullptr, "mr_dcn2_bwd: workspace missing (mr_dcn2_ws_bytes)");

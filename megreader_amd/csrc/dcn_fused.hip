@@ -696,6 +696,10 @@ __global__ __launch_bounds__(256) void dcn2_dx_gcol_kernel(DcnFusedArgs a, const
 bool dcn_use_gcol(int dtype, int C) {
   return dtype == MR_BF16 && g_dcn_gcol && (C == 64 || C == 128 || C == 256 || C == 512);
 }
+#define g_dcn_col_fwd MR_TUNE(dcn_col_fwd)
+// forward through the column matrix too (bf16, gcol shapes): col is written ONCE by the forward into the caller's col_ws and the
+// backward's weight gradient reads it there instead of sampling it again (mr_dcn2_bwd3: col_saved)
+bool dcn_use_col_fwd(int dtype, int C) { return dcn_use_gcol(dtype, C) && g_dcn_col_fwd; }
 
 // ------------------------------------------------------------------------------------------------ CSR of the scatter
 // key = tap * Q + q (q = input pixel index over the whole batch; tap-major, so that the neighbouring pixels a wave handles
@@ -1112,6 +1116,21 @@ int dcn_fused_fwd(int dtype, const void* x, const void* w_n, const float* bias, 
   MR_CHECK_ARG(dcn_fits_32bit(dtype, (long long)g.N * g.H * g.W * g.C, (long long)a.P * Co, (long long)Co * g.kh * g.kw * g.C),
                "dcn (fused path): x / y / weights must each be smaller than 2 GiB (mr_tuning.dcn_fused = 0 selects the general "
                "kernels)");
+  if (dcn_use_col_fwd(dtype, g.C)) {
+    // col[P, taps*C] = sampled x (one bandwidth-bound pass), y = col * W on the tuned NT GEMM; col stays in the caller's buffer
+    // for the backward (the reference keeps `columns` only as scratch and samples again, deform_conv_cuda.cpp:641-658)
+    MR_CHECK_ARG(ws != nullptr, "dcn forward: column workspace missing (mr_dcn2_ws_bytes)");
+    const int K = g.kh * g.kw * g.C;
+    int rc;
+    {
+      PhaseScope ph(MR_PH_DCN_IM2COL, 2.0 * g.N * g.H * g.W * g.C + 2.0 * a.P * K + 12.0 * a.P * g.kh * g.kw, stream);
+      rc = mr_dcn2_im2col(dtype, x, offset, g.off_bs, mask, g.msk_bs, ws, g.N, g.H, g.W, g.C, g.kh, g.kw, g.stride, g.pad, g.dil,
+                          g.Ho, g.Wo, stream);
+    }
+    if (rc) return rc;
+    PhaseScope ph(MR_PH_DCN_FWD, 2.0 * a.P * Co * K, stream);
+    return mr_gemm_nt(dtype, ws, K, w_n, K, y, Co, bias, 0, a.P, Co, K, stream);
+  }
   const int tiles_m = cdiv(a.P, 64);
   const int bn = Co % 128 == 0 ? 128 : 64;
   PhaseScope ph_fwd(MR_PH_DCN_FWD, 2.0 * a.P * Co * g.kh * g.kw * g.C, stream);
@@ -1140,8 +1159,9 @@ int dcn_fused_fwd(int dtype, const void* x, const void* w_n, const float* bias, 
 }
 
 // forward workspace of the fused path: the f32 accumulator of the tap-split launch (small layers), else nothing
-long long dcn_fused_fwd_ws_bytes(int N, int Ho, int Wo, int Co, int taps) {
+long long dcn_fused_fwd_ws_bytes(int dtype, int C, int N, int Ho, int Wo, int Co, int taps) {
   const long long P = (long long)N * Ho * Wo;
+  if (dcn_use_col_fwd(dtype, C)) return P * taps * C * 2;
   const int bn = Co % 128 == 0 ? 128 : 64;
   const int tsplit = dcn_tap_split(((P + 63) / 64) * (Co / bn), taps);
   return tsplit > 1 ? P * Co * 4 * tsplit : 0;
@@ -1164,7 +1184,7 @@ bool dcn_fused_dx_direct(int dtype, int N, int H, int W, int C, int taps) {
 // zero (a workspace that only this function has used since it was zeroed: the fill pass returns every counter to zero).
 int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, const float* offset, const float* mask,
                   void* ws, float* dx32, void* dx_t, int flags, float* doffset, float* dmask, float* dw, float* dbias,
-                  const DcnGeom& g, int Co, hipStream_t stream) {
+                  const DcnGeom& g, int Co, const void* col_saved, hipStream_t stream) {
   const int taps = g.kh * g.kw;
   const long long Q = (long long)g.N * g.H * g.W, P = (long long)g.N * g.Ho * g.Wo;
   MR_CHECK_ARG(Q * taps < (1ll << 31) - SCAN_BLOCK && P * taps * 4 < (1ll << 31) && Q * g.C < (1ll << 31),
@@ -1270,6 +1290,10 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
     // kernel below samples every B tile again per 128-row output tile and reduces its pixel splits with f32 atomics
     // (237 us per layer at batch 16 against ~110 us for the two launches here).
     DcnWs w = dcn_ws_layout(ws, Q, P, taps, dcn_gcol_bytes(dtype, g.C, P, taps));
+    if (col_saved != nullptr) {          // the forward's column matrix is still there (mr_dcn2_bwd3)
+      PhaseScope ph(MR_PH_DCN_WGRAD, gemm_flops, stream);
+      return mr_gemm_tn(dtype, dy, Co, col_saved, taps * g.C, dw, taps * g.C, (int)P, Co, taps * g.C, 0, dbias, stream);
+    }
     int rc;
     {
       PhaseScope ph(MR_PH_DCN_IM2COL, es * Q * g.C + 2.0 * P * taps * g.C + 12.0 * P * taps, stream);

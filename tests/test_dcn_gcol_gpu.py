@@ -37,8 +37,8 @@ def test_gcol_backward_vs_fused_kernels_and_oracle(layer):
     w = (torch.randn(Co, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5)
     gy = torch.randn(N, Co, Ho, Wo, generator=g).bfloat16()
 
-    def run(gcol):
-        old = _lib.set_tuning(dcn_gcol=gcol)
+    def run(gcol, col_fwd=1):
+        old = _lib.set_tuning(dcn_gcol=gcol, dcn_col_fwd=col_fwd)
         try:
             xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
             offd, mskd = off.to(DEV).requires_grad_(True), msk.to(DEV).requires_grad_(True)
@@ -51,6 +51,8 @@ def test_gcol_backward_vs_fused_kernels_and_oracle(layer):
             _lib.set_tuning(**old)
 
     new, new2, old = run(1), run(1), run(0)
+    resampled = run(1, 0)        # the backward samples the column matrix again instead of reading the forward's: the same matrix
+    assert _rel(new[3], resampled[3]) < 1e-3
     # the coordinate pass has one writer per element and a fixed summation order: the same bits every run.  (dx sums each CSR list in
     # the order the fill pass happened to claim its slots -- f32 rounding differs run to run, as in the reference's atomic col2im,
     # quirk Q12; dW still uses f32 atomics.)

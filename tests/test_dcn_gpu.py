@@ -358,8 +358,10 @@ def test_fused_path_equals_general_path(dtype, case):
     fused = C % 64 == 0 and Co % 64 == 0          # (case 4 has Co = 32: it stays on the general path, both runs equal)
     col_bytes = N * Ho * Wo * 9 * C * (2 if dtype == torch.bfloat16 else 4)       # what the general path's forward needs
     ws = lib.mr_dcn2_ws_bytes(1 if dtype == torch.bfloat16 else 0, N, H, W, C, Co, 3, 3, Ho, Wo, 0)
-    # fused: nothing, or the nine tap groups' f32 slabs of a small layer (which may happen to equal col_bytes: C = 2 Co in bf16)
-    assert ws in (0, 9 * N * Ho * Wo * Co * 4) if fused else ws == col_bytes
+    # fused: nothing, or the nine tap groups' f32 slabs of a small layer (which may happen to equal col_bytes: C = 2 Co in bf16);
+    # round 6: the bf16 materialised path (C in {64, 128, 256, 512}) writes the column matrix in the forward and keeps it
+    col_fwd = fused and bool(lib.mr_dcn2_col_saved(1 if dtype == torch.bfloat16 else 0, H, W, C, Co, 3, 3))
+    assert (ws == col_bytes if col_fwd else ws in (0, 9 * N * Ho * Wo * Co * 4)) if fused else ws == col_bytes
     got = run()
     old = lib.mr_set_dcn_fused(0)
     try:

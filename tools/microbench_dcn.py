@@ -73,8 +73,11 @@ def main():
         msk = torch.rand(N, k * k, Ho, Wo, device="cuda", generator=g)
         y = torch.empty(N, Ho, Wo, Co, device="cuda", dtype=dtype)
         lib = load()
-        nbytes = max(lib.mr_dcn2_ws_bytes(dt, N, H, W, C, Co, k, k, Ho, Wo, 0), lib.mr_dcn2_ws_bytes(dt, N, H, W, C, Co, k, k, Ho, Wo, 1), 16)
-        col = torch.empty(nbytes, dtype=torch.uint8, device="cuda")      # one workspace for both directions
+        # forward column workspace (kept for the backward's weight gradient where the library says so, mr_dcn2_col_saved) and the
+        # backward workspace (CSR + gcol), as megreader_amd/assets/ops/dcn/deform_conv.py allocates them
+        colf = torch.empty(max(lib.mr_dcn2_ws_bytes(dt, N, H, W, C, Co, k, k, Ho, Wo, 0), 16), dtype=torch.uint8, device="cuda")
+        col = torch.zeros(max(lib.mr_dcn2_ws_bytes(dt, N, H, W, C, Co, k, k, Ho, Wo, 1), 16), dtype=torch.uint8, device="cuda")
+        col_saved = ptr(colf) if (a.fused and lib.mr_dcn2_col_saved(dt, H, W, C, Co, k, k)) else 0
         gy = torch.randn(N, Ho, Wo, Co, device="cuda", generator=g).to(dtype)
         dx32 = torch.zeros(N, H, W, C, device="cuda")
         doff, dmsk = torch.zeros_like(off), torch.zeros_like(msk)
@@ -82,11 +85,11 @@ def main():
 
         def fwd():
             call("mr_dcn2_fwd", dt, ptr(x), ptr(w_n), 0, ptr(off), off[0].numel(), ptr(msk), msk[0].numel(), ptr(y),
-                 ptr(col), N, H, W, C, Co, k, k, s, pad, 1, Ho, Wo)
+                 ptr(colf), N, H, W, C, Co, k, k, s, pad, 1, Ho, Wo)
 
         def bwd():
-            call("mr_dcn2_bwd", dt, ptr(gy), ptr(x), ptr(w_t), ptr(off), off[0].numel(), ptr(msk), msk[0].numel(),
-                 ptr(col), ptr(dx32), ptr(doff), ptr(dmsk), ptr(gw), 0, N, H, W, C, Co, k, k, s, pad, 1, Ho, Wo)
+            call("mr_dcn2_bwd3", dt, ptr(gy), ptr(x), ptr(w_t), ptr(off), off[0].numel(), ptr(msk), msk[0].numel(),
+                 ptr(col), ptr(dx32), 0, 0, ptr(doff), ptr(dmsk), ptr(gw), 0, col_saved, N, H, W, C, Co, k, k, s, pad, 1, Ho, Wo)
 
         tf, tb = timeit(fwd, a.iters), timeit(bwd, a.iters)
         P = N * Ho * Wo
