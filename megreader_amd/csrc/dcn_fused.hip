@@ -606,7 +606,8 @@ __global__ __launch_bounds__(256) void dcn2_dx_fused_kernel(DcnFusedArgs a) {
 //                            sum_e w_e * gcol[p_e, tap, :] in f32 -- the reference's col2im inverted (no atomics, same bits every run).
 // float32 keeps the fused kernels (their f32 accumulators are what the 2e-4 parity bars against the reference extension need).
 template <int L>   // lanes per item = C / 8
-__global__ __launch_bounds__(256) void dcn2_coord_gcol_kernel(DcnFusedArgs a, const bf16_t* __restrict__ gcol) {
+__global__ __launch_bounds__(256) void dcn2_coord_gcol_kernel(DcnFusedArgs a, const bf16_t* __restrict__ gcol,
+                                                               int* __restrict__ count) {
   const DcnGeom& g = a.g;
   const int taps = g.kh * g.kw, C = L * 8;
   const long long item = (long long)blockIdx.x * (256 / L) + threadIdx.x / L;
@@ -620,6 +621,15 @@ __global__ __launch_bounds__(256) void dcn2_coord_gcol_kernel(DcnFusedArgs a, co
   const DcnDesc d = dcn_desc(g, a.offset, a.mask, n, tap, ho, wo);
   const bf16_t* __restrict__ X = (const bf16_t*)a.x;
   float S[4] = {0.f, 0.f, 0.f, 0.f};
+  if (count != nullptr && live && d.hl != -2 && sub < 4) {
+    // first pass of the CSR build rides here (the descriptor is already in registers): lane k counts corner k, exactly as
+    // dcn_csr_kernel<false> does -- one launch less per layer in front of the scan
+    const int k = sub;
+    const int h = d.hl + (k >> 1), w = d.wl + (k & 1);
+    const float wk = ((k >> 1) ? d.lh : 1.f - d.lh) * ((k & 1) ? d.lw : 1.f - d.lw) * d.m;
+    if (dcn_inside(g, h, w) && wk != 0.f)
+      atomicAdd(count + (long long)tap * ((long long)g.N * g.H * g.W) + ((n * g.H + h) * g.W + w), 1);
+  }
   if (live && d.hl != -2) {
     const uint4 gv = *(const uint4*)(gcol + it * C + sub * 8);
     const bf16_t* gp = (const bf16_t*)&gv;
@@ -1209,14 +1219,14 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
     const int rc = mr_gemm_nt(MR_BF16, dy, Co, w_t, Co, w.gcol, taps * g.C, nullptr, 0, (int)P, taps * g.C, Co, stream);
     if (rc) return rc;
   }
-#define MR_DCN_GCOL_LAUNCH(KERN, ITEMS)                                                                                   \
+#define MR_DCN_GCOL_LAUNCH(KERN, ITEMS, ...)                                                                              \
   {                                                                                                                      \
     const int L_ = g.C / 8;                                                                                              \
     const unsigned nb_ = (unsigned)cdivll((long long)(ITEMS), 256 / L_);                                                 \
-    if (L_ == 8) hipLaunchKernelGGL((KERN<8>), dim3(nb_), dim3(256), 0, stream, a, gcol);                                \
-    else if (L_ == 16) hipLaunchKernelGGL((KERN<16>), dim3(nb_), dim3(256), 0, stream, a, gcol);                         \
-    else if (L_ == 32) hipLaunchKernelGGL((KERN<32>), dim3(nb_), dim3(256), 0, stream, a, gcol);                         \
-    else hipLaunchKernelGGL((KERN<64>), dim3(nb_), dim3(256), 0, stream, a, gcol);                                       \
+    if (L_ == 8) hipLaunchKernelGGL((KERN<8>), dim3(nb_), dim3(256), 0, stream, a, gcol, ##__VA_ARGS__);                 \
+    else if (L_ == 16) hipLaunchKernelGGL((KERN<16>), dim3(nb_), dim3(256), 0, stream, a, gcol, ##__VA_ARGS__);          \
+    else if (L_ == 32) hipLaunchKernelGGL((KERN<32>), dim3(nb_), dim3(256), 0, stream, a, gcol, ##__VA_ARGS__);          \
+    else hipLaunchKernelGGL((KERN<64>), dim3(nb_), dim3(256), 0, stream, a, gcol, ##__VA_ARGS__);                        \
     MR_CHECK_LAUNCH();                                                                                                   \
   }
   // The three parts below are independent of each other (each reads dy / x / w / offset / mask and writes its own outputs):
@@ -1224,10 +1234,21 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
   // ---- offset / mask gradients (gcol tiles stay in registers)
   const double es = dtype == MR_F32 ? 4.0 : 2.0;
   const double gemm_flops = 2.0 * P * Co * taps * g.C;
+  bool counted = false;      // the CSR's counting pass already ran (inside the coordinate pass)
   if (doffset && dmask && use_gcol) {
     // algorithmic bytes: gcol + x once, offsets / mask read, their three gradients read-modify-written
     PhaseScope ph(MR_PH_DCN_COORD, 2.0 * P * taps * g.C + es * Q * g.C + 9.0 * 4 * 3 * P * taps, stream);
-    MR_DCN_GCOL_LAUNCH(dcn2_coord_gcol_kernel, P * taps)
+    int* count_here = nullptr;
+    if (dx32 || dx_t) {      // the CSR build follows: its counting pass rides in this launch (the counters must be zero NOW)
+      DcnWs w = dcn_ws_layout(ws, Q, P, taps, dcn_gcol_bytes(dtype, g.C, P, taps));
+      if (!(flags & 1) && hipMemsetAsync(w.count, 0, (size_t)w.nkeys * 4, stream) != hipSuccess) {
+        mr::set_error("dcn backward: hipMemsetAsync failed");
+        return MR_ERR_LAUNCH;
+      }
+      count_here = w.count;
+      counted = true;
+    }
+    MR_DCN_GCOL_LAUNCH(dcn2_coord_gcol_kernel, P * taps, count_here)
   } else if (doffset && dmask) {
     PhaseScope ph(MR_PH_DCN_COORD, gemm_flops, stream);
     if (g.C % 128 == 0) {
@@ -1243,7 +1264,7 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
   if (dx32 || dx_t) {
     MR_CHECK_ARG(ws != nullptr, "dcn backward: workspace missing (mr_dcn2_ws_bytes)");
     DcnWs w = dcn_ws_layout(ws, Q, P, taps, dcn_gcol_bytes(dtype, g.C, P, taps));
-    if (!(flags & 1) && hipMemsetAsync(w.count, 0, (size_t)w.nkeys * 4, stream) != hipSuccess) {
+    if (!counted && !(flags & 1) && hipMemsetAsync(w.count, 0, (size_t)w.nkeys * 4, stream) != hipSuccess) {
       mr::set_error("dcn backward: hipMemsetAsync failed");
       return MR_ERR_LAUNCH;
     }
@@ -1251,8 +1272,9 @@ int dcn_fused_bwd(int dtype, const void* dy, const void* x, const void* w_t, con
     {
     // bytes: offsets + mask twice, counters (atomics) twice, the scan over Q * taps keys, the entries
     PhaseScope ph(MR_PH_DCN_CSR, 2.0 * 12 * P * taps + 5.0 * 4 * Q * taps + 8.0 * 4 * P * taps, stream);
-    hipLaunchKernelGGL((dcn_csr_kernel<false>), dim3(items), dim3(256), 0, stream, offset, mask, w.count,
-                       (const int*)nullptr, (int2*)nullptr, g, (int)P);
+    if (!counted)
+      hipLaunchKernelGGL((dcn_csr_kernel<false>), dim3(items), dim3(256), 0, stream, offset, mask, w.count,
+                         (const int*)nullptr, (int2*)nullptr, g, (int)P);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(w.nblocks), dim3(256), 0, stream, (const int*)w.count, w.bsum, w.nkeys);
     hipLaunchKernelGGL(scan_write_kernel, dim3(w.nblocks), dim3(256), 0, stream, (const int*)w.count, (const int*)w.bsum,
                        w.start, w.nkeys);
