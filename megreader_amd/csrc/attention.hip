@@ -268,15 +268,22 @@ __global__ void embed_rows_bwd_kernel(const long long* __restrict__ idx, const T
 template <typename T> struct AttVec;
 template <> struct AttVec<bf16_t> {
   static constexpr int N = 8;
-  static __device__ __forceinline__ void load(const bf16_t* p, float* f) {
-    const uint4 v = *(const uint4*)p;
+  static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
     const bf16_t* q = (const bf16_t*)&v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = (float)q[j];
   }
+  static __device__ __forceinline__ void load(const bf16_t* p, float* f) {
+    const uint4 v = *(const uint4*)p;
+    unpack(v, f);
+  }
 };
 template <> struct AttVec<float> {
   static constexpr int N = 4;
+  static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
+    const float* q = (const float*)&v;
+    f[0] = q[0]; f[1] = q[1]; f[2] = q[2]; f[3] = q[3];
+  }
   static __device__ __forceinline__ void load(const float* p, float* f) {
     const f32x4 v = *(const f32x4*)p;
     f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
@@ -297,6 +304,89 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const T* __restrict__ hp
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T* hp = hproj + (long long)n * ldh;
   const bool vec_ok = (Hd % VEC == 0) && (Ep % VEC == 0) && (ldh % VEC == 0);
+  // Round 6 fast path (the published shape: Hd = 512 in bf16): the kernel is a chain of dependent memory round trips -- 8
+  // score iterations per wave, then up to 10 context iterations per thread, each behind its own global load (9.5 us per decode
+  // step for ~140 KB of L2-resident operands).  Here EVERY global load of the step is issued up front -- the eproj rows of the
+  // wave's positions and the enc rows of the thread's (position group, channel vector) pairs do not depend on the softmax -- so
+  // the step pays one round trip; same arithmetic in the same order.
+  constexpr int MAXC = 10;
+  if (vec_ok && Hd == 64 * VEC && Tn <= 64) {
+    const int nv = Ep / VEC;
+    const int groups = max(1, min(512 / nv, Tn));
+    if ((Tn + groups - 1) / groups <= MAXC) {
+      const int gidx = tid / nv, cv = tid - gidx * nv;
+      const bool ctx_thread = tid < groups * nv;
+      uint4 er[8], ev[MAXC];
+      const uint4 hv = *(const uint4*)(hp + lane * VEC);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int t = wave + 8 * i;
+        er[i] = t < Tn ? *(const uint4*)(eproj + ((long long)n * Tn + t) * Hd + lane * VEC) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int t = gidx + groups * i;
+        ev[i] = (ctx_thread && t < Tn) ? *(const uint4*)(enc + ((long long)n * Tn + t) * Ep + cv * VEC) : make_uint4(0, 0, 0, 0);
+      }
+      float vv[VEC], a[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC; q += 4) {
+        const f32x4 v0 = *(const f32x4*)(v + lane * VEC + q);
+        vv[q] = v0[0]; vv[q + 1] = v0[1]; vv[q + 2] = v0[2]; vv[q + 3] = v0[3];
+      }
+      AttVec<T>::unpack(hv, a);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int t = wave + 8 * i;
+        if (t < Tn) {                      // wave-uniform
+          float b[VEC];
+          AttVec<T>::unpack(er[i], b);
+          float s2 = 0.f;
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) s2 += vv[q] * tanhf(a[q] + b[q]);
+          s2 = wave_sum(s2);
+          if (lane == 0) en[t] = s2;
+        }
+      }
+      __syncthreads();
+      if (wave == 0) {
+        float e = lane < Tn ? en[lane] : -INFINITY;
+        const float mx = wave_max(e);
+        float ex = lane < Tn ? expf(e - mx) : 0.f;
+        const float sm = wave_sum(ex);
+        if (lane < Tn) {
+          en[lane] = ex / sm;
+          weights[(long long)n * Tn + lane] = ex / sm;
+        }
+      }
+      __syncthreads();
+      if (ctx_thread) {
+        float acc[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+          const int t = gidx + groups * i;
+          if (t < Tn) {
+            float f[VEC];
+            AttVec<T>::unpack(ev[i], f);
+            const float w = en[t];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[q] += w * f[q];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) part[gidx * Ep + cv * VEC + q] = acc[q];
+      }
+      __syncthreads();
+      for (int c = tid; c < Ep; c += 512) {
+        float s2 = 0.f;
+        for (int gi = 0; gi < groups; ++gi) s2 += part[gi * Ep + c];
+        context[(long long)n * Ep + c] = from_f32<T>(s2);
+      }
+      return;
+    }
+  }
   if (vec_ok) {
     for (int t = wave; t < Tn; t += 8) {
       const T* ep = eproj + ((long long)n * Tn + t) * Hd;
@@ -388,6 +478,86 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(const T* __restrict__ dc
   constexpr int VEC = AttVec<T>::N;
   __shared__ float dw[64], de[64], red[4][64], redv[4][64];
   const int n = blockIdx.x, js = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Round 6 fast path (as attn_fwd2_kernel): every global load of the step -- the dcontext / enc slices of the dw dot products
+  // and the eproj / deproj elements of this workgroup's 64-unit slice of the tanh chain -- is issued before anything is computed,
+  // so the launch pays one memory round trip instead of ~9 + 16 dependent ones; same arithmetic in the same order.
+  constexpr int MAXI = 9;
+  if (Ep % VEC == 0 && Ep / VEC <= 8 * MAXI && Tn <= 64) {
+    const int nv = Ep / VEC, part8 = tid & 7, tq = tid >> 3;
+    const int j = js * 64 + lane;
+    uint4 av[MAXI], b0[MAXI], b1[MAXI];
+    float epv[16], dpv[16];
+    const T* dr = dcontext + (long long)n * Ep;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const int cvi = part8 + 8 * i;
+      const bool okc = cvi < nv;
+      av[i] = okc ? *(const uint4*)(dr + cvi * VEC) : make_uint4(0, 0, 0, 0);
+      b0[i] = (okc && tq < Tn) ? *(const uint4*)(enc + ((long long)n * Tn + tq) * Ep + cvi * VEC) : make_uint4(0, 0, 0, 0);
+      b1[i] = (okc && tq + 32 < Tn) ? *(const uint4*)(enc + ((long long)n * Tn + tq + 32) * Ep + cvi * VEC) : make_uint4(0, 0, 0, 0);
+    }
+    float hj = 0.f, vj = 0.f;
+    if (j < Hd) {
+      hj = to_f32(hproj[(long long)n * ldh + j]);
+      vj = v[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = wave + 4 * i;
+      const long long o = ((long long)n * Tn + t) * Hd + j;
+      const bool ok = j < Hd && t < Tn;
+      epv[i] = ok ? to_f32(eproj[o]) : 0.f;
+      dpv[i] = ok ? deproj[o] : 0.f;
+    }
+    const float w_l = lane < Tn ? weights[(long long)n * Tn + lane] : 0.f;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      float a[VEC], b[VEC];
+      AttVec<T>::unpack(av[i], a);
+      AttVec<T>::unpack(b0[i], b);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) s0 += a[q] * b[q];
+      AttVec<T>::unpack(b1[i], b);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) s1 += a[q] * b[q];
+    }
+    s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64); s0 += __shfl_xor(s0, 4, 64);
+    s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
+    if (part8 == 0) {
+      if (tq < Tn) dw[tq] = s0 + (dweights ? dweights[(long long)n * ldw + tq] : 0.f);
+      if (tq + 32 < Tn) dw[tq + 32] = s1 + (dweights ? dweights[(long long)n * ldw + tq + 32] : 0.f);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const float d = lane < Tn ? dw[lane] : 0.f;
+      const float dot = wave_sum(w_l * d);
+      if (lane < Tn) de[lane] = w_l * (d - dot);
+    }
+    __syncthreads();
+    float dh = 0.f, dvj = 0.f;
+    if (j < Hd) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int t = wave + 4 * i;
+        if (t < Tn) {
+          const float th = tanhf(hj + epv[i]);
+          const float gg = de[t] * vj * (1.f - th * th);
+          dh += gg;
+          deproj[((long long)n * Tn + t) * Hd + j] = dpv[i] + gg;
+          dvj += de[t] * th;
+        }
+      }
+    }
+    red[wave][lane] = dh;
+    redv[wave][lane] = dvj;
+    __syncthreads();
+    if (wave == 0 && j < Hd) {
+      dhproj[(long long)n * lddh + j] = from_f32<T>(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+      atomicAdd(dv + j, redv[0][lane] + redv[1][lane] + redv[2][lane] + redv[3][lane]);
+    }
+    return;
+  }
   if (Ep % VEC == 0) {
     for (int t0 = 0; t0 < Tn; t0 += 32) {
       const int t = t0 + (tid >> 3), part8 = tid & 7;

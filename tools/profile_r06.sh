@@ -24,6 +24,12 @@ trace res50ppm adam_kernel --workload res50ppm
 trace fpn_attention adam_kernel --workload fpn_attention
 trace fpn_attention_random_coins adam_kernel --workload fpn_attention --teacher-forcing random
 trace db sgd_kernel --workload db
+# the configuration every rank runs when WORLD_SIZE > 1 (one-pass BatchNorm backward off), at the 8-GPU strong-scaling shard and
+# at configs[3]'s per-GPU batch: the kernel statistics DESIGN.md section 7 bases its 8-GPU model on
+export MEGREADER_TUNING=bn_onepass=0
+trace crnn_b32_world_gt1 adam_kernel --workload crnn --batch 32
+trace fpn_attention_world_gt1 adam_kernel --workload fpn_attention
+unset MEGREADER_TUNING
 if [ "$1" != "quick" ]; then
 pmc() {   # json name, bench args...
   local w=$1; shift
@@ -43,3 +49,22 @@ pmc db --workload db
 pmc res50ppm_64x256 --workload res50ppm --crop 64x256
 fi
 echo done
+# ---- extras of round 6: the configuration world > 1 actually runs (bn_onepass = 0), the multi-GPU code path on one rank, the
+# reference-precision line, the MFMA ceiling
+{
+echo "# bench.py, hipGraph replay, one MI355X: default vs MEGREADER_TUNING=bn_onepass=0 (what every rank runs when WORLD_SIZE > 1: the"
+echo "# one-pass BatchNorm backward is a resident-grid kernel and is refused beside collectives) -- per-GPU cost of that rule"
+B="--no-cpu-baseline --no-secondary --no-kernel-timer --steps 30 --warmup 5"
+for wl in "crnn" "crnn --batch 32" "res50ppm" "fpn_attention" "db"; do
+  for cfg in "bn_onepass=1" "bn_onepass=0"; do
+    ms=$(MEGREADER_TUNING=$cfg timeout 300 python bench.py --workload $wl $B 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1)
+    echo "$wl | $cfg | $ms"
+  done
+done
+} > $O/ab_world_gt1_configuration.txt 2>&1
+RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 timeout 300 python bench.py --force-ddp --ddp-mode capture --no-cpu-baseline --no-secondary --steps 20 --warmup 5 > $O/bench_force_ddp_capture.json 2> $O/bench_force_ddp_capture.err
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 20 --warmup 5 --no-secondary --no-cpu-baseline > $O/bench_torchrun_n1.json 2> $O/bench_torchrun_n1.err
+timeout 300 python bench.py --workload res50ppm --dtype f32 --no-secondary --steps 10 --warmup 3 > $O/bench_res50ppm_f32.json 2> $O/bench_res50ppm_f32.err
+tools/mfma_ceiling > $O/mfma_ceiling.txt 2>&1
+python bench.py > $O/bench_default_final.json 2> $O/bench_default_final.err
+echo extras done
