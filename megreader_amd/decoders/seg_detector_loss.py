@@ -133,7 +133,10 @@ class L1BalanceCELoss(nn.Module):
         self.bce_scale = bce_scale
 
     def forward(self, pred, batch):
-        if FUSED_DB_LOSS and _fused_ok(pred, batch):
+        # (the fused kernels use ONE eps for the balanced-BCE denominator and the Dice union: only when the two modules agree --
+        # the reference builds DiceLoss(eps=eps) from the constructor argument and BalanceCrossEntropyLoss() with its own default,
+        # decoders/seg_detector_loss.py:160-170; a non-default L1BalanceCELoss(eps=...) takes the unfused path -- ADVICE r5)
+        if FUSED_DB_LOSS and getattr(self.dice_loss, "eps", None) == self.bce_loss.eps and _fused_ok(pred, batch):
             r = _DBLossFn.apply(pred['binary'], pred['thresh'], pred['thresh_binary'], batch['gt'], batch['mask'],
                                 batch['thresh_map'], batch['thresh_mask'], self.bce_loss.negative_ratio, self.bce_loss.eps,
                                 self.l1_scale, self.bce_scale)

@@ -123,7 +123,7 @@ class _GraphedTrainStep(object):
             return self.original(trainer, model, optimizer, batch, epoch=epoch, step=step, **kwargs)
         sig = self._signature(batch)
         if self.state is not None and self.state[0] != sig:
-            return self.original(trainer, model, optimizer, batch, epoch=epoch, step=step, **kwargs)
+            return self._eager_other_signature(trainer, model, optimizer, batch, epoch, step, kwargs)
         if self.state is None:
             device = getattr(trainer, "device", torch.device("cuda"))
             static = {k: (v.to(device).clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
@@ -201,6 +201,25 @@ class _GraphedTrainStep(object):
             raise
         self.mode = "graph2"
         return graphed
+
+    def _eager_other_signature(self, trainer, model, optimizer, batch, epoch, step, kwargs):
+        """A batch whose shapes differ from the captured ones (the partial last batch of a DistributedSampler with drop_last=False,
+        data/data_loader.py:40-48) takes the reference's eager step.  In 'graph2' mode the data-parallel shim is SUSPENDED and the
+        1 / world factor lives in the optimizer (the captured step exchanges gradients between its two graphs): an eager step
+        would then update with LOCAL gradients scaled by 1 / world and the ranks would diverge silently.  For that one
+        step the shim is switched back on (its hooks all-reduce during backward) and the fold is undone; both are restored after."""
+        shim = getattr(model, "model", None)
+        if self.mode != "graph2" or shim is None or not getattr(shim, "suspended", False):
+            return self.original(trainer, model, optimizer, batch, epoch=epoch, step=step, **kwargs)
+        scale = getattr(optimizer, "_grad_scale", None)
+        shim.suspended = False
+        optimizer.set_grad_scale(1.0)
+        try:
+            return self.original(trainer, model, optimizer, batch, epoch=epoch, step=step, **kwargs)
+        finally:
+            shim.suspended = True
+            if scale is not None:
+                optimizer.set_grad_scale(scale)
 
     def _upload(self, batch, static):
         """Host batch -> the graph's static tensors without stalling the host: H2D into one of two staging sets on a copy
