@@ -124,7 +124,9 @@ typedef struct mr_tuning {
   int dcn_col_fwd;   /* round 6: 1 (default) = on the dcn_gcol shapes the bf16 forward also goes through the column matrix (one sampling
                         pass into the caller's col_ws + the tuned NT GEMM) and leaves it there for the backward's weight gradient
                         (mr_dcn2_col_saved / mr_dcn2_bwd3); 0 = the fused forward kernel, the backward samples again */
-  int reserved[4];   /* zero */
+  int decode_persist; /* round 6: 1 (default) = the teacher-forced attention-GRU decode loop runs its forward as ONE persistent launch
+                        (decode_persist.hip: bf16, H = 512, T <= 64, Ep <= 576; mr_decode_persist_ok); 0 = three launches per step */
+  int reserved[3];   /* zero */
 } mr_tuning;
 int mr_tuning_get(mr_tuning* out);
 int mr_tuning_defaults(mr_tuning* out);
@@ -623,6 +625,23 @@ int mr_gru_bwd2(int dtype, const void* dh_a, const void* dh_b, const void* dh_c,
                 hipStream_t stream);
 int mr_rows_scatter_add(int dtype, const long long* idx, const void* rows, long long ldr, float* dtable, int R, int V,
                         int D, hipStream_t stream);
+
+/* Persistent forward of the teacher-forced attention-GRU decode loop (reference decoders/attention_decoder.py:84-118 around
+ * AttentionRNNCell :146-231): all S steps in ONE launch of ceil(N/16) x 32 co-resident workgroups; the stacked hidden projection
+ * [4H][H] (attention hidden half + W_hh), the context columns of W_ih and the encoder rows stay in registers / LDS for the whole
+ * sequence and the three per-step hand-offs (partial energies -> owners, contexts, h') go through tagged 8-byte granules
+ * (decode_persist.hip).  bf16 only, H = 512.  cat_w [4H][H], cat_b [4H] f32 (nullable), ic_w [3H][ldic], G = word table
+ * [classes][ldG >= 3H] gathered by idx [S][N] (the word fed to each step), eproj [N][T][H], enc [N][T][Ep], v [H] f32.
+ * Writes what the per-step path (mr_gemm_nt + mr_attn_fwd2 + mr_gemm_gru_fwd) saves for the backward: H_all [S+1][N][H]
+ * (H_all[0] = the initial state, read), HC_all [S][N][4H], W_att [S][N][T] f32, CTX_all [S][N][Ep], SAVE_all [S][N][3H] f32.
+ * ws: exchange workspace of mr_decode_persist_ws_bytes(N) bytes, zeroed by the call (ws_bytes > 0) or by the caller (pass the
+ * size NEGATIVE).  A hand-off that times out records a code in the status word behind the workspace and poisons h' with NaN. */
+int mr_decode_persist_ok(int dtype, int N, int T, int H, int Ep);   /* host only; 0 also when mr_tuning.decode_persist = 0 */
+long long mr_decode_persist_ws_bytes(int N);                        /* host only */
+int mr_decode_persist_fwd(const void* cat_w, const float* cat_b, const void* ic_w, long long ldic, const void* G, long long ldG,
+                          const long long* idx, const void* eproj, const void* enc, const float* v, void* H_all, void* HC_all,
+                          float* W_att, void* CTX_all, float* SAVE_all, void* ws, long long ws_bytes, int S, int N, int T,
+                          int Ep, hipStream_t stream);
 
 /* ---- Round-4 decode-step fusions (csrc/gemm_skinny.hip): the element-wise GRU kernels in the epilogue of the M <= 32 GEMM next
  *      to them, the output layer + log-softmax + NLL + arg-max feedback as one kernel.  Same reference lines as above

@@ -106,6 +106,7 @@ SIGNATURES = {
     "mr_scatter_strided": "ippiiiiiiiis",
     "mr_gemm_gru_fwd": "iplplplpplpppiiis",
     "mr_gemm_gru_bwd": "iplplpppplppplpiiis",
+    "mr_decode_persist_fwd": "ppp" + "l" + "p" + "l" + "p" * 10 + "l" + "iiii" + "s",
     "mr_out_nll_fwd": "iplplpplpppppp" + "iiiis",
     "mr_nll_step_fwd": "ipiplppppiiiis",
     "mr_nll_step_feed_fwd": "ipiplpppppp" + "iiis",
@@ -129,12 +130,12 @@ _lib = None
 
 TUNING_FIELDS = ("nt_variant", "nt_deep", "nt_big", "nt_p8", "nt_force_bm", "nt_force_bn", "gemm_skinny", "tn_big", "tn_buf",
                  "tn_taps", "tn_taps_group", "tn_group", "tn_fin", "tn_taps_fin", "tn_taps_w8", "tn_model", "tn_splits",
-                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth", "nt_big_min_k", "tn_taps_min_p", "tn_defer", "pool_fixed", "ctc_linear", "nt_wide8", "nt_ksplit", "nt_m32", "nt_m32_opt", "dcn_gcol", "dcn_col_fwd")
+                 "bn_fused", "lstm_persist", "lstm_fwd_bn", "lstm_bwd_bn", "dcn_fused", "dcn_v1_bwd", "bn_onepass", "skinny_depth", "nt_big_min_k", "tn_taps_min_p", "tn_defer", "pool_fixed", "ctc_linear", "nt_wide8", "nt_ksplit", "nt_m32", "nt_m32_opt", "dcn_gcol", "dcn_col_fwd", "decode_persist")
 
 
 class Tuning(ctypes.Structure):
     """struct mr_tuning (include/megreader_hip.h): the library's only process-wide switches."""
-    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 4)]
+    _fields_ = [(name, ctypes.c_int) for name in TUNING_FIELDS] + [("reserved", ctypes.c_int * 3)]
 
 
 def get_tuning():
@@ -269,6 +270,10 @@ def load():
     lib.mr_lstm_debug_buffer.argtypes = [ctypes.c_void_p]
     lib.mr_lstm_ws_bytes.restype = ctypes.c_longlong
     lib.mr_lstm_ws_bytes.argtypes = [ctypes.c_int] * 4
+    lib.mr_decode_persist_ok.restype = ctypes.c_int
+    lib.mr_decode_persist_ok.argtypes = [ctypes.c_int] * 5
+    lib.mr_decode_persist_ws_bytes.restype = ctypes.c_longlong
+    lib.mr_decode_persist_ws_bytes.argtypes = [ctypes.c_int]
     lib.mr_sizeof_img_desc.restype = ctypes.c_int
     lib.mr_sizeof_img_desc.argtypes = []
     lib.mr_tn_defer.restype = ctypes.c_int

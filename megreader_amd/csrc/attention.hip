@@ -12,6 +12,14 @@
 
 namespace mr {
 
+// tanh of the attention energies: 1 - 2 / (1 + 2^(x * 2/ln 2)) on the hardware exp2 / rcp units (absolute error ~2e-7; exact
+// limits +-1 at +-inf).  The library tanhf is ~40 VALU instructions and a decode step evaluates T*Hd = 32768 of them per sample
+// on ONE workgroup: round 6 measured attn_fwd2_kernel as bound by exactly that (prefetching every global load of the step
+// changed nothing; profiles/r06_attention_tanh.txt), so both directions share this form.
+__device__ __forceinline__ float att_tanh(float x) {
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.885390081777927f));
+}
+
 // ---------------------------------------------------------------- attention step
 template <typename T>
 __global__ __launch_bounds__(256) void attn_step_fwd_kernel(const T* __restrict__ hproj, const T* __restrict__ eproj,
@@ -24,7 +32,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_kernel(const T* __restrict_
   for (int t = wave; t < Tn; t += 4) {
     const T* ep = eproj + ((long long)n * Tn + t) * Hd;
     float s = 0.f;
-    for (int j = lane; j < Hd; j += 64) s += v[j] * tanhf(to_f32(hp[j]) + to_f32(ep[j]));
+    for (int j = lane; j < Hd; j += 64) s += v[j] * att_tanh(to_f32(hp[j]) + to_f32(ep[j]));
     s = wave_sum(s);
     if (lane == 0) en[t] = s;
   }
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(const T* __restrict_
     float dh = 0.f, dvj = 0.f;
     for (int t = 0; t < Tn; ++t) {
       const long long o = ((long long)n * Tn + t) * Hd + j;
-      const float th = tanhf(hj + to_f32(eproj[o]));
+      const float th = att_tanh(hj + to_f32(eproj[o]));
       const float g = de[t] * vj * (1.f - th * th);
       dh += g;
       deproj[o] += g;
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const T* __restrict__ hp
           AttVec<T>::unpack(er[i], b);
           float s2 = 0.f;
 #pragma unroll
-          for (int q = 0; q < VEC; ++q) s2 += vv[q] * tanhf(a[q] + b[q]);
+          for (int q = 0; q < VEC; ++q) s2 += vv[q] * att_tanh(a[q] + b[q]);
           s2 = wave_sum(s2);
           if (lane == 0) en[t] = s2;
         }
@@ -397,11 +405,11 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const T* __restrict__ hp
         AttVec<T>::load(ep + j, b);
         const f32x4 v0 = *(const f32x4*)(v + j);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s += v0[q] * tanhf(a[q] + b[q]);
+        for (int q = 0; q < 4; ++q) s += v0[q] * att_tanh(a[q] + b[q]);
         if (VEC == 8) {
           const f32x4 v1 = *(const f32x4*)(v + j + 4);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) s += v1[q] * tanhf(a[4 + q] + b[4 + q]);
+          for (int q = 0; q < 4; ++q) s += v1[q] * att_tanh(a[4 + q] + b[4 + q]);
         }
       }
       s = wave_sum(s);
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const T* __restrict__ hp
     for (int t = wave; t < Tn; t += 8) {
       const T* ep = eproj + ((long long)n * Tn + t) * Hd;
       float s = 0.f;
-      for (int j = lane; j < Hd; j += 64) s += v[j] * tanhf(to_f32(hp[j]) + to_f32(ep[j]));
+      for (int j = lane; j < Hd; j += 64) s += v[j] * att_tanh(to_f32(hp[j]) + to_f32(ep[j]));
       s = wave_sum(s);
       if (lane == 0) en[t] = s;
     }
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(const T* __restrict__ dc
       for (int i = 0; i < 16; ++i) {
         const int t = wave + 4 * i;
         if (t < Tn) {
-          const float th = tanhf(hj + epv[i]);
+          const float th = att_tanh(hj + epv[i]);
           const float gg = de[t] * vj * (1.f - th * th);
           dh += gg;
           deproj[((long long)n * Tn + t) * Hd + j] = dpv[i] + gg;
@@ -603,7 +611,7 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(const T* __restrict__ dc
     const float vj = v[j];
     for (int t = wave; t < Tn; t += 4) {
       const long long o = ((long long)n * Tn + t) * Hd + j;
-      const float th = tanhf(hj + to_f32(eproj[o]));
+      const float th = att_tanh(hj + to_f32(eproj[o]));
       const float gg = de[t] * vj * (1.f - th * th);
       dh += gg;
       deproj[o] += gg;

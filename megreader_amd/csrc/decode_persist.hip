@@ -1,0 +1,560 @@
+// Persistent forward of the Bahdanau-attention GRU decode loop for gfx950: ONE launch for all S steps instead of three dependent
+// launches per step (reference: the python loop of decoders/attention_decoder.py:84-118 around AttentionRNNCell, :146-231).
+//
+// Why: a teacher-forced step at the published shape (N = 16 samples, T = 64 positions, H = 512, Ep = 552) is
+//   [h W_cat^T]  ->  [energies / softmax / context]  ->  [context W_ic^T + GRU cell]
+// = 4.2 + 6.8 + 7.3 us of launch-latency-sized kernels plus the gaps between them (18.5 us per step replayed from a graph), 32
+// times, on 16-32 of 256 CUs, each launch re-reading its weights (2 MB + 1.7 MB) from L2.
+//
+// Decomposition (bf16, H = 512).  Samples are independent through the recurrence, hidden units are not:
+//   * the batch is cut into groups of R rows (R = 4, 8 or 16: the smallest that keeps the grid within half the chip -- the bytes
+//     a workgroup gathers per hand-off scale with R); groups never talk to each other;
+//   * a group is 32 workgroups ("slices"); slice g owns the hidden units [16g, 16g+16): their column of the attention hidden
+//     projection, their r / z / n rows of W_hh (4 x 16 rows of W_cat, one MFMA tile per wave) and of W_ic (3 tiles).  All of it
+//     -- 64 + 54 KB -- is loaded ONCE into the waves' VGPRs and stays there for all S steps; the slice's 16 columns of eproj
+//     stay in LDS;
+//   * slice g also serves sample g / (32/R) of the group: it holds a 1/(32/R) share of that sample's encoder channels in LDS.
+// One step = three all-to-all hand-offs inside the group:
+//   1. slice g computes hproj / gh of its units (MFMA, h from LDS) and, for every (sample, position), the PARTIAL energy
+//      sum_{j in own units} v_j tanh(hproj_j + eproj_j); every slice REDUCES the partials of its sample over the 32 producers
+//      (16 KB of granules in), softmax, and the context of its channel share = sum_t w_t enc_t from LDS;
+//   2. the R contexts are ALL-GATHERED (R x Ep bf16) into every slice's LDS; GEMM with the W_ic tiles; GRU cell of the
+//      slice's units (one thread per (sample, unit));
+//   3. h' is ALL-GATHERED (R x 512 bf16) into every slice's LDS: the next step's MFMA operand.
+// Protocol: lstm_persist.hip's -- a granule is one naturally aligned 8-byte {value, tag} written by one sc1 (agent scope,
+// write-through) store and polled by sc1 loads; tag = step + 1, never 0; the exchange buffer is zeroed ahead of the launch;
+// two slots alternate (every hand-off is all-to-all inside the group, so no producer can run two steps ahead of a consumer).
+// Every spin is bounded: on timeout the workgroup records a code in the status word, stops waiting and POISONS h' with NaN.
+//
+// Results: the buffers the per-step path saves for the backward (H_all, HC_all, W_att, CTX_all, SAVE_all), rounded at the same
+// points (hproj / gh / context / h to bf16, the context part of the input gates kept in f32), so the backward is unchanged.
+#include "common.h"
+#include "igemm_core.h"
+#include "../../include/megreader_hip.h"
+
+namespace mr {
+
+namespace {
+
+constexpr int DH = 512;          // hidden size
+constexpr int DG = 32;           // slices per batch group
+constexpr int DU = DH / DG;      // hidden units per slice (16: one MFMA tile)
+constexpr int DT = 64;           // positions (max)
+constexpr int DEPMAX = 576;      // encoder channels (max, multiple of 32)
+constexpr int HLD = DH + 8;      // LDS row stride of h (elements): conflict-free 16-byte fragment reads
+constexpr int CLD = DEPMAX + 8;  // LDS row stride of the contexts
+constexpr unsigned SPIN_LIMIT = 1u << 21;
+constexpr unsigned TIMING_MAGIC = 0x54494D45u;
+
+typedef unsigned long long u64;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+constexpr int AUX_SC1 = 16;
+
+// exchange layout of one batch group of R rows (bytes)
+template <int R>
+struct Xch {
+  static constexpr unsigned XS_SLOT = DG * R * DT * 8;           // partial energies: [producer][sample][position] {f32, tag}
+  static constexpr unsigned XC_SLOT = R * (DEPMAX / 4) * 16;     // contexts: [sample][4-channel unit] {bf16x2, tag} x 2
+  static constexpr unsigned XH_SLOT = R * (DH / 4) * 16;         // hidden:   [sample][4-unit unit]
+  static constexpr unsigned XS_OFF = 0, XC_OFF = 2 * XS_SLOT, XH_OFF = XC_OFF + 2 * XC_SLOT;
+  static constexpr unsigned GROUP = XH_OFF + 2 * XH_SLOT;
+  static constexpr int CNT_C = (R * (DEPMAX / 4) + 255) / 256;   // 16-byte pairs per thread of the context gather
+  static constexpr int CNT_H = R * (DH / 4) / 256;               // ... of the hidden gather
+};
+
+__device__ __forceinline__ void gran2_store(rsrc_t r, unsigned byte_off, unsigned v0, unsigned v1, unsigned tag) {
+  __builtin_amdgcn_raw_buffer_store_b128(u32x4{v0, tag, v1, tag}, r, (int)byte_off, 0, AUX_SC1);
+}
+__device__ __forceinline__ u32x4 gran2_load(rsrc_t r, unsigned byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, AUX_SC1);
+}
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const bf16_t x = (bf16_t)a, y = (bf16_t)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+// the energies' tanh: the form of attention.hip (att_tanh)
+__device__ __forceinline__ float dec_tanh(float x) {
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.885390081777927f));
+}
+
+// Cross-lane sums on the DPP path (one VALU op a level; __shfl_xor is a ds_bpermute round trip a level and the softmax of a step
+// sits on the chain 12 levels deep).  After the two quad permutations every quad is uniform, so the (half-)row mirrors act as
+// xor 4 / xor 8.  All lanes of the wave must be executing.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int LANES>   // sum over aligned groups of LANES (2, 4, 8, 16) adjacent lanes, result in every lane of the group
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_mov<0xB1>(v);                            // quad_perm [1,0,3,2]
+  if constexpr (LANES >= 4) v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
+  if constexpr (LANES >= 8) v += dpp_mov<0x141>(v); // row_half_mirror
+  if constexpr (LANES >= 16) v += dpp_mov<0x140>(v);// row_mirror
+  return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = group_sum<16>(v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// Gather CNT 16-byte granule pairs (bit k of `want`: this thread needs pair k at byte offset base + off[k]); a pair is accepted
+// when both of its tags equal `tag`.  The wave leaves together.  Returns false on timeout.
+template <int CNT>
+__device__ __forceinline__ bool gather_pairs(rsrc_t rx, const unsigned (&off)[CNT], unsigned base, unsigned want, unsigned tag,
+                                             u32x4 (&v)[CNT]) {
+  unsigned need = want;
+  for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) {
+      if ((need >> k) & 1u) {
+        const u32x4 t = gran2_load(rx, base + off[k]);
+        if (t[1] == tag && t[3] == tag) {
+          v[k] = t;
+          need &= ~(1u << k);
+        }
+      }
+    }
+    if (__all(need == 0)) return true;
+    if (spins > SPIN_LIMIT) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+struct DecP {
+  const bf16_t* cat_w;     // [4H][H]: rows [0,H) attention hidden projection, [H,4H) W_hh (r, z, n)
+  const float* cat_b;      // [4H] or null
+  const bf16_t* ic_w;      // [3H][ldic]: context columns of W_ih
+  long long ldic;
+  const bf16_t* G;         // word table [classes][ldG >= 3H] (W_ih word part + b_ih, gathered by idx)
+  long long ldG;
+  const long long* idx;    // [S][N] word fed to each step
+  const bf16_t* eproj;     // [N][T][H]
+  const bf16_t* enc;       // [N][T][Ep]
+  const float* v;          // [H]
+  bf16_t* H_all;           // [S+1][N][H]   ([0] is the initial state: read)
+  bf16_t* HC_all;          // [S][N][4H]
+  float* W_att;            // [S][N][T]
+  bf16_t* CTX_all;         // [S][N][Ep]
+  float* SAVE_all;         // [S][N][3H]  r, z, n
+  u64* xch;
+  unsigned* status;
+  int S, N, T, Ep, nbg;
+};
+
+// LDS carve-up (bytes), shared by the kernel and the launcher
+template <int R>
+struct Lds {
+  static constexpr int HBUF = 0;                                  // bf16 [16][HLD]   (rows >= R stay zero)
+  static constexpr int EP = HBUF + 16 * HLD * 2;                  // uint4 [2 halves][R * 64 (sample, position)]: 8 units each
+  static constexpr int HC = EP + 2 * R * DT * 16;                 // f32 [4 tiles][16 rows][16 units]
+  static constexpr int GI = HC + 4 * 16 * DU * 4;                 // f32 [3 gates][16 rows][16 units]
+  static constexpr int SC = GI + 3 * 16 * DU * 4;                 // f32 [8][64] partial energies, [64] weights
+  static constexpr int DEAD = SC + 9 * 64 * 4;                    // int [4]
+  static constexpr int CTX = DEAD + 16;                           // bf16 [16][CLD]   (rows >= R, columns >= Ep stay zero)
+  static constexpr int ENC = CTX + 16 * CLD * 2;                  // bf16 [T][4 * upp]: this slice's channel share of its sample
+  static size_t bytes(int T, int Ep) {
+    const int upp = cdiv(Ep / 4, DG / R);
+    return (size_t)ENC + (size_t)T * upp * 8;
+  }
+};
+
+}  // namespace
+
+template <int R>
+__global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
+  typedef Mma<bf16_t>::Frag Frag;
+  typedef Xch<R> X;
+  typedef Lds<R> L;
+  constexpr int SPS = DG / R;        // slices serving one sample
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* hbuf = (bf16_t*)(smem + L::HBUF);
+  uint4* sEp = (uint4*)(smem + L::EP);
+  float* sHC = (float*)(smem + L::HC);
+  float* sGI = (float*)(smem + L::GI);
+  float* sSc = (float*)(smem + L::SC);
+  int* sDead = (int*)(smem + L::DEAD);
+  bf16_t* sCtx = (bf16_t*)(smem + L::CTX);
+  bf16_t* sEnc = (bf16_t*)(smem + L::ENC);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int g = blockIdx.x % DG, bg = blockIdx.x / DG;
+  const int T = a.T, Ep = a.Ep, N = a.N, S = a.S;
+  const int nu = Ep >> 2;                       // 4-channel units per context row
+  const int row_f = bg * R + l15;               // batch row of this lane's MFMA output column
+  const bool row_f_ok = l15 < R && row_f < N;
+  // the sample this slice reduces the energies of, and its share of that sample's context channels
+  const int nloc = g / SPS, cpart = g % SPS, row_o = bg * R + nloc;
+  const bool row_o_ok = row_o < N;
+  const int upp = (nu + SPS - 1) / SPS;         // 4-channel units per share
+  const int u0 = cpart * upp;                   // first unit of this slice's share
+  const int nown = max(0, min(upp, nu - u0));   // units of the share that exist
+  // context sum: TG adjacent lanes share a unit, each takes the positions t = ctg (mod TG); upp * TG <= 144 threads
+  constexpr int TG = 32 / R;
+  const int cu = tid / TG, ctg = tid % TG;      // this thread's (unit, position group)
+  const bool ctx_thread = cu < nown;
+
+  // ---- weights: VGPR-resident MFMA fragments.  wave w: W_cat tile w (w = 0: hproj, 1..3: gh r/z/n); waves 0..2: W_ic gate w
+  Frag wcat[16], wic[18];
+  {
+    const int rc = (wave == 0 ? 0 : DH + (wave - 1) * DH) + g * DU + l15;
+    const bf16_t* p = a.cat_w + (long long)rc * DH + lg * 8;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) wcat[c] = *(const Frag*)(p + c * 32);
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    const bf16_t* q = a.ic_w + (long long)((wave < 3 ? wave : 0) * DH + g * DU + l15) * a.ldic + lg * 8;
+#pragma unroll
+    for (int c = 0; c < 18; ++c) {
+      uint4 t = z4;
+      if (wave < 3 && c * 32 + lg * 8 < Ep) t = *(const uint4*)(q + c * 32);
+      wic[c] = *(const Frag*)&t;
+    }
+  }
+  const int colbase = (wave == 0 ? 0 : DH + (wave - 1) * DH) + g * DU + lg * 4;   // first of this lane's 4 W_cat columns
+  f32x4 cbias = {0.f, 0.f, 0.f, 0.f};
+  if (a.cat_b) cbias = *(const f32x4*)(a.cat_b + colbase);
+  float vv[DU];
+#pragma unroll
+  for (int j = 0; j < DU; j += 4) {
+    const f32x4 t = *(const f32x4*)(a.v + g * DU + j);
+    vv[j] = t[0]; vv[j + 1] = t[1]; vv[j + 2] = t[2]; vv[j + 3] = t[3];
+  }
+  // ---- LDS residents: the slice's eproj columns, its encoder share, h_0, zero padding of the context tile
+  for (int p = tid; p < R * DT; p += 256) {
+    const int n = p >> 6, t = p & 63, r = bg * R + n;
+    uint4 e0 = make_uint4(0, 0, 0, 0), e1 = e0;
+    if (r < N && t < T) {
+      const bf16_t* ep = a.eproj + ((long long)r * T + t) * DH + g * DU;
+      e0 = *(const uint4*)ep;
+      e1 = *(const uint4*)(ep + 8);
+    }
+    sEp[p] = e0;
+    sEp[R * DT + p] = e1;
+  }
+  for (int i = tid; i < T * upp; i += 256) {
+    const int t = i / upp, u = i - t * upp;
+    uint2 e = make_uint2(0, 0);
+    if (row_o_ok && u < nown) e = *(const uint2*)(a.enc + ((long long)row_o * T + t) * Ep + (u0 + u) * 4);
+    *(uint2*)(sEnc + (long long)i * 4) = e;
+  }
+  for (int i = tid; i < 16 * HLD / 8; i += 256) {
+    const int r = i / (HLD / 8), c = (i - r * (HLD / 8)) * 8, rr = bg * R + r;
+    uint4 h0 = make_uint4(0, 0, 0, 0);
+    if (r < R && rr < N && c < DH) h0 = *(const uint4*)(a.H_all + (long long)rr * DH + c);
+    *(uint4*)(hbuf + r * HLD + c) = h0;
+  }
+  for (int i = tid; i < 16 * CLD / 8; i += 256) ((uint4*)sCtx)[i] = make_uint4(0, 0, 0, 0);
+  if (tid < 4) sDead[tid] = 0;
+
+  const rsrc_t rx = make_rsrc(a.xch);
+  const unsigned xg = (unsigned)bg * X::GROUP;
+  // per-thread constants of the gathers
+  unsigned offC[X::CNT_C], ldsC[X::CNT_C], wantC = 0;      // contexts: R * nu pairs
+#pragma unroll
+  for (int k = 0; k < X::CNT_C; ++k) {
+    const int u = tid + 256 * k;
+    offC[k] = (unsigned)u * 16u;
+    const int r = u / nu, c = u - r * nu;
+    ldsC[k] = (unsigned)(r * CLD + c * 4);
+    if (u < R * nu) wantC |= 1u << k;
+  }
+  unsigned offH[X::CNT_H];                                 // hidden: R * 128 pairs, linear
+#pragma unroll
+  for (int k = 0; k < X::CNT_H; ++k) offH[k] = (unsigned)(tid + 256 * k) * 16u;
+  unsigned offS[4];                                        // the partial energies of this slice's sample from 32 producers
+  {
+    const int tp = tid & 31, pg = tid >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) offS[k] = (unsigned)(((pg + 8 * k) * R * DT + nloc * DT + tp * 2) * 8);
+  }
+  // GRU ownership: thread <-> (sample gm, unit gu of the slice)
+  const int gm = tid >> 4, gu = tid & 15, row_g = bg * R + gm, jg = g * DU + gu;
+  const bool gru_thread = gm < R;
+  const bool row_g_ok = gru_thread && row_g < N;
+  bool dead = false;
+  // the word rows of the GRU's input gates, fetched one step ahead (idx -> row is a dependent pair of loads)
+  long long widx = row_g_ok ? a.idx[row_g] : 0;
+  unsigned short gw[3] = {0, 0, 0};       // raw bf16: converted where they are used, so the loads are waited for there
+  if (row_g_ok) {
+    const unsigned short* gp = (const unsigned short*)(a.G + widx * a.ldG + jg);
+    gw[0] = gp[0]; gw[1] = gp[DH]; gw[2] = gp[2 * DH];
+  }
+  __syncthreads();
+  // phase clock (tools/microbench_decode.py): thread 0 of slices 0 and 1 of group 0 adds the 100 MHz wall clock spent in each
+  // phase of a step into status words [8 + 16 g + phase]; only when the caller set status word 2 (the product never does)
+  const bool timing = tid == 0 && bg == 0 && g < 2 && a.status[2] == TIMING_MAGIC;
+  unsigned long long tprev = timing ? wall_clock64() : 0ull;
+  unsigned tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define DEC_TICK(i)                                   \
+  if (timing) {                                       \
+    const unsigned long long tn_ = wall_clock64();    \
+    tacc[i] += (unsigned)(tn_ - tprev);               \
+    tprev = tn_;                                      \
+  }
+
+  for (int s = 0; s < S; ++s) {
+    const unsigned tag = (unsigned)(s + 1);
+    const unsigned slot = (unsigned)(s & 1);
+    if (row_g_ok && s + 1 < S) widx = a.idx[(long long)(s + 1) * N + row_g];     // used after the context hand-off
+    // ---- 1. stacked hidden projection of the slice's units: [16 rows] x [this wave's 16 columns of W_cat]
+    {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int c = 0; c < 16; c += 2) {
+        const Frag h0 = *(const Frag*)(hbuf + l15 * HLD + c * 32 + lg * 8);
+        const Frag h1 = *(const Frag*)(hbuf + l15 * HLD + c * 32 + 32 + lg * 8);
+        Mma<bf16_t>::run(acc0, wcat[c], h0);      // D[column][row]: this lane = 4 consecutive columns of row l15
+        Mma<bf16_t>::run(acc1, wcat[c + 1], h1);
+      }
+      const f32x4 acc = acc0 + acc1;
+      const unsigned p01 = pack_bf16(acc[0] + cbias[0], acc[1] + cbias[1]);
+      const unsigned p23 = pack_bf16(acc[2] + cbias[2], acc[3] + cbias[3]);
+      *(f32x4*)(sHC + (wave * 16 + l15) * DU + lg * 4) = f32x4{bf16_lo(p01), bf16_hi(p01), bf16_lo(p23), bf16_hi(p23)};
+      if (row_f_ok) *(uint2*)(a.HC_all + ((long long)s * N + row_f) * 4 * DH + colbase) = make_uint2(p01, p23);
+    }
+    __syncthreads();
+    DEC_TICK(0)
+    // ---- partial energies of (sample w + 4i, position lane) over the slice's 16 units -> the slices of that sample
+    {
+      const unsigned xs = xg + X::XS_OFF + slot * X::XS_SLOT + (unsigned)(g * R * DT * 8);
+#pragma unroll
+      for (int i = 0; i < R / 4; ++i) {
+        const int n = wave + 4 * i, p = n * DT + lane;
+        const uint4 e0 = sEp[p], e1 = sEp[R * DT + p];
+        const float* hp = sHC + n * DU;          // tile 0 = hproj
+        const unsigned ew[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+        float sc0 = 0.f, sc1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          sc0 += vv[2 * q] * dec_tanh(hp[2 * q] + bf16_lo(ew[q]));
+          sc1 += vv[2 * q + 1] * dec_tanh(hp[2 * q + 1] + bf16_hi(ew[q]));
+        }
+        float sc = sc0 + sc1;
+        if (lane >= T) sc = 0.f;
+        const float nb = __shfl_down(sc, 1, 64);
+        if (!(lane & 1)) gran2_store(rx, xs + (unsigned)(p * 8), __float_as_uint(sc), __float_as_uint(nb), tag);
+      }
+    }
+    DEC_TICK(1)
+    // ---- 2. reduce the partials of this slice's sample, softmax, context of its channel share
+    {
+      u32x4 pv[4];
+      if (!dead && !gather_pairs<4>(rx, offS, xg + X::XS_OFF + slot * X::XS_SLOT, 0xfu, tag, pv)) {
+        dead = true;
+        if (lane == 0) { atomicMax(a.status, 1u); sDead[0] = 1; }
+      }
+      DEC_TICK(2)
+      float s0 = 0.f, s1 = 0.f;
+      if (!dead) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0 += __uint_as_float(pv[k][0]); s1 += __uint_as_float(pv[k][2]); }
+      }
+      {
+        const int tp = tid & 31, pg = tid >> 5;
+        *(float2*)(sSc + pg * 64 + tp * 2) = make_float2(s0, s1);
+      }
+      __syncthreads();
+      {
+        // every wave runs the 64-wide softmax redundantly (lane t of every wave holds w_t): no barrier before the context sum
+        float e = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e += sSc[k * 64 + lane];
+        e = lane < T ? e : -INFINITY;
+        const float mx = wave_max_dpp(e);
+        const float ex = lane < T ? expf(e - mx) : 0.f;
+        const float sm = wave_sum_dpp(ex);
+        const float w = ex / sm;
+        if (wave == 0 && cpart == 0 && lane < T && row_o_ok) a.W_att[((long long)s * N + row_o) * T + lane] = w;
+        // this thread's positions of the context sum: t = ctg, ctg + TG, ...  (every lane runs every iteration: a shuffle
+        // reads 0 from a lane that is not executing)
+        f32x4 cacc = {0.f, 0.f, 0.f, 0.f};
+        const bf16_t* er = sEnc + cu * 4;
+#pragma unroll
+        for (int i = 0; i < DT / TG; ++i) {
+          const int t = ctg + i * TG;
+          const bool ok = ctx_thread && t < T;
+          const uint2 ev = ok ? *(const uint2*)(er + t * upp * 4) : make_uint2(0, 0);
+          const float wt = __shfl(w, t, 64);
+          cacc[0] += wt * bf16_lo(ev.x); cacc[1] += wt * bf16_hi(ev.x);
+          cacc[2] += wt * bf16_lo(ev.y); cacc[3] += wt * bf16_hi(ev.y);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cacc[q] = group_sum<TG>(cacc[q]);
+        DEC_TICK(3)
+        if (ctx_thread && ctg == 0) {
+          const unsigned p01 = pack_bf16(cacc[0], cacc[1]), p23 = pack_bf16(cacc[2], cacc[3]);
+          gran2_store(rx, xg + X::XC_OFF + slot * X::XC_SLOT + (unsigned)((nloc * nu + u0 + cu) * 16), p01, p23, tag);
+          if (row_o_ok) *(uint2*)(a.CTX_all + ((long long)s * N + row_o) * Ep + (u0 + cu) * 4) = make_uint2(p01, p23);
+        }
+      }
+    }
+    DEC_TICK(4)
+    // ---- all-gather of the R contexts -> LDS
+    {
+      u32x4 cv[X::CNT_C];
+      if (!dead && !gather_pairs<X::CNT_C>(rx, offC, xg + X::XC_OFF + slot * X::XC_SLOT, wantC, tag, cv)) {
+        dead = true;
+        if (lane == 0) { atomicMax(a.status, 2u); sDead[1] = 1; }
+      }
+      if (!dead) {
+#pragma unroll
+        for (int k = 0; k < X::CNT_C; ++k)
+          if ((wantC >> k) & 1u) *(uint2*)(sCtx + ldsC[k]) = make_uint2(cv[k][0], cv[k][2]);
+      }
+    }
+    __syncthreads();
+    DEC_TICK(5)
+    // ---- context part of the input gates (f32), GRU cell of the slice's units
+    if (wave < 3) {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int c = 0; c < 18; c += 2) {
+        const Frag c0 = *(const Frag*)(sCtx + l15 * CLD + c * 32 + lg * 8);
+        const Frag c1 = *(const Frag*)(sCtx + l15 * CLD + c * 32 + 32 + lg * 8);
+        Mma<bf16_t>::run(acc0, wic[c], c0);
+        Mma<bf16_t>::run(acc1, wic[c + 1], c1);
+      }
+      *(f32x4*)(sGI + (wave * 16 + l15) * DU + lg * 4) = acc0 + acc1;
+    }
+    __syncthreads();
+    DEC_TICK(6)
+    if (gru_thread) {
+      const int o = gm * DU + gu;
+      const float ir = bf16_lo(gw[0]) + sGI[o], iz = bf16_lo(gw[1]) + sGI[16 * DU + o],
+                  in_ = bf16_lo(gw[2]) + sGI[2 * 16 * DU + o];
+      const float hr = sHC[16 * DU + o], hz = sHC[2 * 16 * DU + o], hn = sHC[3 * 16 * DU + o];
+      const float r = sigmoidf_(ir + hr), z = sigmoidf_(iz + hz);
+      const float nn_ = tanhf_(in_ + r * hn);
+      const float hp = (float)hbuf[gm * HLD + jg];
+      float hnew = (1.f - z) * nn_ + z * hp;
+      if (sDead[0] | sDead[1] | sDead[2]) hnew = __builtin_nanf("");
+      if (row_g_ok) {
+        float* sv = a.SAVE_all + ((long long)s * N + row_g) * 3 * DH + jg;
+        sv[0] = r; sv[DH] = z; sv[2 * DH] = nn_;
+      }
+      if (!row_g_ok) hnew = 0.f;
+      if (row_g_ok && s + 1 < S) {        // the next step's word rows: a whole step to arrive
+        const unsigned short* gp = (const unsigned short*)(a.G + widx * a.ldG + jg);
+        gw[0] = gp[0]; gw[1] = gp[DH]; gw[2] = gp[2 * DH];
+      }
+      const float h1 = __shfl_down(hnew, 1, 64), h2 = __shfl_down(hnew, 2, 64), h3 = __shfl_down(hnew, 3, 64);
+      if (!(gu & 3)) {
+        const unsigned p01 = pack_bf16(hnew, h1), p23 = pack_bf16(h2, h3);
+        if (s + 1 < S)
+          gran2_store(rx, xg + X::XH_OFF + slot * X::XH_SLOT + (unsigned)((gm * (DH / 4) + (jg >> 2)) * 16), p01, p23, tag);
+        if (row_g_ok) *(uint2*)(a.H_all + ((long long)(s + 1) * N + row_g) * DH + jg) = make_uint2(p01, p23);
+      }
+    }
+    DEC_TICK(7)
+    if (s + 1 == S) break;
+    // ---- 3. all-gather of h' -> LDS
+    {
+      u32x4 hv[X::CNT_H];
+      const bool okh =
+          dead || gather_pairs<X::CNT_H>(rx, offH, xg + X::XH_OFF + slot * X::XH_SLOT, (1u << X::CNT_H) - 1u, tag, hv);
+      if (!okh) {
+        dead = true;
+        if (lane == 0) { atomicMax(a.status, 3u); sDead[2] = 1; }
+      }
+      __syncthreads();        // every GRU thread has read its h
+      if (!dead) {
+#pragma unroll
+        for (int k = 0; k < X::CNT_H; ++k) {
+          const int u = tid + 256 * k, r = u >> 7, c = (u & 127) * 4;
+          *(uint2*)(hbuf + r * HLD + c) = make_uint2(hv[k][0], hv[k][2]);
+        }
+      }
+    }
+    __syncthreads();
+    DEC_TICK(8)
+  }
+  if (timing) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) a.status[8 + 16 * g + i] = tacc[i];
+  }
+#undef DEC_TICK
+}
+
+namespace {
+// rows per batch group: the smallest of 4 / 8 / 16 that keeps the grid (32 workgroups per group, one per CU) within 128 CUs
+int decode_rows(int N) { return N <= 16 ? 4 : N <= 32 ? 8 : 16; }
+unsigned decode_group_bytes(int R) { return R == 4 ? Xch<4>::GROUP : R == 8 ? Xch<8>::GROUP : Xch<16>::GROUP; }
+long long decode_ws_bytes(int N) {
+  const int R = decode_rows(N);
+  return (long long)cdiv(N, R) * decode_group_bytes(R) + 256;
+}
+
+template <int R>
+int decode_launch(const DecP& a, hipStream_t stream) {
+  static bool attr_set[MR_MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev >= 0 && dev < MR_MAX_DEVICES && !attr_set[dev]) {
+    if (hipFuncSetAttribute((const void*)decode_fwd_persist_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)Lds<R>::bytes(DT, DEPMAX)) != hipSuccess) {
+      set_error("mr_decode_persist_fwd: cannot raise the dynamic LDS limit");
+      return MR_ERR_LAUNCH;
+    }
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(decode_fwd_persist_kernel<R>, dim3(a.nbg * DG), dim3(256), Lds<R>::bytes(a.T, a.Ep), stream, a);
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// host only: can the persistent decode forward take this shape?  (bf16, H = 512, N <= 64, T <= 64, Ep <= 576 a multiple of 8)
+int mr_decode_persist_ok(int dtype, int N, int T, int H, int Ep) {
+  return (dtype == MR_BF16 && H == DH && N >= 1 && N <= 64 && T >= 1 && T <= DT && Ep >= 8 && Ep <= DEPMAX && Ep % 8 == 0 &&
+          MR_TUNE(decode_persist) != 0)
+             ? 1
+             : 0;
+}
+
+long long mr_decode_persist_ws_bytes(int N) { return decode_ws_bytes(N); }
+
+// All S teacher-forced steps of the attention-GRU decode loop in one launch (see the file header).  idx [S][N] = the word fed
+// to each step; H_all[0] = the initial state.  ws_bytes negative: the caller already zeroed the workspace.
+int mr_decode_persist_fwd(const void* cat_w, const float* cat_b, const void* ic_w, long long ldic, const void* G, long long ldG,
+                          const long long* idx, const void* eproj, const void* enc, const float* v, void* H_all, void* HC_all,
+                          float* W_att, void* CTX_all, float* SAVE_all, void* ws, long long ws_bytes, int S, int N, int T,
+                          int Ep, hipStream_t stream) {
+  const bool prezeroed = ws_bytes < 0;
+  if (prezeroed) ws_bytes = -ws_bytes;
+  MR_CHECK_ARG(S >= 1 && N >= 1 && N <= 64 && T >= 1 && T <= DT && Ep >= 8 && Ep <= DEPMAX && Ep % 8 == 0 && ldic >= Ep &&
+                   ldG >= 3 * DH,
+               "mr_decode_persist_fwd: bad shape S=%d N=%d T=%d Ep=%d", S, N, T, Ep);
+  MR_CHECK_ARG(ws_bytes >= decode_ws_bytes(N), "mr_decode_persist_fwd: workspace too small (%lld < %lld)", ws_bytes,
+               decode_ws_bytes(N));
+  const int R = decode_rows(N), nbg = cdiv(N, R);
+  if (!prezeroed && hipMemsetAsync(ws, 0, (size_t)decode_ws_bytes(N), stream) != hipSuccess) {
+    set_error("mr_decode_persist_fwd: memset of the exchange buffer failed");
+    return MR_ERR_LAUNCH;
+  }
+  DecP a{(const bf16_t*)cat_w, cat_b, (const bf16_t*)ic_w, ldic, (const bf16_t*)G, ldG, idx, (const bf16_t*)eproj,
+         (const bf16_t*)enc, v, (bf16_t*)H_all, (bf16_t*)HC_all, W_att, (bf16_t*)CTX_all, SAVE_all, (u64*)ws,
+         (unsigned*)((char*)ws + (long long)nbg * decode_group_bytes(R)), S, N, T, Ep, nbg};
+  return R == 4 ? decode_launch<4>(a, stream) : R == 8 ? decode_launch<8>(a, stream) : decode_launch<16>(a, stream);
+}
+
+}  // extern "C"
+
+}  // namespace mr

@@ -31,7 +31,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from .. import get_compute_dtype
-from .._lib import call, dtype_code, ptr, vec_of
+from .._lib import call, dtype_code, load, ptr, vec_of
 from ..charsets import DefaultCharset
 from ..nn import Conv2d, BatchNorm2d, MaxPool2d, FusedReLU
 from ..nn import prep
@@ -45,6 +45,27 @@ FUSED_STEP = os.environ.get("MEGREADER_DECODE_FUSED", "1") != "0"
 # behind the loop instead of a launch per step on the chain (32 launches, ~0.23 ms of the FPN step).  MEGREADER_DECODE_BATCHED_OUT=0
 # keeps the per-step launches (A/B); random coins (the YAML default) and `gt_as_output=False` always take the per-step path.
 BATCHED_OUT = os.environ.get("MEGREADER_DECODE_BATCHED_OUT", "1") != "0"
+# round 6: the teacher-forced forward loop as one persistent launch (mr_decode_persist_fwd; also mr_tuning.decode_persist).
+# MEGREADER_DECODE_PERSIST=0 keeps the three launches per step.
+PERSIST = os.environ.get("MEGREADER_DECODE_PERSIST", "1") != "0"
+
+
+def _persist_workspace(N, dev):
+    """(exchange buffer, size argument) of mr_decode_persist_fwd: zero at launch -- from the pre-zeroed arena (size passed NEGATIVE)
+    or, when that is exhausted, from torch's allocator (the C call zeroes it).  The status word (last 256 bytes) joins the list
+    nn.functional.LSTM_STATUS collects for tests and bench.py."""
+    from ..nn import functional as F_
+    nbytes = load().mr_decode_persist_ws_bytes(N)
+    size = nbytes
+    arena = F_.ZeroArena.take(dev, (nbytes + 7) // 8)
+    if arena is not None:
+        ws = arena.view(torch.uint8)[:nbytes]
+        size = -nbytes
+    else:
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    if F_.LSTM_STATUS is not None:
+        F_.LSTM_STATUS.append(ws[nbytes - 256:nbytes - 252])
+    return ws, size
 
 
 def _ceil_to(x, m):
@@ -327,7 +348,16 @@ class _DecodeLoopFn(Function):
         else:
             idx_all = torch.empty((S, N), dtype=torch.int64, device=dev)
             idx_all[0].fill_(int(blank))
-        for s in range(S):
+        # round 6: with every step teacher-forced nothing inside the loop depends on the output layer, and the whole forward loop is
+        # ONE persistent launch (csrc/decode_persist.hip) that leaves the same saved buffers behind as the per-step launches below
+        persist = (batched_out and PERSIST and dtype == torch.bfloat16 and Ep % 8 == 0
+                   and bool(load().mr_decode_persist_ok(dt, N, T, Hd, Ep)))
+        if persist:
+            ws, ws_size = _persist_workspace(N, dev)
+            call("mr_decode_persist_fwd", ptr(cat.w_n), ptr(cat.bias_d), ptr(ic.w_n), Ep, ptr(G), ldG, ptr(idx_all), ptr(eproj),
+                 ptr(enc), ptr(vf), ptr(H_all), ptr(HC_all), ptr(W_att), ptr(CTX_all), ptr(SAVE_all), ptr(ws), ws_size, S, N, T,
+                 Ep)
+        for s in range(0 if persist else S):
             call("mr_gemm_nt", dt, ptr(H_all[s]), Hd, ptr(cat.w_n), Hd, ptr(HC_all[s]), HC, ptr(cat.bias_d), 0, N, HC, Hd)
             call("mr_attn_fwd2", dt, ptr(HC_all[s]), HC, ptr(eproj), ptr(vf), ptr(enc), ptr(W_att[s]), ptr(CTX_all[s]), N, T,
                  Hd, Ep)

@@ -1,0 +1,156 @@
+"""mr_decode_persist_fwd (csrc/decode_persist.hip): the teacher-forced attention-GRU decode loop of the reference
+(decoders/attention_decoder.py:84-118 around AttentionRNNCell :146-231) as ONE persistent launch, against
+
+  * the per-step launches it replaces (mr_gemm_nt + mr_attn_fwd2 + mr_gemm_gru_fwd through the C ABI), buffer by buffer: both round
+    at the same points, so only f32 summation order (and one bf16 ulp where that order flips a rounding) separates them;
+  * a float64 restatement of the same recurrence on the same bf16 inputs.
+
+Shapes: the published one (N = 16, T = 64, H = 512, Ep = 552, S = 32), two batch groups, ragged groups / positions / channels.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from megreader_amd._lib import call, dtype_code, load, ptr  # noqa: E402
+
+DEV = "cuda"
+H = 512
+
+
+def _inputs(N, T, Ep, S, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    bf = torch.bfloat16
+    d = {}
+    d["cat_w"] = (torch.randn(4 * H, H, generator=g) * H ** -0.5).to(bf)
+    d["cat_b"] = torch.cat([torch.zeros(H), torch.randn(3 * H, generator=g) * 0.1]).float()
+    d["ic_w"] = (torch.randn(3 * H, Ep, generator=g) * Ep ** -0.5).to(bf)
+    d["G"] = (torch.randn(C, 3 * H, generator=g) * 0.5).to(bf)
+    d["idx"] = torch.randint(0, C, (S, N), generator=g, dtype=torch.int64)
+    d["eproj"] = (torch.randn(N, T, H, generator=g) * 0.7).to(bf)
+    d["enc"] = torch.randn(N, T, Ep, generator=g).to(bf)
+    d["v"] = (torch.randn(H, generator=g) * H ** -0.5 * 4).float()
+    d["h0"] = (torch.randn(N, H, generator=g) * 0.3).to(bf)
+    return {k: v.to(DEV).contiguous() for k, v in d.items()}
+
+
+def _buffers(N, T, Ep, S, h0):
+    bf = torch.bfloat16
+    b = {"H_all": torch.full((S + 1, N, H), float("nan"), dtype=bf, device=DEV),
+         "HC_all": torch.full((S, N, 4 * H), float("nan"), dtype=bf, device=DEV),
+         "W_att": torch.full((S, N, T), float("nan"), dtype=torch.float32, device=DEV),
+         "CTX_all": torch.full((S, N, Ep), float("nan"), dtype=bf, device=DEV),
+         "SAVE_all": torch.full((S, N, 3 * H), float("nan"), dtype=torch.float32, device=DEV)}
+    b["H_all"][0].copy_(h0)
+    return b
+
+
+def _per_step(d, N, T, Ep, S):
+    dt = dtype_code(torch.bfloat16)
+    b = _buffers(N, T, Ep, S, d["h0"])
+    HC = 4 * H
+    for s in range(S):
+        call("mr_gemm_nt", dt, ptr(b["H_all"][s]), H, ptr(d["cat_w"]), H, ptr(b["HC_all"][s]), HC, ptr(d["cat_b"]), 0, N, HC, H)
+        call("mr_attn_fwd2", dt, ptr(b["HC_all"][s]), HC, ptr(d["eproj"]), ptr(d["v"]), ptr(d["enc"]), ptr(b["W_att"][s]),
+             ptr(b["CTX_all"][s]), N, T, H, Ep)
+        call("mr_gemm_gru_fwd", dt, ptr(b["CTX_all"][s]), Ep, ptr(d["ic_w"]), Ep, ptr(d["G"]), 3 * H, ptr(d["idx"][s]),
+             ptr(b["HC_all"][s]) + H * 2, HC, ptr(b["H_all"][s]), ptr(b["H_all"][s + 1]), ptr(b["SAVE_all"][s]), N, H, Ep)
+    return b
+
+
+def _persistent(d, N, T, Ep, S, prezero):
+    b = _buffers(N, T, Ep, S, d["h0"])
+    nbytes = load().mr_decode_persist_ws_bytes(N)
+    ws = torch.zeros((nbytes,), dtype=torch.uint8, device=DEV) if prezero else \
+        torch.full((nbytes,), 0xAB, dtype=torch.uint8, device=DEV)
+    call("mr_decode_persist_fwd", ptr(d["cat_w"]), ptr(d["cat_b"]), ptr(d["ic_w"]), Ep, ptr(d["G"]), 3 * H, ptr(d["idx"]),
+         ptr(d["eproj"]), ptr(d["enc"]), ptr(d["v"]), ptr(b["H_all"]), ptr(b["HC_all"]), ptr(b["W_att"]), ptr(b["CTX_all"]),
+         ptr(b["SAVE_all"]), ptr(ws), -nbytes if prezero else nbytes, S, N, T, Ep)
+    torch.cuda.synchronize()
+    status = int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item())
+    return b, status
+
+
+def _f64(d, N, T, Ep, S):
+    """The recurrence in float64 on the same (bf16-valued) inputs; no intermediate rounding."""
+    f = {k: v.double() for k, v in d.items() if k != "idx"}
+    h = f["h0"]
+    out = {"H_all": [h], "W_att": [], "CTX_all": []}
+    for s in range(S):
+        hc = h @ f["cat_w"].t() + f["cat_b"]
+        hproj, gh = hc[:, :H], hc[:, H:]
+        energy = torch.tanh(hproj.unsqueeze(1) + f["eproj"]) @ f["v"]
+        w = torch.softmax(energy, dim=1)
+        ctx = torch.bmm(w.unsqueeze(1), f["enc"]).squeeze(1)
+        gi = f["G"][d["idx"][s]] + ctx @ f["ic_w"].t()
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n + z * h
+        out["H_all"].append(h)
+        out["W_att"].append(w)
+        out["CTX_all"].append(ctx)
+    return {k: torch.stack(v) for k, v in out.items()}
+
+
+CASES = [(16, 64, 552, 32, 38), (32, 64, 576, 6, 97), (5, 33, 64, 4, 11), (17, 20, 8, 3, 5), (1, 1, 16, 2, 3), (16, 64, 552, 1, 38)]
+
+
+@pytest.mark.parametrize("N,T,Ep,S,C", CASES)
+@pytest.mark.parametrize("prezero", [True, False])
+def test_persistent_decode_matches_per_step_launches(N, T, Ep, S, C, prezero):
+    assert load().mr_decode_persist_ok(dtype_code(torch.bfloat16), N, T, H, Ep) == 1
+    d = _inputs(N, T, Ep, S, C, seed=N * 131 + T)
+    ref = _per_step(d, N, T, Ep, S)
+    got, status = _persistent(d, N, T, Ep, S, prezero)
+    assert status == 0, "a hand-off of the persistent decode kernel timed out (code %d)" % status
+    for k in ("H_all", "HC_all", "W_att", "CTX_all", "SAVE_all"):
+        a, b = got[k].double(), ref[k].double()
+        assert torch.isfinite(a).all(), k
+        # one bf16 ulp of the largest magnitude, a few times over the steps (a flipped rounding feeds the next step)
+        tol = 3e-2 if got[k].dtype == torch.bfloat16 else 2e-2
+        assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())), k
+        # ... and almost everywhere far closer than that
+        assert float(((a - b).abs() > 4e-3 * max(1.0, float(b.abs().max()))).double().mean()) < 0.02, k
+    assert float((got["W_att"].sum(-1) - 1).abs().max()) < 1e-5
+
+
+# N <= 16 runs groups of 4 rows, N <= 32 of 8, N <= 64 of 16 (decode_persist.hip: decode_rows); the per-step GRU launch stops at 32
+@pytest.mark.parametrize("N,T,Ep,S,C", CASES[:4] + [(40, 64, 552, 3, 38), (64, 37, 576, 2, 7), (9, 64, 552, 5, 38)])
+def test_persistent_decode_vs_f64(N, T, Ep, S, C):
+    d = _inputs(N, T, Ep, S, C, seed=N * 17 + S)
+    got, status = _persistent(d, N, T, Ep, S, True)
+    assert status == 0
+    ref = _f64(d, N, T, Ep, S)
+    per = _per_step(d, N, T, Ep, S) if N <= 32 else None
+    for k in ("H_all", "W_att", "CTX_all"):
+        assert torch.isfinite(got[k].double()).all(), k
+        e_new = float((got[k].double() - ref[k]).abs().max())
+        scale = max(1.0, float(ref[k].abs().max()))
+        assert e_new <= 3e-2 * scale, (k, e_new)
+        if per is not None:
+            e_old = float((per[k].double() - ref[k]).abs().max())
+            assert e_new <= 2.0 * e_old + 4e-3 * scale, (k, e_new, e_old)   # no further from f64 than the launches it replaces
+
+
+def test_persistent_decode_repeatable_and_shape_gate():
+    N, T, Ep, S, C = 16, 64, 552, 8, 38
+    d = _inputs(N, T, Ep, S, C, seed=5)
+    a, sa = _persistent(d, N, T, Ep, S, True)
+    b, sb = _persistent(d, N, T, Ep, S, False)
+    assert sa == 0 and sb == 0
+    for k in a:
+        assert torch.equal(a[k], b[k]), k          # granule arrival order never enters the arithmetic
+    lib = load()
+    bf = dtype_code(torch.bfloat16)
+    assert lib.mr_decode_persist_ok(dtype_code(torch.float32), N, T, H, Ep) == 0
+    assert lib.mr_decode_persist_ok(bf, N, T, 256, Ep) == 0
+    assert lib.mr_decode_persist_ok(bf, N, 65, H, Ep) == 0
+    assert lib.mr_decode_persist_ok(bf, N, T, H, 580) == 0
+    assert lib.mr_decode_persist_ok(bf, 65, T, H, Ep) == 0
+    from megreader_amd._lib import set_tuning
+    set_tuning(decode_persist=0)
+    try:
+        assert lib.mr_decode_persist_ok(bf, N, T, H, Ep) == 0
+    finally:
+        set_tuning(decode_persist=1)

@@ -1,0 +1,63 @@
+"""Persistent decode forward (mr_decode_persist_fwd) beside the per-step launches it replaces, plus the kernel's own phase clock.
+  python tools/microbench_decode.py [N T Ep S]
+"""
+import sys
+import torch
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import test_decode_persist_gpu as t  # noqa: E402
+from megreader_amd._lib import call, load, ptr  # noqa: E402
+
+N, T, Ep, S = [int(x) for x in sys.argv[1:5]] if len(sys.argv) >= 5 else (16, 64, 552, 32)
+d = t._inputs(N, T, Ep, S, 38, 1)
+H = t.H
+
+
+def timed(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+b = t._buffers(N, T, Ep, S, d["h0"])
+nbytes = load().mr_decode_persist_ws_bytes(N)
+ws = torch.zeros((nbytes,), dtype=torch.uint8, device="cuda")
+
+
+def persistent(timing=False):
+    ws.zero_()
+    if timing:
+        ws[nbytes - 256:].view(torch.int32)[2] = 0x54494D45
+    call("mr_decode_persist_fwd", ptr(d["cat_w"]), ptr(d["cat_b"]), ptr(d["ic_w"]), Ep, ptr(d["G"]), 3 * H, ptr(d["idx"]),
+         ptr(d["eproj"]), ptr(d["enc"]), ptr(d["v"]), ptr(b["H_all"]), ptr(b["HC_all"]), ptr(b["W_att"]), ptr(b["CTX_all"]),
+         ptr(b["SAVE_all"]), ptr(ws), -nbytes, S, N, T, Ep)
+
+
+# the per-step launches inside one hipGraph (as the training step replays them)
+g = torch.cuda.CUDAGraph()
+s_ = torch.cuda.Stream()
+with torch.cuda.stream(s_):
+    t._per_step(d, N, T, Ep, S)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s_):
+        t._per_step(d, N, T, Ep, S)
+print("per-step launches (graph replay): %.1f us  = %.2f us/step" % (timed(g.replay), timed(g.replay) / S))
+us = timed(persistent)
+print("persistent (incl. ws memset)    : %.1f us  = %.2f us/step" % (us, us / S))
+persistent(True)
+torch.cuda.synchronize()
+st = ws[nbytes - 256:].view(torch.int32).cpu()
+names = ["gemm1+sync", "energies+publish", "owner gather", "reduce+softmax", "ctx+publish", "ctx gather", "gemm2+sync",
+         "gru+publish", "h gather"]
+for g_ in (0, 1):
+    v = [int(st[8 + 16 * g_ + i]) * 0.01 / S for i in range(9)]
+    print("slice %d (%s): " % (g_, "owner" if g_ == 0 else "non-owner") +
+          "  ".join("%s %.2f" % (n, x) for n, x in zip(names, v)) + "   sum %.2f us/step" % sum(v))
+print("status", int(st[0]))
