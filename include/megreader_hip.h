@@ -642,6 +642,18 @@ int mr_decode_persist_fwd(const void* cat_w, const float* cat_b, const void* ic_
                           const long long* idx, const void* eproj, const void* enc, const float* v, void* H_all, void* HC_all,
                           float* W_att, void* CTX_all, float* SAVE_all, void* ws, long long ws_bytes, int S, int N, int T,
                           int Ep, hipStream_t stream);
+/* ... and its backward: all S steps in reverse in one launch -- what mr_gemm_gru_bwd / mr_gru_bwd2 + mr_gemm_nt + mr_attn_bwd2 compute
+ * per step (N <= 32).  cat_wt [H][4H] and ic_wt [Ep][ldict >= 3H] are the TRANSPOSED weight images (row = output of the backward
+ * GEMM, K = stacked column / gate unit); DHO_all [S][N][H] = gradient of every h' from the output layer; ga (nullable) = gradient
+ * of the attention weights, element (n, s, t) at ga[n * ldga + s * T + t].  Writes DGI_all [S][N][3H], DHC_all [S][N][4H],
+ * DCTX_all [S][N][Ep], deproj [N][T][H] (f32, plain stores: the per-step path accumulates into it) and ADDS into dv [H] (f32). */
+int mr_decode_persist_bwd_ok(int dtype, int N, int T, int H, int Ep);   /* host only */
+long long mr_decode_persist_bwd_ws_bytes(int N);                        /* host only */
+int mr_decode_persist_bwd(const void* cat_wt, const void* ic_wt, long long ldict, const void* eproj, const void* enc,
+                          const float* v, const void* H_all, const void* HC_all, const float* W_att, const float* SAVE_all,
+                          const void* DHO_all, const float* ga, long long ldga, void* DGI_all, void* DHC_all, void* DCTX_all,
+                          float* deproj, float* dv, void* ws, long long ws_bytes, int S, int N, int T, int Ep,
+                          hipStream_t stream);
 
 /* ---- Round-4 decode-step fusions (csrc/gemm_skinny.hip): the element-wise GRU kernels in the epilogue of the M <= 32 GEMM next
  *      to them, the output layer + log-softmax + NLL + arg-max feedback as one kernel.  Same reference lines as above

@@ -107,6 +107,7 @@ SIGNATURES = {
     "mr_gemm_gru_fwd": "iplplplpplpppiiis",
     "mr_gemm_gru_bwd": "iplplpppplppplpiiis",
     "mr_decode_persist_fwd": "ppp" + "l" + "p" + "l" + "p" * 10 + "l" + "iiii" + "s",
+    "mr_decode_persist_bwd": "pp" + "l" + "p" * 9 + "l" + "p" * 6 + "l" + "iiii" + "s",
     "mr_out_nll_fwd": "iplplpplpppppp" + "iiiis",
     "mr_nll_step_fwd": "ipiplppppiiiis",
     "mr_nll_step_feed_fwd": "ipiplpppppp" + "iiis",
@@ -274,6 +275,10 @@ def load():
     lib.mr_decode_persist_ok.argtypes = [ctypes.c_int] * 5
     lib.mr_decode_persist_ws_bytes.restype = ctypes.c_longlong
     lib.mr_decode_persist_ws_bytes.argtypes = [ctypes.c_int]
+    lib.mr_decode_persist_bwd_ok.restype = ctypes.c_int
+    lib.mr_decode_persist_bwd_ok.argtypes = [ctypes.c_int] * 5
+    lib.mr_decode_persist_bwd_ws_bytes.restype = ctypes.c_longlong
+    lib.mr_decode_persist_bwd_ws_bytes.argtypes = [ctypes.c_int]
     lib.mr_sizeof_img_desc.restype = ctypes.c_int
     lib.mr_sizeof_img_desc.argtypes = []
     lib.mr_tn_defer.restype = ctypes.c_int

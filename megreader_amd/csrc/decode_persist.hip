@@ -7,8 +7,8 @@
 // times, on 16-32 of 256 CUs, each launch re-reading its weights (2 MB + 1.7 MB) from L2.
 //
 // Decomposition (bf16, H = 512).  Samples are independent through the recurrence, hidden units are not:
-//   * the batch is cut into groups of R rows (R = 4, 8 or 16: the smallest that keeps the grid within half the chip -- the bytes
-//     a workgroup gathers per hand-off scale with R); groups never talk to each other;
+//   * the batch is cut into groups of R rows (R = 4 up to 32 samples, else 8: the bytes a workgroup gathers per hand-off scale
+//     with R); groups never talk to each other;
 //   * a group is 32 workgroups ("slices"); slice g owns the hidden units [16g, 16g+16): their column of the attention hidden
 //     projection, their r / z / n rows of W_hh (4 x 16 rows of W_cat, one MFMA tile per wave) and of W_ic (3 tiles).  All of it
 //     -- 64 + 54 KB -- is loaded ONCE into the waves' VGPRs and stays there for all S steps; the slice's 16 columns of eproj
@@ -491,10 +491,446 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
 #undef DEC_TICK
 }
 
+// ------------------------------------------------------------------------------------------------------------------ backward
+// Persistent BACKWARD of the decode loop: all S steps (in reverse) in one launch, the same 32 slices per group of R rows.  The
+// per-step path is [GEMM(dHC W_cat) + GRU backward] -> [GEMM(dgi W_ic)] -> [attention backward] = 12.9 + 6.6 + 7.4 us a step.
+//   Slice g keeps, for its 16 hidden units, the K = 48 rows (r, z, n gate units) of W_ic^T and the K = 64 rows (hproj column +
+//   gh r/z/n) of W_cat^T as VGPR-resident MFMA fragments: both GEMMs of a step have their REDUCTION dimension distributed over
+//   the slices, so each produces f32 partial sums that are REDUCE-SCATTERED to the slice that consumes them:
+//   1. (carried dh_b in a register) + reduce of the 32 partial dh_a of the previous iteration + dh_c -> GRU backward of the own
+//      units (dgi -> DGI_all, dgh -> DHC_all);  partial dctx = dgi[own 48] W_ic[own 48, :]            -> edge A (R x Ep f32)
+//   2. slice (sample n, channel share c) reduces its share of dctx[n] over the 32 producers (-> DCTX_all) and the partial
+//      dw[t] = dctx[share] . enc[n, t, share] from LDS                                                -> edge B (R x 32/R x 64 f32)
+//   3. every slice sums the partial dw of every sample, softmax backward de = w (dw - w . dw), then for its 16 units the tanh
+//      chain: dhproj (-> DHC_all), deproj and dv accumulated IN REGISTERS over all steps (written once at the end);
+//      partial dh_a = dHC[own 64] W_cat[own 64, :]                                                    -> edge C (R x 512 f32)
 namespace {
-// rows per batch group: the smallest of 4 / 8 / 16 that keeps the grid (32 workgroups per group, one per CU) within 128 CUs
-int decode_rows(int N) { return N <= 16 ? 4 : N <= 32 ? 8 : 16; }
-unsigned decode_group_bytes(int R) { return R == 4 ? Xch<4>::GROUP : R == 8 ? Xch<8>::GROUP : Xch<16>::GROUP; }
+struct DecB {
+  const bf16_t* cat_wt;    // [H][4H]: row = hidden unit, K = stacked column
+  const bf16_t* ic_wt;     // [Ep][ldict]: row = context channel, K = gate unit (3H)
+  long long ldict;
+  const bf16_t* eproj;     // [N][T][H]
+  const bf16_t* enc;       // [N][T][Ep]
+  const float* v;          // [H]
+  const bf16_t* H_all;     // [S+1][N][H]
+  const bf16_t* HC_all;    // [S][N][4H]
+  const float* W_att;      // [S][N][T]
+  const float* SAVE_all;   // [S][N][3H]
+  const bf16_t* DHO_all;   // [S][N][H]  gradient of h' from the output layer
+  const float* ga;         // gradient of the attention weights: ga[n * ldga + s * T + t], or null
+  long long ldga;
+  bf16_t* DGI_all;         // [S][N][3H]
+  bf16_t* DHC_all;         // [S][N][4H]
+  bf16_t* DCTX_all;        // [S][N][Ep]
+  float* deproj;           // [N][T][H]   written
+  float* dv;               // [H]         atomically added to
+  u64* xch;
+  unsigned* status;
+  int S, N, T, Ep, nbg;
+};
+
+template <int R>
+struct XchB {
+  static constexpr int SPS = DG / R;
+  static constexpr unsigned XD_SLOT = DG * R * DEPMAX * 8;      // partial dctx: [producer][sample][channel] {f32, tag}
+  static constexpr unsigned XW_SLOT = R * SPS * DT * 8;         // partial dw:   [sample][share][position]
+  static constexpr unsigned XA_SLOT = DG * R * DH * 8;          // partial dh_a: [producer][sample][unit]
+  static constexpr unsigned XD_OFF = 0, XW_OFF = 2 * XD_SLOT, XA_OFF = XW_OFF + 2 * XW_SLOT;
+  static constexpr unsigned GROUP = XA_OFF + 2 * XA_SLOT;
+  static constexpr int CNT_D = R == 4 ? 5 : 11;                 // producers per thread of the dctx reduce (see PGA below)
+};
+
+constexpr int GLD = 64 + 8;   // LDS row stride (elements) of the two K = 64 MFMA operand tiles
+
+template <int R>
+struct LdsB {
+  static constexpr int EP = 0;                                    // uint4 [2 halves][R * 64]
+  static constexpr int DGT = EP + 2 * R * DT * 16;                // bf16 [16][GLD]  dgi  (r | z | n | 0)
+  static constexpr int DHCT = DGT + 16 * GLD * 2;                 // bf16 [16][GLD]  dhproj | dgh r | z | n
+  static constexpr int REDA = DHCT + 16 * GLD * 2;                // f32 [32/R][R][16]
+  static constexpr int REDD = REDA + 512 * 4;                     // f32 [256][2]
+  static constexpr int DCTX = REDD + 512 * 4;                     // f32 [288]
+  static constexpr int DWP = DCTX + 288 * 4;                      // f32 [4][64]
+  static constexpr int DE = DWP + 256 * 4;                        // f32 [R][64]
+  static constexpr int HP = DE + R * 64 * 4;                      // f32 [R][16]
+  static constexpr int DEAD = HP + R * 16 * 4;                    // int [4]
+  static constexpr int ENC = DEAD + 16;                           // bf16 [T][4 * upp]
+  static size_t bytes(int T, int Ep) {
+    const int upp = cdiv(Ep / 4, DG / R);
+    return (size_t)ENC + (size_t)T * upp * 8;
+  }
+};
+
+}  // namespace
+
+template <int R>
+__global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
+  typedef Mma<bf16_t>::Frag Frag;
+  typedef XchB<R> X;
+  typedef LdsB<R> L;
+  constexpr int SPS = DG / R;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* sEp = (uint4*)(smem + L::EP);
+  bf16_t* sDG = (bf16_t*)(smem + L::DGT);
+  bf16_t* sDHC = (bf16_t*)(smem + L::DHCT);
+  float* sRedA = (float*)(smem + L::REDA);
+  float* sRedD = (float*)(smem + L::REDD);
+  float* sDctx = (float*)(smem + L::DCTX);
+  float* sDwP = (float*)(smem + L::DWP);
+  float* sDe = (float*)(smem + L::DE);
+  float* sHp = (float*)(smem + L::HP);
+  int* sDead = (int*)(smem + L::DEAD);
+  bf16_t* sEnc = (bf16_t*)(smem + L::ENC);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int g = blockIdx.x % DG, bg = blockIdx.x / DG;
+  const int T = a.T, Ep = a.Ep, N = a.N, S = a.S;
+  const int nu = Ep >> 2;
+  const int nloc = g / SPS, cpart = g % SPS, row_o = bg * R + nloc;
+  const bool row_o_ok = row_o < N;
+  const int upp = (nu + SPS - 1) / SPS;
+  const int u0 = cpart * upp;
+  const int nown = max(0, min(upp, nu - u0));
+
+  // ---- weights: VGPR-resident MFMA fragments, rows = OUTPUT (context channel / hidden unit), K = this slice's 48 / 64 columns
+  Frag wicT[9][2], wcatT[8][2];
+  {
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    const int kc = g * DU + (lg & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int ch = (wave + 4 * i) * 16 + l15;
+      const bf16_t* p = a.ic_wt + (long long)ch * a.ldict + kc;
+      uint4 t0 = z4, t1 = z4;
+      if (ch < Ep) {
+        t0 = *(const uint4*)(p + (lg < 2 ? 0 : DH));
+        if (lg < 2) t1 = *(const uint4*)(p + 2 * DH);
+      }
+      wicT[i][0] = *(const Frag*)&t0;
+      wicT[i][1] = *(const Frag*)&t1;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int u = (wave + 4 * i) * 16 + l15;
+      const bf16_t* p = a.cat_wt + (long long)u * 4 * DH + kc;
+      wcatT[i][0] = *(const Frag*)(p + (lg < 2 ? 0 : DH));
+      wcatT[i][1] = *(const Frag*)(p + (lg < 2 ? 2 * DH : 3 * DH));
+    }
+  }
+  float vv[DU];
+#pragma unroll
+  for (int j = 0; j < DU; j += 4) {
+    const f32x4 t = *(const f32x4*)(a.v + g * DU + j);
+    vv[j] = t[0]; vv[j + 1] = t[1]; vv[j + 2] = t[2]; vv[j + 3] = t[3];
+  }
+  // ---- LDS residents
+  for (int p = tid; p < R * DT; p += 256) {
+    const int n = p >> 6, t = p & 63, r = bg * R + n;
+    uint4 e0 = make_uint4(0, 0, 0, 0), e1 = e0;
+    if (r < N && t < T) {
+      const bf16_t* ep = a.eproj + ((long long)r * T + t) * DH + g * DU;
+      e0 = *(const uint4*)ep;
+      e1 = *(const uint4*)(ep + 8);
+    }
+    sEp[p] = e0;
+    sEp[R * DT + p] = e1;
+  }
+  for (int i = tid; i < T * upp; i += 256) {
+    const int t = i / upp, u = i - t * upp;
+    uint2 e = make_uint2(0, 0);
+    if (row_o_ok && u < nown) e = *(const uint2*)(a.enc + ((long long)row_o * T + t) * Ep + (u0 + u) * 4);
+    *(uint2*)(sEnc + (long long)i * 4) = e;
+  }
+  for (int i = tid; i < 2 * 16 * GLD / 8; i += 256) ((uint4*)sDG)[i] = make_uint4(0, 0, 0, 0);   // sDG and sDHC (adjacent)
+  for (int i = tid; i < 288; i += 256) sDctx[i] = 0.f;
+  if (tid < 4) sDead[tid] = 0;
+
+  const rsrc_t rx = make_rsrc(a.xch);
+  const unsigned xg = (unsigned)bg * X::GROUP;
+  // GRU ownership: thread <-> (sample gm, unit gu of the slice)
+  const int gm = tid >> 4, gu = tid & 15, row_g = bg * R + gm, jg = g * DU + gu;
+  const bool gru_thread = gm < R;
+  const bool row_g_ok = gru_thread && row_g < N;
+  // edge C consumer: (producer group pg, sample cm, unit pair p8) -> R producers each
+  const int p8 = tid & 7, cm = (tid >> 3) & (R - 1), pgc = tid / (8 * R);
+  unsigned offA[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) offA[k] = (unsigned)((((pgc + SPS * k) * R + cm) * DH + g * DU + p8 * 2) * 8);
+  // edge A consumer: (producer group pga, channel pair pr of the share) -> up to CNT_D producers
+  const int npair = 2 * upp, PGA = 256 / npair;
+  const int pr = tid % npair, pga = tid / npair;
+  unsigned offD[X::CNT_D], wantD = 0;
+#pragma unroll
+  for (int k = 0; k < X::CNT_D; ++k) {
+    const int prod = pga + PGA * k;
+    offD[k] = (unsigned)(((prod * R + nloc) * DEPMAX + u0 * 4 + pr * 2) * 8);
+    if (pga < PGA && prod < DG && pr < 2 * nown) wantD |= 1u << k;
+  }
+  const int npga = min(PGA, DG);
+  // edge B consumer: lane = (half, position pair tp); samples wave + 4i
+  const int tp = lane & 31, half = lane >> 5;
+  float dacc[R / 4][DU], dvacc[DU];
+#pragma unroll
+  for (int q = 0; q < DU; ++q) {
+    dvacc[q] = 0.f;
+#pragma unroll
+    for (int i = 0; i < R / 4; ++i) dacc[i][q] = 0.f;
+  }
+  float dh_b = 0.f;
+  bool dead = false;
+  __syncthreads();
+
+  for (int it = 0; it < S; ++it) {
+    const int s = S - 1 - it;
+    const unsigned tag = (unsigned)(it + 1);
+    const unsigned slot = (unsigned)(it & 1);
+    // ---- operands that depend on nothing of the chain: in flight during the hand-off below
+    float sr = 0.f, sz = 0.f, sn = 0.f;
+    unsigned short ghn = 0, hpv = 0, dhc = 0, hpj = 0;
+    if (row_g_ok) {
+      const long long rn = (long long)s * N + row_g;
+      const float* sv = a.SAVE_all + rn * 3 * DH + jg;
+      sr = sv[0]; sz = sv[DH]; sn = sv[2 * DH];
+      const unsigned short* hc = (const unsigned short*)(a.HC_all + rn * 4 * DH);
+      hpj = hc[jg];
+      ghn = hc[DH + 2 * DH + jg];
+      hpv = ((const unsigned short*)a.H_all)[rn * DH + jg];
+      dhc = ((const unsigned short*)a.DHO_all)[rn * DH + jg];
+    }
+    float2 wat[R / 4];
+#pragma unroll
+    for (int i = 0; i < R / 4; ++i) {
+      const int r = bg * R + wave + 4 * i;
+      wat[i] = make_float2(0.f, 0.f);
+      if (r < N) {
+        const float* wp = a.W_att + ((long long)s * N + r) * T;
+        if (2 * tp < T) wat[i].x = wp[2 * tp];
+        if (2 * tp + 1 < T) wat[i].y = wp[2 * tp + 1];
+      }
+    }
+    // ---- edge C of the previous iteration: dh_a of the own units = sum over the 32 producers
+    float dh_a = 0.f;
+    if (it > 0) {
+      u32x4 av[R];
+      if (!dead && !gather_pairs<R>(rx, offA, xg + X::XA_OFF + (slot ^ 1u) * X::XA_SLOT, (1u << R) - 1u, tag - 1u, av)) {
+        dead = true;
+        if (lane == 0) { atomicMax(a.status, 4u); sDead[0] = 1; }
+      }
+      float s0 = 0.f, s1 = 0.f;
+      if (!dead) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) { s0 += __uint_as_float(av[k][0]); s1 += __uint_as_float(av[k][2]); }
+      }
+      *(float2*)(sRedA + (pgc * R + cm) * DU + p8 * 2) = make_float2(s0, s1);
+      __syncthreads();
+      if (gru_thread) {
+#pragma unroll
+        for (int k = 0; k < SPS; ++k) dh_a += sRedA[(k * R + gm) * DU + gu];
+      }
+    }
+    // ---- GRU backward of the own units
+    if (gru_thread) {
+      const float hn = bf16_lo(ghn), hp = bf16_lo(hpv);
+      float gsum = dh_a + dh_b + bf16_lo(dhc);
+      if (sDead[0] | sDead[1] | sDead[2]) gsum = __builtin_nanf("");
+      const float dn = gsum * (1.f - sz);
+      const float dz = gsum * (hp - sn);
+      const float dpre_n = dn * (1.f - sn * sn);
+      const float dr = dpre_n * hn;
+      const float dpre_r = dr * sr * (1.f - sr);
+      const float dpre_z = dz * sz * (1.f - sz);
+      dh_b = gsum * sz;
+      const bf16_t b_r = (bf16_t)dpre_r, b_z = (bf16_t)dpre_z, b_n = (bf16_t)dpre_n, b_nr = (bf16_t)(dpre_n * sr);
+      bf16_t* dg = sDG + gm * GLD;
+      dg[gu] = b_r; dg[16 + gu] = b_z; dg[32 + gu] = b_n;
+      bf16_t* dc = sDHC + gm * GLD;
+      dc[16 + gu] = b_r; dc[32 + gu] = b_z; dc[48 + gu] = b_nr;
+      sHp[gm * DU + gu] = bf16_lo(hpj);
+      if (row_g_ok) {
+        const long long rn = (long long)s * N + row_g;
+        bf16_t* o1 = a.DGI_all + rn * 3 * DH + jg;
+        o1[0] = b_r; o1[DH] = b_z; o1[2 * DH] = b_n;
+        bf16_t* o2 = a.DHC_all + rn * 4 * DH + DH + jg;
+        o2[0] = b_r; o2[DH] = b_z; o2[2 * DH] = b_nr;
+      }
+    }
+    __syncthreads();
+    // ---- partial dctx of every sample over the own 48 gate units -> edge A
+    {
+      const Frag a0 = *(const Frag*)(sDG + l15 * GLD + lg * 8);
+      const Frag a1 = *(const Frag*)(sDG + l15 * GLD + 32 + lg * 8);
+      const unsigned xd = xg + X::XD_OFF + slot * X::XD_SLOT + (unsigned)(((g * R + l15) * DEPMAX + lg * 4) * 8);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        Mma<bf16_t>::run(acc, wicT[i][0], a0);
+        Mma<bf16_t>::run(acc, wicT[i][1], a1);
+        const int c0 = (wave + 4 * i) * 16 + lg * 4;
+        if (l15 < R && c0 < Ep) {
+          const unsigned o = xd + (unsigned)((wave + 4 * i) * 16 * 8);
+          gran2_store(rx, o, __float_as_uint(acc[0]), __float_as_uint(acc[1]), tag);
+          gran2_store(rx, o + 16, __float_as_uint(acc[2]), __float_as_uint(acc[3]), tag);
+        }
+      }
+    }
+    // ---- reduce this slice's channel share of dctx[sample nloc] over the producers
+    {
+      u32x4 dvv[X::CNT_D];
+      if (!dead && !gather_pairs<X::CNT_D>(rx, offD, xg + X::XD_OFF + slot * X::XD_SLOT, wantD, tag, dvv)) {
+        dead = true;
+        if (lane == 0) { atomicMax(a.status, 5u); sDead[1] = 1; }
+      }
+      float s0 = 0.f, s1 = 0.f;
+      if (!dead) {
+#pragma unroll
+        for (int k = 0; k < X::CNT_D; ++k)
+          if ((wantD >> k) & 1u) { s0 += __uint_as_float(dvv[k][0]); s1 += __uint_as_float(dvv[k][2]); }
+      }
+      *(float2*)(sRedD + tid * 2) = make_float2(s0, s1);
+      __syncthreads();
+      if (tid < 4 * nown) {
+        float c = 0.f;
+        for (int k = 0; k < npga; ++k) c += sRedD[k * 2 * npair + tid];
+        const bf16_t cb = (bf16_t)c;
+        sDctx[tid] = (float)cb;
+        if (row_o_ok) a.DCTX_all[((long long)s * N + row_o) * Ep + u0 * 4 + tid] = cb;
+      }
+      __syncthreads();
+    }
+    // ---- partial dw[t] = dctx[share] . enc[t, share]  (wave = unit quarter, lane = position) -> edge B
+    {
+      const int uq = (nown + 3) >> 2, ub = wave * uq, ue = min(nown, ub + uq);
+      float d = 0.f;
+      if (lane < T) {
+        const bf16_t* er = sEnc + lane * upp * 4;
+        for (int u = ub; u < ue; ++u) {
+          const uint2 ev = *(const uint2*)(er + u * 4);
+          const f32x4 dc = *(const f32x4*)(sDctx + u * 4);
+          d += dc[0] * bf16_lo(ev.x) + dc[1] * bf16_hi(ev.x) + dc[2] * bf16_lo(ev.y) + dc[3] * bf16_hi(ev.y);
+        }
+      }
+      sDwP[wave * 64 + lane] = d;
+      __syncthreads();
+      if (tid < 32) {
+        float d0 = (sDwP[2 * tid] + sDwP[64 + 2 * tid]) + (sDwP[128 + 2 * tid] + sDwP[192 + 2 * tid]);
+        float d1 = (sDwP[2 * tid + 1] + sDwP[64 + 2 * tid + 1]) + (sDwP[128 + 2 * tid + 1] + sDwP[192 + 2 * tid + 1]);
+        if (a.ga && cpart == 0 && row_o_ok) {
+          const float* gp = a.ga + (long long)row_o * a.ldga + (long long)s * T;
+          if (2 * tid < T) d0 += gp[2 * tid];
+          if (2 * tid + 1 < T) d1 += gp[2 * tid + 1];
+        }
+        gran2_store(rx, xg + X::XW_OFF + slot * X::XW_SLOT + (unsigned)(((nloc * SPS + cpart) * DT + 2 * tid) * 8),
+                    __float_as_uint(d0), __float_as_uint(d1), tag);
+      }
+    }
+    // ---- dw of every sample = sum over its channel shares; softmax backward
+    {
+      constexpr int NB = (R / 4) * (SPS / 2);
+      unsigned offW[NB];
+      u32x4 wv[NB];
+#pragma unroll
+      for (int i = 0; i < R / 4; ++i)
+#pragma unroll
+        for (int k = 0; k < SPS / 2; ++k)
+          offW[i * (SPS / 2) + k] = (unsigned)((((wave + 4 * i) * SPS + half * (SPS / 2) + k) * DT + 2 * tp) * 8);
+      if (!dead && !gather_pairs<NB>(rx, offW, xg + X::XW_OFF + slot * X::XW_SLOT, (1u << NB) - 1u, tag, wv)) {
+        dead = true;
+        if (lane == 0) { atomicMax(a.status, 6u); sDead[2] = 1; }
+      }
+#pragma unroll
+      for (int i = 0; i < R / 4; ++i) {
+        float d0 = 0.f, d1 = 0.f;
+        if (!dead) {
+#pragma unroll
+          for (int k = 0; k < SPS / 2; ++k) {
+            d0 += __uint_as_float(wv[i * (SPS / 2) + k][0]);
+            d1 += __uint_as_float(wv[i * (SPS / 2) + k][2]);
+          }
+        }
+        d0 += __shfl_xor(d0, 32, 64);
+        d1 += __shfl_xor(d1, 32, 64);
+        // both halves of the wave hold the same pairs: the wave sum counts every position twice
+        const float dot = 0.5f * wave_sum_dpp(wat[i].x * d0 + wat[i].y * d1);
+        if (half == 0) *(float2*)(sDe + (wave + 4 * i) * 64 + 2 * tp) = make_float2(wat[i].x * (d0 - dot), wat[i].y * (d1 - dot));
+      }
+      __syncthreads();
+    }
+    // ---- tanh chain of the own units: dhproj (reduced over the positions), deproj / dv (accumulated over the steps)
+    {
+#pragma unroll
+      for (int i = 0; i < R / 4; ++i) {
+        const int n = wave + 4 * i, p = n * DT + lane;
+        const float de = sDe[p];
+        const uint4 e0 = sEp[p], e1 = sEp[R * DT + p];
+        const unsigned ew[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+        const float* hp = sHp + n * DU;
+        float mine = 0.f;
+#pragma unroll
+        for (int q = 0; q < DU; ++q) {
+          const float e = (q & 1) ? bf16_hi(ew[q >> 1]) : bf16_lo(ew[q >> 1]);
+          const float th = dec_tanh(hp[q] + e);
+          const float gg = de * vv[q] * (1.f - th * th);
+          dacc[i][q] += gg;
+          dvacc[q] += de * th;
+          const float tot = wave_sum_dpp(gg);
+          mine = l15 == q ? tot : mine;
+        }
+        if (lane < DU) {
+          const bf16_t hb = (bf16_t)mine;
+          sDHC[n * GLD + lane] = hb;
+          const int r = bg * R + n;
+          if (r < N) a.DHC_all[((long long)s * N + r) * 4 * DH + g * DU + lane] = hb;
+        }
+      }
+    }
+    if (s == 0) break;
+    __syncthreads();
+    // ---- partial dh_a of every sample over the own 64 stacked columns -> edge C
+    {
+      const Frag a0 = *(const Frag*)(sDHC + l15 * GLD + lg * 8);
+      const Frag a1 = *(const Frag*)(sDHC + l15 * GLD + 32 + lg * 8);
+      const unsigned xa = xg + X::XA_OFF + slot * X::XA_SLOT + (unsigned)(((g * R + l15) * DH + lg * 4) * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        Mma<bf16_t>::run(acc, wcatT[i][0], a0);
+        Mma<bf16_t>::run(acc, wcatT[i][1], a1);
+        if (l15 < R) {
+          const unsigned o = xa + (unsigned)((wave + 4 * i) * 16 * 8);
+          gran2_store(rx, o, __float_as_uint(acc[0]), __float_as_uint(acc[1]), tag);
+          gran2_store(rx, o + 16, __float_as_uint(acc[2]), __float_as_uint(acc[3]), tag);
+        }
+      }
+    }
+  }
+  // ---- the accumulated gradients of eproj (own 16 columns) and v
+#pragma unroll
+  for (int i = 0; i < R / 4; ++i) {
+    const int r = bg * R + wave + 4 * i;
+    if (r < N && lane < T) {
+      float* dp = a.deproj + ((long long)r * T + lane) * DH + g * DU;
+#pragma unroll
+      for (int q = 0; q < DU; q += 4) *(f32x4*)(dp + q) = f32x4{dacc[i][q], dacc[i][q + 1], dacc[i][q + 2], dacc[i][q + 3]};
+    }
+  }
+  {
+    float mine = 0.f;
+#pragma unroll
+    for (int q = 0; q < DU; ++q) {
+      const float tot = wave_sum_dpp(dvacc[q]);
+      mine = l15 == q ? tot : mine;
+    }
+    if (lane < DU) atomicAdd(a.dv + g * DU + lane, mine);
+  }
+}
+
+namespace {
+// rows per batch group: 4 while the grid (32 workgroups per group, ONE per CU: 460+ registers a lane) stays within the 256 CUs,
+// else 8.  The bytes a workgroup gathers per hand-off scale with the rows: 4-row groups run a step in 8.3 us forward / 12.3 us
+// backward, 8-row groups in 10.6 / 21 us (the backward then spills).  All workgroups of a group must be co-resident; workgroups that
+// are dispatched late (a kernel of another stream still holds their CU) only delay their group -- every wait is bounded.
+int decode_rows(int N) { return N <= 32 ? 4 : 8; }
+unsigned decode_group_bytes(int R) { return R == 4 ? Xch<4>::GROUP : Xch<8>::GROUP; }
 long long decode_ws_bytes(int N) {
   const int R = decode_rows(N);
   return (long long)cdiv(N, R) * decode_group_bytes(R) + 256;
@@ -514,6 +950,29 @@ int decode_launch(const DecP& a, hipStream_t stream) {
     attr_set[dev] = true;
   }
   hipLaunchKernelGGL(decode_fwd_persist_kernel<R>, dim3(a.nbg * DG), dim3(256), Lds<R>::bytes(a.T, a.Ep), stream, a);
+  MR_CHECK_LAUNCH();
+  return MR_OK;
+}
+unsigned decode_bwd_group_bytes(int) { return XchB<4>::GROUP; }
+long long decode_bwd_ws_bytes(int N) {
+  const int R = decode_rows(N);
+  return (long long)cdiv(N, R) * decode_bwd_group_bytes(R) + 256;
+}
+
+template <int R>
+int decode_bwd_launch(const DecB& a, hipStream_t stream) {
+  static bool attr_set[MR_MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev >= 0 && dev < MR_MAX_DEVICES && !attr_set[dev]) {
+    if (hipFuncSetAttribute((const void*)decode_bwd_persist_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LdsB<R>::bytes(DT, DEPMAX)) != hipSuccess) {
+      set_error("mr_decode_persist_bwd: cannot raise the dynamic LDS limit");
+      return MR_ERR_LAUNCH;
+    }
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(decode_bwd_persist_kernel<R>, dim3(a.nbg * DG), dim3(256), LdsB<R>::bytes(a.T, a.Ep), stream, a);
   MR_CHECK_LAUNCH();
   return MR_OK;
 }
@@ -552,7 +1011,43 @@ int mr_decode_persist_fwd(const void* cat_w, const float* cat_b, const void* ic_
   DecP a{(const bf16_t*)cat_w, cat_b, (const bf16_t*)ic_w, ldic, (const bf16_t*)G, ldG, idx, (const bf16_t*)eproj,
          (const bf16_t*)enc, v, (bf16_t*)H_all, (bf16_t*)HC_all, W_att, (bf16_t*)CTX_all, SAVE_all, (u64*)ws,
          (unsigned*)((char*)ws + (long long)nbg * decode_group_bytes(R)), S, N, T, Ep, nbg};
-  return R == 4 ? decode_launch<4>(a, stream) : R == 8 ? decode_launch<8>(a, stream) : decode_launch<16>(a, stream);
+  return R == 4 ? decode_launch<4>(a, stream) : decode_launch<8>(a, stream);
+}
+
+// host only: the persistent BACKWARD of the loop (groups of 4 rows only: N <= 32)
+int mr_decode_persist_bwd_ok(int dtype, int N, int T, int H, int Ep) {
+  return (N <= 32 && mr_decode_persist_ok(dtype, N, T, H, Ep)) ? 1 : 0;
+}
+
+long long mr_decode_persist_bwd_ws_bytes(int N) { return N <= 32 ? decode_bwd_ws_bytes(N) : 0; }
+
+// All S steps of the decode loop's backward (in reverse) in one launch -- what the per-step mr_gemm_gru_bwd / mr_gru_bwd2 +
+// mr_gemm_nt + mr_attn_bwd2 launches compute.  cat_wt [H][4H] and ic_wt [Ep][ldict >= 3H] are the TRANSPOSED weight images
+// (row = output of the backward GEMM); DHO_all [S][N][H] = gradient of every h' from the output layer; ga (nullable) = gradient
+// of the attention weights, element (n, s, t) at ga[n * ldga + s * T + t].  Writes DGI_all [S][N][3H], DHC_all [S][N][4H],
+// DCTX_all [S][N][Ep], deproj [N][T][H] (f32, plain stores) and ADDS into dv [H] (f32).  ws as mr_decode_persist_fwd
+// (mr_decode_persist_bwd_ws_bytes).
+int mr_decode_persist_bwd(const void* cat_wt, const void* ic_wt, long long ldict, const void* eproj, const void* enc,
+                          const float* v, const void* H_all, const void* HC_all, const float* W_att, const float* SAVE_all,
+                          const void* DHO_all, const float* ga, long long ldga, void* DGI_all, void* DHC_all, void* DCTX_all,
+                          float* deproj, float* dv, void* ws, long long ws_bytes, int S, int N, int T, int Ep,
+                          hipStream_t stream) {
+  const bool prezeroed = ws_bytes < 0;
+  if (prezeroed) ws_bytes = -ws_bytes;
+  MR_CHECK_ARG(S >= 1 && N >= 1 && N <= 32 && T >= 1 && T <= DT && Ep >= 8 && Ep <= DEPMAX && Ep % 8 == 0 && ldict >= 3 * DH,
+               "mr_decode_persist_bwd: bad shape S=%d N=%d T=%d Ep=%d", S, N, T, Ep);
+  MR_CHECK_ARG(ws_bytes >= decode_bwd_ws_bytes(N), "mr_decode_persist_bwd: workspace too small (%lld < %lld)", ws_bytes,
+               decode_bwd_ws_bytes(N));
+  const int R = decode_rows(N), nbg = cdiv(N, R);
+  if (!prezeroed && hipMemsetAsync(ws, 0, (size_t)decode_bwd_ws_bytes(N), stream) != hipSuccess) {
+    set_error("mr_decode_persist_bwd: memset of the exchange buffer failed");
+    return MR_ERR_LAUNCH;
+  }
+  DecB a{(const bf16_t*)cat_wt, (const bf16_t*)ic_wt, ldict, (const bf16_t*)eproj, (const bf16_t*)enc, v,
+         (const bf16_t*)H_all, (const bf16_t*)HC_all, W_att, SAVE_all, (const bf16_t*)DHO_all, ga, ldga, (bf16_t*)DGI_all,
+         (bf16_t*)DHC_all, (bf16_t*)DCTX_all, deproj, dv, (u64*)ws,
+         (unsigned*)((char*)ws + (long long)nbg * decode_bwd_group_bytes(R)), S, N, T, Ep, nbg};
+  return decode_bwd_launch<4>(a, stream);
 }
 
 }  // extern "C"

@@ -45,17 +45,19 @@ FUSED_STEP = os.environ.get("MEGREADER_DECODE_FUSED", "1") != "0"
 # behind the loop instead of a launch per step on the chain (32 launches, ~0.23 ms of the FPN step).  MEGREADER_DECODE_BATCHED_OUT=0
 # keeps the per-step launches (A/B); random coins (the YAML default) and `gt_as_output=False` always take the per-step path.
 BATCHED_OUT = os.environ.get("MEGREADER_DECODE_BATCHED_OUT", "1") != "0"
-# round 6: the teacher-forced forward loop as one persistent launch (mr_decode_persist_fwd; also mr_tuning.decode_persist).
-# MEGREADER_DECODE_PERSIST=0 keeps the three launches per step.
-PERSIST = os.environ.get("MEGREADER_DECODE_PERSIST", "1") != "0"
+# round 6: the teacher-forced forward loop and the backward loop as one persistent launch each (mr_decode_persist_fwd / _bwd; also
+# mr_tuning.decode_persist).  MEGREADER_DECODE_PERSIST=0 keeps the three launches per step; "fwd" / "bwd" switch one side on.
+_PERSIST_ENV = os.environ.get("MEGREADER_DECODE_PERSIST", "1")       # "0" | "1" | "fwd" | "bwd"
+PERSIST = _PERSIST_ENV in ("1", "fwd")
+PERSIST_BWD = _PERSIST_ENV in ("1", "bwd")
 
 
-def _persist_workspace(N, dev):
-    """(exchange buffer, size argument) of mr_decode_persist_fwd: zero at launch -- from the pre-zeroed arena (size passed NEGATIVE)
+def _persist_workspace(N, dev, backward=False):
+    """(exchange buffer, size argument) of mr_decode_persist_fwd / _bwd: zero at launch -- from the pre-zeroed arena (size passed NEGATIVE)
     or, when that is exhausted, from torch's allocator (the C call zeroes it).  The status word (last 256 bytes) joins the list
     nn.functional.LSTM_STATUS collects for tests and bench.py."""
     from ..nn import functional as F_
-    nbytes = load().mr_decode_persist_ws_bytes(N)
+    nbytes = load().mr_decode_persist_bwd_ws_bytes(N) if backward else load().mr_decode_persist_ws_bytes(N)
     size = nbytes
     arena = F_.ZeroArena.take(dev, (nbytes + 7) // 8)
     if arena is not None:
@@ -429,7 +431,16 @@ class _DecodeLoopFn(Function):
         DHO_all = torch.empty((S, N, Hd), dtype=dtype, device=dev)
         call("mr_gemm_nt", dt, ptr(DL_all), out.np_, ptr(out.w_t), out.np_, ptr(DHO_all), Hd, 0, 0, S * N, Hd, out.np_)
         fused = FUSED_STEP and N <= 32
-        for s in range(S - 1, -1, -1):
+        # round 6: the whole reverse loop as ONE persistent launch (csrc/decode_persist.hip); nothing in it depends on how the
+        # forward chose the fed words, so it serves teacher forcing and arg-max feedback alike
+        persist = (fused and PERSIST_BWD and dtype == torch.bfloat16 and Ep % 8 == 0 and ic.np_ == H3 and cat.np_ == HC
+                   and bool(load().mr_decode_persist_bwd_ok(dt, N, T, Hd, Ep)))
+        if persist:
+            ws, ws_size = _persist_workspace(N, dev, backward=True)
+            call("mr_decode_persist_bwd", ptr(cat.w_t), ptr(ic.w_t), H3, ptr(eproj), ptr(enc), ptr(vf), ptr(H_all), ptr(HC_all),
+                 ptr(W_att), ptr(SAVE_all), ptr(DHO_all), ptr(ga) if ga is not None else 0, S * T, ptr(DGI_all), ptr(DHC_all),
+                 ptr(DCTX_all), ptr(deproj), ptr(dv), ptr(ws), ws_size, S, N, T, Ep)
+        for s in range(-1 if persist else S - 1, -1, -1):
             last = s == S - 1
             if fused and not last:
                 # round 4: the GEMM that sends the next step's stacked-projection gradient back to h' carries this step's

@@ -61,3 +61,30 @@ for g_ in (0, 1):
     print("slice %d (%s): " % (g_, "owner" if g_ == 0 else "non-owner") +
           "  ".join("%s %.2f" % (n, x) for n, x in zip(names, v)) + "   sum %.2f us/step" % sum(v))
 print("status", int(st[0]))
+
+# ---- backward
+fw = t._per_step(d, N, T, Ep, S)
+x = t._bwd_inputs(d, fw, N, T, Ep, S, seed=3, with_ga=False)
+gb = torch.cuda.CUDAGraph()
+with torch.cuda.stream(s_):
+    t._bwd_per_step(d, fw, x, N, T, Ep, S)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(gb, stream=s_):
+        t._bwd_per_step(d, fw, x, N, T, Ep, S)
+us = timed(gb.replay)
+print("backward per-step launches (graph replay): %.1f us  = %.2f us/step" % (us, us / S))
+bb = t._bwd_buffers(N, T, Ep, S)
+nb = load().mr_decode_persist_bwd_ws_bytes(N)
+wsb = torch.zeros((nb,), dtype=torch.uint8, device="cuda")
+
+
+def persistent_bwd():
+    wsb.zero_()
+    call("mr_decode_persist_bwd", ptr(x["cat_wt"]), ptr(x["ic_wt"]), 3 * H, ptr(d["eproj"]), ptr(d["enc"]), ptr(d["v"]),
+         ptr(fw["H_all"]), ptr(fw["HC_all"]), ptr(fw["W_att"]), ptr(fw["SAVE_all"]), ptr(x["DHO"]), 0, S * T, ptr(bb["DGI"]),
+         ptr(bb["DHC"]), ptr(bb["DCTX"]), ptr(bb["deproj"]), ptr(bb["dv"]), ptr(wsb), -nb, S, N, T, Ep)
+
+
+us = timed(persistent_bwd)
+print("backward persistent (incl. ws memset)     : %.1f us  = %.2f us/step" % (us, us / S))
+print("status", int(wsb[nb - 256:].view(torch.int32)[0]))
