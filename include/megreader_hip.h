@@ -626,7 +626,7 @@ int mr_gru_bwd2(int dtype, const void* dh_a, const void* dh_b, const void* dh_c,
 int mr_rows_scatter_add(int dtype, const long long* idx, const void* rows, long long ldr, float* dtable, int R, int V,
                         int D, hipStream_t stream);
 
-/* Persistent forward of the teacher-forced attention-GRU decode loop (reference decoders/attention_decoder.py:84-118 around
+/* Persistent forward of the attention-GRU decode loop (reference decoders/attention_decoder.py:84-118 around
  * AttentionRNNCell :146-231): all S steps in ONE launch of ceil(N/16) x 32 co-resident workgroups; the stacked hidden projection
  * [4H][H] (attention hidden half + W_hh), the context columns of W_ih and the encoder rows stay in registers / LDS for the whole
  * sequence and the three per-step hand-offs (partial energies -> owners, contexts, h') go through tagged 8-byte granules
@@ -634,14 +634,17 @@ int mr_rows_scatter_add(int dtype, const long long* idx, const void* rows, long 
  * [classes][ldG >= 3H] gathered by idx [S][N] (the word fed to each step), eproj [N][T][H], enc [N][T][Ep], v [H] f32.
  * Writes what the per-step path (mr_gemm_nt + mr_attn_fwd2 + mr_gemm_gru_fwd) saves for the backward: H_all [S+1][N][H]
  * (H_all[0] = the initial state, read), HC_all [S][N][4H], W_att [S][N][T] f32, CTX_all [S][N][Ep], SAVE_all [S][N][3H] f32.
+ * flags null: every step is fed the word idx[s] (teacher forcing).  flags [S] int32 on the device (the per-step coins of
+ * attention_decoder.py:107-110): where flags[s] == 0, step s + 1 is fed the arg-max of step s's output layer out_w [C][H] / out_b
+ * (f32, nullable), C <= 256, first index on ties as mr_out_nll_fwd -- and the kernel WRITES that word to idx[s + 1].
  * ws: exchange workspace of mr_decode_persist_ws_bytes(N) bytes, zeroed by the call (ws_bytes > 0) or by the caller (pass the
  * size NEGATIVE).  A hand-off that times out records a code in the status word behind the workspace and poisons h' with NaN. */
 int mr_decode_persist_ok(int dtype, int N, int T, int H, int Ep);   /* host only; 0 also when mr_tuning.decode_persist = 0 */
 long long mr_decode_persist_ws_bytes(int N);                        /* host only */
 int mr_decode_persist_fwd(const void* cat_w, const float* cat_b, const void* ic_w, long long ldic, const void* G, long long ldG,
-                          const long long* idx, const void* eproj, const void* enc, const float* v, void* H_all, void* HC_all,
-                          float* W_att, void* CTX_all, float* SAVE_all, void* ws, long long ws_bytes, int S, int N, int T,
-                          int Ep, hipStream_t stream);
+                          long long* idx, const int* flags, const void* out_w, const float* out_b, int C, const void* eproj,
+                          const void* enc, const float* v, void* H_all, void* HC_all, float* W_att, void* CTX_all,
+                          float* SAVE_all, void* ws, long long ws_bytes, int S, int N, int T, int Ep, hipStream_t stream);
 /* ... and its backward: all S steps in reverse in one launch -- what mr_gemm_gru_bwd / mr_gru_bwd2 + mr_gemm_nt + mr_attn_bwd2 compute
  * per step (N <= 32).  cat_wt [H][4H] and ic_wt [Ep][ldict >= 3H] are the TRANSPOSED weight images (row = output of the backward
  * GEMM, K = stacked column / gate unit); DHO_all [S][N][H] = gradient of every h' from the output layer; ga (nullable) = gradient

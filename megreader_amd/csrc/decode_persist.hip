@@ -56,8 +56,9 @@ struct Xch {
   static constexpr unsigned XS_SLOT = DG * R * DT * 8;           // partial energies: [producer][sample][position] {f32, tag}
   static constexpr unsigned XC_SLOT = R * (DEPMAX / 4) * 16;     // contexts: [sample][4-channel unit] {bf16x2, tag} x 2
   static constexpr unsigned XH_SLOT = R * (DH / 4) * 16;         // hidden:   [sample][4-unit unit]
-  static constexpr unsigned XS_OFF = 0, XC_OFF = 2 * XS_SLOT, XH_OFF = XC_OFF + 2 * XC_SLOT;
-  static constexpr unsigned GROUP = XH_OFF + 2 * XH_SLOT;
+  static constexpr unsigned XL_SLOT = R * DG * 16;               // best class: [sample][slice] {logit, tag, class, tag}
+  static constexpr unsigned XS_OFF = 0, XC_OFF = 2 * XS_SLOT, XH_OFF = XC_OFF + 2 * XC_SLOT, XL_OFF = XH_OFF + 2 * XH_SLOT;
+  static constexpr unsigned GROUP = XL_OFF + 2 * XL_SLOT;
   static constexpr int CNT_C = (R * (DEPMAX / 4) + 255) / 256;   // 16-byte pairs per thread of the context gather
   static constexpr int CNT_H = R * (DH / 4) / 256;               // ... of the hidden gather
 };
@@ -144,7 +145,12 @@ struct DecP {
   long long ldic;
   const bf16_t* G;         // word table [classes][ldG >= 3H] (W_ih word part + b_ih, gathered by idx)
   long long ldG;
-  const long long* idx;    // [S][N] word fed to each step
+  long long* idx;          // [S][N] word fed to each step (flags != null: rows of arg-max steps are WRITTEN by the kernel)
+  const int* flags;        // [S] or null (= every step is fed the word in idx).  flags[s] == 0: step s + 1 is fed the arg-max of
+                           // step s's output layer (attention_decoder.py:107-110) instead of idx[s + 1]
+  const bf16_t* out_w;     // [C][H] output layer (flags != null), C <= 256: slice g scores the classes [8g, 8g + 8)
+  const float* out_b;      // [C] or null
+  int C;
   const bf16_t* eproj;     // [N][T][H]
   const bf16_t* enc;       // [N][T][Ep]
   const float* v;          // [H]
@@ -167,7 +173,8 @@ struct Lds {
   static constexpr int GI = HC + 4 * 16 * DU * 4;                 // f32 [3 gates][16 rows][16 units]
   static constexpr int SC = GI + 3 * 16 * DU * 4;                 // f32 [8][64] partial energies, [64] weights
   static constexpr int DEAD = SC + 9 * 64 * 4;                    // int [4]
-  static constexpr int CTX = DEAD + 16;                           // bf16 [16][CLD]   (rows >= R, columns >= Ep stay zero)
+  static constexpr int WORD = DEAD + 16;                          // int [16] fed word of each row (arg-max steps)
+  static constexpr int CTX = WORD + 64;                           // bf16 [16][CLD]   (rows >= R, columns >= Ep stay zero)
   static constexpr int ENC = CTX + 16 * CLD * 2;                  // bf16 [T][4 * upp]: this slice's channel share of its sample
   static size_t bytes(int T, int Ep) {
     const int upp = cdiv(Ep / 4, DG / R);
@@ -190,6 +197,7 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
   float* sGI = (float*)(smem + L::GI);
   float* sSc = (float*)(smem + L::SC);
   int* sDead = (int*)(smem + L::DEAD);
+  int* sWord = (int*)(smem + L::WORD);
   bf16_t* sCtx = (bf16_t*)(smem + L::CTX);
   bf16_t* sEnc = (bf16_t*)(smem + L::ENC);
 
@@ -219,11 +227,25 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
     for (int c = 0; c < 16; ++c) wcat[c] = *(const Frag*)(p + c * 32);
     const uint4 z4 = make_uint4(0, 0, 0, 0);
     const bf16_t* q = a.ic_w + (long long)((wave < 3 ? wave : 0) * DH + g * DU + l15) * a.ldic + lg * 8;
+    // wave 3 has no W_ic tile: with arg-max feedback its fragments hold the slice's 8 rows of the output layer instead
+    const int cls = g * 8 + l15;
+    const bool out_row = a.flags != nullptr && wave == 3 && l15 < 8 && cls < a.C;
+    const bf16_t* qo = a.out_w + (long long)(out_row ? cls : 0) * DH + lg * 8;
 #pragma unroll
     for (int c = 0; c < 18; ++c) {
       uint4 t = z4;
       if (wave < 3 && c * 32 + lg * 8 < Ep) t = *(const uint4*)(q + c * 32);
+      if (out_row && c < 16) t = *(const uint4*)(qo + c * 32);
       wic[c] = *(const Frag*)&t;
+    }
+  }
+  const bool coin = a.flags != nullptr;
+  f32x4 obias = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // classes that do not exist never win
+  if (coin && wave == 3 && lg < 2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = g * 8 + lg * 4 + q;
+      if (c < a.C) obias[q] = a.out_b ? a.out_b[c] : 0.f;
     }
   }
   const int colbase = (wave == 0 ? 0 : DH + (wave - 1) * DH) + g * DU + lg * 4;   // first of this lane's 4 W_cat columns
@@ -311,16 +333,42 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
   for (int s = 0; s < S; ++s) {
     const unsigned tag = (unsigned)(s + 1);
     const unsigned slot = (unsigned)(s & 1);
-    if (row_g_ok && s + 1 < S) widx = a.idx[(long long)(s + 1) * N + row_g];     // used after the context hand-off
+    // arg-max feedback: is the word of THIS step the arg-max of the previous step's output layer?  (uniform)
+    const bool fed_argmax = coin && s > 0 && a.flags[s - 1] == 0;
+    if (coin) {
+      if (row_g_ok) widx = a.idx[(long long)s * N + row_g];                        // the given word (ignored on arg-max steps)
+    } else if (row_g_ok && s + 1 < S) {
+      widx = a.idx[(long long)(s + 1) * N + row_g];                                // used after the context hand-off
+    }
     // ---- 1. stacked hidden projection of the slice's units: [16 rows] x [this wave's 16 columns of W_cat]
     {
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, lo0 = acc0, lo1 = acc0;
+      const bool do_logits = fed_argmax && wave == 3;      // h in LDS is h' of the previous step: its output layer, 8 classes
 #pragma unroll
       for (int c = 0; c < 16; c += 2) {
         const Frag h0 = *(const Frag*)(hbuf + l15 * HLD + c * 32 + lg * 8);
         const Frag h1 = *(const Frag*)(hbuf + l15 * HLD + c * 32 + 32 + lg * 8);
         Mma<bf16_t>::run(acc0, wcat[c], h0);      // D[column][row]: this lane = 4 consecutive columns of row l15
         Mma<bf16_t>::run(acc1, wcat[c + 1], h1);
+        if (do_logits) {
+          Mma<bf16_t>::run(lo0, wic[c], h0);
+          Mma<bf16_t>::run(lo1, wic[c + 1], h1);
+        }
+      }
+      if (do_logits) {
+        // best class of this slice for sample l15 (first index wins ties, as mr_out_nll_fwd): lanes lg = 0 / 1 hold 4 classes each
+        const f32x4 lgt = (lo0 + lo1) + obias;
+        float bv = lgt[0];
+        int bc = g * 8 + lg * 4;
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+          if (lgt[q] > bv) { bv = lgt[q]; bc = g * 8 + lg * 4 + q; }
+        const float ov = __shfl_xor(bv, 16, 64);
+        const int oc = __shfl_xor(bc, 16, 64);
+        if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
+        if (lg == 0 && l15 < R)
+          gran2_store(rx, xg + X::XL_OFF + slot * X::XL_SLOT + (unsigned)((l15 * DG + g) * 16), __float_as_uint(bv), (unsigned)bc,
+                      tag);
       }
       const f32x4 acc = acc0 + acc1;
       const unsigned p01 = pack_bf16(acc[0] + cbias[0], acc[1] + cbias[1]);
@@ -354,12 +402,46 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
     DEC_TICK(1)
     // ---- 2. reduce the partials of this slice's sample, softmax, context of its channel share
     {
-      u32x4 pv[4];
-      if (!dead && !gather_pairs<4>(rx, offS, xg + X::XS_OFF + slot * X::XS_SLOT, 0xfu, tag, pv)) {
+      u32x4 pv[5];
+      unsigned offS5[5] = {offS[0], offS[1], offS[2], offS[3], 0u};
+      // arg-max steps: the 32 slices' best classes of every sample ride in the same sweep (thread <-> (sample, slice))
+      offS5[4] = (X::XL_OFF + slot * X::XL_SLOT + (unsigned)tid * 16u) - (X::XS_OFF + slot * X::XS_SLOT);
+      const unsigned wantS = 0xfu | ((fed_argmax && tid < R * DG) ? 0x10u : 0u);
+      pv[4] = u32x4{0u, 0u, 0u, 0u};
+      if (!dead && !gather_pairs<5>(rx, offS5, xg + X::XS_OFF + slot * X::XS_SLOT, wantS, tag, pv)) {
         dead = true;
         if (lane == 0) { atomicMax(a.status, 1u); sDead[0] = 1; }
       }
       DEC_TICK(2)
+      if (fed_argmax && tid < R * DG) {         // (whole waves: R * 32 threads)
+        // arg-max over the 32 slices of a sample = over a half wave: doubling shifts inside the rows of 16, then the two rows
+        float bv = __uint_as_float(pv[4][0]);
+        int bc = (int)pv[4][2];
+#define DEC_ARGMAX_STEP(CTRL)                                                                                   \
+  {                                                                                                             \
+    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, bv),         \
+                                                                           __builtin_bit_cast(int, bv), CTRL, 0xf, 0xf, false)); \
+    const int oc = __builtin_amdgcn_update_dpp(bc, bc, CTRL, 0xf, 0xf, false);                                  \
+    if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }                                                 \
+  }
+        DEC_ARGMAX_STEP(0x111) DEC_ARGMAX_STEP(0x112) DEC_ARGMAX_STEP(0x114) DEC_ARGMAX_STEP(0x118)
+#undef DEC_ARGMAX_STEP
+        const int hb = lane & 32;
+        const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 15));
+        const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 31));
+        const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 47));
+        const float v3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 63));
+        const int c0 = __builtin_amdgcn_readlane(bc, 15), c1 = __builtin_amdgcn_readlane(bc, 31);
+        const int c2 = __builtin_amdgcn_readlane(bc, 47), c3 = __builtin_amdgcn_readlane(bc, 63);
+        const float va = hb ? v2 : v0, vb = hb ? v3 : v1;
+        const int ca = hb ? c2 : c0, cb = hb ? c3 : c1;
+        const int word = (vb > va || (vb == va && cb < ca)) ? cb : ca;
+        if ((lane & 31) == 0) {
+          const int r = tid >> 5;
+          sWord[r] = dead ? 0 : word;
+          if (g == 0 && bg * R + r < N) a.idx[(long long)s * N + bg * R + r] = dead ? 0 : word;
+        }
+      }
       float s0 = 0.f, s1 = 0.f;
       if (!dead) {
 #pragma unroll
@@ -370,6 +452,11 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
         *(float2*)(sSc + pg * 64 + tp * 2) = make_float2(s0, s1);
       }
       __syncthreads();
+      if (coin && row_g_ok) {                 // the word rows of this step's input gates: known only now on arg-max steps
+        const long long w = fed_argmax ? (long long)sWord[gm] : widx;
+        const unsigned short* gp = (const unsigned short*)(a.G + w * a.ldG + jg);
+        gw[0] = gp[0]; gw[1] = gp[DH]; gw[2] = gp[2 * DH];
+      }
       {
         // every wave runs the 64-wide softmax redundantly (lane t of every wave holds w_t): no barrier before the context sum
         float e = 0.f;
@@ -449,7 +536,7 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
         sv[0] = r; sv[DH] = z; sv[2 * DH] = nn_;
       }
       if (!row_g_ok) hnew = 0.f;
-      if (row_g_ok && s + 1 < S) {        // the next step's word rows: a whole step to arrive
+      if (!coin && row_g_ok && s + 1 < S) {        // the next step's word rows: a whole step to arrive
         const unsigned short* gp = (const unsigned short*)(a.G + widx * a.ldG + jg);
         gw[0] = gp[0]; gw[1] = gp[DH]; gw[2] = gp[2 * DH];
       }
@@ -679,6 +766,16 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
   float dh_b = 0.f;
   bool dead = false;
   __syncthreads();
+  // phase clock, as in the forward kernel
+  const bool timing = tid == 0 && bg == 0 && g < 2 && a.status[2] == TIMING_MAGIC;
+  unsigned long long tprev = timing ? wall_clock64() : 0ull;
+  unsigned tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define DEC_TICK(i)                                   \
+  if (timing) {                                       \
+    const unsigned long long tn_ = wall_clock64();    \
+    tacc[i] += (unsigned)(tn_ - tprev);               \
+    tprev = tn_;                                      \
+  }
 
   for (int it = 0; it < S; ++it) {
     const int s = S - 1 - it;
@@ -728,6 +825,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         for (int k = 0; k < SPS; ++k) dh_a += sRedA[(k * R + gm) * DU + gu];
       }
     }
+    DEC_TICK(0)
     // ---- GRU backward of the own units
     if (gru_thread) {
       const float hn = bf16_lo(ghn), hp = bf16_lo(hpv);
@@ -755,6 +853,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
       }
     }
     __syncthreads();
+    DEC_TICK(1)
     // ---- partial dctx of every sample over the own 48 gate units -> edge A
     {
       const Frag a0 = *(const Frag*)(sDG + l15 * GLD + lg * 8);
@@ -773,6 +872,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         }
       }
     }
+    DEC_TICK(2)
     // ---- reduce this slice's channel share of dctx[sample nloc] over the producers
     {
       u32x4 dvv[X::CNT_D];
@@ -780,6 +880,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         dead = true;
         if (lane == 0) { atomicMax(a.status, 5u); sDead[1] = 1; }
       }
+      DEC_TICK(3)
       float s0 = 0.f, s1 = 0.f;
       if (!dead) {
 #pragma unroll
@@ -797,6 +898,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
       }
       __syncthreads();
     }
+    DEC_TICK(4)
     // ---- partial dw[t] = dctx[share] . enc[t, share]  (wave = unit quarter, lane = position) -> edge B
     {
       const int uq = (nown + 3) >> 2, ub = wave * uq, ue = min(nown, ub + uq);
@@ -823,6 +925,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
                     __float_as_uint(d0), __float_as_uint(d1), tag);
       }
     }
+    DEC_TICK(5)
     // ---- dw of every sample = sum over its channel shares; softmax backward
     {
       constexpr int NB = (R / 4) * (SPS / 2);
@@ -837,6 +940,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         dead = true;
         if (lane == 0) { atomicMax(a.status, 6u); sDead[2] = 1; }
       }
+      DEC_TICK(6)
 #pragma unroll
       for (int i = 0; i < R / 4; ++i) {
         float d0 = 0.f, d1 = 0.f;
@@ -855,6 +959,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
       }
       __syncthreads();
     }
+    DEC_TICK(7)
     // ---- tanh chain of the own units: dhproj (reduced over the positions), deproj / dv (accumulated over the steps)
     {
 #pragma unroll
@@ -883,6 +988,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         }
       }
     }
+    DEC_TICK(8)
     if (s == 0) break;
     __syncthreads();
     // ---- partial dh_a of every sample over the own 64 stacked columns -> edge C
@@ -902,7 +1008,13 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         }
       }
     }
+    DEC_TICK(9)
   }
+  if (timing) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) a.status[8 + 16 * g + i] = tacc[i];
+  }
+#undef DEC_TICK
   // ---- the accumulated gradients of eproj (own 16 columns) and v
 #pragma unroll
   for (int i = 0; i < R / 4; ++i) {
@@ -990,17 +1102,21 @@ int mr_decode_persist_ok(int dtype, int N, int T, int H, int Ep) {
 
 long long mr_decode_persist_ws_bytes(int N) { return decode_ws_bytes(N); }
 
-// All S teacher-forced steps of the attention-GRU decode loop in one launch (see the file header).  idx [S][N] = the word fed
-// to each step; H_all[0] = the initial state.  ws_bytes negative: the caller already zeroed the workspace.
+// All S steps of the attention-GRU decode loop in one launch (see the file header).  idx [S][N] = the word fed to each step;
+// H_all[0] = the initial state.  flags null: every step is fed idx[s].  flags [S] (device): where flags[s] == 0, step s + 1 is fed
+// the arg-max of step s's output layer out_w [C][H] / out_b (C <= 256) instead, and the kernel WRITES that word to idx[s + 1].
+// ws_bytes negative: the caller already zeroed the workspace.
 int mr_decode_persist_fwd(const void* cat_w, const float* cat_b, const void* ic_w, long long ldic, const void* G, long long ldG,
-                          const long long* idx, const void* eproj, const void* enc, const float* v, void* H_all, void* HC_all,
-                          float* W_att, void* CTX_all, float* SAVE_all, void* ws, long long ws_bytes, int S, int N, int T,
-                          int Ep, hipStream_t stream) {
+                          long long* idx, const int* flags, const void* out_w, const float* out_b, int C, const void* eproj,
+                          const void* enc, const float* v, void* H_all, void* HC_all, float* W_att, void* CTX_all,
+                          float* SAVE_all, void* ws, long long ws_bytes, int S, int N, int T, int Ep, hipStream_t stream) {
   const bool prezeroed = ws_bytes < 0;
   if (prezeroed) ws_bytes = -ws_bytes;
   MR_CHECK_ARG(S >= 1 && N >= 1 && N <= 64 && T >= 1 && T <= DT && Ep >= 8 && Ep <= DEPMAX && Ep % 8 == 0 && ldic >= Ep &&
                    ldG >= 3 * DH,
                "mr_decode_persist_fwd: bad shape S=%d N=%d T=%d Ep=%d", S, N, T, Ep);
+  MR_CHECK_ARG(flags == nullptr || (out_w != nullptr && C >= 1 && C <= 8 * DG),
+               "mr_decode_persist_fwd: arg-max feedback needs the output layer and C <= 256 (C=%d)", C);
   MR_CHECK_ARG(ws_bytes >= decode_ws_bytes(N), "mr_decode_persist_fwd: workspace too small (%lld < %lld)", ws_bytes,
                decode_ws_bytes(N));
   const int R = decode_rows(N), nbg = cdiv(N, R);
@@ -1008,7 +1124,8 @@ int mr_decode_persist_fwd(const void* cat_w, const float* cat_b, const void* ic_
     set_error("mr_decode_persist_fwd: memset of the exchange buffer failed");
     return MR_ERR_LAUNCH;
   }
-  DecP a{(const bf16_t*)cat_w, cat_b, (const bf16_t*)ic_w, ldic, (const bf16_t*)G, ldG, idx, (const bf16_t*)eproj,
+  DecP a{(const bf16_t*)cat_w, cat_b, (const bf16_t*)ic_w, ldic, (const bf16_t*)G, ldG, idx, flags, (const bf16_t*)out_w, out_b, C,
+         (const bf16_t*)eproj,
          (const bf16_t*)enc, v, (bf16_t*)H_all, (bf16_t*)HC_all, W_att, (bf16_t*)CTX_all, SAVE_all, (u64*)ws,
          (unsigned*)((char*)ws + (long long)nbg * decode_group_bytes(R)), S, N, T, Ep, nbg};
   return R == 4 ? decode_launch<4>(a, stream) : decode_launch<8>(a, stream);

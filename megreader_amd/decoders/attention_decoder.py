@@ -341,7 +341,13 @@ class _DecodeLoopFn(Function):
         # step s + 1 reads it there, and the backward scatters through idx_all
         assert flags.dtype == torch.int32 and flags.is_cuda and flags.numel() >= S
         fused = FUSED_STEP and N <= 32 and C <= 256
-        batched_out = fused and all_teacher
+        # round 6: the whole forward loop as ONE persistent launch (csrc/decode_persist.hip) that leaves the same saved buffers behind
+        # as the per-step launches below.  With arg-max feedback (flags[s] == 0) the kernel scores the output layer of the previous
+        # step itself -- only the arg-max is needed inside the loop -- so the log-softmax / NLL of all steps is batched behind the
+        # loop in both modes
+        persist = (fused and PERSIST and dtype == torch.bfloat16 and Ep % 8 == 0 and BATCHED_OUT
+                   and bool(load().mr_decode_persist_ok(dt, N, T, Hd, Ep)))
+        batched_out = fused and (all_teacher or persist)
         if batched_out and S > 1:
             # the word fed to step s + 1 is the target of step s.  One concatenation KERNEL: a same-dtype device-to-device
             # `copy_` is a memcpy NODE in the captured step, and a kernel that waits for a memcpy node waits tens of microseconds
@@ -350,15 +356,11 @@ class _DecodeLoopFn(Function):
         else:
             idx_all = torch.empty((S, N), dtype=torch.int64, device=dev)
             idx_all[0].fill_(int(blank))
-        # round 6: with every step teacher-forced nothing inside the loop depends on the output layer, and the whole forward loop is
-        # ONE persistent launch (csrc/decode_persist.hip) that leaves the same saved buffers behind as the per-step launches below
-        persist = (batched_out and PERSIST and dtype == torch.bfloat16 and Ep % 8 == 0
-                   and bool(load().mr_decode_persist_ok(dt, N, T, Hd, Ep)))
         if persist:
             ws, ws_size = _persist_workspace(N, dev)
-            call("mr_decode_persist_fwd", ptr(cat.w_n), ptr(cat.bias_d), ptr(ic.w_n), Ep, ptr(G), ldG, ptr(idx_all), ptr(eproj),
-                 ptr(enc), ptr(vf), ptr(H_all), ptr(HC_all), ptr(W_att), ptr(CTX_all), ptr(SAVE_all), ptr(ws), ws_size, S, N, T,
-                 Ep)
+            call("mr_decode_persist_fwd", ptr(cat.w_n), ptr(cat.bias_d), ptr(ic.w_n), Ep, ptr(G), ldG, ptr(idx_all),
+                 0 if all_teacher else ptr(flags), ptr(out.w_n), ptr(out.bias_d), C, ptr(eproj), ptr(enc), ptr(vf), ptr(H_all),
+                 ptr(HC_all), ptr(W_att), ptr(CTX_all), ptr(SAVE_all), ptr(ws), ws_size, S, N, T, Ep)
         for s in range(0 if persist else S):
             call("mr_gemm_nt", dt, ptr(H_all[s]), Hd, ptr(cat.w_n), Hd, ptr(HC_all[s]), HC, ptr(cat.bias_d), 0, N, HC, Hd)
             call("mr_attn_fwd2", dt, ptr(HC_all[s]), HC, ptr(eproj), ptr(vf), ptr(enc), ptr(W_att[s]), ptr(CTX_all[s]), N, T,

@@ -64,8 +64,8 @@ def _persistent(d, N, T, Ep, S, prezero):
     ws = torch.zeros((nbytes,), dtype=torch.uint8, device=DEV) if prezero else \
         torch.full((nbytes,), 0xAB, dtype=torch.uint8, device=DEV)
     call("mr_decode_persist_fwd", ptr(d["cat_w"]), ptr(d["cat_b"]), ptr(d["ic_w"]), Ep, ptr(d["G"]), 3 * H, ptr(d["idx"]),
-         ptr(d["eproj"]), ptr(d["enc"]), ptr(d["v"]), ptr(b["H_all"]), ptr(b["HC_all"]), ptr(b["W_att"]), ptr(b["CTX_all"]),
-         ptr(b["SAVE_all"]), ptr(ws), -nbytes if prezero else nbytes, S, N, T, Ep)
+         0, 0, 0, 0, ptr(d["eproj"]), ptr(d["enc"]), ptr(d["v"]), ptr(b["H_all"]), ptr(b["HC_all"]), ptr(b["W_att"]),
+         ptr(b["CTX_all"]), ptr(b["SAVE_all"]), ptr(ws), -nbytes if prezero else nbytes, S, N, T, Ep)
     torch.cuda.synchronize()
     status = int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item())
     return b, status
@@ -299,3 +299,81 @@ def test_persistent_decode_backward_repeatable():
         assert torch.equal(a[k], b[k]), k
     assert float((a["dv"] - b["dv"]).abs().max()) <= 1e-5 * float(b["dv"].abs().max())     # atomics: order of the four waves
     assert load().mr_decode_persist_bwd_ok(dtype_code(torch.bfloat16), 33, T, H, Ep) == 0
+
+
+# ------------------------------------------------------------------------------------------------------- arg-max feedback
+def _coin_inputs(d, N, S, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = {"out_w": (torch.randn(C, H, generator=g) * H ** -0.5 * 3).to(torch.bfloat16).to(DEV),
+         "out_b": (torch.randn(C, generator=g) * 0.2).float().to(DEV),
+         "targets": torch.randint(0, C, (S, N), generator=g, dtype=torch.int64).to(DEV),
+         "flags": (torch.rand(S, generator=g) > 0.5).to(torch.int32).to(DEV)}
+    x["idx0"] = torch.cat((torch.full((1, N), C - 1, dtype=torch.int64, device=DEV), x["targets"][:S - 1]), 0).contiguous()
+    return x
+
+
+def _per_step_coins(d, x, N, T, Ep, S, C):
+    """_DecodeLoopFn.forward's fused launches with the per-step output layer + feedback word (mr_out_nll_fwd)."""
+    dt = dtype_code(torch.bfloat16)
+    b = _buffers(N, T, Ep, S, d["h0"])
+    HC = 4 * H
+    idx = torch.empty((S, N), dtype=torch.int64, device=DEV)
+    idx[0].copy_(x["idx0"][0])
+    lp = torch.empty((S, N, C), dtype=torch.float32, device=DEV)
+    loss = torch.zeros((N,), dtype=torch.float32, device=DEV)
+    am = torch.empty((S, N), dtype=torch.int64, device=DEV)
+    mask = torch.ones((S, N), dtype=torch.float32, device=DEV)
+    for s in range(S):
+        call("mr_gemm_nt", dt, ptr(b["H_all"][s]), H, ptr(d["cat_w"]), H, ptr(b["HC_all"][s]), HC, ptr(d["cat_b"]), 0, N, HC, H)
+        call("mr_attn_fwd2", dt, ptr(b["HC_all"][s]), HC, ptr(d["eproj"]), ptr(d["v"]), ptr(d["enc"]), ptr(b["W_att"][s]),
+             ptr(b["CTX_all"][s]), N, T, H, Ep)
+        call("mr_gemm_gru_fwd", dt, ptr(b["CTX_all"][s]), Ep, ptr(d["ic_w"]), Ep, ptr(d["G"]), 3 * H, ptr(idx[s]),
+             ptr(b["HC_all"][s]) + H * 2, HC, ptr(b["H_all"][s]), ptr(b["H_all"][s + 1]), ptr(b["SAVE_all"][s]), N, H, Ep)
+        last = s + 1 == S
+        call("mr_out_nll_fwd", dt, ptr(b["H_all"][s + 1]), H, ptr(x["out_w"]), H, ptr(x["out_b"]), ptr(x["targets"][s]), 1,
+             ptr(mask[s]), ptr(lp[s]), ptr(loss), ptr(am[s]), 0 if last else ptr(x["flags"]) + 4 * s,
+             0 if last else ptr(idx[s + 1]), N, C, H, 1 if s else 0)
+    b["idx"] = idx
+    return b
+
+
+def _persistent_coins(d, x, N, T, Ep, S, C):
+    b = _buffers(N, T, Ep, S, d["h0"])
+    nbytes = load().mr_decode_persist_ws_bytes(N)
+    ws = torch.zeros((nbytes,), dtype=torch.uint8, device=DEV)
+    idx = x["idx0"].clone()
+    call("mr_decode_persist_fwd", ptr(d["cat_w"]), ptr(d["cat_b"]), ptr(d["ic_w"]), Ep, ptr(d["G"]), 3 * H, ptr(idx),
+         ptr(x["flags"]), ptr(x["out_w"]), ptr(x["out_b"]), C, ptr(d["eproj"]), ptr(d["enc"]), ptr(d["v"]), ptr(b["H_all"]),
+         ptr(b["HC_all"]), ptr(b["W_att"]), ptr(b["CTX_all"]), ptr(b["SAVE_all"]), ptr(ws), -nbytes, S, N, T, Ep)
+    torch.cuda.synchronize()
+    b["idx"] = idx
+    return b, int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item())
+
+
+@pytest.mark.parametrize("N,T,Ep,S,C", [(16, 64, 552, 32, 38), (32, 64, 552, 12, 38), (5, 33, 64, 9, 11), (17, 20, 8, 7, 5),
+                                        (3, 9, 16, 6, 256), (40, 64, 552, 5, 97)])
+def test_persistent_decode_argmax_feedback(N, T, Ep, S, C):
+    d = _inputs(N, T, Ep, S, C, seed=N * 5 + S)
+    x = _coin_inputs(d, N, S, C, seed=S)
+    assert int(x["flags"].sum()) < S          # some steps feed the arg-max
+    got, status = _persistent_coins(d, x, N, T, Ep, S, C)
+    assert status == 0
+    if N <= 32:
+        ref = _per_step_coins(d, x, N, T, Ep, S, C)
+        # the fed words decide everything downstream: they must agree (random logits are never close to a tie)
+        assert torch.equal(got["idx"], ref["idx"])
+        for k in ("H_all", "HC_all", "W_att", "CTX_all", "SAVE_all"):
+            a, b = got[k].double(), ref[k].double()
+            assert torch.isfinite(a).all(), k
+            assert float((a - b).abs().max()) <= 3e-2 * max(1.0, float(b.abs().max())), k
+    # the words the kernel wrote are the arg-max of ITS OWN hidden states (first index on ties), the others were left alone
+    logits = got["H_all"][1:].float() @ x["out_w"].float().t() + x["out_b"]
+    am = logits.argmax(-1)
+    for s in range(S - 1):
+        if int(x["flags"][s]) == 0:
+            top2 = logits[s].topk(2, dim=-1).values
+            clear = (top2[:, 0] - top2[:, 1]) > 1e-3
+            assert torch.equal(got["idx"][s + 1][clear], am[s][clear]), s
+        else:
+            assert torch.equal(got["idx"][s + 1], x["targets"][s]), s
+    assert torch.equal(got["idx"][0], x["idx0"][0])

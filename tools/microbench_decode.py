@@ -26,6 +26,8 @@ def timed(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+COINS = len(sys.argv) > 5 and sys.argv[5] == "coins"
+xc = t._coin_inputs(d, N, S, 38, 3)
 b = t._buffers(N, T, Ep, S, d["h0"])
 nbytes = load().mr_decode_persist_ws_bytes(N)
 ws = torch.zeros((nbytes,), dtype=torch.uint8, device="cuda")
@@ -36,7 +38,7 @@ def persistent(timing=False):
     if timing:
         ws[nbytes - 256:].view(torch.int32)[2] = 0x54494D45
     call("mr_decode_persist_fwd", ptr(d["cat_w"]), ptr(d["cat_b"]), ptr(d["ic_w"]), Ep, ptr(d["G"]), 3 * H, ptr(d["idx"]),
-         ptr(d["eproj"]), ptr(d["enc"]), ptr(d["v"]), ptr(b["H_all"]), ptr(b["HC_all"]), ptr(b["W_att"]), ptr(b["CTX_all"]),
+         ptr(xc["flags"]) if COINS else 0, ptr(xc["out_w"]), ptr(xc["out_b"]), 38, ptr(d["eproj"]), ptr(d["enc"]), ptr(d["v"]), ptr(b["H_all"]), ptr(b["HC_all"]), ptr(b["W_att"]), ptr(b["CTX_all"]),
          ptr(b["SAVE_all"]), ptr(ws), -nbytes, S, N, T, Ep)
 
 
@@ -78,8 +80,10 @@ nb = load().mr_decode_persist_bwd_ws_bytes(N)
 wsb = torch.zeros((nb,), dtype=torch.uint8, device="cuda")
 
 
-def persistent_bwd():
+def persistent_bwd(timing=False):
     wsb.zero_()
+    if timing:
+        wsb[nb - 256:].view(torch.int32)[2] = 0x54494D45
     call("mr_decode_persist_bwd", ptr(x["cat_wt"]), ptr(x["ic_wt"]), 3 * H, ptr(d["eproj"]), ptr(d["enc"]), ptr(d["v"]),
          ptr(fw["H_all"]), ptr(fw["HC_all"]), ptr(fw["W_att"]), ptr(fw["SAVE_all"]), ptr(x["DHO"]), 0, S * T, ptr(bb["DGI"]),
          ptr(bb["DHC"]), ptr(bb["DCTX"]), ptr(bb["deproj"]), ptr(bb["dv"]), ptr(wsb), -nb, S, N, T, Ep)
@@ -87,4 +91,12 @@ def persistent_bwd():
 
 us = timed(persistent_bwd)
 print("backward persistent (incl. ws memset)     : %.1f us  = %.2f us/step" % (us, us / S))
-print("status", int(wsb[nb - 256:].view(torch.int32)[0]))
+persistent_bwd(True)
+torch.cuda.synchronize()
+st = wsb[nb - 256:].view(torch.int32).cpu()
+names = ["dh gather+reduce", "gru bwd", "dctx mfma+publish", "dctx gather", "dctx reduce", "dw partial+publish", "dw gather",
+         "softmax bwd", "tanh chain", "dh mfma+publish"]
+for g_ in (0, 1):
+    v = [int(st[8 + 16 * g_ + i]) * 0.01 / S for i in range(10)]
+    print("slice %d: " % g_ + "  ".join("%s %.2f" % (n, x) for n, x in zip(names, v)) + "   sum %.2f us/step" % sum(v))
+print("status", int(st[0]))
