@@ -124,8 +124,9 @@ typedef struct mr_tuning {
   int dcn_col_fwd;   /* round 6: 1 (default) = on the dcn_gcol shapes the bf16 forward also goes through the column matrix (one sampling
                         pass into the caller's col_ws + the tuned NT GEMM) and leaves it there for the backward's weight gradient
                         (mr_dcn2_col_saved / mr_dcn2_bwd3); 0 = the fused forward kernel, the backward samples again */
-  int decode_persist; /* round 6: 1 (default) = the teacher-forced attention-GRU decode loop runs its forward as ONE persistent launch
-                        (decode_persist.hip: bf16, H = 512, T <= 64, Ep <= 576; mr_decode_persist_ok); 0 = three launches per step */
+  int decode_persist; /* round 6: 1 (default) = the attention-GRU decode loop runs its forward and its backward as ONE persistent launch
+                        each (decode_persist.hip: bf16, H = 512, T <= 64, Ep <= 576; mr_decode_persist_ok); 0 = three launches per
+                        step; 2 = persistent without the block map that puts a batch group's 32 workgroups on one XCD (A/B knob) */
   int reserved[3];   /* zero */
 } mr_tuning;
 int mr_tuning_get(mr_tuning* out);

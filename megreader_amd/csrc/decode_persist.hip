@@ -66,6 +66,15 @@ struct Xch {
 __device__ __forceinline__ void gran2_store(rsrc_t r, unsigned byte_off, unsigned v0, unsigned v1, unsigned tag) {
   __builtin_amdgcn_raw_buffer_store_b128(u32x4{v0, tag, v1, tag}, r, (int)byte_off, 0, AUX_SC1);
 }
+// `local` (uniform): all 32 slices of the batch group were found on ONE XCD (group_on_one_xcd below).  A plain store then KEEPS the
+// line in that XCD's L2 and the siblings' sc1 (L1-bypassing) polls hit it there; an sc1 store drops the line from L2 and every
+// poll pays the fabric round trip (MI355X_MICROARCH.md, "stores of each flavour"; lstm_persist.hip does the same with 4 slices).
+__device__ __forceinline__ void gran2_publish(rsrc_t r, unsigned byte_off, unsigned v0, unsigned v1, unsigned tag, bool local) {
+  if (local)
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{v0, tag, v1, tag}, r, (int)byte_off, 0, 0);
+  else
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{v0, tag, v1, tag}, r, (int)byte_off, 0, AUX_SC1);
+}
 __device__ __forceinline__ u32x4 gran2_load(rsrc_t r, unsigned byte_off) {
   return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, AUX_SC1);
 }
@@ -75,6 +84,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 }
 __device__ __forceinline__ float bf16_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ int wave_of_thread() { return (int)(threadIdx.x >> 6); }
 // the energies' tanh: the form of attention.hip (att_tanh)
 __device__ __forceinline__ float dec_tanh(float x) {
   return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.885390081777927f));
@@ -138,6 +148,54 @@ __device__ __forceinline__ bool gather_pairs(rsrc_t rx, const unsigned (&off)[CN
   }
 }
 
+constexpr unsigned HELLO_TAG = 0x48454C4Fu;
+constexpr unsigned HELLO_BYTES = 8 * DG * 16;     // [8 groups][32 slices] granule pairs, between the exchange slots and the status
+
+// Workgroup -> (slice g, batch group bg).  xmap: the grid is 8 x 32 workgroups and hardware workgroup b is dispatched to XCD
+// b % 8 (round-robin), so group bg takes the block indices congruent to bg mod 8: its 32 slices fill the 32 CUs of ONE XCD (one
+// workgroup per CU: 460+ registers a lane).  Returns false for the workgroups of groups that do not exist.
+__device__ __forceinline__ bool decode_roles(int xmap, int nbg, int& g, int& bg) {
+  const int b = blockIdx.x;
+  if (xmap) {
+    bg = b & 7;
+    g = b >> 3;
+    return bg < nbg;
+  }
+  g = b % DG;
+  bg = b / DG;
+  return true;
+}
+
+// Are the 32 slices of this batch group on one XCD?  The placement above is a dispatch-order ASSUMPTION, so it is verified: every
+// workgroup publishes its HW_REG_XCC_ID (sc1 store: visible anywhere) and reads its 31 siblings'.  Only if all agree does this
+// workgroup publish with plain stores.  A sibling that does not answer within the spin bound counts as "elsewhere" (sc1 stores
+// are always correct).  `sh` is one LDS word; status word 1 counts the workgroups that answered yes.
+__device__ __forceinline__ bool group_on_one_xcd(rsrc_t rx, unsigned hello_base, int g, int xmap, int* sh, unsigned* status) {
+  if (!xmap) return false;
+  unsigned me;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(me));
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) gran2_store(rx, hello_base + (unsigned)(g * 16), me, me, HELLO_TAG);
+  if (tid < 64) {
+    bool same = true;
+    if (lane < DG && lane != g) {
+      same = false;
+      for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+        const u32x4 v = gran2_load(rx, hello_base + (unsigned)(lane * 16));
+        if (v[1] == HELLO_TAG) { same = v[0] == me; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    const bool all_same = __all(same);
+    if (lane == 0) {
+      *sh = all_same ? 1 : 0;
+      if (all_same) atomicAdd(status + 1, 1u);
+    }
+  }
+  __syncthreads();
+  return *sh != 0;
+}
+
 struct DecP {
   const bf16_t* cat_w;     // [4H][H]: rows [0,H) attention hidden projection, [H,4H) W_hh (r, z, n)
   const float* cat_b;      // [4H] or null
@@ -162,6 +220,8 @@ struct DecP {
   u64* xch;
   unsigned* status;
   int S, N, T, Ep, nbg;
+  int xmap;                // block -> role map that puts a group's 32 slices on one XCD (decode_roles)
+  unsigned hello_off;      // byte offset (from xch) of the XCC-id exchange
 };
 
 // LDS carve-up (bytes), shared by the kernel and the launcher
@@ -202,7 +262,8 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
   bf16_t* sEnc = (bf16_t*)(smem + L::ENC);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
-  const int g = blockIdx.x % DG, bg = blockIdx.x / DG;
+  int g, bg;
+  if (!decode_roles(a.xmap, a.nbg, g, bg)) return;
   const int T = a.T, Ep = a.Ep, N = a.N, S = a.S;
   const int nu = Ep >> 2;                       // 4-channel units per context row
   const int row_f = bg * R + l15;               // batch row of this lane's MFMA output column
@@ -286,6 +347,7 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
 
   const rsrc_t rx = make_rsrc(a.xch);
   const unsigned xg = (unsigned)bg * X::GROUP;
+  const bool local = group_on_one_xcd(rx, a.hello_off + (unsigned)(bg * DG * 16), g, a.xmap, &sDead[3], a.status);
   // per-thread constants of the gathers
   unsigned offC[X::CNT_C], ldsC[X::CNT_C], wantC = 0;      // contexts: R * nu pairs
 #pragma unroll
@@ -367,8 +429,8 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
         const int oc = __shfl_xor(bc, 16, 64);
         if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
         if (lg == 0 && l15 < R)
-          gran2_store(rx, xg + X::XL_OFF + slot * X::XL_SLOT + (unsigned)((l15 * DG + g) * 16), __float_as_uint(bv), (unsigned)bc,
-                      tag);
+          gran2_publish(rx, xg + X::XL_OFF + slot * X::XL_SLOT + (unsigned)((l15 * DG + g) * 16), __float_as_uint(bv), (unsigned)bc,
+                      tag, local);
       }
       const f32x4 acc = acc0 + acc1;
       const unsigned p01 = pack_bf16(acc[0] + cbias[0], acc[1] + cbias[1]);
@@ -396,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
         float sc = sc0 + sc1;
         if (lane >= T) sc = 0.f;
         const float nb = __shfl_down(sc, 1, 64);
-        if (!(lane & 1)) gran2_store(rx, xs + (unsigned)(p * 8), __float_as_uint(sc), __float_as_uint(nb), tag);
+        if (!(lane & 1)) gran2_publish(rx, xs + (unsigned)(p * 8), __float_as_uint(sc), __float_as_uint(nb), tag, local);
       }
     }
     DEC_TICK(1)
@@ -486,7 +548,7 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
         DEC_TICK(3)
         if (ctx_thread && ctg == 0) {
           const unsigned p01 = pack_bf16(cacc[0], cacc[1]), p23 = pack_bf16(cacc[2], cacc[3]);
-          gran2_store(rx, xg + X::XC_OFF + slot * X::XC_SLOT + (unsigned)((nloc * nu + u0 + cu) * 16), p01, p23, tag);
+          gran2_publish(rx, xg + X::XC_OFF + slot * X::XC_SLOT + (unsigned)((nloc * nu + u0 + cu) * 16), p01, p23, tag, local);
           if (row_o_ok) *(uint2*)(a.CTX_all + ((long long)s * N + row_o) * Ep + (u0 + cu) * 4) = make_uint2(p01, p23);
         }
       }
@@ -544,7 +606,7 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
       if (!(gu & 3)) {
         const unsigned p01 = pack_bf16(hnew, h1), p23 = pack_bf16(h2, h3);
         if (s + 1 < S)
-          gran2_store(rx, xg + X::XH_OFF + slot * X::XH_SLOT + (unsigned)((gm * (DH / 4) + (jg >> 2)) * 16), p01, p23, tag);
+          gran2_publish(rx, xg + X::XH_OFF + slot * X::XH_SLOT + (unsigned)((gm * (DH / 4) + (jg >> 2)) * 16), p01, p23, tag, local);
         if (row_g_ok) *(uint2*)(a.H_all + ((long long)(s + 1) * N + row_g) * DH + jg) = make_uint2(p01, p23);
       }
     }
@@ -614,6 +676,8 @@ struct DecB {
   u64* xch;
   unsigned* status;
   int S, N, T, Ep, nbg;
+  int xmap;                // block -> role map that puts a group's 32 slices on one XCD (decode_roles)
+  unsigned hello_off;      // byte offset (from xch) of the XCC-id exchange
 };
 
 template <int R>
@@ -631,8 +695,8 @@ constexpr int GLD = 64 + 8;   // LDS row stride (elements) of the two K = 64 MFM
 
 template <int R>
 struct LdsB {
-  static constexpr int EP = 0;                                    // uint4 [2 halves][R * 64]
-  static constexpr int DGT = EP + 2 * R * DT * 16;                // bf16 [16][GLD]  dgi  (r | z | n | 0)
+  static constexpr int STG = 0;                                   // f32 [4 waves][9 tiles][R][16]: partial sums on their way out
+  static constexpr int DGT = STG + 4 * 9 * R * 16 * 4;            // bf16 [16][GLD]  dgi  (r | z | n | 0)
   static constexpr int DHCT = DGT + 16 * GLD * 2;                 // bf16 [16][GLD]  dhproj | dgh r | z | n
   static constexpr int REDA = DHCT + 16 * GLD * 2;                // f32 [32/R][R][16]
   static constexpr int REDD = REDA + 512 * 4;                     // f32 [256][2]
@@ -657,7 +721,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
   typedef LdsB<R> L;
   constexpr int SPS = DG / R;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint4* sEp = (uint4*)(smem + L::EP);
+  float* sStg = (float*)(smem + L::STG) + wave_of_thread() * 9 * R * 16;   // this wave's staging tile
   bf16_t* sDG = (bf16_t*)(smem + L::DGT);
   bf16_t* sDHC = (bf16_t*)(smem + L::DHCT);
   float* sRedA = (float*)(smem + L::REDA);
@@ -670,7 +734,8 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
   bf16_t* sEnc = (bf16_t*)(smem + L::ENC);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
-  const int g = blockIdx.x % DG, bg = blockIdx.x / DG;
+  int g, bg;
+  if (!decode_roles(a.xmap, a.nbg, g, bg)) return;
   const int T = a.T, Ep = a.Ep, N = a.N, S = a.S;
   const int nu = Ep >> 2;
   const int nloc = g / SPS, cpart = g % SPS, row_o = bg * R + nloc;
@@ -704,24 +769,23 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
       wcatT[i][1] = *(const Frag*)(p + (lg < 2 ? 2 * DH : 3 * DH));
     }
   }
-  float vv[DU];
+  // tanh chain ownership: wave <-> sample, lane <-> (unit tq of the slice, chunk tc of 16 positions).  The thread's 16 eproj
+  // elements and its 16 deproj accumulators live in registers for the whole sequence.
+  static_assert(R == 4, "the backward kernel is built for groups of 4 rows");
+  const int tq = lane & 15, tc = lane >> 4;
+  const float vq = a.v[g * DU + tq];
+  float evr[16], dacc[16];
+  {
+    const int r = bg * R + wave;
 #pragma unroll
-  for (int j = 0; j < DU; j += 4) {
-    const f32x4 t = *(const f32x4*)(a.v + g * DU + j);
-    vv[j] = t[0]; vv[j + 1] = t[1]; vv[j + 2] = t[2]; vv[j + 3] = t[3];
-  }
-  // ---- LDS residents
-  for (int p = tid; p < R * DT; p += 256) {
-    const int n = p >> 6, t = p & 63, r = bg * R + n;
-    uint4 e0 = make_uint4(0, 0, 0, 0), e1 = e0;
-    if (r < N && t < T) {
-      const bf16_t* ep = a.eproj + ((long long)r * T + t) * DH + g * DU;
-      e0 = *(const uint4*)ep;
-      e1 = *(const uint4*)(ep + 8);
+    for (int j = 0; j < 16; ++j) {
+      const int t = tc * 16 + j;
+      evr[j] = (r < N && t < T) ? (float)a.eproj[((long long)r * T + t) * DH + g * DU + tq] : 0.f;
+      dacc[j] = 0.f;
     }
-    sEp[p] = e0;
-    sEp[R * DT + p] = e1;
   }
+  float dvq = 0.f;
+  // ---- LDS residents
   for (int i = tid; i < T * upp; i += 256) {
     const int t = i / upp, u = i - t * upp;
     uint2 e = make_uint2(0, 0);
@@ -734,6 +798,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
 
   const rsrc_t rx = make_rsrc(a.xch);
   const unsigned xg = (unsigned)bg * X::GROUP;
+  const bool local = group_on_one_xcd(rx, a.hello_off + (unsigned)(bg * DG * 16), g, a.xmap, &sDead[3], a.status);
   // GRU ownership: thread <-> (sample gm, unit gu of the slice)
   const int gm = tid >> 4, gu = tid & 15, row_g = bg * R + gm, jg = g * DU + gu;
   const bool gru_thread = gm < R;
@@ -756,13 +821,6 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
   const int npga = min(PGA, DG);
   // edge B consumer: lane = (half, position pair tp); samples wave + 4i
   const int tp = lane & 31, half = lane >> 5;
-  float dacc[R / 4][DU], dvacc[DU];
-#pragma unroll
-  for (int q = 0; q < DU; ++q) {
-    dvacc[q] = 0.f;
-#pragma unroll
-    for (int i = 0; i < R / 4; ++i) dacc[i][q] = 0.f;
-  }
   float dh_b = 0.f;
   bool dead = false;
   __syncthreads();
@@ -859,16 +917,26 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
       const Frag a0 = *(const Frag*)(sDG + l15 * GLD + lg * 8);
       const Frag a1 = *(const Frag*)(sDG + l15 * GLD + 32 + lg * 8);
       const unsigned xd = xg + X::XD_OFF + slot * X::XD_SLOT + (unsigned)(((g * R + l15) * DEPMAX + lg * 4) * 8);
+      // only the R rows of a 16-row MFMA tile are samples: the tiles go through the wave's staging area so that ALL lanes store
+      // (9 tiles x R rows x 8 pairs = 288 pairs = 5 store instructions a wave instead of 18 by a quarter of the lanes)
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         Mma<bf16_t>::run(acc, wicT[i][0], a0);
         Mma<bf16_t>::run(acc, wicT[i][1], a1);
-        const int c0 = (wave + 4 * i) * 16 + lg * 4;
-        if (l15 < R && c0 < Ep) {
-          const unsigned o = xd + (unsigned)((wave + 4 * i) * 16 * 8);
-          gran2_store(rx, o, __float_as_uint(acc[0]), __float_as_uint(acc[1]), tag);
-          gran2_store(rx, o + 16, __float_as_uint(acc[2]), __float_as_uint(acc[3]), tag);
+        if (l15 < R) *(f32x4*)(sStg + (i * R + l15) * 16 + lg * 4) = acc;
+      }
+      (void)xd;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes, then its reads (no other wave involved)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int pp = lane + 64 * k;                    // pair index: [tile][row][pair of 8]
+        const int ti = pp >> 5, rw = (pp >> 3) & 3, pr8 = pp & 7;
+        const int c0 = (wave + 4 * ti) * 16 + pr8 * 2;
+        if (pp < 288 && c0 < Ep) {
+          const float2 v2 = *(const float2*)(sStg + pp * 2);
+          gran2_publish(rx, xg + X::XD_OFF + slot * X::XD_SLOT + (unsigned)(((g * R + rw) * DEPMAX + c0) * 8),
+                        __float_as_uint(v2.x), __float_as_uint(v2.y), tag, local);
         }
       }
     }
@@ -891,6 +959,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
       __syncthreads();
       if (tid < 4 * nown) {
         float c = 0.f;
+#pragma unroll 8
         for (int k = 0; k < npga; ++k) c += sRedD[k * 2 * npair + tid];
         const bf16_t cb = (bf16_t)c;
         sDctx[tid] = (float)cb;
@@ -921,8 +990,8 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
           if (2 * tid < T) d0 += gp[2 * tid];
           if (2 * tid + 1 < T) d1 += gp[2 * tid + 1];
         }
-        gran2_store(rx, xg + X::XW_OFF + slot * X::XW_SLOT + (unsigned)(((nloc * SPS + cpart) * DT + 2 * tid) * 8),
-                    __float_as_uint(d0), __float_as_uint(d1), tag);
+        gran2_publish(rx, xg + X::XW_OFF + slot * X::XW_SLOT + (unsigned)(((nloc * SPS + cpart) * DT + 2 * tid) * 8),
+                    __float_as_uint(d0), __float_as_uint(d1), tag, local);
       }
     }
     DEC_TICK(5)
@@ -962,30 +1031,28 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
     DEC_TICK(7)
     // ---- tanh chain of the own units: dhproj (reduced over the positions), deproj / dv (accumulated over the steps)
     {
+      const int n = wave;
+      const float hp = sHp[n * DU + tq];
+      float dhp = 0.f;
 #pragma unroll
-      for (int i = 0; i < R / 4; ++i) {
-        const int n = wave + 4 * i, p = n * DT + lane;
-        const float de = sDe[p];
-        const uint4 e0 = sEp[p], e1 = sEp[R * DT + p];
-        const unsigned ew[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-        const float* hp = sHp + n * DU;
-        float mine = 0.f;
+      for (int j4 = 0; j4 < 16; j4 += 4) {
+        const f32x4 de4 = *(const f32x4*)(sDe + n * 64 + tc * 16 + j4);
 #pragma unroll
-        for (int q = 0; q < DU; ++q) {
-          const float e = (q & 1) ? bf16_hi(ew[q >> 1]) : bf16_lo(ew[q >> 1]);
-          const float th = dec_tanh(hp[q] + e);
-          const float gg = de * vv[q] * (1.f - th * th);
-          dacc[i][q] += gg;
-          dvacc[q] += de * th;
-          const float tot = wave_sum_dpp(gg);
-          mine = l15 == q ? tot : mine;
+        for (int e = 0; e < 4; ++e) {
+          const float th = dec_tanh(hp + evr[j4 + e]);
+          const float gg = de4[e] * vq * (1.f - th * th);
+          dacc[j4 + e] += gg;
+          dvq += de4[e] * th;
+          dhp += gg;
         }
-        if (lane < DU) {
-          const bf16_t hb = (bf16_t)mine;
-          sDHC[n * GLD + lane] = hb;
-          const int r = bg * R + n;
-          if (r < N) a.DHC_all[((long long)s * N + r) * 4 * DH + g * DU + lane] = hb;
-        }
+      }
+      dhp += __shfl_xor(dhp, 16, 64);
+      dhp += __shfl_xor(dhp, 32, 64);
+      if (lane < DU) {
+        const bf16_t hb = (bf16_t)dhp;
+        sDHC[n * GLD + lane] = hb;
+        const int r = bg * R + n;
+        if (r < N) a.DHC_all[((long long)s * N + r) * 4 * DH + g * DU + lane] = hb;
       }
     }
     DEC_TICK(8)
@@ -1001,11 +1068,17 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         Mma<bf16_t>::run(acc, wcatT[i][0], a0);
         Mma<bf16_t>::run(acc, wcatT[i][1], a1);
-        if (l15 < R) {
-          const unsigned o = xa + (unsigned)((wave + 4 * i) * 16 * 8);
-          gran2_store(rx, o, __float_as_uint(acc[0]), __float_as_uint(acc[1]), tag);
-          gran2_store(rx, o + 16, __float_as_uint(acc[2]), __float_as_uint(acc[3]), tag);
-        }
+        if (l15 < R) *(f32x4*)(sStg + (i * R + l15) * 16 + lg * 4) = acc;
+      }
+      (void)xa;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int pp = lane + 64 * k;                    // 8 tiles x R rows x 8 pairs = 256 pairs
+        const int ti = pp >> 5, rw = (pp >> 3) & 3, pr8 = pp & 7;
+        const float2 v2 = *(const float2*)(sStg + pp * 2);
+        gran2_publish(rx, xg + X::XA_OFF + slot * X::XA_SLOT + (unsigned)(((g * R + rw) * DH + (wave + 4 * ti) * 16 + pr8 * 2) * 8),
+                      __float_as_uint(v2.x), __float_as_uint(v2.y), tag, local);
       }
     }
     DEC_TICK(9)
@@ -1016,23 +1089,18 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
   }
 #undef DEC_TICK
   // ---- the accumulated gradients of eproj (own 16 columns) and v
-#pragma unroll
-  for (int i = 0; i < R / 4; ++i) {
-    const int r = bg * R + wave + 4 * i;
-    if (r < N && lane < T) {
-      float* dp = a.deproj + ((long long)r * T + lane) * DH + g * DU;
-#pragma unroll
-      for (int q = 0; q < DU; q += 4) *(f32x4*)(dp + q) = f32x4{dacc[i][q], dacc[i][q + 1], dacc[i][q + 2], dacc[i][q + 3]};
-    }
-  }
   {
-    float mine = 0.f;
+    const int r = bg * R + wave;
+    if (r < N) {
 #pragma unroll
-    for (int q = 0; q < DU; ++q) {
-      const float tot = wave_sum_dpp(dvacc[q]);
-      mine = l15 == q ? tot : mine;
+      for (int j = 0; j < 16; ++j) {
+        const int t = tc * 16 + j;
+        if (t < T) a.deproj[((long long)r * T + t) * DH + g * DU + tq] = dacc[j];
+      }
     }
-    if (lane < DU) atomicAdd(a.dv + g * DU + lane, mine);
+    dvq += __shfl_xor(dvq, 16, 64);
+    dvq += __shfl_xor(dvq, 32, 64);
+    if (lane < DU) atomicAdd(a.dv + g * DU + lane, dvq);
   }
 }
 
@@ -1042,10 +1110,12 @@ namespace {
 // backward, 8-row groups in 10.6 / 21 us (the backward then spills).  All workgroups of a group must be co-resident; workgroups that
 // are dispatched late (a kernel of another stream still holds their CU) only delay their group -- every wait is bounded.
 int decode_rows(int N) { return N <= 32 ? 4 : 8; }
+// decode_persist = 2: never use the XCD-colocating block map (A/B knob)
+int decode_xmap(int nbg) { return (MR_TUNE(decode_persist) != 2 && nbg <= 8) ? 1 : 0; }
 unsigned decode_group_bytes(int R) { return R == 4 ? Xch<4>::GROUP : Xch<8>::GROUP; }
 long long decode_ws_bytes(int N) {
   const int R = decode_rows(N);
-  return (long long)cdiv(N, R) * decode_group_bytes(R) + 256;
+  return (long long)cdiv(N, R) * decode_group_bytes(R) + HELLO_BYTES + 256;
 }
 
 template <int R>
@@ -1061,14 +1131,14 @@ int decode_launch(const DecP& a, hipStream_t stream) {
     }
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(decode_fwd_persist_kernel<R>, dim3(a.nbg * DG), dim3(256), Lds<R>::bytes(a.T, a.Ep), stream, a);
+  hipLaunchKernelGGL(decode_fwd_persist_kernel<R>, dim3((a.xmap ? 8 : a.nbg) * DG), dim3(256), Lds<R>::bytes(a.T, a.Ep), stream, a);
   MR_CHECK_LAUNCH();
   return MR_OK;
 }
 unsigned decode_bwd_group_bytes(int) { return XchB<4>::GROUP; }
 long long decode_bwd_ws_bytes(int N) {
   const int R = decode_rows(N);
-  return (long long)cdiv(N, R) * decode_bwd_group_bytes(R) + 256;
+  return (long long)cdiv(N, R) * decode_bwd_group_bytes(R) + HELLO_BYTES + 256;
 }
 
 template <int R>
@@ -1084,7 +1154,7 @@ int decode_bwd_launch(const DecB& a, hipStream_t stream) {
     }
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(decode_bwd_persist_kernel<R>, dim3(a.nbg * DG), dim3(256), LdsB<R>::bytes(a.T, a.Ep), stream, a);
+  hipLaunchKernelGGL(decode_bwd_persist_kernel<R>, dim3((a.xmap ? 8 : a.nbg) * DG), dim3(256), LdsB<R>::bytes(a.T, a.Ep), stream, a);
   MR_CHECK_LAUNCH();
   return MR_OK;
 }
@@ -1127,7 +1197,8 @@ int mr_decode_persist_fwd(const void* cat_w, const float* cat_b, const void* ic_
   DecP a{(const bf16_t*)cat_w, cat_b, (const bf16_t*)ic_w, ldic, (const bf16_t*)G, ldG, idx, flags, (const bf16_t*)out_w, out_b, C,
          (const bf16_t*)eproj,
          (const bf16_t*)enc, v, (bf16_t*)H_all, (bf16_t*)HC_all, W_att, (bf16_t*)CTX_all, SAVE_all, (u64*)ws,
-         (unsigned*)((char*)ws + (long long)nbg * decode_group_bytes(R)), S, N, T, Ep, nbg};
+         (unsigned*)((char*)ws + (long long)nbg * decode_group_bytes(R) + HELLO_BYTES), S, N, T, Ep, nbg, decode_xmap(nbg),
+         (unsigned)(nbg * decode_group_bytes(R))};
   return R == 4 ? decode_launch<4>(a, stream) : decode_launch<8>(a, stream);
 }
 
@@ -1163,7 +1234,8 @@ int mr_decode_persist_bwd(const void* cat_wt, const void* ic_wt, long long ldict
   DecB a{(const bf16_t*)cat_wt, (const bf16_t*)ic_wt, ldict, (const bf16_t*)eproj, (const bf16_t*)enc, v,
          (const bf16_t*)H_all, (const bf16_t*)HC_all, W_att, SAVE_all, (const bf16_t*)DHO_all, ga, ldga, (bf16_t*)DGI_all,
          (bf16_t*)DHC_all, (bf16_t*)DCTX_all, deproj, dv, (u64*)ws,
-         (unsigned*)((char*)ws + (long long)nbg * decode_bwd_group_bytes(R)), S, N, T, Ep, nbg};
+         (unsigned*)((char*)ws + (long long)nbg * decode_bwd_group_bytes(R) + HELLO_BYTES), S, N, T, Ep, nbg, decode_xmap(nbg),
+         (unsigned)(nbg * decode_bwd_group_bytes(R))};
   return decode_bwd_launch<4>(a, stream);
 }
 

@@ -36,7 +36,7 @@ static const Field k_fields[] = {
     MR_F(tn_taps, 0, 1), MR_F(tn_taps_group, 0, 1 << 20), MR_F(tn_group, 0, 1 << 20), MR_F(tn_fin, 0, 2),
     MR_F(tn_taps_fin, 0, 2), MR_F(tn_taps_w8, 0, 1), MR_F(tn_model, 0, 1), MR_F(tn_splits, 0, 1 << 20), MR_F(bn_fused, 0, 1),
     MR_F(lstm_persist, 0, 2), MR_F(lstm_fwd_bn, 0, 64), MR_F(lstm_bwd_bn, 0, 64), MR_F(dcn_fused, 0, 1),
-    MR_F(dcn_v1_bwd, 0, 1), MR_F(bn_onepass, 0, 1), MR_F(skinny_depth, 0, 8), MR_F(nt_big_min_k, 32, 1 << 20), MR_F(tn_taps_min_p, 0, 1 << 30), MR_F(tn_defer, 0, 1), MR_F(pool_fixed, 0, 1), MR_F(ctc_linear, 0, 1), MR_F(nt_wide8, 0, 63), MR_F(nt_ksplit, 0, 8), MR_F(nt_m32, 0, 5), MR_F(nt_m32_opt, 0, 99), MR_F(dcn_gcol, 0, 1), MR_F(dcn_col_fwd, 0, 1), MR_F(decode_persist, 0, 1)};
+    MR_F(dcn_v1_bwd, 0, 1), MR_F(bn_onepass, 0, 1), MR_F(skinny_depth, 0, 8), MR_F(nt_big_min_k, 32, 1 << 20), MR_F(tn_taps_min_p, 0, 1 << 30), MR_F(tn_defer, 0, 1), MR_F(pool_fixed, 0, 1), MR_F(ctc_linear, 0, 1), MR_F(nt_wide8, 0, 63), MR_F(nt_ksplit, 0, 8), MR_F(nt_m32, 0, 5), MR_F(nt_m32_opt, 0, 99), MR_F(dcn_gcol, 0, 1), MR_F(dcn_col_fwd, 0, 1), MR_F(decode_persist, 0, 2)};
 #undef MR_F
 
 static const char* check(const mr_tuning& t) {

@@ -62,7 +62,7 @@ for g_ in (0, 1):
     v = [int(st[8 + 16 * g_ + i]) * 0.01 / S for i in range(9)]
     print("slice %d (%s): " % (g_, "owner" if g_ == 0 else "non-owner") +
           "  ".join("%s %.2f" % (n, x) for n, x in zip(names, v)) + "   sum %.2f us/step" % sum(v))
-print("status", int(st[0]))
+print("status", int(st[0]), "workgroups that found their group on one XCD:", int(st[1]))
 
 # ---- backward
 fw = t._per_step(d, N, T, Ep, S)
@@ -99,4 +99,4 @@ names = ["dh gather+reduce", "gru bwd", "dctx mfma+publish", "dctx gather", "dct
 for g_ in (0, 1):
     v = [int(st[8 + 16 * g_ + i]) * 0.01 / S for i in range(10)]
     print("slice %d: " % g_ + "  ".join("%s %.2f" % (n, x) for n, x in zip(names, v)) + "   sum %.2f us/step" % sum(v))
-print("status", int(st[0]))
+print("status", int(st[0]), "workgroups that found their group on one XCD:", int(st[1]))
