@@ -321,7 +321,8 @@ def load():
 HOST_ONLY = ("mr_abi_version", "mr_nt_tile_code", "mr_init", "mr_tuning_get", "mr_tuning_set", "mr_tuning_defaults",
              "mr_stem_bwd_workspace", "mr_lstm_ws_bytes", "mr_lstm_debug_buffer", "mr_dcn2_ws_bytes", "mr_bn_scratch_doubles",
              "mr_sizeof_img_desc", "mr_nt_kernel_code", "mr_tn_taps_would_run", "mr_set_tn_taps_workspace",
-             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending", "mr_tn_discard", "mr_phase_timer", "mr_phase_read", "mr_conv2d_fwd_pool_ok", "mr_dcn2_col_saved", "mr_dcn2_dx_direct", "mr_dcn2_fused", "mr_db_loss_ws_bytes")  # entry points that take no stream and launch nothing
+             "mr_sizeof_prep_job", "mr_tn_defer", "mr_tn_pending", "mr_tn_discard", "mr_phase_timer", "mr_phase_read", "mr_conv2d_fwd_pool_ok", "mr_dcn2_col_saved", "mr_dcn2_dx_direct", "mr_dcn2_fused", "mr_db_loss_ws_bytes", "mr_decode_persist_ok", "mr_decode_persist_ws_bytes", "mr_decode_persist_bwd_ok",
+             "mr_decode_persist_bwd_ws_bytes")  # entry points that take no stream and launch nothing
 
 
 def dtype_code(dtype):

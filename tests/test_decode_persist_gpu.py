@@ -377,3 +377,36 @@ def test_persistent_decode_argmax_feedback(N, T, Ep, S, C):
         else:
             assert torch.equal(got["idx"][s + 1], x["targets"][s]), s
     assert torch.equal(got["idx"][0], x["idx0"][0])
+
+
+def test_persistent_decode_beside_a_busy_side_stream():
+    """The two kernels need every workgroup of a batch group co-resident (N = 32: 256 workgroups, one per CU).  Beside a foreign
+    stream of chip-filling kernels (what a gradient all-reduce is to the scheduler; tests/test_persistent_beside_gpu.py) workgroups
+    are dispatched late: the groups wait (bounded), nothing times out, the results do not change."""
+    N, T, Ep, S, C = 32, 64, 552, 32, 38
+    d = _inputs(N, T, Ep, S, C, seed=21)
+    x = _coin_inputs(d, N, S, C, seed=4)
+    ref, st = _persistent_coins(d, x, N, T, Ep, S, C)
+    assert st == 0
+    bx = _bwd_inputs(d, ref, N, T, Ep, S, seed=5, with_ga=False)
+    bref, st = _bwd_persistent(d, ref, bx, N, T, Ep, S)
+    assert st == 0
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    big = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    big2 = torch.empty_like(big)
+    for it in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                torch.mm(a, a)
+                big2.copy_(big)
+        for _ in range(3):
+            got, st = _persistent_coins(d, x, N, T, Ep, S, C)
+            assert st == 0, (it, st)
+            bgot, st = _bwd_persistent(d, got, bx, N, T, Ep, S)
+            assert st == 0, (it, st)
+        for k in ("H_all", "HC_all", "W_att", "CTX_all", "SAVE_all", "idx"):
+            assert torch.equal(got[k], ref[k]), (it, k)
+        for k in ("DGI", "DHC", "DCTX", "deproj"):
+            assert torch.equal(bgot[k], bref[k]), (it, k)
+    torch.cuda.synchronize()

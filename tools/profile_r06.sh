@@ -66,5 +66,22 @@ RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 timeout
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 20 --warmup 5 --no-secondary --no-cpu-baseline > $O/bench_torchrun_n1.json 2> $O/bench_torchrun_n1.err
 timeout 300 python bench.py --workload res50ppm --dtype f32 --no-secondary --steps 10 --warmup 3 > $O/bench_res50ppm_f32.json 2> $O/bench_res50ppm_f32.err
 tools/mfma_ceiling > $O/mfma_ceiling.txt 2>&1
+# the persistent decode kernels beside the per-step launches they replace, with the kernels' own phase clock
+{
+for cfg in "32 64 552 32" "32 64 552 32 coins" "16 64 552 32"; do
+  echo "## python tools/microbench_decode.py $cfg"
+  timeout 300 python tools/microbench_decode.py $cfg 2>&1 | grep -v amdgpu.ids
+done
+echo "## MEGREADER_TUNING=decode_persist=2 (no XCD-colocating block map): python tools/microbench_decode.py 32 64 552 32"
+MEGREADER_TUNING=decode_persist=2 timeout 300 python tools/microbench_decode.py 32 64 552 32 2>&1 | grep -v amdgpu.ids | grep "persistent\|status"
+echo "## bench.py --workload fpn_attention, MEGREADER_DECODE_PERSIST = 1 / fwd / bwd / 0, fixed teacher forcing then the YAML-default coins"
+B="--no-cpu-baseline --no-secondary --no-kernel-timer --steps 30 --warmup 5"
+for tf in "" "--teacher-forcing random"; do
+  for p in 1 fwd bwd 0; do
+    ms=$(MEGREADER_DECODE_PERSIST=$p timeout 300 python bench.py --workload fpn_attention $tf $B 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1)
+    echo "fpn_attention $tf | MEGREADER_DECODE_PERSIST=$p | $ms"
+  done
+done
+} > $O/decode_persist_microbench.txt 2>&1
 python bench.py > $O/bench_default_final.json 2> $O/bench_default_final.err
 echo extras done
