@@ -562,7 +562,7 @@ def main():
             bad = int(tb)
         if bad:
             raise RuntimeError("bench.py: invalid step on some rank -- %s%s (rank %d: final loss %r, LSTM status words %r)" %
-                               ("non-finite loss " if bad & 1 else "", "persistent-LSTM timeout" if bad & 2 else "", rank,
+                               ("non-finite loss " if bad & 1 else "", "persistent-kernel (LSTM / decode) timeout" if bad & 2 else "", rank,
                                 final_loss, lstm_words))
         if use_graph and not args.no_kernel_timer:
             # HIP events cannot bracket kernels inside a graph replay: measure the dominant kernel's launch durations

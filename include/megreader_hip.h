@@ -640,7 +640,8 @@ int mr_rows_scatter_add(int dtype, const long long* idx, const void* rows, long 
  * (f32, nullable), C <= 256, first index on ties as mr_out_nll_fwd -- and the kernel WRITES that word to idx[s + 1].
  * ws: exchange workspace of mr_decode_persist_ws_bytes(N) bytes, zeroed by the call (ws_bytes > 0) or by the caller (pass the
  * size NEGATIVE).  A hand-off that times out records a code in the status word behind the workspace and poisons h' with NaN. */
-int mr_decode_persist_ok(int dtype, int N, int T, int H, int Ep);   /* host only; 0 also when mr_tuning.decode_persist = 0 */
+int mr_decode_persist_ok(int dtype, int N, int T, int H, int Ep);   /* host only; 0 also when mr_tuning.decode_persist = 0 or the
+                                                                        current device has fewer CUs than the launch has workgroups */
 long long mr_decode_persist_ws_bytes(int N);                        /* host only */
 int mr_decode_persist_fwd(const void* cat_w, const float* cat_b, const void* ic_w, long long ldic, const void* G, long long ldG,
                           long long* idx, const int* flags, const void* out_w, const float* out_b, int C, const void* eproj,
@@ -650,13 +651,14 @@ int mr_decode_persist_fwd(const void* cat_w, const float* cat_b, const void* ic_
  * per step (N <= 32).  cat_wt [H][4H] and ic_wt [Ep][ldict >= 3H] are the TRANSPOSED weight images (row = output of the backward
  * GEMM, K = stacked column / gate unit); DHO_all [S][N][H] = gradient of every h' from the output layer; ga (nullable) = gradient
  * of the attention weights, element (n, s, t) at ga[n * ldga + s * T + t].  Writes DGI_all [S][N][3H], DHC_all [S][N][4H],
- * DCTX_all [S][N][Ep], deproj [N][T][H] (f32, plain stores: the per-step path accumulates into it) and ADDS into dv [H] (f32). */
+ * DCTX_all [S][N][Ep], deproj [N][T][H] (f32, plain stores: the per-step path accumulates into it), ADDS into dv [H] (f32) and,
+ * when denc is not null, writes denc [N][T][Ep] = sum_s W_att[s] dctx[s] (what mr_attn_denc computes after the per-step loop). */
 int mr_decode_persist_bwd_ok(int dtype, int N, int T, int H, int Ep);   /* host only */
 long long mr_decode_persist_bwd_ws_bytes(int N);                        /* host only */
 int mr_decode_persist_bwd(const void* cat_wt, const void* ic_wt, long long ldict, const void* eproj, const void* enc,
                           const float* v, const void* H_all, const void* HC_all, const float* W_att, const float* SAVE_all,
                           const void* DHO_all, const float* ga, long long ldga, void* DGI_all, void* DHC_all, void* DCTX_all,
-                          float* deproj, float* dv, void* ws, long long ws_bytes, int S, int N, int T, int Ep,
+                          float* deproj, float* dv, void* denc, void* ws, long long ws_bytes, int S, int N, int T, int Ep,
                           hipStream_t stream);
 
 /* ---- Round-4 decode-step fusions (csrc/gemm_skinny.hip): the element-wise GRU kernels in the epilogue of the M <= 32 GEMM next

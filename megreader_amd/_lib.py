@@ -107,7 +107,7 @@ SIGNATURES = {
     "mr_gemm_gru_fwd": "iplplplpplpppiiis",
     "mr_gemm_gru_bwd": "iplplpppplppplpiiis",
     "mr_decode_persist_fwd": "ppp" + "l" + "p" + "l" + "pppp" + "i" + "p" * 9 + "l" + "iiii" + "s",
-    "mr_decode_persist_bwd": "pp" + "l" + "p" * 9 + "l" + "p" * 6 + "l" + "iiii" + "s",
+    "mr_decode_persist_bwd": "pp" + "l" + "p" * 9 + "l" + "p" * 7 + "l" + "iiii" + "s",
     "mr_out_nll_fwd": "iplplpplpppppp" + "iiiis",
     "mr_nll_step_fwd": "ipiplppppiiiis",
     "mr_nll_step_feed_fwd": "ipiplpppppp" + "iiis",

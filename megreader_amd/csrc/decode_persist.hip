@@ -1,10 +1,11 @@
-// Persistent forward of the Bahdanau-attention GRU decode loop for gfx950: ONE launch for all S steps instead of three dependent
-// launches per step (reference: the python loop of decoders/attention_decoder.py:84-118 around AttentionRNNCell, :146-231).
+// The Bahdanau-attention GRU decode loop as persistent kernels for gfx950: ONE launch for all S steps of the forward pass and one
+// for the backward pass, instead of three dependent launches per step and direction (reference: the python loop of
+// decoders/attention_decoder.py:84-118 around AttentionRNNCell, :146-231).
 //
-// Why: a teacher-forced step at the published shape (N = 16 samples, T = 64 positions, H = 512, Ep = 552) is
+// Why: a step at the published shape (N = 32 samples, T = 64 positions, H = 512, Ep = 552) is
 //   [h W_cat^T]  ->  [energies / softmax / context]  ->  [context W_ic^T + GRU cell]
-// = 4.2 + 6.8 + 7.3 us of launch-latency-sized kernels plus the gaps between them (18.5 us per step replayed from a graph), 32
-// times, on 16-32 of 256 CUs, each launch re-reading its weights (2 MB + 1.7 MB) from L2.
+// = 4.2 + 6.8 + 7.3 us of launch-latency-sized kernels plus the gaps between them (20.4 us per step replayed from a graph; 27.4 us
+// for the backward), 32 times, on 16-32 of 256 CUs, each launch re-reading its weights (2 MB + 1.7 MB) from L2.
 //
 // Decomposition (bf16, H = 512).  Samples are independent through the recurrence, hidden units are not:
 //   * the batch is cut into groups of R rows (R = 4 up to 32 samples, else 8: the bytes a workgroup gathers per hand-off scale
@@ -13,21 +14,26 @@
 //     projection, their r / z / n rows of W_hh (4 x 16 rows of W_cat, one MFMA tile per wave) and of W_ic (3 tiles).  All of it
 //     -- 64 + 54 KB -- is loaded ONCE into the waves' VGPRs and stays there for all S steps; the slice's 16 columns of eproj
 //     stay in LDS;
-//   * slice g also serves sample g / (32/R) of the group: it holds a 1/(32/R) share of that sample's encoder channels in LDS.
-// One step = three all-to-all hand-offs inside the group:
+//   * slice g also serves sample g / (32/R) of the group: it holds a 1/(32/R) share of that sample's encoder channels in LDS;
+//   * 32 slices are the 32 CUs of one XCD: the block map puts a group on one XCD (decode_roles), the placement is VERIFIED per
+//     launch (group_on_one_xcd) and only then are granules published with plain stores that stay in that XCD's L2.
+// One forward step = three all-to-all hand-offs inside the group:
 //   1. slice g computes hproj / gh of its units (MFMA, h from LDS) and, for every (sample, position), the PARTIAL energy
 //      sum_{j in own units} v_j tanh(hproj_j + eproj_j); every slice REDUCES the partials of its sample over the 32 producers
 //      (16 KB of granules in), softmax, and the context of its channel share = sum_t w_t enc_t from LDS;
 //   2. the R contexts are ALL-GATHERED (R x Ep bf16) into every slice's LDS; GEMM with the W_ic tiles; GRU cell of the
 //      slice's units (one thread per (sample, unit));
 //   3. h' is ALL-GATHERED (R x 512 bf16) into every slice's LDS: the next step's MFMA operand.
-// Protocol: lstm_persist.hip's -- a granule is one naturally aligned 8-byte {value, tag} written by one sc1 (agent scope,
-// write-through) store and polled by sc1 loads; tag = step + 1, never 0; the exchange buffer is zeroed ahead of the launch;
-// two slots alternate (every hand-off is all-to-all inside the group, so no producer can run two steps ahead of a consumer).
+//   With arg-max feedback (flags[s] == 0: attention_decoder.py:107-110) wave 3 also scores the slice's 8 classes of the output
+//   layer on the h' it holds; the best (logit, class) of every (sample, slice) rides in the energies sweep of the next step.
+// The backward kernel (second half of the file) runs the steps in reverse with three reduce-scatters of f32 partial sums.
+// Protocol: lstm_persist.hip's -- a granule is one naturally aligned 8-byte {value, tag} written by one store and polled by sc1
+// (agent scope, L1-bypassing) loads; tag = step + 1, never 0; the exchange buffer is zeroed ahead of the launch; two slots
+// alternate (every hand-off is all-to-all inside the group, so no producer can run two steps ahead of a consumer).
 // Every spin is bounded: on timeout the workgroup records a code in the status word, stops waiting and POISONS h' with NaN.
 //
 // Results: the buffers the per-step path saves for the backward (H_all, HC_all, W_att, CTX_all, SAVE_all), rounded at the same
-// points (hproj / gh / context / h to bf16, the context part of the input gates kept in f32), so the backward is unchanged.
+// points (hproj / gh / context / h to bf16, the context part of the input gates kept in f32), so either backward can follow.
 #include "common.h"
 #include "igemm_core.h"
 #include "../../include/megreader_hip.h"
@@ -673,6 +679,8 @@ struct DecB {
   bf16_t* DCTX_all;        // [S][N][Ep]
   float* deproj;           // [N][T][H]   written
   float* dv;               // [H]         atomically added to
+  bf16_t* denc;            // [N][T][Ep]  gradient of the encoder rows, sum_s w[s, n, t] dctx[s, n, c] (what mr_attn_denc computes
+                           //             after the per-step loop), or null
   u64* xch;
   unsigned* status;
   int S, N, T, Ep, nbg;
@@ -785,6 +793,10 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
     }
   }
   float dvq = 0.f;
+  // denc of this slice's (sample, channel share): thread <-> (position lane, channel group wave of 18), over all steps
+  float dnc[18];
+#pragma unroll
+  for (int j = 0; j < 18; ++j) dnc[j] = 0.f;
   // ---- LDS residents
   for (int i = tid; i < T * upp; i += 256) {
     const int t = i / upp, u = i - t * upp;
@@ -852,6 +864,8 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
       hpv = ((const unsigned short*)a.H_all)[rn * DH + jg];
       dhc = ((const unsigned short*)a.DHO_all)[rn * DH + jg];
     }
+    float wden = 0.f;            // softmax weight of (this slice's sample, position lane)
+    if (a.denc && row_o_ok && lane < T) wden = a.W_att[((long long)s * N + row_o) * T + lane];
     float2 wat[R / 4];
 #pragma unroll
     for (int i = 0; i < R / 4; ++i) {
@@ -969,6 +983,14 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
     }
     DEC_TICK(4)
     // ---- partial dw[t] = dctx[share] . enc[t, share]  (wave = unit quarter, lane = position) -> edge B
+    if (a.denc) {
+#pragma unroll
+      for (int j = 0; j < 18; j += 2) {
+        const float2 dc = *(const float2*)(sDctx + wave * 18 + j);
+        dnc[j] += wden * dc.x;
+        dnc[j + 1] += wden * dc.y;
+      }
+    }
     {
       const int uq = (nown + 3) >> 2, ub = wave * uq, ue = min(nown, ub + uq);
       float d = 0.f;
@@ -1098,6 +1120,12 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         if (t < T) a.deproj[((long long)r * T + t) * DH + g * DU + tq] = dacc[j];
       }
     }
+    if (a.denc && row_o_ok && lane < T) {
+      bf16_t* dp = a.denc + ((long long)row_o * T + lane) * Ep + u0 * 4 + wave * 18;
+#pragma unroll
+      for (int j = 0; j < 18; j += 2)
+        if (wave * 18 + j < 4 * nown) *(unsigned*)(dp + j) = pack_bf16(dnc[j], dnc[j + 1]);
+    }
     dvq += __shfl_xor(dvq, 16, 64);
     dvq += __shfl_xor(dvq, 32, 64);
     if (lane < DU) atomicAdd(a.dv + g * DU + lane, dvq);
@@ -1106,12 +1134,25 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
 
 namespace {
 // rows per batch group: 4 while the grid (32 workgroups per group, ONE per CU: 460+ registers a lane) stays within the 256 CUs,
-// else 8.  The bytes a workgroup gathers per hand-off scale with the rows: 4-row groups run a step in 8.3 us forward / 12.3 us
-// backward, 8-row groups in 10.6 / 21 us (the backward then spills).  All workgroups of a group must be co-resident; workgroups that
-// are dispatched late (a kernel of another stream still holds their CU) only delay their group -- every wait is bounded.
+// else 8.  The bytes a workgroup gathers per hand-off scale with the rows: before the XCD placement 4-row groups ran a step in
+// 8.6 us forward / 13.5 us backward, 8-row groups in 10.6 / 21 us (the backward then spills; it is built for 4 rows only).  All
+// workgroups of a group must be co-resident; workgroups that are dispatched late (a kernel of another stream still holds their CU)
+// only delay their group -- every wait is bounded (tests/test_decode_persist_gpu.py: beside a busy side stream).
 int decode_rows(int N) { return N <= 32 ? 4 : 8; }
-// decode_persist = 2: never use the XCD-colocating block map (A/B knob)
-int decode_xmap(int nbg) { return (MR_TUNE(decode_persist) != 2 && nbg <= 8) ? 1 : 0; }
+// CUs of the current device (cached per device): every workgroup of a launch must be resident at once, one per CU
+int decode_cus() {
+  static int cus[MR_MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MR_MAX_DEVICES) return 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus[dev] = n > 0 ? n : -1;
+  }
+  return cus[dev] > 0 ? cus[dev] : 0;
+}
+// the XCD-colocating block map assumes the whole chip: 8 XCDs x 32 CUs.  decode_persist = 2: never use it (A/B knob)
+int decode_xmap(int nbg) { return (MR_TUNE(decode_persist) != 2 && nbg <= 8 && decode_cus() == 8 * DG) ? 1 : 0; }
 unsigned decode_group_bytes(int R) { return R == 4 ? Xch<4>::GROUP : Xch<8>::GROUP; }
 long long decode_ws_bytes(int N) {
   const int R = decode_rows(N);
@@ -1162,12 +1203,14 @@ int decode_bwd_launch(const DecB& a, hipStream_t stream) {
 
 extern "C" {
 
-// host only: can the persistent decode forward take this shape?  (bf16, H = 512, N <= 64, T <= 64, Ep <= 576 a multiple of 8)
+// host only: can the persistent decode forward take this shape on the current device?  (bf16, H = 512, N <= 64, T <= 64,
+// Ep <= 576 a multiple of 8, ceil(N / rows) * 32 <= CUs)
 int mr_decode_persist_ok(int dtype, int N, int T, int H, int Ep) {
-  return (dtype == MR_BF16 && H == DH && N >= 1 && N <= 64 && T >= 1 && T <= DT && Ep >= 8 && Ep <= DEPMAX && Ep % 8 == 0 &&
-          MR_TUNE(decode_persist) != 0)
-             ? 1
-             : 0;
+  if (!(dtype == MR_BF16 && H == DH && N >= 1 && N <= 64 && T >= 1 && T <= DT && Ep >= 8 && Ep <= DEPMAX && Ep % 8 == 0 &&
+        MR_TUNE(decode_persist) != 0))
+    return 0;
+  // one workgroup per CU, all of them resident at once (a partitioned or smaller device falls back to the per-step launches)
+  return cdiv(N, decode_rows(N)) * DG <= decode_cus() ? 1 : 0;
 }
 
 long long mr_decode_persist_ws_bytes(int N) { return decode_ws_bytes(N); }
@@ -1213,12 +1256,12 @@ long long mr_decode_persist_bwd_ws_bytes(int N) { return N <= 32 ? decode_bwd_ws
 // mr_gemm_nt + mr_attn_bwd2 launches compute.  cat_wt [H][4H] and ic_wt [Ep][ldict >= 3H] are the TRANSPOSED weight images
 // (row = output of the backward GEMM); DHO_all [S][N][H] = gradient of every h' from the output layer; ga (nullable) = gradient
 // of the attention weights, element (n, s, t) at ga[n * ldga + s * T + t].  Writes DGI_all [S][N][3H], DHC_all [S][N][4H],
-// DCTX_all [S][N][Ep], deproj [N][T][H] (f32, plain stores) and ADDS into dv [H] (f32).  ws as mr_decode_persist_fwd
-// (mr_decode_persist_bwd_ws_bytes).
+// DCTX_all [S][N][Ep], deproj [N][T][H] (f32, plain stores), ADDS into dv [H] (f32) and, when denc is not null, writes
+// denc [N][T][Ep] = sum_s W_att[s] dctx[s] (mr_attn_denc's result).  ws as mr_decode_persist_fwd (mr_decode_persist_bwd_ws_bytes).
 int mr_decode_persist_bwd(const void* cat_wt, const void* ic_wt, long long ldict, const void* eproj, const void* enc,
                           const float* v, const void* H_all, const void* HC_all, const float* W_att, const float* SAVE_all,
                           const void* DHO_all, const float* ga, long long ldga, void* DGI_all, void* DHC_all, void* DCTX_all,
-                          float* deproj, float* dv, void* ws, long long ws_bytes, int S, int N, int T, int Ep,
+                          float* deproj, float* dv, void* denc, void* ws, long long ws_bytes, int S, int N, int T, int Ep,
                           hipStream_t stream) {
   const bool prezeroed = ws_bytes < 0;
   if (prezeroed) ws_bytes = -ws_bytes;
@@ -1233,7 +1276,7 @@ int mr_decode_persist_bwd(const void* cat_wt, const void* ic_wt, long long ldict
   }
   DecB a{(const bf16_t*)cat_wt, (const bf16_t*)ic_wt, ldict, (const bf16_t*)eproj, (const bf16_t*)enc, v,
          (const bf16_t*)H_all, (const bf16_t*)HC_all, W_att, SAVE_all, (const bf16_t*)DHO_all, ga, ldga, (bf16_t*)DGI_all,
-         (bf16_t*)DHC_all, (bf16_t*)DCTX_all, deproj, dv, (u64*)ws,
+         (bf16_t*)DHC_all, (bf16_t*)DCTX_all, deproj, dv, (bf16_t*)denc, (u64*)ws,
          (unsigned*)((char*)ws + (long long)nbg * decode_bwd_group_bytes(R) + HELLO_BYTES), S, N, T, Ep, nbg, decode_xmap(nbg),
          (unsigned)(nbg * decode_bwd_group_bytes(R))};
   return decode_bwd_launch<4>(a, stream);

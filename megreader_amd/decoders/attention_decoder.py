@@ -439,9 +439,10 @@ class _DecodeLoopFn(Function):
                    and bool(load().mr_decode_persist_bwd_ok(dt, N, T, Hd, Ep)))
         if persist:
             ws, ws_size = _persist_workspace(N, dev, backward=True)
+            denc = torch.empty((N, T, Ep), dtype=dtype, device=dev)       # summed over the steps inside the kernel
             call("mr_decode_persist_bwd", ptr(cat.w_t), ptr(ic.w_t), H3, ptr(eproj), ptr(enc), ptr(vf), ptr(H_all), ptr(HC_all),
                  ptr(W_att), ptr(SAVE_all), ptr(DHO_all), ptr(ga) if ga is not None else 0, S * T, ptr(DGI_all), ptr(DHC_all),
-                 ptr(DCTX_all), ptr(deproj), ptr(dv), ptr(ws), ws_size, S, N, T, Ep)
+                 ptr(DCTX_all), ptr(deproj), ptr(dv), ptr(denc), ptr(ws), ws_size, S, N, T, Ep)
         for s in range(-1 if persist else S - 1, -1, -1):
             last = s == S - 1
             if fused and not last:
@@ -471,8 +472,9 @@ class _DecodeLoopFn(Function):
         call("mr_gemm_tn", dt, ptr(DL_all), out.np_, ptr(H_all[1]), Hd, ptr(dWout), Hd, P, out.np_, Hd, 0, ptr(dbout))
         dG = torch.zeros((G.shape[0], G.shape[1]), dtype=torch.float32, device=dev)
         call("mr_rows_scatter_add", dt, ptr(idx_all), ptr(DGI_all), H3, ptr(dG), P, G.shape[0], G.shape[1])
-        denc = torch.empty((N, T, Ep), dtype=dtype, device=dev)
-        call("mr_attn_denc", dt, ptr(W_att), ptr(DCTX_all), ptr(denc), S, N, T, Ep)
+        if not persist:
+            denc = torch.empty((N, T, Ep), dtype=dtype, device=dev)
+            call("mr_attn_denc", dt, ptr(W_att), ptr(DCTX_all), ptr(denc), S, N, T, Ep)
         return (dG.to(dtype), deproj.to(dtype), denc, dv, dWcat[:Hd], dWcat[Hd:], dbcat[Hd:], dWic[:, :E], dWout[:C],
                 dbout[:C], None, None, None, None)
 

@@ -170,6 +170,7 @@ def _bwd_buffers(N, T, Ep, S):
     return {"DGI": torch.full((S, N, 3 * H), float("nan"), dtype=bf, device=DEV),
             "DHC": torch.full((S, N, 4 * H), float("nan"), dtype=bf, device=DEV),
             "DCTX": torch.full((S, N, Ep), float("nan"), dtype=bf, device=DEV),
+            "denc": torch.full((N, T, Ep), float("nan"), dtype=bf, device=DEV),
             "deproj": torch.zeros((N, T, H), dtype=torch.float32, device=DEV),
             "dv": torch.zeros((H,), dtype=torch.float32, device=DEV)}
 
@@ -194,6 +195,7 @@ def _bwd_per_step(d, fw, x, N, T, Ep, S):
         call("mr_attn_bwd2", dt, ptr(b["DCTX"][s]), (ptr(ga) + s * T * 4) if ga is not None else 0, S * T,
              ptr(fw["HC_all"][s]), HC, ptr(d["eproj"]), ptr(d["v"]), ptr(d["enc"]), ptr(fw["W_att"][s]), ptr(b["DHC"][s]), HC,
              ptr(b["deproj"]), ptr(b["dv"]), N, T, H, Ep)
+    call("mr_attn_denc", dt, ptr(fw["W_att"]), ptr(b["DCTX"]), ptr(b["denc"]), S, N, T, Ep)
     return b
 
 
@@ -207,7 +209,7 @@ def _bwd_persistent(d, fw, x, N, T, Ep, S, prezero=True):
     call("mr_decode_persist_bwd", ptr(x["cat_wt"]), ptr(x["ic_wt"]), 3 * H, ptr(d["eproj"]), ptr(d["enc"]), ptr(d["v"]),
          ptr(fw["H_all"]), ptr(fw["HC_all"]), ptr(fw["W_att"]), ptr(fw["SAVE_all"]), ptr(x["DHO"]),
          ptr(ga) if ga is not None else 0, S * T, ptr(b["DGI"]), ptr(b["DHC"]), ptr(b["DCTX"]), ptr(b["deproj"]), ptr(b["dv"]),
-         ptr(ws), -nbytes if prezero else nbytes, S, N, T, Ep)
+         ptr(b["denc"]), ptr(ws), -nbytes if prezero else nbytes, S, N, T, Ep)
     torch.cuda.synchronize()
     status = int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item())
     return b, status
@@ -264,7 +266,7 @@ def test_persistent_decode_backward_matches_per_step_launches(N, T, Ep, S, C, wi
     assert status == 0, "a hand-off of the persistent decode backward timed out (code %d)" % status
     # both paths round dgi / dgh / dctx / dhproj to bf16 at the same points; the persistent kernel carries dh_b in f32 (the
     # launches round it to bf16 between steps) and sums its GEMMs in another order
-    for k in ("DGI", "DHC", "DCTX"):
+    for k in ("DGI", "DHC", "DCTX", "denc"):
         _close(got[k], ref[k], 4e-2, 1e-2, k)
     _close(got["deproj"], ref["deproj"], 2e-2, 5e-3, "deproj")
     _close(got["dv"], ref["dv"], 2e-2, 1e-2, "dv")
@@ -295,7 +297,7 @@ def test_persistent_decode_backward_repeatable():
     a, sa = _bwd_persistent(d, fw, x, N, T, Ep, S, True)
     b, sb = _bwd_persistent(d, fw, x, N, T, Ep, S, False)
     assert sa == 0 and sb == 0
-    for k in ("DGI", "DHC", "DCTX", "deproj"):
+    for k in ("DGI", "DHC", "DCTX", "deproj", "denc"):
         assert torch.equal(a[k], b[k]), k
     assert float((a["dv"] - b["dv"]).abs().max()) <= 1e-5 * float(b["dv"].abs().max())     # atomics: order of the four waves
     assert load().mr_decode_persist_bwd_ok(dtype_code(torch.bfloat16), 33, T, H, Ep) == 0
@@ -407,6 +409,6 @@ def test_persistent_decode_beside_a_busy_side_stream():
             assert st == 0, (it, st)
         for k in ("H_all", "HC_all", "W_att", "CTX_all", "SAVE_all", "idx"):
             assert torch.equal(got[k], ref[k]), (it, k)
-        for k in ("DGI", "DHC", "DCTX", "deproj"):
+        for k in ("DGI", "DHC", "DCTX", "deproj", "denc"):
             assert torch.equal(bgot[k], bref[k]), (it, k)
     torch.cuda.synchronize()

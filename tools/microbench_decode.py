@@ -86,7 +86,7 @@ def persistent_bwd(timing=False):
         wsb[nb - 256:].view(torch.int32)[2] = 0x54494D45
     call("mr_decode_persist_bwd", ptr(x["cat_wt"]), ptr(x["ic_wt"]), 3 * H, ptr(d["eproj"]), ptr(d["enc"]), ptr(d["v"]),
          ptr(fw["H_all"]), ptr(fw["HC_all"]), ptr(fw["W_att"]), ptr(fw["SAVE_all"]), ptr(x["DHO"]), 0, S * T, ptr(bb["DGI"]),
-         ptr(bb["DHC"]), ptr(bb["DCTX"]), ptr(bb["deproj"]), ptr(bb["dv"]), ptr(wsb), -nb, S, N, T, Ep)
+         ptr(bb["DHC"]), ptr(bb["DCTX"]), ptr(bb["deproj"]), ptr(bb["dv"]), ptr(bb["denc"]), ptr(wsb), -nb, S, N, T, Ep)
 
 
 us = timed(persistent_bwd)

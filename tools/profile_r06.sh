@@ -3,10 +3,12 @@
 #   rocprofv3 kernel traces of the five bench workloads + the CRNN at 32 crops per GPU: per-kernel statistics and the launch
 #   sequence of one replayed step; FETCH_SIZE / WRITE_SIZE PMC passes (separate passes) of ALL five workloads ->
 #   pmc_traffic_<workload>.json, stamped with the kernel-source hash bench.py checks.
-# usage: bash tools/profile_r06.sh [quick]      (quick: no PMC passes)
+# usage: bash tools/profile_r06.sh [quick|pmc]      (quick: no PMC passes; pmc: only the PMC passes)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r06p; mkdir -p $O
+MODE=$1
 trace() {   # name, marker, bench args...
+  if [ "$MODE" = "pmc" ]; then return; fi
   local name=$1; local marker=$2; shift; shift
   timeout 300 rocprofv3 --kernel-trace -d $O/trace_$name -- python bench.py "$@" --no-cpu-baseline --no-secondary --no-kernel-timer --steps 10 --warmup 3 > $O/trace_$name.log 2>&1
   local db=$(find $O/trace_$name -name "*.db" | head -1)
@@ -49,6 +51,7 @@ pmc db --workload db
 pmc res50ppm_64x256 --workload res50ppm --crop 64x256
 fi
 echo done
+if [ "$MODE" = "pmc" ]; then exit 0; fi
 # ---- extras of round 6: the configuration world > 1 actually runs (bn_onepass = 0), the multi-GPU code path on one rank, the
 # reference-precision line, the MFMA ceiling
 {
