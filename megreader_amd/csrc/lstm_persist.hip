@@ -182,6 +182,17 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
   const int j0 = g * PHS + u0;                // ... as a hidden-unit index
   float cst[4] = {0.f, 0.f, 0.f, 0.f};
   bool dead = false;
+  // phase clock (tools/microbench_lstm.py --phases): thread 0 of workgroup 0 adds the 100 MHz wall clock spent in each phase of a
+  // step into status words [8 + phase]; only when the caller set status word 2 (the product never does)
+  const bool timing = tid == 0 && blockIdx.x == 0 && a.status[2] == 0x54494D45u;
+  unsigned long long tprev = timing ? wall_clock64() : 0ull;
+  unsigned tacc[4] = {0, 0, 0, 0};
+#define LSTM_TICK(i)                                  \
+  if (timing) {                                       \
+    const unsigned long long tn_ = wall_clock64();    \
+    tacc[i] += (unsigned)(tn_ - tprev);               \
+    tprev = tn_;                                      \
+  }
 
   for (int s = 0; s < a.T; ++s) {
     const int t = dir == 0 ? s : a.T - 1 - s;
@@ -227,6 +238,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
           __builtin_amdgcn_s_sleep(1);
         }
       }
+      LSTM_TICK(0)
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int gf = k + (k >= g);
@@ -241,6 +253,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) Mma<bf16_t>::run(acc[i], wf[i][c], hf[c]);
     }
+    LSTM_TICK(1)
     // ---- gate math (lane owns the 4 gates of (row, unit) for 4 consecutive units), state in registers
     float hv[4], gt[4][4];
 #pragma unroll
@@ -268,6 +281,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
                     (unsigned)(s + 1), local);
       *(uint2*)(&hbuf[(s + 1) & 1][l15][j0]) = make_uint2(h01, h23);
     }
+    LSTM_TICK(2)
     if (row_ok) {
       *(uint2*)(a.out + r * 2 * H + dir * H + j0) = make_uint2(h01, h23);
       *(f32x4*)(a.cbuf + r * 2 * H + dir * H + j0) = f32x4{cst[0], cst[1], cst[2], cst[3]};
@@ -280,7 +294,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
       *(uint4*)gp = g0;
       *(uint4*)(gp + 8) = g1;
     }
+    LSTM_TICK(3)
   }
+  if (timing) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.status[8 + i] = tacc[i];
+  }
+#undef LSTM_TICK
 }
 
 struct LstmPBwd {

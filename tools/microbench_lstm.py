@@ -66,6 +66,26 @@ def main():
         print("  workgroups that found their batch group on one XCD (fwd, bwd): %s of %d" %
               ([int(w.view(torch.int32).item()) for w in F.LSTM_LOCAL], 2 * ((N + 15) // 16) * 4))
         F.LSTM_LOCAL = None
+        if "--phases" in sys.argv:
+            # the forward kernel's own phase clock (status words 8..11 of its workspace, armed by status word 2)
+            orig = F._lstm_workspace
+            seen = []
+
+            def armed(dt, T_, N_, H_, dev):
+                ws, size = orig(dt, T_, N_, H_, dev)
+                if ws is not None:
+                    ws[ws.numel() - 256:].view(torch.int32)[2] = 0x54494D45
+                    seen.append(ws)
+                return ws, size
+            F._lstm_workspace = armed
+            try:
+                fwd()
+                torch.cuda.synchronize()
+            finally:
+                F._lstm_workspace = orig
+            st = seen[0][seen[0].numel() - 256:].view(torch.int32).cpu()
+            names = ["gather wait", "LDS + MFMA", "gate math + publish", "stores"]
+            print("  forward phases (us per step): " + "  ".join("%s %.2f" % (n, int(st[8 + i]) * 0.01 / T) for i, n in enumerate(names)))
         tf = timeit(graphed(fwd))
         tfb = timeit(graphed(fwdbwd))
         print("  BiLSTM I=%d: fwd %.1f us, fwd+bwd %.1f us (bwd ~%.1f us)" % (I, tf, tfb, tfb - tf))

@@ -69,6 +69,7 @@ RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 timeout
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 20 --warmup 5 --no-secondary --no-cpu-baseline > $O/bench_torchrun_n1.json 2> $O/bench_torchrun_n1.err
 timeout 300 python bench.py --workload res50ppm --dtype f32 --no-secondary --steps 10 --warmup 3 > $O/bench_res50ppm_f32.json 2> $O/bench_res50ppm_f32.err
 tools/mfma_ceiling > $O/mfma_ceiling.txt 2>&1
+timeout 300 python tools/microbench_lstm.py --phases 2>&1 | grep -v amdgpu.ids > $O/lstm_phases.txt
 # the persistent decode kernels beside the per-step launches they replace, with the kernels' own phase clock
 {
 for cfg in "32 64 552 32" "32 64 552 32 coins" "16 64 552 32"; do
