@@ -182,6 +182,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
   const int j0 = g * PHS + u0;                // ... as a hidden-unit index
   float cst[4] = {0.f, 0.f, 0.f, 0.f};
   bool dead = false;
+  // The step's global stores (out / cbuf / gates, 56 bytes a lane) are off the chain, but a vector-memory wait counts loads and
+  // stores together: issued right behind the publish they made the NEXT step's granule sweep wait for their write
+  // acknowledgements.  They are held in registers and issued when that sweep has completed, in the shadow of the MFMAs.
+  uint2 pend_h = make_uint2(0, 0);
+  f32x4 pend_c = {0.f, 0.f, 0.f, 0.f};
+  uint4 pend_g0 = make_uint4(0, 0, 0, 0), pend_g1 = pend_g0;
+  long long pend_r = -1;
   // phase clock (tools/microbench_lstm.py --phases): thread 0 of workgroup 0 adds the 100 MHz wall clock spent in each phase of a
   // step into status words [8 + phase]; only when the caller set status word 2 (the product never does)
   const bool timing = tid == 0 && blockIdx.x == 0 && a.status[2] == 0x54494D45u;
@@ -197,19 +204,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
   for (int s = 0; s < a.T; ++s) {
     const int t = dir == 0 ? s : a.T - 1 - s;
     const long long r = (long long)t * a.N + row;
-    // operands of the gate math that do not depend on the recurrent term: in flight during the exchange
-    f32x4 xg[4];
-    {
+    // operands of the gate math that do not depend on the recurrent term: in flight during the exchange.  (Fetching them a step
+    // ahead -- behind the sweep, behind the MFMAs or at the end of the step -- measured 2-5 us slower per layer: the loads
+    // then sit in front of the fragment reads or the gate math instead of under the hand-off wait.)
+    uint4 x0 = make_uint4(0, 0, 0, 0), x1 = x0;
+    if (row_ok) {
       const bf16_t* xp = a.xproj + r * 8 * H + dir * 4 * H + 4 * j0;
-      uint4 x0 = make_uint4(0, 0, 0, 0), x1 = x0;
-      if (row_ok) { x0 = *(const uint4*)xp; x1 = *(const uint4*)(xp + 8); }
-      const bf16_t* p0 = (const bf16_t*)&x0;
-      const bf16_t* p1 = (const bf16_t*)&x1;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        xg[0][q] = (float)p0[q]; xg[1][q] = (float)p0[4 + q];
-        xg[2][q] = (float)p1[q]; xg[3][q] = (float)p1[4 + q];
-      }
+      x0 = *(const uint4*)xp;
+      x1 = *(const uint4*)(xp + 8);
     }
     f32x4 acc[4];
 #pragma unroll
@@ -244,6 +246,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
         const int gf = k + (k >= g);
         *(uint2*)(hb + l15 * PLD + gf * PHS + u0) = make_uint2(v[k][0], v[k][2]);
       }
+      if (pend_r >= 0) {       // the previous step's outputs
+        *(uint2*)(a.out + pend_r * 2 * H + dir * H + j0) = pend_h;
+        *(f32x4*)(a.cbuf + pend_r * 2 * H + dir * H + j0) = pend_c;
+        bf16_t* gpp = a.gates + pend_r * 8 * H + dir * 4 * H + 4 * j0;
+        *(uint4*)gpp = pend_g0;
+        *(uint4*)(gpp + 8) = pend_g1;
+      }
       __syncthreads();
       Frag hf[8];
 #pragma unroll
@@ -254,6 +263,17 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
         for (int i = 0; i < 4; ++i) Mma<bf16_t>::run(acc[i], wf[i][c], hf[c]);
     }
     LSTM_TICK(1)
+    // operands of the gate math that do not depend on the recurrent term
+    f32x4 xg[4];
+    {
+      const bf16_t* p0 = (const bf16_t*)&x0;
+      const bf16_t* p1 = (const bf16_t*)&x1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        xg[0][q] = (float)p0[q]; xg[1][q] = (float)p0[4 + q];
+        xg[2][q] = (float)p1[q]; xg[3][q] = (float)p1[4 + q];
+      }
+    }
     // ---- gate math (lane owns the 4 gates of (row, unit) for 4 consecutive units), state in registers
     float hv[4], gt[4][4];
 #pragma unroll
@@ -282,19 +302,23 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
       *(uint2*)(&hbuf[(s + 1) & 1][l15][j0]) = make_uint2(h01, h23);
     }
     LSTM_TICK(2)
-    if (row_ok) {
-      *(uint2*)(a.out + r * 2 * H + dir * H + j0) = make_uint2(h01, h23);
-      *(f32x4*)(a.cbuf + r * 2 * H + dir * H + j0) = f32x4{cst[0], cst[1], cst[2], cst[3]};
-      uint4 g0, g1;
-      g0.x = pack_bf16(gt[0][0], gt[0][1]); g0.y = pack_bf16(gt[0][2], gt[0][3]);
-      g0.z = pack_bf16(gt[1][0], gt[1][1]); g0.w = pack_bf16(gt[1][2], gt[1][3]);
-      g1.x = pack_bf16(gt[2][0], gt[2][1]); g1.y = pack_bf16(gt[2][2], gt[2][3]);
-      g1.z = pack_bf16(gt[3][0], gt[3][1]); g1.w = pack_bf16(gt[3][2], gt[3][3]);
-      bf16_t* gp = a.gates + r * 8 * H + dir * 4 * H + 4 * j0;
-      *(uint4*)gp = g0;
-      *(uint4*)(gp + 8) = g1;
+    {
+      pend_h = make_uint2(h01, h23);
+      pend_c = f32x4{cst[0], cst[1], cst[2], cst[3]};
+      pend_g0.x = pack_bf16(gt[0][0], gt[0][1]); pend_g0.y = pack_bf16(gt[0][2], gt[0][3]);
+      pend_g0.z = pack_bf16(gt[1][0], gt[1][1]); pend_g0.w = pack_bf16(gt[1][2], gt[1][3]);
+      pend_g1.x = pack_bf16(gt[2][0], gt[2][1]); pend_g1.y = pack_bf16(gt[2][2], gt[2][3]);
+      pend_g1.z = pack_bf16(gt[3][0], gt[3][1]); pend_g1.w = pack_bf16(gt[3][2], gt[3][3]);
+      pend_r = row_ok ? r : -1;
     }
     LSTM_TICK(3)
+  }
+  if (pend_r >= 0) {           // the last step's outputs
+    *(uint2*)(a.out + pend_r * 2 * H + dir * H + j0) = pend_h;
+    *(f32x4*)(a.cbuf + pend_r * 2 * H + dir * H + j0) = pend_c;
+    bf16_t* gpp = a.gates + pend_r * 8 * H + dir * 4 * H + 4 * j0;
+    *(uint4*)gpp = pend_g0;
+    *(uint4*)(gpp + 8) = pend_g1;
   }
   if (timing) {
 #pragma unroll
@@ -348,30 +372,38 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
   const int j0 = g * PHS + u0;               // global hidden unit of e = 0
   float dcar[4] = {0.f, 0.f, 0.f, 0.f};
   bool dead = false;
+  // the step's global store (the gate gradients, 32 bytes a lane) is held back until the NEXT step's granule sweep has completed:
+  // behind the publish it made that sweep wait for its write acknowledgement (see the forward kernel)
+  uint4 pend_d0 = make_uint4(0, 0, 0, 0), pend_d1 = pend_d0;
+  bf16_t* pend_gp = nullptr;
 
+  // The step's operands (dout, c_t, c_{t-1}, the saved gates: 72 bytes a lane out of 70 MB of buffers: HBM latency) are fetched
+  // ONE STEP AHEAD, behind the granule sweep: issued in front of it, the sweep's wait included their latency.
+  f32x4 n_up = {0.f, 0.f, 0.f, 0.f}, n_ct = n_up, n_cp = n_up;
+  uint4 n_x0 = make_uint4(0, 0, 0, 0), n_x1 = n_x0;
+  auto fetch = [&](int s1) {
+    const int t1 = dir == 0 ? a.T - 1 - s1 : s1;
+    const int tp1 = dir == 0 ? t1 - 1 : t1 + 1;
+    const bool has_prev1 = dir == 0 ? t1 > 0 : t1 < a.T - 1;
+    const long long r1 = (long long)t1 * a.N + row;
+    n_cp = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row_ok) {
+      n_up = load4(a.dout + r1 * 2 * H + dir * H + j0);
+      n_ct = *(const f32x4*)(a.cbuf + r1 * 2 * H + dir * H + j0);
+      if (has_prev1) n_cp = *(const f32x4*)(a.cbuf + ((long long)tp1 * a.N + row) * 2 * H + dir * H + j0);
+      const bf16_t* gp1 = a.gates + r1 * 8 * H + dir * 4 * H + 4 * j0;
+      n_x0 = *(const uint4*)gp1;
+      n_x1 = *(const uint4*)(gp1 + 8);
+    }
+  };
+  if (a.T > 0) fetch(0);
   for (int s = 0; s < a.T; ++s) {
     // backward visits the steps in the reverse of the forward order of that direction
     const int t = dir == 0 ? a.T - 1 - s : s;
-    const int tp = dir == 0 ? t - 1 : t + 1;     // previous step in forward order (c_prev)
-    const bool has_prev = dir == 0 ? t > 0 : t < a.T - 1;
     const long long r = (long long)t * a.N + row;
-    f32x4 up = {0.f, 0.f, 0.f, 0.f}, ct = up, cp = up, gq[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) gq[e] = up;
+    const f32x4 up = n_up, ct = n_ct, cp = n_cp;
+    const uint4 x0 = n_x0, x1 = n_x1;
     bf16_t* gp = a.gates + r * 8 * H + dir * 4 * H + 4 * j0;
-    if (row_ok) {
-      up = load4(a.dout + r * 2 * H + dir * H + j0);
-      ct = *(const f32x4*)(a.cbuf + r * 2 * H + dir * H + j0);
-      if (has_prev) cp = *(const f32x4*)(a.cbuf + ((long long)tp * a.N + row) * 2 * H + dir * H + j0);
-      const uint4 x0 = *(const uint4*)gp, x1 = *(const uint4*)(gp + 8);
-      const bf16_t* p0 = (const bf16_t*)&x0;
-      const bf16_t* p1 = (const bf16_t*)&x1;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        gq[0][q] = (float)p0[q]; gq[1][q] = (float)p0[4 + q];
-        gq[2][q] = (float)p1[q]; gq[3][q] = (float)p1[4 + q];
-      }
-    }
     f32x4 dh = up;
     if (s > 0) {
       // ---- reduce-scatter: 3 foreign partial sums (tag s, slot (s-1)&1) + the own one from LDS.
@@ -398,6 +430,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
           __builtin_amdgcn_s_sleep(1);
         }
       }
+      if (pend_gp) {
+        *(uint4*)pend_gp = pend_d0;
+        *(uint4*)(pend_gp + 8) = pend_d1;
+        pend_gp = nullptr;
+      }
+      if (s + 1 < a.T) fetch(s + 1);
       const f32x4 own = *(const f32x4*)&obuf[wave][lane][0];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -407,10 +445,21 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
         dh[e] += sum;
       }
     }
+    if (s == 0 && a.T > 1) fetch(1);      // first step: nothing to wait for
     // a timed-out hand-off poisons the gradients of this workgroup's rows with NaN (see the forward kernel)
     if (dead) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) dh[e] = __builtin_nanf("");
+    }
+    f32x4 gq[4];
+    {
+      const bf16_t* p0 = (const bf16_t*)&x0;
+      const bf16_t* p1 = (const bf16_t*)&x1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        gq[0][q] = (float)p0[q]; gq[1][q] = (float)p0[4 + q];
+        gq[2][q] = (float)p1[q]; gq[3][q] = (float)p1[4 + q];
+      }
     }
     // ---- gate algebra (EpiLstmBwd of lstm.hip with dc carried in registers)
     float dg[4][4];
@@ -434,8 +483,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
     *(uint4*)(&abuf[l15][4 * u0]) = d0;
     *(uint4*)(&abuf[l15][4 * u0 + 8]) = d1;
     if (row_ok) {
-      *(uint4*)gp = d0;
-      *(uint4*)(gp + 8) = d1;
+      if (s + 1 == a.T) {
+        *(uint4*)gp = d0;
+        *(uint4*)(gp + 8) = d1;
+      } else {
+        pend_d0 = d0; pend_d1 = d1; pend_gp = gp;
+      }
     }
     if (s + 1 == a.T) break;
     __syncthreads();   // abuf complete; every thread has consumed obuf of the previous step
