@@ -163,6 +163,16 @@ class GraphedTrainStep(object):
         self.graph = torch.cuda.CUDAGraph()
         same = os.environ.get("MEGREADER_CAPTURE_STREAM", "same") != "own"    # "own": torch's internal capture stream (A/B)
         kw = {"stream": s} if same else {}
+        # With a process group alive, RCCL's watchdog thread polls the events of recent collectives (hipEventQuery).  In the default
+        # "global" capture mode a call like that from ANY thread invalidates the capture ("operation failed due to a previous
+        # error during capture", seen once in ~10 runs of tests/test_ddp_gpu.py::...grad_sync_single_rank_rccl at the capture of
+        # the update graph, right behind the eager all-reduce): only this thread's calls are policed while a group exists.
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                kw["capture_error_mode"] = "thread_local"
+        except Exception:
+            pass
         # self.loss is the captured step's loss buffer WITHOUT its autograd graph: a retained graph would keep the step's
         # AccumulateGrad nodes alive -- bound to THIS capture's stream -- and a later capture (another GraphedTrainStep on the
         # same parameters) would be pulled onto that stream through them (see the hazard note above; measured: replays of the
@@ -176,6 +186,7 @@ class GraphedTrainStep(object):
             self.loss = self._fwd_bwd().detach()
         gc.collect()
         self.grad_sync()
+        torch.cuda.synchronize()       # no collective in flight when the second capture begins
         self.graph_update = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_update, **kw):
             self.optimizer.step()
