@@ -95,6 +95,18 @@ __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
 
+// Workgroup barrier that orders LDS traffic only: vector-memory loads / stores in flight STAY in flight (fences restricted to the
+// "local" address space compile to s_waitcnt lgkmcnt(0) + s_barrier).  __syncthreads() also waits for vmcnt(0) -- every outstanding
+// global access of the wave: on the per-step chain of the persistent kernels that put the HBM latency of prefetches and the write
+// acknowledgement of result stores in front of every barrier.  (An inline-asm barrier with a "memory" clobber is NOT the same: the
+// compiler drains the vector-memory counter in front of it.)  Only where the waves of a workgroup hand data to each other through
+// LDS, never through global memory.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

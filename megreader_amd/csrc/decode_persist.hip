@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
       *(f32x4*)(sHC + (wave * 16 + l15) * DU + lg * 4) = f32x4{bf16_lo(p01), bf16_hi(p01), bf16_lo(p23), bf16_hi(p23)};
       if (row_f_ok) *(uint2*)(a.HC_all + ((long long)s * N + row_f) * 4 * DH + colbase) = make_uint2(p01, p23);
     }
-    __syncthreads();
+    lds_barrier();
     DEC_TICK(0)
     // ---- partial energies of (sample w + 4i, position lane) over the slice's 16 units -> the slices of that sample
     {
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
         const int tp = tid & 31, pg = tid >> 5;
         *(float2*)(sSc + pg * 64 + tp * 2) = make_float2(s0, s1);
       }
-      __syncthreads();
+      lds_barrier();
       if (coin && row_g_ok) {                 // the word rows of this step's input gates: known only now on arg-max steps
         const long long w = fed_argmax ? (long long)sWord[gm] : widx;
         const unsigned short* gp = (const unsigned short*)(a.G + w * a.ldG + jg);
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
           if ((wantC >> k) & 1u) *(uint2*)(sCtx + ldsC[k]) = make_uint2(cv[k][0], cv[k][2]);
       }
     }
-    __syncthreads();
+    lds_barrier();
     DEC_TICK(5)
     // ---- context part of the input gates (f32), GRU cell of the slice's units
     if (wave < 3) {
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
       }
       *(f32x4*)(sGI + (wave * 16 + l15) * DU + lg * 4) = acc0 + acc1;
     }
-    __syncthreads();
+    lds_barrier();
     DEC_TICK(6)
     if (gru_thread) {
       const int o = gm * DU + gu;
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
         dead = true;
         if (lane == 0) { atomicMax(a.status, 3u); sDead[2] = 1; }
       }
-      __syncthreads();        // every GRU thread has read its h
+      lds_barrier();        // every GRU thread has read its h
       if (!dead) {
 #pragma unroll
         for (int k = 0; k < X::CNT_H; ++k) {
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     DEC_TICK(8)
   }
   if (timing) {
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         for (int k = 0; k < R; ++k) { s0 += __uint_as_float(av[k][0]); s1 += __uint_as_float(av[k][2]); }
       }
       *(float2*)(sRedA + (pgc * R + cm) * DU + p8 * 2) = make_float2(s0, s1);
-      __syncthreads();
+      lds_barrier();
       if (gru_thread) {
 #pragma unroll
         for (int k = 0; k < SPS; ++k) dh_a += sRedA[(k * R + gm) * DU + gu];
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         o2[0] = b_r; o2[DH] = b_z; o2[2 * DH] = b_nr;
       }
     }
-    __syncthreads();
+    lds_barrier();
     DEC_TICK(1)
     // ---- partial dctx of every sample over the own 48 gate units -> edge A
     {
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
           if ((wantD >> k) & 1u) { s0 += __uint_as_float(dvv[k][0]); s1 += __uint_as_float(dvv[k][2]); }
       }
       *(float2*)(sRedD + tid * 2) = make_float2(s0, s1);
-      __syncthreads();
+      lds_barrier();
       if (tid < 4 * nown) {
         float c = 0.f;
 #pragma unroll 8
@@ -979,7 +979,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         sDctx[tid] = (float)cb;
         if (row_o_ok) a.DCTX_all[((long long)s * N + row_o) * Ep + u0 * 4 + tid] = cb;
       }
-      __syncthreads();
+      lds_barrier();
     }
     DEC_TICK(4)
     // ---- partial dw[t] = dctx[share] . enc[t, share]  (wave = unit quarter, lane = position) -> edge B
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         }
       }
       sDwP[wave * 64 + lane] = d;
-      __syncthreads();
+      lds_barrier();
       if (tid < 32) {
         float d0 = (sDwP[2 * tid] + sDwP[64 + 2 * tid]) + (sDwP[128 + 2 * tid] + sDwP[192 + 2 * tid]);
         float d1 = (sDwP[2 * tid + 1] + sDwP[64 + 2 * tid + 1]) + (sDwP[128 + 2 * tid + 1] + sDwP[192 + 2 * tid + 1]);
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         const float dot = 0.5f * wave_sum_dpp(wat[i].x * d0 + wat[i].y * d1);
         if (half == 0) *(float2*)(sDe + (wave + 4 * i) * 64 + 2 * tp) = make_float2(wat[i].x * (d0 - dot), wat[i].y * (d1 - dot));
       }
-      __syncthreads();
+      lds_barrier();
     }
     DEC_TICK(7)
     // ---- tanh chain of the own units: dhproj (reduced over the positions), deproj / dv (accumulated over the steps)
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
     }
     DEC_TICK(8)
     if (s == 0) break;
-    __syncthreads();
+    lds_barrier();
     // ---- partial dh_a of every sample over the own 64 stacked columns -> edge C
     {
       const Frag a0 = *(const Frag*)(sDHC + l15 * GLD + lg * 8);

@@ -201,18 +201,25 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
     tprev = tn_;                                      \
   }
 
+  // The x-projection (32 bytes a lane out of a 34 MB buffer: HBM latency) is fetched ONE STEP AHEAD, right behind the granule sweep,
+  // and the barrier behind it orders LDS only: issued in front of the sweep the loads made the sweep wait for them (loads return in
+  // order), behind it a __syncthreads() drained them.  116 -> 101 us per layer forward at N = 256 together with the held-back stores.
+  uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = nx0;
+  if (row_ok) {
+    const bf16_t* xp = a.xproj + ((long long)(dir == 0 ? 0 : a.T - 1) * a.N + row) * 8 * H + dir * 4 * H + 4 * j0;
+    nx0 = *(const uint4*)xp;
+    nx1 = *(const uint4*)(xp + 8);
+  }
   for (int s = 0; s < a.T; ++s) {
     const int t = dir == 0 ? s : a.T - 1 - s;
     const long long r = (long long)t * a.N + row;
     // operands of the gate math that do not depend on the recurrent term: in flight during the exchange.  (Fetching them a step
     // ahead -- behind the sweep, behind the MFMAs or at the end of the step -- measured 2-5 us slower per layer: the loads
     // then sit in front of the fragment reads or the gate math instead of under the hand-off wait.)
-    uint4 x0 = make_uint4(0, 0, 0, 0), x1 = x0;
-    if (row_ok) {
-      const bf16_t* xp = a.xproj + r * 8 * H + dir * 4 * H + 4 * j0;
-      x0 = *(const uint4*)xp;
-      x1 = *(const uint4*)(xp + 8);
-    }
+    const uint4 x0 = nx0, x1 = nx1;
+    const bool fetch_next = row_ok && s + 1 < a.T;
+    const bf16_t* xpn = a.xproj + ((long long)(dir == 0 ? s + 1 : a.T - 2 - s) * a.N + row) * 8 * H + dir * 4 * H + 4 * j0;
+    if (s == 0 && fetch_next) { nx0 = *(const uint4*)xpn; nx1 = *(const uint4*)(xpn + 8); }
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -253,7 +260,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
         *(uint4*)gpp = pend_g0;
         *(uint4*)(gpp + 8) = pend_g1;
       }
-      __syncthreads();
+      if (fetch_next) { nx0 = *(const uint4*)xpn; nx1 = *(const uint4*)(xpn + 8); }
+      lds_barrier();                           // the loads just issued stay in flight
       Frag hf[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) hf[c] = *(const Frag*)(hb + l15 * PLD + c * 32 + lg * 8);
@@ -397,6 +405,16 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
     }
   };
   if (a.T > 0) fetch(0);
+  // phase clock, as in the forward kernel (status words [12 + phase])
+  const bool timing = tid == 0 && blockIdx.x == 0 && a.status[2] == 0x54494D45u;
+  unsigned long long tprev = timing ? wall_clock64() : 0ull;
+  unsigned tacc[4] = {0, 0, 0, 0};
+#define LSTM_TICK(i)                                  \
+  if (timing) {                                       \
+    const unsigned long long tn_ = wall_clock64();    \
+    tacc[i] += (unsigned)(tn_ - tprev);               \
+    tprev = tn_;                                      \
+  }
   for (int s = 0; s < a.T; ++s) {
     // backward visits the steps in the reverse of the forward order of that direction
     const int t = dir == 0 ? a.T - 1 - s : s;
@@ -445,6 +463,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
         dh[e] += sum;
       }
     }
+    LSTM_TICK(0)
     if (s == 0 && a.T > 1) fetch(1);      // first step: nothing to wait for
     // a timed-out hand-off poisons the gradients of this workgroup's rows with NaN (see the forward kernel)
     if (dead) {
@@ -491,7 +510,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
       }
     }
     if (s + 1 == a.T) break;
-    __syncthreads();   // abuf complete; every thread has consumed obuf of the previous step
+    lds_barrier();   // abuf complete; every thread has consumed obuf of the previous step
+    LSTM_TICK(1)
     Frag af[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) af[c] = *(const Frag*)(&abuf[l15][c * 32 + lg * 8]);
@@ -521,8 +541,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
                       (unsigned)(s + 1), local);
       }
     }
-    __syncthreads();   // obuf visible; all fragment reads of abuf done before the next step overwrites it
+    LSTM_TICK(2)
+    lds_barrier();   // obuf visible; all fragment reads of abuf done before the next step overwrites it
+    LSTM_TICK(3)
   }
+  if (timing) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.status[12 + i] = tacc[i];
+  }
+#undef LSTM_TICK
 }
 
 // layout: [granule slots][XCC-id exchange: 2*nbg groups x PG granule pairs of 16 B][status: 256 B, word 0 = timeout

@@ -79,13 +79,17 @@ def main():
                 return ws, size
             F._lstm_workspace = armed
             try:
-                fwd()
+                fwdbwd()
                 torch.cuda.synchronize()
             finally:
                 F._lstm_workspace = orig
             st = seen[0][seen[0].numel() - 256:].view(torch.int32).cpu()
             names = ["gather wait", "LDS + MFMA", "gate math + publish", "stores"]
             print("  forward phases (us per step): " + "  ".join("%s %.2f" % (n, int(st[8 + i]) * 0.01 / T) for i, n in enumerate(names)))
+            if len(seen) > 1:
+                st = seen[1][seen[1].numel() - 256:].view(torch.int32).cpu()
+                names = ["gather wait + reduce", "gate algebra + LDS + barrier", "MFMA + publish", "barrier"]
+                print("  backward phases (us per step): " + "  ".join("%s %.2f" % (n, int(st[12 + i]) * 0.01 / T) for i, n in enumerate(names)))
         tf = timeit(graphed(fwd))
         tfb = timeit(graphed(fwdbwd))
         print("  BiLSTM I=%d: fwd %.1f us, fwd+bwd %.1f us (bwd ~%.1f us)" % (I, tf, tfb, tfb - tf))
