@@ -131,21 +131,23 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
-// Gather CNT 16-byte granule pairs (bit k of `want`: this thread needs pair k at byte offset base + off[k]); a pair is accepted
-// when both of its tags equal `tag`.  The wave leaves together.  Returns false on timeout.
+// Gather CNT 16-byte granule pairs (bit k of `want`: this thread needs pair k at byte offset base + off[k]; the other offsets must
+// still point into the workspace); a pair is accepted when both of its tags equal `tag`.  Every sweep issues ALL its loads before
+// it looks at any of them: with a load inside the per-pair branch the compiler put `s_waitcnt vmcnt(0)` behind each one (seen in
+// the ISA) and a 5-pair sweep paid five L2 round trips in a row.  The wave leaves together.  Returns false on timeout.
 template <int CNT>
 __device__ __forceinline__ bool gather_pairs(rsrc_t rx, const unsigned (&off)[CNT], unsigned base, unsigned want, unsigned tag,
                                              u32x4 (&v)[CNT]) {
   unsigned need = want;
   for (unsigned spins = 0;; ++spins) {
+    u32x4 t[CNT];
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) t[k] = gran2_load(rx, base + off[k]);
 #pragma unroll
     for (int k = 0; k < CNT; ++k) {
-      if ((need >> k) & 1u) {
-        const u32x4 t = gran2_load(rx, base + off[k]);
-        if (t[1] == tag && t[3] == tag) {
-          v[k] = t;
-          need &= ~(1u << k);
-        }
+      if (((need >> k) & 1u) && t[k][1] == tag && t[k][3] == tag) {
+        v[k] = t[k];
+        need &= ~(1u << k);
       }
     }
     if (__all(need == 0)) return true;
@@ -153,6 +155,7 @@ __device__ __forceinline__ bool gather_pairs(rsrc_t rx, const unsigned (&off)[CN
     __builtin_amdgcn_s_sleep(1);
   }
 }
+
 
 constexpr unsigned HELLO_TAG = 0x48454C4Fu;
 constexpr unsigned HELLO_BYTES = 8 * DG * 16;     // [8 groups][32 slices] granule pairs, between the exchange slots and the status
@@ -363,6 +366,7 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
     const int r = u / nu, c = u - r * nu;
     ldsC[k] = (unsigned)(r * CLD + c * 4);
     if (u < R * nu) wantC |= 1u << k;
+    else offC[k] = 0u;                       // (every offset is loaded from)
   }
   unsigned offH[X::CNT_H];                                 // hidden: R * 128 pairs, linear
 #pragma unroll
@@ -398,11 +402,14 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
     tprev = tn_;                                      \
   }
 
+  int flag_prev = 1;             // flags[s - 1] while step s runs
   for (int s = 0; s < S; ++s) {
     const unsigned tag = (unsigned)(s + 1);
     const unsigned slot = (unsigned)(s & 1);
     // arg-max feedback: is the word of THIS step the arg-max of the previous step's output layer?  (uniform)
-    const bool fed_argmax = coin && s > 0 && a.flags[s - 1] == 0;
+    // (the coin of step s is fetched during step s: read here it was a global round trip at the top of every step)
+    const bool fed_argmax = coin && s > 0 && flag_prev == 0;
+    if (coin) flag_prev = a.flags[s];
     if (coin) {
       if (row_g_ok) widx = a.idx[(long long)s * N + row_g];                        // the given word (ignored on arg-max steps)
     } else if (row_g_ok && s + 1 < S) {
@@ -473,8 +480,8 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
       u32x4 pv[5];
       unsigned offS5[5] = {offS[0], offS[1], offS[2], offS[3], 0u};
       // arg-max steps: the 32 slices' best classes of every sample ride in the same sweep (thread <-> (sample, slice))
-      offS5[4] = (X::XL_OFF + slot * X::XL_SLOT + (unsigned)tid * 16u) - (X::XS_OFF + slot * X::XS_SLOT);
       const unsigned wantS = 0xfu | ((fed_argmax && tid < R * DG) ? 0x10u : 0u);
+      offS5[4] = (wantS & 0x10u) ? (X::XL_OFF + slot * X::XL_SLOT + (unsigned)tid * 16u) - (X::XS_OFF + slot * X::XS_SLOT) : offS[0];
       pv[4] = u32x4{0u, 0u, 0u, 0u};
       if (!dead && !gather_pairs<5>(rx, offS5, xg + X::XS_OFF + slot * X::XS_SLOT, wantS, tag, pv)) {
         dead = true;
@@ -785,10 +792,13 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
   float evr[16], dacc[16];
   {
     const int r = bg * R + wave;
+    unsigned short raw[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)      // (all sixteen in flight: selected against 0 inside this loop they were 16 round trips in a row)
+      raw[j] = ((const unsigned short*)a.eproj)[((long long)min(r, N - 1) * T + min(tc * 16 + j, T - 1)) * DH + g * DU + tq];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int t = tc * 16 + j;
-      evr[j] = (r < N && t < T) ? (float)a.eproj[((long long)r * T + t) * DH + g * DU + tq] : 0.f;
+      evr[j] = (r < N && tc * 16 + j < T) ? bf16_lo(raw[j]) : 0.f;
       dacc[j] = 0.f;
     }
   }
@@ -827,8 +837,9 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
 #pragma unroll
   for (int k = 0; k < X::CNT_D; ++k) {
     const int prod = pga + PGA * k;
-    offD[k] = (unsigned)(((prod * R + nloc) * DEPMAX + u0 * 4 + pr * 2) * 8);
-    if (pga < PGA && prod < DG && pr < 2 * nown) wantD |= 1u << k;
+    const bool wanted = pga < PGA && prod < DG && pr < 2 * nown;
+    offD[k] = wanted ? (unsigned)(((prod * R + nloc) * DEPMAX + u0 * 4 + pr * 2) * 8) : 0u;   // (every offset is loaded from)
+    if (wanted) wantD |= 1u << k;
   }
   const int npga = min(PGA, DG);
   // edge B consumer: lane = (half, position pair tp); samples wave + 4i
@@ -852,10 +863,13 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
     const unsigned tag = (unsigned)(it + 1);
     const unsigned slot = (unsigned)(it & 1);
     // ---- operands that depend on nothing of the chain: in flight during the hand-off below
-    float sr = 0.f, sz = 0.f, sn = 0.f;
-    unsigned short ghn = 0, hpv = 0, dhc = 0, hpj = 0;
-    if (row_g_ok) {
-      const long long rn = (long long)s * N + row_g;
+    // UNCONDITIONAL loads, rows / positions clamped into the buffers, masked where they are USED: a load under a branch (or
+    // selected against a constant right behind it) is waited for at the join -- the ISA had `s_waitcnt vmcnt(0)` behind this block,
+    // a full memory round trip at the top of every step, in front of the sweep
+    float sr, sz, sn;
+    unsigned short ghn, hpv, dhc, hpj;
+    if (gru_thread) {          // (whole waves; no value on the other path, so nothing is merged and nothing waited for)
+      const long long rn = (long long)s * N + min(row_g, N - 1);
       const float* sv = a.SAVE_all + rn * 3 * DH + jg;
       sr = sv[0]; sz = sv[DH]; sn = sv[2 * DH];
       const unsigned short* hc = (const unsigned short*)(a.HC_all + rn * 4 * DH);
@@ -864,18 +878,16 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
       hpv = ((const unsigned short*)a.H_all)[rn * DH + jg];
       dhc = ((const unsigned short*)a.DHO_all)[rn * DH + jg];
     }
-    float wden = 0.f;            // softmax weight of (this slice's sample, position lane)
-    if (a.denc && row_o_ok && lane < T) wden = a.W_att[((long long)s * N + row_o) * T + lane];
+    const int tl = min(lane, T - 1), t0c = min(2 * tp, T - 1), t1c = min(2 * tp + 1, T - 1);
+    // softmax weight of (this slice's sample, position lane): masked by wden_ok where it is used
+    const float wden = a.W_att[((long long)s * N + min(row_o, N - 1)) * T + tl];
+    const bool wden_ok = a.denc && row_o_ok && lane < T;
     float2 wat[R / 4];
 #pragma unroll
     for (int i = 0; i < R / 4; ++i) {
-      const int r = bg * R + wave + 4 * i;
-      wat[i] = make_float2(0.f, 0.f);
-      if (r < N) {
-        const float* wp = a.W_att + ((long long)s * N + r) * T;
-        if (2 * tp < T) wat[i].x = wp[2 * tp];
-        if (2 * tp + 1 < T) wat[i].y = wp[2 * tp + 1];
-      }
+      const float* wp = a.W_att + ((long long)s * N + min(bg * R + wave + 4 * i, N - 1)) * T;
+      wat[i].x = wp[t0c];
+      wat[i].y = wp[t1c];
     }
     // ---- edge C of the previous iteration: dh_a of the own units = sum over the 32 producers
     float dh_a = 0.f;
@@ -910,7 +922,9 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
       const float dpre_r = dr * sr * (1.f - sr);
       const float dpre_z = dz * sz * (1.f - sz);
       dh_b = gsum * sz;
-      const bf16_t b_r = (bf16_t)dpre_r, b_z = (bf16_t)dpre_z, b_n = (bf16_t)dpre_n, b_nr = (bf16_t)(dpre_n * sr);
+      const float vm = row_g_ok ? 1.f : 0.f;          // rows beyond the batch carry the clamped row's operands: keep them out
+      const bf16_t b_r = (bf16_t)(vm * dpre_r), b_z = (bf16_t)(vm * dpre_z), b_n = (bf16_t)(vm * dpre_n),
+                   b_nr = (bf16_t)(vm * dpre_n * sr);
       bf16_t* dg = sDG + gm * GLD;
       dg[gu] = b_r; dg[16 + gu] = b_z; dg[32 + gu] = b_n;
       bf16_t* dc = sDHC + gm * GLD;
@@ -984,11 +998,12 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
     DEC_TICK(4)
     // ---- partial dw[t] = dctx[share] . enc[t, share]  (wave = unit quarter, lane = position) -> edge B
     if (a.denc) {
+      const float wd = wden_ok ? wden : 0.f;
 #pragma unroll
       for (int j = 0; j < 18; j += 2) {
         const float2 dc = *(const float2*)(sDctx + wave * 18 + j);
-        dnc[j] += wden * dc.x;
-        dnc[j + 1] += wden * dc.y;
+        dnc[j] += wd * dc.x;
+        dnc[j + 1] += wd * dc.y;
       }
     }
     {
@@ -1045,8 +1060,10 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         d0 += __shfl_xor(d0, 32, 64);
         d1 += __shfl_xor(d1, 32, 64);
         // both halves of the wave hold the same pairs: the wave sum counts every position twice
-        const float dot = 0.5f * wave_sum_dpp(wat[i].x * d0 + wat[i].y * d1);
-        if (half == 0) *(float2*)(sDe + (wave + 4 * i) * 64 + 2 * tp) = make_float2(wat[i].x * (d0 - dot), wat[i].y * (d1 - dot));
+        const bool rv = bg * R + wave + 4 * i < N;
+        const float w0 = (rv && 2 * tp < T) ? wat[i].x : 0.f, w1 = (rv && 2 * tp + 1 < T) ? wat[i].y : 0.f;
+        const float dot = 0.5f * wave_sum_dpp(w0 * d0 + w1 * d1);
+        if (half == 0) *(float2*)(sDe + (wave + 4 * i) * 64 + 2 * tp) = make_float2(w0 * (d0 - dot), w1 * (d1 - dot));
       }
       lds_barrier();
     }

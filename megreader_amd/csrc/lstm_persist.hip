@@ -204,9 +204,9 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
   // The x-projection (32 bytes a lane out of a 34 MB buffer: HBM latency) is fetched ONE STEP AHEAD, right behind the granule sweep,
   // and the barrier behind it orders LDS only: issued in front of the sweep the loads made the sweep wait for them (loads return in
   // order), behind it a __syncthreads() drained them.  116 -> 101 us per layer forward at N = 256 together with the held-back stores.
-  uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = nx0;
-  if (row_ok) {
-    const bf16_t* xp = a.xproj + ((long long)(dir == 0 ? 0 : a.T - 1) * a.N + row) * 8 * H + dir * 4 * H + 4 * j0;
+  uint4 nx0, nx1;       // (rows beyond the batch read row N - 1: their results are never stored)
+  {
+    const bf16_t* xp = a.xproj + ((long long)(dir == 0 ? 0 : a.T - 1) * a.N + min(row, a.N - 1)) * 8 * H + dir * 4 * H + 4 * j0;
     nx0 = *(const uint4*)xp;
     nx1 = *(const uint4*)(xp + 8);
   }
@@ -217,9 +217,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
     // ahead -- behind the sweep, behind the MFMAs or at the end of the step -- measured 2-5 us slower per layer: the loads
     // then sit in front of the fragment reads or the gate math instead of under the hand-off wait.)
     const uint4 x0 = nx0, x1 = nx1;
-    const bool fetch_next = row_ok && s + 1 < a.T;
-    const bf16_t* xpn = a.xproj + ((long long)(dir == 0 ? s + 1 : a.T - 2 - s) * a.N + row) * 8 * H + dir * 4 * H + 4 * j0;
-    if (s == 0 && fetch_next) { nx0 = *(const uint4*)xpn; nx1 = *(const uint4*)(xpn + 8); }
+    // UNCONDITIONAL loads (row and step clamped into the buffer): a load under a divergent or uniform branch is waited for at the
+    // join -- s_waitcnt vmcnt right behind it, the whole latency on the chain (seen in the ISA of the backward kernel)
+    const int sn = min(s + 1, a.T - 1);
+    const bf16_t* xpn = a.xproj + ((long long)(dir == 0 ? sn : a.T - 1 - sn) * a.N + min(row, a.N - 1)) * 8 * H + dir * 4 * H + 4 * j0;
+    if (s == 0) { nx0 = *(const uint4*)xpn; nx1 = *(const uint4*)(xpn + 8); }
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -260,7 +262,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persist_kernel(LstmPFwd a) {
         *(uint4*)gpp = pend_g0;
         *(uint4*)(gpp + 8) = pend_g1;
       }
-      if (fetch_next) { nx0 = *(const uint4*)xpn; nx1 = *(const uint4*)(xpn + 8); }
+      nx0 = *(const uint4*)xpn;
+      nx1 = *(const uint4*)(xpn + 8);
       lds_barrier();                           // the loads just issued stay in flight
       Frag hf[8];
 #pragma unroll
@@ -387,22 +390,22 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
 
   // The step's operands (dout, c_t, c_{t-1}, the saved gates: 72 bytes a lane out of 70 MB of buffers: HBM latency) are fetched
   // ONE STEP AHEAD, behind the granule sweep: issued in front of it, the sweep's wait included their latency.
-  f32x4 n_up = {0.f, 0.f, 0.f, 0.f}, n_ct = n_up, n_cp = n_up;
+  uint2 n_upr = make_uint2(0, 0);
+  f32x4 n_ct = {0.f, 0.f, 0.f, 0.f}, n_cp = n_ct;
   uint4 n_x0 = make_uint4(0, 0, 0, 0), n_x1 = n_x0;
+  // UNCONDITIONAL loads (row / step clamped into the buffers; c_{t-1} of the first step is masked where it is used): under a branch
+  // the compiler waits for a load at the join -- `s_waitcnt vmcnt(0)` right behind the c_{t-1} load, the whole latency on the chain
+  const int rowc = min(row, a.N - 1);
   auto fetch = [&](int s1) {
     const int t1 = dir == 0 ? a.T - 1 - s1 : s1;
-    const int tp1 = dir == 0 ? t1 - 1 : t1 + 1;
-    const bool has_prev1 = dir == 0 ? t1 > 0 : t1 < a.T - 1;
-    const long long r1 = (long long)t1 * a.N + row;
-    n_cp = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (row_ok) {
-      n_up = load4(a.dout + r1 * 2 * H + dir * H + j0);
-      n_ct = *(const f32x4*)(a.cbuf + r1 * 2 * H + dir * H + j0);
-      if (has_prev1) n_cp = *(const f32x4*)(a.cbuf + ((long long)tp1 * a.N + row) * 2 * H + dir * H + j0);
-      const bf16_t* gp1 = a.gates + r1 * 8 * H + dir * 4 * H + 4 * j0;
-      n_x0 = *(const uint4*)gp1;
-      n_x1 = *(const uint4*)(gp1 + 8);
-    }
+    const int tp1 = min(max(dir == 0 ? t1 - 1 : t1 + 1, 0), a.T - 1);
+    const long long r1 = (long long)t1 * a.N + rowc;
+    n_upr = *(const uint2*)(a.dout + r1 * 2 * H + dir * H + j0);       // raw bf16 x 4: converted where it is used
+    n_ct = *(const f32x4*)(a.cbuf + r1 * 2 * H + dir * H + j0);
+    n_cp = *(const f32x4*)(a.cbuf + ((long long)tp1 * a.N + rowc) * 2 * H + dir * H + j0);
+    const bf16_t* gp1 = a.gates + r1 * 8 * H + dir * 4 * H + 4 * j0;
+    n_x0 = *(const uint4*)gp1;
+    n_x1 = *(const uint4*)(gp1 + 8);
   };
   if (a.T > 0) fetch(0);
   // phase clock, as in the forward kernel (status words [12 + phase])
@@ -419,7 +422,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
     // backward visits the steps in the reverse of the forward order of that direction
     const int t = dir == 0 ? a.T - 1 - s : s;
     const long long r = (long long)t * a.N + row;
-    const f32x4 up = n_up, ct = n_ct, cp = n_cp;
+    const bool has_prev = dir == 0 ? t > 0 : t < a.T - 1;
+    const f32x4 up = {__builtin_bit_cast(float, n_upr.x << 16), __builtin_bit_cast(float, n_upr.x & 0xffff0000u),
+                      __builtin_bit_cast(float, n_upr.y << 16), __builtin_bit_cast(float, n_upr.y & 0xffff0000u)};
+    const f32x4 ct = n_ct;
+    const f32x4 cp = has_prev ? n_cp : f32x4{0.f, 0.f, 0.f, 0.f};
     const uint4 x0 = n_x0, x1 = n_x1;
     bf16_t* gp = a.gates + r * 8 * H + dir * 4 * H + 4 * j0;
     f32x4 dh = up;
@@ -453,7 +460,6 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
         *(uint4*)(pend_gp + 8) = pend_d1;
         pend_gp = nullptr;
       }
-      if (s + 1 < a.T) fetch(s + 1);
       const f32x4 own = *(const f32x4*)&obuf[wave][lane][0];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -464,7 +470,6 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
       }
     }
     LSTM_TICK(0)
-    if (s == 0 && a.T > 1) fetch(1);      // first step: nothing to wait for
     // a timed-out hand-off poisons the gradients of this workgroup's rows with NaN (see the forward kernel)
     if (dead) {
 #pragma unroll
@@ -512,6 +517,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persist_kernel(LstmPBwd a) {
     if (s + 1 == a.T) break;
     lds_barrier();   // abuf complete; every thread has consumed obuf of the previous step
     LSTM_TICK(1)
+    // the coming step's operands: behind the gate algebra, a whole step to arrive (right behind the sweep the compiler waited for
+    // them where the algebra first reads THIS step's operands: the sweep phase 1.0 -> 0.5 us, -6 us per layer with this placement;
+    // refilling the operand registers in place instead of copying them at the top of the step measured slower again)
+    if (s + 1 < a.T) fetch(s + 1);
+
     Frag af[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) af[c] = *(const Frag*)(&abuf[l15][c * 32 + lg * 8]);
