@@ -91,6 +91,11 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 __device__ __forceinline__ float bf16_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 __device__ __forceinline__ int wave_of_thread() { return (int)(threadIdx.x >> 6); }
+// sigmoid on the hardware exp2 / rcp units (the GRU cell sits on the chain: the library forms cost ~0.15 us per step; absolute
+// error ~2e-7, h is rounded to bf16 right after -- lstm_persist.hip does the same)
+__device__ __forceinline__ float dec_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 // the energies' tanh: the form of attention.hip (att_tanh)
 __device__ __forceinline__ float dec_tanh(float x) {
   return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.885390081777927f));
@@ -143,6 +148,7 @@ __device__ __forceinline__ bool gather_pairs(rsrc_t rx, const unsigned (&off)[CN
     u32x4 t[CNT];
 #pragma unroll
     for (int k = 0; k < CNT; ++k) t[k] = gran2_load(rx, base + off[k]);
+    __builtin_amdgcn_sched_barrier(0);       // (the scheduler otherwise sinks the last load behind the first wait)
 #pragma unroll
     for (int k = 0; k < CNT; ++k) {
       if (((need >> k) & 1u) && t[k][1] == tag && t[k][3] == tag) {
@@ -539,9 +545,9 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
         for (int k = 0; k < 8; ++k) e += sSc[k * 64 + lane];
         e = lane < T ? e : -INFINITY;
         const float mx = wave_max_dpp(e);
-        const float ex = lane < T ? expf(e - mx) : 0.f;
+        const float ex = lane < T ? __builtin_amdgcn_exp2f((e - mx) * 1.4426950408889634f) : 0.f;
         const float sm = wave_sum_dpp(ex);
-        const float w = ex / sm;
+        const float w = ex * __builtin_amdgcn_rcpf(sm);
         if (wave == 0 && cpart == 0 && lane < T && row_o_ok) a.W_att[((long long)s * N + row_o) * T + lane] = w;
         // this thread's positions of the context sum: t = ctg, ctg + TG, ...  (every lane runs every iteration: a shuffle
         // reads 0 from a lane that is not executing)
@@ -601,8 +607,8 @@ __global__ __launch_bounds__(256, 1) void decode_fwd_persist_kernel(DecP a) {
       const float ir = bf16_lo(gw[0]) + sGI[o], iz = bf16_lo(gw[1]) + sGI[16 * DU + o],
                   in_ = bf16_lo(gw[2]) + sGI[2 * 16 * DU + o];
       const float hr = sHC[16 * DU + o], hz = sHC[2 * 16 * DU + o], hn = sHC[3 * 16 * DU + o];
-      const float r = sigmoidf_(ir + hr), z = sigmoidf_(iz + hz);
-      const float nn_ = tanhf_(in_ + r * hn);
+      const float r = dec_sigmoid(ir + hr), z = dec_sigmoid(iz + hz);
+      const float nn_ = dec_tanh(in_ + r * hn);
       const float hp = (float)hbuf[gm * HLD + jg];
       float hnew = (1.f - z) * nn_ + z * hp;
       if (sDead[0] | sDead[1] | sDead[2]) hnew = __builtin_nanf("");
