@@ -864,37 +864,46 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
     tprev = tn_;                                      \
   }
 
+  // The operands of a step that depend on nothing of the chain (saved gates, h, the output layer's gradient, the softmax weights:
+  // HBM latency) are fetched ONE ITERATION AHEAD, behind the GRU backward: in front of the first sweep of their own step they
+  // delayed it (loads return in order).  UNCONDITIONAL loads, rows / positions clamped into the buffers, masked where they are
+  // USED: a load under a branch (or selected against a constant right behind it) is waited for at the join.
+  float n_sr = 0.f, n_sz = 0.f, n_sn = 0.f, n_wden = 0.f;
+  unsigned short n_ghn = 0, n_hpv = 0, n_dhc = 0, n_hpj = 0;
+  float2 n_wat[R / 4];
+  const int tl = min(lane, T - 1), t0c = min(2 * tp, T - 1), t1c = min(2 * tp + 1, T - 1);
+  auto fetch_ops = [&](int s1) {
+    if (gru_thread) {          // (whole waves)
+      const long long rn = (long long)s1 * N + min(row_g, N - 1);
+      const float* sv = a.SAVE_all + rn * 3 * DH + jg;
+      n_sr = sv[0]; n_sz = sv[DH]; n_sn = sv[2 * DH];
+      const unsigned short* hc = (const unsigned short*)(a.HC_all + rn * 4 * DH);
+      n_hpj = hc[jg];
+      n_ghn = hc[DH + 2 * DH + jg];
+      n_hpv = ((const unsigned short*)a.H_all)[rn * DH + jg];
+      n_dhc = ((const unsigned short*)a.DHO_all)[rn * DH + jg];
+    }
+    n_wden = a.W_att[((long long)s1 * N + min(row_o, N - 1)) * T + tl];
+#pragma unroll
+    for (int i = 0; i < R / 4; ++i) {
+      const float* wp = a.W_att + ((long long)s1 * N + min(bg * R + wave + 4 * i, N - 1)) * T;
+      n_wat[i].x = wp[t0c];
+      n_wat[i].y = wp[t1c];
+    }
+  };
+  fetch_ops(S - 1);
   for (int it = 0; it < S; ++it) {
     const int s = S - 1 - it;
     const unsigned tag = (unsigned)(it + 1);
     const unsigned slot = (unsigned)(it & 1);
-    // ---- operands that depend on nothing of the chain: in flight during the hand-off below
-    // UNCONDITIONAL loads, rows / positions clamped into the buffers, masked where they are USED: a load under a branch (or
-    // selected against a constant right behind it) is waited for at the join -- the ISA had `s_waitcnt vmcnt(0)` behind this block,
-    // a full memory round trip at the top of every step, in front of the sweep
-    float sr, sz, sn;
-    unsigned short ghn, hpv, dhc, hpj;
-    if (gru_thread) {          // (whole waves; no value on the other path, so nothing is merged and nothing waited for)
-      const long long rn = (long long)s * N + min(row_g, N - 1);
-      const float* sv = a.SAVE_all + rn * 3 * DH + jg;
-      sr = sv[0]; sz = sv[DH]; sn = sv[2 * DH];
-      const unsigned short* hc = (const unsigned short*)(a.HC_all + rn * 4 * DH);
-      hpj = hc[jg];
-      ghn = hc[DH + 2 * DH + jg];
-      hpv = ((const unsigned short*)a.H_all)[rn * DH + jg];
-      dhc = ((const unsigned short*)a.DHO_all)[rn * DH + jg];
-    }
-    const int tl = min(lane, T - 1), t0c = min(2 * tp, T - 1), t1c = min(2 * tp + 1, T - 1);
-    // softmax weight of (this slice's sample, position lane): masked by wden_ok where it is used
-    const float wden = a.W_att[((long long)s * N + min(row_o, N - 1)) * T + tl];
+    // ---- operands that depend on nothing of the chain (fetched during the PREVIOUS iteration, see fetch_ops)
+    const float sr = n_sr, sz = n_sz, sn = n_sn;
+    const unsigned short ghn = n_ghn, hpv = n_hpv, dhc = n_dhc, hpj = n_hpj;
+    const float wden = n_wden;
     const bool wden_ok = a.denc && row_o_ok && lane < T;
     float2 wat[R / 4];
 #pragma unroll
-    for (int i = 0; i < R / 4; ++i) {
-      const float* wp = a.W_att + ((long long)s * N + min(bg * R + wave + 4 * i, N - 1)) * T;
-      wat[i].x = wp[t0c];
-      wat[i].y = wp[t1c];
-    }
+    for (int i = 0; i < R / 4; ++i) wat[i] = n_wat[i];
     // ---- edge C of the previous iteration: dh_a of the own units = sum over the 32 producers
     float dh_a = 0.f;
     if (it > 0) {
@@ -944,6 +953,7 @@ __global__ __launch_bounds__(256, 1) void decode_bwd_persist_kernel(DecB a) {
         o2[0] = b_r; o2[DH] = b_z; o2[2 * DH] = b_nr;
       }
     }
+    if (s > 0) fetch_ops(s - 1);       // a whole iteration to arrive
     lds_barrier();
     DEC_TICK(1)
     // ---- partial dctx of every sample over the own 48 gate units -> edge A
