@@ -91,3 +91,20 @@ def test_product_code_never_imports_oracle():
                 with open(os.path.join(dirpath, fn)) as f:
                     src = f.read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dirpath, fn)
+
+
+def test_decode_persist_host_queries_without_a_gpu():
+    """Host-only entry points of the persistent decode kernels (include/megreader_hip.h): workspace sizes follow the group layout of
+    csrc/decode_persist.hip (groups of 4 rows up to 32 samples, of 8 beyond; + the XCC-id exchange + 256 status bytes), and without
+    a device (or with too few CUs) `mr_decode_persist_ok` says no, so the decoder keeps its per-step launches."""
+    lib = _lib.load()
+    w4, w8, w32, w33 = (lib.mr_decode_persist_ws_bytes(n) for n in (4, 8, 32, 33))
+    group4 = w4 - 4096 - 256
+    assert group4 > 0 and w8 == 2 * group4 + 4096 + 256 and w32 == 8 * group4 + 4096 + 256
+    assert (w33 - 4096 - 256) % 5 == 0 and (w33 - 4096 - 256) // 5 > group4          # 5 groups of 8 rows
+    b4 = lib.mr_decode_persist_bwd_ws_bytes(4)
+    assert lib.mr_decode_persist_bwd_ws_bytes(32) == 8 * (b4 - 4096 - 256) + 4096 + 256
+    assert lib.mr_decode_persist_bwd_ws_bytes(33) == 0                                # the backward kernel stops at 32 samples
+    if not torch.cuda.is_available():
+        assert lib.mr_decode_persist_ok(_lib.dtype_code(torch.bfloat16), 16, 64, 512, 552) == 0
+        assert lib.mr_decode_persist_bwd_ok(_lib.dtype_code(torch.bfloat16), 16, 64, 512, 552) == 0
